@@ -1,0 +1,314 @@
+/*
+ * lob_engine.h — C ABI of the MI355X-native batched limit-order-book
+ * environment + tile-coded TD(lambda) learner.
+ *
+ * This is the drop-in boundary for the ONE hot path of tspooner/rl_markets
+ * (SURVEY.md §8): `market::Book` / `environment::Intraday` step, state/reward
+ * extraction, CMAC tile coding and the linear-Q SARSA(lambda)/Q(lambda)
+ * update, batched struct-of-arrays over thousands of independent books and
+ * executed by hand-written HIP kernels for gfx950.  Plain pointers and sizes
+ * only: no C++/torch types cross this boundary.  The reference has no FFI
+ * layer of its own; each entry point below names the reference C++ interface
+ * it stands in for (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - every function returning `int` returns LOB_OK (0) or a negative
+ *     LOB_E* code; `lob_last_error()` gives a human-readable message
+ *     (the reference throws std::runtime_error / returns bool — see
+ *     INTEGRATION.md for the mapping);
+ *   - "host" pointers are caller-owned host memory, "dev" pointers are device
+ *     (HBM) addresses valid on the engine's GPU;
+ *   - one engine handle per GPU, not thread-safe per handle (same rule as the
+ *     reference: one Environment + Runner per thread, src/main.cpp:45-58).
+ *   - the library needs a gfx950 GPU: there is NO CPU fallback.  Without a
+ *     device `lob_create` fails with LOB_ENODEV.
+ */
+#ifndef LOB_ENGINE_H
+#define LOB_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LOB_ABI_VERSION 1
+
+#define LOB_N_ACTIONS 9   /* reference Intraday::DoAction table, src/environment/intraday.cpp:181-219 */
+#define LOB_N_TILINGS 32  /* config/example.yaml:18 (compile-time in the kernels) */
+#define LOB_MAX_DEPTH 10
+#define LOB_MAX_TRADES 8
+#define LOB_MAX_BANDS 20
+#define LOB_MAX_VARS 13
+#define LOB_MAX_WINDOW 256
+#define LOB_TRACE_GENS 32 /* ring capacity, generations of 32 tiles */
+
+enum {
+    LOB_OK = 0,
+    LOB_EINVAL = -1,   /* bad argument / unsupported parameter */
+    LOB_ENODEV = -2,   /* no usable gfx950 device */
+    LOB_ENOMEM = -3,   /* hipMalloc failed */
+    LOB_ESTATE = -4,   /* call sequence error (e.g. step before reset) */
+    LOB_EDATA = -5,    /* malformed event stream (the reference throws, src/market/book.cpp:74-77) */
+    LOB_EHIP = -6      /* HIP runtime error */
+};
+
+/* Variable ids: reference enum class Variable, include/environment/intraday.h:17-24 */
+enum {
+    LOB_VAR_POS = 0, LOB_VAR_SPD, LOB_VAR_MPM, LOB_VAR_IMB, LOB_VAR_SVL, LOB_VAR_VOL,
+    LOB_VAR_RSI, LOB_VAR_VWAP, LOB_VAR_A_DIST, LOB_VAR_A_QUEUE, LOB_VAR_B_DIST,
+    LOB_VAR_B_QUEUE, LOB_VAR_LAST_ACTION
+};
+
+/* Reward measures: reference enum class RewardMeasure, include/environment/base.h:24-35 */
+enum {
+    LOB_REWARD_NONE = 0, LOB_REWARD_PNL, LOB_REWARD_PNL_DAMPED, LOB_REWARD_SPREAD,
+    LOB_REWARD_NORMED, LOB_REWARD_LOVOL, LOB_REWARD_MM_LINEAR, LOB_REWARD_MM_EXP,
+    LOB_REWARD_MM_DIV
+};
+
+/* Target-price object actually instantiated by the reference factory
+ * (src/environment/base.cpp:101-112, quirk Q5: "midprice" -> MicroPrice,
+ * anything else -> MidPrice) and the quoting mode of the Intraday ctor
+ * (src/environment/intraday.cpp:64-82). */
+enum { LOB_TP_MIDPRICE = 0, LOB_TP_MICROPRICE = 1 };
+enum { LOB_QUOTE_TARGET = 0, LOB_QUOTE_BOOK = 1 };
+
+/* Learning algorithms: rl::SARSA (src/rl/agent.cpp:296-311),
+ * rl::QLearn = Watkins Q(lambda) (src/rl/agent.cpp:268-292). */
+enum { LOB_ALGO_SARSA = 0, LOB_ALGO_QLAMBDA = 1 };
+
+/* Weight sharing: one theta shared by all books of the engine (the batched
+ * analogue of the reference's Hogwild threads, src/main.cpp:196-206), or one
+ * private theta per book (B independent learners = B copies of the
+ * single-book reference; used for exact parity tests). */
+enum { LOB_THETA_SHARED = 0, LOB_THETA_PRIVATE = 1 };
+
+/* Venue description: reference market::Market (include/market/market.h:13-52).
+ * Bands ascending by lower bound, as std::map<double,double> pts_ iterates. */
+typedef struct lob_market {
+    int64_t open_ms;                   /* mo_ */
+    int64_t close_ms;                  /* mc_ */
+    int32_t n_bands;
+    int32_t _pad;
+    double band_lb[LOB_MAX_BANDS];     /* price lower bound of band i   */
+    double band_tick[LOB_MAX_BANDS];   /* tick size inside band i       */
+} lob_market;
+
+/* Engine parameters = the subset of the reference YAML config the hot path
+ * reads (config/example.yaml; consumers src/environment/base.cpp:14-115,
+ * src/rl/agent.cpp:13-60, src/rl/policy.cpp:58-82). */
+typedef struct lob_params {
+    int32_t abi_version;        /* LOB_ABI_VERSION */
+    int32_t depth;              /* book levels per side, 1..LOB_MAX_DEPTH (reference: 5, quirk Q18) */
+    int32_t max_trades;         /* trade price levels per event, 1..LOB_MAX_TRADES */
+    int32_t n_vars;             /* state variables V (example.yaml: 8) */
+    int32_t vars[LOB_MAX_VARS]; /* LOB_VAR_* in config order */
+
+    lob_market market;
+
+    int32_t order_size;         /* market.order_size */
+    int32_t reward_measure;     /* LOB_REWARD_* */
+    int64_t pos_lb, pos_ub;     /* market.pos_lb / pos_ub */
+    float damping_factor;       /* reward.damping_factor (float in the reference) */
+    float pos_weight, trd_weight, pnl_weight;
+
+    int32_t lb_mpm, lb_vlt, lb_svl, lb_vwap, lb_rsi; /* state.lookback.* (>=1 after max(.,1)) */
+    int32_t lb_spread;          /* policy.spread_lookback */
+    int32_t lb_pnl;             /* reward.pnl_lookback */
+    int32_t lb_target;          /* market.target_price.lookback */
+    int32_t target_price;       /* LOB_TP_* */
+    int32_t quote_mode;         /* LOB_QUOTE_* */
+
+    int64_t memory_size;        /* learning.memory_size M (theta length, < 2^31) */
+    int32_t n_tilings;          /* must be LOB_N_TILINGS */
+    int32_t n_actions;          /* must be LOB_N_ACTIONS */
+    double group_weights[3];    /* learning.group_weights */
+    double gamma, lambda;
+    double alpha;               /* current step size (alpha schedule is host-side, lob_set_alpha) */
+    double epsilon;             /* current epsilon (schedule host-side, lob_set_epsilon) */
+    int32_t algo;               /* LOB_ALGO_* */
+    int32_t theta_mode;         /* LOB_THETA_* */
+    uint64_t seed;              /* counter-based policy RNG seed (DESIGN.md "RNG") */
+    uint64_t book_id_offset;    /* global id of local book 0 (multi-GPU shards) */
+} lob_params;
+
+/* Synthetic event-stream generator. */
+typedef struct lob_gen_params {
+    uint64_t seed;
+    int32_t n_events;
+    int32_t t0_ms;              /* timestamp of event 0 */
+    int32_t dt_ms;              /* cadence */
+    int32_t start_ticks;        /* best bid = start_ticks * tick (0.1-tick grid of LSE HSBA band [500,1000)) */
+    int32_t min_ticks, max_ticks;
+    int32_t move_prob_q16;      /* P(best bid moves +-1 tick) * 65536 */
+    int32_t spread2_prob_q16;   /* P(spread == 2 ticks) * 65536 */
+    int32_t trade_prob_q16;     /* P(a trade in the interval) * 65536 */
+    int32_t trade2_prob_q16;    /* P(a second trade on the other side | first) * 65536 */
+    int32_t touch_prob_q16;     /* P(trade at touch rather than 2nd level) * 65536 */
+    int32_t vol_min, vol_max;   /* level volumes U{min..max} */
+    int32_t trade_min, trade_max;
+} lob_gen_params;
+
+/* Parity dump of one book's full environment state (test / debugging aid;
+ * mirrors the protected members of environment::Base, include/environment/base.h:39-95,
+ * and market::Book, include/market/book.h:34-48). */
+typedef struct lob_book_dump {
+    double ask_px[LOB_MAX_DEPTH], bid_px[LOB_MAX_DEPTH];
+    double ask_last_px[LOB_MAX_DEPTH], bid_last_px[LOB_MAX_DEPTH];
+    int64_t ask_vol[LOB_MAX_DEPTH], bid_vol[LOB_MAX_DEPTH];
+    int64_t ask_last_vol[LOB_MAX_DEPTH], bid_last_vol[LOB_MAX_DEPTH];
+    int64_t ask_total_volume, bid_total_volume;
+    int64_t ask_last_total_volume, bid_last_total_volume;
+    int32_t ask_n_transacted, bid_n_transacted;
+    /* the (at most one, quirk Q13) live order per side */
+    int32_t ask_has_order, bid_has_order;
+    double ask_order_px, bid_order_px;
+    int64_t ask_order_rem, bid_order_rem;
+    int64_t ask_q_head, bid_q_head, ask_q_tail, bid_q_tail;
+    int64_t position;
+    double ask_quote, bid_quote;
+    int32_t ask_level, bid_level;
+    double pnl_step, momentum_pnl_step;
+    int32_t lo_vol_step;
+    int32_t last_action;
+    double episode_reward, episode_pnl, episode_bandh;
+    double spread_mean, target_price;
+    int64_t time_ms;
+    int32_t cursor;            /* next unread event index */
+    int32_t terminal;          /* 1 = isTerminal(), 2 = stream exhausted */
+    int32_t total_ticks;       /* TickStatistics::total_ticks */
+    int32_t n_traces;          /* live eligibility traces */
+} lob_book_dump;
+
+typedef struct lob_engine lob_engine;
+
+/* ---- library / parameter helpers (host only, no GPU needed) -------------- */
+
+int lob_abi_version(void);
+const char* lob_last_error(void);
+
+/* config/example.yaml defaults (D=5, T=2, 8 vars, SARSA, LSE HSBA venue). */
+void lob_default_params(lob_params* p);
+
+/* Venue tables: reference Market::make_market, src/market/market.cpp:39-59
+ * (tables :142-314).  `ticker` = "SYMBOL.VENUE", e.g. "HSBA.L". */
+int lob_market_preset(const char* ticker, lob_market* out);
+
+/* Tick maths on the host (reference Market::ToTicks / ToPrice / tick_size,
+ * src/market/market.cpp:78-138).  Exposed for the host adaptors and tests. */
+int lob_to_ticks(const lob_market* m, double price, int32_t* ticks);
+int lob_to_price(const lob_market* m, int32_t ticks, double* price);
+int lob_tick_size(const lob_market* m, double price, double* tick);
+
+/* ---- event streams -------------------------------------------------------
+ * One record per (book, event), little-endian 32-bit words:
+ *   [0] time_ms  [1] flags
+ *   ask_px[D] f32, ask_vol[D] i32, bid_px[D] f32, bid_vol[D] i32,
+ *   trade_px[T] f32 (ascending), trade_vol[T] i32 (0 = empty slot),
+ *   zero padding to a multiple of 4 words.
+ * An event = what one Intraday::NextState consumes (src/environment/intraday.cpp:225-272):
+ * the trades aggregated per price since the previous depth snapshot
+ * (data::TimeAndSalesRecord, include/data/records.h:30-37) followed by the
+ * new depth snapshot (data::MarketDepthRecord, include/data/records.h:20-28).
+ * Layout in memory: records[book][event] (each book's events contiguous).
+ */
+#define LOB_EVT_FLAG_SAME_TIME 1u /* more depth rows with this timestamp follow (quirk Q14) */
+
+int32_t lob_record_words(int32_t depth, int32_t max_trades);
+void lob_default_gen_params(lob_gen_params* g);
+/* Fill `out` (n_books * n_events * record_words * 4 bytes) on the host. */
+int lob_gen_stream_host(const lob_gen_params* g, int32_t depth, int32_t max_trades,
+                        uint64_t first_book_id, int32_t n_books, uint32_t* out);
+/* Check a host stream against the engine preconditions (positive prices and
+ * volumes, strictly monotone price keys per side, ascending trade prices). */
+int lob_validate_stream(const uint32_t* records, int32_t depth, int32_t max_trades,
+                        int32_t n_books, int32_t n_events);
+
+/* ---- engine lifetime ----------------------------------------------------- */
+
+/* Replaces constructing environment::Intraday<> + rl::Agent + serial::Learner
+ * (src/main.cpp:45-58,140-189) for `n_books` books on GPU `device`. */
+int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine** out);
+void lob_destroy(lob_engine* e);
+
+/* Replaces Intraday::LoadData (src/environment/intraday.cpp:141-150):
+ * upload host records / synthesise the same records directly in HBM. */
+int lob_load_events(lob_engine* e, const uint32_t* host_records, int32_t n_events);
+int lob_gen_events_device(lob_engine* e, const lob_gen_params* g);
+
+/* ---- environment interface (environment::Base, include/environment/base.h:117-151) */
+
+/* Initialise() for every book: clear books/stats/windows, fast-forward to
+ * market open, warm the windows, place the (1,1) quotes, extract the first
+ * state and its tile features (Runner::RunEpisode prologue,
+ * src/experiment/serial.cpp:18-26). */
+int lob_reset(lob_engine* e);
+/* performAction(action) for every live book; `actions` host int32[n_books]. */
+int lob_step(lob_engine* e, const int32_t* host_actions);
+/* getState(): host float[n_books][n_vars]. */
+int lob_get_state(lob_engine* e, float* host_out);
+/* getReward(): host double[n_books]. */
+int lob_get_reward(lob_engine* e, double* host_out);
+/* isTerminal() (1) / out of data (2) / live (0): host uint8[n_books]. */
+int lob_get_terminal(lob_engine* e, uint8_t* host_out);
+/* ClearInventory() for every book (Runner::RunEpisode epilogue, serial.cpp:31). */
+int lob_clear_inventory(lob_engine* e);
+int lob_get_book(lob_engine* e, int32_t book, lob_book_dump* out);
+
+/* ---- learner interface (rl::Agent, include/rl/agent.h:48-77) ------------- */
+
+/* `n_steps` x Learner::_step (src/experiment/serial.cpp:53-70) for every live
+ * book: action(s) -> performAction -> newState -> HandleTransition. */
+int lob_td_step(lob_engine* e, int32_t n_steps);
+/* Backtester::_step (serial.cpp:124-137): greedy action, no learning. */
+int lob_eval_step(lob_engine* e, int32_t n_steps);
+/* Agent::HandleTerminal (src/rl/agent.cpp:103-109): traces.decay(0). The
+ * alpha / epsilon schedules are evaluated by the host adaptor. */
+int lob_handle_terminal(lob_engine* e);
+int lob_set_alpha(lob_engine* e, double alpha);
+int lob_set_epsilon(lob_engine* e, double epsilon);
+
+/* State::newState(vector<float>&) + getFeatures (src/rl/state.cpp:45-70):
+ * n states of n_vars floats -> int32[n][9][96] tile indices. */
+int lob_features(lob_engine* e, const float* host_vars, int32_t n, int32_t* host_out);
+/* Agent::getQ for all actions (src/rl/agent.cpp:117-135): double[n][9]. */
+int lob_q_values(lob_engine* e, const float* host_vars, int32_t n, double* host_out);
+
+/* theta access: Agent::write_theta (src/rl/agent.cpp:176-181) + the missing
+ * load path.  `which` = book for LOB_THETA_PRIVATE, 0 for shared. */
+int lob_theta_get(lob_engine* e, int32_t which, double* host_out, int64_t count);
+int lob_theta_set(lob_engine* e, int32_t which, const double* host_in, int64_t count);
+/* Last actions / rewards / TD errors of the most recent lob_td_step. */
+int lob_get_last_actions(lob_engine* e, int32_t* host_out);
+int lob_get_last_td(lob_engine* e, double* host_out);
+/* Live traces of one book: indices and eligibilities (rl::Traces). */
+int lob_get_traces(lob_engine* e, int32_t book, int32_t* idx, float* elig, int32_t cap, int32_t* n);
+
+/* Counters: [0] env-steps performed, [1] market events consumed,
+ * [2] live books, [3] td updates applied. */
+int lob_get_counters(lob_engine* e, int64_t out[4]);
+
+/* ---- multi-GPU weight exchange ---------------------------
+ * The engine never calls a collective itself: it exposes the dense delta
+ * buffer so the launcher can all-reduce it over RCCL/xGMI.
+ *   lob_delta_begin : dev_delta[i] = theta[i] - theta_sync[i]
+ *   (caller: all-reduce SUM dev_delta over ranks)
+ *   lob_delta_apply : theta = theta_sync + dev_delta ; theta_sync = theta
+ */
+int lob_delta_begin(lob_engine* e, double** dev_delta, int64_t* count);
+int lob_delta_apply(lob_engine* e);
+
+/* Synchronise the engine's stream / expose it (hipStream_t as void*). */
+int lob_sync(lob_engine* e);
+void* lob_stream(lob_engine* e);
+/* Average duration (ms) of the named kernel over launches since the last
+ * reset of the timers, measured with HIP events on the engine stream. */
+int lob_kernel_time_ms(lob_engine* e, const char* kernel, double* avg_ms, int64_t* launches);
+int lob_kernel_timing(lob_engine* e, int32_t enable);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LOB_ENGINE_H */

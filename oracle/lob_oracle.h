@@ -1,0 +1,80 @@
+/* TEST INFRASTRUCTURE ONLY — "oracle": a CPU restatement of the reference's
+ * algorithm for the hot path.  It is the CHECKER for the HIP
+ * engine; nothing under rl_markets_amd/ may include, link or call it.  Only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it.
+ *
+ * Parity status: PINNED.  The restatement is validated against
+ *   (1) the reference's own unit-test known answers (test/test_Order.cpp,
+ *       test/test_Book.cpp, test/test_Market.cpp, test/test_Accumulators.cpp),
+ *   (2) trajectories, tile indices and tick conversions produced by the
+ *       UNMODIFIED reference compiled in this container (oracle/_ref, built by
+ *       oracle/Makefile) and committed as fixtures under tests/golden/.
+ */
+#ifndef LOB_ORACLE_H
+#define LOB_ORACLE_H
+
+#include <stdint.h>
+
+#include "../include/lob_engine.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* One record per learner step; written identically by oracle/ref_harness
+ * (from the real reference) and by lob_oracle (numpy dtype in tests/ref_io.py). */
+typedef struct oracle_step_rec {
+    int32_t action;   /* -1: state after reset, -2: after ClearInventory */
+    int32_t n_vars;
+    double reward;
+    double td;
+    float vars[LOB_MAX_VARS];
+    int32_t _pad;
+    uint64_t rng_ctr;
+    lob_book_dump book;
+} oracle_step_rec;
+
+typedef struct oracle_learner oracle_learner;
+
+/* Batched learner over `n_books` books (records[book][event], lob_engine.h
+ * layout).  theta_mode SHARED: synchronous-batch semantic: per
+ * step every book reads theta_t, all updates are summed into theta_{t+1}
+ * in book order.  With n_books == 1 this is exactly the reference's
+ * Learner::_step loop (src/experiment/serial.cpp:53-70). */
+oracle_learner* oracle_create(const lob_params* p, int32_t n_books, const uint32_t* records,
+                              int32_t n_events);
+void oracle_destroy(oracle_learner* o);
+int oracle_reset(oracle_learner* o);                       /* Runner::RunEpisode prologue */
+int oracle_td_step(oracle_learner* o, int32_t n_steps);    /* n x Learner::_step */
+int oracle_eval_step(oracle_learner* o, int32_t n_steps);  /* n x Backtester::_step */
+int oracle_env_step(oracle_learner* o, const int32_t* actions); /* performAction only */
+int oracle_clear_inventory(oracle_learner* o);
+int oracle_handle_terminal(oracle_learner* o);
+void oracle_set_alpha(oracle_learner* o, double a);
+void oracle_set_epsilon(oracle_learner* o, double e);
+/* last step's record for `book` */
+void oracle_get_rec(oracle_learner* o, int32_t book, oracle_step_rec* out);
+double* oracle_theta(oracle_learner* o, int32_t which);
+int32_t oracle_get_traces(oracle_learner* o, int32_t book, int32_t* idx, float* e, int32_t cap);
+void oracle_get_counters(oracle_learner* o, int64_t out[4]);
+
+/* ---- unit-level entry points (known-answer tests) ------------------------ */
+void oracle_tiles(int64_t memory_size, const float* vars, int32_t n_vars, int32_t n, int32_t* out /*[n][9][96]*/);
+int32_t oracle_hash_unh(const int32_t* ints, int32_t n, int64_t m, int32_t increment);
+void oracle_rndseq(uint32_t* out2048);
+int32_t oracle_to_ticks(const lob_market* m, double price);
+double oracle_to_price(const lob_market* m, int32_t ticks);
+double oracle_tick_size(const lob_market* m, double price);
+/* Order queue model: ops[i] = {kind, volume}; kind 0 doTransaction, 1 doCancellation,
+ * 2 addVolumeBehind, 3 clearQueues.  out[i] = {q_head, q_tail, remaining, ret}. */
+void oracle_order_script(double price, int64_t size, int64_t q_head, const int64_t* ops, int32_t n_ops,
+                         int64_t* out);
+/* RollingMean<double>: push values, report mean/var/std/sum/full after each. */
+void oracle_rolling_mean(int32_t window, const double* vals, int32_t n, double* out /*[n][5]*/);
+/* Generic book script (known answers of test/test_Book.cpp); see tests/test_oracle_kat.py. */
+int oracle_book_script(int32_t depth, const double* script, int32_t n_words, double* out, int32_t out_cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

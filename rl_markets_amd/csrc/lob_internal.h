@@ -1,0 +1,94 @@
+// Internal declarations shared by the host and device halves of the engine.
+#ifndef LOB_INTERNAL_H
+#define LOB_INTERNAL_H
+
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/lob_engine.h"
+#include "lob_stream.h"
+
+void lob_set_error(const std::string& s);
+
+// Tick maths shared by host (lob_to_ticks...) and device (state extraction,
+// quoting).  Restates reference Market::ToTicks / ToPrice / tick_size
+// (src/market/market.cpp:78-138) over the ascending band table; the
+// int/long "+= double" truncations of quirk Q16 are kept.
+namespace lobh {
+
+struct TickTable {
+    int n;
+    double lb[LOB_MAX_BANDS];
+    double tick[LOB_MAX_BANDS];
+    int64_t cum[LOB_MAX_BANDS];  // tts_ keys: cumulative ticks at each band's lower bound
+};
+
+LOB_HD void build_tick_table(const lob_market& m, TickTable& t) {
+    t.n = m.n_bands;
+    for (int i = 0; i < LOB_MAX_BANDS; i++) {
+        t.lb[i] = i < m.n_bands ? m.band_lb[i] : 0.0;
+        t.tick[i] = i < m.n_bands ? m.band_tick[i] : 1.0;
+        t.cum[i] = 0;
+    }
+    // Market ctor, src/market/market.cpp:27-36: long acc_ticks += double
+    int64_t acc = 0;
+    for (int i = 1; i < m.n_bands; i++) {
+        acc = (int64_t)((double)acc + (m.band_lb[i] - m.band_lb[i - 1]) / m.band_tick[i - 1]);
+        t.cum[i] = acc;
+    }
+}
+
+template <class TT> LOB_HD double tick_size_t(const TT& t, double price) {
+    // prev(upper_bound(price)): the last band whose lower bound is <= price
+    double ts = t.tick[0];
+    for (int i = 1; i < t.n; i++)
+        if (t.lb[i] <= price) ts = t.tick[i];
+    return ts;
+}
+
+template <class TT> LOB_HD int to_ticks_t(const TT& t, double price) {
+    int ticks = 0;
+    const double half = tick_size_t(t, price) / 2.0;
+    for (int i = 0; i < t.n; i++) {
+        const double lb = t.lb[i], tk = t.tick[i];
+        if (!(price + tk / 2.0 > lb)) break;
+        double ub;
+        if (i == t.n - 1 || price < t.lb[i + 1]) ub = price + half;
+        else ub = t.lb[i + 1];
+        ticks = (int)((double)ticks + (ub - lb) / tk);  // `int += double`
+    }
+    return ticks;
+}
+
+template <class TT> LOB_HD double to_price_t(const TT& t, int ticks) {
+    double price = 0.0;
+    for (int i = 0; i < t.n; i++) {
+        if (!((int64_t)ticks > t.cum[i])) break;
+        double ub;
+        if (i == t.n - 1 || (int64_t)ticks < t.cum[i + 1]) ub = (double)ticks;
+        else ub = (double)t.cum[i + 1];
+        price += (ub - (double)t.cum[i]) * t.tick[i];
+    }
+    return price;
+}
+
+inline double tick_size(const lob_market& m, double price) {
+    TickTable t;
+    build_tick_table(m, t);
+    return tick_size_t(t, price);
+}
+inline int to_ticks(const lob_market& m, double price) {
+    TickTable t;
+    build_tick_table(m, t);
+    return to_ticks_t(t, price);
+}
+inline double to_price(const lob_market& m, int ticks) {
+    TickTable t;
+    build_tick_table(m, t);
+    return to_price_t(t, ticks);
+}
+
+}  // namespace lobh
+
+#endif
