@@ -256,6 +256,7 @@ int lob_get_terminal(lob_engine* e, uint8_t* host_out);
 /* ClearInventory() for every book (Runner::RunEpisode epilogue, serial.cpp:31). */
 int lob_clear_inventory(lob_engine* e);
 int lob_get_book(lob_engine* e, int32_t book, lob_book_dump* out);
+int lob_get_books(lob_engine* e, int32_t first, int32_t n, lob_book_dump* out);
 
 /* ---- learner interface (rl::Agent, include/rl/agent.h:48-77) ------------- */
 
@@ -283,6 +284,13 @@ int lob_theta_set(lob_engine* e, int32_t which, const double* host_in, int64_t c
 /* Last actions / rewards / TD errors of the most recent lob_td_step. */
 int lob_get_last_actions(lob_engine* e, int32_t* host_out);
 int lob_get_last_td(lob_engine* e, double* host_out);
+int lob_get_last_rewards(lob_engine* e, double* host_out);
+/* 1 where the most recent step performed an env-step + TD update */
+int lob_get_stepped(lob_engine* e, int32_t* host_out);
+/* draws consumed so far from each book's policy RNG stream */
+int lob_get_rng_counters(lob_engine* e, uint64_t* host_out);
+/* state_vars of the rl::State produced by the last step: float[n_books][n_vars] */
+int lob_get_learner_state(lob_engine* e, float* host_out);
 /* Live traces of one book: indices and eligibilities (rl::Traces). */
 int lob_get_traces(lob_engine* e, int32_t book, int32_t* idx, float* elig, int32_t cap, int32_t* n);
 
@@ -293,10 +301,12 @@ int lob_get_counters(lob_engine* e, int64_t out[4]);
 /* ---- multi-GPU weight exchange ---------------------------
  * The engine never calls a collective itself: it exposes the dense delta
  * buffer so the launcher can all-reduce it over RCCL/xGMI.
+ *   lob_delta_init  : theta_sync = theta (call once, right after create / theta_set)
  *   lob_delta_begin : dev_delta[i] = theta[i] - theta_sync[i]
  *   (caller: all-reduce SUM dev_delta over ranks)
  *   lob_delta_apply : theta = theta_sync + dev_delta ; theta_sync = theta
  */
+int lob_delta_init(lob_engine* e);
 int lob_delta_begin(lob_engine* e, double** dev_delta, int64_t* count);
 int lob_delta_apply(lob_engine* e);
 

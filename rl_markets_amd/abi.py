@@ -133,6 +133,7 @@ def load():
         "lob_get_terminal": (C.c_int, [vp, vp]),
         "lob_clear_inventory": (C.c_int, [vp]),
         "lob_get_book": (C.c_int, [vp, C.c_int32, P(BookDump)]),
+        "lob_get_books": (C.c_int, [vp, C.c_int32, C.c_int32, vp]),
         "lob_td_step": (C.c_int, [vp, C.c_int32]),
         "lob_eval_step": (C.c_int, [vp, C.c_int32]),
         "lob_handle_terminal": (C.c_int, [vp]),
@@ -144,8 +145,13 @@ def load():
         "lob_theta_set": (C.c_int, [vp, C.c_int32, vp, C.c_int64]),
         "lob_get_last_actions": (C.c_int, [vp, vp]),
         "lob_get_last_td": (C.c_int, [vp, vp]),
+        "lob_get_last_rewards": (C.c_int, [vp, vp]),
+        "lob_get_stepped": (C.c_int, [vp, vp]),
+        "lob_get_rng_counters": (C.c_int, [vp, vp]),
+        "lob_get_learner_state": (C.c_int, [vp, vp]),
         "lob_get_traces": (C.c_int, [vp, C.c_int32, vp, vp, C.c_int32, P(C.c_int32)]),
         "lob_get_counters": (C.c_int, [vp, vp]),
+        "lob_delta_init": (C.c_int, [vp]),
         "lob_delta_begin": (C.c_int, [vp, P(vp), P(C.c_int64)]),
         "lob_delta_apply": (C.c_int, [vp]),
         "lob_sync": (C.c_int, [vp]),

@@ -1,0 +1,651 @@
+// Host side of the C ABI (include/lob_engine.h): device memory management,
+// kernel launches on one HIP stream, HIP-event kernel timing.  gfx950 only;
+// there is no CPU execution path in this file.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "lob_internal.h"
+#include "lob_kernels.h"
+
+#define HIPCHK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            lob_set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                \
+            return LOB_EHIP;                                                                 \
+        }                                                                                    \
+    } while (0)
+
+struct KTimer {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    double total_ms = 0.0;
+    int64_t launches = 0;
+};
+
+struct lob_engine {
+    int device = 0;
+    int B = 0;
+    lob_params params;
+    DevParams P;
+    DevState S;
+    hipStream_t stream = nullptr;
+    std::vector<void*> allocs;
+    uint32_t* rnd_dev = nullptr;
+    uint32_t* records_dev = nullptr;
+    i32* actions_dev = nullptr;
+    lob_book_dump* dump_dev = nullptr;
+    int dump_cap = 0;
+    bool have_events = false, was_reset = false;
+    bool timing = false;
+    std::map<std::string, KTimer> timers;
+    std::vector<hipEvent_t> event_pool;
+};
+
+namespace {
+
+// The 2048-entry table of the UNH CMAC hash (reference src/rl/tiles.cpp:133)
+// is the low-byte stream of an unseeded glibc rand() (generator left commented
+// out at tiles.cpp:141-149).  Regenerated from the glibc TYPE_3 additive
+// feedback recurrence r[i] = r[i-3] + r[i-31]; tests compare it with the
+// reference's own table.
+void make_rndseq(uint32_t* t) {
+    const int total = 344 + 4 * 2048;
+    std::vector<int32_t> r(total);
+    r[0] = 1;
+    for (int i = 1; i < 31; i++) {
+        int64_t v = (16807LL * r[i - 1]) % 2147483647LL;
+        if (v < 0) v += 2147483647LL;
+        r[i] = (int32_t)v;
+    }
+    for (int i = 31; i < 34; i++) r[i] = r[i - 31];
+    for (int i = 34; i < total; i++) r[i] = (int32_t)((uint32_t)r[i - 31] + (uint32_t)r[i - 3]);
+    for (int k = 0; k < 2048; k++) {
+        uint32_t v = 0;
+        for (int i = 0; i < 4; i++) v = (v << 8) | ((((uint32_t)r[344 + 4 * k + i]) >> 1) & 0xff);
+        t[k] = v;
+    }
+}
+
+template <class T> int dev_alloc(lob_engine* e, T** p, size_t count) {
+    void* q = nullptr;
+    size_t bytes = count * sizeof(T);
+    if (bytes == 0) bytes = sizeof(T);
+    hipError_t err = hipMalloc(&q, bytes);
+    if (err != hipSuccess) {
+        lob_set_error(std::string("hipMalloc failed: ") + hipGetErrorString(err));
+        return LOB_ENOMEM;
+    }
+    err = hipMemsetAsync(q, 0, bytes, e->stream);
+    if (err != hipSuccess) { lob_set_error("hipMemset failed"); return LOB_EHIP; }
+    e->allocs.push_back(q);
+    *p = (T*)q;
+    return LOB_OK;
+}
+
+int grid_lanes(int B) { return (B + 255) / 256; }
+int grid_waves(int B) { return (B + LOB_WAVES_PER_BLOCK - 1) / LOB_WAVES_PER_BLOCK; }
+
+struct TimedLaunch {
+    lob_engine* e;
+    KTimer* t = nullptr;
+    hipEvent_t a = nullptr, b = nullptr;
+    TimedLaunch(lob_engine* e_, const char* name) : e(e_) {
+        if (!e->timing) return;
+        t = &e->timers[name];
+        auto get = [&]() {
+            hipEvent_t ev;
+            if (!e->event_pool.empty()) { ev = e->event_pool.back(); e->event_pool.pop_back(); }
+            else hipEventCreate(&ev);
+            return ev;
+        };
+        a = get();
+        b = get();
+        hipEventRecord(a, e->stream);
+    }
+    ~TimedLaunch() {
+        if (!t) return;
+        hipEventRecord(b, e->stream);
+        t->pending.push_back({a, b});
+    }
+};
+
+void drain_timers(lob_engine* e) {
+    for (auto& kv : e->timers) {
+        for (auto& pr : kv.second.pending) {
+            hipEventSynchronize(pr.second);
+            float ms = 0;
+            hipEventElapsedTime(&ms, pr.first, pr.second);
+            kv.second.total_ms += ms;
+            kv.second.launches++;
+            e->event_pool.push_back(pr.first);
+            e->event_pool.push_back(pr.second);
+        }
+        kv.second.pending.clear();
+    }
+}
+
+int check_device_errors(lob_engine* e) {
+    i32 flag = 0;
+    HIPCHK(hipMemcpyAsync(&flag, e->S.error_flag, sizeof flag, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (flag) {
+        std::string m = "device reported a condition on which the reference throws:";
+        if (flag & LOB_ERR_BAD_ORDER_PRICE) m += " [order price <= 0]";
+        if (flag & LOB_ERR_BAD_LEVEL) m += " [level price/volume <= 0]";
+        if (flag & LOB_ERR_UNDEF_PRICE) m += " [undefined book price]";
+        lob_set_error(m);
+        return LOB_EDATA;
+    }
+    return LOB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine** out) {
+    if (!p || !out || n_books < 1) { lob_set_error("lob_create: bad argument"); return LOB_EINVAL; }
+    if (p->abi_version != LOB_ABI_VERSION) { lob_set_error("lob_create: ABI version mismatch"); return LOB_EINVAL; }
+    if (p->depth < 1 || p->depth > LOB_MAX_DEPTH || p->max_trades < 1 || p->max_trades > LOB_MAX_TRADES) {
+        lob_set_error("lob_create: depth/max_trades out of range"); return LOB_EINVAL;
+    }
+    if (p->n_tilings != LOB_N_TILINGS || p->n_actions != LOB_N_ACTIONS) {
+        lob_set_error("lob_create: kernels are built for n_tilings=32, n_actions=9"); return LOB_EINVAL;
+    }
+    if (p->n_vars < 4 || p->n_vars > LOB_MAX_VARS) { lob_set_error("lob_create: n_vars must be in [4,13]"); return LOB_EINVAL; }
+    if (p->memory_size < 1 || p->memory_size >= (1LL << 31)) { lob_set_error("lob_create: memory_size out of range"); return LOB_EINVAL; }
+    if (p->market.n_bands < 1 || p->market.n_bands > LOB_MAX_BANDS) { lob_set_error("lob_create: bad tick table"); return LOB_EINVAL; }
+    if (p->reward_measure == LOB_REWARD_MM_EXP) { lob_set_error("lob_create: reward mm_exp not implemented (SURVEY.md §8f N4)"); return LOB_EINVAL; }
+    const int lbs[] = {p->lb_mpm, p->lb_vlt, p->lb_svl, p->lb_vwap, p->lb_rsi, p->lb_spread, p->lb_pnl, p->lb_target};
+    for (int w : lbs)
+        if (w < 1 || w > LOB_MAX_WINDOW) { lob_set_error("lob_create: lookbacks must be in [1,256]"); return LOB_EINVAL; }
+    if (p->order_size < 1) { lob_set_error("lob_create: order_size"); return LOB_EINVAL; }
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || device < 0 || device >= ndev) {
+        lob_set_error("lob_create: no usable HIP device (the engine has no CPU fallback)");
+        return LOB_ENODEV;
+    }
+    HIPCHK(hipSetDevice(device));
+    lob_engine* e = new lob_engine();
+    e->device = device;
+    e->B = n_books;
+    e->params = *p;
+    HIPCHK(hipStreamCreate(&e->stream));
+
+    // ---- DevParams ----
+    DevParams& P = e->P;
+    memset(&P, 0, sizeof P);
+    P.D = p->depth; P.T = p->max_trades; P.W = lob_rec_words(p->depth, p->max_trades); P.V = p->n_vars;
+    for (int i = 0; i < LOB_MAX_VARS; i++) P.vars[i] = p->vars[i];
+    lobh::TickTable tt;
+    lobh::build_tick_table(p->market, tt);
+    P.n_bands = tt.n;
+    for (int i = 0; i < LOB_MAX_BANDS; i++) { P.band_lb[i] = tt.lb[i]; P.band_tick[i] = tt.tick[i]; P.band_cum[i] = tt.cum[i]; }
+    P.open_ms = p->market.open_ms; P.close_ms = p->market.close_ms;
+    P.order_size = p->order_size; P.reward_measure = p->reward_measure;
+    P.pos_lb = p->pos_lb; P.pos_ub = p->pos_ub;
+    P.damping_factor = p->damping_factor; P.pos_weight = p->pos_weight; P.trd_weight = p->trd_weight; P.pnl_weight = p->pnl_weight;
+    P.target_price = p->target_price; P.quote_mode = p->quote_mode;
+    P.ewma_alpha = 2.0 / ((double)(size_t)p->lb_rsi + 1.0);
+    P.M = p->memory_size; P.inv_M = 1.0 / (double)p->memory_size;
+    P.w0 = p->group_weights[0]; P.w1 = p->group_weights[1]; P.w2 = p->group_weights[2];
+    P.gamma = p->gamma; P.alpha = p->alpha; P.epsilon = p->epsilon;
+    P.trace_rate = (float)(p->gamma * p->lambda);  // Traces::decay(float rate), quirk Q15
+    P.trace_pow[0] = 1.0f;
+    P.trace_kmax = -1;
+    for (int k = 1; k <= LOB_TRACE_GENS; k++) {
+        P.trace_pow[k] = P.trace_pow[k - 1] * P.trace_rate;
+        if (P.trace_kmax < 0 && P.trace_pow[k] < 0.01f) P.trace_kmax = k;
+    }
+    if (P.trace_kmax < 0 || P.trace_kmax > LOB_TRACE_GENS) {
+        lob_set_error("lob_create: gamma*lambda too close to 1 for the trace ring (LOB_TRACE_GENS generations)");
+        delete e;
+        return LOB_EINVAL;
+    }
+    P.algo = p->algo; P.theta_private = p->theta_mode == LOB_THETA_PRIVATE;
+    P.seed = p->seed; P.book_id_offset = p->book_id_offset;
+
+    // ---- DevState ----
+    DevState& S = e->S;
+    memset(&S, 0, sizeof S);
+    const size_t B = (size_t)n_books;
+    S.B = n_books; S.D = P.D; S.T = P.T; S.W = P.W;
+    int rc = LOB_OK;
+#define X(t, n) if (rc == LOB_OK) rc = dev_alloc(e, &S.n, B);
+    LOB_ENV_FIELDS(X)
+    LOB_LEARN_FIELDS(X)
+#undef X
+    auto alloc_rm = [&](RMPtrs& r, int w) {
+        r.w = w;
+        if (rc == LOB_OK) rc = dev_alloc(e, &r.ring, B * w);
+        if (rc == LOB_OK) rc = dev_alloc(e, &r.cnt, B);
+        if (rc == LOB_OK) rc = dev_alloc(e, &r.head, B);
+        if (rc == LOB_OK) rc = dev_alloc(e, &r.sum, B);
+        if (rc == LOB_OK) rc = dev_alloc(e, &r.mean, B);
+        if (rc == LOB_OK) rc = dev_alloc(e, &r.s, B);
+    };
+    auto alloc_acc = [&](AccPtrs& r, int w) {
+        r.w = w;
+        if (rc == LOB_OK) rc = dev_alloc(e, &r.ring, B * w);
+        if (rc == LOB_OK) rc = dev_alloc(e, &r.cnt, B);
+        if (rc == LOB_OK) rc = dev_alloc(e, &r.head, B);
+        if (rc == LOB_OK) rc = dev_alloc(e, &r.sum, B);
+    };
+    alloc_rm(S.f_midprice, p->lb_mpm);
+    alloc_rm(S.f_volatility, p->lb_vlt);
+    alloc_rm(S.f_ask_tx, p->lb_svl);
+    alloc_rm(S.f_bid_tx, p->lb_svl);
+    alloc_rm(S.spread_window, p->lb_spread);
+    alloc_rm(S.pnl_ups, p->lb_pnl);
+    alloc_rm(S.pnl_downs, p->lb_pnl);
+    alloc_rm(S.tp_mp, p->lb_target);
+    alloc_acc(S.f_vwap_numer, p->lb_vwap);
+    alloc_acc(S.f_vwap_denom, p->lb_vwap);
+    if (rc == LOB_OK) rc = dev_alloc(e, &S.px, B * 4 * P.D);
+    if (rc == LOB_OK) rc = dev_alloc(e, &S.vol, B * 4 * P.D);
+    if (rc == LOB_OK) rc = dev_alloc(e, &S.vars, B * 3 * 16);
+    if (rc == LOB_OK) rc = dev_alloc(e, &S.qs_last, B * LOB_N_ACTIONS);
+    if (rc == LOB_OK) rc = dev_alloc(e, &S.tr_idx, B * LOB_TRACE_GENS * 32);
+    if (rc == LOB_OK) rc = dev_alloc(e, &S.tr_alive, B * LOB_TRACE_GENS);
+    if (rc == LOB_OK) rc = dev_alloc(e, &S.theta, (size_t)P.M * (P.theta_private ? B : 1));
+    if (rc == LOB_OK) rc = dev_alloc(e, &S.counters, 8);
+    if (rc == LOB_OK) rc = dev_alloc(e, &S.error_flag, 1);
+    if (rc == LOB_OK) rc = dev_alloc(e, &e->rnd_dev, 2048);
+    if (rc == LOB_OK) rc = dev_alloc(e, &e->actions_dev, B);
+    if (rc != LOB_OK) { lob_destroy(e); return rc; }
+    // the two rl::State objects start with constructor zeros (src/rl/state.cpp:10-19)
+    {
+        std::vector<i32> ones(B, 1);
+        HIPCHK(hipMemcpyAsync(S.zero0, ones.data(), B * sizeof(i32), hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(S.zero1, ones.data(), B * sizeof(i32), hipMemcpyHostToDevice, e->stream));
+        uint32_t rnd[2048];
+        make_rndseq(rnd);
+        HIPCHK(hipMemcpyAsync(e->rnd_dev, rnd, sizeof rnd, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+    }
+    *out = e;
+    return LOB_OK;
+}
+
+void lob_destroy(lob_engine* e) {
+    if (!e) return;
+    hipSetDevice(e->device);
+    if (e->stream) hipStreamSynchronize(e->stream);
+    drain_timers(e);
+    for (auto ev : e->event_pool) hipEventDestroy(ev);
+    for (void* p : e->allocs) hipFree(p);
+    if (e->records_dev) hipFree(e->records_dev);
+    if (e->dump_dev) hipFree(e->dump_dev);
+    if (e->stream) hipStreamDestroy(e->stream);
+    delete e;
+}
+
+static int set_records(lob_engine* e, int32_t n_events) {
+    if (e->records_dev) { hipFree(e->records_dev); e->records_dev = nullptr; }
+    size_t bytes = (size_t)e->B * n_events * e->P.W * 4;
+    hipError_t err = hipMalloc((void**)&e->records_dev, bytes);
+    if (err != hipSuccess) { lob_set_error("hipMalloc(records) failed"); return LOB_ENOMEM; }
+    e->S.records = e->records_dev;
+    e->S.n_events = n_events;
+    e->have_events = true;
+    e->was_reset = false;
+    return LOB_OK;
+}
+
+int lob_load_events(lob_engine* e, const uint32_t* host_records, int32_t n_events) {
+    if (!e || !host_records || n_events < 2) { lob_set_error("lob_load_events: bad argument"); return LOB_EINVAL; }
+    HIPCHK(hipSetDevice(e->device));
+    int rc = lob_validate_stream(host_records, e->P.D, e->P.T, e->B, n_events);
+    if (rc != LOB_OK) return rc;
+    rc = set_records(e, n_events);
+    if (rc != LOB_OK) return rc;
+    HIPCHK(hipMemcpyAsync(e->records_dev, host_records, (size_t)e->B * n_events * e->P.W * 4, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return LOB_OK;
+}
+
+int lob_gen_events_device(lob_engine* e, const lob_gen_params* g) {
+    if (!e || !g || g->n_events < 2) { lob_set_error("lob_gen_events_device: bad argument"); return LOB_EINVAL; }
+    HIPCHK(hipSetDevice(e->device));
+    int rc = set_records(e, g->n_events);
+    if (rc != LOB_OK) return rc;
+    hipLaunchKernelGGL(gen_events_kernel, dim3(grid_lanes(e->B)), dim3(256), 0, e->stream, *g, e->P.D, e->P.T,
+                       e->P.book_id_offset, e->B, e->records_dev);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return LOB_OK;
+}
+
+int lob_reset(lob_engine* e) {
+    if (!e) return LOB_EINVAL;
+    if (!e->have_events) { lob_set_error("lob_reset: no event stream loaded"); return LOB_ESTATE; }
+    HIPCHK(hipSetDevice(e->device));
+    {
+        TimedLaunch t(e, "reset_kernel");
+        hipLaunchKernelGGL(reset_kernel, dim3(grid_lanes(e->B)), dim3(256), 0, e->stream, e->P, e->S);
+    }
+    HIPCHK(hipGetLastError());
+    e->was_reset = true;
+    return check_device_errors(e);
+}
+
+static int need_reset(lob_engine* e, const char* who) {
+    if (!e) return LOB_EINVAL;
+    if (!e->was_reset) { lob_set_error(std::string(who) + ": call lob_reset first"); return LOB_ESTATE; }
+    return LOB_OK;
+}
+
+int lob_step(lob_engine* e, const int32_t* host_actions) {
+    int rc = need_reset(e, "lob_step");
+    if (rc) return rc;
+    if (!host_actions) { lob_set_error("lob_step: actions == NULL"); return LOB_EINVAL; }
+    for (int b = 0; b < e->B; b++)
+        if (host_actions[b] < 0 || host_actions[b] >= LOB_N_ACTIONS) { lob_set_error("lob_step: action out of range"); return LOB_EINVAL; }
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemcpyAsync(e->actions_dev, host_actions, (size_t)e->B * 4, hipMemcpyHostToDevice, e->stream));
+    {
+        TimedLaunch t(e, "env_kernel");
+        hipLaunchKernelGGL(env_kernel, dim3(grid_lanes(e->B)), dim3(256), 0, e->stream, e->P, e->S, (const i32*)e->actions_dev);
+    }
+    HIPCHK(hipGetLastError());
+    return check_device_errors(e);
+}
+
+int lob_get_state(lob_engine* e, float* host_out) {
+    int rc = need_reset(e, "lob_get_state");
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(e->device));
+    f32* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, (size_t)e->B * e->P.V * 4));
+    hipLaunchKernelGGL(get_state_kernel, dim3(grid_lanes(e->B)), dim3(256), 0, e->stream, e->P, e->S, d, (f64*)nullptr);
+    hipError_t err = hipMemcpyAsync(host_out, d, (size_t)e->B * e->P.V * 4, hipMemcpyDeviceToHost, e->stream);
+    hipStreamSynchronize(e->stream);
+    hipFree(d);
+    HIPCHK(err);
+    return LOB_OK;
+}
+
+int lob_get_reward(lob_engine* e, double* host_out) {
+    int rc = need_reset(e, "lob_get_reward");
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(e->device));
+    f64* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, (size_t)e->B * 8));
+    hipLaunchKernelGGL(get_state_kernel, dim3(grid_lanes(e->B)), dim3(256), 0, e->stream, e->P, e->S, (f32*)nullptr, d);
+    hipError_t err = hipMemcpyAsync(host_out, d, (size_t)e->B * 8, hipMemcpyDeviceToHost, e->stream);
+    hipStreamSynchronize(e->stream);
+    hipFree(d);
+    HIPCHK(err);
+    return LOB_OK;
+}
+
+int lob_get_terminal(lob_engine* e, uint8_t* host_out) {
+    int rc = need_reset(e, "lob_get_terminal");
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(e->device));
+    std::vector<i32> done(e->B), tm(e->B);
+    HIPCHK(hipMemcpyAsync(done.data(), e->S.done, (size_t)e->B * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(tm.data(), e->S.time_ms, (size_t)e->B * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (int b = 0; b < e->B; b++) {
+        bool open = ((i64)tm[b] > e->P.open_ms + 30 * 60000LL) && ((i64)tm[b] < e->P.close_ms - 30 * 60000LL);
+        host_out[b] = done[b] == 2 ? 2 : (open ? 0 : 1);
+    }
+    return LOB_OK;
+}
+
+int lob_clear_inventory(lob_engine* e) {
+    int rc = need_reset(e, "lob_clear_inventory");
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(e->device));
+    hipLaunchKernelGGL(clear_inventory_kernel, dim3(grid_lanes(e->B)), dim3(256), 0, e->stream, e->P, e->S);
+    HIPCHK(hipGetLastError());
+    return check_device_errors(e);
+}
+
+int lob_get_books(lob_engine* e, int32_t first, int32_t n, lob_book_dump* out) {
+    if (!e || !out || first < 0 || n < 1 || first + n > e->B) { lob_set_error("lob_get_books: bad range"); return LOB_EINVAL; }
+    HIPCHK(hipSetDevice(e->device));
+    if (e->dump_cap < n) {
+        if (e->dump_dev) hipFree(e->dump_dev);
+        HIPCHK(hipMalloc((void**)&e->dump_dev, (size_t)n * sizeof(lob_book_dump)));
+        e->dump_cap = n;
+    }
+    hipLaunchKernelGGL(dump_kernel, dim3((n + 63) / 64), dim3(64), 0, e->stream, e->P, e->S, first, n, e->dump_dev);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, e->dump_dev, (size_t)n * sizeof(lob_book_dump), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return LOB_OK;
+}
+int lob_get_book(lob_engine* e, int32_t book, lob_book_dump* out) { return lob_get_books(e, book, 1, out); }
+
+static int run_steps(lob_engine* e, int32_t n_steps, int mode) {
+    HIPCHK(hipSetDevice(e->device));
+    const int gw = grid_waves(e->B), gl = grid_lanes(e->B);
+    for (int s = 0; s < n_steps; s++) {
+        {
+            TimedLaunch t(e, "act_kernel");
+            hipLaunchKernelGGL(act_kernel, dim3(gw), dim3(LOB_BLOCK), 0, e->stream, e->P, e->S, (const uint32_t*)e->rnd_dev, mode);
+        }
+        {
+            TimedLaunch t(e, "env_kernel");
+            hipLaunchKernelGGL(env_kernel, dim3(gl), dim3(256), 0, e->stream, e->P, e->S, (const i32*)nullptr);
+        }
+        if (mode == 0) {
+            {
+                TimedLaunch t(e, "learn_kernel");
+                hipLaunchKernelGGL(learn_kernel, dim3(gw), dim3(LOB_BLOCK), 0, e->stream, e->P, e->S, (const uint32_t*)e->rnd_dev);
+            }
+            {
+                TimedLaunch t(e, "update_kernel");
+                hipLaunchKernelGGL(update_kernel, dim3(gw), dim3(LOB_BLOCK), 0, e->stream, e->P, e->S);
+            }
+        }
+    }
+    HIPCHK(hipGetLastError());
+    return LOB_OK;
+}
+
+int lob_td_step(lob_engine* e, int32_t n_steps) {
+    int rc = need_reset(e, "lob_td_step");
+    if (rc) return rc;
+    if (n_steps < 0) return LOB_EINVAL;
+    return run_steps(e, n_steps, 0);
+}
+int lob_eval_step(lob_engine* e, int32_t n_steps) {
+    int rc = need_reset(e, "lob_eval_step");
+    if (rc) return rc;
+    if (n_steps < 0) return LOB_EINVAL;
+    return run_steps(e, n_steps, 1);
+}
+
+int lob_handle_terminal(lob_engine* e) {
+    if (!e) return LOB_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    hipLaunchKernelGGL(clear_traces_kernel, dim3(grid_lanes(e->B)), dim3(256), 0, e->stream, e->S);
+    HIPCHK(hipGetLastError());
+    return LOB_OK;
+}
+int lob_set_alpha(lob_engine* e, double alpha) { if (!e) return LOB_EINVAL; e->P.alpha = alpha; e->params.alpha = alpha; return LOB_OK; }
+int lob_set_epsilon(lob_engine* e, double eps) { if (!e) return LOB_EINVAL; e->P.epsilon = eps; e->params.epsilon = eps; return LOB_OK; }
+
+static int features_impl(lob_engine* e, const float* host_vars, int32_t n, int32_t* out_idx, double* out_q) {
+    if (!e || !host_vars || n < 1) { lob_set_error("lob_features: bad argument"); return LOB_EINVAL; }
+    HIPCHK(hipSetDevice(e->device));
+    f32* dv = nullptr; i32* di = nullptr; f64* dq = nullptr;
+    HIPCHK(hipMalloc((void**)&dv, (size_t)n * e->P.V * 4));
+    if (out_idx) HIPCHK(hipMalloc((void**)&di, (size_t)n * LOB_N_ACTIONS * 96 * 4));
+    if (out_q) HIPCHK(hipMalloc((void**)&dq, (size_t)n * LOB_N_ACTIONS * 8));
+    HIPCHK(hipMemcpyAsync(dv, host_vars, (size_t)n * e->P.V * 4, hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(features_kernel, dim3(grid_waves(n)), dim3(LOB_BLOCK), 0, e->stream, e->P, (const f64*)e->S.theta,
+                       (const uint32_t*)e->rnd_dev, (const f32*)dv, n, di, dq);
+    hipError_t err = hipGetLastError();
+    if (err == hipSuccess && out_idx) err = hipMemcpyAsync(out_idx, di, (size_t)n * LOB_N_ACTIONS * 96 * 4, hipMemcpyDeviceToHost, e->stream);
+    if (err == hipSuccess && out_q) err = hipMemcpyAsync(out_q, dq, (size_t)n * LOB_N_ACTIONS * 8, hipMemcpyDeviceToHost, e->stream);
+    hipStreamSynchronize(e->stream);
+    hipFree(dv);
+    if (di) hipFree(di);
+    if (dq) hipFree(dq);
+    HIPCHK(err);
+    return LOB_OK;
+}
+int lob_features(lob_engine* e, const float* host_vars, int32_t n, int32_t* host_out) { return features_impl(e, host_vars, n, host_out, nullptr); }
+int lob_q_values(lob_engine* e, const float* host_vars, int32_t n, double* host_out) { return features_impl(e, host_vars, n, nullptr, host_out); }
+
+int lob_theta_get(lob_engine* e, int32_t which, double* host_out, int64_t count) {
+    if (!e || !host_out || count < 0 || count > e->P.M) return LOB_EINVAL;
+    if (which < 0 || which >= (e->P.theta_private ? e->B : 1)) return LOB_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemcpyAsync(host_out, e->S.theta + (size_t)which * e->P.M, (size_t)count * 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return LOB_OK;
+}
+int lob_theta_set(lob_engine* e, int32_t which, const double* host_in, int64_t count) {
+    if (!e || !host_in || count < 0 || count > e->P.M) return LOB_EINVAL;
+    if (which < 0 || which >= (e->P.theta_private ? e->B : 1)) return LOB_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemcpyAsync(e->S.theta + (size_t)which * e->P.M, host_in, (size_t)count * 8, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return LOB_OK;
+}
+
+#define COPY_FIELD(field, T)                                                                                   \
+    HIPCHK(hipSetDevice(e->device));                                                                           \
+    HIPCHK(hipMemcpyAsync(host_out, e->S.field, (size_t)e->B * sizeof(T), hipMemcpyDeviceToHost, e->stream));  \
+    HIPCHK(hipStreamSynchronize(e->stream));                                                                   \
+    return LOB_OK;
+int lob_get_last_actions(lob_engine* e, int32_t* host_out) { if (!e || !host_out) return LOB_EINVAL; COPY_FIELD(action, i32) }
+int lob_get_last_td(lob_engine* e, double* host_out) { if (!e || !host_out) return LOB_EINVAL; COPY_FIELD(td, f64) }
+int lob_get_last_rewards(lob_engine* e, double* host_out) { if (!e || !host_out) return LOB_EINVAL; COPY_FIELD(reward, f64) }
+int lob_get_stepped(lob_engine* e, int32_t* host_out) { if (!e || !host_out) return LOB_EINVAL; COPY_FIELD(stepped, i32) }
+int lob_get_rng_counters(lob_engine* e, uint64_t* host_out) { if (!e || !host_out) return LOB_EINVAL; COPY_FIELD(rng_ctr, u64) }
+
+/* current `state` variables of the learner (the rl::State the last step produced): float[B][n_vars] */
+int lob_get_learner_state(lob_engine* e, float* host_out) {
+    if (!e || !host_out) return LOB_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    std::vector<f32> v((size_t)e->B * 48);
+    std::vector<i32> cur(e->B);
+    HIPCHK(hipMemcpyAsync(v.data(), e->S.vars, v.size() * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(cur.data(), e->S.slot_cur, (size_t)e->B * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (int b = 0; b < e->B; b++)
+        for (int i = 0; i < e->P.V; i++) host_out[(size_t)b * e->P.V + i] = v[((size_t)b * 3 + cur[b]) * 16 + i];
+    return LOB_OK;
+}
+
+int lob_get_traces(lob_engine* e, int32_t book, int32_t* idx, float* elig, int32_t cap, int32_t* n) {
+    if (!e || book < 0 || book >= e->B || !n) return LOB_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    std::vector<i32> ti(LOB_TRACE_GENS * 32);
+    std::vector<uint32_t> al(LOB_TRACE_GENS);
+    i32 head = 0, ng = 0;
+    HIPCHK(hipMemcpyAsync(ti.data(), e->S.tr_idx + (size_t)book * LOB_TRACE_GENS * 32, ti.size() * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(al.data(), e->S.tr_alive + (size_t)book * LOB_TRACE_GENS, al.size() * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(&head, e->S.tr_head + book, 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(&ng, e->S.tr_n + book, 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    int k = 0;
+    for (int age = 0; age < ng; age++) {
+        int slot = (head - age + 2 * LOB_TRACE_GENS) % LOB_TRACE_GENS;
+        for (int j = 0; j < 32; j++)
+            if ((al[slot] >> j) & 1u) {
+                if (k < cap) {
+                    if (idx) idx[k] = ti[slot * 32 + j];
+                    if (elig) elig[k] = e->P.trace_pow[age];
+                }
+                k++;
+            }
+    }
+    *n = k;
+    return LOB_OK;
+}
+
+int lob_get_counters(lob_engine* e, int64_t out[4]) {
+    if (!e || !out) return LOB_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    i64 c[8];
+    std::vector<i32> done(e->B);
+    HIPCHK(hipMemcpyAsync(c, e->S.counters, sizeof c, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(done.data(), e->S.done, (size_t)e->B * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    i64 live = 0;
+    for (int b = 0; b < e->B; b++) live += done[b] == 0;
+    out[0] = c[0]; out[1] = c[1]; out[2] = live; out[3] = c[3];
+    return LOB_OK;
+}
+
+int lob_delta_init(lob_engine* e) {
+    if (!e) return LOB_EINVAL;
+    if (e->P.theta_private) { lob_set_error("lob_delta_*: shared theta only"); return LOB_EINVAL; }
+    HIPCHK(hipSetDevice(e->device));
+    if (!e->S.theta_sync) {
+        int rc = dev_alloc(e, &e->S.theta_sync, (size_t)e->P.M);
+        if (rc == LOB_OK) rc = dev_alloc(e, &e->S.delta, (size_t)e->P.M);
+        if (rc != LOB_OK) return rc;
+    }
+    HIPCHK(hipMemcpyAsync(e->S.theta_sync, e->S.theta, (size_t)e->P.M * 8, hipMemcpyDeviceToDevice, e->stream));
+    return LOB_OK;
+}
+int lob_delta_begin(lob_engine* e, double** dev_delta, int64_t* count) {
+    if (!e || !dev_delta || !count) return LOB_EINVAL;
+    if (!e->S.theta_sync) { lob_set_error("lob_delta_begin: call lob_delta_init first"); return LOB_ESTATE; }
+    HIPCHK(hipSetDevice(e->device));
+    {
+        TimedLaunch t(e, "delta_begin_kernel");
+        hipLaunchKernelGGL(delta_begin_kernel, dim3(2048), dim3(256), 0, e->stream, (const f64*)e->S.theta, (const f64*)e->S.theta_sync, e->S.delta, e->P.M);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->stream));
+    *dev_delta = e->S.delta;
+    *count = e->P.M;
+    return LOB_OK;
+}
+int lob_delta_apply(lob_engine* e) {
+    if (!e) return LOB_EINVAL;
+    if (!e->S.theta_sync) { lob_set_error("lob_delta_apply: call lob_delta_init first"); return LOB_ESTATE; }
+    HIPCHK(hipSetDevice(e->device));
+    {
+        TimedLaunch t(e, "delta_apply_kernel");
+        hipLaunchKernelGGL(delta_apply_kernel, dim3(2048), dim3(256), 0, e->stream, e->S.theta, e->S.theta_sync, (const f64*)e->S.delta, e->P.M);
+    }
+    HIPCHK(hipGetLastError());
+    return LOB_OK;
+}
+
+int lob_sync(lob_engine* e) {
+    if (!e) return LOB_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return check_device_errors(e);
+}
+void* lob_stream(lob_engine* e) { return e ? (void*)e->stream : nullptr; }
+
+int lob_kernel_timing(lob_engine* e, int32_t enable) {
+    if (!e) return LOB_EINVAL;
+    hipSetDevice(e->device);
+    hipStreamSynchronize(e->stream);
+    drain_timers(e);
+    e->timers.clear();
+    e->timing = enable != 0;
+    return LOB_OK;
+}
+int lob_kernel_time_ms(lob_engine* e, const char* kernel, double* avg_ms, int64_t* launches) {
+    if (!e || !kernel || !avg_ms || !launches) return LOB_EINVAL;
+    hipSetDevice(e->device);
+    drain_timers(e);
+    auto it = e->timers.find(kernel);
+    if (it == e->timers.end() || it->second.launches == 0) { *avg_ms = 0.0; *launches = 0; return LOB_OK; }
+    *avg_ms = it->second.total_ms / (double)it->second.launches;
+    *launches = it->second.launches;
+    return LOB_OK;
+}
+
+}  // extern "C"

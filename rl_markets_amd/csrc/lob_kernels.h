@@ -1,0 +1,535 @@
+// HIP kernels of the batched engine (gfx950).  One env-step of every book =
+//   act_kernel    (wave / book)  swap states, Q(last_state,.), policy -> action
+//   env_kernel    (lane / book)  performAction: book/order/event loop, reward, new state vars
+//   learn_kernel  (wave / book)  traces, Q(state,.), TD error
+//   update_kernel (wave / book)  theta[f] += alpha*delta/32 * e[f]   (f64 atomics)
+// act/learn only READ theta, update only WRITES it, so within one step every
+// book sees the same theta_t ("synchronous batch" semantic); with
+// one book this is exactly the reference's Learner::_step order
+// (src/experiment/serial.cpp:53-70).
+#ifndef LOB_KERNELS_H
+#define LOB_KERNELS_H
+
+#include <hip/hip_runtime.h>
+
+#include "lob_state.h"
+#include "lob_stream.h"
+
+struct TickView {
+    int n;
+    const f64* lb;
+    const f64* tick;
+    const i64* cum;
+};
+__device__ inline TickView P_tick(const DevParams& P) { return TickView{P.n_bands, P.band_lb, P.band_tick, P.band_cum}; }
+
+#include "lob_env.h"
+#include "lob_learn.h"
+
+#define LOB_WAVES_PER_BLOCK 4
+#define LOB_BLOCK (64 * LOB_WAVES_PER_BLOCK)
+
+// ---------------------------------------------------------------------------
+__global__ void gen_events_kernel(lob_gen_params g, int D, int T, u64 first_book, int B, uint32_t* out) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int W = lob_rec_words(D, T);
+    lob_gen_state s;
+    lob_gen_init(g, s);
+    uint32_t rec[64];
+    for (int e = 0; e < g.n_events; e++) {
+        lob_gen_event(g, D, T, first_book + (u64)b, e, s, rec);
+        uint32_t* dst = out + ((size_t)b * g.n_events + e) * W;
+        for (int i = 0; i < W; i += 4)
+            *reinterpret_cast<uint4*>(dst + i) = make_uint4(rec[i], rec[i + 1], rec[i + 2], rec[i + 3]);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Base::Initialise + Intraday::Initialise (base.cpp:123-135, intraday.cpp:103-138)
+// followed by the Runner prologue `last_state->newState(environment)`
+// (serial.cpp:25).  Lane per book.
+__global__ void __launch_bounds__(256) reset_kernel(DevParams P, DevState S) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= S.B) return;
+    EnvCtx c(P, S, b);
+    EnvR e;
+    env_load(S, b, e);  // position, pnl_step, levels of quotes etc. persist across episodes
+    const i64 ev0 = e.events;
+    for (int sel = 0; sel < 2; sel++)
+        for (int side = 0; side < 2; side++)
+            for (int l = 0; l < P.D; l++) {
+                S.px[c.lvl(sel, side, l)] = 0.0f;
+                S.vol[c.lvl(sel, side, l)] = 0;
+            }
+    e.sel = 0; e.cursor = 0; e.time_ms = 0; e.done = 0;
+    e.ask_quote = 0.0; e.bid_quote = 0.0;
+    e.a_tv = e.a_ltv = 0; e.a_ntr = 0; e.a_obsval = 0.0; e.a_obsvol = 0; e.a_on = 0;
+    e.b_tv = e.b_ltv = 0; e.b_ntr = 0; e.b_obsval = 0.0; e.b_obsvol = 0; e.b_on = 0;
+    e.ep_reward = e.ep_pnl = e.ep_bandh = 0.0;
+    e.total_ticks = e.market_buys = e.market_sells = 0;
+    e.ap0 = e.bp0 = e.lap0 = e.lbp0 = 0.0;
+    // ClearWindows: deques emptied, running sums kept (quirk Q7)
+#define X(n) S.n.cnt[b] = 0;
+    LOB_ROLLING_MEANS(X)
+    LOB_ACCUMULATORS(X)
+#undef X
+    f64 tp0[LOB_MAX_TRADES];
+    i64 tv0[LOB_MAX_TRADES];
+    for (int i = 0; i < LOB_MAX_TRADES; i++) { tp0[i] = 0.0; tv0[i] = 0; }
+    bool ok = true;
+    while (ok && !is_open(P, e.time_ms)) ok = update_book_profiles(c, e, tp0, tv0);
+    while (ok && !(rm_full(S.f_ask_tx, b) && rm_full(S.f_bid_tx, b) && S.f_vwap_numer.cnt[b] == S.f_vwap_numer.w &&
+                   S.f_vwap_denom.cnt[b] == S.f_vwap_denom.w && rm_full(S.f_volatility, b) &&
+                   rm_full(S.f_midprice, b) && rm_full(S.tp_mp, b) && rm_full(S.spread_window, b)))
+        ok = next_state(c, e);
+    if (ok) {
+        place_orders(c, e, 1, 1);
+        // last_state->newState(env).  Slot 2 always mirrors the latest getState():
+        // Backtester::_step extracts the state itself before acting (serial.cpp:124-137).
+        const int last = S.slot_cur[b] ^ 1;
+        f32* v = S.vars + ((size_t)b * 3 + last) * 16;
+        f32* vf = S.vars + ((size_t)b * 3 + 2) * 16;
+        for (int i = 0; i < P.V; i++) {
+            v[i] = (f32)get_variable(c, e, P.vars[i]);
+            vf[i] = v[i];
+        }
+        if (last == 0) S.zero0[b] = 0; else S.zero1[b] = 0;
+    } else {
+        e.done = 2;
+    }
+    S.stepped[b] = 0;
+    env_store(S, b, e);
+    atomicAdd((u64*)&S.counters[1], (u64)(e.events - ev0));  // warm-up events count as consumed
+}
+
+// Evaluate getState() for every book (lob_get_state): lane per book.
+__global__ void __launch_bounds__(256) get_state_kernel(DevParams P, DevState S, f32* out /*[B][V]*/, f64* reward /*[B] or null*/) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= S.B) return;
+    EnvCtx c(P, S, b);
+    EnvR e;
+    env_load(S, b, e);
+    env_load_best(c, e);
+    if (out)
+        for (int i = 0; i < P.V; i++) out[(size_t)b * P.V + i] = (f32)get_variable(c, e, P.vars[i]);
+    if (reward) reward[b] = get_reward(c, e);
+}
+
+// performAction for every book that has an action pending (S.stepped).
+// mode 0: learner step (new vars go to `state` = slot_cur); mode 1: host
+// supplied actions (lob_step).
+__global__ void __launch_bounds__(256) env_kernel(DevParams P, DevState S, const i32* host_actions) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    i64 d_steps = 0, d_events = 0;
+    if (b < S.B) {
+        bool go;
+        int action;
+        if (host_actions) {
+            go = S.done[b] != 2;
+            action = host_actions[b];
+            S.action[b] = action;
+        } else {
+            go = S.stepped[b] != 0;
+            action = S.action[b];
+        }
+        if (go) {
+            EnvCtx c(P, S, b);
+            EnvR e;
+            env_load(S, b, e);
+            env_load_best(c, e);
+            i64 ev0 = e.events;
+            bool ok = perform_action(c, e, action);
+            d_events = e.events - ev0;
+            if (ok) {
+                const int cur = S.slot_cur[b];
+                f32* v = S.vars + ((size_t)b * 3 + cur) * 16;
+                f32* vf = S.vars + ((size_t)b * 3 + 2) * 16;
+                for (int i = 0; i < P.V; i++) {
+                    v[i] = (f32)get_variable(c, e, P.vars[i]);
+                    vf[i] = v[i];
+                }
+                if (cur == 0) S.zero0[b] = 0; else S.zero1[b] = 0;
+                S.reward[b] = get_reward(c, e);
+                S.stepped[b] = 1;
+                d_steps = 1;
+            } else {
+                S.stepped[b] = 0;
+            }
+            env_store(S, b, e);
+        } else {
+            S.stepped[b] = 0;
+        }
+    }
+    // one atomic per wave for the counters
+    for (int off = 32; off > 0; off >>= 1) {
+        d_steps += __shfl_down(d_steps, off);
+        d_events += __shfl_down(d_events, off);
+    }
+    if ((threadIdx.x & 63) == 0 && (d_steps | d_events)) {
+        atomicAdd((u64*)&S.counters[0], (u64)d_steps);
+        atomicAdd((u64*)&S.counters[1], (u64)d_events);
+    }
+}
+
+// Base::ClearInventory for every book (Runner::RunEpisode epilogue, serial.cpp:31)
+__global__ void __launch_bounds__(256) clear_inventory_kernel(DevParams P, DevState S) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= S.B) return;
+    EnvCtx c(P, S, b);
+    EnvR e;
+    env_load(S, b, e);
+    env_load_best(c, e);
+    clear_inventory(c, e);
+    env_store(S, b, e);
+}
+
+// ---------------------------------------------------------------------------
+// Shared LDS image of a learner block.
+struct LearnLds {
+    uint32_t rnd[2048];                                   // hash_UNH table
+    u64 act_terms[3 * LOB_N_ACTIONS];                     // trailing-coordinate terms, per group/action
+    f64 vals[LOB_WAVES_PER_BLOCK][LOB_N_ACTIONS * LOB_QSTRIDE];  // gathered theta / hash set (aliased)
+    f32 vars[LOB_WAVES_PER_BLOCK][2][16];
+};
+
+__device__ inline void learn_lds_init(const DevParams& P, const uint32_t* __restrict__ rnd_g, LearnLds& L) {
+    for (int i = threadIdx.x; i < 2048; i += blockDim.x) L.rnd[i] = rnd_g[i];
+    __syncthreads();
+    if (threadIdx.x < 3 * LOB_N_ACTIONS) {
+        const int g = threadIdx.x / LOB_N_ACTIONS, a = threadIdx.x % LOB_N_ACTIONS;
+        const int nf = g == 0 ? 3 : (g == 1 ? P.V - 3 : P.V);
+        L.act_terms[threadIdx.x] = tile_action_term(nf, g * LOB_N_ACTIONS + a, L.rnd);
+    }
+    __syncthreads();
+}
+
+// mode 0: Learner::_step prologue (swap, terminal check, epsilon-greedy action)
+// mode 1: Backtester::_step prologue (no swap, greedy action on the current state)
+__global__ void __launch_bounds__(LOB_BLOCK) act_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g,
+                                                        int mode) {
+    __shared__ LearnLds L;
+    learn_lds_init(P, rnd_g, L);
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.x * LOB_WAVES_PER_BLOCK + w;
+    if (b >= S.B) return;
+    if (S.done[b]) { if (lane == 0) S.stepped[b] = 0; return; }
+    int cur = S.slot_cur[b];
+    if (mode == 0) {
+        cur ^= 1;  // swap(state, last_state)
+        if (lane == 0) S.slot_cur[b] = cur;
+    }
+    if (!is_open(P, S.time_ms[b])) {  // environment.isTerminal()
+        if (lane == 0) { S.done[b] = 1; S.stepped[b] = 0; }
+        return;
+    }
+    // the State the action is computed from: last_state (learner) / state (backtester)
+    const int src = mode == 0 ? (cur ^ 1) : 2;
+    const bool zero = mode == 0 && (src == 0 ? S.zero0[b] : S.zero1[b]) != 0;
+    if (lane < 16) L.vars[w][0][lane] = S.vars[((size_t)b * 3 + src) * 16 + lane];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    const f64* theta = S.theta + (P.theta_private ? (size_t)b * (size_t)P.M : 0);
+    f64 qs[LOB_N_ACTIONS];
+    q_values(P, theta, L.vars[w][0], zero, L.rnd, L.act_terms, L.vals[w], lane, qs);
+    Rng g{P.seed, P.book_id_offset + (u64)b, S.rng_ctr[b]};
+    const int action = policy_sample(qs, P.epsilon, mode == 1, g);
+    if (lane < LOB_N_ACTIONS) S.qs_last[(size_t)b * LOB_N_ACTIONS + lane] = qs[lane];
+    if (lane == 0) {
+        S.action[b] = action;
+        S.stepped[b] = 1;
+        S.rng_ctr[b] = g.ctr;
+    }
+}
+
+__device__ inline i32 sel5(const i32* f, int k) {
+    i32 r = f[0];
+    r = k == 1 ? f[1] : r;
+    r = k == 2 ? f[2] : r;
+    r = k == 3 ? f[3] : r;
+    r = k == 4 ? f[4] : r;
+    return r;
+}
+
+// Agent::HandleTransition up to (not including) updateQ: UpdateTraces +
+// the TD error of UpdateWeights (agent.cpp:86-115, 268-311).
+__global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g) {
+    __shared__ LearnLds L;
+    learn_lds_init(P, rnd_g, L);
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.x * LOB_WAVES_PER_BLOCK + w;
+    if (b >= S.B) return;
+    if (!S.stepped[b]) return;
+    const int cur = S.slot_cur[b], last = cur ^ 1;
+    const bool zero_last = (last == 0 ? S.zero0[b] : S.zero1[b]) != 0;
+    if (lane < 16) L.vars[w][0][lane] = S.vars[((size_t)b * 3 + cur) * 16 + lane];         // state (to)
+    else if (lane < 32) L.vars[w][1][lane - 16] = S.vars[((size_t)b * 3 + last) * 16 + lane - 16];  // last_state (from)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+
+    const int action = S.action[b];
+    f64 qs_last[LOB_N_ACTIONS];
+#pragma unroll
+    for (int a = 0; a < LOB_N_ACTIONS; a++) qs_last[a] = S.qs_last[(size_t)b * LOB_N_ACTIONS + a];
+    Rng g{P.seed, P.book_id_offset + (u64)b, S.rng_ctr[b]};
+
+    // ---- group-0 tiles of last_state for all nine actions: lane -> (a = half + 2k, j) ----
+    const int j = lane & 31, half = lane >> 5;
+    i32 F[5];
+    {
+        u64 base = zero_last ? 0 : tile_base(L.vars[w][1], 3, j, L.rnd);
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int a = half + 2 * k;
+            F[k] = (a < LOB_N_ACTIONS && !zero_last) ? mod_m(base + L.act_terms[a < LOB_N_ACTIONS ? a : 0], P.M, P.inv_M) : 0;
+        }
+    }
+
+    // ---- Traces::decay (traces.cpp:30-38) ----
+    int n_old = S.tr_n[b];
+    const int head = S.tr_head[b];
+    int kmax = P.trace_kmax;
+    if (P.algo == LOB_ALGO_QLAMBDA) {
+        const int amax = argmax_ties(qs_last, g);  // QLearn::UpdateTraces (agent.cpp:272-280)
+        if (action != amax) kmax = 1;              // traces.decay(0.0)
+    }
+    if (n_old > kmax - 1) n_old = kmax - 1;        // generations whose eligibility fell below tolerance
+
+    // ---- Traces::update (traces.cpp:40-50) ----
+    // hash set of the 288 current tiles; a live older entry that appears in it
+    // is either cleared (other action) or re-set to 1 (chosen action): in both
+    // cases it leaves its old generation.
+    i32* tab = reinterpret_cast<i32*>(L.vals[w]);
+    for (int i = lane; i < LOB_HSLOTS; i += 64) tab[i] = -1;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const int a = half + 2 * k;
+        if (a < LOB_N_ACTIONS) {
+            const i32 x = F[k];
+            unsigned s = ((unsigned)x * 2654435761u) >> 22;
+            while (true) {
+                i32 old = atomicCAS(&tab[s], -1, x);
+                if (old == -1 || old == x) break;
+                s = (s + 1) & (LOB_HSLOTS - 1);
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    i32* tr_idx = S.tr_idx + (size_t)b * LOB_TRACE_GENS * 32;
+    uint32_t* tr_alive = S.tr_alive + (size_t)b * LOB_TRACE_GENS;
+    for (int k0 = 0; k0 < n_old; k0 += 2) {
+        const int k = k0 + half;  // old age (before this step's decay) of the generation this half-wave scans
+        bool alive = false;
+        int slot = 0;
+        if (k < n_old) {
+            slot = (head - k + 2 * LOB_TRACE_GENS) % LOB_TRACE_GENS;
+            alive = (tr_alive[slot] >> j) & 1u;
+            if (alive) {
+                const i32 x = tr_idx[slot * 32 + j];
+                unsigned s = ((unsigned)x * 2654435761u) >> 22;
+                while (true) {
+                    i32 v = tab[s];
+                    if (v == x) { alive = false; break; }
+                    if (v == -1) break;
+                    s = (s + 1) & (LOB_HSLOTS - 1);
+                }
+            }
+        }
+        const u64 m = __ballot(alive);
+        if (k < n_old && j == 0) tr_alive[slot] = half ? (uint32_t)(m >> 32) : (uint32_t)m;
+    }
+    // new generation: the chosen action's tiles, minus those a later action
+    // clears again and minus duplicates inside the list (set() of a live tile
+    // only overwrites its eligibility).
+    {
+        const i32 N = __shfl(sel5(F, action >> 1), (action & 1) * 32 + j);
+        bool dead = false;
+#pragma unroll
+        for (int ap = 0; ap < LOB_N_ACTIONS; ap++) {
+            if (ap > action) {
+                const i32 fk = F[ap >> 1];
+#pragma unroll 8
+                for (int jj = 0; jj < 32; jj++) {
+                    const i32 v = __shfl(fk, (ap & 1) * 32 + jj);
+                    dead |= (v == N);
+                }
+            }
+        }
+#pragma unroll 8
+        for (int jj = 0; jj < 32; jj++) {
+            const i32 v = __shfl(N, jj);
+            dead |= (jj < j) && (v == N);
+        }
+        const int nh = (head + 1) % LOB_TRACE_GENS;
+        const u64 m = __ballot(!dead && half == 0);
+        if (half == 0) tr_idx[nh * 32 + j] = N;
+        if (lane == 0) {
+            tr_alive[nh] = (uint32_t)m;
+            S.tr_head[b] = nh;
+            S.tr_n[b] = n_old + 1;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- UpdateWeights: TD error under theta_t ----
+    const f64* theta = S.theta + (P.theta_private ? (size_t)b * (size_t)P.M : 0);
+    f64 qs_to[LOB_N_ACTIONS];
+    q_values(P, theta, L.vars[w][0], false, L.rnd, L.act_terms, L.vals[w], lane, qs_to);
+    const f64 reward = S.reward[b];
+    const f64 Q1 = qs_last[0 * 0 + (action < LOB_N_ACTIONS ? action : 0)];
+    f64 delta;
+    const f64 F_term = P.gamma * 0.0 - 0.0;  // potentials are identically 0 (base.cpp:239-242)
+    if (P.algo == LOB_ALGO_QLAMBDA) {
+        const int am2 = argmax_ties(qs_to, g);  // maxQ(to_state)
+        delta = reward + F_term + P.gamma * qs_to[am2] - Q1;
+    } else {
+        const int a2 = policy_sample(qs_to, P.epsilon, false, g);  // this->action(to_state), quirk Q9
+        delta = reward + F_term + P.gamma * qs_to[a2] - Q1;
+    }
+    if (lane == 0) {
+        S.td[b] = delta;
+        S.upd[b] = P.alpha * delta;
+        S.rng_ctr[b] = g.ctr;
+    }
+}
+
+// Agent::updateQ (agent.cpp:137-142): theta[f] += (alpha*delta / N_TILINGS) * e[f]
+__global__ void __launch_bounds__(LOB_BLOCK) update_kernel(DevParams P, DevState S) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.x * LOB_WAVES_PER_BLOCK + w;
+    if (b >= S.B) return;
+    if (!S.stepped[b]) return;
+    const int n = S.tr_n[b], head = S.tr_head[b];
+    const f64 scaled = S.upd[b] / (f64)LOB_N_TILINGS;
+    f64* theta = S.theta + (P.theta_private ? (size_t)b * (size_t)P.M : 0);
+    const i32* tr_idx = S.tr_idx + (size_t)b * LOB_TRACE_GENS * 32;
+    const uint32_t* tr_alive = S.tr_alive + (size_t)b * LOB_TRACE_GENS;
+    const int j = lane & 31, half = lane >> 5;
+    for (int k0 = 0; k0 < n; k0 += 2) {
+        const int k = k0 + half;  // age
+        if (k < n) {
+            const int slot = (head - k + 2 * LOB_TRACE_GENS) % LOB_TRACE_GENS;
+            if ((tr_alive[slot] >> j) & 1u) {
+                const i32 f = tr_idx[slot * 32 + j];
+                const f64 val = scaled * (f64)P.trace_pow[k];
+                __hip_atomic_fetch_add(&theta[f], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    if (lane == 0) atomicAdd((u64*)&S.counters[3], 1ull);
+}
+
+// Agent::HandleTerminal: traces.decay(0.0) (agent.cpp:103-109)
+__global__ void clear_traces_kernel(DevState S) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < S.B) S.tr_n[b] = 0;
+}
+
+// State::newState(vector<float>&) + getFeatures / Agent::getQ for n free-standing
+// states (lob_features / lob_q_values).  Wave per state.
+__global__ void __launch_bounds__(LOB_BLOCK) features_kernel(DevParams P, const f64* __restrict__ theta,
+                                                             const uint32_t* __restrict__ rnd_g, const f32* vars,
+                                                             int n, i32* out_idx, f64* out_q) {
+    __shared__ LearnLds L;
+    learn_lds_init(P, rnd_g, L);
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int s = blockIdx.x * LOB_WAVES_PER_BLOCK + w;
+    if (s >= n) return;
+    if (lane < 16) L.vars[w][0][lane] = lane < P.V ? vars[(size_t)s * P.V + lane] : 0.0f;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (out_idx) {
+        for (int p = lane; p < 96; p += 64) {
+            const int g = p >> 5, j = p & 31;
+            const int nf = g == 0 ? 3 : (g == 1 ? P.V - 3 : P.V);
+            const f32* v = g == 1 ? L.vars[w][0] + 3 : L.vars[w][0];
+            u64 base = tile_base(v, nf, j, L.rnd);
+            for (int a = 0; a < LOB_N_ACTIONS; a++)
+                out_idx[((size_t)s * LOB_N_ACTIONS + a) * 96 + p] = mod_m(base + L.act_terms[g * LOB_N_ACTIONS + a], P.M, P.inv_M);
+        }
+    }
+    if (out_q) {
+        f64 qs[LOB_N_ACTIONS];
+        q_values(P, theta, L.vars[w][0], false, L.rnd, L.act_terms, L.vals[w], lane, qs);
+        if (lane < LOB_N_ACTIONS) out_q[(size_t)s * LOB_N_ACTIONS + lane] = qs[lane];
+    }
+}
+
+// ---- multi-GPU weight exchange --------------------------------------------
+__global__ void delta_begin_kernel(const f64* __restrict__ theta, const f64* __restrict__ sync, f64* delta, i64 M) {
+    i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (; i < M; i += stride) delta[i] = theta[i] - sync[i];
+}
+__global__ void delta_apply_kernel(f64* theta, f64* sync, const f64* __restrict__ delta, i64 M) {
+    i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (; i < M; i += stride) {
+        const f64 t = sync[i] + delta[i];
+        theta[i] = t;
+        sync[i] = t;
+    }
+}
+
+// ---- parity dump -------------------------------------------------------------
+__global__ void dump_kernel(DevParams P, DevState S, int first, int n, lob_book_dump* out) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int b = first + t;
+    EnvCtx c(P, S, b);
+    EnvR e;
+    env_load(S, b, e);
+    lob_book_dump d;
+    memset(&d, 0, sizeof d);
+    for (int l = 0; l < P.D; l++) {
+        d.ask_px[l] = (f64)S.px[c.lvl(e.sel, 0, l)];       d.ask_vol[l] = S.vol[c.lvl(e.sel, 0, l)];
+        d.bid_px[l] = (f64)S.px[c.lvl(e.sel, 1, l)];       d.bid_vol[l] = S.vol[c.lvl(e.sel, 1, l)];
+        d.ask_last_px[l] = (f64)S.px[c.lvl(e.sel ^ 1, 0, l)]; d.ask_last_vol[l] = S.vol[c.lvl(e.sel ^ 1, 0, l)];
+        d.bid_last_px[l] = (f64)S.px[c.lvl(e.sel ^ 1, 1, l)]; d.bid_last_vol[l] = S.vol[c.lvl(e.sel ^ 1, 1, l)];
+        if (d.ask_px[l] == 0.0) d.ask_vol[l] = 0;
+        if (d.bid_px[l] == 0.0) d.bid_vol[l] = 0;
+        if (d.ask_last_px[l] == 0.0) d.ask_last_vol[l] = 0;
+        if (d.bid_last_px[l] == 0.0) d.bid_last_vol[l] = 0;
+    }
+    d.ask_total_volume = e.a_tv; d.bid_total_volume = e.b_tv;
+    d.ask_last_total_volume = e.a_ltv; d.bid_last_total_volume = e.b_ltv;
+    d.ask_n_transacted = e.a_ntr; d.bid_n_transacted = e.b_ntr;
+    d.ask_has_order = e.a_on; d.bid_has_order = e.b_on;
+    if (e.a_on) {
+        d.ask_order_px = e.a_opx;
+        i64 r = e.a_osz - e.a_oex; d.ask_order_rem = r > 0 ? r : 0;
+        d.ask_q_head = e.a_oqh; d.ask_q_tail = e.a_oqt;
+    }
+    if (e.b_on) {
+        d.bid_order_px = e.b_opx;
+        i64 r = e.b_osz - e.b_oex; d.bid_order_rem = r > 0 ? r : 0;
+        d.bid_q_head = e.b_oqh; d.bid_q_tail = e.b_oqt;
+    }
+    d.position = e.position;
+    d.ask_quote = e.ask_quote; d.bid_quote = e.bid_quote;
+    d.ask_level = e.ask_level; d.bid_level = e.bid_level;
+    d.pnl_step = e.pnl_step; d.momentum_pnl_step = e.momentum_pnl_step;
+    d.lo_vol_step = e.lo_vol_step; d.last_action = e.last_action;
+    d.episode_reward = e.ep_reward; d.episode_pnl = e.ep_pnl; d.episode_bandh = e.ep_bandh;
+    d.spread_mean = S.spread_window.mean[b]; d.target_price = e.tp_val;
+    d.time_ms = e.time_ms;
+    d.cursor = e.cursor;
+    d.terminal = e.done == 2 ? 2 : (is_open(P, e.time_ms) ? 0 : 1);
+    d.total_ticks = e.total_ticks;
+    int n_tr = 0;
+    {
+        const int ng = S.tr_n[b], head = S.tr_head[b];
+        for (int k = 0; k < ng; k++) {
+            const int slot = (head - k + 2 * LOB_TRACE_GENS) % LOB_TRACE_GENS;
+            n_tr += __popc(S.tr_alive[(size_t)b * LOB_TRACE_GENS + slot]);
+        }
+    }
+    d.n_traces = n_tr;
+    out[t] = d;
+}
+
+#endif

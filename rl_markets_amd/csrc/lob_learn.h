@@ -1,0 +1,137 @@
+// Device-side learner pieces: CMAC tile coding, linear-Q evaluation, policy
+// sampling and eligibility-trace maintenance, one WAVE (64 lanes) per book.
+//   tiles()/hash_UNH        src/rl/tiles.cpp:31-75,130-169
+//   State::populateFeatures src/rl/state.cpp:53-65
+//   Agent::getQ/argmaxQ     src/rl/agent.cpp:117-169
+//   Greedy/EpsilonGreedy    src/rl/policy.cpp:37-75
+//   Traces                  src/rl/traces.cpp:30-102
+#ifndef LOB_LEARN_H
+#define LOB_LEARN_H
+
+#include <hip/hip_runtime.h>
+
+#include "lob_state.h"
+#include "lob_stream.h"
+
+#define LOB_QSTRIDE 97  // 96 features + 1 pad double: lanes a=0..8 read column i without bank conflicts
+#define LOB_HSLOTS 1024 // per-wave LDS hash set for the 288 "current" tiles
+
+// S % M for S < 2^37, M < 2^31 through a double reciprocal (+-1 fix-up).
+__device__ inline i32 mod_m(u64 s, i64 M, f64 inv_M) {
+    i64 q = (i64)((f64)s * inv_M);
+    i64 r = (i64)s - q * M;
+    if (r < 0) r += M;
+    if (r >= M) r -= M;
+    return (i32)r;
+}
+
+// Sum of the table terms of tiling j of group g that do not depend on the
+// action: the nf float coordinates and the tiling index (tiles.cpp:50-70).
+// `v` = the group's float sub-array (State::populateFeatures passes
+// &state_vars[0] or &state_vars[3]).
+__device__ inline u64 tile_base(const f32* v, int nf, int j, const uint32_t* rnd) {
+    u64 sum = 0;
+    for (int i = 0; i < nf; i++) {
+        int q = (int)floorf(v[i] * 32.0f);  // (int) floor(floats[i] * num_tilings)
+        int base = j * (1 + 2 * i);
+        int c;
+        if (q >= base) c = q - ((q - base) % 32);
+        else c = q + 1 + ((base - q - 1) % 32) - 32;
+        sum += (u64)rnd[(c + 449 * i) & 2047];
+    }
+    sum += (u64)rnd[(j + 449 * nf) & 2047];
+    return sum;
+}
+// table term of the trailing integer coordinate (the action code)
+__device__ inline u64 tile_action_term(int nf, int code, const uint32_t* rnd) {
+    return (u64)rnd[(code + 449 * (nf + 1)) & 2047];
+}
+
+// ---- policy RNG (counter-based; DESIGN.md "RNG") ----------------------------
+struct Rng {
+    u64 seed, stream, ctr;
+    __device__ u64 raw() { return lob_rng(seed, stream, ctr++); }
+    __device__ int rnd() { return (int)(raw() >> 33); }  // stands in for libc rand()
+};
+
+// Greedy::Sample (policy.cpp:37-55)
+__device__ inline int greedy_sample(const f64* qs, Rng& g) {
+    int argmax = 0, n_ties = 1;
+    for (int a = 1; a < LOB_N_ACTIONS; a++) {
+        if (qs[a] > qs[argmax]) argmax = a;
+        else if (qs[a] >= qs[argmax]) {
+            n_ties++;
+            if (0 == g.rnd() % n_ties) argmax = a;
+        }
+    }
+    return argmax;
+}
+// EpsilonGreedy::Sample (policy.cpp:69-75)
+__device__ inline int policy_sample(const f64* qs, f64 eps, bool greedy, Rng& g) {
+    if (!greedy) {
+        f64 u = (f64)(g.raw() >> 11) * (1.0 / 9007199254740992.0);
+        if (u < eps) return (int)(((g.raw() >> 32) * 9ull) >> 32);
+    }
+    return greedy_sample(qs, g);
+}
+// Agent::argmaxQ (agent.cpp:144-169)
+__device__ inline int argmax_ties(const f64* qs, Rng& g) {
+    int index = 0, n_ties = 1;
+    f64 cur = qs[0];
+    for (int a = 1; a < LOB_N_ACTIONS; a++) {
+        f64 val = qs[a];
+        if (val >= cur) {
+            if (val > cur) { cur = val; index = a; }
+            else {
+                n_ties++;
+                if (0 == g.rnd() % n_ties) { cur = val; index = a; }
+            }
+        }
+    }
+    return index;
+}
+
+// Q(s, a) for all 9 actions of one state, one wave.
+//   vars      : V floats of the state (LDS or global), ignored if `zero`
+//   zero      : the rl::State still holds its constructor zeros (all tiles 0)
+//   vals      : per-wave LDS scratch [9][LOB_QSTRIDE] doubles
+//   out_q[9]  : every lane returns all nine Q values
+// Gathers are issued for all 864 (action, tile) pairs before any is consumed;
+// the sum then follows the reference's sequential order term by term so that
+// Q is bitwise the value Agent::getQ computes (quirk Q3 included).
+__device__ inline void q_values(const DevParams& P, const f64* __restrict__ theta, const f32* vars, bool zero,
+                                const uint32_t* rnd, const u64* act_terms /*[3][9] LDS*/, f64* vals, int lane,
+                                f64* out_q) {
+    // 96 (group, tiling) pairs over 64 lanes: pair p = lane and lane + 64
+    for (int p = lane; p < 96; p += 64) {
+        const int g = p >> 5, j = p & 31;
+        const int nf = g == 0 ? 3 : (g == 1 ? P.V - 3 : P.V);
+        const f32* v = g == 1 ? vars + 3 : vars;
+        u64 base = zero ? 0 : tile_base(v, nf, j, rnd);
+        f64 t[LOB_N_ACTIONS];
+#pragma unroll
+        for (int a = 0; a < LOB_N_ACTIONS; a++) {
+            i32 idx = zero ? 0 : mod_m(base + act_terms[g * LOB_N_ACTIONS + a], P.M, P.inv_M);
+            t[a] = theta[idx];
+        }
+#pragma unroll
+        for (int a = 0; a < LOB_N_ACTIONS; a++) vals[a * LOB_QSTRIDE + p] = t[a];
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): LDS writes of this wave have landed
+    f64 q = 0.0;
+    if (lane < LOB_N_ACTIONS) {
+        const f64* v = vals + lane * LOB_QSTRIDE;
+        f64 w = P.w0;
+        for (int i = 0; i < 32; i++) q += w * v[i];
+        w = P.w1;
+        for (int i = 32; i < 64; i++) q += w * v[i];
+        w = P.w2;
+        for (int i = 32; i < 96; i++) q += w * v[i];
+    }
+#pragma unroll
+    for (int a = 0; a < LOB_N_ACTIONS; a++) out_q[a] = __shfl(q, a);
+    __builtin_amdgcn_wave_barrier();
+}
+
+#endif

@@ -1,0 +1,164 @@
+// Device-resident state of the batched engine: struct-of-arrays over books.
+//
+// Layout (DESIGN.md "Data layout in HBM"):
+//   * every per-book scalar is its own array  field[B]  -> lane b of the
+//     lane-per-book environment kernel reads element b: fully coalesced;
+//   * book levels are ping-pong  px[sel][side][level][B]  so that
+//     Book::StashState (reference src/market/book.cpp:51-55) is a parity flip,
+//     never a copy;
+//   * rolling windows are rings  ring[slot][B];
+//   * data consumed by the wave-per-book learner kernels (state variables,
+//     trace lists) is book-major so that one wave reads one contiguous block.
+#ifndef LOB_STATE_H
+#define LOB_STATE_H
+
+#include <stdint.h>
+
+#include "../../include/lob_engine.h"
+
+typedef long long i64;
+typedef unsigned long long u64;
+typedef int i32;
+typedef double f64;
+typedef float f32;
+
+// name, window-size parameter
+#define LOB_ROLLING_MEANS(X) \
+    X(f_midprice)            \
+    X(f_volatility)          \
+    X(f_ask_tx)              \
+    X(f_bid_tx)              \
+    X(spread_window)         \
+    X(pnl_ups)               \
+    X(pnl_downs)             \
+    X(tp_mp)
+#define LOB_ACCUMULATORS(X) \
+    X(f_vwap_numer)         \
+    X(f_vwap_denom)
+
+// Per-book scalars touched by the environment kernel.
+#define LOB_ENV_FIELDS(X)                                                                                     \
+    X(i32, done)      /* 0 live, 1 isTerminal(), 2 out of data */                                              \
+    X(i32, cursor)    /* next depth record (market_depth.record_next) */                                       \
+    X(i32, time_ms)   /* Market::time_ */                                                                      \
+    X(i32, sel)       /* ping-pong parity of the level arrays */                                               \
+    X(i64, position)  /* RiskManager::position_ */                                                             \
+    X(i32, last_action)                                                                                        \
+    X(i32, lo_vol_step)                                                                                        \
+    X(f64, pnl_step)                                                                                           \
+    X(f64, momentum_pnl_step)                                                                                  \
+    X(f64, ask_quote)                                                                                          \
+    X(f64, bid_quote)                                                                                          \
+    X(i32, ask_level)                                                                                          \
+    X(i32, bid_level)                                                                                          \
+    X(f64, tp_val)                                                                                             \
+    X(f64, ep_reward)                                                                                          \
+    X(f64, ep_pnl)                                                                                             \
+    X(f64, ep_bandh)                                                                                           \
+    X(i32, total_ticks)                                                                                        \
+    X(i32, market_buys)                                                                                        \
+    X(i32, market_sells)                                                                                       \
+    X(i64, events)                                                                                             \
+    X(f64, ret_ups_mean)                                                                                       \
+    X(f64, ret_downs_mean)                                                                                     \
+    /* per side: Book<> members + the single live order (quirk Q13) */                                        \
+    X(i64, a_tv) X(i64, a_ltv) X(i32, a_ntr) X(f64, a_obsval) X(i64, a_obsvol)                                 \
+    X(i32, a_on) X(f64, a_opx) X(i64, a_osz) X(i64, a_oqh) X(i64, a_oqt) X(i64, a_oex) X(i64, a_oiq)           \
+    X(i64, b_tv) X(i64, b_ltv) X(i32, b_ntr) X(f64, b_obsval) X(i64, b_obsvol)                                 \
+    X(i32, b_on) X(f64, b_opx) X(i64, b_osz) X(i64, b_oqh) X(i64, b_oqt) X(i64, b_oex) X(i64, b_oiq)
+
+// Per-book scalars of the learner (Runner / Agent / Traces).
+#define LOB_LEARN_FIELDS(X)                                                      \
+    X(u64, rng_ctr)   /* draws consumed from this book's policy stream */        \
+    X(i32, action)    /* action chosen in the current step */                    \
+    X(i32, stepped)   /* 1 if performAction succeeded in the current step */     \
+    X(f64, reward)    /* getReward() after performAction */                      \
+    X(f64, td)        /* last TD error */                                        \
+    X(f64, upd)       /* alpha * delta to scatter */                             \
+    X(i32, slot_cur)  /* which of the two rl::State objects is `state` */        \
+    X(i32, zero0)     /* State object 0 still holds its ctor zeros */            \
+    X(i32, zero1)                                                                \
+    X(i32, tr_head)   /* ring slot of the newest trace generation */             \
+    X(i32, tr_n)      /* live generations */
+
+struct RMPtrs {  // RollingMean<double>
+    f64* ring;   // [w][B]
+    i32* cnt;
+    i32* head;
+    f64* sum;
+    f64* mean;
+    f64* s;
+    i32 w;
+};
+struct AccPtrs {  // Accumulator<double>
+    f64* ring;
+    i32* cnt;
+    i32* head;
+    f64* sum;
+    i32 w;
+};
+
+struct DevState {
+    i32 B;
+    i32 D, T, W;       // depth, trade slots, record words
+    i32 n_events;
+    const uint32_t* records;  // [B][n_events][W]
+
+#define X(t, n) t* n;
+    LOB_ENV_FIELDS(X)
+    LOB_LEARN_FIELDS(X)
+#undef X
+#define X(n) RMPtrs n;
+    LOB_ROLLING_MEANS(X)
+#undef X
+#define X(n) AccPtrs n;
+    LOB_ACCUMULATORS(X)
+#undef X
+
+    f32* px;   // [2 sel][2 side][D][B]
+    i32* vol;  // [2 sel][2 side][D][B]
+
+    f32* vars;      // [B][3][16]  the two rl::State objects' state_vars + the latest getState()
+    f64* qs_last;   // [B][9] Q(last_state, .) of the current step
+    i32* tr_idx;    // [B][LOB_TRACE_GENS][32]
+    uint32_t* tr_alive;  // [B][LOB_TRACE_GENS]
+
+    f64* theta;       // [M] or [B][M]
+    f64* theta_sync;  // [M] (multi-GPU) or null
+    f64* delta;       // [M] scratch for the all-reduce or null
+    i64* counters;    // [8] device counters
+    i32* error_flag;  // [1] bits: reference-would-throw conditions
+};
+
+// Parameters copied to the device once (kernel argument, uniform).
+struct DevParams {
+    i32 D, T, W, V;
+    i32 vars[LOB_MAX_VARS];
+    // tick table
+    i32 n_bands;
+    f64 band_lb[LOB_MAX_BANDS];
+    f64 band_tick[LOB_MAX_BANDS];
+    i64 band_cum[LOB_MAX_BANDS];
+    i64 open_ms, close_ms;
+    i32 order_size, reward_measure;
+    i64 pos_lb, pos_ub;
+    f32 damping_factor, pos_weight, trd_weight, pnl_weight;
+    i32 target_price, quote_mode;
+    f64 ewma_alpha;
+    // learning
+    i64 M;
+    f64 inv_M;
+    f64 w0, w1, w2;
+    f64 gamma, alpha, epsilon;
+    f32 trace_rate;                   // (float)(gamma*lambda)
+    f32 trace_pow[LOB_TRACE_GENS + 1];  // eligibility by age, iterated float products
+    i32 trace_kmax;                   // first age whose eligibility < tolerance
+    i32 algo, theta_private;
+    u64 seed, book_id_offset;
+};
+
+#define LOB_ERR_BAD_ORDER_PRICE 1  /* Order ctor would throw (src/market/order.cpp:22-27) */
+#define LOB_ERR_BAD_LEVEL 2        /* ApplyChanges would throw (src/market/book.cpp:74-77) */
+#define LOB_ERR_UNDEF_PRICE 4      /* Book::price() would throw (src/market/book.cpp:171-173) */
+
+#endif

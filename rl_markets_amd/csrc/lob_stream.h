@@ -56,20 +56,12 @@ LOB_HD float lob_tick_to_price_f32(int ticks) {
 
 LOB_HD uint32_t lob_f32_bits(float f) {
     uint32_t u;
-#if defined(__HIP_DEVICE_COMPILE__)
-    u = __float_as_uint(f);
-#else
-    memcpy(&u, &f, 4);
-#endif
+    __builtin_memcpy(&u, &f, 4);
     return u;
 }
 LOB_HD float lob_bits_f32(uint32_t u) {
     float f;
-#if defined(__HIP_DEVICE_COMPILE__)
-    f = __uint_as_float(u);
-#else
-    memcpy(&f, &u, 4);
-#endif
+    __builtin_memcpy(&f, &u, 4);
     return f;
 }
 

@@ -1,0 +1,225 @@
+"""Thin Python handle over the C ABI (include/lob_engine.h).
+
+Only plumbing lives here (buffer allocation, error mapping); every
+computation happens in liblob_engine.so on the GPU.  The class mirrors the
+reference's call surface for the hot path:
+
+    reset()            environment::Base::Initialise + Runner prologue
+    step(actions)      environment::Base::performAction
+    get_state()        environment::Base::getState
+    get_reward()       environment::Base::getReward
+    td_step(n)         experiment::serial::Learner::_step  x n
+    eval_step(n)       experiment::serial::Backtester::_step x n
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+
+
+class LobError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("lob_engine error %d: %s" % (code, msg))
+        self.code = code
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def default_params():
+    lib = abi.load()
+    p = abi.Params()
+    lib.lob_default_params(C.byref(p))
+    return p
+
+
+def default_gen_params():
+    lib = abi.load()
+    g = abi.GenParams()
+    lib.lob_default_gen_params(C.byref(g))
+    return g
+
+
+def record_words(depth, max_trades):
+    return abi.load().lob_record_words(depth, max_trades)
+
+
+def gen_stream_host(gen, depth, max_trades, first_book, n_books):
+    lib = abi.load()
+    W = lib.lob_record_words(depth, max_trades)
+    out = np.zeros((n_books, gen.n_events, W), dtype=np.uint32)
+    rc = lib.lob_gen_stream_host(C.byref(gen), depth, max_trades, C.c_uint64(first_book), n_books, _ptr(out))
+    if rc:
+        raise LobError(rc, lib.lob_last_error().decode())
+    return out
+
+
+class Engine:
+    def __init__(self, params, n_books, device=0):
+        self.lib = abi.load()
+        self.params = params
+        self.B = int(n_books)
+        self.V = params.n_vars
+        self.M = params.memory_size
+        h = C.c_void_p()
+        self._check(self.lib.lob_create(C.byref(params), self.B, device, C.byref(h)))
+        self.h = h
+
+    def _check(self, rc):
+        if rc != abi.LOB_OK:
+            raise LobError(rc, self.lib.lob_last_error().decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.lob_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- streams ----
+    def load_events(self, records):
+        rec = np.ascontiguousarray(records, dtype=np.uint32)
+        assert rec.shape[0] == self.B
+        self._check(self.lib.lob_load_events(self.h, _ptr(rec), rec.shape[1]))
+
+    def gen_events(self, gen):
+        self._check(self.lib.lob_gen_events_device(self.h, C.byref(gen)))
+
+    # ---- environment ----
+    def reset(self):
+        self._check(self.lib.lob_reset(self.h))
+
+    def step(self, actions):
+        a = np.ascontiguousarray(actions, dtype=np.int32)
+        assert a.shape == (self.B,)
+        self._check(self.lib.lob_step(self.h, _ptr(a)))
+
+    def get_state(self):
+        out = np.zeros((self.B, self.V), np.float32)
+        self._check(self.lib.lob_get_state(self.h, _ptr(out)))
+        return out
+
+    def get_reward(self):
+        out = np.zeros(self.B, np.float64)
+        self._check(self.lib.lob_get_reward(self.h, _ptr(out)))
+        return out
+
+    def get_terminal(self):
+        out = np.zeros(self.B, np.uint8)
+        self._check(self.lib.lob_get_terminal(self.h, _ptr(out)))
+        return out
+
+    def clear_inventory(self):
+        self._check(self.lib.lob_clear_inventory(self.h))
+
+    def get_books(self, first=0, n=None):
+        n = self.B - first if n is None else n
+        out = (abi.BookDump * n)()
+        self._check(self.lib.lob_get_books(self.h, first, n, C.cast(out, C.c_void_p)))
+        return out
+
+    # ---- learner ----
+    def td_step(self, n=1):
+        self._check(self.lib.lob_td_step(self.h, n))
+
+    def eval_step(self, n=1):
+        self._check(self.lib.lob_eval_step(self.h, n))
+
+    def handle_terminal(self):
+        self._check(self.lib.lob_handle_terminal(self.h))
+
+    def set_alpha(self, a):
+        self._check(self.lib.lob_set_alpha(self.h, a))
+
+    def set_epsilon(self, e):
+        self._check(self.lib.lob_set_epsilon(self.h, e))
+
+    def features(self, vars_):
+        v = np.ascontiguousarray(vars_, dtype=np.float32).reshape(-1, self.V)
+        out = np.zeros((v.shape[0], 9, 96), np.int32)
+        self._check(self.lib.lob_features(self.h, _ptr(v), v.shape[0], _ptr(out)))
+        return out
+
+    def q_values(self, vars_):
+        v = np.ascontiguousarray(vars_, dtype=np.float32).reshape(-1, self.V)
+        out = np.zeros((v.shape[0], 9), np.float64)
+        self._check(self.lib.lob_q_values(self.h, _ptr(v), v.shape[0], _ptr(out)))
+        return out
+
+    def theta(self, which=0):
+        out = np.zeros(self.M, np.float64)
+        self._check(self.lib.lob_theta_get(self.h, which, _ptr(out), self.M))
+        return out
+
+    def set_theta(self, values, which=0):
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        assert v.shape == (self.M,)
+        self._check(self.lib.lob_theta_set(self.h, which, _ptr(v), self.M))
+
+    def _vec(self, fn, dtype):
+        out = np.zeros(self.B, dtype)
+        self._check(fn(self.h, _ptr(out)))
+        return out
+
+    def last_actions(self):
+        return self._vec(self.lib.lob_get_last_actions, np.int32)
+
+    def last_td(self):
+        return self._vec(self.lib.lob_get_last_td, np.float64)
+
+    def last_rewards(self):
+        return self._vec(self.lib.lob_get_last_rewards, np.float64)
+
+    def stepped(self):
+        return self._vec(self.lib.lob_get_stepped, np.int32)
+
+    def rng_counters(self):
+        return self._vec(self.lib.lob_get_rng_counters, np.uint64)
+
+    def learner_state(self):
+        out = np.zeros((self.B, self.V), np.float32)
+        self._check(self.lib.lob_get_learner_state(self.h, _ptr(out)))
+        return out
+
+    def traces(self, book):
+        idx = np.zeros(1024, np.int32)
+        e = np.zeros(1024, np.float32)
+        n = C.c_int32()
+        self._check(self.lib.lob_get_traces(self.h, book, _ptr(idx), _ptr(e), 1024, C.byref(n)))
+        return idx[:n.value].copy(), e[:n.value].copy()
+
+    def counters(self):
+        c = np.zeros(4, np.int64)
+        self._check(self.lib.lob_get_counters(self.h, _ptr(c)))
+        return c
+
+    # ---- multi-GPU weight exchange ----
+    def delta_init(self):
+        self._check(self.lib.lob_delta_init(self.h))
+
+    def delta_begin(self):
+        p = C.c_void_p()
+        n = C.c_int64()
+        self._check(self.lib.lob_delta_begin(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def delta_apply(self):
+        self._check(self.lib.lob_delta_apply(self.h))
+
+    def sync(self):
+        self._check(self.lib.lob_sync(self.h))
+
+    def kernel_timing(self, enable=True):
+        self._check(self.lib.lob_kernel_timing(self.h, 1 if enable else 0))
+
+    def kernel_time_ms(self, name):
+        ms = C.c_double()
+        n = C.c_int64()
+        self._check(self.lib.lob_kernel_time_ms(self.h, name.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value

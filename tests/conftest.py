@@ -1,0 +1,30 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built():
+    """Build the engine library (hipcc cross-compiles without a GPU) and the oracle."""
+    import __graft_entry__ as g
+    g.build()
+    yield
+
+
+def has_gpu():
+    try:
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        n = ctypes.c_int(0)
+        return hip.hipGetDeviceCount(ctypes.byref(n)) == 0 and n.value > 0
+    except OSError:
+        return False

@@ -1,0 +1,201 @@
+"""GPU parity tests: the HIP engine (through the C ABI) against the oracle
+(oracle/liblob_oracle.so, itself pinned to the unmodified reference by
+tests/test_oracle_vs_reference.py and tests/golden/).  Bit-exact for book /
+order / state / reward / RNG; learned weights bit-exact for private theta and
+within 1e-9 relative for shared theta (f64 atomic ordering)."""
+import numpy as np
+import pytest
+
+from rl_markets_amd import abi, engine
+from tests import oracle_lib as ol
+from tests.parity import compare_env, compare_learner_step
+
+pytestmark = pytest.mark.gpu
+
+
+def make(depth=5, trades=2, n_events=500, B=4, algo=abi.ALGO_SARSA, theta_mode=abi.THETA_PRIVATE, mem=1 << 18,
+         first_book=0, seed=1994, **over):
+    p = engine.default_params()
+    p.depth, p.max_trades = depth, trades
+    p.algo, p.theta_mode, p.memory_size = algo, theta_mode, mem
+    p.book_id_offset = first_book
+    p.seed = seed
+    for k, v in over.items():
+        setattr(p, k, v)
+    g = engine.default_gen_params()
+    g.n_events = n_events
+    rec = engine.gen_stream_host(g, depth, trades, first_book, B)
+    eng = engine.Engine(p, B)
+    eng.load_events(rec)
+    orc = ol.Oracle(p, rec)
+    return p, g, rec, eng, orc
+
+
+def test_no_cpu_fallback_symbols():
+    lib = abi.load()
+    assert lib.lob_abi_version() == 1
+
+
+def test_features_match_oracle():
+    p = engine.default_params()  # M = 20 000 000
+    eng = engine.Engine(p, 1)
+    rng = np.random.default_rng(7)
+    v = np.concatenate([
+        rng.uniform(-12, 12, size=(300, 8)),
+        rng.integers(-100, 20, size=(100, 8)).astype(np.float64),
+        np.array([[1, -100, 2, 0, 3, 1.7, -2.5, 0.4], [0] * 8, [-0.0, -1e-9, 1e-9, 31.999999, -32, 5, 5, 5]]),
+    ]).astype(np.float32)
+    got = eng.features(v)
+    want = np.zeros_like(got)
+    ol.load().oracle_tiles(p.memory_size, ol.ptr(v), 8, v.shape[0], ol.ptr(want))
+    np.testing.assert_array_equal(got, want)
+    # SURVEY.md §8c known answer from the unmodified reference
+    i = 400
+    assert list(got[i, 0, :4]) == [7277022, 11975445, 7036608, 19940000]
+    assert list(got[i, 8, 64:68]) == [6750499, 5357726, 13423606, 5907867]
+
+
+def test_q_values_bitwise():
+    p = engine.default_params()
+    p.memory_size = 1 << 16
+    eng = engine.Engine(p, 1)
+    rng = np.random.default_rng(3)
+    th = rng.standard_normal(p.memory_size)
+    eng.set_theta(th)
+    v = rng.uniform(-10, 10, size=(64, 8)).astype(np.float32)
+    q = eng.q_values(v)
+    f = eng.features(v)
+    w = list(p.group_weights)
+    for i in range(v.shape[0]):
+        for a in range(9):
+            Q = 0.0
+            for k in range(32):
+                Q += w[0] * th[f[i, a, k]]
+            for k in range(32, 64):
+                Q += w[1] * th[f[i, a, k]]
+            for k in range(32, 96):
+                Q += w[2] * th[f[i, a, k]]  # quirk Q3
+            assert q[i, a] == Q
+
+
+@pytest.mark.parametrize("depth,trades", [(5, 2), (10, 2), (3, 1)])
+def test_env_random_actions(depth, trades):
+    B = 64
+    p, g, rec, eng, orc = make(depth=depth, trades=trades, n_events=700, B=B)
+    eng.reset()
+    orc.reset()
+    compare_env(eng, orc, "reset")
+    np.testing.assert_array_equal(eng.get_state(), orc.recs()["vars"][:, :8])
+    rng = np.random.default_rng(depth)
+    for step in range(150):
+        a = rng.integers(0, 9, size=B).astype(np.int32)
+        eng.step(a)
+        orc.env_step(a)
+        compare_env(eng, orc, "D=%d step %d" % (depth, step))
+    live = eng.get_terminal() == 0
+    np.testing.assert_array_equal(eng.get_state()[live], orc.recs()["vars"][live][:, :8])
+    np.testing.assert_array_equal(eng.get_reward()[live], orc.recs()["reward"][live])
+    c = eng.counters()
+    oc = orc.counters()
+    assert c[0] == oc[0] and c[1] == oc[1]
+
+
+@pytest.mark.parametrize("algo", [abi.ALGO_SARSA, abi.ALGO_QLAMBDA])
+def test_td_private_theta_bit_exact(algo):
+    B = 16
+    p, g, rec, eng, orc = make(n_events=600, B=B, algo=algo, theta_mode=abi.THETA_PRIVATE, first_book=100)
+    eng.reset()
+    orc.reset()
+    for step in range(250):
+        eng.td_step(1)
+        orc.td_step(1)
+        compare_learner_step(eng, orc, "algo %d step %d" % (algo, step))
+    for b in range(B):
+        np.testing.assert_array_equal(eng.theta(b), orc.theta(b))
+        ei, ee = eng.traces(b)
+        oi, oe = orc.traces(b)
+        assert dict(zip(ei.tolist(), ee.tolist())) == dict(zip(oi.tolist(), oe.tolist()))
+
+
+def test_td_runs_to_stream_end():
+    B = 8
+    p, g, rec, eng, orc = make(n_events=300, B=B, theta_mode=abi.THETA_PRIVATE)
+    eng.reset()
+    orc.reset()
+    for step in range(260):
+        eng.td_step(1)
+        orc.td_step(1)
+    compare_env(eng, orc, "end")
+    assert (eng.get_terminal() == 2).all()
+    for b in range(B):
+        np.testing.assert_array_equal(eng.theta(b), orc.theta(b))
+    assert eng.counters()[0] == orc.counters()[0]
+
+
+@pytest.mark.parametrize("algo", [abi.ALGO_SARSA, abi.ALGO_QLAMBDA])
+def test_td_shared_theta(algo):
+    B = 32
+    p, g, rec, eng, orc = make(depth=10, n_events=400, B=B, algo=algo, theta_mode=abi.THETA_SHARED, mem=1 << 20)
+    eng.reset()
+    orc.reset()
+    for step in range(120):
+        eng.td_step(1)
+        orc.td_step(1)
+        compare_learner_step(eng, orc, "shared step %d" % step, exact=False, rtol=1e-9)
+    th, oth = eng.theta(), orc.theta()
+    assert np.array_equal(th != 0, oth != 0)
+    np.testing.assert_allclose(th, oth, rtol=1e-9, atol=1e-12)  # north-star tolerance: 1e-5 relative
+
+
+def test_eval_step_greedy():
+    B = 8
+    p, g, rec, eng, orc = make(n_events=400, B=B, theta_mode=abi.THETA_SHARED)
+    rng = np.random.default_rng(5)
+    th = rng.standard_normal(p.memory_size) * 1e-3
+    eng.set_theta(th)
+    orc.theta()[:] = th
+    eng.reset()
+    orc.reset()
+    for step in range(60):
+        eng.eval_step(1)
+        orc.eval_step(1)
+        compare_env(eng, orc, "eval step %d" % step)
+        np.testing.assert_array_equal(eng.last_actions(), orc.recs()["action"])
+    np.testing.assert_array_equal(eng.theta(), th)
+
+
+def test_device_generator_matches_host():
+    p = engine.default_params()
+    p.depth = 10
+    g = engine.default_gen_params()
+    g.n_events = 200
+    B = 16
+    p.book_id_offset = 5
+    rec = engine.gen_stream_host(g, 10, 2, 5, B)
+    e1 = engine.Engine(p, B)
+    e1.load_events(rec)
+    e1.reset()
+    e2 = engine.Engine(p, B)
+    e2.gen_events(g)
+    e2.reset()
+    e1.td_step(50)
+    e2.td_step(50)
+    from tests.parity import dumps_to_np, assert_books_equal
+    assert_books_equal(dumps_to_np(e1.get_books()), dumps_to_np(e2.get_books()), "host vs device generator")
+
+
+def test_bad_stream_rejected():
+    p, g, rec, eng, orc = make(n_events=50, B=2)
+    bad = rec.copy()
+    bad[1, 10, 2 + 5] = 0  # ask volume of level 0 -> 0 : reference throws (src/market/book.cpp:76)
+    with pytest.raises(engine.LobError) as ei:
+        eng.load_events(bad)
+    assert ei.value.code == abi.LOB_EDATA
+
+
+def test_step_before_reset_is_an_error():
+    p = engine.default_params()
+    eng = engine.Engine(p, 2)
+    with pytest.raises(engine.LobError) as ei:
+        eng.td_step(1)
+    assert ei.value.code == abi.LOB_ESTATE
