@@ -101,7 +101,7 @@ struct TimedLaunch {
         auto get = [&]() {
             hipEvent_t ev;
             if (!e->event_pool.empty()) { ev = e->event_pool.back(); e->event_pool.pop_back(); }
-            else hipEventCreate(&ev);
+            else hipEventCreateWithFlags(&ev, hipEventDisableSystemFence);
             return ev;
         };
         a = get();
@@ -352,7 +352,7 @@ int lob_step(lob_engine* e, const int32_t* host_actions) {
     HIPCHK(hipMemcpyAsync(e->actions_dev, host_actions, (size_t)e->B * 4, hipMemcpyHostToDevice, e->stream));
     {
         TimedLaunch t(e, "env_kernel");
-        hipLaunchKernelGGL(env_kernel, dim3(grid_lanes(e->B)), dim3(256), 0, e->stream, e->P, e->S, (const i32*)e->actions_dev);
+        hipLaunchKernelGGL(env_kernel, dim3(grid_lanes(e->B)), dim3(256), 0, e->stream, e->P, e->S, (const i32*)e->actions_dev, 0);
     }
     HIPCHK(hipGetLastError());
     return check_device_errors(e);
@@ -436,7 +436,7 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode) {
         }
         {
             TimedLaunch t(e, "env_kernel");
-            hipLaunchKernelGGL(env_kernel, dim3(gl), dim3(256), 0, e->stream, e->P, e->S, (const i32*)nullptr);
+            hipLaunchKernelGGL(env_kernel, dim3(gl), dim3(256), 0, e->stream, e->P, e->S, (const i32*)nullptr, mode == 0 ? 1 : 0);
         }
         if (mode == 0) {
             {

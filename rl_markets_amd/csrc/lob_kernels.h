@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(256) get_state_kernel(DevParams P, DevState S,
 // performAction for every book that has an action pending (S.stepped).
 // mode 0: learner step (new vars go to `state` = slot_cur); mode 1: host
 // supplied actions (lob_step).
-__global__ void __launch_bounds__(256) env_kernel(DevParams P, DevState S, const i32* host_actions) {
+__global__ void __launch_bounds__(256) env_kernel(DevParams P, DevState S, const i32* host_actions, int count_updates) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     i64 d_steps = 0, d_events = 0;
     if (b < S.B) {
@@ -169,6 +169,7 @@ __global__ void __launch_bounds__(256) env_kernel(DevParams P, DevState S, const
     if ((threadIdx.x & 63) == 0 && (d_steps | d_events)) {
         atomicAdd((u64*)&S.counters[0], (u64)d_steps);
         atomicAdd((u64*)&S.counters[1], (u64)d_events);
+        if (count_updates) atomicAdd((u64*)&S.counters[3], (u64)d_steps);  // every stepped book gets one TD update
     }
 }
 
@@ -420,7 +421,6 @@ __global__ void __launch_bounds__(LOB_BLOCK) update_kernel(DevParams P, DevState
             }
         }
     }
-    if (lane == 0) atomicAdd((u64*)&S.counters[3], 1ull);
 }
 
 // Agent::HandleTerminal: traces.decay(0.0) (agent.cpp:103-109)
