@@ -51,13 +51,6 @@ def hip_device_sync():
         raise RuntimeError("hipDeviceSynchronize failed: %d" % rc)
 
 
-class DevArray:
-    """Expose a raw device pointer to torch (for the RCCL all-reduce)."""
-
-    def __init__(self, ptr, n):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
-
-
 def cpu_baseline():
     """Time the UNMODIFIED reference (oracle/_ref/ref_harness, built from the
     reference's own sources) on a bounded sample of the workload on this
@@ -137,26 +130,12 @@ def main():
     eng = engine.Engine(p, args.books, device=local_rank)
     eng.gen_events(g)       # synthetic streams generated directly in HBM (never timed)
     eng.reset()
-    if world > 1:
-        eng.delta_init()
 
-    def sync_weights():
-        ptr, n = eng.delta_begin()
-        t = torch.as_tensor(DevArray(ptr, n), device="cuda:%d" % local_rank)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        torch.cuda.synchronize()
-        eng.delta_apply()
+    from rl_markets_amd.parallel import EngineBackend, ShardedLearner
+    learner = ShardedLearner(EngineBackend(eng, torch, "cuda:%d" % local_rank), dist, sync_every=SYNC_EVERY)
 
     def run(n_steps, first):
-        done = 0
-        while done < n_steps:
-            chunk = n_steps - done
-            if world > 1:
-                chunk = min(chunk, SYNC_EVERY - (first + done) % SYNC_EVERY)
-            eng.td_step(chunk)
-            done += chunk
-            if world > 1 and (first + done) % SYNC_EVERY == 0:
-                sync_weights()
+        learner.run(n_steps)
 
     def barrier():
         eng.sync()

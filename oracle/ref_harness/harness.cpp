@@ -46,6 +46,7 @@
 #include "rl/agent.h"
 #include "rl/policy.h"
 #include "rl/state.h"
+#include "rl/tiles.h"
 #include "utilities/config.h"
 
 #include "../../rl_markets_amd/csrc/lob_stream.h"  // record layout + lob_rng (inputs only)
@@ -410,6 +411,19 @@ int main(int argc, char** argv) {
                 auto& f = st.getFeatures(act);
                 fwrite(f.data(), 4, 96, out);
             }
+        }
+        fclose(out);
+        return 0;
+    }
+    if (mode == "rndseq") {
+        // The 2048-entry table of hash_UNH (src/rl/tiles.cpp:133), read back through the
+        // reference function itself: with one coordinate k, increment 0 and m > 2^32 the
+        // hash returns rndseq[k & 2047] (tiles.cpp:152-166).
+        FILE* out = fopen(a.get("out").c_str(), "wb");
+        for (int k = 0; k < 2048; k++) {
+            int c = k;
+            uint32_t v = (uint32_t)hash_UNH(&c, 1, 1L << 40, 0);
+            fwrite(&v, 4, 1, out);
         }
         fclose(out);
         return 0;

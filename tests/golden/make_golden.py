@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the UNMODIFIED
+reference (oracle/_ref/ref_harness = /root/reference sources compiled in
+place by oracle/Makefile).  Runs only in the build container (the reference
+checkout is not present on the GPU box); the fixtures it writes are committed.
+
+    python tests/golden/make_golden.py
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from rl_markets_amd import abi, engine  # noqa: E402  (host-side helpers only: stream generator)
+from tests import oracle_lib as ol  # noqa: E402
+
+HARNESS = ol.REF_HARNESS
+
+# Fields of the per-step record kept in the trajectory fixtures.
+TRAJ_CASES = [
+    # name, algo, n_events, book id, extra harness args, param overrides for the oracle
+    ("sarsa_b0", "sarsa", 700, 0, {}, {}),
+    ("qlearn_b3", "q_learn", 700, 3, {}, {}),
+    ("sarsa_mm_linear_b11", "sarsa", 500, 11, {"reward": "mm_linear", "pos_weight": "0.05"},
+     {"reward_measure": abi.REWARD_MM_LINEAR, "pos_weight": 0.05}),
+    ("qlearn_pnl_tpmid_b5", "q_learn", 500, 5, {"reward": "pnl", "tp": "microprice", "lb_target": 3},
+     {"reward_measure": abi.REWARD_PNL, "target_price": abi.TP_MIDPRICE, "lb_target": 3}),
+    ("sarsa_tight_bounds_b7", "sarsa", 600, 7, {"pos_ub": 20, "pos_lb": -20, "order_size": 15, "eps": "0.3"},
+     {"pos_ub": 20, "pos_lb": -20, "order_size": 15, "epsilon": 0.3}),
+    ("sarsa_book_quotes_b9", "sarsa", 500, 9, {"tp": "book"}, {"quote_mode": abi.QUOTE_BOOK, "target_price": abi.TP_MIDPRICE}),
+]
+
+
+def run(cmd):
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("%s\n%s\n%s" % (" ".join(cmd), res.stdout, res.stderr))
+    return res.stdout
+
+
+def main():
+    assert ol.have_ref(), "build oracle/_ref first: make -C oracle ref"
+    rng = np.random.default_rng(20260925)
+    with tempfile.TemporaryDirectory() as td:
+        # ---- hash table ----
+        p = os.path.join(td, "rnd.bin")
+        run([HARNESS, "rndseq", "--out", p])
+        rnd = np.fromfile(p, dtype=np.uint32)
+        assert rnd.shape == (2048,)
+
+        # ---- tiles known answers: rl::State::newState(vector<float>&) ----
+        v = np.concatenate([
+            rng.uniform(-12, 12, size=(200, 8)),
+            rng.integers(-100, 20, size=(60, 8)).astype(np.float64),
+            np.array([[1, -100, 2, 0, 3, 1.7, -2.5, 0.4], [0] * 8, [-0.0, -1e-9, 1e-9, 31.999999, -32, 5, 5, 5]]),
+        ]).astype(np.float32)
+        tiles = {}
+        for mem in (20000000, 1 << 20, 999983):
+            vin, vout = os.path.join(td, "v.f32"), os.path.join(td, "t.i32")
+            v.tofile(vin)
+            run([HARNESS, "tiles", "--mem", str(mem), "--nvars", "8", "--in", vin, "--out", vout])
+            tiles[mem] = np.fromfile(vout, dtype=np.int32).reshape(v.shape[0], 9, 96)
+        v5 = rng.uniform(-5, 5, size=(40, 5)).astype(np.float32)
+        vin, vout = os.path.join(td, "v5.f32"), os.path.join(td, "t5.i32")
+        v5.tofile(vin)
+        run([HARNESS, "tiles", "--mem", "20000000", "--nvars", "5", "--in", vin, "--out", vout])
+        tiles5 = np.fromfile(vout, dtype=np.int32).reshape(40, 9, 96)
+
+        # ---- tick conversion known answers: Market::ToTicks / ToPrice / tick_size ----
+        ticks = {}
+        for ticker, lo, hi in (("HSBA.L", 0.5, 12000.0), ("BAES.L", 0.3, 12000.0), ("AIRF.PA", 0.01, 400.0),
+                               ("CRDI.MI", 0.01, 80.0), ("NOKIA.HE", 0.01, 120000.0), ("NESN.VX", 0.2, 15000.0),
+                               ("OMV.VI", 0.01, 300.0)):
+            prices = np.concatenate([np.exp(rng.uniform(np.log(lo), np.log(hi), size=400)),
+                                     np.float32(rng.uniform(lo, min(hi, 1000.0), size=200)).astype(np.float64),
+                                     np.array([702.1, 702.5, 2750.0, 9.5, 12.6, 1.96885, 46021.0, 46025.0])])
+            prices = prices[(prices >= lo)]
+            pin, pout = os.path.join(td, "p.f64"), os.path.join(td, "p.out")
+            prices.tofile(pin)
+            run([HARNESS, "ticks", "--ticker", ticker, "--in", pin, "--out", pout])
+            out = np.fromfile(pout, dtype=[("ticks", np.int32), ("pad", np.int32), ("back", np.float64), ("tick", np.float64)])
+            ticks[ticker] = (prices, out["ticks"].copy(), out["back"].copy(), out["tick"].copy())
+
+        np.savez_compressed(os.path.join(HERE, "kat_reference.npz"), rndseq=rnd, tiles_vars=v,
+                            **{"tiles_%d" % m: t for m, t in tiles.items()}, tiles5_vars=v5, tiles5=tiles5,
+                            **{"ticks_%s_%s" % (k, n): a for k, (pr, tk, bk, ts) in ticks.items()
+                               for n, a in (("price", pr), ("ticks", tk), ("back", bk), ("tick", ts))})
+
+        # ---- full trajectories through Intraday + Agent ----
+        g = engine.default_gen_params()
+        for name, algo, n_events, book, extra, _over in TRAJ_CASES:
+            g.n_events = n_events
+            rec = engine.gen_stream_host(g, 5, 2, book, 1)
+            traj, info, theta = ol.run_ref_episode(rec[0], algo=algo, mem=1 << 20, rng_stream=book, extra=extra)
+            np.savez_compressed(os.path.join(HERE, "traj_%s.npz" % name), traj=traj, theta_idx=theta[0],
+                                theta_val=theta[1], steps=info["steps"], end=info["end"], rng_ctr=info["rng_ctr"])
+            print(name, info)
+    print("golden fixtures written to", HERE)
+
+
+if __name__ == "__main__":
+    main()

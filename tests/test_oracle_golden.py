@@ -1,0 +1,138 @@
+"""The oracle (oracle/lob_oracle.cpp) against fixtures produced by the
+UNMODIFIED reference (tests/golden/make_golden.py -> oracle/_ref/ref_harness).
+CPU only.  This is what "parity pinned" rests on: every field of every step of
+six full Intraday+Agent episodes, 263 x 9 x 96 tile indices at three memory
+sizes, the hash table and ~4000 tick conversions on seven venues, bit-exact."""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from rl_markets_amd import abi, engine
+from tests import oracle_lib as ol
+from tests.golden.make_golden import TRAJ_CASES
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+KAT = np.load(os.path.join(GOLD, "kat_reference.npz"))
+
+
+def test_rndseq_table_matches_reference():
+    t = np.zeros(2048, np.uint32)
+    ol.load().oracle_rndseq(ol.ptr(t))
+    np.testing.assert_array_equal(t, KAT["rndseq"])
+    assert int(t[0]) == 1741056371  # first entry of src/rl/tiles.cpp:133
+
+
+@pytest.mark.parametrize("mem", [20000000, 1 << 20, 999983])
+def test_tiles_match_reference(mem):
+    v = KAT["tiles_vars"]
+    out = np.zeros((v.shape[0], 9, 96), np.int32)
+    ol.load().oracle_tiles(mem, ol.ptr(v), 8, v.shape[0], ol.ptr(out))
+    np.testing.assert_array_equal(out, KAT["tiles_%d" % mem])
+
+
+def test_tiles_five_vars():
+    v = KAT["tiles5_vars"]
+    out = np.zeros((v.shape[0], 9, 96), np.int32)
+    ol.load().oracle_tiles(20000000, ol.ptr(v), 5, v.shape[0], ol.ptr(out))
+    np.testing.assert_array_equal(out, KAT["tiles5"])
+
+
+def test_survey_known_answers():
+    lib = ol.load()
+    ints = np.array([0, 0, 0], np.int32)
+    assert lib.oracle_hash_unh(ol.ptr(ints), 3, 20000000, 449) == 17865234
+    ints = np.array([5, -3, 7, 2], np.int32)
+    assert lib.oracle_hash_unh(ol.ptr(ints), 4, 20000000, 449) == 3874936
+    assert lib.oracle_hash_unh(ol.ptr(ints), 4, 1048576, 449) == 769912
+
+
+@pytest.mark.parametrize("ticker", ["HSBA.L", "BAES.L", "AIRF.PA", "CRDI.MI", "NOKIA.HE", "NESN.VX", "OMV.VI"])
+def test_tick_maths_match_reference(ticker):
+    lib = abi.load()
+    m = abi.Market()
+    assert lib.lob_market_preset(ticker.encode(), C.byref(m)) == 0
+    o = ol.load()
+    price, ticks, back, tick = (KAT["ticks_%s_%s" % (ticker, n)] for n in ("price", "ticks", "back", "tick"))
+    for p, t, b, ts in zip(price, ticks, back, tick):
+        assert o.oracle_to_ticks(C.byref(m), p) == t
+        assert o.oracle_to_price(C.byref(m), int(t)) == b
+        assert o.oracle_tick_size(C.byref(m), p) == ts
+        # the product's own host tick maths (same arithmetic as the device functions)
+        ti, pr, tk = C.c_int32(), C.c_double(), C.c_double()
+        assert lib.lob_to_ticks(C.byref(m), p, C.byref(ti)) == 0 and ti.value == t
+        assert lib.lob_to_price(C.byref(m), int(t), C.byref(pr)) == 0 and pr.value == b
+        assert lib.lob_tick_size(C.byref(m), p, C.byref(tk)) == 0 and tk.value == ts
+
+
+def _params_for(over, algo, book):
+    p = engine.default_params()
+    p.memory_size = 1 << 20
+    p.algo = abi.ALGO_SARSA if algo == "sarsa" else abi.ALGO_QLAMBDA
+    p.book_id_offset = book
+    for k, v in over.items():
+        setattr(p, k, v)
+    return p
+
+
+def compare_traj(step_fn, rec_fn, traj, tag, skip_book=("cursor",)):
+    for i in range(1, len(traj)):
+        step_fn()
+        got = rec_fn()
+        want = traj[i]
+        for name in ("action", "reward", "td", "rng_ctr"):
+            assert got[name] == want[name], "%s step %d: %s %r != %r" % (tag, i, name, got[name], want[name])
+        np.testing.assert_array_equal(got["vars"], want["vars"], err_msg="%s step %d vars" % (tag, i))
+        for name in got["book"].dtype.names:
+            if name in skip_book:
+                continue
+            assert np.array_equal(got["book"][name], want["book"][name]), \
+                "%s step %d: book.%s %r != %r" % (tag, i, name, got["book"][name], want["book"][name])
+
+
+@pytest.mark.parametrize("case", TRAJ_CASES, ids=[c[0] for c in TRAJ_CASES])
+def test_oracle_reproduces_reference_trajectory(case):
+    name, algo, n_events, book, _extra, over = case
+    fx = np.load(os.path.join(GOLD, "traj_%s.npz" % name))
+    traj = fx["traj"]
+    g = engine.default_gen_params()
+    g.n_events = n_events
+    rec = engine.gen_stream_host(g, 5, 2, book, 1)
+    p = _params_for(over, algo, book)
+    o = ol.Oracle(p, rec)
+    o.reset()
+    r0 = o.rec(0)
+    for n in r0["book"].dtype.names:
+        if n != "cursor":
+            assert np.array_equal(r0["book"][n], traj[0]["book"][n]), "reset book.%s" % n
+    np.testing.assert_array_equal(r0["vars"], traj[0]["vars"])
+    compare_traj(lambda: o.td_step(1), lambda: o.rec(0), traj, name)
+    # one more step: the reference ended on out-of-data (end == 2)
+    o.td_step(1)
+    assert o.counters()[0] == int(fx["steps"])
+    th = o.theta(0)
+    nz = np.nonzero(th)[0]
+    np.testing.assert_array_equal(nz, fx["theta_idx"])
+    np.testing.assert_array_equal(th[nz], fx["theta_val"])
+
+
+@pytest.mark.skipif(not ol.have_ref(), reason="oracle/_ref/ref_harness not built")
+def test_live_reference_run_matches_oracle():
+    """When the prebuilt reference binary is present, run it live on a fresh
+    stream (not a committed fixture) and compare with the oracle."""
+    g = engine.default_gen_params()
+    g.n_events = 450
+    book = 77
+    rec = engine.gen_stream_host(g, 5, 2, book, 1)
+    traj, info, theta = ol.run_ref_episode(rec[0], algo="q_learn", mem=1 << 18, rng_stream=book)
+    p = _params_for({}, "q_learn", book)
+    p.memory_size = 1 << 18
+    o = ol.Oracle(p, rec)
+    o.reset()
+    compare_traj(lambda: o.td_step(1), lambda: o.rec(0), traj, "live")
+    th = o.theta(0)
+    nz = np.nonzero(th)[0]
+    np.testing.assert_array_equal(nz, theta[0])
+    np.testing.assert_array_equal(th[nz], theta[1])
