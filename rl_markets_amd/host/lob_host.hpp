@@ -1,0 +1,370 @@
+// Host-side C++ mirror of the reference's interfaces for the hot path, on top
+// of the C ABI (include/lob_engine.h).  Same names, argument meaning and error
+// behaviour as the reference classes so that its call sites read unchanged:
+//
+//   lob::Config            <- Config (include/utilities/config.h:7-12): the YAML keys the
+//                             path reads (config/example.yaml), parsed by a small subset
+//                             reader (block maps, flow sequences, scalars, comments)
+//   lob::BatchedIntraday   <- environment::Base / Intraday<> (include/environment/base.h:117-151,
+//                             include/environment/intraday.h:62-75): Initialise(),
+//                             performAction(), getState(), getReward(), isTerminal(),
+//                             ClearInventory(), getEpisodeReward()/getEpisodePnL()...
+//                             for ALL books at once, with a per-book view
+//   lob::Agent             <- rl::Agent (include/rl/agent.h:48-77): HandleTerminal(episode)
+//                             (alpha / epsilon schedules, src/rl/agent.cpp:103-109,
+//                             src/rl/policy.cpp:79-82), GoGreedy(), write_theta()
+//   lob::Learner / lob::Backtester
+//                          <- experiment::serial::Learner / Backtester
+//                             (include/experiment/serial.h:38-58): RunEpisode(), _step()
+//
+// Errors: the reference throws std::runtime_error / std::invalid_argument and
+// returns false for "out of data"; so do these classes (every non-OK ABI status
+// becomes a std::runtime_error carrying lob_last_error()).
+#ifndef LOB_HOST_HPP
+#define LOB_HOST_HPP
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <fstream>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/lob_engine.h"
+
+namespace lob {
+
+inline void check(int rc, const char* what) {
+    if (rc != LOB_OK) throw std::runtime_error(std::string(what) + ": " + lob_last_error());
+}
+
+// ---------------------------------------------------------------------------
+// YAML-subset configuration (same key paths as the reference's Config).
+class Config {
+    std::map<std::string, std::string> kv_;                // "a.b.c" -> scalar
+    std::map<std::string, std::vector<std::string>> seq_;  // "a.b" -> flow sequence
+
+    static std::string strip(const std::string& s) {
+        size_t a = s.find_first_not_of(" \t\r\n"), b = s.find_last_not_of(" \t\r\n");
+        return a == std::string::npos ? "" : s.substr(a, b - a + 1);
+    }
+    static std::string unq(const std::string& s) {
+        if (s.size() >= 2 && (s.front() == '"' || s.front() == '\'') && s.back() == s.front()) return s.substr(1, s.size() - 2);
+        return s;
+    }
+
+public:
+    Config() {}
+    explicit Config(const std::string& path) {
+        std::ifstream f(path);
+        if (!f.is_open()) throw std::runtime_error("[Config] cannot open " + path);
+        parse(f);
+    }
+    static Config FromString(const std::string& text) {
+        Config c;
+        std::istringstream is(text);
+        c.parse(is);
+        return c;
+    }
+    void parse(std::istream& in) {
+        std::vector<std::pair<int, std::string>> stack;
+        std::string line;
+        while (std::getline(in, line)) {
+            size_t h = line.find(" #");
+            if (h != std::string::npos) line = line.substr(0, h);
+            if (!line.empty() && line[0] == '#') continue;
+            if (strip(line).empty()) continue;
+            int indent = 0;
+            while ((size_t)indent < line.size() && line[indent] == ' ') indent++;
+            std::string body = strip(line);
+            size_t colon = body.find(':');
+            if (colon == std::string::npos) throw std::runtime_error("[Config] unsupported line: " + line);
+            std::string key = unq(strip(body.substr(0, colon))), val = strip(body.substr(colon + 1));
+            while (!stack.empty() && stack.back().first >= indent) stack.pop_back();
+            std::string path;
+            for (auto& s : stack) path += s.second + ".";
+            path += key;
+            if (val.empty()) stack.push_back({indent, key});
+            else if (val.front() == '[' && val.back() == ']') {
+                std::vector<std::string> items;
+                std::string cur;
+                for (char ch : val.substr(1, val.size() - 2)) {
+                    if (ch == ',') { if (!strip(cur).empty()) items.push_back(unq(strip(cur))); cur.clear(); }
+                    else cur.push_back(ch);
+                }
+                if (!strip(cur).empty()) items.push_back(unq(strip(cur)));
+                seq_[path] = items;
+            } else kv_[path] = unq(val);
+        }
+    }
+    bool has(const std::string& k) const { return kv_.count(k) || seq_.count(k); }
+    void set(const std::string& k, const std::string& v) { kv_[k] = v; }
+    std::string str(const std::string& k) const {
+        auto it = kv_.find(k);
+        if (it == kv_.end()) throw std::runtime_error("[Config] missing key " + k);
+        return it->second;
+    }
+    std::string str(const std::string& k, const std::string& d) const { return kv_.count(k) ? kv_.at(k) : d; }
+    double num(const std::string& k) const { return std::stod(str(k)); }
+    double num(const std::string& k, double d) const { return kv_.count(k) ? std::stod(kv_.at(k)) : d; }
+    long integer(const std::string& k) const { return std::stol(str(k)); }
+    long integer(const std::string& k, long d) const { return kv_.count(k) ? std::stol(kv_.at(k)) : d; }
+    const std::vector<std::string>& list(const std::string& k) const {
+        auto it = seq_.find(k);
+        if (it == seq_.end()) throw std::runtime_error("[Config] missing sequence " + k);
+        return it->second;
+    }
+
+    // The parameter reads of Base/Intraday/Agent/Policy constructors
+    // (src/environment/base.cpp:14-115, src/environment/intraday.cpp:37-82,
+    //  src/rl/agent.cpp:13-60, src/main.cpp:140-189) folded into lob_params.
+    lob_params to_params(const std::string& ticker, int depth = 5, int max_trades = 2) const {
+        lob_params p;
+        lob_default_params(&p);
+        p.depth = depth;
+        p.max_trades = max_trades;
+        check(lob_market_preset(ticker.c_str(), &p.market), "Market::make_market");
+        static const std::map<std::string, int> v2i = {
+            {"pos", LOB_VAR_POS}, {"spd", LOB_VAR_SPD}, {"mpm", LOB_VAR_MPM}, {"imb", LOB_VAR_IMB},
+            {"svl", LOB_VAR_SVL}, {"vol", LOB_VAR_VOL}, {"rsi", LOB_VAR_RSI}, {"vwap", LOB_VAR_VWAP},
+            {"a_dist", LOB_VAR_A_DIST}, {"a_queue", LOB_VAR_A_QUEUE}, {"b_dist", LOB_VAR_B_DIST},
+            {"b_queue", LOB_VAR_B_QUEUE}, {"last_action", LOB_VAR_LAST_ACTION}};
+        const auto& vars = list("state.variables");
+        if (vars.size() > LOB_MAX_VARS) throw std::runtime_error("too many state variables");
+        p.n_vars = (int)vars.size();
+        for (size_t i = 0; i < vars.size(); i++) {
+            auto it = v2i.find(vars[i]);
+            if (it == v2i.end()) throw std::out_of_range("Unknown state variable: " + vars[i]);  // intraday.cpp:50-58
+            p.vars[i] = it->second;
+        }
+        p.order_size = (int)integer("market.order_size", 1);
+        p.pos_lb = integer("market.pos_lb");
+        p.pos_ub = integer("market.pos_ub");
+        static const std::map<std::string, int> r2i = {
+            {"none", LOB_REWARD_NONE}, {"pnl", LOB_REWARD_PNL}, {"pnl_damped", LOB_REWARD_PNL_DAMPED},
+            {"spread", LOB_REWARD_SPREAD}, {"normed", LOB_REWARD_NORMED}, {"lovol", LOB_REWARD_LOVOL},
+            {"mm_linear", LOB_REWARD_MM_LINEAR}, {"mm_exp", LOB_REWARD_MM_EXP}, {"mm_div", LOB_REWARD_MM_DIV}};
+        std::string rm = str("reward.measure", "pnl");
+        if (!r2i.count(rm)) throw std::runtime_error("Unknown reward measure: " + rm);  // base.cpp:75
+        p.reward_measure = r2i.at(rm);
+        p.pos_weight = (float)num("reward.pos_weight", 0.0);
+        p.trd_weight = (float)num("reward.trd_weight", 0.0);
+        p.pnl_weight = (float)num("reward.pnl_weight", 1.0);
+        p.damping_factor = (float)num("reward.damping_factor", 1.0);
+        auto lb = [&](const char* k, long d) { return (int)std::max(integer(k, d), 1L); };
+        p.lb_vwap = lb("state.lookback.vwap", 0);
+        p.lb_mpm = lb("state.lookback.mpm", 0);
+        p.lb_vlt = lb("state.lookback.vlt", 0);
+        p.lb_svl = lb("state.lookback.svl", 0);
+        p.lb_rsi = lb("state.lookback.rsi", 0);
+        p.lb_spread = lb("policy.spread_lookback", 10);
+        p.lb_pnl = lb("reward.pnl_lookback", 0);
+        std::string lt = str("market.latency.type", "fixed");
+        if (lt != "fixed") throw std::invalid_argument("latency type " + lt + " is outside the hot path (SURVEY.md row 4)");
+        // quirk Q5 (base.cpp:101-112): "midprice" builds MicroPrice, anything else MidPrice
+        std::string tp = str("market.target_price.type", "midprice");
+        p.target_price = (tp != "midprice") ? LOB_TP_MIDPRICE : LOB_TP_MICROPRICE;
+        p.quote_mode = (tp == "book") ? LOB_QUOTE_BOOK : LOB_QUOTE_TARGET;  // intraday.cpp:64
+        p.lb_target = (int)integer("market.target_price.lookback", 1);
+        p.memory_size = integer("learning.memory_size");
+        p.n_tilings = (int)integer("learning.n_tilings");
+        p.n_actions = (int)integer("learning.n_actions");
+        if (has("learning.group_weights")) {  // agent.cpp:42-50
+            const auto& gw = list("learning.group_weights");
+            p.group_weights[0] = std::stod(gw.at(0));
+            p.group_weights[1] = std::stod(gw.at(1));
+            p.group_weights[2] = gw.size() > 2 ? std::stod(gw[2]) : 1.0 - (p.group_weights[0] + p.group_weights[1]);
+        } else p.group_weights[0] = p.group_weights[1] = p.group_weights[2] = 1.0 / 3;
+        p.gamma = num("learning.gamma");
+        p.lambda = num("learning.lambda");
+        p.alpha = num("learning.alpha_start", 0.2);
+        p.epsilon = num("policy.eps_init", 0.0);
+        std::string algo = str("learning.algorithm", "sarsa");
+        if (algo == "sarsa") p.algo = LOB_ALGO_SARSA;
+        else if (algo == "q_learn") p.algo = LOB_ALGO_QLAMBDA;
+        else throw std::invalid_argument("Unknown learning algorithm: " + algo + " (hot path: sarsa, q_learn; SURVEY.md §8f)");
+        p.seed = (uint64_t)integer("debug.random_seed", 1994);
+        return p;
+    }
+};
+
+// ---------------------------------------------------------------------------
+// environment::Base-shaped handle over all books of one engine.
+class BatchedIntraday {
+    lob_engine* e_ = nullptr;
+    lob_params p_;
+    int B_;
+    std::vector<float> state_cache_;
+    std::vector<double> reward_cache_;
+    std::vector<uint8_t> term_cache_;
+    bool cache_ok_ = false;
+
+    void refresh() {
+        if (cache_ok_) return;
+        state_cache_.resize((size_t)B_ * p_.n_vars);
+        reward_cache_.resize(B_);
+        term_cache_.resize(B_);
+        check(lob_get_state(e_, state_cache_.data()), "getState");
+        check(lob_get_reward(e_, reward_cache_.data()), "getReward");
+        check(lob_get_terminal(e_, term_cache_.data()), "isTerminal");
+        cache_ok_ = true;
+    }
+
+public:
+    BatchedIntraday(const lob_params& p, int n_books, int device = 0) : p_(p), B_(n_books) {
+        check(lob_create(&p, n_books, device, &e_), "Intraday::Intraday");
+    }
+    ~BatchedIntraday() { lob_destroy(e_); }
+    BatchedIntraday(const BatchedIntraday&) = delete;
+    BatchedIntraday& operator=(const BatchedIntraday&) = delete;
+
+    lob_engine* handle() { return e_; }
+    const lob_params& params() const { return p_; }
+    int n_books() const { return B_; }
+    void invalidate() { cache_ok_ = false; }
+
+    // LoadData(symbol, md_path, tas_path) (intraday.cpp:141-150): records instead of CSV paths
+    void LoadData(const uint32_t* records, int n_events) { check(lob_load_events(e_, records, n_events), "LoadData"); invalidate(); }
+    void LoadSynthetic(const lob_gen_params& g) { check(lob_gen_events_device(e_, &g), "LoadData"); invalidate(); }
+
+    bool Initialise() {  // false = no data for at least one book (base.h:122)
+        check(lob_reset(e_), "Initialise");
+        invalidate();
+        refresh();
+        for (int b = 0; b < B_; b++) if (term_cache_[b] == 2) return false;
+        return true;
+    }
+    // performAction for every book; returns false when any book ran out of data (base.h:132)
+    bool performAction(const std::vector<int32_t>& actions) {
+        if ((int)actions.size() != B_) throw std::invalid_argument("performAction: one action per book");
+        check(lob_step(e_, actions.data()), "performAction");
+        invalidate();
+        refresh();
+        for (int b = 0; b < B_; b++) if (term_cache_[b] == 2) return false;
+        return true;
+    }
+    bool performAction(int action) { return performAction(std::vector<int32_t>(B_, action)); }
+    void getState(std::vector<float>& out, int book = 0) {  // APPENDS n_vars floats (base.h:125)
+        refresh();
+        out.insert(out.end(), state_cache_.begin() + (size_t)book * p_.n_vars, state_cache_.begin() + (size_t)(book + 1) * p_.n_vars);
+    }
+    double getReward(int book = 0) { refresh(); return reward_cache_[book]; }
+    double getPotential() { return 0.0; }  // base.cpp:239-242
+    bool isTerminal(int book = 0) { refresh(); return term_cache_[book] != 0; }
+    void ClearInventory() { check(lob_clear_inventory(e_), "ClearInventory"); invalidate(); }
+    lob_book_dump book(int b) { lob_book_dump d; check(lob_get_book(e_, b, &d), "book"); return d; }
+    double getEpisodeReward(int b = 0) { return book(b).episode_reward; }
+    double getEpisodePnL(int b = 0) { return book(b).episode_pnl; }
+    double getMeanEpisodeReward(int b = 0) { lob_book_dump d = book(b); return d.episode_reward / d.total_ticks; }
+    std::string getEpisodeId() { return "synthetic"; }
+};
+
+// ---------------------------------------------------------------------------
+// rl::Agent-shaped object: theta lives on the GPU inside the engine.
+class Agent {
+    BatchedIntraday& env_;
+    double alpha_start_, alpha_floor_, omega_;
+    double eps_init_, eps_floor_, eps_T_;
+    bool greedy_ = false;
+
+public:
+    Agent(BatchedIntraday& env, const Config& c)
+        : env_(env), alpha_start_(c.num("learning.alpha_start", 0.2)), alpha_floor_(c.num("learning.alpha_floor", 0.001)),
+          omega_(c.num("learning.omega", 1.0)), eps_init_(c.num("policy.eps_init", 0.0)),
+          eps_floor_(c.num("policy.eps_floor", 0.0)), eps_T_(c.num("policy.eps_T", 1.0)) {}
+    void GoGreedy() { greedy_ = true; }
+    bool greedy() const { return greedy_; }
+    // Agent::HandleTerminal (agent.cpp:103-109) + EpsilonGreedy::HandleTerminal (policy.cpp:79-82)
+    void HandleTerminal(int episode) {
+        check(lob_handle_terminal(env_.handle()), "HandleTerminal");
+        double alpha = std::max(alpha_floor_, alpha_start_ * std::pow(omega_, (double)episode));
+        check(lob_set_alpha(env_.handle(), alpha), "HandleTerminal");
+        double eps = eps_init_ * std::pow(eps_floor_ / eps_init_, (double)episode / eps_T_);
+        check(lob_set_epsilon(env_.handle(), eps), "HandleTerminal");
+        epsilon_ = eps;
+    }
+    double epsilon_ = -1.0;
+    // Agent::write_theta (agent.cpp:176-181): raw double[MEMORY_SIZE]
+    void write_theta(const std::string& filename) {
+        std::vector<double> th((size_t)env_.params().memory_size);
+        check(lob_theta_get(env_.handle(), 0, th.data(), (int64_t)th.size()), "write_theta");
+        std::ofstream f(filename.c_str(), std::ios::binary);
+        f.write((const char*)th.data(), (std::streamsize)(th.size() * sizeof(double)));
+    }
+    void load_theta(const std::string& filename) {
+        std::vector<double> th((size_t)env_.params().memory_size);
+        std::ifstream f(filename.c_str(), std::ios::binary);
+        if (!f.read((char*)th.data(), (std::streamsize)(th.size() * sizeof(double)))) throw std::runtime_error("load_theta: short file");
+        check(lob_theta_set(env_.handle(), 0, th.data(), (int64_t)th.size()), "load_theta");
+    }
+};
+
+// ---------------------------------------------------------------------------
+// experiment::serial::Runner family (serial.cpp:18-34, 53-70, 124-137).
+class Runner {
+protected:
+    BatchedIntraday& environment;
+    virtual bool _step(Agent* m) = 0;  // true when every book is terminal
+    long n_live() {
+        int64_t c[4];
+        check(lob_get_counters(environment.handle(), c), "counters");
+        return (long)c[2];
+    }
+
+public:
+    explicit Runner(BatchedIntraday& env) : environment(env) {}
+    virtual ~Runner() {}
+    virtual bool RunEpisode(Agent* m) {
+        if (!environment.Initialise()) return false;
+        bool is_terminal;
+        do { is_terminal = _step(m); } while (!is_terminal);
+        environment.ClearInventory();
+        return true;
+    }
+};
+
+class Learner : public Runner {
+    int steps_per_call_;
+    unsigned long _step_counter = 0;
+    int _episode_counter = 0;
+
+protected:
+    bool _step(Agent*) override {
+        check(lob_td_step(environment.handle(), steps_per_call_), "Learner::_step");
+        environment.invalidate();
+        _step_counter += steps_per_call_;
+        return n_live() == 0;
+    }
+
+public:
+    // steps_per_call: how many env-steps of every book are enqueued per host round trip
+    Learner(BatchedIntraday& env, int steps_per_call = 1) : Runner(env), steps_per_call_(steps_per_call) {}
+    unsigned long step_counter() const { return _step_counter; }
+    bool RunEpisode(Agent* m) override {  // serial.cpp:72-93
+        _step_counter = 0;
+        if (Runner::RunEpisode(m)) {
+            m->HandleTerminal(_episode_counter++);
+            return true;
+        }
+        return false;
+    }
+};
+
+class Backtester : public Runner {
+protected:
+    bool _step(Agent*) override {
+        check(lob_eval_step(environment.handle(), 1), "Backtester::_step");
+        environment.invalidate();
+        return n_live() == 0;
+    }
+
+public:
+    explicit Backtester(BatchedIntraday& env) : Runner(env) {}
+};
+
+}  // namespace lob
+#endif

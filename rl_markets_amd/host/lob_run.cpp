@@ -1,0 +1,60 @@
+// Thin driver with the reference's factory choices (src/main.cpp:82-245) for the
+// hot path: read a YAML config, build the batched environment + learner, train
+// n episodes on synthetic streams, evaluate greedily, print the per-episode
+// rows of the reference's training_log (serial.cpp:81-88) for book 0.
+//
+//   lob_run -c config/example.yaml [-n books] [-e episodes] [-a sarsa|q_learn] [--events N] [--depth D] [--theta out.bin]
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "lob_host.hpp"
+
+int main(int argc, char** argv) {
+    std::string cfg_path, algo, theta_out;
+    int books = 1, episodes = 1, events = 2112, depth = 5;
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        auto next = [&]() { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(1); } return std::string(argv[++i]); };
+        if (a == "-c" || a == "--config") cfg_path = next();
+        else if (a == "-n") books = atoi(next().c_str());
+        else if (a == "-e") episodes = atoi(next().c_str());
+        else if (a == "-a" || a == "--algorithm") algo = next();
+        else if (a == "--events") events = atoi(next().c_str());
+        else if (a == "--depth") depth = atoi(next().c_str());
+        else if (a == "--theta") theta_out = next();
+        else { fprintf(stderr, "unknown flag %s\n", a.c_str()); return 1; }
+    }
+    try {
+        if (cfg_path.empty()) throw std::runtime_error("A configuration file must be provided (-c)");  // main.cpp:300-304
+        lob::Config c(cfg_path);
+        if (!algo.empty()) c.set("learning.algorithm", algo);  // CLI override, main.cpp:342-347
+        std::string ticker = c.has("data.symbols") ? c.list("data.symbols").at(0) : "HSBA.L";
+        lob_params p = c.to_params(ticker, depth, 2);
+        lob::BatchedIntraday env(p, books);
+        lob_gen_params g;
+        lob_default_gen_params(&g);
+        g.n_events = events;
+        g.seed = p.seed;
+        env.LoadSynthetic(g);
+        lob::Agent agent(env, c);
+        lob::Learner learner(env, 8);
+        printf("episode,episode_id,reward,pnl,n_steps,epsilon\n");
+        for (int ep = 0; ep < episodes; ep++) {
+            auto t0 = std::chrono::steady_clock::now();
+            if (!learner.RunEpisode(&agent)) { fprintf(stderr, "[!] no data\n"); return 2; }
+            double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            int64_t cnt[4];
+            lob::check(lob_get_counters(env.handle(), cnt), "counters");
+            printf("%d,%s,%.10g,%.10g,%d,%.6g\n", ep + 1, env.getEpisodeId().c_str(), env.getEpisodeReward(0), env.getEpisodePnL(0),
+                   env.book(0).total_ticks, agent.epsilon_);
+            fprintf(stderr, "episode %d: %lld env-steps over %d books in %.3f s\n", ep + 1, (long long)cnt[0], books, sec);
+        }
+        if (!theta_out.empty()) agent.write_theta(theta_out);
+    } catch (std::exception& e) {
+        fprintf(stderr, "Unhandled Exception: %s\n", e.what());  // main.cpp:364-368
+        return 2;
+    }
+    return 0;
+}

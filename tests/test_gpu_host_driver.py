@@ -1,0 +1,53 @@
+"""The C++ host adaptors (rl_markets_amd/host/lob_host.hpp: Config, BatchedIntraday,
+Agent, Learner with the reference's class shapes) driven through the lob_run
+executable on config/example.yaml, checked against the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from rl_markets_amd import abi, engine
+from tests import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_lob_run_single_book_matches_oracle(tmp_path):
+    exe = os.path.join(ROOT, "rl_markets_amd", "host", "lob_run")
+    theta_file = str(tmp_path / "theta.bin")
+    events = 500
+    out = subprocess.run([exe, "-c", os.path.join(ROOT, "config", "example.yaml"), "-a", "q_learn", "-n", "1", "-e", "1",
+                          "--events", str(events), "--theta", theta_file], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    rows = out.stdout.strip().splitlines()
+    assert rows[0] == "episode,episode_id,reward,pnl,n_steps,epsilon"
+    ep, _id, reward, pnl, n_steps, eps = rows[1].split(",")
+
+    p = engine.default_params()        # == config/example.yaml
+    p.algo = abi.ALGO_QLAMBDA
+    g = engine.default_gen_params()
+    g.n_events = events
+    rec = engine.gen_stream_host(g, 5, 2, 0, 1)
+    orc = ol.Oracle(p, rec)
+    orc.reset()
+    for _ in range(events):
+        orc.td_step(1)
+    orc.clear_inventory()
+    r = orc.rec(0)
+    assert int(n_steps) == r["book"]["total_ticks"]
+    assert float(reward) == pytest.approx(r["book"]["episode_reward"], rel=1e-9)
+    assert float(pnl) == pytest.approx(r["book"]["episode_pnl"], rel=1e-9)
+    # EpsilonGreedy::HandleTerminal(0): eps = eps_init * (floor/init)^(0/T) = eps_init
+    assert float(eps) == pytest.approx(0.8)
+    th = np.fromfile(theta_file, dtype=np.float64)
+    np.testing.assert_array_equal(th, orc.theta(0))
+
+
+def test_lob_run_errors_like_the_reference():
+    exe = os.path.join(ROOT, "rl_markets_amd", "host", "lob_run")
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 2 and "Unhandled Exception" in out.stderr
+    out = subprocess.run([exe, "-c", os.path.join(ROOT, "config", "example.yaml"), "-a", "r_learn"], capture_output=True, text=True)
+    assert out.returncode == 2 and "Unknown learning algorithm" in out.stderr
