@@ -103,17 +103,19 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
+    dist = torch = None
+    if world > 1:
+        # torch first: it brings its own HIP runtime and must be the one liblob_engine.so binds to
+        import torch
+        import torch.distributed as dist
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
     import __graft_entry__ as ge
     if not os.path.exists(os.path.join(ROOT, "rl_markets_amd", "csrc", "liblob_engine.so")):
         ge.build()
     from rl_markets_amd import abi, engine
-
-    dist = torch = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     p = engine.default_params()
     p.depth, p.max_trades = args.depth, 2

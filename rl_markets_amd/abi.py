@@ -107,6 +107,9 @@ def load():
         raise EngineLibraryMissing(
             "%s not found: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
             "There is no CPU fallback." % LIB_PATH)
+    # NB: PyTorch-ROCm bundles its own libamdhip64.so.7.  Exactly one HIP runtime may live
+    # in a process: whoever needs torch as well (multi-GPU bench) must `import torch`
+    # BEFORE this call so that the library below resolves to the runtime torch loaded.
     lib = C.CDLL(LIB_PATH)
     P = C.POINTER
     vp = C.c_void_p

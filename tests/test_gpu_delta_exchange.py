@@ -1,0 +1,80 @@
+"""Multi-GPU weight exchange pieces on ONE GPU: two engines (= two book shards)
+on the same device, the delta buffers handed to torch through
+__cuda_array_interface__ exactly as bench.py does for the RCCL all-reduce, the
+all-reduce itself emulated by a torch sum.  Checked against the oracle running
+the same two-shard schedule.
+
+Runs in a fresh interpreter that imports torch BEFORE liblob_engine.so is
+loaded (as bench.py does for N > 1): torch bundles its own libamdhip64 with the
+same SONAME as /opt/rocm's, and whichever HIP runtime is loaded first must be
+the only one in the process."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_delta_exchange_two_shards_one_gpu():
+    out = subprocess.run([sys.executable, os.path.abspath(__file__)], capture_output=True, text=True, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "DELTA-EXCHANGE-OK" in out.stdout
+
+
+def main():
+    import torch
+    assert torch.cuda.is_available()
+    total, world, steps, sync = 12, 2, 48, 16
+    g = engine.default_gen_params()
+    g.n_events = 200
+    engs, orcs, backs = [], [], []
+    for r in range(world):
+        first, n = shard_books(total, world, r)
+        p = engine.default_params()
+        p.memory_size = 1 << 16
+        p.book_id_offset = first
+        rec = engine.gen_stream_host(g, p.depth, p.max_trades, first, n)
+        e = engine.Engine(p, n)
+        e.load_events(rec)
+        e.reset()
+        e.delta_init()
+        o = ol.Oracle(p, rec)
+        o.reset()
+        engs.append(e)
+        orcs.append(o)
+        backs.append(EngineBackend(e, torch, "cuda:0"))
+    osync = np.zeros(1 << 16)
+    for s0 in range(0, steps, sync):
+        for e, o in zip(engs, orcs):
+            e.td_step(sync)
+            o.td_step(sync)
+        ts = [b.delta_tensor() for b in backs]
+        assert ts[0].dtype == torch.float64 and ts[0].is_cuda and ts[0].numel() == 1 << 16
+        tot = ts[0] + ts[1]          # stands in for all_reduce(SUM)
+        for t in ts:
+            t.copy_(tot)
+        torch.cuda.synchronize()
+        for e in engs:
+            e.delta_apply()
+        ototal = sum(o.theta(0) - osync for o in orcs)
+        for o in orcs:
+            o.theta(0)[:] = osync + ototal
+        osync = orcs[0].theta(0).copy()
+    t0, t1 = engs[0].theta(), engs[1].theta()
+    np.testing.assert_array_equal(t0, t1)
+    np.testing.assert_allclose(t0, orcs[0].theta(0), rtol=1e-9, atol=1e-15)
+    assert np.count_nonzero(t0) > 100
+
+
+if __name__ == "__main__":
+    sys.path.insert(0, ROOT)
+    import torch  # noqa: F401  (first: see module docstring)
+    import numpy as np
+    from rl_markets_amd import abi, engine
+    from rl_markets_amd.parallel import EngineBackend, shard_books
+    from tests import oracle_lib as ol
+    main()
+    print("DELTA-EXCHANGE-OK")
