@@ -33,8 +33,12 @@ struct lob_engine {
     int B = 0;
     lob_params params;
     DevParams P;
+    DevParams* P_dev = nullptr;  // device copy for the lane-per-book kernels
     DevState S;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;   // main stream (all API calls)
+    hipStream_t stream2 = nullptr;  // second book group of the step pipeline
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int n_groups = 1;
     std::vector<void*> allocs;
     uint32_t* rnd_dev = nullptr;
     uint32_t* records_dev = nullptr;
@@ -88,6 +92,11 @@ template <class T> int dev_alloc(lob_engine* e, T** p, size_t count) {
     return LOB_OK;
 }
 
+int push_params(lob_engine* e) {
+    if (hipMemcpyAsync(e->P_dev, &e->P, sizeof(DevParams), hipMemcpyHostToDevice, e->stream) != hipSuccess) { lob_set_error("param upload failed"); return LOB_EHIP; }
+    return LOB_OK;
+}
+
 int grid_lanes(int B) { return (B + 255) / 256; }
 int grid_waves(int B) { return (B + LOB_WAVES_PER_BLOCK - 1) / LOB_WAVES_PER_BLOCK; }
 
@@ -95,7 +104,8 @@ struct TimedLaunch {
     lob_engine* e;
     KTimer* t = nullptr;
     hipEvent_t a = nullptr, b = nullptr;
-    TimedLaunch(lob_engine* e_, const char* name) : e(e_) {
+    hipStream_t st;
+    TimedLaunch(lob_engine* e_, const char* name, hipStream_t s = nullptr) : e(e_), st(s ? s : e_->stream) {
         if (!e->timing) return;
         t = &e->timers[name];
         auto get = [&]() {
@@ -106,11 +116,11 @@ struct TimedLaunch {
         };
         a = get();
         b = get();
-        hipEventRecord(a, e->stream);
+        hipEventRecord(a, st);
     }
     ~TimedLaunch() {
         if (!t) return;
-        hipEventRecord(b, e->stream);
+        hipEventRecord(b, st);
         t->pending.push_back({a, b});
     }
 };
@@ -178,6 +188,11 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     e->B = n_books;
     e->params = *p;
     HIPCHK(hipStreamCreate(&e->stream));
+    HIPCHK(hipStreamCreate(&e->stream2));
+    HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming | hipEventDisableSystemFence));
+    HIPCHK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming | hipEventDisableSystemFence));
+    // two book groups pipelined on two streams hide the latency-bound env kernel behind the gather kernels
+    e->n_groups = n_books >= 4096 ? 2 : 1;
 
     // ---- DevParams ----
     DevParams& P = e->P;
@@ -220,8 +235,8 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     int rc = LOB_OK;
 #define X(t, n) if (rc == LOB_OK) rc = dev_alloc(e, &S.n, B);
     LOB_ENV_FIELDS(X)
-    LOB_LEARN_FIELDS(X)
 #undef X
+    if (rc == LOB_OK) rc = dev_alloc(e, &S.hdr, B);
     auto alloc_rm = [&](RMPtrs& r, int w) {
         r.w = w;
         if (rc == LOB_OK) rc = dev_alloc(e, &r.ring, B * w);
@@ -257,16 +272,28 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     if (rc == LOB_OK) rc = dev_alloc(e, &S.theta, (size_t)P.M * (P.theta_private ? B : 1));
     if (rc == LOB_OK) rc = dev_alloc(e, &S.counters, 8);
     if (rc == LOB_OK) rc = dev_alloc(e, &S.error_flag, 1);
-    if (rc == LOB_OK) rc = dev_alloc(e, &e->rnd_dev, 2048);
+    if (rc == LOB_OK) rc = dev_alloc(e, &e->rnd_dev, 2048 + 64);
     if (rc == LOB_OK) rc = dev_alloc(e, &e->actions_dev, B);
+    if (rc == LOB_OK) rc = dev_alloc(e, &e->P_dev, 1);
+    if (rc == LOB_OK) rc = push_params(e);
     if (rc != LOB_OK) { lob_destroy(e); return rc; }
     // the two rl::State objects start with constructor zeros (src/rl/state.cpp:10-19)
     {
-        std::vector<i32> ones(B, 1);
-        HIPCHK(hipMemcpyAsync(S.zero0, ones.data(), B * sizeof(i32), hipMemcpyHostToDevice, e->stream));
-        HIPCHK(hipMemcpyAsync(S.zero1, ones.data(), B * sizeof(i32), hipMemcpyHostToDevice, e->stream));
-        uint32_t rnd[2048];
+        std::vector<LHdr> hdr(B);
+        memset(hdr.data(), 0, B * sizeof(LHdr));
+        for (size_t b = 0; b < B; b++) hdr[b].zero_mask = 3;
+        HIPCHK(hipMemcpyAsync(S.hdr, hdr.data(), B * sizeof(LHdr), hipMemcpyHostToDevice, e->stream));
+        // hash table followed by the 27 trailing-coordinate (action code) terms
+        // rndseq[(code + 449*(nf+1)) & 2047], code = group*9 + action (state.cpp:56-63, tiles.cpp:46,152-163)
+        uint32_t rnd[2048 + 64];
+        memset(rnd, 0, sizeof rnd);
         make_rndseq(rnd);
+        uint64_t* terms = reinterpret_cast<uint64_t*>(rnd + 2048);
+        for (int g = 0; g < 3; g++) {
+            const int nf = g == 0 ? 3 : (g == 1 ? P.V - 3 : P.V);
+            for (int a = 0; a < LOB_N_ACTIONS; a++)
+                terms[g * LOB_N_ACTIONS + a] = rnd[((g * LOB_N_ACTIONS + a) + 449 * (nf + 1)) & 2047];
+        }
         HIPCHK(hipMemcpyAsync(e->rnd_dev, rnd, sizeof rnd, hipMemcpyHostToDevice, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
     }
@@ -277,8 +304,12 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
 void lob_destroy(lob_engine* e) {
     if (!e) return;
     hipSetDevice(e->device);
+    if (e->stream2) hipStreamSynchronize(e->stream2);
     if (e->stream) hipStreamSynchronize(e->stream);
     drain_timers(e);
+    if (e->ev_fork) hipEventDestroy(e->ev_fork);
+    if (e->ev_join) hipEventDestroy(e->ev_join);
+    if (e->stream2) hipStreamDestroy(e->stream2);
     for (auto ev : e->event_pool) hipEventDestroy(ev);
     for (void* p : e->allocs) hipFree(p);
     if (e->records_dev) hipFree(e->records_dev);
@@ -329,7 +360,7 @@ int lob_reset(lob_engine* e) {
     HIPCHK(hipSetDevice(e->device));
     {
         TimedLaunch t(e, "reset_kernel");
-        hipLaunchKernelGGL(reset_kernel, dim3(grid_lanes(e->B)), dim3(256), 0, e->stream, e->P, e->S);
+        hipLaunchKernelGGL(reset_kernel, dim3(grid_lanes(e->B)), dim3(256), 0, e->stream, (const DevParams*)e->P_dev, e->S);
     }
     HIPCHK(hipGetLastError());
     e->was_reset = true;
@@ -352,7 +383,7 @@ int lob_step(lob_engine* e, const int32_t* host_actions) {
     HIPCHK(hipMemcpyAsync(e->actions_dev, host_actions, (size_t)e->B * 4, hipMemcpyHostToDevice, e->stream));
     {
         TimedLaunch t(e, "env_kernel");
-        hipLaunchKernelGGL(env_kernel, dim3(grid_lanes(e->B)), dim3(256), 0, e->stream, e->P, e->S, (const i32*)e->actions_dev, 0);
+        hipLaunchKernelGGL(env_kernel, dim3(grid_lanes(e->B)), dim3(256), 0, e->stream, (const DevParams*)e->P_dev, e->S, (const i32*)e->actions_dev, 0, 0, e->B);
     }
     HIPCHK(hipGetLastError());
     return check_device_errors(e);
@@ -364,7 +395,7 @@ int lob_get_state(lob_engine* e, float* host_out) {
     HIPCHK(hipSetDevice(e->device));
     f32* d = nullptr;
     HIPCHK(hipMalloc((void**)&d, (size_t)e->B * e->P.V * 4));
-    hipLaunchKernelGGL(get_state_kernel, dim3(grid_lanes(e->B)), dim3(256), 0, e->stream, e->P, e->S, d, (f64*)nullptr);
+    hipLaunchKernelGGL(get_state_kernel, dim3(grid_lanes(e->B)), dim3(256), 0, e->stream, (const DevParams*)e->P_dev, e->S, d, (f64*)nullptr);
     hipError_t err = hipMemcpyAsync(host_out, d, (size_t)e->B * e->P.V * 4, hipMemcpyDeviceToHost, e->stream);
     hipStreamSynchronize(e->stream);
     hipFree(d);
@@ -378,7 +409,7 @@ int lob_get_reward(lob_engine* e, double* host_out) {
     HIPCHK(hipSetDevice(e->device));
     f64* d = nullptr;
     HIPCHK(hipMalloc((void**)&d, (size_t)e->B * 8));
-    hipLaunchKernelGGL(get_state_kernel, dim3(grid_lanes(e->B)), dim3(256), 0, e->stream, e->P, e->S, (f32*)nullptr, d);
+    hipLaunchKernelGGL(get_state_kernel, dim3(grid_lanes(e->B)), dim3(256), 0, e->stream, (const DevParams*)e->P_dev, e->S, (f32*)nullptr, d);
     hipError_t err = hipMemcpyAsync(host_out, d, (size_t)e->B * 8, hipMemcpyDeviceToHost, e->stream);
     hipStreamSynchronize(e->stream);
     hipFree(d);
@@ -405,7 +436,7 @@ int lob_clear_inventory(lob_engine* e) {
     int rc = need_reset(e, "lob_clear_inventory");
     if (rc) return rc;
     HIPCHK(hipSetDevice(e->device));
-    hipLaunchKernelGGL(clear_inventory_kernel, dim3(grid_lanes(e->B)), dim3(256), 0, e->stream, e->P, e->S);
+    hipLaunchKernelGGL(clear_inventory_kernel, dim3(grid_lanes(e->B)), dim3(256), 0, e->stream, (const DevParams*)e->P_dev, e->S);
     HIPCHK(hipGetLastError());
     return check_device_errors(e);
 }
@@ -418,7 +449,7 @@ int lob_get_books(lob_engine* e, int32_t first, int32_t n, lob_book_dump* out) {
         HIPCHK(hipMalloc((void**)&e->dump_dev, (size_t)n * sizeof(lob_book_dump)));
         e->dump_cap = n;
     }
-    hipLaunchKernelGGL(dump_kernel, dim3((n + 63) / 64), dim3(64), 0, e->stream, e->P, e->S, first, n, e->dump_dev);
+    hipLaunchKernelGGL(dump_kernel, dim3((n + 63) / 64), dim3(64), 0, e->stream, (const DevParams*)e->P_dev, e->S, first, n, e->dump_dev);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, e->dump_dev, (size_t)n * sizeof(lob_book_dump), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -426,27 +457,43 @@ int lob_get_books(lob_engine* e, int32_t first, int32_t n, lob_book_dump* out) {
 }
 int lob_get_book(lob_engine* e, int32_t book, lob_book_dump* out) { return lob_get_books(e, book, 1, out); }
 
+// One env-step of every book.  The books are split into n_groups contiguous
+// groups, each running act -> env -> learn on its own stream; both groups only
+// READ theta, so the synchronous-batch semantic is unchanged.  The update of all
+// books runs on the main stream after both groups have joined.
 static int run_steps(lob_engine* e, int32_t n_steps, int mode) {
     HIPCHK(hipSetDevice(e->device));
-    const int gw = grid_waves(e->B), gl = grid_lanes(e->B);
+    const int G = e->n_groups;
+    const uint32_t* rnd = (const uint32_t*)e->rnd_dev;
     for (int s = 0; s < n_steps; s++) {
-        {
-            TimedLaunch t(e, "act_kernel");
-            hipLaunchKernelGGL(act_kernel, dim3(gw), dim3(LOB_BLOCK), 0, e->stream, e->P, e->S, (const uint32_t*)e->rnd_dev, mode);
+        if (G > 1) {
+            HIPCHK(hipEventRecord(e->ev_fork, e->stream));
+            HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
         }
-        {
-            TimedLaunch t(e, "env_kernel");
-            hipLaunchKernelGGL(env_kernel, dim3(gl), dim3(256), 0, e->stream, e->P, e->S, (const i32*)nullptr, mode == 0 ? 1 : 0);
+        for (int g = 0; g < G; g++) {
+            hipStream_t st = g == 0 ? e->stream : e->stream2;
+            const int b0 = (int)((long long)e->B * g / G), nb = (int)((long long)e->B * (g + 1) / G) - b0;
+            const int gw = grid_waves(nb), gl = grid_lanes(nb);
+            {
+                TimedLaunch t(e, "act_kernel", st);
+                hipLaunchKernelGGL(act_kernel, dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, mode, b0, nb);
+            }
+            {
+                TimedLaunch t(e, "env_kernel", st);
+                hipLaunchKernelGGL(env_kernel, dim3(gl), dim3(256), 0, st, (const DevParams*)e->P_dev, e->S, (const i32*)nullptr, mode == 0 ? 1 : 0, b0, nb);
+            }
+            if (mode == 0) {
+                TimedLaunch t(e, "learn_kernel", st);
+                hipLaunchKernelGGL(learn_kernel, dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, b0, nb);
+            }
+        }
+        if (G > 1) {
+            HIPCHK(hipEventRecord(e->ev_join, e->stream2));
+            HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join, 0));
         }
         if (mode == 0) {
-            {
-                TimedLaunch t(e, "learn_kernel");
-                hipLaunchKernelGGL(learn_kernel, dim3(gw), dim3(LOB_BLOCK), 0, e->stream, e->P, e->S, (const uint32_t*)e->rnd_dev);
-            }
-            {
-                TimedLaunch t(e, "update_kernel");
-                hipLaunchKernelGGL(update_kernel, dim3(gw), dim3(LOB_BLOCK), 0, e->stream, e->P, e->S);
-            }
+            TimedLaunch t(e, "update_kernel");
+            hipLaunchKernelGGL(update_kernel, dim3(grid_waves(e->B)), dim3(LOB_BLOCK), 0, e->stream, e->P, e->S);
         }
     }
     HIPCHK(hipGetLastError());
@@ -473,8 +520,8 @@ int lob_handle_terminal(lob_engine* e) {
     HIPCHK(hipGetLastError());
     return LOB_OK;
 }
-int lob_set_alpha(lob_engine* e, double alpha) { if (!e) return LOB_EINVAL; e->P.alpha = alpha; e->params.alpha = alpha; return LOB_OK; }
-int lob_set_epsilon(lob_engine* e, double eps) { if (!e) return LOB_EINVAL; e->P.epsilon = eps; e->params.epsilon = eps; return LOB_OK; }
+int lob_set_alpha(lob_engine* e, double alpha) { if (!e) return LOB_EINVAL; e->P.alpha = alpha; e->params.alpha = alpha; hipSetDevice(e->device); return push_params(e); }
+int lob_set_epsilon(lob_engine* e, double eps) { if (!e) return LOB_EINVAL; e->P.epsilon = eps; e->params.epsilon = eps; hipSetDevice(e->device); return push_params(e); }
 
 static int features_impl(lob_engine* e, const float* host_vars, int32_t n, int32_t* out_idx, double* out_q) {
     if (!e || !host_vars || n < 1) { lob_set_error("lob_features: bad argument"); return LOB_EINVAL; }
@@ -516,28 +563,39 @@ int lob_theta_set(lob_engine* e, int32_t which, const double* host_in, int64_t c
     return LOB_OK;
 }
 
-#define COPY_FIELD(field, T)                                                                                   \
-    HIPCHK(hipSetDevice(e->device));                                                                           \
-    HIPCHK(hipMemcpyAsync(host_out, e->S.field, (size_t)e->B * sizeof(T), hipMemcpyDeviceToHost, e->stream));  \
-    HIPCHK(hipStreamSynchronize(e->stream));                                                                   \
+static int fetch_hdr(lob_engine* e, std::vector<LHdr>& h) {
+    h.resize(e->B);
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemcpyAsync(h.data(), e->S.hdr, (size_t)e->B * sizeof(LHdr), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
     return LOB_OK;
-int lob_get_last_actions(lob_engine* e, int32_t* host_out) { if (!e || !host_out) return LOB_EINVAL; COPY_FIELD(action, i32) }
-int lob_get_last_td(lob_engine* e, double* host_out) { if (!e || !host_out) return LOB_EINVAL; COPY_FIELD(td, f64) }
-int lob_get_last_rewards(lob_engine* e, double* host_out) { if (!e || !host_out) return LOB_EINVAL; COPY_FIELD(reward, f64) }
-int lob_get_stepped(lob_engine* e, int32_t* host_out) { if (!e || !host_out) return LOB_EINVAL; COPY_FIELD(stepped, i32) }
-int lob_get_rng_counters(lob_engine* e, uint64_t* host_out) { if (!e || !host_out) return LOB_EINVAL; COPY_FIELD(rng_ctr, u64) }
+}
+#define HDR_GETTER(name, T, field)                                   \
+    int name(lob_engine* e, T* host_out) {                           \
+        if (!e || !host_out) return LOB_EINVAL;                      \
+        std::vector<LHdr> h;                                         \
+        int rc = fetch_hdr(e, h);                                    \
+        if (rc) return rc;                                           \
+        for (int b = 0; b < e->B; b++) host_out[b] = (T)h[b].field;  \
+        return LOB_OK;                                               \
+    }
+HDR_GETTER(lob_get_last_actions, int32_t, action)
+HDR_GETTER(lob_get_last_td, double, td)
+HDR_GETTER(lob_get_last_rewards, double, reward)
+HDR_GETTER(lob_get_stepped, int32_t, stepped)
+HDR_GETTER(lob_get_rng_counters, uint64_t, rng_ctr)
 
 /* current `state` variables of the learner (the rl::State the last step produced): float[B][n_vars] */
 int lob_get_learner_state(lob_engine* e, float* host_out) {
     if (!e || !host_out) return LOB_EINVAL;
-    HIPCHK(hipSetDevice(e->device));
+    std::vector<LHdr> h;
+    int rc = fetch_hdr(e, h);
+    if (rc) return rc;
     std::vector<f32> v((size_t)e->B * 48);
-    std::vector<i32> cur(e->B);
     HIPCHK(hipMemcpyAsync(v.data(), e->S.vars, v.size() * 4, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(cur.data(), e->S.slot_cur, (size_t)e->B * 4, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     for (int b = 0; b < e->B; b++)
-        for (int i = 0; i < e->P.V; i++) host_out[(size_t)b * e->P.V + i] = v[((size_t)b * 3 + cur[b]) * 16 + i];
+        for (int i = 0; i < e->P.V; i++) host_out[(size_t)b * e->P.V + i] = v[((size_t)b * 3 + h[b].slot_cur) * 16 + i];
     return LOB_OK;
 }
 
@@ -549,9 +607,11 @@ int lob_get_traces(lob_engine* e, int32_t book, int32_t* idx, float* elig, int32
     i32 head = 0, ng = 0;
     HIPCHK(hipMemcpyAsync(ti.data(), e->S.tr_idx + (size_t)book * LOB_TRACE_GENS * 32, ti.size() * 4, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipMemcpyAsync(al.data(), e->S.tr_alive + (size_t)book * LOB_TRACE_GENS, al.size() * 4, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(&head, e->S.tr_head + book, 4, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(&ng, e->S.tr_n + book, 4, hipMemcpyDeviceToHost, e->stream));
+    LHdr hb;
+    HIPCHK(hipMemcpyAsync(&hb, e->S.hdr + book, sizeof hb, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    head = hb.tr_head;
+    ng = hb.tr_n;
     int k = 0;
     for (int age = 0; age < ng; age++) {
         int slot = (head - age + 2 * LOB_TRACE_GENS) % LOB_TRACE_GENS;

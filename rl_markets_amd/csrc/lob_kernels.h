@@ -26,6 +26,19 @@ __device__ inline TickView P_tick(const DevParams& P) { return TickView{P.n_band
 #include "lob_env.h"
 #include "lob_learn.h"
 
+// The per-book environment registers of the lane-per-book kernels live in LDS
+// (one padded slot per lane) instead of VGPRs: the fully inlined event loop
+// otherwise spills ~1 KB per lane to scratch, and every spill reload is a
+// vector-memory round trip on the critical path of a latency-bound kernel.
+// Slot stride = sizeof(EnvR) rounded up to an odd multiple of 8 bytes, so a
+// wave's 64-bit accesses to one field are at most 2-way bank conflicted.
+struct EnvSlot {
+    EnvR e;
+    char pad[((sizeof(EnvR) / 8) % 2 == 0) ? 8 : 16];
+};
+static_assert(sizeof(EnvSlot) % 8 == 0 && (sizeof(EnvSlot) / 8) % 2 == 1, "odd 8-byte stride");
+static_assert(sizeof(EnvSlot) * 256 <= 160 * 1024, "one 256-lane block per CU must fit in LDS");
+
 #define LOB_WAVES_PER_BLOCK 4
 #define LOB_BLOCK (64 * LOB_WAVES_PER_BLOCK)
 
@@ -49,11 +62,13 @@ __global__ void gen_events_kernel(lob_gen_params g, int D, int T, u64 first_book
 // Base::Initialise + Intraday::Initialise (base.cpp:123-135, intraday.cpp:103-138)
 // followed by the Runner prologue `last_state->newState(environment)`
 // (serial.cpp:25).  Lane per book.
-__global__ void __launch_bounds__(256) reset_kernel(DevParams P, DevState S) {
+__global__ void __launch_bounds__(256, 1) reset_kernel(const DevParams* __restrict__ Pp, DevState S) {
+    const DevParams& P = *Pp;  // parameters read through the scalar cache, never copied to scratch
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= S.B) return;
     EnvCtx c(P, S, b);
-    EnvR e;
+    __shared__ EnvSlot lds_env[256];
+    EnvR& e = lds_env[threadIdx.x].e;
     env_load(S, b, e);  // position, pnl_step, levels of quotes etc. persist across episodes
     const i64 ev0 = e.events;
     for (int sel = 0; sel < 2; sel++)
@@ -87,24 +102,28 @@ __global__ void __launch_bounds__(256) reset_kernel(DevParams P, DevState S) {
         place_orders(c, e, 1, 1);
         // last_state->newState(env).  Slot 2 always mirrors the latest getState():
         // Backtester::_step extracts the state itself before acting (serial.cpp:124-137).
-        const int last = S.slot_cur[b] ^ 1;
+        LHdr& h = S.hdr[b];
+        const int last = h.slot_cur ^ 1;
         f32* v = S.vars + ((size_t)b * 3 + last) * 16;
         f32* vf = S.vars + ((size_t)b * 3 + 2) * 16;
         for (int i = 0; i < P.V; i++) {
             v[i] = (f32)get_variable(c, e, P.vars[i]);
             vf[i] = v[i];
         }
-        if (last == 0) S.zero0[b] = 0; else S.zero1[b] = 0;
+        h.zero_mask &= ~(1 << last);
     } else {
         e.done = 2;
     }
-    S.stepped[b] = 0;
+    S.hdr[b].stepped = 0;
+    S.hdr[b].done = e.done;
+    S.hdr[b].time_ms = e.time_ms;
     env_store(S, b, e);
     atomicAdd((u64*)&S.counters[1], (u64)(e.events - ev0));  // warm-up events count as consumed
 }
 
 // Evaluate getState() for every book (lob_get_state): lane per book.
-__global__ void __launch_bounds__(256) get_state_kernel(DevParams P, DevState S, f32* out /*[B][V]*/, f64* reward /*[B] or null*/) {
+__global__ void __launch_bounds__(256) get_state_kernel(const DevParams* __restrict__ Pp, DevState S, f32* out /*[B][V]*/, f64* reward /*[B] or null*/) {
+    const DevParams& P = *Pp;  // parameters read through the scalar cache, never copied to scratch
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= S.B) return;
     EnvCtx c(P, S, b);
@@ -119,46 +138,52 @@ __global__ void __launch_bounds__(256) get_state_kernel(DevParams P, DevState S,
 // performAction for every book that has an action pending (S.stepped).
 // mode 0: learner step (new vars go to `state` = slot_cur); mode 1: host
 // supplied actions (lob_step).
-__global__ void __launch_bounds__(256) env_kernel(DevParams P, DevState S, const i32* host_actions, int count_updates) {
-    int b = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(256, 1) env_kernel(const DevParams* __restrict__ Pp, DevState S, const i32* host_actions, int count_updates, int b0, int nb) {
+    const DevParams& P = *Pp;  // parameters read through the scalar cache, never copied to scratch
+    __shared__ EnvSlot lds_env[256];
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = b0 + t;
     i64 d_steps = 0, d_events = 0;
-    if (b < S.B) {
+    if (t < nb) {
+        LHdr& h = S.hdr[b];
         bool go;
         int action;
         if (host_actions) {
             go = S.done[b] != 2;
             action = host_actions[b];
-            S.action[b] = action;
+            h.action = action;
         } else {
-            go = S.stepped[b] != 0;
-            action = S.action[b];
+            go = h.stepped != 0;
+            action = h.action;
         }
         if (go) {
             EnvCtx c(P, S, b);
-            EnvR e;
+            EnvR& e = lds_env[threadIdx.x].e;
             env_load(S, b, e);
             env_load_best(c, e);
             i64 ev0 = e.events;
             bool ok = perform_action(c, e, action);
             d_events = e.events - ev0;
             if (ok) {
-                const int cur = S.slot_cur[b];
+                const int cur = h.slot_cur;
                 f32* v = S.vars + ((size_t)b * 3 + cur) * 16;
                 f32* vf = S.vars + ((size_t)b * 3 + 2) * 16;
                 for (int i = 0; i < P.V; i++) {
                     v[i] = (f32)get_variable(c, e, P.vars[i]);
                     vf[i] = v[i];
                 }
-                if (cur == 0) S.zero0[b] = 0; else S.zero1[b] = 0;
-                S.reward[b] = get_reward(c, e);
-                S.stepped[b] = 1;
+                h.zero_mask &= ~(1 << cur);
+                h.reward = get_reward(c, e);
+                h.stepped = 1;
                 d_steps = 1;
             } else {
-                S.stepped[b] = 0;
+                h.stepped = 0;
             }
+            h.done = e.done;
+            h.time_ms = e.time_ms;
             env_store(S, b, e);
         } else {
-            S.stepped[b] = 0;
+            h.stepped = 0;
         }
     }
     // one atomic per wave for the counters
@@ -174,7 +199,8 @@ __global__ void __launch_bounds__(256) env_kernel(DevParams P, DevState S, const
 }
 
 // Base::ClearInventory for every book (Runner::RunEpisode epilogue, serial.cpp:31)
-__global__ void __launch_bounds__(256) clear_inventory_kernel(DevParams P, DevState S) {
+__global__ void __launch_bounds__(256) clear_inventory_kernel(const DevParams* __restrict__ Pp, DevState S) {
+    const DevParams& P = *Pp;  // parameters read through the scalar cache, never copied to scratch
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= S.B) return;
     EnvCtx c(P, S, b);
@@ -189,57 +215,63 @@ __global__ void __launch_bounds__(256) clear_inventory_kernel(DevParams P, DevSt
 // Shared LDS image of a learner block.
 struct LearnLds {
     uint32_t rnd[2048];                                   // hash_UNH table
-    u64 act_terms[3 * LOB_N_ACTIONS];                     // trailing-coordinate terms, per group/action
+    u64 act_terms[32];                                    // trailing-coordinate terms [group][action] (27 used)
     f64 vals[LOB_WAVES_PER_BLOCK][LOB_N_ACTIONS * LOB_QSTRIDE];  // gathered theta / hash set (aliased)
-    f32 vars[LOB_WAVES_PER_BLOCK][2][16];
+    f32 vars[LOB_WAVES_PER_BLOCK][3][16];
 };
 
-__device__ inline void learn_lds_init(const DevParams& P, const uint32_t* __restrict__ rnd_g, LearnLds& L) {
-    for (int i = threadIdx.x; i < 2048; i += blockDim.x) L.rnd[i] = rnd_g[i];
-    __syncthreads();
-    if (threadIdx.x < 3 * LOB_N_ACTIONS) {
-        const int g = threadIdx.x / LOB_N_ACTIONS, a = threadIdx.x % LOB_N_ACTIONS;
-        const int nf = g == 0 ? 3 : (g == 1 ? P.V - 3 : P.V);
-        L.act_terms[threadIdx.x] = tile_action_term(nf, g * LOB_N_ACTIONS + a, L.rnd);
-    }
+// Stage the hash table (8 KB, two 16-byte loads per thread), the 27 action terms
+// and this wave's three state-variable slots; ONE barrier.
+__device__ inline void learn_lds_init(const uint32_t* __restrict__ rnd_g, const f32* __restrict__ vars_b, bool have_book,
+                                      LearnLds& L) {
+    const uint4* src = reinterpret_cast<const uint4*>(rnd_g);
+    uint4* dst = reinterpret_cast<uint4*>(L.rnd);
+    const uint4 r0 = src[threadIdx.x], r1 = src[threadIdx.x + LOB_BLOCK];
+    f32 vv = 0.0f;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (have_book && lane < 48) vv = vars_b[lane];
+    dst[threadIdx.x] = r0;
+    dst[threadIdx.x + LOB_BLOCK] = r1;
+    if (threadIdx.x < 27) L.act_terms[threadIdx.x] = reinterpret_cast<const u64*>(rnd_g + 2048)[threadIdx.x];
+    if (lane < 48) (&L.vars[w][0][0])[lane] = vv;
     __syncthreads();
 }
 
 // mode 0: Learner::_step prologue (swap, terminal check, epsilon-greedy action)
 // mode 1: Backtester::_step prologue (no swap, greedy action on the current state)
 __global__ void __launch_bounds__(LOB_BLOCK) act_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g,
-                                                        int mode) {
+                                                        int mode, int b0, int nb) {
     __shared__ LearnLds L;
-    learn_lds_init(P, rnd_g, L);
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int b = blockIdx.x * LOB_WAVES_PER_BLOCK + w;
-    if (b >= S.B) return;
-    if (S.done[b]) { if (lane == 0) S.stepped[b] = 0; return; }
-    int cur = S.slot_cur[b];
-    if (mode == 0) {
-        cur ^= 1;  // swap(state, last_state)
-        if (lane == 0) S.slot_cur[b] = cur;
-    }
-    if (!is_open(P, S.time_ms[b])) {  // environment.isTerminal()
-        if (lane == 0) { S.done[b] = 1; S.stepped[b] = 0; }
+    const int t = __builtin_amdgcn_readfirstlane(blockIdx.x * LOB_WAVES_PER_BLOCK + w);
+    const int b = b0 + t;
+    const bool have = t < nb;
+    const int bb = have ? b : 0;
+    const LHdr h = S.hdr[bb];  // one scalar 64-byte load, issued before the LDS staging
+    learn_lds_init(rnd_g, S.vars + (size_t)bb * 48, have, L);
+    if (!have) return;
+    LHdr* hp = S.hdr + b;
+    if (h.done) { if (lane == 0) hp->stepped = 0; return; }
+    int cur = h.slot_cur;
+    if (mode == 0) cur ^= 1;  // swap(state, last_state)
+    if (!is_open(P, h.time_ms)) {  // environment.isTerminal()
+        if (lane == 0) { hp->slot_cur = cur; hp->done = 1; hp->stepped = 0; S.done[b] = 1; }
         return;
     }
-    // the State the action is computed from: last_state (learner) / state (backtester)
+    // the State the action is computed from: last_state (learner) / latest getState() (backtester)
     const int src = mode == 0 ? (cur ^ 1) : 2;
-    const bool zero = mode == 0 && (src == 0 ? S.zero0[b] : S.zero1[b]) != 0;
-    if (lane < 16) L.vars[w][0][lane] = S.vars[((size_t)b * 3 + src) * 16 + lane];
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
+    const bool zero = mode == 0 && ((h.zero_mask >> src) & 1);
     const f64* theta = S.theta + (P.theta_private ? (size_t)b * (size_t)P.M : 0);
     f64 qs[LOB_N_ACTIONS];
-    q_values(P, theta, L.vars[w][0], zero, L.rnd, L.act_terms, L.vals[w], lane, qs);
-    Rng g{P.seed, P.book_id_offset + (u64)b, S.rng_ctr[b]};
+    q_values(P, theta, L.vars[w][src], zero, L.rnd, L.act_terms, L.vals[w], lane, qs);
+    Rng g{P.seed, P.book_id_offset + (u64)b, h.rng_ctr};
     const int action = policy_sample(qs, P.epsilon, mode == 1, g);
     if (lane < LOB_N_ACTIONS) S.qs_last[(size_t)b * LOB_N_ACTIONS + lane] = qs[lane];
     if (lane == 0) {
-        S.action[b] = action;
-        S.stepped[b] = 1;
-        S.rng_ctr[b] = g.ctr;
+        hp->slot_cur = cur;
+        hp->action = action;
+        hp->stepped = 1;
+        hp->rng_ctr = g.ctr;
     }
 }
 
@@ -254,31 +286,34 @@ __device__ inline i32 sel5(const i32* f, int k) {
 
 // Agent::HandleTransition up to (not including) updateQ: UpdateTraces +
 // the TD error of UpdateWeights (agent.cpp:86-115, 268-311).
-__global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g) {
+__global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g,
+                                                          int b0, int nb) {
     __shared__ LearnLds L;
-    learn_lds_init(P, rnd_g, L);
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int b = blockIdx.x * LOB_WAVES_PER_BLOCK + w;
-    if (b >= S.B) return;
-    if (!S.stepped[b]) return;
-    const int cur = S.slot_cur[b], last = cur ^ 1;
-    const bool zero_last = (last == 0 ? S.zero0[b] : S.zero1[b]) != 0;
-    if (lane < 16) L.vars[w][0][lane] = S.vars[((size_t)b * 3 + cur) * 16 + lane];         // state (to)
-    else if (lane < 32) L.vars[w][1][lane - 16] = S.vars[((size_t)b * 3 + last) * 16 + lane - 16];  // last_state (from)
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-
-    const int action = S.action[b];
+    const int t = __builtin_amdgcn_readfirstlane(blockIdx.x * LOB_WAVES_PER_BLOCK + w);
+    const int b = b0 + t;
+    const bool have = t < nb;
+    const int bb = have ? b : 0;
+    const LHdr h = S.hdr[bb];
     f64 qs_last[LOB_N_ACTIONS];
 #pragma unroll
-    for (int a = 0; a < LOB_N_ACTIONS; a++) qs_last[a] = S.qs_last[(size_t)b * LOB_N_ACTIONS + a];
-    Rng g{P.seed, P.book_id_offset + (u64)b, S.rng_ctr[b]};
+    for (int a = 0; a < LOB_N_ACTIONS; a++) qs_last[a] = S.qs_last[(size_t)bb * LOB_N_ACTIONS + a];
+    learn_lds_init(rnd_g, S.vars + (size_t)bb * 48, have, L);
+    if (!have) return;
+    if (!h.stepped) return;
+    LHdr* hp = S.hdr + b;
+    const int cur = h.slot_cur, last = cur ^ 1;
+    const bool zero_last = (h.zero_mask >> last) & 1;
+    const f32* vars_to = L.vars[w][cur];
+    const f32* vars_from = L.vars[w][last];
+    const int action = h.action;
+    Rng g{P.seed, P.book_id_offset + (u64)b, h.rng_ctr};
 
     // ---- group-0 tiles of last_state for all nine actions: lane -> (a = half + 2k, j) ----
     const int j = lane & 31, half = lane >> 5;
     i32 F[5];
     {
-        u64 base = zero_last ? 0 : tile_base(L.vars[w][1], 3, j, L.rnd);
+        u64 base = zero_last ? 0 : tile_base(vars_from, 3, j, L.rnd);
 #pragma unroll
         for (int k = 0; k < 5; k++) {
             const int a = half + 2 * k;
@@ -287,8 +322,8 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
     }
 
     // ---- Traces::decay (traces.cpp:30-38) ----
-    int n_old = S.tr_n[b];
-    const int head = S.tr_head[b];
+    int n_old = h.tr_n;
+    const int head = h.tr_head;
     int kmax = P.trace_kmax;
     if (P.algo == LOB_ALGO_QLAMBDA) {
         const int amax = argmax_ties(qs_last, g);  // QLearn::UpdateTraces (agent.cpp:272-280)
@@ -369,8 +404,8 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
         if (half == 0) tr_idx[nh * 32 + j] = N;
         if (lane == 0) {
             tr_alive[nh] = (uint32_t)m;
-            S.tr_head[b] = nh;
-            S.tr_n[b] = n_old + 1;
+            hp->tr_head = nh;
+            hp->tr_n = n_old + 1;
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -379,8 +414,8 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
     // ---- UpdateWeights: TD error under theta_t ----
     const f64* theta = S.theta + (P.theta_private ? (size_t)b * (size_t)P.M : 0);
     f64 qs_to[LOB_N_ACTIONS];
-    q_values(P, theta, L.vars[w][0], false, L.rnd, L.act_terms, L.vals[w], lane, qs_to);
-    const f64 reward = S.reward[b];
+    q_values(P, theta, vars_to, false, L.rnd, L.act_terms, L.vals[w], lane, qs_to);
+    const f64 reward = h.reward;
     const f64 Q1 = qs_last[0 * 0 + (action < LOB_N_ACTIONS ? action : 0)];
     f64 delta;
     const f64 F_term = P.gamma * 0.0 - 0.0;  // potentials are identically 0 (base.cpp:239-242)
@@ -392,20 +427,21 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
         delta = reward + F_term + P.gamma * qs_to[a2] - Q1;
     }
     if (lane == 0) {
-        S.td[b] = delta;
-        S.upd[b] = P.alpha * delta;
-        S.rng_ctr[b] = g.ctr;
+        hp->td = delta;
+        hp->upd = P.alpha * delta;
+        hp->rng_ctr = g.ctr;
     }
 }
 
 // Agent::updateQ (agent.cpp:137-142): theta[f] += (alpha*delta / N_TILINGS) * e[f]
 __global__ void __launch_bounds__(LOB_BLOCK) update_kernel(DevParams P, DevState S) {
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int b = blockIdx.x * LOB_WAVES_PER_BLOCK + w;
+    const int b = __builtin_amdgcn_readfirstlane(blockIdx.x * LOB_WAVES_PER_BLOCK + w);
     if (b >= S.B) return;
-    if (!S.stepped[b]) return;
-    const int n = S.tr_n[b], head = S.tr_head[b];
-    const f64 scaled = S.upd[b] / (f64)LOB_N_TILINGS;
+    const LHdr h = S.hdr[b];
+    if (!h.stepped) return;
+    const int n = h.tr_n, head = h.tr_head;
+    const f64 scaled = h.upd / (f64)LOB_N_TILINGS;
     f64* theta = S.theta + (P.theta_private ? (size_t)b * (size_t)P.M : 0);
     const i32* tr_idx = S.tr_idx + (size_t)b * LOB_TRACE_GENS * 32;
     const uint32_t* tr_alive = S.tr_alive + (size_t)b * LOB_TRACE_GENS;
@@ -426,7 +462,7 @@ __global__ void __launch_bounds__(LOB_BLOCK) update_kernel(DevParams P, DevState
 // Agent::HandleTerminal: traces.decay(0.0) (agent.cpp:103-109)
 __global__ void clear_traces_kernel(DevState S) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < S.B) S.tr_n[b] = 0;
+    if (b < S.B) S.hdr[b].tr_n = 0;
 }
 
 // State::newState(vector<float>&) + getFeatures / Agent::getQ for n free-standing
@@ -435,9 +471,9 @@ __global__ void __launch_bounds__(LOB_BLOCK) features_kernel(DevParams P, const 
                                                              const uint32_t* __restrict__ rnd_g, const f32* vars,
                                                              int n, i32* out_idx, f64* out_q) {
     __shared__ LearnLds L;
-    learn_lds_init(P, rnd_g, L);
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int s = blockIdx.x * LOB_WAVES_PER_BLOCK + w;
+    learn_lds_init(rnd_g, (const f32*)nullptr, false, L);
     if (s >= n) return;
     if (lane < 16) L.vars[w][0][lane] = lane < P.V ? vars[(size_t)s * P.V + lane] : 0.0f;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -476,7 +512,8 @@ __global__ void delta_apply_kernel(f64* theta, f64* sync, const f64* __restrict_
 }
 
 // ---- parity dump -------------------------------------------------------------
-__global__ void dump_kernel(DevParams P, DevState S, int first, int n, lob_book_dump* out) {
+__global__ void dump_kernel(const DevParams* __restrict__ Pp, DevState S, int first, int n, lob_book_dump* out) {
+    const DevParams& P = *Pp;  // parameters read through the scalar cache, never copied to scratch
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const int b = first + t;
@@ -522,7 +559,7 @@ __global__ void dump_kernel(DevParams P, DevState S, int first, int n, lob_book_
     d.total_ticks = e.total_ticks;
     int n_tr = 0;
     {
-        const int ng = S.tr_n[b], head = S.tr_head[b];
+        const int ng = S.hdr[b].tr_n, head = S.hdr[b].tr_head;
         for (int k = 0; k < ng; k++) {
             const int slot = (head - k + 2 * LOB_TRACE_GENS) % LOB_TRACE_GENS;
             n_tr += __popc(S.tr_alive[(size_t)b * LOB_TRACE_GENS + slot]);

@@ -67,19 +67,23 @@ typedef float f32;
     X(i64, b_tv) X(i64, b_ltv) X(i32, b_ntr) X(f64, b_obsval) X(i64, b_obsvol)                                 \
     X(i32, b_on) X(f64, b_opx) X(i64, b_osz) X(i64, b_oqh) X(i64, b_oqt) X(i64, b_oex) X(i64, b_oiq)
 
-// Per-book scalars of the learner (Runner / Agent / Traces).
-#define LOB_LEARN_FIELDS(X)                                                      \
-    X(u64, rng_ctr)   /* draws consumed from this book's policy stream */        \
-    X(i32, action)    /* action chosen in the current step */                    \
-    X(i32, stepped)   /* 1 if performAction succeeded in the current step */     \
-    X(f64, reward)    /* getReward() after performAction */                      \
-    X(f64, td)        /* last TD error */                                        \
-    X(f64, upd)       /* alpha * delta to scatter */                             \
-    X(i32, slot_cur)  /* which of the two rl::State objects is `state` */        \
-    X(i32, zero0)     /* State object 0 still holds its ctor zeros */            \
-    X(i32, zero1)                                                                \
-    X(i32, tr_head)   /* ring slot of the newest trace generation */             \
-    X(i32, tr_n)      /* live generations */
+// Per-book learner header (Runner / Agent / Traces scalars), one 64-byte
+// record per book: the wave-per-book kernels fetch it with a single scalar
+// load (s_load_dwordx16) instead of a chain of dependent per-field loads.
+struct __attribute__((aligned(64))) LHdr {
+    i32 done;       // copy of the env's done flag (0 live, 1 isTerminal(), 2 out of data)
+    i32 time_ms;    // copy of Market::time_ (isTerminal() test of Learner::_step)
+    i32 slot_cur;   // which of the two rl::State objects is `state`
+    i32 zero_mask;  // bit s: State object s still holds its constructor zeros
+    i32 action;     // action chosen in the current step
+    i32 stepped;    // act: an action is pending; env: performAction succeeded
+    i32 tr_head;    // ring slot of the newest trace generation
+    i32 tr_n;       // live generations
+    u64 rng_ctr;    // draws consumed from this book's policy stream
+    f64 reward;     // getReward() after performAction
+    f64 td;         // last TD error
+    f64 upd;        // alpha * delta to scatter
+};
 
 struct RMPtrs {  // RollingMean<double>
     f64* ring;   // [w][B]
@@ -106,7 +110,6 @@ struct DevState {
 
 #define X(t, n) t* n;
     LOB_ENV_FIELDS(X)
-    LOB_LEARN_FIELDS(X)
 #undef X
 #define X(n) RMPtrs n;
     LOB_ROLLING_MEANS(X)
@@ -118,6 +121,7 @@ struct DevState {
     f32* px;   // [2 sel][2 side][D][B]
     i32* vol;  // [2 sel][2 side][D][B]
 
+    LHdr* hdr;      // [B]
     f32* vars;      // [B][3][16]  the two rl::State objects' state_vars + the latest getState()
     f64* qs_last;   // [B][9] Q(last_state, .) of the current step
     i32* tr_idx;    // [B][LOB_TRACE_GENS][32]
