@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -37,7 +38,7 @@ struct lob_engine {
     DevState S;
     hipStream_t stream = nullptr;   // main stream (all API calls)
     hipStream_t stream2 = nullptr;  // second book group of the step pipeline
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_stagger = nullptr;
     int n_groups = 1;
     std::vector<void*> allocs;
     uint32_t* rnd_dev = nullptr;
@@ -191,8 +192,10 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     HIPCHK(hipStreamCreate(&e->stream2));
     HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming | hipEventDisableSystemFence));
     HIPCHK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming | hipEventDisableSystemFence));
+    HIPCHK(hipEventCreateWithFlags(&e->ev_stagger, hipEventDisableTiming | hipEventDisableSystemFence));
     // two book groups pipelined on two streams hide the latency-bound env kernel behind the gather kernels
     e->n_groups = n_books >= 4096 ? 2 : 1;
+    if (const char* g = getenv("LOB_GROUPS")) { int v = atoi(g); if (v >= 1 && v <= 2) e->n_groups = v; }
 
     // ---- DevParams ----
     DevParams& P = e->P;
@@ -270,6 +273,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     if (rc == LOB_OK) rc = dev_alloc(e, &S.tr_idx, B * LOB_TRACE_GENS * 32);
     if (rc == LOB_OK) rc = dev_alloc(e, &S.tr_alive, B * LOB_TRACE_GENS);
     if (rc == LOB_OK) rc = dev_alloc(e, &S.theta, (size_t)P.M * (P.theta_private ? B : 1));
+    if (rc == LOB_OK) rc = dev_alloc(e, &S.theta_nz, (size_t)((P.M + 31) >> 5) * (P.theta_private ? B : 1));
     if (rc == LOB_OK) rc = dev_alloc(e, &S.counters, 8);
     if (rc == LOB_OK) rc = dev_alloc(e, &S.error_flag, 1);
     if (rc == LOB_OK) rc = dev_alloc(e, &e->rnd_dev, 2048 + 64);
@@ -309,6 +313,7 @@ void lob_destroy(lob_engine* e) {
     drain_timers(e);
     if (e->ev_fork) hipEventDestroy(e->ev_fork);
     if (e->ev_join) hipEventDestroy(e->ev_join);
+    if (e->ev_stagger) hipEventDestroy(e->ev_stagger);
     if (e->stream2) hipStreamDestroy(e->stream2);
     for (auto ev : e->event_pool) hipEventDestroy(ev);
     for (void* p : e->allocs) hipFree(p);
@@ -474,10 +479,14 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode) {
             hipStream_t st = g == 0 ? e->stream : e->stream2;
             const int b0 = (int)((long long)e->B * g / G), nb = (int)((long long)e->B * (g + 1) / G) - b0;
             const int gw = grid_waves(nb), gl = grid_lanes(nb);
+            // stagger: group 1 starts acting when group 0 has finished acting, so that the
+            // latency-bound env kernel of one group runs beside a gather kernel of the other
+            if (G > 1 && g == 1) HIPCHK(hipStreamWaitEvent(st, e->ev_stagger, 0));
             {
                 TimedLaunch t(e, "act_kernel", st);
                 hipLaunchKernelGGL(act_kernel, dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, mode, b0, nb);
             }
+            if (G > 1 && g == 0) HIPCHK(hipEventRecord(e->ev_stagger, st));
             {
                 TimedLaunch t(e, "env_kernel", st);
                 hipLaunchKernelGGL(env_kernel, dim3(gl), dim3(256), 0, st, (const DevParams*)e->P_dev, e->S, (const i32*)nullptr, mode == 0 ? 1 : 0, b0, nb);
@@ -532,7 +541,7 @@ static int features_impl(lob_engine* e, const float* host_vars, int32_t n, int32
     if (out_q) HIPCHK(hipMalloc((void**)&dq, (size_t)n * LOB_N_ACTIONS * 8));
     HIPCHK(hipMemcpyAsync(dv, host_vars, (size_t)n * e->P.V * 4, hipMemcpyHostToDevice, e->stream));
     hipLaunchKernelGGL(features_kernel, dim3(grid_waves(n)), dim3(LOB_BLOCK), 0, e->stream, e->P, (const f64*)e->S.theta,
-                       (const uint32_t*)e->rnd_dev, (const f32*)dv, n, di, dq);
+                       (const uint32_t*)e->S.theta_nz, (const uint32_t*)e->rnd_dev, (const f32*)dv, n, di, dq);
     hipError_t err = hipGetLastError();
     if (err == hipSuccess && out_idx) err = hipMemcpyAsync(out_idx, di, (size_t)n * LOB_N_ACTIONS * 96 * 4, hipMemcpyDeviceToHost, e->stream);
     if (err == hipSuccess && out_q) err = hipMemcpyAsync(out_q, dq, (size_t)n * LOB_N_ACTIONS * 8, hipMemcpyDeviceToHost, e->stream);
@@ -559,6 +568,9 @@ int lob_theta_set(lob_engine* e, int32_t which, const double* host_in, int64_t c
     if (which < 0 || which >= (e->P.theta_private ? e->B : 1)) return LOB_EINVAL;
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipMemcpyAsync(e->S.theta + (size_t)which * e->P.M, host_in, (size_t)count * 8, hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(rebuild_nz_kernel, dim3(1024), dim3(256), 0, e->stream, (const f64*)(e->S.theta + (size_t)which * e->P.M),
+                       e->S.theta_nz + (size_t)which * (size_t)((e->P.M + 31) >> 5), e->P.M);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(e->stream));
     return LOB_OK;
 }
@@ -674,7 +686,7 @@ int lob_delta_apply(lob_engine* e) {
     HIPCHK(hipSetDevice(e->device));
     {
         TimedLaunch t(e, "delta_apply_kernel");
-        hipLaunchKernelGGL(delta_apply_kernel, dim3(2048), dim3(256), 0, e->stream, e->S.theta, e->S.theta_sync, (const f64*)e->S.delta, e->P.M);
+        hipLaunchKernelGGL(delta_apply_kernel, dim3(2048), dim3(256), 0, e->stream, e->S.theta, e->S.theta_sync, (const f64*)e->S.delta, e->S.theta_nz, e->P.M);
     }
     HIPCHK(hipGetLastError());
     return LOB_OK;

@@ -263,7 +263,8 @@ __global__ void __launch_bounds__(LOB_BLOCK) act_kernel(DevParams P, DevState S,
     const bool zero = mode == 0 && ((h.zero_mask >> src) & 1);
     const f64* theta = S.theta + (P.theta_private ? (size_t)b * (size_t)P.M : 0);
     f64 qs[LOB_N_ACTIONS];
-    q_values(P, theta, L.vars[w][src], zero, L.rnd, L.act_terms, L.vals[w], lane, qs);
+    const uint32_t* nz = S.theta_nz + (P.theta_private ? (size_t)b * (size_t)((P.M + 31) >> 5) : 0);
+    q_values(P, theta, nz, L.vars[w][src], zero, L.rnd, L.act_terms, L.vals[w], lane, qs);
     Rng g{P.seed, P.book_id_offset + (u64)b, h.rng_ctr};
     const int action = policy_sample(qs, P.epsilon, mode == 1, g);
     if (lane < LOB_N_ACTIONS) S.qs_last[(size_t)b * LOB_N_ACTIONS + lane] = qs[lane];
@@ -414,7 +415,8 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
     // ---- UpdateWeights: TD error under theta_t ----
     const f64* theta = S.theta + (P.theta_private ? (size_t)b * (size_t)P.M : 0);
     f64 qs_to[LOB_N_ACTIONS];
-    q_values(P, theta, vars_to, false, L.rnd, L.act_terms, L.vals[w], lane, qs_to);
+    const uint32_t* nz = S.theta_nz + (P.theta_private ? (size_t)b * (size_t)((P.M + 31) >> 5) : 0);
+    q_values(P, theta, nz, vars_to, false, L.rnd, L.act_terms, L.vals[w], lane, qs_to);
     const f64 reward = h.reward;
     const f64 Q1 = qs_last[0 * 0 + (action < LOB_N_ACTIONS ? action : 0)];
     f64 delta;
@@ -443,6 +445,7 @@ __global__ void __launch_bounds__(LOB_BLOCK) update_kernel(DevParams P, DevState
     const int n = h.tr_n, head = h.tr_head;
     const f64 scaled = h.upd / (f64)LOB_N_TILINGS;
     f64* theta = S.theta + (P.theta_private ? (size_t)b * (size_t)P.M : 0);
+    uint32_t* nz = S.theta_nz + (P.theta_private ? (size_t)b * (size_t)((P.M + 31) >> 5) : 0);
     const i32* tr_idx = S.tr_idx + (size_t)b * LOB_TRACE_GENS * 32;
     const uint32_t* tr_alive = S.tr_alive + (size_t)b * LOB_TRACE_GENS;
     const int j = lane & 31, half = lane >> 5;
@@ -454,6 +457,8 @@ __global__ void __launch_bounds__(LOB_BLOCK) update_kernel(DevParams P, DevState
                 const i32 f = tr_idx[slot * 32 + j];
                 const f64 val = scaled * (f64)P.trace_pow[k];
                 __hip_atomic_fetch_add(&theta[f], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t bit = 1u << (f & 31);
+                if (!(nz[f >> 5] & bit)) atomicOr(&nz[f >> 5], bit);  // monotone: set once, then a plain L2 hit
             }
         }
     }
@@ -468,7 +473,7 @@ __global__ void clear_traces_kernel(DevState S) {
 // State::newState(vector<float>&) + getFeatures / Agent::getQ for n free-standing
 // states (lob_features / lob_q_values).  Wave per state.
 __global__ void __launch_bounds__(LOB_BLOCK) features_kernel(DevParams P, const f64* __restrict__ theta,
-                                                             const uint32_t* __restrict__ rnd_g, const f32* vars,
+                                                             const uint32_t* __restrict__ nz, const uint32_t* __restrict__ rnd_g, const f32* vars,
                                                              int n, i32* out_idx, f64* out_q) {
     __shared__ LearnLds L;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -490,7 +495,7 @@ __global__ void __launch_bounds__(LOB_BLOCK) features_kernel(DevParams P, const 
     }
     if (out_q) {
         f64 qs[LOB_N_ACTIONS];
-        q_values(P, theta, L.vars[w][0], false, L.rnd, L.act_terms, L.vals[w], lane, qs);
+        q_values(P, theta, nz, L.vars[w][0], false, L.rnd, L.act_terms, L.vals[w], lane, qs);
         if (lane < LOB_N_ACTIONS) out_q[(size_t)s * LOB_N_ACTIONS + lane] = qs[lane];
     }
 }
@@ -501,13 +506,32 @@ __global__ void delta_begin_kernel(const f64* __restrict__ theta, const f64* __r
     const i64 stride = (i64)gridDim.x * blockDim.x;
     for (; i < M; i += stride) delta[i] = theta[i] - sync[i];
 }
-__global__ void delta_apply_kernel(f64* theta, f64* sync, const f64* __restrict__ delta, i64 M) {
+__global__ void delta_apply_kernel(f64* theta, f64* sync, const f64* __restrict__ delta, uint32_t* nz, i64 M) {
     i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     const i64 stride = (i64)gridDim.x * blockDim.x;
     for (; i < M; i += stride) {
-        const f64 t = sync[i] + delta[i];
+        const f64 d = delta[i];
+        const f64 t = sync[i] + d;
         theta[i] = t;
         sync[i] = t;
+        if (d != 0.0) {  // written on some rank: from now on the weight must be fetched
+            const uint32_t bit = 1u << (i & 31);
+            if (!(nz[i >> 5] & bit)) atomicOr(&nz[i >> 5], bit);
+        }
+    }
+}
+// rebuild the bitmap after lob_theta_set: bit = (theta != +0.0 bitwise)
+__global__ void rebuild_nz_kernel(const f64* __restrict__ theta, uint32_t* nz, i64 M) {
+    i64 wi = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    const i64 words = (M + 31) >> 5;
+    for (; wi < words; wi += stride) {
+        uint32_t m = 0;
+        for (int k = 0; k < 32; k++) {
+            const i64 i = wi * 32 + k;
+            if (i < M && __double_as_longlong(theta[i]) != 0) m |= 1u << k;
+        }
+        nz[wi] = m;
     }
 }
 

@@ -99,7 +99,13 @@ __device__ inline int argmax_ties(const f64* qs, Rng& g) {
 // Gathers are issued for all 864 (action, tile) pairs before any is consumed;
 // the sum then follows the reference's sequential order term by term so that
 // Q is bitwise the value Agent::getQ computes (quirk Q3 included).
-__device__ inline void q_values(const DevParams& P, const f64* __restrict__ theta, const f32* vars, bool zero,
+// `nz` is the "ever written" bitmap of theta (lob_state.h): weights start at +0.0
+// and only group-0 tiles are ever updated (quirk Q4), so almost every group-1/2
+// gather would fetch a 64-byte sector from HBM to read a zero.  One bit per
+// weight (2.5 MB at M = 20 M: L2-resident) answers that without the fetch; the
+// value used is bit-identical either way.
+__device__ inline void q_values(const DevParams& P, const f64* __restrict__ theta, const uint32_t* __restrict__ nz,
+                                const f32* vars, bool zero,
                                 const uint32_t* rnd, const u64* act_terms /*[3][9] LDS*/, f64* vals, int lane,
                                 f64* out_q) {
     // 96 (group, tiling) pairs over 64 lanes: pair p = lane and lane + 64
@@ -109,16 +115,23 @@ __device__ inline void q_values(const DevParams& P, const f64* __restrict__ thet
         const f32* v = g == 1 ? vars + 3 : vars;
         u64 base = zero ? 0 : tile_base(v, nf, j, rnd);
         f64 t[LOB_N_ACTIONS];
+        i32 idx[LOB_N_ACTIONS];
+        uint32_t word[LOB_N_ACTIONS];
 #pragma unroll
         for (int a = 0; a < LOB_N_ACTIONS; a++) {
-            i32 idx = zero ? 0 : mod_m(base + act_terms[g * LOB_N_ACTIONS + a], P.M, P.inv_M);
-            t[a] = theta[idx];
+            idx[a] = zero ? 0 : mod_m(base + act_terms[g * LOB_N_ACTIONS + a], P.M, P.inv_M);
+            word[a] = nz[idx[a] >> 5];
+        }
+#pragma unroll
+        for (int a = 0; a < LOB_N_ACTIONS; a++) {
+            t[a] = 0.0;
+            if ((word[a] >> (idx[a] & 31)) & 1u) t[a] = theta[idx[a]];
         }
 #pragma unroll
         for (int a = 0; a < LOB_N_ACTIONS; a++) vals[a * LOB_QSTRIDE + p] = t[a];
     }
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): LDS writes of this wave have landed
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // LDS writes of this wave have landed
     f64 q = 0.0;
     if (lane < LOB_N_ACTIONS) {
         const f64* v = vals + lane * LOB_QSTRIDE;

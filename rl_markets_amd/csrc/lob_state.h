@@ -128,6 +128,7 @@ struct DevState {
     uint32_t* tr_alive;  // [B][LOB_TRACE_GENS]
 
     f64* theta;       // [M] or [B][M]
+    uint32_t* theta_nz;  // bitmap, bit i set once theta[i] has ever been written: clear bit => theta[i] == +0.0
     f64* theta_sync;  // [M] (multi-GPU) or null
     f64* delta;       // [M] scratch for the all-reduce or null
     i64* counters;    // [8] device counters
