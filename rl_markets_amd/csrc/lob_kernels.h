@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(256) clear_inventory_kernel(const DevParams* _
 struct LearnLds {
     uint32_t rnd[2048];                                   // hash_UNH table
     u64 act_terms[32];                                    // trailing-coordinate terms [group][action] (27 used)
-    f64 vals[LOB_WAVES_PER_BLOCK][LOB_N_ACTIONS * LOB_QSTRIDE];  // gathered theta / hash set (aliased)
+    f64 vals[LOB_WAVES_PER_BLOCK][LOB_HSLOTS / 2];  // 4 KB per wave: one group's gathered theta (9 x 33 f64) / trace hash set (aliased)
     f32 vars[LOB_WAVES_PER_BLOCK][3][16];
 };
 

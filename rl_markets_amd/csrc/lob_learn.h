@@ -13,7 +13,7 @@
 #include "lob_state.h"
 #include "lob_stream.h"
 
-#define LOB_QSTRIDE 97  // 96 features + 1 pad double: lanes a=0..8 read column i without bank conflicts
+#define LOB_QSTRIDE 33  // 32 tiles of one group + 1 pad double: lanes a=0..8 read column i without bank conflicts
 #define LOB_HSLOTS 1024 // per-wave LDS hash set for the 288 "current" tiles
 
 // S % M for S < 2^37, M < 2^31 through a double reciprocal (+-1 fix-up).
@@ -92,58 +92,93 @@ __device__ inline int argmax_ties(const f64* qs, Rng& g) {
 }
 
 // Q(s, a) for all 9 actions of one state, one wave.
-//   vars      : V floats of the state (LDS or global), ignored if `zero`
+//   vars      : V floats of the state (LDS), ignored if `zero`
 //   zero      : the rl::State still holds its constructor zeros (all tiles 0)
-//   vals      : per-wave LDS scratch [9][LOB_QSTRIDE] doubles
+//   vals      : per-wave LDS scratch [9][LOB_QSTRIDE] doubles (one tile GROUP at a time)
 //   out_q[9]  : every lane returns all nine Q values
-// Gathers are issued for all 864 (action, tile) pairs before any is consumed;
-// the sum then follows the reference's sequential order term by term so that
-// Q is bitwise the value Agent::getQ computes (quirk Q3 included).
+// Lane l < 32 owns tiling l of groups 0 and 2, lane 32 + l owns tiling l of
+// group 1: 13.5 gathers per lane, all issued before any is consumed.  The sum
+// then follows the reference's sequential order term by term -- group 0 (w0),
+// group 1 (w1), group 1 again and group 2 (w2): quirk Q3 -- on nine lanes (one
+// per action), the 32 x 9 values of one group staged through LDS at a time, so
+// that Q is bitwise the value Agent::getQ computes.
 // `nz` is the "ever written" bitmap of theta (lob_state.h): weights start at +0.0
 // and only group-0 tiles are ever updated (quirk Q4), so almost every group-1/2
 // gather would fetch a 64-byte sector from HBM to read a zero.  One bit per
 // weight (2.5 MB at M = 20 M: L2-resident) answers that without the fetch; the
 // value used is bit-identical either way.
+__device__ inline void gather9(const DevParams& P, const f64* __restrict__ theta, const uint32_t* __restrict__ nz,
+                               const f32* vars, bool zero, const uint32_t* rnd, const u64* act_terms, int g, int j,
+                               f64* t) {
+    const int nf = g == 0 ? 3 : (g == 1 ? P.V - 3 : P.V);
+    const f32* v = g == 1 ? vars + 3 : vars;
+    const u64 base = zero ? 0 : tile_base(v, nf, j, rnd);
+    i32 idx[LOB_N_ACTIONS];
+    uint32_t word[LOB_N_ACTIONS];
+#pragma unroll
+    for (int a = 0; a < LOB_N_ACTIONS; a++) {
+        idx[a] = zero ? 0 : mod_m(base + act_terms[g * LOB_N_ACTIONS + a], P.M, P.inv_M);
+        word[a] = nz[idx[a] >> 5];
+    }
+#pragma unroll
+    for (int a = 0; a < LOB_N_ACTIONS; a++) {
+        t[a] = 0.0;
+        if ((word[a] >> (idx[a] & 31)) & 1u) t[a] = theta[idx[a]];
+    }
+}
+
 __device__ inline void q_values(const DevParams& P, const f64* __restrict__ theta, const uint32_t* __restrict__ nz,
                                 const f32* vars, bool zero,
                                 const uint32_t* rnd, const u64* act_terms /*[3][9] LDS*/, f64* vals, int lane,
                                 f64* out_q) {
-    // 96 (group, tiling) pairs over 64 lanes: pair p = lane and lane + 64
-    for (int p = lane; p < 96; p += 64) {
-        const int g = p >> 5, j = p & 31;
-        const int nf = g == 0 ? 3 : (g == 1 ? P.V - 3 : P.V);
-        const f32* v = g == 1 ? vars + 3 : vars;
-        u64 base = zero ? 0 : tile_base(v, nf, j, rnd);
-        f64 t[LOB_N_ACTIONS];
-        i32 idx[LOB_N_ACTIONS];
-        uint32_t word[LOB_N_ACTIONS];
-#pragma unroll
-        for (int a = 0; a < LOB_N_ACTIONS; a++) {
-            idx[a] = zero ? 0 : mod_m(base + act_terms[g * LOB_N_ACTIONS + a], P.M, P.inv_M);
-            word[a] = nz[idx[a] >> 5];
-        }
-#pragma unroll
-        for (int a = 0; a < LOB_N_ACTIONS; a++) {
-            t[a] = 0.0;
-            if ((word[a] >> (idx[a] & 31)) & 1u) t[a] = theta[idx[a]];
-        }
-#pragma unroll
-        for (int a = 0; a < LOB_N_ACTIONS; a++) vals[a * LOB_QSTRIDE + p] = t[a];
-    }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // LDS writes of this wave have landed
+    const int j = lane & 31, hi = lane >> 5;
+    f64 ta[LOB_N_ACTIONS], tb[LOB_N_ACTIONS];
+    gather9(P, theta, nz, vars, zero, rnd, act_terms, hi ? 1 : 0, j, ta);      // group 0 (lanes 0-31) / group 1 (32-63)
+    if (!hi) gather9(P, theta, nz, vars, zero, rnd, act_terms, 2, j, tb);      // group 2 (lanes 0-31)
     f64 q = 0.0;
+    const f64* col = vals + lane * LOB_QSTRIDE;
+    // ---- group 0 ----
+    if (!hi) {
+#pragma unroll
+        for (int a = 0; a < LOB_N_ACTIONS; a++) vals[a * LOB_QSTRIDE + j] = ta[a];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
     if (lane < LOB_N_ACTIONS) {
-        const f64* v = vals + lane * LOB_QSTRIDE;
-        f64 w = P.w0;
-        for (int i = 0; i < 32; i++) q += w * v[i];
-        w = P.w1;
-        for (int i = 32; i < 64; i++) q += w * v[i];
+        const f64 w = P.w0;
+        for (int i = 0; i < 32; i++) q += w * col[i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    // ---- group 1: once with w1, once more with w2 (quirk Q3) ----
+    if (hi) {
+#pragma unroll
+        for (int a = 0; a < LOB_N_ACTIONS; a++) vals[a * LOB_QSTRIDE + j] = ta[a];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < LOB_N_ACTIONS) {
+        f64 w = P.w1;
+        for (int i = 0; i < 32; i++) q += w * col[i];
         w = P.w2;
-        for (int i = 32; i < 96; i++) q += w * v[i];
+        for (int i = 0; i < 32; i++) q += w * col[i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    // ---- group 2 ----
+    if (!hi) {
+#pragma unroll
+        for (int a = 0; a < LOB_N_ACTIONS; a++) vals[a * LOB_QSTRIDE + j] = tb[a];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < LOB_N_ACTIONS) {
+        const f64 w = P.w2;
+        for (int i = 0; i < 32; i++) q += w * col[i];
     }
 #pragma unroll
     for (int a = 0; a < LOB_N_ACTIONS; a++) out_q[a] = __shfl(q, a);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
 }
 
