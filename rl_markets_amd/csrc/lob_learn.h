@@ -118,7 +118,8 @@ __device__ inline void gather9(const DevParams& P, const f64* __restrict__ theta
 #pragma unroll
     for (int a = 0; a < LOB_N_ACTIONS; a++) {
         idx[a] = zero ? 0 : mod_m(base + act_terms[g * LOB_N_ACTIONS + a], P.M, P.inv_M);
-        word[a] = nz[idx[a] >> 5];
+        // group-0 tiles are the ones that get written: fetch them directly (one request, not two)
+        word[a] = g == 0 ? 0xffffffffu : nz[idx[a] >> 5];
     }
 #pragma unroll
     for (int a = 0; a < LOB_N_ACTIONS; a++) {
