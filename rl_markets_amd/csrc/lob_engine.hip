@@ -43,6 +43,7 @@ struct lob_engine {
     std::vector<void*> allocs;
     uint32_t* rnd_dev = nullptr;
     uint32_t* records_dev = nullptr;
+    Track* track_dev = nullptr;
     i32* actions_dev = nullptr;
     lob_book_dump* dump_dev = nullptr;
     int dump_cap = 0;
@@ -266,8 +267,12 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     alloc_rm(S.tp_mp, p->lb_target);
     alloc_acc(S.f_vwap_numer, p->lb_vwap);
     alloc_acc(S.f_vwap_denom, p->lb_vwap);
-    if (rc == LOB_OK) rc = dev_alloc(e, &S.px, B * 4 * P.D);
-    if (rc == LOB_OK) rc = dev_alloc(e, &S.vol, B * 4 * P.D);
+    if (rc == LOB_OK) rc = dev_alloc(e, &S.meta, B);
+    if (rc == LOB_OK) rc = dev_alloc(e, &S.ewma_up, B);
+    if (rc == LOB_OK) rc = dev_alloc(e, &S.ewma_down, B);
+    if (rc == LOB_OK) rc = dev_alloc(e, &S.tp_val, B);
+    if (rc == LOB_OK) rc = dev_alloc(e, &S.persist, B * LOB_PERSIST_N);
+    if (rc == LOB_OK) rc = dev_alloc(e, &S.k_stop, B);
     if (rc == LOB_OK) rc = dev_alloc(e, &S.vars, B * 3 * 16);
     if (rc == LOB_OK) rc = dev_alloc(e, &S.qs_last, B * LOB_N_ACTIONS);
     if (rc == LOB_OK) rc = dev_alloc(e, &S.tr_idx, B * LOB_TRACE_GENS * 32);
@@ -283,6 +288,9 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     if (rc != LOB_OK) { lob_destroy(e); return rc; }
     // the two rl::State objects start with constructor zeros (src/rl/state.cpp:10-19)
     {
+        std::vector<f64> neg1(B, -1.0);
+        HIPCHK(hipMemcpyAsync(S.tp_val, neg1.data(), B * sizeof(f64), hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
         std::vector<LHdr> hdr(B);
         memset(hdr.data(), 0, B * sizeof(LHdr));
         for (size_t b = 0; b < B; b++) hdr[b].zero_mask = 3;
@@ -318,6 +326,7 @@ void lob_destroy(lob_engine* e) {
     for (auto ev : e->event_pool) hipEventDestroy(ev);
     for (void* p : e->allocs) hipFree(p);
     if (e->records_dev) hipFree(e->records_dev);
+    if (e->track_dev) hipFree(e->track_dev);
     if (e->dump_dev) hipFree(e->dump_dev);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
@@ -328,6 +337,10 @@ static int set_records(lob_engine* e, int32_t n_events) {
     size_t bytes = (size_t)e->B * n_events * e->P.W * 4;
     hipError_t err = hipMalloc((void**)&e->records_dev, bytes);
     if (err != hipSuccess) { lob_set_error("hipMalloc(records) failed"); return LOB_ENOMEM; }
+    if (e->track_dev) { hipFree(e->track_dev); e->track_dev = nullptr; }
+    err = hipMalloc((void**)&e->track_dev, (size_t)e->B * n_events * sizeof(Track));
+    if (err != hipSuccess) { lob_set_error("hipMalloc(track) failed"); return LOB_ENOMEM; }
+    e->S.track = e->track_dev;
     e->S.records = e->records_dev;
     e->S.n_events = n_events;
     e->have_events = true;

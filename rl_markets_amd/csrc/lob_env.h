@@ -11,6 +11,19 @@
 // (lob_validate_stream) the level map degenerates to the sorted level arrays.
 // All arithmetic that feeds book state is integer or IEEE f64 evaluated in the
 // reference's order (compile with -ffp-contract=off).
+//
+// Split in two:
+//  * market pre-pass (`market_prepass`, once per episode, lane per book): every
+//    quantity of Intraday::NextState that does not depend on the agent -- which
+//    rows are applied (same-timestamp rows, invalid states), midprices,
+//    cumulative volumes, observed trade volumes, the ten rolling windows, target
+//    price, the state variables spd/mpm/imb/svl/vol/rsi/vwap -- written to the
+//    per-event `Track`.  Even the step boundaries are agent-independent: a step
+//    ends when the accumulated midprice move is >= 1e-5 (base.cpp:285-305).
+//  * agent step (`perform_action`, every step): order matching against the
+//    trades, queue updates against consecutive snapshots (read straight from the
+//    immutable event records), adverse selection, inventory, PnL, reward,
+//    quoting, and the agent-dependent state variables.
 #ifndef LOB_ENV_H
 #define LOB_ENV_H
 
@@ -23,8 +36,6 @@ struct EnvR {
 #define X(t, n) t n;
     LOB_ENV_FIELDS(X)
 #undef X
-    // cached best prices of the current / stashed snapshot (0.0 = undefined)
-    f64 ap0, bp0, lap0, lbp0;
 };
 
 struct EnvCtx {
@@ -32,10 +43,12 @@ struct EnvCtx {
     const DevState& S;
     int b;
     __device__ EnvCtx(const DevParams& p, const DevState& s, int book) : P(p), S(s), b(book) {}
-    __device__ size_t lvl(int sel, int side, int l) const {
-        return ((size_t)((sel * 2 + side) * P.D + l)) * (size_t)S.B + (size_t)b;
-    }
     __device__ void err(int bit) const { atomicOr(S.error_flag, bit); }
+    __device__ const uint32_t* row(int i) const {
+        return S.records + ((size_t)b * (size_t)S.n_events + (size_t)i) * (size_t)P.W;
+    }
+    __device__ const Track& track(int k) const { return S.track[(size_t)b * (size_t)S.n_events + (size_t)k]; }
+    __device__ Track& track_w(int k) const { return S.track[(size_t)b * (size_t)S.n_events + (size_t)k]; }
 };
 
 __device__ inline f64 key4(f64 p) { return rint(p * 10000.0); }  // utilities/comparison.h:4-34
@@ -214,28 +227,23 @@ __device__ inline void acc_apply(const AccPtrs& r, int B, int b, AccReg& g, f64 
     r.cnt[b] = g.cnt; r.head[b] = g.head; r.sum[b] = g.sum;
 }
 
-// ---- measures (include/market/measures.h:9-55) ------------------------------
-__device__ inline f64 e_mid(const EnvCtx& c, const EnvR& e) {
-    if (e.ap0 == 0.0 || e.bp0 == 0.0) c.err(LOB_ERR_UNDEF_PRICE);
-    return (e.ap0 + e.bp0) / 2.0;
+// ---- snapshots are read straight from the (immutable) event records ---------
+__device__ inline f64 rec_price(const EnvCtx& c, int rec, int side, int l) {
+    if (rec < 0) return 0.0;
+    const uint32_t* r = c.row(rec);
+    return (f64)__uint_as_float(r[(side == 0 ? lob_rec_ask_px(c.P.D, c.P.T) : lob_rec_bid_px(c.P.D, c.P.T)) + l]);
 }
-__device__ inline f64 e_last_mid(const EnvCtx& c, const EnvR& e) {
-    if (e.lap0 == 0.0 || e.lbp0 == 0.0) c.err(LOB_ERR_UNDEF_PRICE);
-    return (e.lap0 + e.lbp0) / 2.0;
-}
-__device__ inline f64 e_micro(const EnvR& e) {
-    f64 div = (f64)(e.a_tv + e.b_tv);
-    f64 mpm_a = (f64)e.a_tv * e.bp0, mpm_b = e.ap0 * (f64)e.b_tv;
-    return (mpm_a + mpm_b) / div;
-}
-
-// ---- Book lookups over the sorted level arrays ------------------------------
-__device__ inline i64 book_volume(const EnvCtx& c, int sel, int side, f64 price) {
+// Book::volume(price) / last_volume(price) (book.cpp:200-214) on the snapshot held by record `rec`
+__device__ inline i64 book_volume(const EnvCtx& c, int rec, int side, f64 price) {
+    if (rec < 0) return 0;
+    const uint32_t* r = c.row(rec);
+    const uint32_t* px = r + (side == 0 ? lob_rec_ask_px(c.P.D, c.P.T) : lob_rec_bid_px(c.P.D, c.P.T));
+    const uint32_t* vol = r + (side == 0 ? lob_rec_ask_vol(c.P.D, c.P.T) : lob_rec_bid_vol(c.P.D, c.P.T));
     const f64 k = key4(price);
     i64 v = 0;
     for (int l = 0; l < c.P.D; l++) {
-        f32 p = c.S.px[c.lvl(sel, side, l)];
-        if (p != 0.0f && key4((f64)p) == k) v = (i64)c.S.vol[c.lvl(sel, side, l)];
+        f32 p = __uint_as_float(px[l]);
+        if (p != 0.0f && key4((f64)p) == k) v = (i64)(i32)vol[l];
     }
     return v;
 }
@@ -249,13 +257,13 @@ __device__ inline void check_orders(const DevParams& P, EnvR& e) {
 // RiskManager::PlaceOrder with ORDER_LIMIT == 1 (risk_manager.cpp:61-99) +
 // Book::PlaceOrder (book.cpp:250-261): cancel whatever rests, place a new
 // order queued behind the displayed volume at that price.
-__device__ inline void place_one(const EnvCtx& c, EnvR& e, int side, f64 price) {
+__device__ inline void place_one(const EnvCtx& c, EnvR& e, int side, f64 price, i32 price_ticks) {
     if (!(price > 0.0)) c.err(LOB_ERR_BAD_ORDER_PRICE);
-    i64 qh = book_volume(c, e.sel, side, price);
+    i64 qh = book_volume(c, e.rec_cur, side, price);
     if (side == 0) {
-        e.a_on = 1; e.a_opx = price; e.a_osz = c.P.order_size; e.a_oqh = qh; e.a_oqt = 0; e.a_oex = 0; e.a_oiq = qh;
+        e.a_on = 1; e.a_opx = price; e.a_osz = c.P.order_size; e.a_oqh = qh; e.a_oqt = 0; e.a_oex = 0; e.a_oiq = qh; e.a_otk = price_ticks;
     } else {
-        e.b_on = 1; e.b_opx = price; e.b_osz = c.P.order_size; e.b_oqh = qh; e.b_oqt = 0; e.b_oex = 0; e.b_oiq = qh;
+        e.b_on = 1; e.b_opx = price; e.b_osz = c.P.order_size; e.b_oqh = qh; e.b_oqt = 0; e.b_oex = 0; e.b_oiq = qh; e.b_otk = price_ticks;
     }
 }
 
@@ -264,37 +272,53 @@ __device__ inline void place_orders(const EnvCtx& c, EnvR& e, int al, int bl) {
     const DevParams& P = c.P;
     e.ask_level = al;
     e.bid_level = bl;
+    int ta, tb;
     if (P.quote_mode == LOB_QUOTE_BOOK) {
-        if (e.ap0 == 0.0 || e.bp0 == 0.0) c.err(LOB_ERR_UNDEF_PRICE);
-        e.ask_quote = lobh::to_price_t(P_tick(P), lobh::to_ticks_t(P_tick(P), e.ap0) + al);
-        e.bid_quote = lobh::to_price_t(P_tick(P), lobh::to_ticks_t(P_tick(P), e.bp0) - bl);
+        const f64 ap0 = rec_price(c, e.rec_cur, 0, 0), bp0 = rec_price(c, e.rec_cur, 1, 0);
+        if (ap0 == 0.0 || bp0 == 0.0) c.err(LOB_ERR_UNDEF_PRICE);
+        ta = lobh::to_ticks_t(P_tick(P), ap0) + al;
+        tb = lobh::to_ticks_t(P_tick(P), bp0) - bl;
     } else {
-        f64 tp = e.tp_val;
-        f64 half = c.S.spread_window.mean[c.b] / 2.0;
+        const Track& t = c.track(e.k - 1);
+        f64 tp = t.tp_val;
+        f64 half = t.spread_mean / 2.0;
         f64 half_spd = 0.0 > half ? 0.0 : half;  // std::max(0.0, x)
-        e.ask_quote = lobh::to_price_t(P_tick(P), lobh::to_ticks_t(P_tick(P), tp + (f64)al * half_spd));
-        e.bid_quote = lobh::to_price_t(P_tick(P), lobh::to_ticks_t(P_tick(P), tp - (f64)bl * half_spd));
+        ta = lobh::to_ticks_t(P_tick(P), tp + (f64)al * half_spd);
+        tb = lobh::to_ticks_t(P_tick(P), tp - (f64)bl * half_spd);
     }
-    place_one(c, e, 0, e.ask_quote);
-    place_one(c, e, 1, e.bid_quote);
+    e.ask_quote = lobh::to_price_t(P_tick(P), ta);
+    e.bid_quote = lobh::to_price_t(P_tick(P), tb);
+    // a_dist / b_dist need ToTicks(order price): computed once, here
+    place_one(c, e, 0, e.ask_quote, lobh::to_ticks_t(P_tick(P), e.ask_quote));
+    place_one(c, e, 1, e.bid_quote, lobh::to_ticks_t(P_tick(P), e.bid_quote));
 }
 
 // AskBook/BidBook::WalkTheBook via BookUtils::MarketOrder (book.cpp:431-456,514-539,595-610)
 __device__ inline void market_order(const EnvCtx& c, EnvR& e, i64 size, i64& out_vol, f64& out_proxy, f64& out_value) {
     out_vol = 0; out_proxy = 0.0; out_value = 0.0;
-    f64 mip = e_mid(c, e);
+    if (e.rec_cur < 0) c.err(LOB_ERR_UNDEF_PRICE);
+    const f64 mip = e.mid;
     if (size == 0) return;
     const int side = size > 0 ? 0 : 1;
     i64 abs_size = size < 0 ? -size : size;
-    i64 tv = side == 0 ? e.a_tv : e.b_tv;  // cumulative (quirk Q1)
+    // cumulative total_volume_ (quirk Q1) of the side being walked
+    i64 tv;
+    if (e.done == 2) {  // after an abandoned event the totals are those of the last complete event
+        tv = e.k > 0 ? (side == 0 ? c.track(e.k - 1).a_tv : c.track(e.k - 1).b_tv) : 0;
+    } else {
+        tv = side == 0 ? c.track(e.k - 1).a_tv : c.track(e.k - 1).b_tv;
+    }
     if (abs_size > tv) return;
     i64 executed = 0;
     f64 proxy = 0.0, value = 0.0;
+    const uint32_t* r = c.row(e.rec_cur);
+    const uint32_t* px = r + (side == 0 ? lob_rec_ask_px(c.P.D, c.P.T) : lob_rec_bid_px(c.P.D, c.P.T));
+    const uint32_t* vol = r + (side == 0 ? lob_rec_ask_vol(c.P.D, c.P.T) : lob_rec_bid_vol(c.P.D, c.P.T));
     for (int l = 0; l < c.P.D; l++) {
-        f32 pf = c.S.px[c.lvl(e.sel, side, l)];
-        if (pf == 0.0f) continue;  // empty map
+        f32 pf = __uint_as_float(px[l]);
+        if (pf == 0.0f) continue;
         f64 p = (f64)pf;
-        i64 lvol = (i64)c.S.vol[c.lvl(e.sel, side, l)];
+        i64 lvol = (i64)(i32)vol[l];
         i64 left = abs_size - executed;
         i64 l_ex = lvol < left ? lvol : left;
         executed += l_ex;
@@ -325,18 +349,20 @@ __device__ inline void clear_inventory(const EnvCtx& c, EnvR& e) {
 
 // Intraday::DoAction (intraday.cpp:176-220)
 __device__ inline void do_action(const EnvCtx& c, EnvR& e, int action) {
+    int al, bl;
     switch (action) {
-        case 0: place_orders(c, e, 1, 1); break;
-        case 1: clear_inventory(c, e); place_orders(c, e, e.ask_level, e.bid_level); break;
-        case 2: place_orders(c, e, 2, 2); break;
-        case 3: place_orders(c, e, 3, 3); break;
-        case 4: place_orders(c, e, 0, 2); break;
-        case 5: place_orders(c, e, 2, 0); break;
-        case 6: place_orders(c, e, 1, 4); break;
-        case 7: place_orders(c, e, 4, 1); break;
-        case 8: place_orders(c, e, 5, 5); break;
-        default: break;
+        case 0: al = 1; bl = 1; break;
+        case 1: clear_inventory(c, e); al = e.ask_level; bl = e.bid_level; break;
+        case 2: al = 2; bl = 2; break;
+        case 3: al = 3; bl = 3; break;
+        case 4: al = 0; bl = 2; break;
+        case 5: al = 2; bl = 0; break;
+        case 6: al = 1; bl = 4; break;
+        case 7: al = 4; bl = 1; break;
+        case 8: al = 5; bl = 5; break;
+        default: return;
     }
+    place_orders(c, e, al, bl);
 }
 
 __device__ inline bool is_open(const DevParams& P, i32 t) {  // Market::IsOpen, market.cpp:67-70
@@ -357,7 +383,7 @@ __device__ inline f64 get_reward(const EnvCtx& c, const EnvR& e) {
             r = e.pnl_step - (f64)P.damping_factor * m;
             break;
         }
-        case LOB_REWARD_SPREAD: r = e.pnl_step / c.S.spread_window.mean[c.b]; break;
+        case LOB_REWARD_SPREAD: r = e.pnl_step / c.track(e.k - 1).spread_mean; break;
         case LOB_REWARD_LOVOL: r = (f64)e.lo_vol_step; break;
         case LOB_REWARD_MM_LINEAR: {
             f32 pen = -P.pos_weight * (f32)abs_pos;  // float product in the reference
@@ -388,24 +414,11 @@ __device__ inline f64 get_reward(const EnvCtx& c, const EnvR& e) {
     return r * 100;
 }
 
-// Book::ApplyChanges + UpdateOrder for one side (book.cpp:64-141).
-// `rec_px/rec_vol`: the new snapshot of this side; tp/tv: the event's trades.
-__device__ inline void apply_changes(const EnvCtx& c, EnvR& e, int side, const uint32_t* rec_px,
-                                     const uint32_t* rec_vol, const f64* tp, const i64* tv) {
+// Book::UpdateOrder (book.cpp:102-141) of one side for ONE applied depth row:
+// `last_rec` = the stashed snapshot, `row_rec` = the row just applied.
+__device__ inline void update_order(const EnvCtx& c, EnvR& e, int side, int last_rec, int row_rec, const f64* tp,
+                                    const i64* tv) {
     const DevParams& P = c.P;
-    i64 tot = side == 0 ? e.a_tv : e.b_tv;
-    if (side == 0) e.a_ltv = tot; else e.b_ltv = tot;
-    for (int l = 0; l < P.D; l++) {
-        f32 p = __uint_as_float(rec_px[l]);
-        i32 v = (i32)rec_vol[l];
-        if (!(p > 0.0f) || v <= 0) c.err(LOB_ERR_BAD_LEVEL);
-        c.S.px[c.lvl(e.sel, side, l)] = p;
-        c.S.vol[c.lvl(e.sel, side, l)] = v;
-        tot += (i64)v;
-    }
-    if (side == 0) { e.a_tv = tot; e.ap0 = (f64)__uint_as_float(rec_px[0]); }
-    else { e.b_tv = tot; e.bp0 = (f64)__uint_as_float(rec_px[0]); }
-
     i32 on = side == 0 ? e.a_on : e.b_on;
     if (!on) return;
     OrderR o;
@@ -416,16 +429,9 @@ __device__ inline void apply_changes(const EnvCtx& c, EnvR& e, int side, const u
         if (side == 0) e.a_on = 0; else e.b_on = 0;
         return;
     }
-    i64 lv = book_volume(c, e.sel ^ 1, side, opx);
+    i64 lv = book_volume(c, last_rec, side, opx);
     if (lv == 0) return;
-    i64 v = 0;  // volume(price) in the snapshot just applied: scan the record itself
-    {
-        const f64 k = key4(opx);
-        for (int l = 0; l < P.D; l++) {
-            f32 p = __uint_as_float(rec_px[l]);
-            if (p != 0.0f && key4((f64)p) == k) v = (i64)(i32)rec_vol[l];
-        }
-    }
+    i64 v = book_volume(c, row_rec, side, opx);
     if (v == 0) {
         o.qh = 0; o.qt = 0;
     } else {
@@ -445,76 +451,33 @@ __device__ inline void apply_changes(const EnvCtx& c, EnvR& e, int side, const u
     else { e.b_oqh = o.qh; e.b_oqt = o.qt; }
 }
 
-// BookUtils::IsValidState (book.cpp:612-625)
-__device__ inline bool is_valid_state(const EnvCtx& c, const EnvR& e) {
-    f64 mp = e_mid(c, e);
-    bool has_a = key4(e.lap0) != key4(0.0), has_b = key4(e.lbp0) != key4(0.0);
-    if (has_a && has_b) {
-        f64 lm = (e.lap0 + e.lbp0) / 2.0;
-        return ((e.ap0 - e.bp0) >= 0.0) && (mp > 0.0) && (fabs(mp - lm) < mp);
-    }
-    return true;
-}
-
-__device__ inline const uint32_t* rec_row(const EnvCtx& c, int i) {
-    return c.S.records + ((size_t)c.b * (size_t)c.S.n_events + (size_t)i) * (size_t)c.P.W;
-}
-
-// Intraday::UpdateBookProfiles (intraday.cpp:275-313).  Returns false when
-// the depth stream has no row after the one being made current (the
-// reference's Streamer::LoadNext fails, src/data/streamer.cpp:42-49).
-__device__ inline bool update_book_profiles(const EnvCtx& c, EnvR& e, const f64* tp, const i64* tv) {
+__device__ inline void load_trades(const EnvCtx& c, int rec, f64* tp, i64* tv) {
     const DevParams& P = c.P;
-    // StashState on both books: parity flip
-    e.sel ^= 1;
-    { f64 t = e.ap0; e.ap0 = e.lap0; e.lap0 = t; }
-    { f64 t = e.bp0; e.bp0 = e.lbp0; e.lbp0 = t; }
-    while (true) {
-        if (e.cursor + 1 >= c.S.n_events) { e.done = 2; return false; }
-        const uint32_t* r = rec_row(c, e.cursor);
-        e.cursor++;
-        e.events++;
-        e.time_ms = (i32)r[LOB_REC_TIME];
-        apply_changes(c, e, 0, r + lob_rec_ask_px(P.D, P.T), r + lob_rec_ask_vol(P.D, P.T), tp, tv);
-        apply_changes(c, e, 1, r + lob_rec_bid_px(P.D, P.T), r + lob_rec_bid_vol(P.D, P.T), tp, tv);
-        if ((i32)rec_row(c, e.cursor)[LOB_REC_TIME] == e.time_ms) continue;  // !WillTimeChange()
-        if (is_valid_state(c, e)) break;
-    }
-    return true;
-}
-
-// Intraday::NextState (intraday.cpp:225-272): one market event.
-__device__ inline bool next_state(const EnvCtx& c, EnvR& e) {
-    const DevParams& P = c.P;
-    const DevState& S = c.S;
-    const int b = c.b, B = S.B;
-    if (e.cursor >= S.n_events) { e.done = 2; return false; }
-    f64 tp[LOB_MAX_TRADES];
-    i64 tv[LOB_MAX_TRADES];
-    {
-        const uint32_t* r = rec_row(c, e.cursor);
+    const uint32_t* r = c.row(rec);
 #pragma unroll
-        for (int i = 0; i < LOB_MAX_TRADES; i++) {
-            if (i < P.T) {
-                f32 p = __uint_as_float(r[lob_rec_trade_px(P.D, P.T) + i]);
-                i32 v = (i32)r[lob_rec_trade_vol(P.D, P.T) + i];
-                bool ok = (p > 0.0f) && (v > 0);
-                tp[i] = ok ? (f64)p : 0.0;
-                tv[i] = ok ? (i64)v : 0;
-            } else { tp[i] = 0.0; tv[i] = 0; }
-        }
+    for (int i = 0; i < LOB_MAX_TRADES; i++) {
+        if (i < P.T) {
+            f32 p = __uint_as_float(r[lob_rec_trade_px(P.D, P.T) + i]);
+            i32 v = (i32)r[lob_rec_trade_vol(P.D, P.T) + i];
+            bool ok = (p > 0.0f) && (v > 0);
+            tp[i] = ok ? (f64)p : 0.0;
+            tv[i] = ok ? (i64)v : 0;
+        } else { tp[i] = 0.0; tv[i] = 0; }
     }
-    const f64 mp = e_mid(c, e);
-    // AskBook::ApplyTransactions (book.cpp:383-427): trades ascending
-    i64 au_vol = 0; f64 au_proxy = 0.0, au_value = 0.0;
-    e.a_obsval = 0.0; e.a_obsvol = 0;
+}
+
+// AskBook / BidBook::ApplyTransactions (book.cpp:383-427, 468-510) for the agent's
+// orders (the observed-volume bookkeeping of the same functions is agent
+// independent and lives in the pre-pass).
+__device__ inline void match_orders(const EnvCtx& c, EnvR& e, const f64* tp, const i64* tv, f64 mp, i64& au_vol,
+                                    f64& au_proxy, f64& au_value, i64& bu_vol, f64& bu_proxy, f64& bu_value) {
+    const DevParams& P = c.P;
+    au_vol = 0; au_proxy = 0.0; au_value = 0.0;
 #pragma unroll
     for (int i = 0; i < LOB_MAX_TRADES; i++) {
         if (i >= P.T || tv[i] <= 0) continue;
         if (tp[i] < mp) continue;
         i64 vol = tv[i];
-        e.a_obsval += tp[i] * (f64)vol;
-        e.a_obsvol += vol;
         if (e.a_on && e.a_opx <= tp[i]) {
             OrderR o{e.a_osz, e.a_oqh, e.a_oqt, e.a_oex};
             i64 rem0 = ord_remaining(o);
@@ -527,17 +490,13 @@ __device__ inline bool next_state(const EnvCtx& c, EnvR& e) {
             if (ord_executed(o)) { e.a_on = 0; e.a_ntr++; }
         }
     }
-    // BidBook::ApplyTransactions (book.cpp:468-510): trades descending
-    i64 bu_vol = 0; f64 bu_proxy = 0.0, bu_value = 0.0;
-    e.b_obsval = 0.0; e.b_obsvol = 0;
+    bu_vol = 0; bu_proxy = 0.0; bu_value = 0.0;
 #pragma unroll
     for (int ii = 0; ii < LOB_MAX_TRADES; ii++) {
         const int i = LOB_MAX_TRADES - 1 - ii;
         if (i >= P.T || tv[i] <= 0) continue;
         if (tp[i] > mp) continue;
         i64 vol = tv[i];
-        e.b_obsval += tp[i] * (f64)vol;
-        e.b_obsvol += vol;
         if (e.b_on && e.b_opx >= tp[i]) {
             OrderR o{e.b_osz, e.b_oqh, e.b_oqt, e.b_oex};
             i64 rem0 = ord_remaining(o);
@@ -550,12 +509,57 @@ __device__ inline bool next_state(const EnvCtx& c, EnvR& e) {
             if (ord_executed(o)) { e.b_on = 0; e.b_ntr++; }
         }
     }
-    if (!update_book_profiles(c, e, tp, tv)) return false;
+}
+
+// Agent-dependent part of Intraday::NextState (intraday.cpp:225-272) for event e.k.
+// Returns false when the stream is exhausted (the abandoned event still matches
+// its trades and stashes the books, like the reference).
+__device__ inline bool next_state(const EnvCtx& c, EnvR& e) {
+    const DevParams& P = c.P;
+    const BookMeta& M = c.S.meta[c.b];
+    f64 tp[LOB_MAX_TRADES];
+    i64 tv[LOB_MAX_TRADES];
+    i64 au_vol, bu_vol; f64 au_proxy, au_value, bu_proxy, bu_value;
+    if (e.k >= M.n_track) {
+        // out of data inside this event (Streamer::LoadNext fails, src/data/streamer.cpp:42-49)
+        if (M.ex_first >= 0) {
+            load_trades(c, M.ex_first, tp, tv);
+            match_orders(c, e, tp, tv, e.mid, au_vol, au_proxy, au_value, bu_vol, bu_proxy, bu_value);
+            // rows applied before the stream ran dry still update the queue model
+            for (int r = M.ex_first; r <= M.ex_cur && M.ex_cur >= M.ex_first; r++) {
+                update_order(c, e, 0, M.ex_last, r, tp, tv);
+                update_order(c, e, 1, M.ex_last, r, tp, tv);
+            }
+        }
+        e.rec_cur = M.ex_cur; e.rec_last = M.ex_last; e.time_ms = M.ex_time;
+        e.mid_prev = e.rec_last >= 0 ? (rec_price(c, e.rec_last, 0, 0) + rec_price(c, e.rec_last, 1, 0)) / 2.0 : 0.0;
+        e.mid = e.rec_cur >= 0 ? (rec_price(c, e.rec_cur, 0, 0) + rec_price(c, e.rec_cur, 1, 0)) / 2.0 : 0.0;
+        e.events += M.ex_records;
+        e.done = 2;
+        return false;
+    }
+    const Track t = c.track(e.k);
+    load_trades(c, t.rec_first, tp, tv);
+    const f64 mp = e.mid;
+    match_orders(c, e, tp, tv, mp, au_vol, au_proxy, au_value, bu_vol, bu_proxy, bu_value);
+    // UpdateBookProfiles: StashState, then ApplyChanges (-> UpdateOrder) for every applied row
+    const int last_rec = e.rec_cur;
+    for (int r = t.rec_first; r <= t.rec_last; r++) {
+        update_order(c, e, 0, last_rec, r, tp, tv);
+        update_order(c, e, 1, last_rec, r, tp, tv);
+    }
+    e.rec_last = last_rec;
+    e.rec_cur = t.rec_last;
+    e.mid_prev = e.mid;
+    e.mid = t.mid;
+    e.time_ms = t.time_ms;
+    e.events += (i64)(t.rec_last - t.rec_first + 1);
+    e.k++;
 
     // BookUtils::HandleAdverseSelection (book.cpp:551-592)
     i64 ad_vol = 0; f64 ad_proxy = 0.0, ad_value = 0.0;
-    {
-        const f64 bap = e.ap0, bbp = e.bp0, rp = e_last_mid(c, e);
+    if (e.a_on || e.b_on) {
+        const f64 bap = rec_price(c, e.rec_cur, 0, 0), bbp = rec_price(c, e.rec_cur, 1, 0), rp = e.mid_prev;
         if (e.a_on && e.a_opx <= bbp) {
             OrderR o{e.a_osz, e.a_oqh, e.a_oqt, e.a_oex};
             i64 rem = ord_remaining(o);
@@ -578,35 +582,6 @@ __device__ inline bool next_state(const EnvCtx& c, EnvR& e) {
     e.ep_pnl += au_value + bu_value + ad_value;
     e.position += bu_vol + au_vol + ad_vol;  // RiskManager::Update
     check_orders(P, e);
-
-    const f64 mid = e_mid(c, e);
-    const i64 mpt = (i64)lobh::to_ticks_t(P_tick(P), mid);
-    const f64 mpm = mid - e_last_mid(c, e), sp = e.ap0 - e.bp0;
-    // ten window pushes, batched: all loads, then all stores
-    RMReg w_mid, w_vol, w_spr, w_tp, w_atx, w_btx;
-    AccReg w_vn, w_vd;
-    rm_load(S.f_midprice, b, w_mid); rm_load(S.f_volatility, b, w_vol); rm_load(S.spread_window, b, w_spr);
-    rm_load(S.tp_mp, b, w_tp); rm_load(S.f_ask_tx, b, w_atx); rm_load(S.f_bid_tx, b, w_btx);
-    acc_load(S.f_vwap_numer, b, w_vn); acc_load(S.f_vwap_denom, b, w_vd);
-    rm_prep(S.f_midprice, B, b, w_mid); rm_prep(S.f_volatility, B, b, w_vol); rm_prep(S.spread_window, B, b, w_spr);
-    rm_prep(S.tp_mp, B, b, w_tp); rm_prep(S.f_ask_tx, B, b, w_atx); rm_prep(S.f_bid_tx, B, b, w_btx);
-    acc_prep(S.f_vwap_numer, B, b, w_vn); acc_prep(S.f_vwap_denom, B, b, w_vd);
-    rm_apply(S.f_midprice, B, b, w_mid, (f64)mpt);
-    rm_apply(S.f_volatility, B, b, w_vol, (f64)mpt);
-    acc_apply(S.f_vwap_numer, B, b, w_vn, e.a_obsval + e.b_obsval);
-    acc_apply(S.f_vwap_denom, B, b, w_vd, (f64)(e.a_obsvol + e.b_obsvol));
-    rm_apply(S.spread_window, B, b, w_spr, 0.0 > sp ? 0.0 : sp);
-    // TargetPrice::update (src/market/target_price.cpp:44-71)
-    rm_apply(S.tp_mp, B, b, w_tp, P.target_price == LOB_TP_MICROPRICE ? e_micro(e) : mid);
-    e.tp_val = w_tp.mean;
-    {   // EWMA<double>::push (accumulators.cpp:157-163)
-        f64 up = 0.0 > mpm ? 0.0 : mpm;
-        f64 dn = fabs(0.0 < mpm ? 0.0 : mpm);
-        e.ret_ups_mean = (P.ewma_alpha * up) + ((1 - P.ewma_alpha) * e.ret_ups_mean);
-        e.ret_downs_mean = (P.ewma_alpha * dn) + ((1 - P.ewma_alpha) * e.ret_downs_mean);
-    }
-    rm_apply(S.f_ask_tx, B, b, w_atx, (f64)e.a_obsvol);
-    rm_apply(S.f_bid_tx, B, b, w_btx, (f64)e.b_obsvol);
     return true;
 }
 
@@ -626,7 +601,7 @@ __device__ inline bool perform_action(const EnvCtx& c, EnvR& e, int action) {
     do {
         e.pnl_step = 0.0;
         if (!next_state(c, e)) return false;
-        f64 mpm = e_mid(c, e) - e_last_mid(c, e);
+        f64 mpm = e.mid - e.mid_prev;
         e.pnl_step += (f64)e.position * mpm;
         e.momentum_pnl_step += (f64)e.position * mpm;
         agg_r += get_reward(c, e);
@@ -646,41 +621,22 @@ __device__ inline bool perform_action(const EnvCtx& c, EnvR& e, int action) {
     return true;
 }
 
-// Intraday::getVariable (intraday.cpp:316-409)
-__device__ inline f64 ulb(f64 val, f64 lb, f64 ub) {
-    f64 m = val < ub ? val : ub;    // std::min(val, ub)
-    return m < lb ? lb : m;         // std::max(., lb)
-}
+// Intraday::getVariable (intraday.cpp:316-409): market variables come from the
+// track entry of the last completed event, agent variables are computed here.
 __device__ inline f64 get_variable(const EnvCtx& c, const EnvR& e, int v) {
     const DevParams& P = c.P;
-    const DevState& S = c.S;
-    const int b = c.b, B = S.B;
+    const Track& t = c.track(e.k > 0 ? e.k - 1 : 0);
     switch (v) {
         case LOB_VAR_POS: return (f64)e.position / (f64)P.order_size;
-        case LOB_VAR_SPD:
-            return ulb((f64)(lobh::to_ticks_t(P_tick(P), e.ap0) - lobh::to_ticks_t(P_tick(P), e.bp0)), 0.0, 20.0);
-        case LOB_VAR_MPM:
-            return ulb((f64)(lobh::to_ticks_t(P_tick(P), rm_front(S.f_midprice, B, b)) -
-                             lobh::to_ticks_t(P_tick(P), rm_back(S.f_midprice, B, b))), -10.0, 10.0);
-        case LOB_VAR_IMB: {
-            f64 v_a = (f64)e.a_tv, v_b = (f64)e.b_tv;
-            return ((v_a + v_b) > 0 ? 5 * (v_b - v_a) / (v_b + v_a) : 0.0);
-        }
-        case LOB_VAR_SVL: {
-            f64 q_a = S.f_ask_tx.sum[b], q_b = S.f_bid_tx.sum[b];
-            return ((q_a + q_b) > 0 ? 5 * (q_b - q_a) / (q_a + q_b) : 0.0);
-        }
-        case LOB_VAR_VOL: return ulb(5.0 * rm_std(S.f_volatility, b), 0.0, 10.0);
-        case LOB_VAR_RSI: {
-            f64 u = e.ret_ups_mean, d = e.ret_downs_mean;
-            return (u + d) != 0.0 ? 5.0 * (u - d) / (u + d) : 0.0;
-        }
-        case LOB_VAR_VWAP: {
-            f64 d = S.f_vwap_numer.sum[b] / S.f_vwap_denom.sum[b];
-            return ulb(d / S.spread_window.mean[b], -10.0, 10.0);
-        }
+        case LOB_VAR_SPD: return (f64)t.mv[LOB_MV_SPD];
+        case LOB_VAR_MPM: return (f64)t.mv[LOB_MV_MPM];
+        case LOB_VAR_IMB: return (f64)t.mv[LOB_MV_IMB];
+        case LOB_VAR_SVL: return (f64)t.mv[LOB_MV_SVL];
+        case LOB_VAR_VOL: return (f64)t.mv[LOB_MV_VOL];
+        case LOB_VAR_RSI: return (f64)t.mv[LOB_MV_RSI];
+        case LOB_VAR_VWAP: return (f64)t.mv[LOB_MV_VWAP];
         case LOB_VAR_A_DIST:
-            if (e.a_on) return ((f64)lobh::to_ticks_t(P_tick(P), e.a_opx) - (f64)lobh::to_ticks_t(P_tick(P), e.ap0));
+            if (e.a_on) return ((f64)e.a_otk - (f64)t.tick_ap0);
             return -100.0;
         case LOB_VAR_A_QUEUE:
             if (e.a_on) {
@@ -690,7 +646,7 @@ __device__ inline f64 get_variable(const EnvCtx& c, const EnvR& e, int v) {
             }
             return -1.0;
         case LOB_VAR_B_DIST:
-            if (e.b_on) return ((f64)lobh::to_ticks_t(P_tick(P), e.bp0) - (f64)lobh::to_ticks_t(P_tick(P), e.b_opx));
+            if (e.b_on) return ((f64)t.tick_bp0 - (f64)e.b_otk);
             return -100.0;
         case LOB_VAR_B_QUEUE:
             if (e.b_on) {
@@ -715,11 +671,216 @@ __device__ inline void env_store(const DevState& S, int b, const EnvR& e) {
     LOB_ENV_FIELDS(X)
 #undef X
 }
-__device__ inline void env_load_best(const EnvCtx& c, EnvR& e) {
-    e.ap0 = (f64)c.S.px[c.lvl(e.sel, 0, 0)];
-    e.bp0 = (f64)c.S.px[c.lvl(e.sel, 1, 0)];
-    e.lap0 = (f64)c.S.px[c.lvl(e.sel ^ 1, 0, 0)];
-    e.lbp0 = (f64)c.S.px[c.lvl(e.sel ^ 1, 1, 0)];
+
+// ---------------------------------------------------------------------------
+// Market pre-pass: the agent-independent part of Intraday::Initialise and of
+// every Intraday::NextState of the stream, once per episode.
+struct MarketR {
+    int cursor, time_ms, rec_cur, rec_last;
+    f64 ap0, bp0, lap0, lbp0;   // best prices of the current / stashed snapshot (0 = undefined)
+    i64 a_tv, b_tv;
+    f64 a_obsval, b_obsval;
+    i64 a_obsvol, b_obsvol;
+    f64 ewma_up, ewma_down, tp_val;
+    i64 records;
+};
+
+__device__ inline f64 ulb(f64 val, f64 lb, f64 ub) {
+    f64 m = val < ub ? val : ub;    // std::min(val, ub)
+    return m < lb ? lb : m;         // std::max(., lb)
+}
+
+// Book::ApplyChanges (book.cpp:64-99) without the order part.
+__device__ inline void mk_apply_row(const EnvCtx& c, MarketR& m, int rec) {
+    const DevParams& P = c.P;
+    const uint32_t* r = c.row(rec);
+    const uint32_t* apx = r + lob_rec_ask_px(P.D, P.T);
+    const uint32_t* avl = r + lob_rec_ask_vol(P.D, P.T);
+    const uint32_t* bpx = r + lob_rec_bid_px(P.D, P.T);
+    const uint32_t* bvl = r + lob_rec_bid_vol(P.D, P.T);
+    for (int l = 0; l < P.D; l++) {
+        f32 pa = __uint_as_float(apx[l]), pb = __uint_as_float(bpx[l]);
+        i32 va = (i32)avl[l], vb = (i32)bvl[l];
+        if (!(pa > 0.0f) || va <= 0 || !(pb > 0.0f) || vb <= 0) c.err(LOB_ERR_BAD_LEVEL);
+        m.a_tv += (i64)va;
+        m.b_tv += (i64)vb;
+    }
+    m.ap0 = (f64)__uint_as_float(apx[0]);
+    m.bp0 = (f64)__uint_as_float(bpx[0]);
+    m.rec_cur = rec;
+    m.time_ms = (i32)r[LOB_REC_TIME];
+}
+
+// Intraday::UpdateBookProfiles (intraday.cpp:275-313), market part.  Returns
+// false when the depth stream has no row after the one being made current
+// (Streamer::LoadNext fails, src/data/streamer.cpp:42-49).
+__device__ inline bool mk_update_book_profiles(const EnvCtx& c, MarketR& m) {
+    // StashState on both books: current <-> stashed
+    { int t = m.rec_cur; m.rec_cur = m.rec_last; m.rec_last = t; }
+    { f64 t = m.ap0; m.ap0 = m.lap0; m.lap0 = t; }
+    { f64 t = m.bp0; m.bp0 = m.lbp0; m.lbp0 = t; }
+    while (true) {
+        if (m.cursor + 1 >= c.S.n_events) return false;
+        const int rec = m.cursor;
+        m.cursor++;
+        m.records++;
+        mk_apply_row(c, m, rec);
+        if ((i32)c.row(m.cursor)[LOB_REC_TIME] == m.time_ms) continue;  // !WillTimeChange()
+        // BookUtils::IsValidState (book.cpp:612-625)
+        const f64 mp = (m.ap0 + m.bp0) / 2.0;
+        const bool has_a = key4(m.lap0) != key4(0.0), has_b = key4(m.lbp0) != key4(0.0);
+        bool valid = true;
+        if (has_a && has_b) {
+            const f64 lm = (m.lap0 + m.lbp0) / 2.0;
+            valid = ((m.ap0 - m.bp0) >= 0.0) && (mp > 0.0) && (fabs(mp - lm) < mp);
+        }
+        if (valid) break;
+    }
+    return true;
+}
+
+// The whole agent-independent evolution of one book: Initialise's skip to market
+// open, then one Track entry per NextState until the stream runs dry.
+// `replay` > 0: only re-run the window arithmetic of the first `replay` events
+// (no track writes) to recover the exact window sums at the point where the
+// previous episode stopped (quirk Q7: sums survive ClearWindows()).
+__device__ inline void market_prepass(const EnvCtx& c, int replay) {
+    const DevParams& P = c.P;
+    const DevState& S = c.S;
+    const int b = c.b, B = S.B;
+    MarketR m;
+    m.cursor = 0; m.time_ms = 0; m.rec_cur = -1; m.rec_last = -1;
+    m.ap0 = m.bp0 = m.lap0 = m.lbp0 = 0.0;
+    m.a_tv = m.b_tv = 0;
+    m.a_obsval = m.b_obsval = 0.0; m.a_obsvol = m.b_obsvol = 0;
+    m.ewma_up = S.ewma_up[b]; m.ewma_down = S.ewma_down[b]; m.tp_val = S.tp_val[b];
+    m.records = 0;
+    // ClearWindows (base.cpp:145-163): deques emptied, running sums kept (quirk Q7)
+#define X(n) S.n.cnt[b] = 0;
+    LOB_ROLLING_MEANS(X)
+    LOB_ACCUMULATORS(X)
+#undef X
+    BookMeta M;
+    M.n_track = 0; M.k_warm = -1; M.init_ok = 0;
+    M.ex_first = -1; M.ex_cur = -1; M.ex_last = -1; M.ex_time = 0; M.ex_records = 0;
+    bool ok = true;
+    while (ok && !is_open(P, m.time_ms)) ok = mk_update_book_profiles(c, m);
+    M.rec_cur0 = m.rec_cur; M.rec_last0 = m.rec_last; M.time0 = m.time_ms;
+    M.mid0 = (m.ap0 + m.bp0) / 2.0; M.mid_prev0 = (m.lap0 + m.lbp0) / 2.0;
+    if (!ok) { M.ex_cur = m.rec_cur; M.ex_last = m.rec_last; M.ex_time = m.time_ms; }
+    int k = 0;
+    while (ok) {
+        if (replay > 0 && k >= replay) break;
+        const int first = m.cursor;
+        f64 tp[LOB_MAX_TRADES];
+        i64 tv[LOB_MAX_TRADES];
+        load_trades(c, first, tp, tv);
+        const f64 mp = (m.ap0 + m.bp0) / 2.0;
+        // observed transaction value / volume of Ask/BidBook::ApplyTransactions (book.cpp:394-400, 479-485)
+        m.a_obsval = 0.0; m.a_obsvol = 0; m.b_obsval = 0.0; m.b_obsvol = 0;
+#pragma unroll
+        for (int i = 0; i < LOB_MAX_TRADES; i++) {
+            if (i >= P.T || tv[i] <= 0) continue;
+            if (tp[i] < mp) continue;
+            m.a_obsval += tp[i] * (f64)tv[i];
+            m.a_obsvol += tv[i];
+        }
+#pragma unroll
+        for (int ii = 0; ii < LOB_MAX_TRADES; ii++) {
+            const int i = LOB_MAX_TRADES - 1 - ii;
+            if (i >= P.T || tv[i] <= 0) continue;
+            if (tp[i] > mp) continue;
+            m.b_obsval += tp[i] * (f64)tv[i];
+            m.b_obsvol += tv[i];
+        }
+        const i64 rec0 = m.records;
+        if (!mk_update_book_profiles(c, m)) {
+            M.ex_first = first; M.ex_cur = m.rec_cur; M.ex_last = m.rec_last; M.ex_time = m.time_ms;
+            M.ex_records = m.records - rec0;
+            break;
+        }
+        if (m.lap0 == 0.0 || m.lbp0 == 0.0) c.err(LOB_ERR_UNDEF_PRICE);
+        const f64 mid = (m.ap0 + m.bp0) / 2.0, lmid = (m.lap0 + m.lbp0) / 2.0;
+        const int tick_ap0 = lobh::to_ticks_t(P_tick(P), m.ap0), tick_bp0 = lobh::to_ticks_t(P_tick(P), m.bp0);
+        const i64 mpt = (i64)lobh::to_ticks_t(P_tick(P), mid);
+        const f64 mpm = mid - lmid, sp = m.ap0 - m.bp0;
+        // ten window pushes (intraday.cpp:253-269), batched: all loads, then all stores
+        RMReg w_mid, w_vol, w_spr, w_tp, w_atx, w_btx;
+        AccReg w_vn, w_vd;
+        rm_load(S.f_midprice, b, w_mid); rm_load(S.f_volatility, b, w_vol); rm_load(S.spread_window, b, w_spr);
+        rm_load(S.tp_mp, b, w_tp); rm_load(S.f_ask_tx, b, w_atx); rm_load(S.f_bid_tx, b, w_btx);
+        acc_load(S.f_vwap_numer, b, w_vn); acc_load(S.f_vwap_denom, b, w_vd);
+        rm_prep(S.f_midprice, B, b, w_mid); rm_prep(S.f_volatility, B, b, w_vol); rm_prep(S.spread_window, B, b, w_spr);
+        rm_prep(S.tp_mp, B, b, w_tp); rm_prep(S.f_ask_tx, B, b, w_atx); rm_prep(S.f_bid_tx, B, b, w_btx);
+        acc_prep(S.f_vwap_numer, B, b, w_vn); acc_prep(S.f_vwap_denom, B, b, w_vd);
+        rm_apply(S.f_midprice, B, b, w_mid, (f64)mpt);
+        rm_apply(S.f_volatility, B, b, w_vol, (f64)mpt);
+        acc_apply(S.f_vwap_numer, B, b, w_vn, m.a_obsval + m.b_obsval);
+        acc_apply(S.f_vwap_denom, B, b, w_vd, (f64)(m.a_obsvol + m.b_obsvol));
+        rm_apply(S.spread_window, B, b, w_spr, 0.0 > sp ? 0.0 : sp);
+        // TargetPrice::update (src/market/target_price.cpp:44-71)
+        f64 micro;
+        {   // measure::microprice (measures.h:40-55)
+            f64 div = (f64)(m.a_tv + m.b_tv);
+            f64 mpm_a = (f64)m.a_tv * m.bp0, mpm_b = m.ap0 * (f64)m.b_tv;
+            micro = (mpm_a + mpm_b) / div;
+        }
+        rm_apply(S.tp_mp, B, b, w_tp, P.target_price == LOB_TP_MICROPRICE ? micro : mid);
+        m.tp_val = w_tp.mean;
+        {   // EWMA<double>::push (accumulators.cpp:157-163)
+            f64 up = 0.0 > mpm ? 0.0 : mpm;
+            f64 dn = fabs(0.0 < mpm ? 0.0 : mpm);
+            m.ewma_up = (P.ewma_alpha * up) + ((1 - P.ewma_alpha) * m.ewma_up);
+            m.ewma_down = (P.ewma_alpha * dn) + ((1 - P.ewma_alpha) * m.ewma_down);
+        }
+        rm_apply(S.f_ask_tx, B, b, w_atx, (f64)m.a_obsvol);
+        rm_apply(S.f_bid_tx, B, b, w_btx, (f64)m.b_obsvol);
+
+        if (replay <= 0) {
+            Track t;
+            t.rec_first = first; t.rec_last = m.rec_cur; t.time_ms = m.time_ms;
+            t.tick_ap0 = tick_ap0; t.tick_bp0 = tick_bp0; t._pad = 0;
+            t.mid = mid; t.tp_val = m.tp_val; t.spread_mean = w_spr.mean;
+            t.a_tv = m.a_tv; t.b_tv = m.b_tv;
+            // Intraday::getVariable (intraday.cpp:316-409), the stream-only variables
+            t.mv[LOB_MV_SPD] = (f32)ulb((f64)(tick_ap0 - tick_bp0), 0.0, 20.0);
+            {
+                const f64 front = (f64)mpt;  // just pushed
+                i32 bi = w_mid.head - w_mid.cnt + 1;
+                if (bi < 0) bi += S.f_midprice.w;
+                const f64 back = S.f_midprice.ring[(size_t)bi * B + b];
+                t.mv[LOB_MV_MPM] = (f32)ulb((f64)(lobh::to_ticks_t(P_tick(P), front) - lobh::to_ticks_t(P_tick(P), back)), -10.0, 10.0);
+            }
+            {
+                f64 v_a = (f64)m.a_tv, v_b = (f64)m.b_tv;
+                t.mv[LOB_MV_IMB] = (f32)((v_a + v_b) > 0 ? 5 * (v_b - v_a) / (v_b + v_a) : 0.0);
+                f64 q_a = w_atx.sum, q_b = w_btx.sum;
+                t.mv[LOB_MV_SVL] = (f32)((q_a + q_b) > 0 ? 5 * (q_b - q_a) / (q_a + q_b) : 0.0);
+            }
+            {
+                f64 var = w_vol.s / (f64)(w_vol.cnt - 1);
+                f64 sd = var > 0 ? sqrt(var) : 0.0;
+                t.mv[LOB_MV_VOL] = (f32)ulb(5.0 * sd, 0.0, 10.0);
+                f64 u = m.ewma_up, d = m.ewma_down;
+                t.mv[LOB_MV_RSI] = (f32)((u + d) != 0.0 ? 5.0 * (u - d) / (u + d) : 0.0);
+                f64 vw = w_vn.sum / w_vd.sum;
+                t.mv[LOB_MV_VWAP] = (f32)ulb(vw / w_spr.mean, -10.0, 10.0);
+                t.mv[7] = 0.0f;
+            }
+            c.track_w(k) = t;
+            if (M.k_warm < 0 && w_atx.cnt == S.f_ask_tx.w && w_btx.cnt == S.f_bid_tx.w && w_vn.cnt == S.f_vwap_numer.w &&
+                w_vd.cnt == S.f_vwap_denom.w && w_vol.cnt == S.f_volatility.w && w_mid.cnt == S.f_midprice.w &&
+                w_tp.cnt == S.tp_mp.w && w_spr.cnt == S.spread_window.w)
+                M.k_warm = k + 1;  // Intraday::Initialise stops pulling events here (intraday.cpp:119-128)
+        }
+        k++;
+    }
+    S.ewma_up[b] = m.ewma_up; S.ewma_down[b] = m.ewma_down; S.tp_val[b] = m.tp_val;
+    if (replay <= 0) {
+        M.n_track = k;
+        M.init_ok = M.k_warm > 0 ? 1 : 0;
+        S.meta[b] = M;
+    }
 }
 
 #endif

@@ -61,44 +61,36 @@ __global__ void gen_events_kernel(lob_gen_params g, int D, int T, u64 first_book
 // ---------------------------------------------------------------------------
 // Base::Initialise + Intraday::Initialise (base.cpp:123-135, intraday.cpp:103-138)
 // followed by the Runner prologue `last_state->newState(environment)`
-// (serial.cpp:25).  Lane per book.
+// (serial.cpp:25).  Lane per book.  The market pre-pass (lob_env.h) walks the
+// whole stream once and leaves the per-event Track; the agent side of
+// Initialise is then: zero the books' agent state, jump to the end of the
+// warm-up, place the (1,1) quotes.
 __global__ void __launch_bounds__(256, 1) reset_kernel(const DevParams* __restrict__ Pp, DevState S) {
-    const DevParams& P = *Pp;  // parameters read through the scalar cache, never copied to scratch
+    const DevParams& P = *Pp;
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= S.B) return;
     EnvCtx c(P, S, b);
     __shared__ EnvSlot lds_env[256];
     EnvR& e = lds_env[threadIdx.x].e;
-    env_load(S, b, e);  // position, pnl_step, levels of quotes etc. persist across episodes
+    env_load(S, b, e);  // position, pnl_step, quote levels etc. persist across episodes
     const i64 ev0 = e.events;
-    for (int sel = 0; sel < 2; sel++)
-        for (int side = 0; side < 2; side++)
-            for (int l = 0; l < P.D; l++) {
-                S.px[c.lvl(sel, side, l)] = 0.0f;
-                S.vol[c.lvl(sel, side, l)] = 0;
-            }
-    e.sel = 0; e.cursor = 0; e.time_ms = 0; e.done = 0;
+    market_prepass(c, 0);
+    const BookMeta M = S.meta[b];
+    e.done = 0;
     e.ask_quote = 0.0; e.bid_quote = 0.0;
-    e.a_tv = e.a_ltv = 0; e.a_ntr = 0; e.a_obsval = 0.0; e.a_obsvol = 0; e.a_on = 0;
-    e.b_tv = e.b_ltv = 0; e.b_ntr = 0; e.b_obsval = 0.0; e.b_obsvol = 0; e.b_on = 0;
+    e.a_ntr = 0; e.a_on = 0; e.b_ntr = 0; e.b_on = 0;
     e.ep_reward = e.ep_pnl = e.ep_bandh = 0.0;
     e.total_ticks = e.market_buys = e.market_sells = 0;
-    e.ap0 = e.bp0 = e.lap0 = e.lbp0 = 0.0;
-    // ClearWindows: deques emptied, running sums kept (quirk Q7)
-#define X(n) S.n.cnt[b] = 0;
-    LOB_ROLLING_MEANS(X)
-    LOB_ACCUMULATORS(X)
-#undef X
-    f64 tp0[LOB_MAX_TRADES];
-    i64 tv0[LOB_MAX_TRADES];
-    for (int i = 0; i < LOB_MAX_TRADES; i++) { tp0[i] = 0.0; tv0[i] = 0; }
-    bool ok = true;
-    while (ok && !is_open(P, e.time_ms)) ok = update_book_profiles(c, e, tp0, tv0);
-    while (ok && !(rm_full(S.f_ask_tx, b) && rm_full(S.f_bid_tx, b) && S.f_vwap_numer.cnt[b] == S.f_vwap_numer.w &&
-                   S.f_vwap_denom.cnt[b] == S.f_vwap_denom.w && rm_full(S.f_volatility, b) &&
-                   rm_full(S.f_midprice, b) && rm_full(S.tp_mp, b) && rm_full(S.spread_window, b)))
-        ok = next_state(c, e);
-    if (ok) {
+    if (M.init_ok) {
+        const int k = M.k_warm;
+        const Track t1 = c.track(k - 1);
+        e.k = k;
+        e.rec_cur = t1.rec_last;
+        e.mid = t1.mid;
+        e.time_ms = t1.time_ms;
+        if (k >= 2) { const Track t0 = c.track(k - 2); e.rec_last = t0.rec_last; e.mid_prev = t0.mid; }
+        else { e.rec_last = M.rec_cur0; e.mid_prev = M.mid0; }
+        e.events += (i64)(t1.rec_last + 1);  // records 0..rec_last were consumed by Initialise
         place_orders(c, e, 1, 1);
         // last_state->newState(env).  Slot 2 always mirrors the latest getState():
         // Backtester::_step extracts the state itself before acting (serial.cpp:124-137).
@@ -112,6 +104,11 @@ __global__ void __launch_bounds__(256, 1) reset_kernel(const DevParams* __restri
         }
         h.zero_mask &= ~(1 << last);
     } else {
+        // Initialise() == false: out of data before the windows filled
+        e.k = M.n_track;
+        e.rec_cur = M.ex_cur; e.rec_last = M.ex_last; e.time_ms = M.ex_time;
+        e.mid = 0.0; e.mid_prev = 0.0;
+        e.events += (i64)(S.n_events > 0 ? S.n_events - 1 : 0);
         e.done = 2;
     }
     S.hdr[b].stepped = 0;
@@ -129,7 +126,6 @@ __global__ void __launch_bounds__(256) get_state_kernel(const DevParams* __restr
     EnvCtx c(P, S, b);
     EnvR e;
     env_load(S, b, e);
-    env_load_best(c, e);
     if (out)
         for (int i = 0; i < P.V; i++) out[(size_t)b * P.V + i] = (f32)get_variable(c, e, P.vars[i]);
     if (reward) reward[b] = get_reward(c, e);
@@ -160,7 +156,6 @@ __global__ void __launch_bounds__(256, 1) env_kernel(const DevParams* __restrict
             EnvCtx c(P, S, b);
             EnvR& e = lds_env[threadIdx.x].e;
             env_load(S, b, e);
-            env_load_best(c, e);
             i64 ev0 = e.events;
             bool ok = perform_action(c, e, action);
             d_events = e.events - ev0;
@@ -206,7 +201,6 @@ __global__ void __launch_bounds__(256) clear_inventory_kernel(const DevParams* _
     EnvCtx c(P, S, b);
     EnvR e;
     env_load(S, b, e);
-    env_load_best(c, e);
     clear_inventory(c, e);
     env_store(S, b, e);
 }
@@ -546,18 +540,32 @@ __global__ void dump_kernel(const DevParams* __restrict__ Pp, DevState S, int fi
     env_load(S, b, e);
     lob_book_dump d;
     memset(&d, 0, sizeof d);
+    const BookMeta M = S.meta[b];
     for (int l = 0; l < P.D; l++) {
-        d.ask_px[l] = (f64)S.px[c.lvl(e.sel, 0, l)];       d.ask_vol[l] = S.vol[c.lvl(e.sel, 0, l)];
-        d.bid_px[l] = (f64)S.px[c.lvl(e.sel, 1, l)];       d.bid_vol[l] = S.vol[c.lvl(e.sel, 1, l)];
-        d.ask_last_px[l] = (f64)S.px[c.lvl(e.sel ^ 1, 0, l)]; d.ask_last_vol[l] = S.vol[c.lvl(e.sel ^ 1, 0, l)];
-        d.bid_last_px[l] = (f64)S.px[c.lvl(e.sel ^ 1, 1, l)]; d.bid_last_vol[l] = S.vol[c.lvl(e.sel ^ 1, 1, l)];
-        if (d.ask_px[l] == 0.0) d.ask_vol[l] = 0;
-        if (d.bid_px[l] == 0.0) d.bid_vol[l] = 0;
-        if (d.ask_last_px[l] == 0.0) d.ask_last_vol[l] = 0;
-        if (d.bid_last_px[l] == 0.0) d.bid_last_vol[l] = 0;
+        d.ask_px[l] = rec_price(c, e.rec_cur, 0, l);  d.bid_px[l] = rec_price(c, e.rec_cur, 1, l);
+        d.ask_last_px[l] = rec_price(c, e.rec_last, 0, l);  d.bid_last_px[l] = rec_price(c, e.rec_last, 1, l);
+        d.ask_vol[l] = d.ask_px[l] != 0.0 ? book_volume(c, e.rec_cur, 0, d.ask_px[l]) : 0;
+        d.bid_vol[l] = d.bid_px[l] != 0.0 ? book_volume(c, e.rec_cur, 1, d.bid_px[l]) : 0;
+        d.ask_last_vol[l] = d.ask_last_px[l] != 0.0 ? book_volume(c, e.rec_last, 0, d.ask_last_px[l]) : 0;
+        d.bid_last_vol[l] = d.bid_last_px[l] != 0.0 ? book_volume(c, e.rec_last, 1, d.bid_last_px[l]) : 0;
     }
-    d.ask_total_volume = e.a_tv; d.bid_total_volume = e.b_tv;
-    d.ask_last_total_volume = e.a_ltv; d.bid_last_total_volume = e.b_ltv;
+    if (e.k > 0) {
+        const Track t = c.track(e.k - 1);
+        d.ask_total_volume = t.a_tv; d.bid_total_volume = t.b_tv;
+        d.spread_mean = t.spread_mean; d.target_price = t.tp_val;
+    }
+    {   // last_total_volume_ = total before the last ApplyChanges row (book.cpp:71)
+        // the last applied row is the current snapshot, except after an abandoned
+        // (out-of-data) event that only stashed: then it is the stashed one
+        const bool swapped = e.done == 2 && M.ex_cur < M.ex_first;
+        i64 sa = 0, sb = 0;
+        for (int l = 0; l < P.D; l++) {
+            sa += swapped ? d.ask_last_vol[l] : d.ask_vol[l];
+            sb += swapped ? d.bid_last_vol[l] : d.bid_vol[l];
+        }
+        d.ask_last_total_volume = d.ask_total_volume - sa;
+        d.bid_last_total_volume = d.bid_total_volume - sb;
+    }
     d.ask_n_transacted = e.a_ntr; d.bid_n_transacted = e.b_ntr;
     d.ask_has_order = e.a_on; d.bid_has_order = e.b_on;
     if (e.a_on) {
@@ -576,9 +584,8 @@ __global__ void dump_kernel(const DevParams* __restrict__ Pp, DevState S, int fi
     d.pnl_step = e.pnl_step; d.momentum_pnl_step = e.momentum_pnl_step;
     d.lo_vol_step = e.lo_vol_step; d.last_action = e.last_action;
     d.episode_reward = e.ep_reward; d.episode_pnl = e.ep_pnl; d.episode_bandh = e.ep_bandh;
-    d.spread_mean = S.spread_window.mean[b]; d.target_price = e.tp_val;
     d.time_ms = e.time_ms;
-    d.cursor = e.cursor;
+    d.cursor = (e.k > 0 ? c.track(e.k - 1).rec_last : M.rec_cur0) + 1 + (e.done == 2 ? (int)M.ex_records : 0);
     d.terminal = e.done == 2 ? 2 : (is_open(P, e.time_ms) ? 0 : 1);
     d.total_ticks = e.total_ticks;
     int n_tr = 0;

@@ -36,12 +36,19 @@ typedef float f32;
     X(f_vwap_numer)         \
     X(f_vwap_denom)
 
-// Per-book scalars touched by the environment kernel.
+// Per-book scalars of the AGENT-DEPENDENT part of the environment (orders,
+// inventory, PnL, cursors).  Everything that depends only on the event stream
+// (snapshots, cumulative volumes, windows, target price, five of the eight
+// state variables, the step boundaries themselves) is precomputed once per
+// episode into the market track below.
 #define LOB_ENV_FIELDS(X)                                                                                     \
     X(i32, done)      /* 0 live, 1 isTerminal(), 2 out of data */                                              \
-    X(i32, cursor)    /* next depth record (market_depth.record_next) */                                       \
+    X(i32, k)         /* number of completed NextState events = index of the next track entry */              \
     X(i32, time_ms)   /* Market::time_ */                                                                      \
-    X(i32, sel)       /* ping-pong parity of the level arrays */                                               \
+    X(i32, rec_cur)   /* record holding the current depth snapshot (-1: none) */                              \
+    X(i32, rec_last)  /* record holding the stashed snapshot (Book::StashState) (-1: none) */                  \
+    X(f64, mid)       /* midprice of the current snapshot */                                                   \
+    X(f64, mid_prev)  /* midprice of the stashed snapshot */                                                   \
     X(i64, position)  /* RiskManager::position_ */                                                             \
     X(i32, last_action)                                                                                        \
     X(i32, lo_vol_step)                                                                                        \
@@ -51,21 +58,51 @@ typedef float f32;
     X(f64, bid_quote)                                                                                          \
     X(i32, ask_level)                                                                                          \
     X(i32, bid_level)                                                                                          \
-    X(f64, tp_val)                                                                                             \
     X(f64, ep_reward)                                                                                          \
     X(f64, ep_pnl)                                                                                             \
     X(f64, ep_bandh)                                                                                           \
     X(i32, total_ticks)                                                                                        \
     X(i32, market_buys)                                                                                        \
     X(i32, market_sells)                                                                                       \
-    X(i64, events)                                                                                             \
-    X(f64, ret_ups_mean)                                                                                       \
-    X(f64, ret_downs_mean)                                                                                     \
-    /* per side: Book<> members + the single live order (quirk Q13) */                                        \
-    X(i64, a_tv) X(i64, a_ltv) X(i32, a_ntr) X(f64, a_obsval) X(i64, a_obsvol)                                 \
-    X(i32, a_on) X(f64, a_opx) X(i64, a_osz) X(i64, a_oqh) X(i64, a_oqt) X(i64, a_oex) X(i64, a_oiq)           \
-    X(i64, b_tv) X(i64, b_ltv) X(i32, b_ntr) X(f64, b_obsval) X(i64, b_obsvol)                                 \
-    X(i32, b_on) X(f64, b_opx) X(i64, b_osz) X(i64, b_oqh) X(i64, b_oqt) X(i64, b_oex) X(i64, b_oiq)
+    X(i64, events)    /* depth records consumed (incl. warm-up) */                                             \
+    /* per side: n_transacted_ + the single live order (quirk Q13); otk = ToTicks(order price) */             \
+    X(i32, a_ntr) X(i32, a_on) X(f64, a_opx) X(i64, a_osz) X(i64, a_oqh) X(i64, a_oqt) X(i64, a_oex) X(i64, a_oiq) X(i32, a_otk) \
+    X(i32, b_ntr) X(i32, b_on) X(f64, b_opx) X(i64, b_osz) X(i64, b_oqh) X(i64, b_oqt) X(i64, b_oex) X(i64, b_oiq) X(i32, b_otk)
+
+// One entry per NextState event of a book: the agent-independent outcome of
+// Intraday::NextState (intraday.cpp:225-272) when started at record rec_first.
+struct __attribute__((aligned(16))) Track {
+    i32 rec_first;  // record whose trade slots this event consumes (cursor at NextState entry)
+    i32 rec_last;   // last depth record applied (the new current snapshot); rows rec_first..rec_last were applied
+    i32 time_ms;
+    i32 tick_ap0;   // ToTicks(best ask), ToTicks(best bid) of the new snapshot
+    i32 tick_bp0;
+    i32 _pad;
+    f64 mid;          // midprice of the new snapshot
+    f64 tp_val;       // TargetPrice::get() after the update
+    f64 spread_mean;  // spread_window.mean()
+    i64 a_tv, b_tv;   // cumulative total_volume_ (quirk Q1)
+    f32 mv[8];        // spd, mpm, imb, svl, vol, rsi, vwap (Intraday::getVariable), [7] unused
+};
+#define LOB_MV_SPD 0
+#define LOB_MV_MPM 1
+#define LOB_MV_IMB 2
+#define LOB_MV_SVL 3
+#define LOB_MV_VOL 4
+#define LOB_MV_RSI 5
+#define LOB_MV_VWAP 6
+
+// Per-book summary of the market pre-pass.
+struct BookMeta {
+    i32 n_track;    // complete events available
+    i32 k_warm;     // events consumed by Intraday::Initialise (windows full)
+    i32 init_ok;    // 0: ran out of data during Initialise
+    i32 rec_cur0, rec_last0, time0;  // state after the "skip to market open" phase
+    i32 ex_first;   // record whose trades the abandoned (out-of-data) event still matches
+    i32 ex_cur, ex_last, ex_time;    // snapshot records / time after that abandoned event
+    i64 ex_records; // depth records consumed by the abandoned event
+    f64 mid0, mid_prev0;
+};
 
 // Per-book learner header (Runner / Agent / Traces scalars), one 64-byte
 // record per book: the wave-per-book kernels fetch it with a single scalar
@@ -84,6 +121,8 @@ struct __attribute__((aligned(64))) LHdr {
     f64 td;         // last TD error
     f64 upd;        // alpha * delta to scatter
 };
+
+#define LOB_PERSIST_N 32
 
 struct RMPtrs {  // RollingMean<double>
     f64* ring;   // [w][B]
@@ -118,8 +157,13 @@ struct DevState {
     LOB_ACCUMULATORS(X)
 #undef X
 
-    f32* px;   // [2 sel][2 side][D][B]
-    i32* vol;  // [2 sel][2 side][D][B]
+    Track* track;      // [B][n_events] market track (pre-pass)
+    BookMeta* meta;    // [B]
+    f64* ewma_up;      // [B] return_ups / return_downs EWMA means (persist across episodes)
+    f64* ewma_down;
+    f64* tp_val;       // [B] TargetPrice::val_ (persists)
+    f64* persist;      // [LOB_PERSIST_N][B] window sums at episode start (exact replay of quirk Q7)
+    i32* k_stop;       // [B] events consumed by the previous episode (for the replay)
 
     LHdr* hdr;      // [B]
     f32* vars;      // [B][3][16]  the two rl::State objects' state_vars + the latest getState()
