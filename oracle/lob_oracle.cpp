@@ -1039,13 +1039,16 @@ int oracle_reset(oracle_learner* o) {
     for (int b = 0; b < o->B; b++) {
         bool ok = o->env[b]->Initialise();
         o->done[b] = ok ? 0 : 2;
-        // last_state->newState(environment), serial.cpp:25.  NB: Learner::_step
-        // starts with swap(state, last_state) (serial.cpp:55), so the state just
-        // extracted becomes `state` and the first action / first TD update of an
-        // episode use the OTHER State object: all-zero features on the first
-        // episode (State ctor, src/rl/state.cpp:10-19), the previous episode's
-        // leftover afterwards.  Reproduced as is.
-        o->new_state(b);
+        // last_state->newState(environment), serial.cpp:25: the object `last_state` points
+        // to is overwritten, the one `state` points to keeps whatever it held.  NB:
+        // Learner::_step starts with swap(state, last_state) (serial.cpp:55), so the
+        // state just extracted becomes `state` and the first action / first TD update of
+        // an episode use the OTHER State object: all-zero features on the first episode
+        // (State ctor, src/rl/state.cpp:10-19), the previous episode's final state
+        // afterwards.  Reproduced as is.
+        o->vars[b].swap(o->last_vars[b]);
+        o->feats[b].swap(o->last_feats[b]);
+        o->new_state(b);             // fills vars/feats = the object last_state points to
         o->record(b, -1, 0.0, 0.0);
         o->vars[b].swap(o->last_vars[b]);
         o->feats[b].swap(o->last_feats[b]);
@@ -1070,6 +1073,7 @@ int oracle_td_step(oracle_learner* o, int32_t n_steps) {
                 o->done[b] = 2;
                 o->recs[b].rng_ctr = o->rng_ctr[b];
                 e.fill(o->recs[b].book);
+                o->recs[b].book.n_traces = (int)o->traces[b].nonzero.size();
                 continue;
             }
             o->new_state(b);

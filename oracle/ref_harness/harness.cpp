@@ -273,10 +273,6 @@ static int run_episode(const Args& a, Config& c, ProbeEnv& env, const std::strin
     FILE* out = fopen(out_path.c_str(), "wb");
     if (!out) { perror("out"); return 2; }
 
-    // Runner::RunEpisode prologue (src/experiment/serial.cpp:18-26)
-    if (!env.Initialise()) { fprintf(stderr, "Initialise failed\n"); return 3; }
-    last_state->newState(env);
-
     StepRec r;
     auto dump = [&](int action, double reward, double td, rl::State* st) {
         memset(&r, 0, sizeof r);
@@ -291,25 +287,38 @@ static int run_episode(const Args& a, Config& c, ProbeEnv& env, const std::strin
         r.book.n_traces = agent.traces_ref().n_nonzero_traces;
         fwrite(&r, sizeof r, 1, out);
     };
-    dump(-1, 0.0, 0.0, last_state);  // record 0 = state after reset
-
     long steps = 0;
     int end_reason = 0;
-    // Learner::_step (src/experiment/serial.cpp:53-70)
-    while (steps < max_steps) {
-        std::swap(state, last_state);
-        if (env.isTerminal()) { end_reason = 1; break; }
-        int action = agent.action(*last_state);
-        if (!env.performAction(action)) { end_reason = 2; break; }
-        state->newState(env);
-        double reward = env.getReward();
-        agent.HandleTransition(*last_state, action, reward, *state);
-        steps++;
-        dump(action, reward, agent.last_delta, state);
-    }
-    if (a.geti("clear_inventory", 0)) {
-        env.ClearInventory();  // Runner::RunEpisode epilogue (serial.cpp:31)
-        dump(-2, 0.0, 0.0, state);
+    std::string ends;
+    const int episodes = (int)a.geti("episodes", 1);
+    for (int ep = 0; ep < episodes; ep++) {
+        // src/main.cpp:55: every episode re-opens its data files
+        if (ep > 0) env.LoadData(a.get("ticker", "HSBA.L"), a.get("md"), a.get("tas"));
+        // Runner::RunEpisode prologue (src/experiment/serial.cpp:18-26)
+        if (!env.Initialise()) { fprintf(stderr, "Initialise failed\n"); return 3; }
+        last_state->newState(env);
+        dump(-1, 0.0, 0.0, last_state);  // state after reset
+        long ep_steps = 0;
+        end_reason = 0;
+        // Learner::_step (src/experiment/serial.cpp:53-70)
+        while (ep_steps < max_steps) {
+            std::swap(state, last_state);
+            if (env.isTerminal()) { end_reason = 1; break; }
+            int action = agent.action(*last_state);
+            if (!env.performAction(action)) { end_reason = 2; break; }
+            state->newState(env);
+            double reward = env.getReward();
+            agent.HandleTransition(*last_state, action, reward, *state);
+            steps++;
+            ep_steps++;
+            dump(action, reward, agent.last_delta, state);
+        }
+        if (a.geti("clear_inventory", 0) || episodes > 1) {
+            env.ClearInventory();  // Runner::RunEpisode epilogue (serial.cpp:31)
+            dump(-2, 0.0, 0.0, state);
+        }
+        if (episodes > 1) agent.HandleTerminal(ep);  // Learner::RunEpisode (serial.cpp:79)
+        ends += (ep ? "," : "") + std::to_string(end_reason);
     }
     fclose(out);
 
@@ -340,8 +349,8 @@ static int run_episode(const Args& a, Config& c, ProbeEnv& env, const std::strin
         }
         fclose(f);
     }
-    printf("{\"steps\": %ld, \"end\": %d, \"rng_ctr\": %llu, \"sizeof_steprec\": %zu}\n", steps, end_reason,
-           (unsigned long long)g_ctr, sizeof(StepRec));
+    printf("{\"steps\": %ld, \"end\": %d, \"ends\": [%s], \"rng_ctr\": %llu, \"sizeof_steprec\": %zu}\n", steps, end_reason,
+           ends.c_str(), (unsigned long long)g_ctr, sizeof(StepRec));
     return 0;
 }
 

@@ -48,6 +48,7 @@ struct lob_engine {
     lob_book_dump* dump_dev = nullptr;
     int dump_cap = 0;
     bool have_events = false, was_reset = false;
+    bool episode_open = false;  // a pre-pass ran and its window sums have not been rolled back to the stop point yet
     bool timing = false;
     std::map<std::string, KTimer> timers;
     std::vector<hipEvent_t> event_pool;
@@ -332,7 +333,17 @@ void lob_destroy(lob_engine* e) {
     delete e;
 }
 
+static int finalize_episode(lob_engine* e) {
+    if (!e->episode_open) return LOB_OK;
+    hipLaunchKernelGGL(finalize_kernel, dim3(grid_lanes(e->B)), dim3(256), 0, e->stream, (const DevParams*)e->P_dev, e->S);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->episode_open = false;
+    return LOB_OK;
+}
+
 static int set_records(lob_engine* e, int32_t n_events) {
+    { int rc = finalize_episode(e); if (rc) return rc; }  // needs the old stream
     if (e->records_dev) { hipFree(e->records_dev); e->records_dev = nullptr; }
     size_t bytes = (size_t)e->B * n_events * e->P.W * 4;
     hipError_t err = hipMalloc((void**)&e->records_dev, bytes);
@@ -376,12 +387,14 @@ int lob_reset(lob_engine* e) {
     if (!e) return LOB_EINVAL;
     if (!e->have_events) { lob_set_error("lob_reset: no event stream loaded"); return LOB_ESTATE; }
     HIPCHK(hipSetDevice(e->device));
+    { int rc = finalize_episode(e); if (rc) return rc; }
     {
         TimedLaunch t(e, "reset_kernel");
         hipLaunchKernelGGL(reset_kernel, dim3(grid_lanes(e->B)), dim3(256), 0, e->stream, (const DevParams*)e->P_dev, e->S);
     }
     HIPCHK(hipGetLastError());
     e->was_reset = true;
+    e->episode_open = true;
     return check_device_errors(e);
 }
 

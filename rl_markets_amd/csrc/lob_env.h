@@ -739,6 +739,34 @@ __device__ inline bool mk_update_book_profiles(const EnvCtx& c, MarketR& m) {
     return true;
 }
 
+// Window sums that survive ClearWindows() (quirk Q7), saved at episode start so that
+// the exact sums at the point where the episode later stops can be regenerated.
+__device__ inline void persist_io(const DevState& S, int b, bool save) {
+    int i = 0;
+    const int B = S.B;
+#define X(n)                                                                                   \
+    if (save) { S.persist[(size_t)(i + 0) * B + b] = S.n.sum[b]; S.persist[(size_t)(i + 1) * B + b] = S.n.mean[b]; S.persist[(size_t)(i + 2) * B + b] = S.n.s[b]; } \
+    else { S.n.sum[b] = S.persist[(size_t)(i + 0) * B + b]; S.n.mean[b] = S.persist[(size_t)(i + 1) * B + b]; S.n.s[b] = S.persist[(size_t)(i + 2) * B + b]; }   \
+    i += 3;
+    X(f_midprice) X(f_volatility) X(f_ask_tx) X(f_bid_tx) X(spread_window) X(tp_mp)
+#undef X
+#define X(n)                                                            \
+    if (save) S.persist[(size_t)i * B + b] = S.n.sum[b];                \
+    else S.n.sum[b] = S.persist[(size_t)i * B + b];                     \
+    i += 1;
+    X(f_vwap_numer) X(f_vwap_denom)
+#undef X
+    if (save) {
+        S.persist[(size_t)(i + 0) * B + b] = S.ewma_up[b];
+        S.persist[(size_t)(i + 1) * B + b] = S.ewma_down[b];
+        S.persist[(size_t)(i + 2) * B + b] = S.tp_val[b];
+    } else {
+        S.ewma_up[b] = S.persist[(size_t)(i + 0) * B + b];
+        S.ewma_down[b] = S.persist[(size_t)(i + 1) * B + b];
+        S.tp_val[b] = S.persist[(size_t)(i + 2) * B + b];
+    }
+}
+
 // The whole agent-independent evolution of one book: Initialise's skip to market
 // open, then one Track entry per NextState until the stream runs dry.
 // `replay` > 0: only re-run the window arithmetic of the first `replay` events

@@ -74,6 +74,7 @@ __global__ void __launch_bounds__(256, 1) reset_kernel(const DevParams* __restri
     EnvR& e = lds_env[threadIdx.x].e;
     env_load(S, b, e);  // position, pnl_step, quote levels etc. persist across episodes
     const i64 ev0 = e.events;
+    persist_io(S, b, true);  // sums as of this episode's start
     market_prepass(c, 0);
     const BookMeta M = S.meta[b];
     e.done = 0;
@@ -116,6 +117,21 @@ __global__ void __launch_bounds__(256, 1) reset_kernel(const DevParams* __restri
     S.hdr[b].time_ms = e.time_ms;
     env_store(S, b, e);
     atomicAdd((u64*)&S.counters[1], (u64)(e.events - ev0));  // warm-up events count as consumed
+}
+
+// End of an episode: the pre-pass has walked the window arithmetic to the END of
+// the stream, but an episode may stop earlier (market close).  Regenerate the
+// window sums exactly as they stood after the `k` events the episode consumed
+// (restore the episode-start sums, replay k events) -- they are what the next
+// episode inherits (quirk Q7).
+__global__ void __launch_bounds__(256, 1) finalize_kernel(const DevParams* __restrict__ Pp, DevState S) {
+    const DevParams& P = *Pp;
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= S.B) return;
+    EnvCtx c(P, S, b);
+    persist_io(S, b, false);
+    const int k = S.k[b];
+    if (k > 0) market_prepass(c, k);
 }
 
 // Evaluate getState() for every book (lob_get_state): lane per book.

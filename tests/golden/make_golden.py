@@ -38,6 +38,13 @@ TRAJ_CASES = [
 ]
 
 
+# name, algo, n_events, book id, harness args (episodes, per-episode step cap)
+MULTI_CASES = [
+    ("early_stop_x3", "q_learn", 420, 21, {"episodes": 3, "steps": 110}),
+    ("exhausted_x2", "sarsa", 260, 22, {"episodes": 2}),
+]
+
+
 def run(cmd):
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
@@ -101,6 +108,14 @@ def main():
             traj, info, theta = ol.run_ref_episode(rec[0], algo=algo, mem=1 << 20, rng_stream=book, extra=extra)
             np.savez_compressed(os.path.join(HERE, "traj_%s.npz" % name), traj=traj, theta_idx=theta[0],
                                 theta_val=theta[1], steps=info["steps"], end=info["end"], rng_ctr=info["rng_ctr"])
+            print(name, info)
+        # ---- multi-episode runs: Runner::RunEpisode x N on one agent (quirks Q7, Q19) ----
+        for name, algo, n_events, book, extra in MULTI_CASES:
+            g.n_events = n_events
+            rec = engine.gen_stream_host(g, 5, 2, book, 1)
+            traj, info, theta = ol.run_ref_episode(rec[0], algo=algo, mem=1 << 20, rng_stream=book, extra=extra)
+            np.savez_compressed(os.path.join(HERE, "multi_%s.npz" % name), traj=traj, theta_idx=theta[0],
+                                theta_val=theta[1], steps=info["steps"], ends=np.array(info["ends"]), rng_ctr=info["rng_ctr"])
             print(name, info)
     print("golden fixtures written to", HERE)
 

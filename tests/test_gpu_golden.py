@@ -107,3 +107,37 @@ def test_full_size_properties():
         assert np.array_equal(b1[name], runs[1][1][name]), name
     np.testing.assert_array_equal(rc, runs[1][4])
     np.testing.assert_allclose(th, runs[1][2], rtol=1e-9, atol=1e-15)
+
+
+from tests.golden.make_golden import MULTI_CASES  # noqa: E402
+from tests.test_oracle_golden import replay_multi  # noqa: E402
+from tests import oracle_lib as ol  # noqa: E402
+
+
+@pytest.mark.parametrize("case", MULTI_CASES, ids=[c[0] for c in MULTI_CASES])
+def test_engine_multi_episode_vs_reference(case):
+    """Runner::RunEpisode x N on one engine against the reference: window sums surviving
+    ClearWindows (Q7), leftover State on the first step (Q19), HandleTerminal."""
+    name, algo, n_events, book, _extra = case
+    fx = np.load(os.path.join(GOLD, "multi_%s.npz" % name))
+    g = engine.default_gen_params()
+    g.n_events = n_events
+    rec = engine.gen_stream_host(g, 5, 2, book, 1)
+    eng = engine.Engine(_params_for({}, algo, book), 1)
+    eng.load_events(rec)
+
+    def rec_fn():
+        r = np.zeros(1, dtype=ol.STEP_DTYPE)[0]
+        r["book"] = dumps_to_np(eng.get_books())[0]
+        r["action"] = eng.last_actions()[0]
+        r["reward"] = eng.last_rewards()[0]
+        r["td"] = eng.last_td()[0]
+        r["rng_ctr"] = eng.rng_counters()[0]
+        r["vars"][:8] = eng.learner_state()[0] if eng.stepped()[0] else eng.get_state()[0]
+        return r
+
+    replay_multi(fx, eng.reset, lambda: eng.td_step(1), eng.clear_inventory, eng.handle_terminal, rec_fn, name)
+    th = eng.theta(0)
+    nz = np.nonzero(th)[0]
+    np.testing.assert_array_equal(nz, fx["theta_idx"])
+    np.testing.assert_array_equal(th[nz], fx["theta_val"])

@@ -199,3 +199,29 @@ def test_step_before_reset_is_an_error():
     with pytest.raises(engine.LobError) as ei:
         eng.td_step(1)
     assert ei.value.code == abi.LOB_ESTATE
+
+
+@pytest.mark.parametrize("stop", ["early", "exhausted"])
+def test_two_episodes_window_sums_persist(stop):
+    """Runner::RunEpisode twice on the same engine: window sums survive ClearWindows()
+    (quirk Q7), traces are decayed by HandleTerminal, theta keeps learning, and the
+    second episode's first step acts on the previous episode's leftover State (quirk Q19)."""
+    B = 8
+    p, g, rec, eng, orc = make(n_events=330, B=B, algo=abi.ALGO_QLAMBDA, theta_mode=abi.THETA_PRIVATE, first_book=40)
+    n1 = 90 if stop == "early" else 300
+    for ep in range(2):
+        eng.reset()
+        orc.reset()
+        compare_env(eng, orc, "episode %d reset" % ep)
+        for step in range(n1 if ep == 0 else 60):
+            eng.td_step(1)
+            orc.td_step(1)
+            if step % 10 == 0 or step < 3:
+                compare_learner_step(eng, orc, "episode %d step %d" % (ep, step))
+        eng.clear_inventory()
+        orc.clear_inventory()
+        compare_env(eng, orc, "episode %d after ClearInventory" % ep)
+        eng.handle_terminal()
+        ol.load().oracle_handle_terminal(orc.h)
+    for b in range(B):
+        np.testing.assert_array_equal(eng.theta(b), orc.theta(b))

@@ -136,3 +136,54 @@ def test_live_reference_run_matches_oracle():
     nz = np.nonzero(th)[0]
     np.testing.assert_array_equal(nz, theta[0])
     np.testing.assert_array_equal(th[nz], theta[1])
+
+
+from tests.golden.make_golden import MULTI_CASES  # noqa: E402
+
+
+def replay_multi(fx, reset, step, clear, terminal, rec_fn, name):
+    """Walk a multi-episode reference trajectory: -1 = state after Initialise,
+    >= 0 = one Learner::_step, -2 = after ClearInventory (+ HandleTerminal)."""
+    traj, ends = fx["traj"], list(fx["ends"])
+    ep = -1
+    for i, want in enumerate(traj):
+        a = int(want["action"])
+        if a == -1:
+            ep += 1
+            reset()
+            got = rec_fn()
+            check = ("vars",)
+        elif a == -2:
+            if ends[ep] != 0:
+                step()      # the reference tried one more _step: swap, (draws,) then terminal / out of data
+            clear()
+            got = rec_fn()
+            terminal()
+            check = ()
+        else:
+            step()
+            got = rec_fn()
+            check = ("action", "reward", "td", "rng_ctr", "vars")
+        for n in check:
+            assert np.array_equal(got[n], want[n]), "%s rec %d: %s %r != %r" % (name, i, n, got[n], want[n])
+        for n in got["book"].dtype.names:
+            if n in ("cursor", "n_traces", "terminal"):
+                continue
+            assert np.array_equal(got["book"][n], want["book"][n]), \
+                "%s rec %d (action %d): book.%s %r != %r" % (name, i, a, n, got["book"][n], want["book"][n])
+
+
+@pytest.mark.parametrize("case", MULTI_CASES, ids=[c[0] for c in MULTI_CASES])
+def test_oracle_multi_episode(case):
+    name, algo, n_events, book, _extra = case
+    fx = np.load(os.path.join(GOLD, "multi_%s.npz" % name))
+    g = engine.default_gen_params()
+    g.n_events = n_events
+    rec = engine.gen_stream_host(g, 5, 2, book, 1)
+    o = ol.Oracle(_params_for({}, algo, book), rec)
+    replay_multi(fx, o.reset, lambda: o.td_step(1), o.clear_inventory,
+                 lambda: ol.load().oracle_handle_terminal(o.h), lambda: o.rec(0), name)
+    th = o.theta(0)
+    nz = np.nonzero(th)[0]
+    np.testing.assert_array_equal(nz, fx["theta_idx"])
+    np.testing.assert_array_equal(th[nz], fx["theta_val"])
