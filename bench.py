@@ -33,14 +33,16 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 # SURVEY.md §8d terms regrouped per kernel; n_live = live traces, measured).
 def algorithmic_bytes(kernel, depth, trades, n_vars, n_live, events_per_step):
     rec = 4 * ((2 + 4 * depth + 2 * trades + 3) // 4 * 4)
-    if kernel == "act_kernel":      # 9*96 theta gathers (f64) + state vars in, Q(last,.) + action out
-        return 9 * 96 * 8 + 4 * 16 + 9 * 8 + 16
-    if kernel == "learn_kernel":    # 9*96 theta gathers + both states' vars + trace index list r/w + scalars
-        return 9 * 96 * 8 + 2 * 4 * 16 + 9 * 8 + n_live * 4 + 32 * 4 + 26 * 4 + 48
-    if kernel == "update_kernel":   # per live trace: index (4) + theta read-modify-write (8 + 8)
-        return n_live * (4 + 8 + 8) + 26 * 4
-    if kernel == "env_kernel":      # event records + ping-pong level write + scalars + ~10 ring slot swaps
-        return events_per_step * (rec + 2 * depth * 8 + 10 * 16) + 2 * 60 * 8
+    hdr = 64                          # learner header, one 64-byte record per book
+    if kernel == "act_kernel":        # header + 3 state slots in, 9*96 weights (f64), Q(last,.) + header out
+        return hdr + 192 + 9 * 96 * 8 + 9 * 8 + 32
+    if kernel == "learn_kernel":      # header + slots + Q(last,.) in, 9*96 weights, trace index list r/w, header out
+        return hdr + 192 + 9 * 8 + 9 * 96 * 8 + n_live * 4 + 32 * 4 + 26 * 4 + 32
+    if kernel == "update_kernel":     # per live trace: index (4) + theta read-modify-write (8 + 8); header + masks
+        return hdr + n_live * (4 + 8 + 8) + 26 * 4
+    if kernel == "env_kernel":        # per event: track entry (96) + trade slots + the two snapshots' levels at the order
+        per_event = 96 + 2 * trades * 4 + 2 * 2 * depth * 8
+        return 2 * 232 + hdr + events_per_step * per_event + 2 * 96 + 3 * 4 * n_vars   # agent scalars r/w + quotes + vars out
     return 0
 
 
@@ -131,7 +133,10 @@ def main():
 
     eng = engine.Engine(p, args.books, device=local_rank)
     eng.gen_events(g)       # synthetic streams generated directly in HBM (never timed)
-    eng.reset()
+    t_reset = time.perf_counter()
+    eng.reset()             # Initialise(): includes the once-per-episode market pre-pass over the whole stream
+    eng.sync()
+    reset_ms = (time.perf_counter() - t_reset) * 1e3
 
     from rl_markets_amd.parallel import EngineBackend, ShardedLearner
     learner = ShardedLearner(EngineBackend(eng, torch, "cuda:%d" % local_rank), dist, sync_every=SYNC_EVERY)
@@ -189,7 +194,7 @@ def main():
             dom = max((k for k in ktimes if k.endswith("_kernel") and not k.startswith("delta")),
                       key=lambda k: ktimes[k]["avg_ms"])
             per_book = algorithmic_bytes(dom, args.depth, 2, p.n_vars, n_live, eps)
-            live_books = steps_done / args.steps / world
+            live_books = steps_done / world / ktimes[dom]["launches"]   # books one launch of that kernel covers
             bytes_per_launch = per_book * live_books
             achieved = bytes_per_launch / (ktimes[dom]["avg_ms"] * 1e-3) / 1e9
             traffic = None
@@ -231,7 +236,7 @@ def main():
                                                                    args.memory_size),
                 "books_per_gpu": args.books, "depth": args.depth, "events_per_book": g.n_events,
                 "events_per_step": round(eps, 4), "live_traces_per_book": round(n_live, 1),
-                "env_steps": steps_done, "sync_every": SYNC_EVERY if world > 1 else None,
+                "env_steps": steps_done, "reset_ms_per_episode": round(reset_ms, 2), "sync_every": SYNC_EVERY if world > 1 else None,
                 "parallelism": "%d book shard(s), dense RCCL all-reduce of delta-theta" % world if world > 1 else "1 shard",
             },
             "roofline": roofline,

@@ -195,8 +195,10 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming | hipEventDisableSystemFence));
     HIPCHK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming | hipEventDisableSystemFence));
     HIPCHK(hipEventCreateWithFlags(&e->ev_stagger, hipEventDisableTiming | hipEventDisableSystemFence));
-    // two book groups pipelined on two streams hide the latency-bound env kernel behind the gather kernels
-    e->n_groups = n_books >= 4096 ? 2 : 1;
+    // Optional (LOB_GROUPS=2): two book groups pipelined on two streams so that the latency-bound env
+    // kernel of one group runs beside a gather kernel of the other.  It paid 7 % before the market
+    // track made the env kernel cheap; now one group is as fast and gives clean per-kernel timings.
+    e->n_groups = 1;
     if (const char* g = getenv("LOB_GROUPS")) { int v = atoi(g); if (v >= 1 && v <= 2) e->n_groups = v; }
 
     // ---- DevParams ----
