@@ -226,6 +226,25 @@ int lob_gen_stream_host(const lob_gen_params* g, int32_t depth, int32_t max_trad
 int lob_validate_stream(const uint32_t* records, int32_t depth, int32_t max_trades,
                         int32_t n_books, int32_t n_events);
 
+/* ---- ingestion of recorded data -------------------------
+ * lob_convert_csv: the reference's two CSV formats (include/data/basic.h:17-24,49-52:
+ * 22-column 5-level market depth, 4-column time-and-sales; header row skipped,
+ * `stof` prices, rows with a non-positive price dropped, src/data/basic.cpp:45-70,
+ * 148-162) -> one record per depth row carrying the trades of its own interval
+ * (time-and-sales rows with prev_depth_time < time <= depth_time, aggregated per
+ * 1e-4 price key like TimeAndSalesRecord::transactions).  Depth is 5.
+ * lob_convert_lobster: LOBSTER message + orderbook files (prices x 10000): one
+ * record per distinct millisecond = last snapshot of that millisecond + the
+ * executions (types 4, 5) of that millisecond aggregated per price; the first
+ * `depth` of `levels_in_file` levels are kept, records with a missing level are
+ * dropped.  Both allocate *out_records (n_events * lob_record_words * 4 bytes);
+ * release with lob_free. */
+int lob_convert_csv(const char* md_path, const char* tas_path, int32_t max_trades, uint32_t** out_records,
+                    int32_t* n_events);
+int lob_convert_lobster(const char* orderbook_path, const char* message_path, int32_t levels_in_file, int32_t depth,
+                        int32_t max_trades, uint32_t** out_records, int32_t* n_events);
+void lob_free(void* p);
+
 /* ---- engine lifetime ----------------------------------------------------- */
 
 /* Replaces constructing environment::Intraday<> + rl::Agent + serial::Learner

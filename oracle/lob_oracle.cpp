@@ -595,6 +595,7 @@ struct Env {
     const uint32_t* rec;  // this book's events
     int n_events;
     int cursor = 0;       // next depth row to load (market_depth.record_next)
+    int trades_from = 0;  // first row whose trade slots have not been handed over yet (T&S stream position)
     bool exhausted = false;
 
     AskBook ask;
@@ -706,15 +707,18 @@ struct Env {
     bool NextState() {
         if (cursor >= n_events) { exhausted = true; return false; }
         // trades carried by the record about to be applied (= LoadUntil(next depth time))
+        // time_and_sales.LoadUntil(next depth row's time): every trade up to that row which
+        // has not been handed over yet (rows carry the trades of their own interval)
         TradeMap tx;
-        {
-            const uint32_t* r = row(cursor);
+        for (int rr = trades_from; rr <= cursor; rr++) {
+            const uint32_t* r = row(rr);
             for (int i = 0; i < T; i++) {
                 int32_t v = (int32_t)r[lob_rec_trade_vol(D, T) + i];
                 double p = (double)lob_bits_f32(r[lob_rec_trade_px(D, T) + i]);
                 if (p > 0.0 && v > 0) tx[p] += v;
             }
         }
+        trades_from = cursor + 1;
         double mp = midprice(ask, bid);
         Fill au = ask.ApplyTransactions(tx, mp), bu = bid.ApplyTransactions(tx, mp);
         if (!UpdateBookProfiles(tx)) return false;
@@ -795,6 +799,7 @@ struct Env {
         TradeMap none;
         while (!market.IsOpen())
             if (!UpdateBookProfiles(none)) return false;
+        trades_from = cursor;  // time_and_sales.SkipUntil(market time), intraday.cpp:116
         while (!(f_ask_tx.full() && f_bid_tx.full() && f_vwap_numer.full() && f_vwap_denom.full() &&
                  f_volatility.full() && f_midprice.full() && tp_mp.full() && spread_window.full()))
             if (!NextState()) return false;

@@ -125,6 +125,9 @@ def load():
         "lob_default_gen_params": (None, [P(GenParams)]),
         "lob_gen_stream_host": (C.c_int, [P(GenParams), C.c_int32, C.c_int32, C.c_uint64, C.c_int32, vp]),
         "lob_validate_stream": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+        "lob_convert_csv": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int32, P(vp), P(C.c_int32)]),
+        "lob_convert_lobster": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, P(vp), P(C.c_int32)]),
+        "lob_free": (None, [vp]),
         "lob_create": (C.c_int, [P(Params), C.c_int32, C.c_int32, P(vp)]),
         "lob_destroy": (None, [vp]),
         "lob_load_events": (C.c_int, [vp, vp, C.c_int32]),

@@ -152,6 +152,7 @@ int check_device_errors(lob_engine* e) {
         if (flag & LOB_ERR_BAD_ORDER_PRICE) m += " [order price <= 0]";
         if (flag & LOB_ERR_BAD_LEVEL) m += " [level price/volume <= 0]";
         if (flag & LOB_ERR_UNDEF_PRICE) m += " [undefined book price]";
+        if (flag & LOB_ERR_TRADE_OVERFLOW) m += " [more trade price levels in one event than max_trades]";
         lob_set_error(m);
         return LOB_EDATA;
     }

@@ -451,18 +451,46 @@ __device__ inline void update_order(const EnvCtx& c, EnvR& e, int side, int last
     else { e.b_oqh = o.qh; e.b_oqt = o.qt; }
 }
 
-__device__ inline void load_trades(const EnvCtx& c, int rec, f64* tp, i64* tv) {
+// The trades one NextState sees: TimeAndSales::LoadUntil(next depth time)
+// (src/data/streamer.cpp:57-80, src/data/basic.cpp:148-181) hands over everything
+// up to the timestamp of the event's FIRST depth row that has not been consumed
+// yet, merged per 1e-4 price key.  Rows carry the trades of their own interval,
+// so an event whose predecessor swallowed several rows (same timestamp, invalid
+// states) merges the slots of rows lo..hi; normally lo == hi.
+__device__ inline void load_trades(const EnvCtx& c, int lo, int hi, f64* tp, i64* tv) {
     const DevParams& P = c.P;
-    const uint32_t* r = c.row(rec);
 #pragma unroll
-    for (int i = 0; i < LOB_MAX_TRADES; i++) {
-        if (i < P.T) {
+    for (int i = 0; i < LOB_MAX_TRADES; i++) { tp[i] = 0.0; tv[i] = 0; }
+    int n = 0;
+    for (int rec = lo; rec <= hi; rec++) {
+        const uint32_t* r = c.row(rec);
+        for (int i = 0; i < P.T; i++) {
             f32 p = __uint_as_float(r[lob_rec_trade_px(P.D, P.T) + i]);
             i32 v = (i32)r[lob_rec_trade_vol(P.D, P.T) + i];
-            bool ok = (p > 0.0f) && (v > 0);
-            tp[i] = ok ? (f64)p : 0.0;
-            tv[i] = ok ? (i64)v : 0;
-        } else { tp[i] = 0.0; tv[i] = 0; }
+            if (!((p > 0.0f) && (v > 0))) continue;
+            const f64 pd = (f64)p, k = key4(pd);
+            // std::map<double,long,FloatComparator>::operator[] += : find the key or insert in order
+            int pos = 0;
+            bool found = false;
+#pragma unroll
+            for (int q = 0; q < LOB_MAX_TRADES; q++) {
+                if (q < n) {
+                    const f64 kq = key4(tp[q]);
+                    if (kq == k) { tv[q] += (i64)v; found = true; }
+                    if (kq < k) pos = q + 1;
+                }
+            }
+            if (found) continue;
+            if (n >= P.T) { c.err(LOB_ERR_TRADE_OVERFLOW); continue; }
+#pragma unroll
+            for (int q = LOB_MAX_TRADES - 1; q > 0; q--) {
+                if (q > pos && q <= n) { tp[q] = tp[q - 1]; tv[q] = tv[q - 1]; }
+            }
+#pragma unroll
+            for (int q = 0; q < LOB_MAX_TRADES; q++)
+                if (q == pos) { tp[q] = pd; tv[q] = (i64)v; }
+            n++;
+        }
     }
 }
 
@@ -523,7 +551,7 @@ __device__ inline bool next_state(const EnvCtx& c, EnvR& e) {
     if (e.k >= M.n_track) {
         // out of data inside this event (Streamer::LoadNext fails, src/data/streamer.cpp:42-49)
         if (M.ex_first >= 0) {
-            load_trades(c, M.ex_first, tp, tv);
+            load_trades(c, (e.k > 0 ? c.track(e.k - 1).rec_first : M.rec_cur0) + 1, M.ex_first, tp, tv);
             match_orders(c, e, tp, tv, e.mid, au_vol, au_proxy, au_value, bu_vol, bu_proxy, bu_value);
             // rows applied before the stream ran dry still update the queue model
             for (int r = M.ex_first; r <= M.ex_cur && M.ex_cur >= M.ex_first; r++) {
@@ -539,7 +567,7 @@ __device__ inline bool next_state(const EnvCtx& c, EnvR& e) {
         return false;
     }
     const Track t = c.track(e.k);
-    load_trades(c, t.rec_first, tp, tv);
+    load_trades(c, (e.k > 0 ? c.track(e.k - 1).rec_first : M.rec_cur0) + 1, t.rec_first, tp, tv);
     const f64 mp = e.mid;
     match_orders(c, e, tp, tv, mp, au_vol, au_proxy, au_value, bu_vol, bu_proxy, bu_value);
     // UpdateBookProfiles: StashState, then ApplyChanges (-> UpdateOrder) for every applied row
@@ -797,12 +825,14 @@ __device__ inline void market_prepass(const EnvCtx& c, int replay) {
     M.mid0 = (m.ap0 + m.bp0) / 2.0; M.mid_prev0 = (m.lap0 + m.lbp0) / 2.0;
     if (!ok) { M.ex_cur = m.rec_cur; M.ex_last = m.rec_last; M.ex_time = m.time_ms; }
     int k = 0;
+    int prev_first = m.rec_cur;  // Initialise: time_and_sales.SkipUntil(market time) drops everything up to here
     while (ok) {
         if (replay > 0 && k >= replay) break;
         const int first = m.cursor;
         f64 tp[LOB_MAX_TRADES];
         i64 tv[LOB_MAX_TRADES];
-        load_trades(c, first, tp, tv);
+        load_trades(c, prev_first + 1, first, tp, tv);
+        prev_first = first;
         const f64 mp = (m.ap0 + m.bp0) / 2.0;
         // observed transaction value / volume of Ask/BidBook::ApplyTransactions (book.cpp:394-400, 479-485)
         m.a_obsval = 0.0; m.a_obsvol = 0; m.b_obsval = 0.0; m.b_obsvol = 0;

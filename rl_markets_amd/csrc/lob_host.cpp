@@ -4,7 +4,13 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <stdlib.h>
+
+#include <algorithm>
+#include <fstream>
+#include <map>
 #include <string>
+#include <vector>
 
 #include "lob_stream.h"
 #include "lob_internal.h"
@@ -238,6 +244,187 @@ int lob_validate_stream(const uint32_t* rec, int32_t D, int32_t T, int32_t n_boo
         }
     }
     return LOB_OK;
+}
+
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// Ingestion
+namespace {
+void split_csv(const std::string& line, std::vector<std::string>& cols) {  // utilities/csv.cpp:30-45
+    cols.clear();
+    size_t pos = 0;
+    while (true) {
+        size_t next = line.find(',', pos);
+        if (next == std::string::npos) { cols.push_back(line.substr(pos)); break; }
+        cols.push_back(line.substr(pos, next - pos));
+        pos = next + 1;
+    }
+}
+bool parse_time(const std::string& s, long& out) {  // utilities/time.h:28-39 "HH:MM:SS.mmm"
+    if (s.size() < 12) return false;
+    out = atol(s.substr(0, 2).c_str()) * 3600000L + atol(s.substr(3, 2).c_str()) * 60000L +
+          atol(s.substr(6, 2).c_str()) * 1000L + atol(s.substr(9, 3).c_str());
+    return true;
+}
+struct Snap {
+    long time;
+    float ap[LOB_MAX_DEPTH], bp[LOB_MAX_DEPTH];
+    int32_t av[LOB_MAX_DEPTH], bv[LOB_MAX_DEPTH];
+};
+struct Trade { long time; float price; long size; };
+
+int emit_records(const std::vector<Snap>& snaps, const std::vector<Trade>& trades, int D, int T, uint32_t** out, int32_t* n) {
+    const int W = lob_rec_words(D, T);
+    const size_t N = snaps.size();
+    if (N < 2) { lob_set_error("convert: fewer than 2 usable depth rows"); return LOB_EDATA; }
+    uint32_t* rec = (uint32_t*)calloc(N * W, 4);
+    if (!rec) return LOB_ENOMEM;
+    size_t ti = 0;
+    char buf[160];
+    for (size_t r = 0; r < N; r++) {
+        uint32_t* w = rec + r * W;
+        const Snap& s = snaps[r];
+        if (r > 0 && s.time < snaps[r - 1].time) { free(rec); lob_set_error("convert: depth rows go backwards in time"); return LOB_EDATA; }
+        w[LOB_REC_TIME] = (uint32_t)(int32_t)s.time;
+        w[LOB_REC_FLAGS] = (r + 1 < N && snaps[r + 1].time == s.time) ? LOB_EVT_FLAG_SAME_TIME : 0;
+        // levels best -> worst (the reference sorts them itself, book.cpp:86)
+        std::vector<std::pair<float, int32_t>> a, b;
+        for (int l = 0; l < D; l++) { a.push_back({s.ap[l], s.av[l]}); b.push_back({s.bp[l], s.bv[l]}); }
+        std::stable_sort(a.begin(), a.end(), [](const std::pair<float, int32_t>& x, const std::pair<float, int32_t>& y) { return rint((double)x.first * 10000) < rint((double)y.first * 10000); });
+        std::stable_sort(b.begin(), b.end(), [](const std::pair<float, int32_t>& x, const std::pair<float, int32_t>& y) { return rint((double)x.first * 10000) > rint((double)y.first * 10000); });
+        for (int l = 0; l < D; l++) {
+            w[lob_rec_ask_px(D, T) + l] = lob_f32_bits(a[l].first);
+            w[lob_rec_ask_vol(D, T) + l] = (uint32_t)a[l].second;
+            w[lob_rec_bid_px(D, T) + l] = lob_f32_bits(b[l].first);
+            w[lob_rec_bid_vol(D, T) + l] = (uint32_t)b[l].second;
+        }
+        // trades of (previous depth time, this depth time], per 1e-4 key, first-seen price kept (std::map semantics)
+        std::map<long long, std::pair<float, long>> agg;
+        while (ti < trades.size() && trades[ti].time <= s.time) {
+            const Trade& t = trades[ti++];
+            long long key = (long long)rint((double)t.price * 10000);
+            auto it = agg.find(key);
+            if (it == agg.end()) agg[key] = {t.price, t.size};
+            else it->second.second += t.size;
+        }
+        if ((int)agg.size() > T) {
+            free(rec);
+            snprintf(buf, sizeof buf, "convert: %zu trade price levels before depth row %zu, max_trades is %d", agg.size(), r, T);
+            lob_set_error(buf);
+            return LOB_EDATA;
+        }
+        int i = 0;
+        for (auto& kv : agg) {
+            w[lob_rec_trade_px(D, T) + i] = lob_f32_bits(kv.second.first);
+            w[lob_rec_trade_vol(D, T) + i] = (uint32_t)kv.second.second;
+            i++;
+        }
+    }
+    int rc = lob_validate_stream(rec, D, T, 1, (int32_t)N);
+    if (rc != LOB_OK) { free(rec); return rc; }
+    *out = rec;
+    *n = (int32_t)N;
+    return LOB_OK;
+}
+}  // namespace
+
+extern "C" {
+
+void lob_free(void* p) { free(p); }
+
+int lob_convert_csv(const char* md_path, const char* tas_path, int32_t T, uint32_t** out, int32_t* n) {
+    if (!md_path || !tas_path || !out || !n || T < 1 || T > LOB_MAX_TRADES) { lob_set_error("lob_convert_csv: bad argument"); return LOB_EINVAL; }
+    std::ifstream md(md_path), ts(tas_path);
+    if (!md.is_open() || !ts.is_open()) { lob_set_error("lob_convert_csv: cannot open input (the reference exits, utilities/csv.cpp:16-19)"); return LOB_EINVAL; }
+    std::string line;
+    std::vector<std::string> c;
+    std::vector<Snap> snaps;
+    int date0 = 0;
+    std::getline(md, line);  // header
+    while (std::getline(md, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (line.empty()) continue;
+        split_csv(line, c);
+        if (c.size() != 22) { lob_set_error("lob_convert_csv: depth row without 22 columns"); return LOB_EDATA; }
+        Snap s;
+        int date = atoi(c[0].c_str());
+        if (!date0) date0 = date;
+        if (date != date0) { lob_set_error("lob_convert_csv: more than one date in the depth file (one episode = one day)"); return LOB_EDATA; }
+        if (!parse_time(c[1], s.time)) { lob_set_error("lob_convert_csv: bad time"); return LOB_EDATA; }
+        bool ok = true;
+        for (int i = 0; i < 5 && ok; i++) {
+            s.ap[i] = strtof(c[2 + i].c_str(), nullptr);   // stof: float32 prices (quirk Q8)
+            s.bp[i] = strtof(c[12 + i].c_str(), nullptr);
+            if (s.ap[i] <= 0.0f || s.bp[i] <= 0.0f) { ok = false; break; }  // row dropped (basic.cpp:54-58)
+            s.av[i] = (int32_t)atol(c[7 + i].c_str());
+            s.bv[i] = (int32_t)atol(c[17 + i].c_str());
+        }
+        if (ok) snaps.push_back(s);
+    }
+    std::vector<Trade> trades;
+    std::getline(ts, line);
+    while (std::getline(ts, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (line.empty()) continue;
+        split_csv(line, c);
+        if (c.size() != 4) { lob_set_error("lob_convert_csv: trade row without 4 columns"); return LOB_EDATA; }
+        Trade t;
+        if (!parse_time(c[1], t.time)) { lob_set_error("lob_convert_csv: bad time"); return LOB_EDATA; }
+        t.price = strtof(c[2].c_str(), nullptr);
+        t.size = atol(c[3].c_str());
+        if (t.price > 0.0f && t.size > 0) trades.push_back(t);  // basic.cpp:156-157
+    }
+    std::stable_sort(trades.begin(), trades.end(), [](const Trade& a, const Trade& b) { return a.time < b.time; });
+    return emit_records(snaps, trades, 5, T, out, n);
+}
+
+int lob_convert_lobster(const char* ob_path, const char* msg_path, int32_t L, int32_t D, int32_t T, uint32_t** out, int32_t* n) {
+    if (!ob_path || !msg_path || !out || !n || L < 1 || D < 1 || D > L || D > LOB_MAX_DEPTH || T < 1 || T > LOB_MAX_TRADES) {
+        lob_set_error("lob_convert_lobster: bad argument");
+        return LOB_EINVAL;
+    }
+    std::ifstream ob(ob_path), msg(msg_path);
+    if (!ob.is_open() || !msg.is_open()) { lob_set_error("lob_convert_lobster: cannot open input"); return LOB_EINVAL; }
+    std::string lo, lm;
+    std::vector<std::string> co, cm;
+    std::vector<Snap> snaps;
+    std::vector<Trade> trades;
+    while (std::getline(ob, lo) && std::getline(msg, lm)) {
+        if (!lo.empty() && lo.back() == '\r') lo.pop_back();
+        if (!lm.empty() && lm.back() == '\r') lm.pop_back();
+        if (lo.empty() || lm.empty()) continue;
+        split_csv(lo, co);
+        split_csv(lm, cm);
+        if ((int)co.size() < 4 * L || cm.size() < 6) { lob_set_error("lob_convert_lobster: short row"); return LOB_EDATA; }
+        const double tsec = atof(cm[0].c_str());
+        const long tms = (long)floor(tsec * 1000.0 + 1e-6);
+        const int type = atoi(cm[1].c_str());
+        if (type == 4 || type == 5) {
+            Trade t;
+            t.time = tms;
+            t.price = (float)((double)atoll(cm[4].c_str()) / 10000.0);
+            t.size = atol(cm[3].c_str());
+            if (t.price > 0.0f && t.size > 0) trades.push_back(t);
+        }
+        Snap s;
+        s.time = tms;
+        bool ok = true;
+        for (int l = 0; l < D; l++) {
+            long long apx = atoll(co[4 * l + 0].c_str()), bpx = atoll(co[4 * l + 2].c_str());
+            long asz = atol(co[4 * l + 1].c_str()), bsz = atol(co[4 * l + 3].c_str());
+            if (apx <= 0 || bpx <= 0 || apx >= 9999999999LL || asz <= 0 || bsz <= 0) { ok = false; break; }  // LOBSTER dummy levels
+            s.ap[l] = (float)((double)apx / 10000.0);
+            s.bp[l] = (float)((double)bpx / 10000.0);
+            s.av[l] = (int32_t)asz;
+            s.bv[l] = (int32_t)bsz;
+        }
+        if (!ok) continue;
+        if (!snaps.empty() && snaps.back().time == tms) snaps.back() = s;  // keep the last snapshot of a millisecond
+        else snaps.push_back(s);
+    }
+    return emit_records(snaps, trades, D, T, out, n);
 }
 
 }  // extern "C"

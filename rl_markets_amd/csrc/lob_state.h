@@ -208,6 +208,7 @@ struct DevParams {
 
 #define LOB_ERR_BAD_ORDER_PRICE 1  /* Order ctor would throw (src/market/order.cpp:22-27) */
 #define LOB_ERR_BAD_LEVEL 2        /* ApplyChanges would throw (src/market/book.cpp:74-77) */
-#define LOB_ERR_UNDEF_PRICE 4      /* Book::price() would throw (src/market/book.cpp:171-173) */
+#define LOB_ERR_UNDEF_PRICE 4
+#define LOB_ERR_TRADE_OVERFLOW 8   /* more distinct trade price keys in one event than max_trades slots */      /* Book::price() would throw (src/market/book.cpp:171-173) */
 
 #endif

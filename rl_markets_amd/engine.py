@@ -56,6 +56,35 @@ def gen_stream_host(gen, depth, max_trades, first_book, n_books):
     return out
 
 
+def _take_records(lib, ptr, n, depth, max_trades):
+    W = lib.lob_record_words(depth, max_trades)
+    buf = (C.c_uint32 * (n * W)).from_address(ptr.value)
+    out = np.frombuffer(buf, dtype=np.uint32).reshape(1, n, W).copy()
+    lib.lob_free(ptr)
+    return out
+
+
+def convert_csv(md_path, tas_path, max_trades=2):
+    """The reference's CSV pair (5-level depth + time-and-sales) -> records[1][n][W]."""
+    lib = abi.load()
+    ptr, n = C.c_void_p(), C.c_int32()
+    rc = lib.lob_convert_csv(md_path.encode(), tas_path.encode(), max_trades, C.byref(ptr), C.byref(n))
+    if rc:
+        raise LobError(rc, lib.lob_last_error().decode())
+    return _take_records(lib, ptr, n.value, 5, max_trades)
+
+
+def convert_lobster(orderbook_path, message_path, levels_in_file, depth, max_trades=4):
+    """LOBSTER orderbook + message files -> records[1][n][W] (one record per millisecond)."""
+    lib = abi.load()
+    ptr, n = C.c_void_p(), C.c_int32()
+    rc = lib.lob_convert_lobster(orderbook_path.encode(), message_path.encode(), levels_in_file, depth, max_trades,
+                                 C.byref(ptr), C.byref(n))
+    if rc:
+        raise LobError(rc, lib.lob_last_error().decode())
+    return _take_records(lib, ptr, n.value, depth, max_trades)
+
+
 class Engine:
     def __init__(self, params, n_books, device=0):
         self.lib = abi.load()

@@ -117,6 +117,30 @@ def main():
             np.savez_compressed(os.path.join(HERE, "multi_%s.npz" % name), traj=traj, theta_idx=theta[0],
                                 theta_val=theta[1], steps=info["steps"], ends=np.array(info["ends"]), rng_ctr=info["rng_ctr"])
             print(name, info)
+        # ---- recorded-data path: the reference reading CSV files that contain same-timestamp
+        # depth rows, a crossed (invalid) book, multi-row trade hand-over (quirk Q14) ----
+        from tests.csv_io import write_reference_csvs
+        g.n_events = 420
+        rec = engine.gen_stream_host(g, 5, 2, 31, 1)[0].copy()
+        for r in (150, 151, 230, 305):          # rows sharing the previous row's timestamp
+            rec[r, 0] = rec[r - 1, 0]
+        for r in (180, 260):                     # crossed book: asks below bids -> IsValidState false
+            rec[r, 2:7], rec[r, 12:17] = rec[r, 12:17][::-1].copy(), rec[r, 2:7][::-1].copy()
+        md, tas = os.path.join(HERE, "q14_md.csv"), os.path.join(HERE, "q14_tas.csv")
+        write_reference_csvs(rec, 5, 2, md, tas)
+        out = os.path.join(td, "q14.traj")
+        th = os.path.join(td, "q14.theta")
+        res = run([HARNESS, "episode", "--md", md, "--tas", tas, "--algo", "sarsa", "--mem", str(1 << 20), "--seed", "1994",
+                   "--rng_stream", "31", "--eps", "0.8", "--out", out, "--theta_out", th, "--tmp", os.path.join(td, "q14h")])
+        import json
+        info = json.loads(res.strip().splitlines()[-1])
+        traj = np.fromfile(out, dtype=ol.STEP_DTYPE)
+        raw = np.fromfile(th, dtype=np.uint8)
+        nn = int(np.frombuffer(raw[:8].tobytes(), dtype=np.int64)[0])
+        pairs = np.frombuffer(raw[8:8 + 16 * nn].tobytes(), dtype=[("i", np.int64), ("v", np.float64)])
+        np.savez_compressed(os.path.join(HERE, "csv_q14.npz"), traj=traj, theta_idx=pairs["i"].copy(), theta_val=pairs["v"].copy(),
+                            steps=info["steps"], end=info["end"])
+        print("csv_q14", info)
     print("golden fixtures written to", HERE)
 
 
