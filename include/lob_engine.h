@@ -76,8 +76,12 @@ enum { LOB_TP_MIDPRICE = 0, LOB_TP_MICROPRICE = 1 };
 enum { LOB_QUOTE_TARGET = 0, LOB_QUOTE_BOOK = 1 };
 
 /* Learning algorithms: rl::SARSA (src/rl/agent.cpp:296-311),
- * rl::QLearn = Watkins Q(lambda) (src/rl/agent.cpp:268-292). */
-enum { LOB_ALGO_SARSA = 0, LOB_ALGO_QLAMBDA = 1 };
+ * rl::QLearn = Watkins Q(lambda) (src/rl/agent.cpp:268-292),
+ * rl::DoubleQLearn (src/rl/agent.cpp:185-264,315-353; config/example.yaml's default): a second
+ * weight vector theta_b (`which` = 1 in lob_theta_get/set for shared theta, book + n_books for
+ * private), actions from (Qa+Qb)/2, a coin flip per step from the agent's own
+ * std::mt19937_64 (seeded with seed + global book id) choosing which vector is updated. */
+enum { LOB_ALGO_SARSA = 0, LOB_ALGO_QLAMBDA = 1, LOB_ALGO_DOUBLE_Q = 2 };
 
 /* Weight sharing: one theta shared by all books of the engine (the batched
  * analogue of the reference's Hogwild threads, src/main.cpp:196-206), or one

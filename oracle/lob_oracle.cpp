@@ -11,6 +11,7 @@
 #include <deque>
 #include <map>
 #include <memory>
+#include <random>
 #include <stdexcept>
 #include <tuple>
 #include <unordered_map>
@@ -928,7 +929,10 @@ struct oracle_learner {
     int B;
     long M;
     std::vector<std::unique_ptr<Env>> env;
-    std::vector<std::vector<double>> theta;  // 1 (shared) or B (private)
+    std::vector<std::vector<double>> theta;    // 1 (shared) or B (private)
+    std::vector<std::vector<double>> theta_b;  // DoubleAgent::theta_b (agent.cpp:188)
+    std::vector<std::mt19937_64> agent_gen;    // Agent::gen (agent.cpp:31): the DoubleQLearn coin
+    std::vector<std::uniform_real_distribution<double>> agent_unif;
     std::vector<Traces> traces;
     // state / last_state per book (Runner::state1/state2)
     std::vector<std::vector<float>> vars, last_vars;
@@ -940,12 +944,13 @@ struct oracle_learner {
     int64_t n_steps_done = 0, n_updates = 0;
 
     double* th(int b) { return theta[P.theta_mode == LOB_THETA_PRIVATE ? b : 0].data(); }
+    double* thb(int b) { return theta_b[P.theta_mode == LOB_THETA_PRIVATE ? b : 0].data(); }
 
     uint64_t raw(int b) { return lob_rng(P.seed, P.book_id_offset + (uint64_t)b, rng_ctr[b]++); }
     int rnd(int b) { return (int)(raw(b) >> 33); }  // interposed libc rand()
 
-    double getQ(int b, const std::vector<std::vector<int>>& f, int action) {  // agent.cpp:117-135 (quirk Q3)
-        const double* t = th(b);
+    double getQ(int b, const std::vector<std::vector<int>>& f, int action, bool use_b = false) {  // agent.cpp:117-135 / getQb :206-227 (quirk Q3)
+        const double* t = use_b ? thb(b) : th(b);
         const std::vector<int>& ft = f[action];
         double Q = 0.0;
         double w = P.group_weights[0];
@@ -956,11 +961,11 @@ struct oracle_learner {
         for (int i = 32; i < 96; i++) Q += w * t[ft[i]];
         return Q;
     }
-    int argmaxQ(int b, const std::vector<std::vector<int>>& f) {  // agent.cpp:144-169
+    int argmaxQ(int b, const std::vector<std::vector<int>>& f, bool use_b = false) {  // agent.cpp:144-169 / argmaxQb :236-262
         int index = 0, n_ties = 1;
-        double cur = getQ(b, f, 0);
+        double cur = getQ(b, f, 0, use_b);
         for (int a = 1; a < 9; a++) {
-            double val = getQ(b, f, a);
+            double val = getQ(b, f, a, use_b);
             if (val >= cur) {
                 if (val > cur) { cur = val; index = a; }
                 else {
@@ -991,7 +996,10 @@ struct oracle_learner {
     }
     int action(int b, const std::vector<std::vector<int>>& f, bool greedy = false) {  // Agent::action, agent.cpp:67-74
         double qs[9];
-        for (int a = 0; a < 9; a++) qs[a] = getQ(b, f, a);
+        if (P.algo == LOB_ALGO_DOUBLE_Q)  // DoubleAgent::action, agent.cpp:196-204
+            for (int a = 0; a < 9; a++) qs[a] = (getQ(b, f, a) + getQ(b, f, a, true)) / 2.0f;
+        else
+            for (int a = 0; a < 9; a++) qs[a] = getQ(b, f, a);
         return policy_sample(b, qs, greedy);
     }
     void new_state(int b) {  // State::newState(env), state.cpp:35-43
@@ -1026,6 +1034,14 @@ oracle_learner* oracle_create(const lob_params* p, int32_t n_books, const uint32
         o->env.emplace_back(new Env(*p, records + (size_t)b * n_events * W, n_events));
     int nt = p->theta_mode == LOB_THETA_PRIVATE ? n_books : 1;
     o->theta.assign(nt, std::vector<double>((size_t)o->M, 0.0));
+    if (p->algo == LOB_ALGO_DOUBLE_Q) {
+        o->theta_b.assign(nt, std::vector<double>((size_t)o->M, 0.0));
+        for (int b = 0; b < n_books; b++) {
+            // gen(c["debug"]["random_seed"].as<unsigned>()), one agent per book: seed + global book id
+            o->agent_gen.emplace_back((unsigned)(p->seed + p->book_id_offset + (uint64_t)b));
+            o->agent_unif.emplace_back(0.0, 1.0);
+        }
+    }
     o->traces.resize(n_books);
     o->vars.resize(n_books);
     o->last_vars.resize(n_books);
@@ -1065,7 +1081,7 @@ int oracle_td_step(oracle_learner* o, int32_t n_steps) {
     const float rate = (float)(o->P.gamma * o->P.lambda);
     for (int s = 0; s < n_steps; s++) {
         std::vector<double> upd(o->B, 0.0);
-        std::vector<char> has(o->B, 0);
+        std::vector<char> has(o->B, 0);  // 1: update theta, 2: update theta_b
         for (int b = 0; b < o->B; b++) {
             if (o->done[b]) continue;
             Env& e = *o->env[b];
@@ -1085,7 +1101,22 @@ int oracle_td_step(oracle_learner* o, int32_t n_steps) {
             double reward = e.getReward();
             // HandleTransition: UpdateTraces, UpdateWeights (agent.cpp:86-115)
             double delta;
-            if (o->P.algo == LOB_ALGO_QLAMBDA) {
+            int target = 1;
+            if (o->P.algo == LOB_ALGO_DOUBLE_Q) {
+                int amax = o->argmaxQ(b, o->last_feats[b]);  // DoubleQLearn::UpdateTraces, agent.cpp:319-327
+                if (a != amax) o->traces[b].decay(0.0f);
+                else o->traces[b].decay(rate);
+                o->traces[b].update(o->last_feats[b], a, 9, 32);
+                double F_term = o->P.gamma * 0.0 - 0.0;
+                if (o->agent_unif[b](o->agent_gen[b]) > 0.5) {  // UPDATE(A), agent.cpp:334-342
+                    double Qa = o->getQ(b, o->last_feats[b], a);
+                    delta = reward + F_term + o->P.gamma * o->getQ(b, o->feats[b], o->argmaxQ(b, o->feats[b]), true) - Qa;
+                } else {  // UPDATE(B)
+                    double Qb = o->getQ(b, o->last_feats[b], a, true);
+                    delta = reward + F_term + o->P.gamma * o->getQ(b, o->feats[b], o->argmaxQ(b, o->feats[b], true)) - Qb;
+                    target = 2;
+                }
+            } else if (o->P.algo == LOB_ALGO_QLAMBDA) {
                 int amax = o->argmaxQ(b, o->last_feats[b]);  // QLearn::UpdateTraces, agent.cpp:272-280
                 if (a != amax) o->traces[b].decay(0.0f);
                 else o->traces[b].decay(rate);
@@ -1105,7 +1136,7 @@ int oracle_td_step(oracle_learner* o, int32_t n_steps) {
                 delta = reward + F + o->P.gamma * Q2 - Q1;
             }
             upd[b] = o->alpha * delta;
-            has[b] = 1;
+            has[b] = (char)target;
             o->n_steps_done++;
             o->record(b, a, reward, delta);
         }
@@ -1113,7 +1144,7 @@ int oracle_td_step(oracle_learner* o, int32_t n_steps) {
         for (int b = 0; b < o->B; b++) {
             if (!has[b]) continue;
             double scaled = upd[b] / 32;
-            double* t = o->th(b);
+            double* t = has[b] == 2 ? o->thb(b) : o->th(b);
             for (int f : o->traces[b].nonzero) t[f] += scaled * o->traces[b].get(f);
             o->n_updates++;
         }
@@ -1164,6 +1195,7 @@ void oracle_set_alpha(oracle_learner* o, double a) { o->alpha = a; }
 void oracle_set_epsilon(oracle_learner* o, double e) { o->epsilon = e; }
 void oracle_get_rec(oracle_learner* o, int32_t book, oracle_step_rec* out) { *out = o->recs[book]; }
 double* oracle_theta(oracle_learner* o, int32_t which) { return o->theta[which].data(); }
+double* oracle_theta_b(oracle_learner* o, int32_t which) { return o->theta_b.empty() ? nullptr : o->theta_b[which].data(); }
 int32_t oracle_get_traces(oracle_learner* o, int32_t b, int32_t* idx, float* e, int32_t cap) {
     int n = (int)o->traces[b].nonzero.size();
     for (int i = 0; i < n && i < cap; i++) {

@@ -55,6 +55,7 @@ void oracle_set_epsilon(oracle_learner* o, double e);
 /* last step's record for `book` */
 void oracle_get_rec(oracle_learner* o, int32_t book, oracle_step_rec* out);
 double* oracle_theta(oracle_learner* o, int32_t which);
+double* oracle_theta_b(oracle_learner* o, int32_t which);
 int32_t oracle_get_traces(oracle_learner* o, int32_t book, int32_t* idx, float* e, int32_t cap);
 void oracle_get_counters(oracle_learner* o, int64_t out[4]);
 

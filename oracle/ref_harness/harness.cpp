@@ -40,6 +40,28 @@
 #include <string>
 #include <vector>
 
+// DoubleAgent::theta_b is private (include/rl/agent.h:82) and the probes below read protected
+// members: widen access for the reference headers only.  Access specifiers do not change the
+// object layout the reference objects were compiled with.
+// (standard / shim headers first so that the widening below touches the reference only)
+#include <algorithm>
+#include <array>
+#include <deque>
+#include <exception>
+#include <functional>
+#include <iomanip>
+#include <iterator>
+#include <list>
+#include <random>
+#include <set>
+#include <sstream>
+#include <stdexcept>
+#include <tuple>
+#include <utility>
+#include <spdlog/spdlog.h>
+#include <yaml-cpp/yaml.h>
+#define private public
+#define protected public
 #include "environment/intraday.h"
 #include "experiment/serial.h"
 #include "market/market.h"
@@ -48,6 +70,8 @@
 #include "rl/state.h"
 #include "rl/tiles.h"
 #include "utilities/config.h"
+#undef private
+#undef protected
 
 #include "../../rl_markets_amd/csrc/lob_stream.h"  // record layout + lob_rng (inputs only)
 #include "../lob_oracle.h"                          // oracle_step_rec layout only
@@ -215,7 +239,7 @@ static void write_csvs(const std::vector<uint32_t>& rec, int D, int T, int n_eve
 
 static std::string make_yaml(const Args& a, const std::string& path) {
     std::ofstream f(path);
-    f << "debug:\n    inspect_books: false\n    random_seed: 1\n";
+    f << "debug:\n    inspect_books: false\n    random_seed: " << a.geti("agent_seed", 1) << "\n";
     f << "learning:\n";
     f << "    memory_size: " << a.geti("mem", 20000000) << "\n";
     f << "    n_tilings: 32\n    n_actions: 9\n";
@@ -256,6 +280,24 @@ static std::vector<uint32_t> load_book(const std::string& path, int D, int T, in
 
 // Trajectory record written per step: oracle_step_rec (oracle/lob_oracle.h).
 typedef oracle_step_rec StepRec;
+
+// sparse dump of DoubleAgent::theta_b (no-op for single-vector agents)
+static void dump_theta_b_impl(rl::DoubleAgent* ag, const std::string& path) {
+    double* tb = ag->theta_b;
+    long M = ag->MEMORY_SIZE;
+    FILE* f = fopen(path.c_str(), "wb");
+    int64_t n = 0;
+    for (long i = 0; i < M; i++) if (tb[i] != 0.0) n++;
+    fwrite(&n, 8, 1, f);
+    for (long i = 0; i < M; i++)
+        if (tb[i] != 0.0) { int64_t idx = i; fwrite(&idx, 8, 1, f); fwrite(&tb[i], 8, 1, f); }
+    fclose(f);
+}
+static void dump_theta_b_impl(void*, const std::string&) {}
+template <class A> static void dump_theta_b(A& ag, const std::string& path) {
+    typedef typename std::conditional<std::is_base_of<rl::DoubleAgent, A>::value, rl::DoubleAgent*, void*>::type P;
+    dump_theta_b_impl((P)&ag, path);
+}
 
 template <class AGENT>
 static int run_episode(const Args& a, Config& c, ProbeEnv& env, const std::string& out_path) {
@@ -335,6 +377,9 @@ static int run_episode(const Args& a, Config& c, ProbeEnv& env, const std::strin
                 fwrite(&agent.theta_ptr()[i], 8, 1, f);
             }
         fclose(f);
+    }
+    if (a.kv.count("theta_b_out")) {
+        dump_theta_b(agent, a.get("theta_b_out"));
     }
     if (a.kv.count("traces_out")) {
         FILE* f = fopen(a.get("traces_out").c_str(), "wb");
@@ -485,10 +530,12 @@ int main(int argc, char** argv) {
     if (mode == "episode") {
         if (algo == "sarsa") rc = run_episode<rl::SARSA>(a, c, env, a.get("out", tmp + ".traj"));
         else if (algo == "q_learn") rc = run_episode<rl::QLearn>(a, c, env, a.get("out", tmp + ".traj"));
+        else if (algo == "double_q_learn") rc = run_episode<rl::DoubleQLearn>(a, c, env, a.get("out", tmp + ".traj"));
         else { fprintf(stderr, "unknown algo\n"); rc = 2; }
     } else if (mode == "learner") {
         if (algo == "sarsa") rc = run_learner<rl::SARSA>(a, c, env);
         else if (algo == "q_learn") rc = run_learner<rl::QLearn>(a, c, env);
+        else if (algo == "double_q_learn") rc = run_learner<rl::DoubleQLearn>(a, c, env);
         else { fprintf(stderr, "unknown algo\n"); rc = 2; }
     } else {
         fprintf(stderr, "unknown mode %s\n", mode.c_str());

@@ -175,6 +175,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     if (p->n_vars < 4 || p->n_vars > LOB_MAX_VARS) { lob_set_error("lob_create: n_vars must be in [4,13]"); return LOB_EINVAL; }
     if (p->memory_size < 1 || p->memory_size >= (1LL << 31)) { lob_set_error("lob_create: memory_size out of range"); return LOB_EINVAL; }
     if (p->market.n_bands < 1 || p->market.n_bands > LOB_MAX_BANDS) { lob_set_error("lob_create: bad tick table"); return LOB_EINVAL; }
+    if (p->algo < LOB_ALGO_SARSA || p->algo > LOB_ALGO_DOUBLE_Q) { lob_set_error("lob_create: unknown algorithm"); return LOB_EINVAL; }
     if (p->reward_measure == LOB_REWARD_MM_EXP) { lob_set_error("lob_create: reward mm_exp not implemented (SURVEY.md §8f N4)"); return LOB_EINVAL; }
     const int lbs[] = {p->lb_mpm, p->lb_vlt, p->lb_svl, p->lb_vwap, p->lb_rsi, p->lb_spread, p->lb_pnl, p->lb_target};
     for (int w : lbs)
@@ -283,6 +284,13 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     if (rc == LOB_OK) rc = dev_alloc(e, &S.tr_alive, B * LOB_TRACE_GENS);
     if (rc == LOB_OK) rc = dev_alloc(e, &S.theta, (size_t)P.M * (P.theta_private ? B : 1));
     if (rc == LOB_OK) rc = dev_alloc(e, &S.theta_nz, (size_t)((P.M + 31) >> 5) * (P.theta_private ? B : 1));
+    if (p->algo == LOB_ALGO_DOUBLE_Q) {
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.theta_b, (size_t)P.M * (P.theta_private ? B : 1));
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.theta_b_nz, (size_t)((P.M + 31) >> 5) * (P.theta_private ? B : 1));
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.qs_last_b, B * LOB_N_ACTIONS);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.mt_state, B * LOB_MT_N);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.mt_idx, B);
+    }
     if (rc == LOB_OK) rc = dev_alloc(e, &S.counters, 8);
     if (rc == LOB_OK) rc = dev_alloc(e, &S.error_flag, 1);
     if (rc == LOB_OK) rc = dev_alloc(e, &e->rnd_dev, 2048 + 64);
@@ -311,6 +319,11 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
                 terms[g * LOB_N_ACTIONS + a] = rnd[((g * LOB_N_ACTIONS + a) + 449 * (nf + 1)) & 2047];
         }
         HIPCHK(hipMemcpyAsync(e->rnd_dev, rnd, sizeof rnd, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+    }
+    if (p->algo == LOB_ALGO_DOUBLE_Q) {
+        hipLaunchKernelGGL(mt_init_kernel, dim3(grid_lanes(e->B)), dim3(256), 0, e->stream, e->P, e->S);
+        HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(e->stream));
     }
     *out = e;
@@ -584,21 +597,35 @@ static int features_impl(lob_engine* e, const float* host_vars, int32_t n, int32
 int lob_features(lob_engine* e, const float* host_vars, int32_t n, int32_t* host_out) { return features_impl(e, host_vars, n, host_out, nullptr); }
 int lob_q_values(lob_engine* e, const float* host_vars, int32_t n, double* host_out) { return features_impl(e, host_vars, n, nullptr, host_out); }
 
+// `which`: shared theta: 0 = theta, 1 = theta_b (double Q); private theta: book, or n_books + book for theta_b
+static int theta_slot(lob_engine* e, int32_t which, f64** th, uint32_t** nz) {
+    const int n = e->P.theta_private ? e->B : 1;
+    const bool dq = e->P.algo == LOB_ALGO_DOUBLE_Q;
+    if (which < 0 || which >= (dq ? 2 * n : n)) { lob_set_error("lob_theta_*: `which` out of range"); return LOB_EINVAL; }
+    const bool second = which >= n;
+    const int idx = second ? which - n : which;
+    *th = (second ? e->S.theta_b : e->S.theta) + (size_t)idx * e->P.M;
+    *nz = (second ? e->S.theta_b_nz : e->S.theta_nz) + (size_t)idx * (size_t)((e->P.M + 31) >> 5);
+    return LOB_OK;
+}
 int lob_theta_get(lob_engine* e, int32_t which, double* host_out, int64_t count) {
     if (!e || !host_out || count < 0 || count > e->P.M) return LOB_EINVAL;
-    if (which < 0 || which >= (e->P.theta_private ? e->B : 1)) return LOB_EINVAL;
+    f64* th; uint32_t* nz;
+    int rc = theta_slot(e, which, &th, &nz);
+    if (rc) return rc;
     HIPCHK(hipSetDevice(e->device));
-    HIPCHK(hipMemcpyAsync(host_out, e->S.theta + (size_t)which * e->P.M, (size_t)count * 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(host_out, th, (size_t)count * 8, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     return LOB_OK;
 }
 int lob_theta_set(lob_engine* e, int32_t which, const double* host_in, int64_t count) {
     if (!e || !host_in || count < 0 || count > e->P.M) return LOB_EINVAL;
-    if (which < 0 || which >= (e->P.theta_private ? e->B : 1)) return LOB_EINVAL;
+    f64* th; uint32_t* nz;
+    int rc = theta_slot(e, which, &th, &nz);
+    if (rc) return rc;
     HIPCHK(hipSetDevice(e->device));
-    HIPCHK(hipMemcpyAsync(e->S.theta + (size_t)which * e->P.M, host_in, (size_t)count * 8, hipMemcpyHostToDevice, e->stream));
-    hipLaunchKernelGGL(rebuild_nz_kernel, dim3(1024), dim3(256), 0, e->stream, (const f64*)(e->S.theta + (size_t)which * e->P.M),
-                       e->S.theta_nz + (size_t)which * (size_t)((e->P.M + 31) >> 5), e->P.M);
+    HIPCHK(hipMemcpyAsync(th, host_in, (size_t)count * 8, hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(rebuild_nz_kernel, dim3(1024), dim3(256), 0, e->stream, (const f64*)th, nz, e->P.M);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(e->stream));
     return LOB_OK;
@@ -686,6 +713,7 @@ int lob_get_counters(lob_engine* e, int64_t out[4]) {
 int lob_delta_init(lob_engine* e) {
     if (!e) return LOB_EINVAL;
     if (e->P.theta_private) { lob_set_error("lob_delta_*: shared theta only"); return LOB_EINVAL; }
+    if (e->P.algo == LOB_ALGO_DOUBLE_Q) { lob_set_error("lob_delta_*: not implemented for double Q yet"); return LOB_EINVAL; }
     HIPCHK(hipSetDevice(e->device));
     if (!e->S.theta_sync) {
         int rc = dev_alloc(e, &e->S.theta_sync, (size_t)e->P.M);

@@ -273,11 +273,21 @@ __global__ void __launch_bounds__(LOB_BLOCK) act_kernel(DevParams P, DevState S,
     const bool zero = mode == 0 && ((h.zero_mask >> src) & 1);
     const f64* theta = S.theta + (P.theta_private ? (size_t)b * (size_t)P.M : 0);
     f64 qs[LOB_N_ACTIONS];
-    const uint32_t* nz = S.theta_nz + (P.theta_private ? (size_t)b * (size_t)((P.M + 31) >> 5) : 0);
+    const size_t nz_off = P.theta_private ? (size_t)b * (size_t)((P.M + 31) >> 5) : 0;
+    const uint32_t* nz = S.theta_nz + nz_off;
     q_values(P, theta, nz, L.vars[w][src], zero, L.rnd, L.act_terms, L.vals[w], lane, qs);
+    if (lane < LOB_N_ACTIONS) S.qs_last[(size_t)b * LOB_N_ACTIONS + lane] = qs[lane];
+    if (P.algo == LOB_ALGO_DOUBLE_Q) {
+        // DoubleAgent::action (agent.cpp:196-204): qs[a] = (getQ + getQb) / 2.0f
+        f64 qb[LOB_N_ACTIONS];
+        q_values(P, S.theta_b + (P.theta_private ? (size_t)b * (size_t)P.M : 0), S.theta_b_nz + nz_off, L.vars[w][src], zero,
+                 L.rnd, L.act_terms, L.vals[w], lane, qb);
+        if (lane < LOB_N_ACTIONS) S.qs_last_b[(size_t)b * LOB_N_ACTIONS + lane] = qb[lane];
+#pragma unroll
+        for (int a = 0; a < LOB_N_ACTIONS; a++) qs[a] = (qs[a] + qb[a]) / 2.0;
+    }
     Rng g{P.seed, P.book_id_offset + (u64)b, h.rng_ctr};
     const int action = policy_sample(qs, P.epsilon, mode == 1, g);
-    if (lane < LOB_N_ACTIONS) S.qs_last[(size_t)b * LOB_N_ACTIONS + lane] = qs[lane];
     if (lane == 0) {
         hp->slot_cur = cur;
         hp->action = action;
@@ -286,6 +296,12 @@ __global__ void __launch_bounds__(LOB_BLOCK) act_kernel(DevParams P, DevState S,
     }
 }
 
+__device__ inline f64 sel9(const f64* q, int k) {
+    f64 r = q[0];
+#pragma unroll
+    for (int a = 1; a < LOB_N_ACTIONS; a++) r = k == a ? q[a] : r;
+    return r;
+}
 __device__ inline i32 sel5(const i32* f, int k) {
     i32 r = f[0];
     r = k == 1 ? f[1] : r;
@@ -336,8 +352,8 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
     int n_old = h.tr_n;
     const int head = h.tr_head;
     int kmax = P.trace_kmax;
-    if (P.algo == LOB_ALGO_QLAMBDA) {
-        const int amax = argmax_ties(qs_last, g);  // QLearn::UpdateTraces (agent.cpp:272-280)
+    if (P.algo == LOB_ALGO_QLAMBDA || P.algo == LOB_ALGO_DOUBLE_Q) {
+        const int amax = argmax_ties(qs_last, g);  // QLearn / DoubleQLearn::UpdateTraces (agent.cpp:272-280, 319-327)
         if (action != amax) kmax = 1;              // traces.decay(0.0)
     }
     if (n_old > kmax - 1) n_old = kmax - 1;        // generations whose eligibility fell below tolerance
@@ -424,20 +440,44 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
 
     // ---- UpdateWeights: TD error under theta_t ----
     const f64* theta = S.theta + (P.theta_private ? (size_t)b * (size_t)P.M : 0);
+    const size_t nz_off = P.theta_private ? (size_t)b * (size_t)((P.M + 31) >> 5) : 0;
+    const uint32_t* nz = S.theta_nz + nz_off;
     f64 qs_to[LOB_N_ACTIONS];
-    const uint32_t* nz = S.theta_nz + (P.theta_private ? (size_t)b * (size_t)((P.M + 31) >> 5) : 0);
     q_values(P, theta, nz, vars_to, false, L.rnd, L.act_terms, L.vals[w], lane, qs_to);
     const f64 reward = h.reward;
-    const f64 Q1 = qs_last[0 * 0 + (action < LOB_N_ACTIONS ? action : 0)];
     f64 delta;
+    int target = 1;
     const f64 F_term = P.gamma * 0.0 - 0.0;  // potentials are identically 0 (base.cpp:239-242)
-    if (P.algo == LOB_ALGO_QLAMBDA) {
+    if (P.algo == LOB_ALGO_DOUBLE_Q) {
+        // DoubleQLearn::UpdateWeights (agent.cpp:329-353)
+        f64 qb_to[LOB_N_ACTIONS];
+        q_values(P, S.theta_b + (P.theta_private ? (size_t)b * (size_t)P.M : 0), S.theta_b_nz + nz_off, vars_to, false, L.rnd,
+                 L.act_terms, L.vals[w], lane, qb_to);
+        // the coin: unif_dist(gen) > 0.5 on the agent's own std::mt19937_64
+        u64* mt = S.mt_state + (size_t)b * LOB_MT_N;
+        int mi = S.mt_idx[b];
+        if (mi >= LOB_MT_N) { mt64_twist_wave(mt, reinterpret_cast<u64*>(L.vals[w]), lane); mi = 0; }
+        const f64 coin = mt64_canonical(mt64_temper(mt[mi]));
+        if (lane == 0) S.mt_idx[b] = mi + 1;
+        if (coin > 0.5) {  // UPDATE(A)
+            const int am = argmax_ties(qs_to, g);
+            delta = reward + F_term + P.gamma * sel9(qb_to, am) - sel9(qs_last, action);
+        } else {           // UPDATE(B)
+            f64 qb_last[LOB_N_ACTIONS];
+#pragma unroll
+            for (int a = 0; a < LOB_N_ACTIONS; a++) qb_last[a] = S.qs_last_b[(size_t)b * LOB_N_ACTIONS + a];
+            const int am = argmax_ties(qb_to, g);
+            delta = reward + F_term + P.gamma * sel9(qs_to, am) - sel9(qb_last, action);
+            target = 2;
+        }
+    } else if (P.algo == LOB_ALGO_QLAMBDA) {
         const int am2 = argmax_ties(qs_to, g);  // maxQ(to_state)
-        delta = reward + F_term + P.gamma * qs_to[am2] - Q1;
+        delta = reward + F_term + P.gamma * sel9(qs_to, am2) - sel9(qs_last, action);
     } else {
         const int a2 = policy_sample(qs_to, P.epsilon, false, g);  // this->action(to_state), quirk Q9
-        delta = reward + F_term + P.gamma * qs_to[a2] - Q1;
+        delta = reward + F_term + P.gamma * sel9(qs_to, a2) - sel9(qs_last, action);
     }
+    if (lane == 0 && target == 2) hp->stepped = 2;  // update_kernel scatters into theta_b
     if (lane == 0) {
         hp->td = delta;
         hp->upd = P.alpha * delta;
@@ -454,8 +494,8 @@ __global__ void __launch_bounds__(LOB_BLOCK) update_kernel(DevParams P, DevState
     if (!h.stepped) return;
     const int n = h.tr_n, head = h.tr_head;
     const f64 scaled = h.upd / (f64)LOB_N_TILINGS;
-    f64* theta = S.theta + (P.theta_private ? (size_t)b * (size_t)P.M : 0);
-    uint32_t* nz = S.theta_nz + (P.theta_private ? (size_t)b * (size_t)((P.M + 31) >> 5) : 0);
+    f64* theta = (h.stepped == 2 ? S.theta_b : S.theta) + (P.theta_private ? (size_t)b * (size_t)P.M : 0);
+    uint32_t* nz = (h.stepped == 2 ? S.theta_b_nz : S.theta_nz) + (P.theta_private ? (size_t)b * (size_t)((P.M + 31) >> 5) : 0);
     const i32* tr_idx = S.tr_idx + (size_t)b * LOB_TRACE_GENS * 32;
     const uint32_t* tr_alive = S.tr_alive + (size_t)b * LOB_TRACE_GENS;
     const int j = lane & 31, half = lane >> 5;
@@ -472,6 +512,14 @@ __global__ void __launch_bounds__(LOB_BLOCK) update_kernel(DevParams P, DevState
             }
         }
     }
+}
+
+// Agent::gen(seed) for every book: std::mt19937_64 seeded with (unsigned)(seed + global book id)
+__global__ void mt_init_kernel(DevParams P, DevState S) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= S.B) return;
+    mt64_seed(S.mt_state + (size_t)b * LOB_MT_N, (u64)(uint32_t)(P.seed + P.book_id_offset + (u64)b));
+    S.mt_idx[b] = LOB_MT_N;  // first draw regenerates the block
 }
 
 // Agent::HandleTerminal: traces.decay(0.0) (agent.cpp:103-109)

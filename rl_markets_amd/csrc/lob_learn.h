@@ -183,4 +183,76 @@ __device__ inline void q_values(const DevParams& P, const f64* __restrict__ thet
     __builtin_amdgcn_wave_barrier();
 }
 
+
+// ---- std::mt19937_64 (the reference's Agent::gen, include/rl/agent.h:37; C++ standard
+// [rand.predef]: w=64 n=312 m=156 r=31 a=0xB5026F5AA96619E9 u=29 d=0x5555555555555555 s=17
+// b=0x71D67FFFEDA60000 t=37 c=0xFFF7EEE000000000 l=43 f=6364136223846793005) ----------------
+#define LOB_MT_N 312
+#define LOB_MT_M 156
+__host__ __device__ inline void mt64_seed(u64* x, u64 seed) {
+    x[0] = seed;
+    for (int i = 1; i < LOB_MT_N; i++) x[i] = 6364136223846793005ull * (x[i - 1] ^ (x[i - 1] >> 62)) + (u64)i;
+}
+__device__ inline u64 mt64_mix(u64 xi, u64 xi1, u64 xm) {
+    const u64 y = (xi & 0xFFFFFFFF80000000ull) | (xi1 & 0x7FFFFFFFull);
+    return xm ^ (y >> 1) ^ ((y & 1ull) ? 0xB5026F5AA96619E9ull : 0ull);
+}
+// Regenerate the 312-word block, one wave, state staged in LDS (`lds`, >= 312 u64).
+// The sequential recurrence reads x[i+1] (old) and x[i+156] (old for i < 156, new
+// afterwards): three phases, every phase reads all its inputs before writing.
+__device__ inline void mt64_twist_wave(u64* gstate, u64* lds, int lane) {
+    for (int i = lane; i < LOB_MT_N; i += 64) lds[i] = gstate[i];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    u64 r[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int i = lane + 64 * k;
+        r[k] = i < LOB_MT_M ? mt64_mix(lds[i], lds[i + 1], lds[i + LOB_MT_M]) : 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int i = lane + 64 * k;
+        if (i < LOB_MT_M) lds[i] = r[k];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int i = LOB_MT_M + lane + 64 * k;
+        r[k] = i < LOB_MT_N - 1 ? mt64_mix(lds[i], lds[i + 1], lds[i - LOB_MT_M]) : 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int i = LOB_MT_M + lane + 64 * k;
+        if (i < LOB_MT_N - 1) lds[i] = r[k];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) lds[LOB_MT_N - 1] = mt64_mix(lds[LOB_MT_N - 1], lds[0], lds[LOB_MT_M - 1]);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < LOB_MT_N; i += 64) gstate[i] = lds[i];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ inline u64 mt64_temper(u64 z) {
+    z ^= (z >> 29) & 0x5555555555555555ull;
+    z ^= (z << 17) & 0x71D67FFFEDA60000ull;
+    z ^= (z << 37) & 0xFFF7EEE000000000ull;
+    z ^= (z >> 43);
+    return z;
+}
+// std::uniform_real_distribution<double>(0,1)(mt19937_64) in libstdc++ =
+// generate_canonical<double,53>: one draw, double(u) / 2^64, clamped below 1.
+__device__ inline f64 mt64_canonical(u64 u) {
+    f64 r = (f64)u * 5.421010862427522e-20;  // 2^-64
+    if (r >= 1.0) r = 0.99999999999999989;   // nextafter(1.0, 0.0)
+    return r;
+}
+
 #endif

@@ -172,6 +172,11 @@ struct DevState {
     uint32_t* tr_alive;  // [B][LOB_TRACE_GENS]
 
     f64* theta;       // [M] or [B][M]
+    f64* theta_b;        // DoubleAgent::theta_b (LOB_ALGO_DOUBLE_Q), same shape as theta, or null
+    uint32_t* theta_b_nz;
+    f64* qs_last_b;      // [B][9] Qb(last_state, .)
+    u64* mt_state;       // [B][312] std::mt19937_64 state of each book's Agent::gen (DoubleQLearn coin)
+    i32* mt_idx;         // [B]
     uint32_t* theta_nz;  // bitmap, bit i set once theta[i] has ever been written: clear bit => theta[i] == +0.0
     f64* theta_sync;  // [M] (multi-GPU) or null
     f64* delta;       // [M] scratch for the all-reduce or null

@@ -186,7 +186,8 @@ public:
         std::string algo = str("learning.algorithm", "sarsa");
         if (algo == "sarsa") p.algo = LOB_ALGO_SARSA;
         else if (algo == "q_learn") p.algo = LOB_ALGO_QLAMBDA;
-        else throw std::invalid_argument("Unknown learning algorithm: " + algo + " (hot path: sarsa, q_learn; SURVEY.md §8f)");
+        else if (algo == "double_q_learn") p.algo = LOB_ALGO_DOUBLE_Q;
+        else throw std::invalid_argument("Unknown learning algorithm: " + algo + " (supported: sarsa, q_learn, double_q_learn; R-learning is out of scope, SURVEY.md §2 row 14)");
         p.seed = (uint64_t)integer("debug.random_seed", 1994);
         return p;
     }

@@ -109,6 +109,20 @@ def main():
             np.savez_compressed(os.path.join(HERE, "traj_%s.npz" % name), traj=traj, theta_idx=theta[0],
                                 theta_val=theta[1], steps=info["steps"], end=info["end"], rng_ctr=info["rng_ctr"])
             print(name, info)
+        # ---- DoubleQLearn (config/example.yaml's default algorithm): theta_b + the agent's own mt19937_64 coin ----
+        for name, n_events, book in (("double_q_b4", 520, 4), ("double_q_b17", 400, 17)):
+            g.n_events = n_events
+            rec = engine.gen_stream_host(g, 5, 2, book, 1)
+            tb = os.path.join(td, "theta_b.bin")
+            traj, info, theta = ol.run_ref_episode(rec[0], algo="double_q_learn", mem=1 << 20, rng_stream=book,
+                                                   extra={"agent_seed": 1994 + book, "theta_b_out": tb})
+            raw = np.fromfile(tb, dtype=np.uint8)
+            nn = int(np.frombuffer(raw[:8].tobytes(), dtype=np.int64)[0])
+            pairs = np.frombuffer(raw[8:8 + 16 * nn].tobytes(), dtype=[("i", np.int64), ("v", np.float64)])
+            np.savez_compressed(os.path.join(HERE, "traj_%s.npz" % name), traj=traj, theta_idx=theta[0], theta_val=theta[1],
+                                theta_b_idx=pairs["i"].copy(), theta_b_val=pairs["v"].copy(), steps=info["steps"],
+                                end=info["end"], rng_ctr=info["rng_ctr"])
+            print(name, info, "theta_b nonzeros", nn)
         # ---- multi-episode runs: Runner::RunEpisode x N on one agent (quirks Q7, Q19) ----
         for name, algo, n_events, book, extra in MULTI_CASES:
             g.n_events = n_events

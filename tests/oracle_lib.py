@@ -67,6 +67,8 @@ def load():
     lib.oracle_get_rec.argtypes = [vp, C.c_int32, P(StepRec)]
     lib.oracle_theta.restype = P(C.c_double)
     lib.oracle_theta.argtypes = [vp, C.c_int32]
+    lib.oracle_theta_b.restype = P(C.c_double)
+    lib.oracle_theta_b.argtypes = [vp, C.c_int32]
     lib.oracle_get_traces.restype = C.c_int32
     lib.oracle_get_traces.argtypes = [vp, C.c_int32, vp, vp, C.c_int32]
     lib.oracle_get_counters.argtypes = [vp, vp]
@@ -137,6 +139,10 @@ class Oracle:
 
     def theta(self, which=0):
         p = self.lib.oracle_theta(self.h, which)
+        return np.ctypeslib.as_array(p, shape=(self.params.memory_size,))
+
+    def theta_b(self, which=0):
+        p = self.lib.oracle_theta_b(self.h, which)
         return np.ctypeslib.as_array(p, shape=(self.params.memory_size,))
 
     def traces(self, book):

@@ -141,3 +141,30 @@ def test_engine_multi_episode_vs_reference(case):
     nz = np.nonzero(th)[0]
     np.testing.assert_array_equal(nz, fx["theta_idx"])
     np.testing.assert_array_equal(th[nz], fx["theta_val"])
+
+
+from tests.test_oracle_golden import DOUBLE_Q_CASES, _check_sparse  # noqa: E402
+
+
+@pytest.mark.parametrize("case", DOUBLE_Q_CASES, ids=[c[0] for c in DOUBLE_Q_CASES])
+def test_engine_double_q_vs_reference(case):
+    """rl::DoubleQLearn: both weight vectors, (Qa+Qb)/2 action values, and the update coin drawn
+    from a device-side std::mt19937_64 that must reproduce libstdc++'s stream."""
+    name, n_events, book = case
+    fx = np.load(os.path.join(GOLD, "traj_%s.npz" % name))
+    traj = fx["traj"]
+    g = engine.default_gen_params()
+    g.n_events = n_events
+    rec = engine.gen_stream_host(g, 5, 2, book, 1)
+    p = _params_for({}, "sarsa", book)
+    p.algo = abi.ALGO_DOUBLE_Q
+    eng = engine.Engine(p, 1)
+    eng.load_events(rec)
+    eng.reset()
+    for i in range(1, len(traj)):
+        eng.td_step(1)
+        assert eng.last_actions()[0] == traj[i]["action"], "%s step %d action" % (name, i)
+        assert eng.last_td()[0] == traj[i]["td"], "%s step %d td" % (name, i)
+        assert eng.rng_counters()[0] == traj[i]["rng_ctr"]
+    _check_sparse(eng.theta(0), fx["theta_idx"], fx["theta_val"])
+    _check_sparse(eng.theta(1), fx["theta_b_idx"], fx["theta_b_val"])

@@ -100,7 +100,7 @@ def test_env_random_actions(depth, trades):
     assert c[0] == oc[0] and c[1] == oc[1]
 
 
-@pytest.mark.parametrize("algo", [abi.ALGO_SARSA, abi.ALGO_QLAMBDA])
+@pytest.mark.parametrize("algo", [abi.ALGO_SARSA, abi.ALGO_QLAMBDA, abi.ALGO_DOUBLE_Q])
 def test_td_private_theta_bit_exact(algo):
     B = 16
     p, g, rec, eng, orc = make(n_events=600, B=B, algo=algo, theta_mode=abi.THETA_PRIVATE, first_book=100)
@@ -112,6 +112,8 @@ def test_td_private_theta_bit_exact(algo):
         compare_learner_step(eng, orc, "algo %d step %d" % (algo, step))
     for b in range(B):
         np.testing.assert_array_equal(eng.theta(b), orc.theta(b))
+        if algo == abi.ALGO_DOUBLE_Q:
+            np.testing.assert_array_equal(eng.theta(B + b), orc.theta_b(b))
         ei, ee = eng.traces(b)
         oi, oe = orc.traces(b)
         assert dict(zip(ei.tolist(), ee.tolist())) == dict(zip(oi.tolist(), oe.tolist()))
@@ -132,7 +134,7 @@ def test_td_runs_to_stream_end():
     assert eng.counters()[0] == orc.counters()[0]
 
 
-@pytest.mark.parametrize("algo", [abi.ALGO_SARSA, abi.ALGO_QLAMBDA])
+@pytest.mark.parametrize("algo", [abi.ALGO_SARSA, abi.ALGO_QLAMBDA, abi.ALGO_DOUBLE_Q])
 def test_td_shared_theta(algo):
     B = 32
     p, g, rec, eng, orc = make(depth=10, n_events=400, B=B, algo=algo, theta_mode=abi.THETA_SHARED, mem=1 << 20)
@@ -142,6 +144,8 @@ def test_td_shared_theta(algo):
         eng.td_step(1)
         orc.td_step(1)
         compare_learner_step(eng, orc, "shared step %d" % step, exact=False, rtol=1e-9)
+    if algo == abi.ALGO_DOUBLE_Q:
+        np.testing.assert_allclose(eng.theta(1), orc.theta_b(), rtol=1e-9, atol=1e-12)
     th, oth = eng.theta(), orc.theta()
     assert np.array_equal(th != 0, oth != 0)
     np.testing.assert_allclose(th, oth, rtol=1e-9, atol=1e-12)  # north-star tolerance: 1e-5 relative

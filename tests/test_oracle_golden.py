@@ -187,3 +187,29 @@ def test_oracle_multi_episode(case):
     nz = np.nonzero(th)[0]
     np.testing.assert_array_equal(nz, fx["theta_idx"])
     np.testing.assert_array_equal(th[nz], fx["theta_val"])
+
+
+DOUBLE_Q_CASES = [("double_q_b4", 520, 4), ("double_q_b17", 400, 17)]
+
+
+def _check_sparse(th, idx, val):
+    nz = np.nonzero(th)[0]
+    np.testing.assert_array_equal(nz, idx)
+    np.testing.assert_array_equal(th[nz], val)
+
+
+@pytest.mark.parametrize("case", DOUBLE_Q_CASES, ids=[c[0] for c in DOUBLE_Q_CASES])
+def test_oracle_double_q_matches_reference(case):
+    name, n_events, book = case
+    fx = np.load(os.path.join(GOLD, "traj_%s.npz" % name))
+    g = engine.default_gen_params()
+    g.n_events = n_events
+    rec = engine.gen_stream_host(g, 5, 2, book, 1)
+    p = _params_for({}, "sarsa", book)
+    p.algo = abi.ALGO_DOUBLE_Q
+    o = ol.Oracle(p, rec)
+    o.reset()
+    compare_traj(lambda: o.td_step(1), lambda: o.rec(0), fx["traj"], name)
+    _check_sparse(o.theta(0), fx["theta_idx"], fx["theta_val"])
+    _check_sparse(o.theta_b(0), fx["theta_b_idx"], fx["theta_b_val"])
+    assert len(fx["theta_b_idx"]) > 100
