@@ -526,7 +526,8 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode) {
             if (G > 1 && g == 1) HIPCHK(hipStreamWaitEvent(st, e->ev_stagger, 0));
             {
                 TimedLaunch t(e, "act_kernel", st);
-                hipLaunchKernelGGL(act_kernel, dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, mode, b0, nb);
+                if (e->P.algo == LOB_ALGO_DOUBLE_Q) hipLaunchKernelGGL(act_kernel<LOB_ALGO_DOUBLE_Q>, dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, mode, b0, nb);
+                else hipLaunchKernelGGL(act_kernel<LOB_ALGO_SARSA>, dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, mode, b0, nb);
             }
             if (G > 1 && g == 0) HIPCHK(hipEventRecord(e->ev_stagger, st));
             {
@@ -535,7 +536,9 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode) {
             }
             if (mode == 0) {
                 TimedLaunch t(e, "learn_kernel", st);
-                hipLaunchKernelGGL(learn_kernel, dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, b0, nb);
+                if (e->P.algo == LOB_ALGO_DOUBLE_Q) hipLaunchKernelGGL(learn_kernel<LOB_ALGO_DOUBLE_Q>, dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, b0, nb);
+                else if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL(learn_kernel<LOB_ALGO_QLAMBDA>, dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, b0, nb);
+                else hipLaunchKernelGGL(learn_kernel<LOB_ALGO_SARSA>, dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, b0, nb);
             }
         }
         if (G > 1) {

@@ -249,6 +249,9 @@ __device__ inline void learn_lds_init(const uint32_t* __restrict__ rnd_g, const 
 
 // mode 0: Learner::_step prologue (swap, terminal check, epsilon-greedy action)
 // mode 1: Backtester::_step prologue (no swap, greedy action on the current state)
+// ALGO is a compile-time parameter: the double-Q path needs a second weight vector and more
+// registers; keeping it out of the SARSA / Q(lambda) instantiations keeps them at 90 VGPRs.
+template <int ALGO>
 __global__ void __launch_bounds__(LOB_BLOCK) act_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g,
                                                         int mode, int b0, int nb) {
     __shared__ LearnLds L;
@@ -277,7 +280,7 @@ __global__ void __launch_bounds__(LOB_BLOCK) act_kernel(DevParams P, DevState S,
     const uint32_t* nz = S.theta_nz + nz_off;
     q_values(P, theta, nz, L.vars[w][src], zero, L.rnd, L.act_terms, L.vals[w], lane, qs);
     if (lane < LOB_N_ACTIONS) S.qs_last[(size_t)b * LOB_N_ACTIONS + lane] = qs[lane];
-    if (P.algo == LOB_ALGO_DOUBLE_Q) {
+    if (ALGO == LOB_ALGO_DOUBLE_Q) {
         // DoubleAgent::action (agent.cpp:196-204): qs[a] = (getQ + getQb) / 2.0f
         f64 qb[LOB_N_ACTIONS];
         q_values(P, S.theta_b + (P.theta_private ? (size_t)b * (size_t)P.M : 0), S.theta_b_nz + nz_off, L.vars[w][src], zero,
@@ -313,6 +316,7 @@ __device__ inline i32 sel5(const i32* f, int k) {
 
 // Agent::HandleTransition up to (not including) updateQ: UpdateTraces +
 // the TD error of UpdateWeights (agent.cpp:86-115, 268-311).
+template <int ALGO>
 __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g,
                                                           int b0, int nb) {
     __shared__ LearnLds L;
@@ -352,7 +356,7 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
     int n_old = h.tr_n;
     const int head = h.tr_head;
     int kmax = P.trace_kmax;
-    if (P.algo == LOB_ALGO_QLAMBDA || P.algo == LOB_ALGO_DOUBLE_Q) {
+    if (ALGO == LOB_ALGO_QLAMBDA || ALGO == LOB_ALGO_DOUBLE_Q) {
         const int amax = argmax_ties(qs_last, g);  // QLearn / DoubleQLearn::UpdateTraces (agent.cpp:272-280, 319-327)
         if (action != amax) kmax = 1;              // traces.decay(0.0)
     }
@@ -448,7 +452,7 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
     f64 delta;
     int target = 1;
     const f64 F_term = P.gamma * 0.0 - 0.0;  // potentials are identically 0 (base.cpp:239-242)
-    if (P.algo == LOB_ALGO_DOUBLE_Q) {
+    if (ALGO == LOB_ALGO_DOUBLE_Q) {
         // DoubleQLearn::UpdateWeights (agent.cpp:329-353)
         f64 qb_to[LOB_N_ACTIONS];
         q_values(P, S.theta_b + (P.theta_private ? (size_t)b * (size_t)P.M : 0), S.theta_b_nz + nz_off, vars_to, false, L.rnd,
@@ -470,12 +474,12 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
             delta = reward + F_term + P.gamma * sel9(qs_to, am) - sel9(qb_last, action);
             target = 2;
         }
-    } else if (P.algo == LOB_ALGO_QLAMBDA) {
+    } else if (ALGO == LOB_ALGO_QLAMBDA) {
         const int am2 = argmax_ties(qs_to, g);  // maxQ(to_state)
-        delta = reward + F_term + P.gamma * sel9(qs_to, am2) - sel9(qs_last, action);
+        delta = reward + F_term + P.gamma * qs_to[am2] - qs_last[action];
     } else {
         const int a2 = policy_sample(qs_to, P.epsilon, false, g);  // this->action(to_state), quirk Q9
-        delta = reward + F_term + P.gamma * sel9(qs_to, a2) - sel9(qs_last, action);
+        delta = reward + F_term + P.gamma * qs_to[a2] - qs_last[action];
     }
     if (lane == 0 && target == 2) hp->stepped = 2;  // update_kernel scatters into theta_b
     if (lane == 0) {

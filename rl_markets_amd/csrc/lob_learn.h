@@ -56,12 +56,15 @@ struct Rng {
 
 // Greedy::Sample (policy.cpp:37-55)
 __device__ inline int greedy_sample(const f64* qs, Rng& g) {
+    // (best value tracked in a register: no runtime-indexed array, which would live in scratch)
     int argmax = 0, n_ties = 1;
+    f64 best = qs[0];
+#pragma unroll
     for (int a = 1; a < LOB_N_ACTIONS; a++) {
-        if (qs[a] > qs[argmax]) argmax = a;
-        else if (qs[a] >= qs[argmax]) {
+        if (qs[a] > best) { argmax = a; best = qs[a]; }
+        else if (qs[a] >= best) {
             n_ties++;
-            if (0 == g.rnd() % n_ties) argmax = a;
+            if (0 == g.rnd() % n_ties) { argmax = a; best = qs[a]; }
         }
     }
     return argmax;
@@ -78,6 +81,7 @@ __device__ inline int policy_sample(const f64* qs, f64 eps, bool greedy, Rng& g)
 __device__ inline int argmax_ties(const f64* qs, Rng& g) {
     int index = 0, n_ties = 1;
     f64 cur = qs[0];
+#pragma unroll
     for (int a = 1; a < LOB_N_ACTIONS; a++) {
         f64 val = qs[a];
         if (val >= cur) {
