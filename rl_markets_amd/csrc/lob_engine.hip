@@ -430,7 +430,7 @@ int lob_step(lob_engine* e, const int32_t* host_actions) {
     HIPCHK(hipMemcpyAsync(e->actions_dev, host_actions, (size_t)e->B * 4, hipMemcpyHostToDevice, e->stream));
     {
         TimedLaunch t(e, "env_kernel");
-        hipLaunchKernelGGL(env_kernel, dim3(grid_lanes(e->B)), dim3(256), 0, e->stream, (const DevParams*)e->P_dev, e->S, (const i32*)e->actions_dev, 0, 0, e->B);
+        hipLaunchKernelGGL(env_kernel, dim3((e->B + LOB_ENV_BLOCK - 1) / LOB_ENV_BLOCK), dim3(LOB_ENV_BLOCK), 0, e->stream, (const DevParams*)e->P_dev, e->S, (const i32*)e->actions_dev, 0, 0, e->B);
     }
     HIPCHK(hipGetLastError());
     return check_device_errors(e);
@@ -532,7 +532,7 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode) {
             if (G > 1 && g == 0) HIPCHK(hipEventRecord(e->ev_stagger, st));
             {
                 TimedLaunch t(e, "env_kernel", st);
-                hipLaunchKernelGGL(env_kernel, dim3(gl), dim3(256), 0, st, (const DevParams*)e->P_dev, e->S, (const i32*)nullptr, mode == 0 ? 1 : 0, b0, nb);
+                hipLaunchKernelGGL(env_kernel, dim3((nb + LOB_ENV_BLOCK - 1) / LOB_ENV_BLOCK), dim3(LOB_ENV_BLOCK), 0, st, (const DevParams*)e->P_dev, e->S, (const i32*)nullptr, mode == 0 ? 1 : 0, b0, nb);
             }
             if (mode == 0) {
                 TimedLaunch t(e, "learn_kernel", st);

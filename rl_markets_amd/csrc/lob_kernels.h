@@ -150,9 +150,10 @@ __global__ void __launch_bounds__(256) get_state_kernel(const DevParams* __restr
 // performAction for every book that has an action pending (S.stepped).
 // mode 0: learner step (new vars go to `state` = slot_cur); mode 1: host
 // supplied actions (lob_step).
-__global__ void __launch_bounds__(256, 1) env_kernel(const DevParams* __restrict__ Pp, DevState S, const i32* host_actions, int count_updates, int b0, int nb) {
+#define LOB_ENV_BLOCK 64  // one wave per block: 23.5 KB of LDS slots, small enough to share a CU with learner blocks
+__global__ void __launch_bounds__(LOB_ENV_BLOCK) env_kernel(const DevParams* __restrict__ Pp, DevState S, const i32* host_actions, int count_updates, int b0, int nb) {
     const DevParams& P = *Pp;  // parameters read through the scalar cache, never copied to scratch
-    __shared__ EnvSlot lds_env[256];
+    __shared__ EnvSlot lds_env[LOB_ENV_BLOCK];
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = b0 + t;
     i64 d_steps = 0, d_events = 0;
