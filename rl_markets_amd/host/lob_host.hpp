@@ -356,15 +356,49 @@ public:
 };
 
 class Backtester : public Runner {
+    std::ofstream profit_log_;
+    double last_bandh_ = 0.0;
+    int date_ = 0;
+
 protected:
     bool _step(Agent*) override {
         check(lob_eval_step(environment.handle(), 1), "Backtester::_step");
         environment.invalidate();
+        if (profit_log_.is_open()) LogProfit();
         return n_live() == 0;
+    }
+    // Intraday::LogProfit (src/environment/intraday.cpp:438-451), book 0, one row per performed step
+    void LogProfit() {
+        int32_t stepped = 0;
+        {
+            std::vector<int32_t> st(environment.n_books());
+            check(lob_get_stepped(environment.handle(), st.data()), "LogProfit");
+            stepped = st[0];
+        }
+        if (!stepped) return;
+        lob_book_dump d = environment.book(0);
+        char buf[512];
+        snprintf(buf, sizeof buf, "%d,%lld,%d,%lld,%.10g,%.10g,%.10g,%.10g,%d,%d,%.10g,%.10g\n", date_, (long long)d.time_ms,
+                 d.last_action, (long long)d.position, (d.ask_px[0] + d.bid_px[0]) / 2.0, d.ask_px[0] - d.bid_px[0], d.ask_quote,
+                 d.bid_quote, d.ask_level, d.bid_level, d.pnl_step, d.episode_bandh - last_bandh_);
+        profit_log_ << buf;
+        last_bandh_ = d.episode_bandh;
     }
 
 public:
     explicit Backtester(BatchedIntraday& env) : Runner(env) {}
+    // Backtester ctor + Base::start_logging (serial.cpp:97-122): profit_log.csv with the reference's header
+    void start_logging(const std::string& path, int date = 0) {
+        profit_log_.open(path.c_str());
+        if (!profit_log_.is_open()) throw std::runtime_error("Loggers not registered!");  // base.cpp:402-403
+        profit_log_ << "episode,step,action,position,midprice,spread,quoted_ask,quoted_bid,ask_level,bid_level,pnl_step,bandh_step\n";
+        date_ = date;
+    }
+    void stop_logging() { profit_log_.close(); }
+    bool RunEpisode(Agent* m) override {
+        last_bandh_ = 0.0;
+        return Runner::RunEpisode(m);
+    }
 };
 
 }  // namespace lob

@@ -3,7 +3,8 @@
 // n episodes on synthetic streams, evaluate greedily, print the per-episode
 // rows of the reference's training_log (serial.cpp:81-88) for book 0.
 //
-//   lob_run -c config/example.yaml [-n books] [-e episodes] [-a sarsa|q_learn] [--events N] [--depth D] [--theta out.bin]
+//   lob_run -c config/example.yaml [-n books] [-e episodes] [-a sarsa|q_learn|double_q_learn] [--events N] [--depth D]
+//           [--theta out.bin] [--profit-log profit_log.csv]
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -12,7 +13,7 @@
 #include "lob_host.hpp"
 
 int main(int argc, char** argv) {
-    std::string cfg_path, algo, theta_out;
+    std::string cfg_path, algo, theta_out, profit_log;
     int books = 1, episodes = 1, events = 2112, depth = 5;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -24,6 +25,7 @@ int main(int argc, char** argv) {
         else if (a == "--events") events = atoi(next().c_str());
         else if (a == "--depth") depth = atoi(next().c_str());
         else if (a == "--theta") theta_out = next();
+        else if (a == "--profit-log") profit_log = next();
         else { fprintf(stderr, "unknown flag %s\n", a.c_str()); return 1; }
     }
     try {
@@ -52,6 +54,15 @@ int main(int argc, char** argv) {
             fprintf(stderr, "episode %d: %lld env-steps over %d books in %.3f s\n", ep + 1, (long long)cnt[0], books, sec);
         }
         if (!theta_out.empty()) agent.write_theta(theta_out);
+        if (!profit_log.empty()) {
+            // src/main.cpp:217-239: GoGreedy() then one Backtester episode with profit logging (book 0)
+            agent.GoGreedy();
+            lob::Backtester bt(env);
+            bt.start_logging(profit_log, 20200102);
+            if (!bt.RunEpisode(&agent)) { fprintf(stderr, "[!] no data\n"); return 2; }
+            bt.stop_logging();
+            printf("backtest,%.10g,%.10g,%d\n", env.getEpisodeReward(0), env.getEpisodePnL(0), env.book(0).total_ticks);
+        }
     } catch (std::exception& e) {
         fprintf(stderr, "Unhandled Exception: %s\n", e.what());  // main.cpp:364-368
         return 2;

@@ -51,3 +51,43 @@ def test_lob_run_errors_like_the_reference():
     assert out.returncode == 2 and "Unhandled Exception" in out.stderr
     out = subprocess.run([exe, "-c", os.path.join(ROOT, "config", "example.yaml"), "-a", "r_learn"], capture_output=True, text=True)
     assert out.returncode == 2 and "Unknown learning algorithm" in out.stderr
+
+
+def test_lob_run_backtest_profit_log(tmp_path):
+    """Backtester with the reference's profit_log schema (serial.cpp:101-107, intraday.cpp:438-451)
+    after one training episode; rows checked against the oracle's greedy evaluation."""
+    exe = os.path.join(ROOT, "rl_markets_amd", "host", "lob_run")
+    log = str(tmp_path / "profit_log.csv")
+    events = 400
+    out = subprocess.run([exe, "-c", os.path.join(ROOT, "config", "example.yaml"), "-a", "sarsa", "-n", "1", "-e", "1",
+                          "--events", str(events), "--profit-log", log], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    rows = open(log).read().strip().splitlines()
+    assert rows[0] == "episode,step,action,position,midprice,spread,quoted_ask,quoted_bid,ask_level,bid_level,pnl_step,bandh_step"
+    p = engine.default_params()
+    p.algo = abi.ALGO_SARSA
+    g = engine.default_gen_params()
+    g.n_events = events
+    rec = engine.gen_stream_host(g, 5, 2, 0, 1)
+    orc = ol.Oracle(p, rec)
+    orc.reset()
+    for _ in range(events):
+        orc.td_step(1)
+    orc.clear_inventory()
+    ol.load().oracle_handle_terminal(orc.h)
+    orc.reset()
+    n = 0
+    last_bandh = 0.0
+    while True:
+        before = orc.counters()[0]
+        orc.eval_step(1)
+        if orc.counters()[0] == before:
+            break
+        r = orc.rec(0)
+        cols = rows[1 + n].split(",")
+        assert int(cols[1]) == r["book"]["time_ms"] and int(cols[2]) == r["action"] and int(cols[3]) == r["book"]["position"]
+        assert float(cols[10]) == pytest.approx(r["book"]["pnl_step"], rel=1e-9, abs=1e-12)
+        assert float(cols[11]) == pytest.approx(r["book"]["episode_bandh"] - last_bandh, rel=1e-6, abs=1e-9)
+        last_bandh = r["book"]["episode_bandh"]
+        n += 1
+    assert n == len(rows) - 1 and n > 50
