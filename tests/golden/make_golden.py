@@ -35,6 +35,18 @@ TRAJ_CASES = [
     ("sarsa_tight_bounds_b7", "sarsa", 600, 7, {"pos_ub": 20, "pos_lb": -20, "order_size": 15, "eps": "0.3"},
      {"pos_ub": 20, "pos_lb": -20, "order_size": 15, "epsilon": 0.3}),
     ("sarsa_book_quotes_b9", "sarsa", 500, 9, {"tp": "book"}, {"quote_mode": abi.QUOTE_BOOK, "target_price": abi.TP_MIDPRICE}),
+    # every state variable of Intraday::getVariable (13), rsi / vwap windows switched on
+    ("qlearn_all_vars_b13", "q_learn", 420, 13,
+     {"vars": '"pos", "spd", "mpm", "imb", "svl", "vol", "rsi", "vwap", "a_dist", "a_queue", "b_dist", "b_queue", "last_action"',
+      "lb_rsi": 10, "lb_vwap": 20},
+     {"n_vars": 13, "vars": [abi.VAR_POS, abi.VAR_SPD, abi.VAR_MPM, abi.VAR_IMB, abi.VAR_SVL, abi.VAR_VOL, abi.VAR_RSI, abi.VAR_VWAP,
+                             abi.VAR_A_DIST, abi.VAR_A_QUEUE, abi.VAR_B_DIST, abi.VAR_B_QUEUE, abi.VAR_LAST_ACTION],
+      "lb_rsi": 10, "lb_vwap": 20}),
+    # the remaining reward measures of Base::getReward
+    ("sarsa_normed_b14", "sarsa", 420, 14, {"reward": "normed", "lb_pnl": 20}, {"reward_measure": abi.REWARD_NORMED, "lb_pnl": 20}),
+    ("sarsa_spread_b15", "sarsa", 400, 15, {"reward": "spread"}, {"reward_measure": abi.REWARD_SPREAD}),
+    ("qlearn_mm_div_b16", "q_learn", 400, 16, {"reward": "mm_div"}, {"reward_measure": abi.REWARD_MM_DIV}),
+    ("sarsa_lovol_b18", "sarsa", 400, 18, {"reward": "lovol"}, {"reward_measure": abi.REWARD_LOVOL}),
 ]
 
 

@@ -39,7 +39,7 @@ def test_engine_reproduces_reference_trajectory(case):
             assert np.array_equal(got[n], want[n]), "%s step %d: book.%s engine=%r reference=%r" % (name, i, n, got[n], want[n])
 
     check_book(0)
-    np.testing.assert_array_equal(eng.get_state()[0], traj[0]["vars"][:8])
+    np.testing.assert_array_equal(eng.get_state()[0], traj[0]["vars"][:eng.V])
     for i in range(1, len(traj)):
         eng.td_step(1)
         assert eng.stepped()[0] == 1
@@ -47,7 +47,7 @@ def test_engine_reproduces_reference_trajectory(case):
         assert eng.last_rewards()[0] == traj[i]["reward"], "%s step %d reward" % (name, i)
         assert eng.last_td()[0] == traj[i]["td"], "%s step %d td" % (name, i)
         assert eng.rng_counters()[0] == traj[i]["rng_ctr"]
-        np.testing.assert_array_equal(eng.learner_state()[0], traj[i]["vars"][:8])
+        np.testing.assert_array_equal(eng.learner_state()[0], traj[i]["vars"][:eng.V])
         check_book(i)
     eng.td_step(1)  # the reference episode ended on out-of-data
     assert eng.stepped()[0] == 0 and eng.get_terminal()[0] == 2

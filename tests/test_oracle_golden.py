@@ -73,7 +73,11 @@ def _params_for(over, algo, book):
     p.algo = abi.ALGO_SARSA if algo == "sarsa" else abi.ALGO_QLAMBDA
     p.book_id_offset = book
     for k, v in over.items():
-        setattr(p, k, v)
+        if k == "vars":
+            for i, x in enumerate(v):
+                p.vars[i] = x
+        else:
+            setattr(p, k, v)
     return p
 
 
