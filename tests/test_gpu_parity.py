@@ -229,3 +229,54 @@ def test_two_episodes_window_sums_persist(stop):
         ol.load().oracle_handle_terminal(orc.h)
     for b in range(B):
         np.testing.assert_array_equal(eng.theta(b), orc.theta(b))
+
+
+def _repack_trades(rec, depth, t_old, t_new):
+    """records with t_old trade slots -> layout with t_new slots (extra slots empty)."""
+    B, N, _ = rec.shape
+    w_new = engine.record_words(depth, t_new)
+    out = np.zeros((B, N, w_new), np.uint32)
+    out[..., :2 + 4 * depth] = rec[..., :2 + 4 * depth]
+    out[..., 2 + 4 * depth:2 + 4 * depth + t_old] = rec[..., 2 + 4 * depth:2 + 4 * depth + t_old]
+    out[..., 2 + 4 * depth + t_new:2 + 4 * depth + t_new + t_old] = rec[..., 2 + 4 * depth + t_old:2 + 4 * depth + 2 * t_old]
+    return out
+
+
+@pytest.mark.parametrize("algo", [abi.ALGO_SARSA, abi.ALGO_QLAMBDA])
+def test_same_timestamp_rows_and_crossed_books_batched(algo):
+    """Quirk Q14 in the batched engine at depth 10: rows sharing a timestamp are applied inside one
+    event, crossed (invalid) snapshots are skipped without re-stash, and the trades of the swallowed
+    rows are handed to the next event (up to 4 price levels here)."""
+    B, D, N = 24, 10, 420
+    p = engine.default_params()
+    p.depth, p.max_trades, p.algo, p.theta_mode, p.memory_size = D, 4, algo, abi.THETA_PRIVATE, 1 << 18
+    g = engine.default_gen_params()
+    g.n_events = N
+    rec = _repack_trades(engine.gen_stream_host(g, D, 2, 0, B), D, 2, 4)
+    rng = np.random.default_rng(11)
+    o_ap, o_bp = 2, 2 + 2 * D
+    for b in range(B):
+        for r in rng.choice(np.arange(70, N - 5), size=10, replace=False):
+            if rng.random() < 0.5:
+                rec[b, r, 0] = rec[b, r - 1, 0]               # same timestamp as the previous row
+            else:                                             # crossed book: asks below bids
+                a = rec[b, r, o_ap:o_ap + D].copy()
+                rec[b, r, o_ap:o_ap + D] = rec[b, r, o_bp:o_bp + D][::-1]
+                rec[b, r, o_bp:o_bp + D] = a[::-1]
+    # keep time monotone after the edits
+    for b in range(B):
+        t = rec[b, :, 0].astype(np.int64)
+        assert (np.diff(t) >= 0).all()
+    eng = engine.Engine(p, B)
+    eng.load_events(rec)
+    orc = ol.Oracle(p, rec)
+    eng.reset()
+    orc.reset()
+    compare_env(eng, orc, "reset")
+    for step in range(200):
+        eng.td_step(1)
+        orc.td_step(1)
+        compare_learner_step(eng, orc, "q14 step %d" % step)
+    for b in range(B):
+        np.testing.assert_array_equal(eng.theta(b), orc.theta(b))
+    assert eng.counters()[1] == orc.counters()[1]
