@@ -40,6 +40,7 @@ struct lob_engine {
     hipStream_t stream2 = nullptr;  // second book group of the step pipeline
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_stagger = nullptr;
     int n_groups = 1;
+    int td_parity = 0;
     std::vector<void*> allocs;
     uint32_t* rnd_dev = nullptr;
     uint32_t* records_dev = nullptr;
@@ -291,6 +292,9 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
         if (rc == LOB_OK) rc = dev_alloc(e, &S.mt_state, B * LOB_MT_N);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.mt_idx, B);
     }
+    if (rc == LOB_OK) rc = dev_alloc(e, &S.verdict, B * LOB_VD_STRIDE);
+    if (rc == LOB_OK) rc = dev_alloc(e, &S.nz_new, 2 * LOB_NZ_WORDS);
+    if (rc == LOB_OK) rc = dev_alloc(e, &S.nz_epoch, 1);
     if (rc == LOB_OK) rc = dev_alloc(e, &S.counters, 8);
     if (rc == LOB_OK) rc = dev_alloc(e, &S.error_flag, 1);
     if (rc == LOB_OK) rc = dev_alloc(e, &e->rnd_dev, 2048 + 64);
@@ -513,6 +517,8 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode) {
     const int G = e->n_groups;
     const uint32_t* rnd = (const uint32_t*)e->rnd_dev;
     for (int s = 0; s < n_steps; s++) {
+        // double-buffered list of newly written weights (verdict carry-over, lob_state.h)
+        const int par = mode == 0 ? (e->td_parity ^= 1) : 0;
         if (G > 1) {
             HIPCHK(hipEventRecord(e->ev_fork, e->stream));
             HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
@@ -526,8 +532,8 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode) {
             if (G > 1 && g == 1) HIPCHK(hipStreamWaitEvent(st, e->ev_stagger, 0));
             {
                 TimedLaunch t(e, "act_kernel", st);
-                if (e->P.algo == LOB_ALGO_DOUBLE_Q) hipLaunchKernelGGL(act_kernel<LOB_ALGO_DOUBLE_Q>, dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, mode, b0, nb);
-                else hipLaunchKernelGGL(act_kernel<LOB_ALGO_SARSA>, dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, mode, b0, nb);
+                if (e->P.algo == LOB_ALGO_DOUBLE_Q) hipLaunchKernelGGL(act_kernel<LOB_ALGO_DOUBLE_Q>, dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, mode, b0, nb, par);
+                else hipLaunchKernelGGL(act_kernel<LOB_ALGO_SARSA>, dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, mode, b0, nb, par);
             }
             if (G > 1 && g == 0) HIPCHK(hipEventRecord(e->ev_stagger, st));
             {
@@ -536,9 +542,9 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode) {
             }
             if (mode == 0) {
                 TimedLaunch t(e, "learn_kernel", st);
-                if (e->P.algo == LOB_ALGO_DOUBLE_Q) hipLaunchKernelGGL(learn_kernel<LOB_ALGO_DOUBLE_Q>, dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, b0, nb);
-                else if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL(learn_kernel<LOB_ALGO_QLAMBDA>, dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, b0, nb);
-                else hipLaunchKernelGGL(learn_kernel<LOB_ALGO_SARSA>, dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, b0, nb);
+                if (e->P.algo == LOB_ALGO_DOUBLE_Q) hipLaunchKernelGGL(learn_kernel<LOB_ALGO_DOUBLE_Q>, dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, b0, nb, par);
+                else if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL(learn_kernel<LOB_ALGO_QLAMBDA>, dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, b0, nb, par);
+                else hipLaunchKernelGGL(learn_kernel<LOB_ALGO_SARSA>, dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, b0, nb, par);
             }
         }
         if (G > 1) {
@@ -547,7 +553,7 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode) {
         }
         if (mode == 0) {
             TimedLaunch t(e, "update_kernel");
-            hipLaunchKernelGGL(update_kernel, dim3(grid_waves(e->B)), dim3(LOB_BLOCK), 0, e->stream, e->P, e->S);
+            hipLaunchKernelGGL(update_kernel, dim3(grid_waves(e->B)), dim3(LOB_BLOCK), 0, e->stream, e->P, e->S, par);
         }
     }
     HIPCHK(hipGetLastError());
@@ -628,7 +634,7 @@ int lob_theta_set(lob_engine* e, int32_t which, const double* host_in, int64_t c
     if (rc) return rc;
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipMemcpyAsync(th, host_in, (size_t)count * 8, hipMemcpyHostToDevice, e->stream));
-    hipLaunchKernelGGL(rebuild_nz_kernel, dim3(1024), dim3(256), 0, e->stream, (const f64*)th, nz, e->P.M);
+    hipLaunchKernelGGL(rebuild_nz_kernel, dim3(1024), dim3(256), 0, e->stream, (const f64*)th, nz, e->S.nz_epoch, e->P.M);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(e->stream));
     return LOB_OK;
@@ -746,7 +752,7 @@ int lob_delta_apply(lob_engine* e) {
     HIPCHK(hipSetDevice(e->device));
     {
         TimedLaunch t(e, "delta_apply_kernel");
-        hipLaunchKernelGGL(delta_apply_kernel, dim3(2048), dim3(256), 0, e->stream, e->S.theta, e->S.theta_sync, (const f64*)e->S.delta, e->S.theta_nz, e->P.M);
+        hipLaunchKernelGGL(delta_apply_kernel, dim3(2048), dim3(256), 0, e->stream, e->S.theta, e->S.theta_sync, (const f64*)e->S.delta, e->S.theta_nz, e->S.nz_epoch, e->P.M);
     }
     HIPCHK(hipGetLastError());
     return LOB_OK;
@@ -781,3 +787,15 @@ int lob_kernel_time_ms(lob_engine* e, const char* kernel, double* avg_ms, int64_
 }
 
 }  // extern "C"
+
+// Diagnostics (not part of include/lob_engine.h): how many weights the last two updates wrote for
+// the first time -- the quantity that decides whether act_kernel can reuse learn_kernel's verdicts.
+extern "C" int lob_debug_new_weights(lob_engine* e, int32_t out[2]) {
+    if (!e || !out) return LOB_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    i32 h[2 * LOB_NZ_WORDS];
+    HIPCHK(hipMemcpyAsync(h, e->S.nz_new, sizeof(h), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    out[0] = h[0]; out[1] = h[LOB_NZ_WORDS];
+    return LOB_OK;
+}

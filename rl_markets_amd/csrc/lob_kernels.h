@@ -41,6 +41,7 @@ static_assert(sizeof(EnvSlot) * 256 <= 160 * 1024, "one 256-lane block per CU mu
 
 #define LOB_WAVES_PER_BLOCK 4
 #define LOB_BLOCK (64 * LOB_WAVES_PER_BLOCK)
+static_assert(LOB_BLOCK == LOB_NZ_WORDS, "learn_kernel block 0 clears one nz_new buffer, a word per thread");
 
 // ---------------------------------------------------------------------------
 __global__ void gen_events_kernel(lob_gen_params g, int D, int T, u64 first_book, int B, uint32_t* out) {
@@ -104,6 +105,7 @@ __global__ void __launch_bounds__(256, 1) reset_kernel(const DevParams* __restri
             vf[i] = v[i];
         }
         h.zero_mask &= ~(1 << last);
+        S.verdict[(size_t)b * LOB_VD_STRIDE + 67] = 0;
     } else {
         // Initialise() == false: out of data before the windows filled
         e.k = M.n_track;
@@ -185,6 +187,7 @@ __global__ void __launch_bounds__(LOB_ENV_BLOCK) env_kernel(const DevParams* __r
                     vf[i] = v[i];
                 }
                 h.zero_mask &= ~(1 << cur);
+                S.verdict[(size_t)b * LOB_VD_STRIDE + 67] = 0;  // a State changed: saved verdicts are void until learn saves new ones
                 h.reward = get_reward(c, e);
                 h.stepped = 1;
                 d_steps = 1;
@@ -229,12 +232,13 @@ struct LearnLds {
     u64 act_terms[32];                                    // trailing-coordinate terms [group][action] (27 used)
     f64 vals[LOB_WAVES_PER_BLOCK][LOB_HSLOTS / 2];  // 4 KB per wave: one group's gathered theta (9 x 33 f64) / trace hash set (aliased)
     f32 vars[LOB_WAVES_PER_BLOCK][3][16];
+    uint32_t newf[LOB_NZ_FILTER];                         // act only: filter of the weights first written by the previous update
 };
 
 // Stage the hash table (8 KB, two 16-byte loads per thread), the 27 action terms
 // and this wave's three state-variable slots; ONE barrier.
 __device__ inline void learn_lds_init(const uint32_t* __restrict__ rnd_g, const f32* __restrict__ vars_b, bool have_book,
-                                      LearnLds& L) {
+                                      LearnLds& L, const i32* __restrict__ nz_buf = nullptr) {
     const uint4* src = reinterpret_cast<const uint4*>(rnd_g);
     uint4* dst = reinterpret_cast<uint4*>(L.rnd);
     const uint4 r0 = src[threadIdx.x], r1 = src[threadIdx.x + LOB_BLOCK];
@@ -245,6 +249,7 @@ __device__ inline void learn_lds_init(const uint32_t* __restrict__ rnd_g, const 
     dst[threadIdx.x + LOB_BLOCK] = r1;
     if (threadIdx.x < 27) L.act_terms[threadIdx.x] = reinterpret_cast<const u64*>(rnd_g + 2048)[threadIdx.x];
     if (lane < 48) (&L.vars[w][0][0])[lane] = vv;
+    if (nz_buf && threadIdx.x < LOB_NZ_FILTER) L.newf[threadIdx.x] = (uint32_t)nz_buf[LOB_NZ_FILTER + threadIdx.x];
     __syncthreads();
 }
 
@@ -252,9 +257,12 @@ __device__ inline void learn_lds_init(const uint32_t* __restrict__ rnd_g, const 
 // mode 1: Backtester::_step prologue (no swap, greedy action on the current state)
 // ALGO is a compile-time parameter: the double-Q path needs a second weight vector and more
 // registers; keeping it out of the SARSA / Q(lambda) instantiations keeps them at 90 VGPRs.
+// tag of a verdict row: theta epoch | State slot | valid (u16 words 64..67 of the row)
+__device__ inline u64 vd_tag(uint32_t epoch, int slot) { return (u64)epoch | ((u64)(uint16_t)slot << 32) | (1ull << 48); }
+
 template <int ALGO>
 __global__ void __launch_bounds__(LOB_BLOCK) act_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g,
-                                                        int mode, int b0, int nb) {
+                                                        int mode, int b0, int nb, int par) {
     __shared__ LearnLds L;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int t = __builtin_amdgcn_readfirstlane(blockIdx.x * LOB_WAVES_PER_BLOCK + w);
@@ -262,7 +270,8 @@ __global__ void __launch_bounds__(LOB_BLOCK) act_kernel(DevParams P, DevState S,
     const bool have = t < nb;
     const int bb = have ? b : 0;
     const LHdr h = S.hdr[bb];  // one scalar 64-byte load, issued before the LDS staging
-    learn_lds_init(rnd_g, S.vars + (size_t)bb * 48, have, L);
+    const i32* nz_new = S.nz_new + (par ^ 1) * LOB_NZ_WORDS;  // written by the previous step's update
+    learn_lds_init(rnd_g, S.vars + (size_t)bb * 48, have, L, nz_new);
     if (!have) return;
     LHdr* hp = S.hdr + b;
     if (h.done) { if (lane == 0) hp->stepped = 0; return; }
@@ -279,7 +288,19 @@ __global__ void __launch_bounds__(LOB_BLOCK) act_kernel(DevParams P, DevState S,
     f64 qs[LOB_N_ACTIONS];
     const size_t nz_off = P.theta_private ? (size_t)b * (size_t)((P.M + 31) >> 5) : 0;
     const uint32_t* nz = S.theta_nz + nz_off;
-    q_values(P, theta, nz, L.vars[w][src], zero, L.rnd, L.act_terms, L.vals[w], lane, qs);
+    {
+        // learn(t) of this book evaluated the very same State: take over its "weight is zero"
+        // verdicts if nothing but update(t) touched theta since (epoch) and that update set only a
+        // few new bits (kept in a 4096-bit filter, staged in LDS above).
+        uint16_t* vd = S.verdict + (size_t)b * LOB_VD_STRIDE;
+        const int n_new = nz_new[0];
+        const uint32_t ep = (uint32_t)S.nz_epoch[0];
+        const u64 tag = *(const u64*)(vd + 64);  // {epoch, slot, valid} in one load
+        const bool reuse = ALGO != LOB_ALGO_DOUBLE_Q && mode == 0 && !zero && !P.theta_private && n_new <= LOB_NZ_NEW_MAX &&
+                           tag == vd_tag(ep, src);
+        if (reuse) q_values(P, theta, nz, L.vars[w][src], zero, L.rnd, L.act_terms, L.vals[w], lane, qs, 2, vd, L.newf);
+        else q_values(P, theta, nz, L.vars[w][src], zero, L.rnd, L.act_terms, L.vals[w], lane, qs);
+    }
     if (lane < LOB_N_ACTIONS) S.qs_last[(size_t)b * LOB_N_ACTIONS + lane] = qs[lane];
     if (ALGO == LOB_ALGO_DOUBLE_Q) {
         // DoubleAgent::action (agent.cpp:196-204): qs[a] = (getQ + getQb) / 2.0f
@@ -319,8 +340,10 @@ __device__ inline i32 sel5(const i32* f, int k) {
 // the TD error of UpdateWeights (agent.cpp:86-115, 268-311).
 template <int ALGO>
 __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g,
-                                                          int b0, int nb) {
+                                                          int b0, int nb, int par) {
     __shared__ LearnLds L;
+    // this step's update appends to nz_new[par]; the list act reads is nz_new[par ^ 1]
+    if (blockIdx.x == 0) S.nz_new[par * LOB_NZ_WORDS + threadIdx.x] = 0;  // LOB_BLOCK == LOB_NZ_WORDS
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int t = __builtin_amdgcn_readfirstlane(blockIdx.x * LOB_WAVES_PER_BLOCK + w);
     const int b = b0 + t;
@@ -448,7 +471,12 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
     const size_t nz_off = P.theta_private ? (size_t)b * (size_t)((P.M + 31) >> 5) : 0;
     const uint32_t* nz = S.theta_nz + nz_off;
     f64 qs_to[LOB_N_ACTIONS];
-    q_values(P, theta, nz, vars_to, false, L.rnd, L.act_terms, L.vals[w], lane, qs_to);
+    {
+        uint16_t* vd = S.verdict + (size_t)b * LOB_VD_STRIDE;
+        const uint32_t ep = (uint32_t)S.nz_epoch[0];
+        q_values(P, theta, nz, vars_to, false, L.rnd, L.act_terms, L.vals[w], lane, qs_to, 1, vd);
+        if (lane == 0) *(u64*)(vd + 64) = vd_tag(ep, cur);
+    }
     const f64 reward = h.reward;
     f64 delta;
     int target = 1;
@@ -491,7 +519,7 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
 }
 
 // Agent::updateQ (agent.cpp:137-142): theta[f] += (alpha*delta / N_TILINGS) * e[f]
-__global__ void __launch_bounds__(LOB_BLOCK) update_kernel(DevParams P, DevState S) {
+__global__ void __launch_bounds__(LOB_BLOCK) update_kernel(DevParams P, DevState S, int par) {
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b = __builtin_amdgcn_readfirstlane(blockIdx.x * LOB_WAVES_PER_BLOCK + w);
     if (b >= S.B) return;
@@ -513,7 +541,14 @@ __global__ void __launch_bounds__(LOB_BLOCK) update_kernel(DevParams P, DevState
                 const f64 val = scaled * (f64)P.trace_pow[k];
                 __hip_atomic_fetch_add(&theta[f], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const uint32_t bit = 1u << (f & 31);
-                if (!(nz[f >> 5] & bit)) atomicOr(&nz[f >> 5], bit);  // monotone: set once, then a plain L2 hit
+                if (!(nz[f >> 5] & bit)) {  // monotone: set once, then a plain L2 hit
+                    const uint32_t old = atomicOr(&nz[f >> 5], bit);
+                    if (!(old & bit) && !P.theta_private && h.stepped != 2) {  // this lane flipped it: tell the next act_kernel
+                        i32* nz_new = S.nz_new + par * LOB_NZ_WORDS;
+                        atomicAdd(&nz_new[0], 1);
+                        atomicOr((uint32_t*)&nz_new[LOB_NZ_FILTER + ((f >> 5) & (LOB_NZ_FILTER - 1))], bit);
+                    }
+                }
             }
         }
     }
@@ -569,8 +604,9 @@ __global__ void delta_begin_kernel(const f64* __restrict__ theta, const f64* __r
     const i64 stride = (i64)gridDim.x * blockDim.x;
     for (; i < M; i += stride) delta[i] = theta[i] - sync[i];
 }
-__global__ void delta_apply_kernel(f64* theta, f64* sync, const f64* __restrict__ delta, uint32_t* nz, i64 M) {
+__global__ void delta_apply_kernel(f64* theta, f64* sync, const f64* __restrict__ delta, uint32_t* nz, i32* nz_epoch, i64 M) {
     i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) atomicAdd(nz_epoch, 1);  // verdicts saved before this exchange are stale
     const i64 stride = (i64)gridDim.x * blockDim.x;
     for (; i < M; i += stride) {
         const f64 d = delta[i];
@@ -584,8 +620,9 @@ __global__ void delta_apply_kernel(f64* theta, f64* sync, const f64* __restrict_
     }
 }
 // rebuild the bitmap after lob_theta_set: bit = (theta != +0.0 bitwise)
-__global__ void rebuild_nz_kernel(const f64* __restrict__ theta, uint32_t* nz, i64 M) {
+__global__ void rebuild_nz_kernel(const f64* __restrict__ theta, uint32_t* nz, i32* nz_epoch, i64 M) {
     i64 wi = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (wi == 0) atomicAdd(nz_epoch, 1);
     const i64 stride = (i64)gridDim.x * blockDim.x;
     const i64 words = (M + 31) >> 5;
     for (; wi < words; wi += stride) {

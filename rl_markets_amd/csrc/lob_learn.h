@@ -111,35 +111,60 @@ __device__ inline int argmax_ties(const f64* qs, Rng& g) {
 // gather would fetch a 64-byte sector from HBM to read a zero.  One bit per
 // weight (2.5 MB at M = 20 M: L2-resident) answers that without the fetch; the
 // value used is bit-identical either way.
+// vd_mode 0: look the bits up in the bitmap; 1: look up AND return them in *vd_bits (learn saves
+// them); 2: take *vd_bits as the verdicts (act re-using learn's), OR-ed with the filter `newf` (LDS,
+// 4096 bits, bit = index mod 4096) of the weights written for the first time since.  A filter
+// false positive only costs a fetch of a weight that is still exactly 0.0.
 __device__ inline void gather9(const DevParams& P, const f64* __restrict__ theta, const uint32_t* __restrict__ nz,
                                const f32* vars, bool zero, const uint32_t* rnd, const u64* act_terms, int g, int j,
-                               f64* t) {
+                               f64* t, int vd_mode, uint32_t* vd_bits, const uint32_t* newf) {
     const int nf = g == 0 ? 3 : (g == 1 ? P.V - 3 : P.V);
     const f32* v = g == 1 ? vars + 3 : vars;
     const u64 base = zero ? 0 : tile_base(v, nf, j, rnd);
     i32 idx[LOB_N_ACTIONS];
-    uint32_t word[LOB_N_ACTIONS];
 #pragma unroll
-    for (int a = 0; a < LOB_N_ACTIONS; a++) {
+    for (int a = 0; a < LOB_N_ACTIONS; a++)
         idx[a] = zero ? 0 : mod_m(base + act_terms[g * LOB_N_ACTIONS + a], P.M, P.inv_M);
-        // group-0 tiles are the ones that get written: fetch them directly (one request, not two)
-        word[a] = g == 0 ? 0xffffffffu : nz[idx[a] >> 5];
+    uint32_t bits;
+    if (g == 0) {
+        bits = 0x1ffu;  // group-0 tiles are the ones that get written: fetch them directly (one request, not two)
+    } else if (vd_mode == 2) {
+        bits = *vd_bits;
+#pragma unroll
+        for (int a = 0; a < LOB_N_ACTIONS; a++)
+            bits |= ((newf[(idx[a] >> 5) & (LOB_NZ_FILTER - 1)] >> (idx[a] & 31)) & 1u) << a;
+    } else {
+        uint32_t word[LOB_N_ACTIONS];
+#pragma unroll
+        for (int a = 0; a < LOB_N_ACTIONS; a++) word[a] = nz[idx[a] >> 5];
+        bits = 0;
+#pragma unroll
+        for (int a = 0; a < LOB_N_ACTIONS; a++) bits |= ((word[a] >> (idx[a] & 31)) & 1u) << a;
+        if (vd_mode == 1) *vd_bits = bits;
     }
 #pragma unroll
     for (int a = 0; a < LOB_N_ACTIONS; a++) {
         t[a] = 0.0;
-        if ((word[a] >> (idx[a] & 31)) & 1u) t[a] = theta[idx[a]];
+        if ((bits >> a) & 1u) t[a] = theta[idx[a]];
     }
 }
 
+// vd: this book's verdict row (64 x u16: [group-1][tiling]) or null.
 __device__ inline void q_values(const DevParams& P, const f64* __restrict__ theta, const uint32_t* __restrict__ nz,
                                 const f32* vars, bool zero,
                                 const uint32_t* rnd, const u64* act_terms /*[3][9] LDS*/, f64* vals, int lane,
-                                f64* out_q) {
+                                f64* out_q, int vd_mode = 0, uint16_t* vd = nullptr, const uint32_t* newf = nullptr) {
     const int j = lane & 31, hi = lane >> 5;
     f64 ta[LOB_N_ACTIONS], tb[LOB_N_ACTIONS];
-    gather9(P, theta, nz, vars, zero, rnd, act_terms, hi ? 1 : 0, j, ta);      // group 0 (lanes 0-31) / group 1 (32-63)
-    if (!hi) gather9(P, theta, nz, vars, zero, rnd, act_terms, 2, j, tb);      // group 2 (lanes 0-31)
+    uint32_t bits = 0;
+    if (vd_mode == 2) bits = vd[(hi ? 0 : 32) + j];  // lanes 32-63 own group 1, lanes 0-31 group 2
+    if (hi) {
+        gather9(P, theta, nz, vars, zero, rnd, act_terms, 1, j, ta, vd_mode, &bits, newf);
+    } else {
+        gather9(P, theta, nz, vars, zero, rnd, act_terms, 0, j, ta, 0, nullptr, nullptr);
+        gather9(P, theta, nz, vars, zero, rnd, act_terms, 2, j, tb, vd_mode, &bits, newf);
+    }
+    if (vd_mode == 1) vd[(hi ? 0 : 32) + j] = (uint16_t)bits;
     f64 q = 0.0;
     const f64* col = vals + lane * LOB_QSTRIDE;
     // ---- group 0 ----

@@ -123,6 +123,10 @@ struct __attribute__((aligned(64))) LHdr {
 };
 
 #define LOB_PERSIST_N 32
+#define LOB_VD_STRIDE 72      /* u16 per book: 64 verdicts + epoch lo/hi + slot + valid, padded to 144 B */
+#define LOB_NZ_WORDS 256      /* per parity: [0] count of newly written weights, [128..255] their 4096-bit filter */
+#define LOB_NZ_FILTER 128     /* filter words (bit = weight index mod 4096) */
+#define LOB_NZ_NEW_MAX 256    /* above this many new weights the filter is too dense to help: full look-ups */
 
 struct RMPtrs {  // RollingMean<double>
     f64* ring;   // [w][B]
@@ -177,6 +181,12 @@ struct DevState {
     f64* qs_last_b;      // [B][9] Qb(last_state, .)
     u64* mt_state;       // [B][312] std::mt19937_64 state of each book's Agent::gen (DoubleQLearn coin)
     i32* mt_idx;         // [B]
+    // Verdict carry-over: learn(t) saves, per book, which group-1/2 tiles of s' hit a written
+    // weight (9 bits per tiling); act(t+1) evaluates the same state and reuses them instead of 576
+    // bitmap look-ups, OR-ed with a small filter of the bits the update in between newly set.
+    uint16_t* verdict;   // [B][LOB_VD_STRIDE] u16: [2 groups][32 tilings], then epoch (2 x u16), slot, valid
+    i32* nz_new;         // [2 parities][LOB_NZ_WORDS]: count + filter of the weights whose bit flipped 0 -> 1 in an update
+    i32* nz_epoch;       // [1] bumped whenever theta / the bitmap change outside update_kernel
     uint32_t* theta_nz;  // bitmap, bit i set once theta[i] has ever been written: clear bit => theta[i] == +0.0
     f64* theta_sync;  // [M] (multi-GPU) or null
     f64* delta;       // [M] scratch for the all-reduce or null
