@@ -235,6 +235,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
         return LOB_EINVAL;
     }
     P.algo = p->algo; P.theta_private = p->theta_mode == LOB_THETA_PRIVATE;
+    { const char* nc = getenv("LOB_NO_CARRY"); P.carry_verdicts = !(nc && nc[0] == '1'); }
     P.seed = p->seed; P.book_id_offset = p->book_id_offset;
 
     // ---- DevState ----

@@ -271,6 +271,12 @@ __global__ void __launch_bounds__(LOB_BLOCK) act_kernel(DevParams P, DevState S,
     const int bb = have ? b : 0;
     const LHdr h = S.hdr[bb];  // one scalar 64-byte load, issued before the LDS staging
     const i32* nz_new = S.nz_new + (par ^ 1) * LOB_NZ_WORDS;  // written by the previous step's update
+    // everything the verdict carry-over needs is loaded up front, beside the header and the LDS staging
+    const uint16_t* vd = S.verdict + (size_t)bb * LOB_VD_STRIDE;
+    const int n_new = nz_new[0];
+    const uint32_t ep = (uint32_t)S.nz_epoch[0];
+    const u64 tag = *(const u64*)(vd + 64);  // {epoch, slot, valid} in one load
+    uint32_t my_vd = vd[lane ^ 32];
     learn_lds_init(rnd_g, S.vars + (size_t)bb * 48, have, L, nz_new);
     if (!have) return;
     LHdr* hp = S.hdr + b;
@@ -292,13 +298,9 @@ __global__ void __launch_bounds__(LOB_BLOCK) act_kernel(DevParams P, DevState S,
         // learn(t) of this book evaluated the very same State: take over its "weight is zero"
         // verdicts if nothing but update(t) touched theta since (epoch) and that update set only a
         // few new bits (kept in a 4096-bit filter, staged in LDS above).
-        uint16_t* vd = S.verdict + (size_t)b * LOB_VD_STRIDE;
-        const int n_new = nz_new[0];
-        const uint32_t ep = (uint32_t)S.nz_epoch[0];
-        const u64 tag = *(const u64*)(vd + 64);  // {epoch, slot, valid} in one load
-        const bool reuse = ALGO != LOB_ALGO_DOUBLE_Q && mode == 0 && !zero && !P.theta_private && n_new <= LOB_NZ_NEW_MAX &&
+        const bool reuse = ALGO != LOB_ALGO_DOUBLE_Q && mode == 0 && !zero && !P.theta_private && P.carry_verdicts && n_new <= LOB_NZ_NEW_MAX &&
                            tag == vd_tag(ep, src);
-        if (reuse) q_values(P, theta, nz, L.vars[w][src], zero, L.rnd, L.act_terms, L.vals[w], lane, qs, 2, vd, L.newf);
+        if (reuse) q_values(P, theta, nz, L.vars[w][src], zero, L.rnd, L.act_terms, L.vals[w], lane, qs, 2, &my_vd, L.newf);
         else q_values(P, theta, nz, L.vars[w][src], zero, L.rnd, L.act_terms, L.vals[w], lane, qs);
     }
     if (lane < LOB_N_ACTIONS) S.qs_last[(size_t)b * LOB_N_ACTIONS + lane] = qs[lane];
@@ -474,7 +476,9 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
     {
         uint16_t* vd = S.verdict + (size_t)b * LOB_VD_STRIDE;
         const uint32_t ep = (uint32_t)S.nz_epoch[0];
-        q_values(P, theta, nz, vars_to, false, L.rnd, L.act_terms, L.vals[w], lane, qs_to, 1, vd);
+        uint32_t my_vd = 0;
+        q_values(P, theta, nz, vars_to, false, L.rnd, L.act_terms, L.vals[w], lane, qs_to, 1, &my_vd);
+        vd[lane ^ 32] = (uint16_t)my_vd;
         if (lane == 0) *(u64*)(vd + 64) = vd_tag(ep, cur);
     }
     const f64 reward = h.reward;

@@ -149,22 +149,22 @@ __device__ inline void gather9(const DevParams& P, const f64* __restrict__ theta
     }
 }
 
-// vd: this book's verdict row (64 x u16: [group-1][tiling]) or null.
+// vd_io: this lane's 9 verdict bits (lanes 32-63: group 1, lanes 0-31: group 2; row index lane ^ 32).
 __device__ inline void q_values(const DevParams& P, const f64* __restrict__ theta, const uint32_t* __restrict__ nz,
                                 const f32* vars, bool zero,
                                 const uint32_t* rnd, const u64* act_terms /*[3][9] LDS*/, f64* vals, int lane,
-                                f64* out_q, int vd_mode = 0, uint16_t* vd = nullptr, const uint32_t* newf = nullptr) {
+                                f64* out_q, int vd_mode = 0, uint32_t* vd_io = nullptr, const uint32_t* newf = nullptr) {
     const int j = lane & 31, hi = lane >> 5;
     f64 ta[LOB_N_ACTIONS], tb[LOB_N_ACTIONS];
     uint32_t bits = 0;
-    if (vd_mode == 2) bits = vd[(hi ? 0 : 32) + j];  // lanes 32-63 own group 1, lanes 0-31 group 2
+    if (vd_mode == 2) bits = *vd_io;
     if (hi) {
         gather9(P, theta, nz, vars, zero, rnd, act_terms, 1, j, ta, vd_mode, &bits, newf);
     } else {
         gather9(P, theta, nz, vars, zero, rnd, act_terms, 0, j, ta, 0, nullptr, nullptr);
         gather9(P, theta, nz, vars, zero, rnd, act_terms, 2, j, tb, vd_mode, &bits, newf);
     }
-    if (vd_mode == 1) vd[(hi ? 0 : 32) + j] = (uint16_t)bits;
+    if (vd_mode == 1) *vd_io = bits;
     f64 q = 0.0;
     const f64* col = vals + lane * LOB_QSTRIDE;
     // ---- group 0 ----

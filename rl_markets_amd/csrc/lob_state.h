@@ -218,6 +218,7 @@ struct DevParams {
     f32 trace_pow[LOB_TRACE_GENS + 1];  // eligibility by age, iterated float products
     i32 trace_kmax;                   // first age whose eligibility < tolerance
     i32 algo, theta_private;
+    i32 carry_verdicts;  // 0 with LOB_NO_CARRY=1 in the environment (A/B switch for the verdict carry-over)
     u64 seed, book_id_offset;
 };
 

@@ -129,6 +129,9 @@ class Oracle:
     def clear_inventory(self):
         self.lib.oracle_clear_inventory(self.h)
 
+    def handle_terminal(self):
+        self.lib.oracle_handle_terminal(self.h)
+
     def rec(self, book):
         r = StepRec()
         self.lib.oracle_get_rec(self.h, book, C.byref(r))

@@ -280,3 +280,68 @@ def test_same_timestamp_rows_and_crossed_books_batched(algo):
     for b in range(B):
         np.testing.assert_array_equal(eng.theta(b), orc.theta(b))
     assert eng.counters()[1] == orc.counters()[1]
+
+
+@pytest.mark.parametrize("algo", [abi.ALGO_SARSA, abi.ALGO_QLAMBDA])
+def test_verdict_carry_over_is_invalidated(algo):
+    """act_kernel reuses learn_kernel's 'weight was never written' verdicts for the same State
+    (verdict carry-over).  A tiny weight table makes group-1/2 tiles collide with
+    written weights all the time, and the sequence walks through everything that must void the
+    saved verdicts: an externally driven step, lob_theta_set, a new episode."""
+    B = 16
+    p, g, rec, eng, orc = make(depth=5, n_events=500, B=B, algo=algo, theta_mode=abi.THETA_SHARED, mem=1 << 13)
+    eng.reset()
+    orc.reset()
+    rng = np.random.default_rng(11)
+    n = 0
+
+    def td(k):
+        nonlocal n
+        for _ in range(k):
+            eng.td_step(1)
+            orc.td_step(1)
+            compare_learner_step(eng, orc, "carry-over step %d" % n, exact=False, rtol=1e-9)
+            n += 1
+
+    td(25)
+    acts = rng.integers(0, 9, size=B).astype(np.int32)
+    eng.step(acts)
+    orc.env_step(acts)
+    compare_env(eng, orc, "after external step")
+    td(10)
+    th = eng.theta()
+    th[rng.integers(0, th.size, size=2000)] += 1e-3  # writes weights the bitmap has never seen
+    eng.set_theta(th)
+    orc.theta()[:] = th
+    td(10)
+    eng.clear_inventory(); orc.clear_inventory()
+    eng.handle_terminal(); orc.handle_terminal()
+    eng.reset(); orc.reset()
+    td(25)
+    np.testing.assert_allclose(eng.theta(), orc.theta(), rtol=1e-9, atol=1e-12)
+
+
+def test_verdict_carry_over_on_off_identical(monkeypatch):
+    """Same run with the carry-over switched off (LOB_NO_CARRY=1, read by lob_create): identical
+    books, actions and weights, also across evaluation steps in the middle of training (a
+    sequence the reference never produces, so there is no oracle for it)."""
+    B = 16
+    out = []
+    for off in ("1", "0"):
+        monkeypatch.setenv("LOB_NO_CARRY", off)
+        p, g, rec, eng, orc = make(depth=5, n_events=500, B=B, algo=abi.ALGO_QLAMBDA, theta_mode=abi.THETA_SHARED, mem=1 << 13)
+        orc.close()
+        eng.reset()
+        trail = []
+        for phase in range(4):
+            for _ in range(15):
+                eng.td_step(1)
+                trail.append((eng.last_actions().copy(), bytes(eng.get_books())))
+            eng.eval_step(3)
+            trail.append((eng.last_actions().copy(), bytes(eng.get_books())))
+        out.append((trail, eng.theta()))
+        eng.close()
+    for k, ((a0, b0), (a1, b1)) in enumerate(zip(out[0][0], out[1][0])):
+        np.testing.assert_array_equal(a0, a1, err_msg="actions, record %d" % k)
+        assert b0 == b1, "books differ at record %d" % k
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-9, atol=1e-12)
