@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(LOB_ENV_BLOCK) env_kernel(const DevParams* __r
         }
     }
     // one atomic per wave for the counters
-    for (int off = 32; off > 0; off >>= 1) {
+    for (int off = LOB_ENV_BLOCK / 2; off > 0; off >>= 1) {
         d_steps += __shfl_down(d_steps, off);
         d_events += __shfl_down(d_events, off);
     }
@@ -536,23 +536,38 @@ __global__ void __launch_bounds__(LOB_BLOCK) update_kernel(DevParams P, DevState
     const i32* tr_idx = S.tr_idx + (size_t)b * LOB_TRACE_GENS * 32;
     const uint32_t* tr_alive = S.tr_alive + (size_t)b * LOB_TRACE_GENS;
     const int j = lane & 31, half = lane >> 5;
-    for (int k0 = 0; k0 < n; k0 += 2) {
-        const int k = k0 + half;  // age
-        if (k < n) {
-            const int slot = (head - k + 2 * LOB_TRACE_GENS) % LOB_TRACE_GENS;
-            if ((tr_alive[slot] >> j) & 1u) {
-                const i32 f = tr_idx[slot * 32 + j];
-                const f64 val = scaled * (f64)P.trace_pow[k];
-                __hip_atomic_fetch_add(&theta[f], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t bit = 1u << (f & 31);
-                if (!(nz[f >> 5] & bit)) {  // monotone: set once, then a plain L2 hit
-                    const uint32_t old = atomicOr(&nz[f >> 5], bit);
-                    if (!(old & bit) && !P.theta_private && h.stepped != 2) {  // this lane flipped it: tell the next act_kernel
-                        i32* nz_new = S.nz_new + par * LOB_NZ_WORDS;
-                        atomicAdd(&nz_new[0], 1);
-                        atomicOr((uint32_t*)&nz_new[LOB_NZ_FILTER + ((f >> 5) & (LOB_NZ_FILTER - 1))], bit);
-                    }
-                }
+    // Three phases, each with all of its loads in flight at once (the kernel is a chain of
+    // dependent memory round trips otherwise): alive masks -> trace indices -> adds + bitmap words.
+    const uint32_t my_alive = tr_alive[j];  // lane j (and j + 32) holds generation slot j's mask
+    constexpr int NIT = LOB_TRACE_GENS / 2;
+    i32 f[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        const int k = 2 * it + half;  // age
+        const int slot = (head - k + 2 * LOB_TRACE_GENS) % LOB_TRACE_GENS;
+        const uint32_t alive = __shfl(my_alive, slot);
+        f[it] = (k < n && ((alive >> j) & 1u)) ? tr_idx[slot * 32 + j] : -1;
+    }
+    uint32_t word[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        word[it] = 0xffffffffu;
+        if (f[it] >= 0) {
+            const f64 val = scaled * (f64)P.trace_pow[2 * it + half];
+            __hip_atomic_fetch_add(&theta[f[it]], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            word[it] = nz[f[it] >> 5];
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        if (f[it] < 0) continue;
+        const uint32_t bit = 1u << (f[it] & 31);
+        if (!(word[it] & bit)) {  // monotone: set once, then a plain L2 hit
+            const uint32_t old = atomicOr(&nz[f[it] >> 5], bit);
+            if (!(old & bit) && !P.theta_private && h.stepped != 2) {  // this lane flipped it: tell the next act_kernel
+                i32* nz_new = S.nz_new + par * LOB_NZ_WORDS;
+                atomicAdd(&nz_new[0], 1);
+                atomicOr((uint32_t*)&nz_new[LOB_NZ_FILTER + ((f[it] >> 5) & (LOB_NZ_FILTER - 1))], bit);
             }
         }
     }
