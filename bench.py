@@ -95,6 +95,9 @@ def main():
     ap.add_argument("--algo", default="q_lambda", choices=["q_lambda", "sarsa"])
     ap.add_argument("--memory-size", type=int, default=20000000)
     ap.add_argument("--events", type=int, default=0, help="events per book (0 = 64 warm-up + 2048)")
+    ap.add_argument("--replay", type=int, default=0, metavar="N_TOTAL",
+                    help="config 5 instead of the headline: every book replays ONE recorded stream of N_TOTAL events "
+                         "from its own phase (lob_load_events_shared); not the headline workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -132,7 +135,15 @@ def main():
         g.n_events = need
 
     eng = engine.Engine(p, args.books, device=local_rank)
-    eng.gen_events(g)       # synthetic streams generated directly in HBM (never timed)
+    if args.replay:
+        import numpy as np
+        g1 = engine.default_gen_params()
+        g1.n_events = max(args.replay, g.n_events)
+        day = engine.gen_stream_host(g1, args.depth, 2, 0, 1)[0]
+        phase = np.random.default_rng(1994 + rank).integers(0, g1.n_events - g.n_events + 1, size=args.books)
+        eng.load_events_shared(day, phase, g.n_events)
+    else:
+        eng.gen_events(g)   # synthetic streams generated directly in HBM (never timed)
     t_reset = time.perf_counter()
     eng.reset()             # Initialise(): includes the once-per-episode market pre-pass over the whole stream
     eng.sync()
@@ -229,9 +240,10 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "C3: %d parallel synthetic %d-level books per GPU, %s with eligibility traces, "
-                            "tile-coded linear Q (32 tilings x 3 groups x 9 actions), memory_size %d, "
-                            "shared theta, synchronous-batch TD" % (args.books, args.depth,
+                "workload": (("C5: %d books replaying one recorded %d-level stream from per-book phases, reward pnl_damped, %s, "
+                              if args.replay else "C3: %d parallel synthetic %d-level books per GPU, %s with eligibility traces, ") +
+                             "tile-coded linear Q (32 tilings x 3 groups x 9 actions), memory_size %d, "
+                             "shared theta, synchronous-batch TD") % (args.books, args.depth,
                                                                    "Q(lambda)" if args.algo == "q_lambda" else "SARSA(lambda)",
                                                                    args.memory_size),
                 "books_per_gpu": args.books, "depth": args.depth, "events_per_book": g.n_events,

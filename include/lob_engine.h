@@ -260,6 +260,15 @@ void lob_destroy(lob_engine* e);
  * upload host records / synthesise the same records directly in HBM. */
 int lob_load_events(lob_engine* e, const uint32_t* host_records, int32_t n_events);
 int lob_gen_events_device(lob_engine* e, const lob_gen_params* g);
+/* One recorded stream replayed by every book (BASELINE config 5: a converted LOBSTER day):
+ * `host_records` holds n_total records of ONE book; book b plays the n_events records
+ * starting at record phase[b] (0 <= phase[b], phase[b] + n_events <= n_total), i.e. it
+ * behaves exactly like a book loaded with that window through lob_load_events.  The
+ * reference replays one file pair per episode and thread (Intraday::LoadData,
+ * src/environment/intraday.cpp:141-150; file cycling in src/experiment/serial.cpp:38-50);
+ * the phases stand in for its per-thread choice of episode file. */
+int lob_load_events_shared(lob_engine* e, const uint32_t* host_records, int64_t n_total, const int64_t* phase,
+                           int32_t n_events);
 
 /* ---- environment interface (environment::Base, include/environment/base.h:117-151) */
 

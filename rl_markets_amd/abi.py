@@ -131,6 +131,7 @@ def load():
         "lob_create": (C.c_int, [P(Params), C.c_int32, C.c_int32, P(vp)]),
         "lob_destroy": (None, [vp]),
         "lob_load_events": (C.c_int, [vp, vp, C.c_int32]),
+        "lob_load_events_shared": (C.c_int, [vp, vp, C.c_int64, vp, C.c_int32]),
         "lob_gen_events_device": (C.c_int, [vp, P(GenParams)]),
         "lob_reset": (C.c_int, [vp]),
         "lob_step": (C.c_int, [vp, vp]),

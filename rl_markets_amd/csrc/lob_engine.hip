@@ -44,6 +44,7 @@ struct lob_engine {
     std::vector<void*> allocs;
     uint32_t* rnd_dev = nullptr;
     uint32_t* records_dev = nullptr;
+    i64* phase_dev = nullptr;  // replayed stream: first record of every book's window
     Track* track_dev = nullptr;
     i32* actions_dev = nullptr;
     lob_book_dump* dump_dev = nullptr;
@@ -348,6 +349,7 @@ void lob_destroy(lob_engine* e) {
     for (auto ev : e->event_pool) hipEventDestroy(ev);
     for (void* p : e->allocs) hipFree(p);
     if (e->records_dev) hipFree(e->records_dev);
+    if (e->phase_dev) hipFree(e->phase_dev);
     if (e->track_dev) hipFree(e->track_dev);
     if (e->dump_dev) hipFree(e->dump_dev);
     if (e->stream) hipStreamDestroy(e->stream);
@@ -363,10 +365,13 @@ static int finalize_episode(lob_engine* e) {
     return LOB_OK;
 }
 
-static int set_records(lob_engine* e, int32_t n_events) {
+// n_rows: records to allocate (B * n_events for per-book streams, the stream length for a replayed one)
+static int set_records(lob_engine* e, int32_t n_events, size_t n_rows) {
     { int rc = finalize_episode(e); if (rc) return rc; }  // needs the old stream
     if (e->records_dev) { hipFree(e->records_dev); e->records_dev = nullptr; }
-    size_t bytes = (size_t)e->B * n_events * e->P.W * 4;
+    if (e->phase_dev) { hipFree(e->phase_dev); e->phase_dev = nullptr; }
+    e->S.rec_phase = nullptr;
+    size_t bytes = n_rows * e->P.W * 4;
     hipError_t err = hipMalloc((void**)&e->records_dev, bytes);
     if (err != hipSuccess) { lob_set_error("hipMalloc(records) failed"); return LOB_ENOMEM; }
     if (e->track_dev) { hipFree(e->track_dev); e->track_dev = nullptr; }
@@ -385,17 +390,41 @@ int lob_load_events(lob_engine* e, const uint32_t* host_records, int32_t n_event
     HIPCHK(hipSetDevice(e->device));
     int rc = lob_validate_stream(host_records, e->P.D, e->P.T, e->B, n_events);
     if (rc != LOB_OK) return rc;
-    rc = set_records(e, n_events);
+    rc = set_records(e, n_events, (size_t)e->B * n_events);
     if (rc != LOB_OK) return rc;
     HIPCHK(hipMemcpyAsync(e->records_dev, host_records, (size_t)e->B * n_events * e->P.W * 4, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     return LOB_OK;
 }
 
+int lob_load_events_shared(lob_engine* e, const uint32_t* host_records, int64_t n_total, const int64_t* phase, int32_t n_events) {
+    if (!e || !host_records || !phase || n_events < 2 || n_total < n_events || n_total > INT32_MAX) {
+        lob_set_error("lob_load_events_shared: bad argument");
+        return LOB_EINVAL;
+    }
+    for (int b = 0; b < e->B; b++)
+        if (phase[b] < 0 || phase[b] + n_events > n_total) {
+            lob_set_error("lob_load_events_shared: phase[" + std::to_string(b) + "] + n_events runs past the stream");
+            return LOB_EINVAL;
+        }
+    HIPCHK(hipSetDevice(e->device));
+    int rc = lob_validate_stream(host_records, e->P.D, e->P.T, 1, (int32_t)n_total);
+    if (rc != LOB_OK) return rc;
+    rc = set_records(e, n_events, (size_t)n_total);
+    if (rc != LOB_OK) return rc;
+    hipError_t err = hipMalloc((void**)&e->phase_dev, (size_t)e->B * sizeof(i64));
+    if (err != hipSuccess) { lob_set_error("hipMalloc(phase) failed"); return LOB_ENOMEM; }
+    HIPCHK(hipMemcpyAsync(e->records_dev, host_records, (size_t)n_total * e->P.W * 4, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->phase_dev, phase, (size_t)e->B * sizeof(i64), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->S.rec_phase = e->phase_dev;
+    return LOB_OK;
+}
+
 int lob_gen_events_device(lob_engine* e, const lob_gen_params* g) {
     if (!e || !g || g->n_events < 2) { lob_set_error("lob_gen_events_device: bad argument"); return LOB_EINVAL; }
     HIPCHK(hipSetDevice(e->device));
-    int rc = set_records(e, g->n_events);
+    int rc = set_records(e, g->n_events, (size_t)e->B * g->n_events);
     if (rc != LOB_OK) return rc;
     hipLaunchKernelGGL(gen_events_kernel, dim3(grid_lanes(e->B)), dim3(256), 0, e->stream, *g, e->P.D, e->P.T,
                        e->P.book_id_offset, e->B, e->records_dev);

@@ -42,11 +42,13 @@ struct EnvCtx {
     const DevParams& P;
     const DevState& S;
     int b;
-    __device__ EnvCtx(const DevParams& p, const DevState& s, int book) : P(p), S(s), b(book) {}
-    __device__ void err(int bit) const { atomicOr(S.error_flag, bit); }
-    __device__ const uint32_t* row(int i) const {
-        return S.records + ((size_t)b * (size_t)S.n_events + (size_t)i) * (size_t)P.W;
+    const uint32_t* rows;  // this book's first record: its own stream, or its window of the replayed one
+    __device__ EnvCtx(const DevParams& p, const DevState& s, int book) : P(p), S(s), b(book) {
+        const size_t first = s.rec_phase ? (size_t)s.rec_phase[book] : (size_t)book * (size_t)s.n_events;
+        rows = s.records + first * (size_t)p.W;
     }
+    __device__ void err(int bit) const { atomicOr(S.error_flag, bit); }
+    __device__ const uint32_t* row(int i) const { return rows + (size_t)i * (size_t)P.W; }
     __device__ const Track& track(int k) const { return S.track[(size_t)b * (size_t)S.n_events + (size_t)k]; }
     __device__ Track& track_w(int k) const { return S.track[(size_t)b * (size_t)S.n_events + (size_t)k]; }
 };

@@ -149,7 +149,8 @@ struct DevState {
     i32 B;
     i32 D, T, W;       // depth, trade slots, record words
     i32 n_events;
-    const uint32_t* records;  // [B][n_events][W]
+    const uint32_t* records;  // [B][n_events][W], or one replayed stream [n_total][W] when rec_phase is set
+    const i64* rec_phase;     // [B] first record of each book's n_events-long window (lob_load_events_shared), else null
 
 #define X(t, n) t* n;
     LOB_ENV_FIELDS(X)

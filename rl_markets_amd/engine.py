@@ -117,6 +117,14 @@ class Engine:
         assert rec.shape[0] == self.B
         self._check(self.lib.lob_load_events(self.h, _ptr(rec), rec.shape[1]))
 
+    def load_events_shared(self, records, phase, n_events):
+        """One recorded stream [n_total][W] replayed by every book from its own phase."""
+        rec = np.ascontiguousarray(records, dtype=np.uint32)
+        assert rec.ndim == 2
+        ph = np.ascontiguousarray(phase, dtype=np.int64)
+        assert ph.shape == (self.B,)
+        self._check(self.lib.lob_load_events_shared(self.h, _ptr(rec), rec.shape[0], _ptr(ph), n_events))
+
     def gen_events(self, gen):
         self._check(self.lib.lob_gen_events_device(self.h, C.byref(gen)))
 

@@ -230,6 +230,12 @@ public:
 
     // LoadData(symbol, md_path, tas_path) (intraday.cpp:141-150): records instead of CSV paths
     void LoadData(const uint32_t* records, int n_events) { check(lob_load_events(e_, records, n_events), "LoadData"); invalidate(); }
+    // one recorded day replayed by every book, book b from record phase[b] on (BASELINE config 5)
+    void LoadReplay(const uint32_t* records, int64_t n_total, const std::vector<int64_t>& phase, int n_events) {
+        if ((int)phase.size() != B_) throw std::invalid_argument("LoadReplay: one phase per book");
+        check(lob_load_events_shared(e_, records, n_total, phase.data(), n_events), "LoadData");
+        invalidate();
+    }
     void LoadSynthetic(const lob_gen_params& g) { check(lob_gen_events_device(e_, &g), "LoadData"); invalidate(); }
 
     bool Initialise() {  // false = no data for at least one book (base.h:122)

@@ -1,0 +1,124 @@
+"""BASELINE config 5: every book replays ONE recorded LOBSTER-format stream from its own phase
+(lob_load_events_shared), with the risk-averse rewards.  Parity against the oracle at a size it
+finishes in seconds (the oracle gets each book's window as a private copy), then at the full
+65 536 books through properties that do not depend on the size."""
+import numpy as np
+import pytest
+
+from rl_markets_amd import abi, engine
+from tests import oracle_lib as ol
+from tests.csv_io import write_lobster
+from tests.parity import compare_learner_step, dumps_to_np
+
+pytestmark = pytest.mark.gpu
+
+
+def lobster_day(tmp_path, n_total, depth=10, trades=2):
+    """Synthetic stream -> LOBSTER message/orderbook files -> lob_convert_lobster -> records."""
+    g = engine.default_gen_params()
+    g.n_events = n_total
+    rec = engine.gen_stream_host(g, depth, trades, 0, 1)
+    ob, msg = str(tmp_path / "ob.csv"), str(tmp_path / "msg.csv")
+    write_lobster(rec[0], depth, trades, depth, ob, msg)
+    day = engine.convert_lobster(ob, msg, depth, depth, trades)[0]
+    assert day.shape[0] == n_total
+    return day
+
+
+def replay_params(reward, algo=abi.ALGO_QLAMBDA, mem=1 << 20):
+    p = engine.default_params()
+    p.depth, p.max_trades = 10, 2
+    p.algo, p.theta_mode, p.memory_size = algo, abi.THETA_SHARED, mem
+    p.reward = reward
+    if reward == abi.REWARD_MM_LINEAR:
+        p.pos_weight = 0.5  # the inventory-penalised variant
+    return p
+
+
+@pytest.mark.parametrize("reward", [abi.REWARD_PNL_DAMPED, abi.REWARD_MM_LINEAR])
+def test_replayed_stream_matches_oracle(tmp_path, reward):
+    B, n_total, n_events = 24, 2500, 500
+    day = lobster_day(tmp_path, n_total)
+    rng = np.random.default_rng(3)
+    phase = rng.integers(0, n_total - n_events + 1, size=B)
+    phase[0], phase[1], phase[2] = 0, n_total - n_events, phase[3]  # both ends, and two books in step
+    p = replay_params(reward)
+    eng = engine.Engine(p, B)
+    eng.load_events_shared(day, phase, n_events)
+    windows = np.stack([day[s:s + n_events] for s in phase])
+    orc = ol.Oracle(p, windows)
+    eng.reset()
+    orc.reset()
+    for step in range(150):
+        eng.td_step(1)
+        orc.td_step(1)
+        compare_learner_step(eng, orc, "replay step %d" % step, exact=False, rtol=1e-9)
+    np.testing.assert_allclose(eng.theta(), orc.theta(), rtol=1e-9, atol=1e-12)
+    # a book with its own copy of the window is the same book
+    eng2 = engine.Engine(p, B)
+    eng2.load_events(windows)
+    eng2.reset()
+    eng2.td_step(150)
+    d1, d2 = dumps_to_np(eng.get_books()), dumps_to_np(eng2.get_books())
+    for name in d1.dtype.names:
+        assert np.array_equal(d1[name], d2[name]), name
+
+
+def test_shared_stream_arguments():
+    p = replay_params(abi.REWARD_PNL_DAMPED)
+    g = engine.default_gen_params()
+    g.n_events = 300
+    day = engine.gen_stream_host(g, 10, 2, 0, 1)[0]
+    eng = engine.Engine(p, 4)
+    with pytest.raises(engine.LobError):
+        eng.load_events_shared(day, [0, 0, 0, 101], 200)   # runs past the stream
+    with pytest.raises(engine.LobError):
+        eng.load_events_shared(day, [0, -1, 0, 0], 200)
+    eng.load_events_shared(day, [0, 50, 100, 100], 200)
+    eng.reset()
+    eng.td_step(5)
+    eng.load_events(np.stack([day[:200]] * 4))                # back to per-book streams
+    eng.reset()
+    eng.td_step(5)
+
+
+def test_config5_full_size(tmp_path):
+    """65 536 books on one replayed day.  With alpha = 0 the books do not interact (theta stays 0,
+    actions come from each book's own RNG stream), so any book of the big run must equal a
+    one-book engine given the same global book id and a private copy of its window."""
+    B, n_total, n_events, steps = 65536, 6000, 400, 60
+    day = lobster_day(tmp_path, n_total)
+    rng = np.random.default_rng(5)
+    phase = rng.integers(0, n_total - n_events + 1, size=B)
+    p = replay_params(abi.REWARD_PNL_DAMPED, mem=20000000)
+    p.alpha = 0.0
+    eng = engine.Engine(p, B)
+    eng.load_events_shared(day, phase, n_events)
+    eng.reset()
+    eng.td_step(steps)
+    cnt = eng.counters()
+    assert cnt[0] == steps * B
+    assert not eng.theta().any()
+    sample = [0, 1, 4097, 32768, 65535]
+    big = dumps_to_np(eng.get_books())
+    acts = eng.last_actions()
+    rew = eng.last_rewards()
+    for b in sample:
+        p1 = replay_params(abi.REWARD_PNL_DAMPED, mem=20000000)
+        p1.alpha = 0.0
+        p1.book_id_offset = b
+        one = engine.Engine(p1, 1)
+        one.load_events(day[phase[b]:phase[b] + n_events][None])
+        one.reset()
+        one.td_step(steps)
+        d = dumps_to_np(one.get_books())
+        for name in d.dtype.names:
+            assert np.array_equal(d[name][0], big[name][b]), (b, name)
+        assert one.last_actions()[0] == acts[b] and one.last_rewards()[0] == rew[b]
+        one.close()
+    # and with learning on: the run completes, every book steps, weights get written
+    eng.set_alpha(0.001)
+    eng.td_step(steps)
+    assert eng.counters()[0] == 2 * steps * B
+    th = eng.theta()
+    assert np.isfinite(th).all() and np.count_nonzero(th) > 1000
