@@ -286,10 +286,10 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     if (rc == LOB_OK) rc = dev_alloc(e, &S.tr_idx, B * LOB_TRACE_GENS * 32);
     if (rc == LOB_OK) rc = dev_alloc(e, &S.tr_alive, B * LOB_TRACE_GENS);
     if (rc == LOB_OK) rc = dev_alloc(e, &S.theta, (size_t)P.M * (P.theta_private ? B : 1));
-    if (rc == LOB_OK) rc = dev_alloc(e, &S.theta_nz, (size_t)((P.M + 31) >> 5) * (P.theta_private ? B : 1));
+    if (rc == LOB_OK) rc = dev_alloc(e, &S.theta_nz, LOB_NZ_NWORDS(P.M) * (P.theta_private ? B : 1));
     if (p->algo == LOB_ALGO_DOUBLE_Q) {
         if (rc == LOB_OK) rc = dev_alloc(e, &S.theta_b, (size_t)P.M * (P.theta_private ? B : 1));
-        if (rc == LOB_OK) rc = dev_alloc(e, &S.theta_b_nz, (size_t)((P.M + 31) >> 5) * (P.theta_private ? B : 1));
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.theta_b_nz, LOB_NZ_NWORDS(P.M) * (P.theta_private ? B : 1));
         if (rc == LOB_OK) rc = dev_alloc(e, &S.qs_last_b, B * LOB_N_ACTIONS);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.mt_state, B * LOB_MT_N);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.mt_idx, B);
@@ -644,7 +644,7 @@ static int theta_slot(lob_engine* e, int32_t which, f64** th, uint32_t** nz) {
     const bool second = which >= n;
     const int idx = second ? which - n : which;
     *th = (second ? e->S.theta_b : e->S.theta) + (size_t)idx * e->P.M;
-    *nz = (second ? e->S.theta_b_nz : e->S.theta_nz) + (size_t)idx * (size_t)((e->P.M + 31) >> 5);
+    *nz = (second ? e->S.theta_b_nz : e->S.theta_nz) + (size_t)idx * LOB_NZ_NWORDS(e->P.M);
     return LOB_OK;
 }
 int lob_theta_get(lob_engine* e, int32_t which, double* host_out, int64_t count) {

@@ -292,7 +292,7 @@ __global__ void __launch_bounds__(LOB_BLOCK) act_kernel(DevParams P, DevState S,
     const bool zero = mode == 0 && ((h.zero_mask >> src) & 1);
     const f64* theta = S.theta + (P.theta_private ? (size_t)b * (size_t)P.M : 0);
     f64 qs[LOB_N_ACTIONS];
-    const size_t nz_off = P.theta_private ? (size_t)b * (size_t)((P.M + 31) >> 5) : 0;
+    const size_t nz_off = P.theta_private ? (size_t)b * LOB_NZ_NWORDS(P.M) : 0;
     const uint32_t* nz = S.theta_nz + nz_off;
     {
         // learn(t) of this book evaluated the very same State: take over its "weight is zero"
@@ -470,7 +470,7 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
 
     // ---- UpdateWeights: TD error under theta_t ----
     const f64* theta = S.theta + (P.theta_private ? (size_t)b * (size_t)P.M : 0);
-    const size_t nz_off = P.theta_private ? (size_t)b * (size_t)((P.M + 31) >> 5) : 0;
+    const size_t nz_off = P.theta_private ? (size_t)b * LOB_NZ_NWORDS(P.M) : 0;
     const uint32_t* nz = S.theta_nz + nz_off;
     f64 qs_to[LOB_N_ACTIONS];
     {
@@ -532,7 +532,7 @@ __global__ void __launch_bounds__(LOB_BLOCK) update_kernel(DevParams P, DevState
     const int n = h.tr_n, head = h.tr_head;
     const f64 scaled = h.upd / (f64)LOB_N_TILINGS;
     f64* theta = (h.stepped == 2 ? S.theta_b : S.theta) + (P.theta_private ? (size_t)b * (size_t)P.M : 0);
-    uint32_t* nz = (h.stepped == 2 ? S.theta_b_nz : S.theta_nz) + (P.theta_private ? (size_t)b * (size_t)((P.M + 31) >> 5) : 0);
+    uint32_t* nz = (h.stepped == 2 ? S.theta_b_nz : S.theta_nz) + (P.theta_private ? (size_t)b * LOB_NZ_NWORDS(P.M) : 0);
     const i32* tr_idx = S.tr_idx + (size_t)b * LOB_TRACE_GENS * 32;
     const uint32_t* tr_alive = S.tr_alive + (size_t)b * LOB_TRACE_GENS;
     const int j = lane & 31, half = lane >> 5;
@@ -555,19 +555,19 @@ __global__ void __launch_bounds__(LOB_BLOCK) update_kernel(DevParams P, DevState
         if (f[it] >= 0) {
             const f64 val = scaled * (f64)P.trace_pow[2 * it + half];
             __hip_atomic_fetch_add(&theta[f[it]], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            word[it] = nz[f[it] >> 5];
+            word[it] = nz[LOB_NZ_WORD(f[it])];
         }
     }
 #pragma unroll
     for (int it = 0; it < NIT; it++) {
         if (f[it] < 0) continue;
-        const uint32_t bit = 1u << (f[it] & 31);
+        const uint32_t bit = LOB_NZ_BIT(f[it]);
         if (!(word[it] & bit)) {  // monotone: set once, then a plain L2 hit
-            const uint32_t old = atomicOr(&nz[f[it] >> 5], bit);
+            const uint32_t old = atomicOr(&nz[LOB_NZ_WORD(f[it])], bit);
             if (!(old & bit) && !P.theta_private && h.stepped != 2) {  // this lane flipped it: tell the next act_kernel
                 i32* nz_new = S.nz_new + par * LOB_NZ_WORDS;
                 atomicAdd(&nz_new[0], 1);
-                atomicOr((uint32_t*)&nz_new[LOB_NZ_FILTER + ((f[it] >> 5) & (LOB_NZ_FILTER - 1))], bit);
+                atomicOr((uint32_t*)&nz_new[LOB_NZ_FILTER + (LOB_NZ_WORD(f[it]) & (LOB_NZ_FILTER - 1))], bit);  // keyed like the map: by group of weights
             }
         }
     }
@@ -633,8 +633,8 @@ __global__ void delta_apply_kernel(f64* theta, f64* sync, const f64* __restrict_
         theta[i] = t;
         sync[i] = t;
         if (d != 0.0) {  // written on some rank: from now on the weight must be fetched
-            const uint32_t bit = 1u << (i & 31);
-            if (!(nz[i >> 5] & bit)) atomicOr(&nz[i >> 5], bit);
+            const uint32_t bit = LOB_NZ_BIT(i);
+            if (!(nz[LOB_NZ_WORD(i)] & bit)) atomicOr(&nz[LOB_NZ_WORD(i)], bit);
         }
     }
 }
@@ -643,12 +643,12 @@ __global__ void rebuild_nz_kernel(const f64* __restrict__ theta, uint32_t* nz, i
     i64 wi = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (wi == 0) atomicAdd(nz_epoch, 1);
     const i64 stride = (i64)gridDim.x * blockDim.x;
-    const i64 words = (M + 31) >> 5;
+    const i64 words = (i64)LOB_NZ_NWORDS(M);
     for (; wi < words; wi += stride) {
         uint32_t m = 0;
-        for (int k = 0; k < 32; k++) {
-            const i64 i = wi * 32 + k;
-            if (i < M && __double_as_longlong(theta[i]) != 0) m |= 1u << k;
+        for (int k = 0; k < (32 << LOB_NZ_SHIFT); k++) {
+            const i64 i = (wi << (LOB_NZ_SHIFT + 5)) + k;
+            if (i < M && __double_as_longlong(theta[i]) != 0) m |= LOB_NZ_BIT(i);
         }
         nz[wi] = m;
     }

@@ -113,7 +113,7 @@ __device__ inline int argmax_ties(const f64* qs, Rng& g) {
 // value used is bit-identical either way.
 // vd_mode 0: look the bits up in the bitmap; 1: look up AND return them in *vd_bits (learn saves
 // them); 2: take *vd_bits as the verdicts (act re-using learn's), OR-ed with the filter `newf` (LDS,
-// 4096 bits, bit = index mod 4096) of the weights written for the first time since.  A filter
+// 4096 bits, keyed like the map itself) of the map bits set for the first time since.  A filter
 // false positive only costs a fetch of a weight that is still exactly 0.0.
 __device__ inline void gather9(const DevParams& P, const f64* __restrict__ theta, const uint32_t* __restrict__ nz,
                                const f32* vars, bool zero, const uint32_t* rnd, const u64* act_terms, int g, int j,
@@ -132,14 +132,14 @@ __device__ inline void gather9(const DevParams& P, const f64* __restrict__ theta
         bits = *vd_bits;
 #pragma unroll
         for (int a = 0; a < LOB_N_ACTIONS; a++)
-            bits |= ((newf[(idx[a] >> 5) & (LOB_NZ_FILTER - 1)] >> (idx[a] & 31)) & 1u) << a;
+            bits |= ((newf[LOB_NZ_WORD(idx[a]) & (LOB_NZ_FILTER - 1)] & LOB_NZ_BIT(idx[a])) ? 1u : 0u) << a;
     } else {
         uint32_t word[LOB_N_ACTIONS];
 #pragma unroll
-        for (int a = 0; a < LOB_N_ACTIONS; a++) word[a] = nz[idx[a] >> 5];
+        for (int a = 0; a < LOB_N_ACTIONS; a++) word[a] = nz[LOB_NZ_WORD(idx[a])];
         bits = 0;
 #pragma unroll
-        for (int a = 0; a < LOB_N_ACTIONS; a++) bits |= ((word[a] >> (idx[a] & 31)) & 1u) << a;
+        for (int a = 0; a < LOB_N_ACTIONS; a++) bits |= ((word[a] & LOB_NZ_BIT(idx[a])) ? 1u : 0u) << a;
         if (vd_mode == 1) *vd_bits = bits;
     }
 #pragma unroll

@@ -124,8 +124,15 @@ struct __attribute__((aligned(64))) LHdr {
 
 #define LOB_PERSIST_N 32
 #define LOB_VD_STRIDE 72      /* u16 per book: 64 verdicts + epoch lo/hi + slot + valid, padded to 144 B */
+/* theta's "ever written" map: one bit per LOB_NZ_GRAN = 8 consecutive weights (312 KB at M = 20M, so
+ * it stays L2-resident under the streaming traffic; one bit per weight, 2.5 MB, did not).  A set
+ * bit only means "fetch the weight"; an unwritten neighbour then reads as exactly +0.0. */
+#define LOB_NZ_SHIFT 3
+#define LOB_NZ_WORD(i) ((i) >> (LOB_NZ_SHIFT + 5))
+#define LOB_NZ_BIT(i) (1u << (((i) >> LOB_NZ_SHIFT) & 31))
+#define LOB_NZ_NWORDS(M) ((((size_t)(M) >> LOB_NZ_SHIFT) >> 5) + 1)
 #define LOB_NZ_WORDS 256      /* per parity: [0] count of newly written weights, [128..255] their 4096-bit filter */
-#define LOB_NZ_FILTER 128     /* filter words (bit = weight index mod 4096) */
+#define LOB_NZ_FILTER 128     /* filter words (bit = map bit index mod 4096) */
 #define LOB_NZ_NEW_MAX 256    /* above this many new weights the filter is too dense to help: full look-ups */
 
 struct RMPtrs {  // RollingMean<double>

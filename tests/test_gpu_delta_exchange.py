@@ -56,7 +56,8 @@ def main():
         tot = ts[0] + ts[1]          # stands in for all_reduce(SUM)
         for t in ts:
             t.copy_(tot)
-        torch.cuda.synchronize()
+        for b in backs:
+            b.after_all_reduce()   # staged tensor -> the engine's buffer
         for e in engs:
             e.delta_apply()
         ototal = sum(o.theta(0) - osync for o in orcs)
@@ -67,6 +68,22 @@ def main():
     np.testing.assert_array_equal(t0, t1)
     np.testing.assert_allclose(t0, orcs[0].theta(0), rtol=1e-9, atol=1e-15)
     assert np.count_nonzero(t0) > 100
+    # RCCL itself (one rank: the only collective a 1-GPU box can run): f64 all-reduce on the staged
+    # tensor and on the engine's own hipMalloc'ed buffer
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    engs[0].td_step(4)
+    t = backs[0].delta_tensor()
+    want = t.clone()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    dist.all_reduce(backs[0].view, op=dist.ReduceOp.SUM)
+    torch.cuda.synchronize()
+    assert torch.equal(t, want) and torch.equal(backs[0].view, want) and int((want != 0).sum()) > 0
+    backs[0].after_all_reduce()
+    engs[0].delta_apply()
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

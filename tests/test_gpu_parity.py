@@ -345,3 +345,19 @@ def test_verdict_carry_over_on_off_identical(monkeypatch):
         np.testing.assert_array_equal(a0, a1, err_msg="actions, record %d" % k)
         assert b0 == b1, "books differ at record %d" % k
     np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-9, atol=1e-12)
+
+
+def test_config2_full_size_against_oracle():
+    """BASELINE config 2 at its full size: 4 096 parallel 10-level books, SARSA(lambda), shared
+    20M-weight table -- small enough for the oracle to follow step by step for a while."""
+    B = 4096
+    p, g, rec, eng, orc = make(depth=10, n_events=160, B=B, algo=abi.ALGO_SARSA, theta_mode=abi.THETA_SHARED, mem=20000000)
+    eng.reset()
+    orc.reset()
+    for step in range(12):
+        eng.td_step(1)
+        orc.td_step(1)
+        compare_learner_step(eng, orc, "C2 step %d" % step, exact=False, rtol=1e-9)
+    th, oth = eng.theta(), orc.theta()
+    assert np.array_equal(th != 0, oth != 0)
+    np.testing.assert_allclose(th, oth, rtol=1e-9, atol=1e-12)
