@@ -318,11 +318,12 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
         uint32_t rnd[2048 + 64];
         memset(rnd, 0, sizeof rnd);
         make_rndseq(rnd);
-        uint64_t* terms = reinterpret_cast<uint64_t*>(rnd + 2048);
+        // (reduced mod M: hash_UNH's single final reduction distributes over the sum)
+        uint32_t* terms = rnd + 2048;
         for (int g = 0; g < 3; g++) {
             const int nf = g == 0 ? 3 : (g == 1 ? P.V - 3 : P.V);
             for (int a = 0; a < LOB_N_ACTIONS; a++)
-                terms[g * LOB_N_ACTIONS + a] = rnd[((g * LOB_N_ACTIONS + a) + 449 * (nf + 1)) & 2047];
+                terms[g * LOB_N_ACTIONS + a] = (uint32_t)((uint64_t)rnd[((g * LOB_N_ACTIONS + a) + 449 * (nf + 1)) & 2047] % (uint64_t)P.M);
         }
         HIPCHK(hipMemcpyAsync(e->rnd_dev, rnd, sizeof rnd, hipMemcpyHostToDevice, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));

@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(256) clear_inventory_kernel(const DevParams* _
 // Shared LDS image of a learner block.
 struct LearnLds {
     uint32_t rnd[2048];                                   // hash_UNH table
-    u64 act_terms[32];                                    // trailing-coordinate terms [group][action] (27 used)
+    uint32_t act_terms[32];                               // trailing-coordinate terms [group][action] mod M (27 used)
     f64 vals[LOB_WAVES_PER_BLOCK][LOB_HSLOTS / 2];  // 4 KB per wave: one group's gathered theta (9 x 33 f64) / trace hash set (aliased)
     f32 vars[LOB_WAVES_PER_BLOCK][3][16];
     uint32_t newf[LOB_NZ_FILTER];                         // act only: filter of the weights first written by the previous update
@@ -247,7 +247,7 @@ __device__ inline void learn_lds_init(const uint32_t* __restrict__ rnd_g, const 
     if (have_book && lane < 48) vv = vars_b[lane];
     dst[threadIdx.x] = r0;
     dst[threadIdx.x + LOB_BLOCK] = r1;
-    if (threadIdx.x < 27) L.act_terms[threadIdx.x] = reinterpret_cast<const u64*>(rnd_g + 2048)[threadIdx.x];
+    if (threadIdx.x < 27) L.act_terms[threadIdx.x] = rnd_g[2048 + threadIdx.x];
     if (lane < 48) (&L.vars[w][0][0])[lane] = vv;
     if (nz_buf && threadIdx.x < LOB_NZ_FILTER) L.newf[threadIdx.x] = (uint32_t)nz_buf[LOB_NZ_FILTER + threadIdx.x];
     __syncthreads();
@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(LOB_BLOCK) act_kernel(DevParams P, DevState S,
     const int n_new = nz_new[0];
     const uint32_t ep = (uint32_t)S.nz_epoch[0];
     const u64 tag = *(const u64*)(vd + 64);  // {epoch, slot, valid} in one load
-    uint32_t my_vd = vd[lane ^ 32];
+    uint32_t my_vd = vd[lane];
     learn_lds_init(rnd_g, S.vars + (size_t)bb * 48, have, L, nz_new);
     if (!have) return;
     LHdr* hp = S.hdr + b;
@@ -370,11 +370,11 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
     const int j = lane & 31, half = lane >> 5;
     i32 F[5];
     {
-        u64 base = zero_last ? 0 : tile_base(vars_from, 3, j, L.rnd);
+        const uint32_t base = zero_last ? 0 : tile_base_m(P, vars_from, 3, j, L.rnd);
 #pragma unroll
         for (int k = 0; k < 5; k++) {
             const int a = half + 2 * k;
-            F[k] = (a < LOB_N_ACTIONS && !zero_last) ? mod_m(base + L.act_terms[a < LOB_N_ACTIONS ? a : 0], P.M, P.inv_M) : 0;
+            F[k] = (a < LOB_N_ACTIONS && !zero_last) ? tile_index(base, L.act_terms[a < LOB_N_ACTIONS ? a : 0], (uint32_t)P.M) : 0;
         }
     }
 
@@ -478,7 +478,7 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
         const uint32_t ep = (uint32_t)S.nz_epoch[0];
         uint32_t my_vd = 0;
         q_values(P, theta, nz, vars_to, false, L.rnd, L.act_terms, L.vals[w], lane, qs_to, 1, &my_vd);
-        vd[lane ^ 32] = (uint16_t)my_vd;
+        vd[lane] = (uint16_t)my_vd;
         if (lane == 0) *(u64*)(vd + 64) = vd_tag(ep, cur);
     }
     const f64 reward = h.reward;
@@ -605,9 +605,9 @@ __global__ void __launch_bounds__(LOB_BLOCK) features_kernel(DevParams P, const 
             const int g = p >> 5, j = p & 31;
             const int nf = g == 0 ? 3 : (g == 1 ? P.V - 3 : P.V);
             const f32* v = g == 1 ? L.vars[w][0] + 3 : L.vars[w][0];
-            u64 base = tile_base(v, nf, j, L.rnd);
+            const uint32_t base = tile_base_m(P, v, nf, j, L.rnd);
             for (int a = 0; a < LOB_N_ACTIONS; a++)
-                out_idx[((size_t)s * LOB_N_ACTIONS + a) * 96 + p] = mod_m(base + L.act_terms[g * LOB_N_ACTIONS + a], P.M, P.inv_M);
+                out_idx[((size_t)s * LOB_N_ACTIONS + a) * 96 + p] = tile_index(base, L.act_terms[g * LOB_N_ACTIONS + a], (uint32_t)P.M);
         }
     }
     if (out_q) {

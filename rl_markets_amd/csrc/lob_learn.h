@@ -35,8 +35,9 @@ __device__ inline u64 tile_base(const f32* v, int nf, int j, const uint32_t* rnd
         int q = (int)floorf(v[i] * 32.0f);  // (int) floor(floats[i] * num_tilings)
         int base = j * (1 + 2 * i);
         int c;
-        if (q >= base) c = q - ((q - base) % 32);
-        else c = q + 1 + ((base - q - 1) % 32) - 32;
+        // tiles.cpp:61-64, both operands of % are non-negative in their branch
+        if (q >= base) c = q - ((q - base) & 31);
+        else c = q + 1 + ((base - q - 1) & 31) - 32;
         sum += (u64)rnd[(c + 449 * i) & 2047];
     }
     sum += (u64)rnd[(j + 449 * nf) & 2047];
@@ -95,116 +96,155 @@ __device__ inline int argmax_ties(const f64* qs, Rng& g) {
     return index;
 }
 
+// (base + term) mod M with both operands already reduced: one add, one compare, one select.
+// hash_UNH sums the table terms and reduces once (tiles.cpp:165-168); reducing the
+// action-independent partial sum and the action term separately gives the same residue.
+__device__ inline uint32_t tile_base_m(const DevParams& P, const f32* v, int nf, int j, const uint32_t* rnd) {
+    return (uint32_t)mod_m(tile_base(v, nf, j, rnd), P.M, P.inv_M);
+}
+__device__ inline i32 tile_index(uint32_t base_m, uint32_t term_m, uint32_t M) {
+    const uint32_t s = base_m + term_m;  // < 2^32: M < 2^31
+    return (i32)(s >= M ? s - M : s);
+}
+
 // Q(s, a) for all 9 actions of one state, one wave.
 //   vars      : V floats of the state (LDS), ignored if `zero`
 //   zero      : the rl::State still holds its constructor zeros (all tiles 0)
+//   terms     : LDS, [3][9] table terms of the trailing (action code) coordinate, reduced mod M
 //   vals      : per-wave LDS scratch [9][LOB_QSTRIDE] doubles (one tile GROUP at a time)
 //   out_q[9]  : every lane returns all nine Q values
-// Lane l < 32 owns tiling l of groups 0 and 2, lane 32 + l owns tiling l of
-// group 1: 13.5 gathers per lane, all issued before any is consumed.  The sum
-// then follows the reference's sequential order term by term -- group 0 (w0),
-// group 1 (w1), group 1 again and group 2 (w2): quirk Q3 -- on nine lanes (one
-// per action), the 32 x 9 values of one group staged through LDS at a time, so
-// that Q is bitwise the value Agent::getQ computes.
-// `nz` is the "ever written" bitmap of theta (lob_state.h): weights start at +0.0
-// and only group-0 tiles are ever updated (quirk Q4), so almost every group-1/2
-// gather would fetch a 64-byte sector from HBM to read a zero.  One bit per
-// weight (2.5 MB at M = 20 M: L2-resident) answers that without the fetch; the
-// value used is bit-identical either way.
-// vd_mode 0: look the bits up in the bitmap; 1: look up AND return them in *vd_bits (learn saves
-// them); 2: take *vd_bits as the verdicts (act re-using learn's), OR-ed with the filter `newf` (LDS,
-// 4096 bits, keyed like the map itself) of the map bits set for the first time since.  A filter
-// false positive only costs a fetch of a weight that is still exactly 0.0.
-__device__ inline void gather9(const DevParams& P, const f64* __restrict__ theta, const uint32_t* __restrict__ nz,
-                               const f32* vars, bool zero, const uint32_t* rnd, const u64* act_terms, int g, int j,
-                               f64* t, int vd_mode, uint32_t* vd_bits, const uint32_t* newf) {
-    const int nf = g == 0 ? 3 : (g == 1 ? P.V - 3 : P.V);
-    const f32* v = g == 1 ? vars + 3 : vars;
-    const u64 base = zero ? 0 : tile_base(v, nf, j, rnd);
-    i32 idx[LOB_N_ACTIONS];
+// The kernels that call this are VALU-issue bound (profiles/r01_pmc.csv: ~1 700-2 400 vector
+// instructions per wave, the gathers themselves are a minor part), so the 96 tiles x 9 actions
+// are spread over the 64 lanes without divergent halves:
+//   pass A  lane l < 32: tiling l of group 0 (9 actions), lane 32 + l: tiling l of group 1;
+//   pass B  tiling l of group 2, actions 0..4 on lanes 0-31 and 5..8 on lanes 32-63.
+// The sum then follows the reference's sequential order term by term -- group 0 (w0),
+// group 1 (w1), group 1 again and group 2 (w2): quirk Q3 -- on nine lanes (one per action),
+// the products w * theta of one group staged through LDS at a time (the product is rounded
+// before the add, as in the reference built without FMA), so that Q is bitwise the value
+// Agent::getQ computes.
+// `nz` is the "ever written" map of theta (lob_state.h): weights start at +0.0 and only
+// group-0 tiles are ever updated (quirk Q4), so almost every group-1/2 gather would fetch a
+// 64-byte sector from HBM to read a zero.  The map answers that from L2; the value used is
+// bit-identical either way.  Group-0 tiles are fetched directly.
+// vd_mode 0: look the map up; 1: look up AND return the verdicts in *vd_io (learn saves them:
+// bits 0-8 pass A, bits 9-13 pass B); 2: take *vd_io as the verdicts (act re-using learn's),
+// OR-ed with the filter `newf` (LDS, 4096 bits, keyed like the map itself) of the map bits set
+// for the first time since.  A false positive only costs a fetch of a weight that is still +0.0.
+__device__ inline void q_values(const DevParams& P, const f64* __restrict__ theta, const uint32_t* __restrict__ nz,
+                                const f32* vars, bool zero, const uint32_t* rnd, const uint32_t* terms, f64* vals,
+                                int lane, f64* out_q, int vd_mode = 0, uint32_t* vd_io = nullptr,
+                                const uint32_t* newf = nullptr) {
+    const int j = lane & 31;
+    const bool hi = lane >= 32;
+    const uint32_t M = (uint32_t)P.M;
+    constexpr int NB = 5;  // pass-B actions per lane
+    i32 iA[LOB_N_ACTIONS], iB[NB];
+    {
+        uint32_t baseA = 0, baseB = 0;
+        if (!zero) {
+            baseA = tile_base_m(P, hi ? vars + 3 : vars, hi ? P.V - 3 : 3, j, rnd);
+            baseB = tile_base_m(P, vars, P.V, j, rnd);
+        }
+        const uint32_t* tA = terms + (hi ? LOB_N_ACTIONS : 0);
+        const uint32_t* tB = terms + 2 * LOB_N_ACTIONS + (hi ? NB : 0);
 #pragma unroll
-    for (int a = 0; a < LOB_N_ACTIONS; a++)
-        idx[a] = zero ? 0 : mod_m(base + act_terms[g * LOB_N_ACTIONS + a], P.M, P.inv_M);
-    uint32_t bits;
-    if (g == 0) {
-        bits = 0x1ffu;  // group-0 tiles are the ones that get written: fetch them directly (one request, not two)
-    } else if (vd_mode == 2) {
-        bits = *vd_bits;
+        for (int a = 0; a < LOB_N_ACTIONS; a++) iA[a] = zero ? 0 : tile_index(baseA, tA[a], M);
+#pragma unroll
+        for (int k = 0; k < NB; k++) iB[k] = zero ? 0 : tile_index(baseB, tB[k < 4 || !hi ? k : 0], M);
+    }
+    const uint32_t maskB = hi ? 0xfu : 0x1fu;  // lanes 32-63 own four actions, their fifth slot is idle
+    uint32_t bA = 0x1ffu, bB;
+    if (vd_mode == 2) {
+        const uint32_t vd = *vd_io;
+        bB = vd >> 9;
+        uint32_t fA = 0;
 #pragma unroll
         for (int a = 0; a < LOB_N_ACTIONS; a++)
-            bits |= ((newf[LOB_NZ_WORD(idx[a]) & (LOB_NZ_FILTER - 1)] & LOB_NZ_BIT(idx[a])) ? 1u : 0u) << a;
+            fA |= ((newf[LOB_NZ_WORD(iA[a]) & (LOB_NZ_FILTER - 1)] & LOB_NZ_BIT(iA[a])) ? 1u : 0u) << a;
+#pragma unroll
+        for (int k = 0; k < NB; k++)
+            bB |= ((newf[LOB_NZ_WORD(iB[k]) & (LOB_NZ_FILTER - 1)] & LOB_NZ_BIT(iB[k])) ? 1u : 0u) << k;
+        if (hi) bA = (vd & 0x1ffu) | fA;
     } else {
-        uint32_t word[LOB_N_ACTIONS];
+        uint32_t wA[LOB_N_ACTIONS], wB[NB];
 #pragma unroll
-        for (int a = 0; a < LOB_N_ACTIONS; a++) word[a] = nz[LOB_NZ_WORD(idx[a])];
-        bits = 0;
+        for (int a = 0; a < LOB_N_ACTIONS; a++) wA[a] = hi ? nz[LOB_NZ_WORD(iA[a])] : 0xffffffffu;  // group 0: fetched directly
 #pragma unroll
-        for (int a = 0; a < LOB_N_ACTIONS; a++) bits |= ((word[a] & LOB_NZ_BIT(idx[a])) ? 1u : 0u) << a;
-        if (vd_mode == 1) *vd_bits = bits;
+        for (int k = 0; k < NB; k++) wB[k] = nz[LOB_NZ_WORD(iB[k])];
+        bA = 0; bB = 0;
+#pragma unroll
+        for (int a = 0; a < LOB_N_ACTIONS; a++) bA |= ((wA[a] & LOB_NZ_BIT(iA[a])) ? 1u : 0u) << a;
+#pragma unroll
+        for (int k = 0; k < NB; k++) bB |= ((wB[k] & LOB_NZ_BIT(iB[k])) ? 1u : 0u) << k;
+        if (!hi) bA = 0x1ffu;
     }
+    bB &= maskB;
+    if (vd_mode == 1) *vd_io = (hi ? bA : 0u) | (bB << 9);
+    f64 tA[LOB_N_ACTIONS], tB[NB];
 #pragma unroll
     for (int a = 0; a < LOB_N_ACTIONS; a++) {
-        t[a] = 0.0;
-        if ((bits >> a) & 1u) t[a] = theta[idx[a]];
+        tA[a] = 0.0;
+        if ((bA >> a) & 1u) tA[a] = theta[iA[a]];
     }
-}
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+        tB[k] = 0.0;
+        if ((bB >> k) & 1u) tB[k] = theta[iB[k]];
+    }
 
-// vd_io: this lane's 9 verdict bits (lanes 32-63: group 1, lanes 0-31: group 2; row index lane ^ 32).
-__device__ inline void q_values(const DevParams& P, const f64* __restrict__ theta, const uint32_t* __restrict__ nz,
-                                const f32* vars, bool zero,
-                                const uint32_t* rnd, const u64* act_terms /*[3][9] LDS*/, f64* vals, int lane,
-                                f64* out_q, int vd_mode = 0, uint32_t* vd_io = nullptr, const uint32_t* newf = nullptr) {
-    const int j = lane & 31, hi = lane >> 5;
-    f64 ta[LOB_N_ACTIONS], tb[LOB_N_ACTIONS];
-    uint32_t bits = 0;
-    if (vd_mode == 2) bits = *vd_io;
-    if (hi) {
-        gather9(P, theta, nz, vars, zero, rnd, act_terms, 1, j, ta, vd_mode, &bits, newf);
-    } else {
-        gather9(P, theta, nz, vars, zero, rnd, act_terms, 0, j, ta, 0, nullptr, nullptr);
-        gather9(P, theta, nz, vars, zero, rnd, act_terms, 2, j, tb, vd_mode, &bits, newf);
-    }
-    if (vd_mode == 1) *vd_io = bits;
     f64 q = 0.0;
     const f64* col = vals + lane * LOB_QSTRIDE;
     // ---- group 0 ----
     if (!hi) {
+        const f64 w = P.w0;
 #pragma unroll
-        for (int a = 0; a < LOB_N_ACTIONS; a++) vals[a * LOB_QSTRIDE + j] = ta[a];
+        for (int a = 0; a < LOB_N_ACTIONS; a++) vals[a * LOB_QSTRIDE + j] = w * tA[a];
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
     if (lane < LOB_N_ACTIONS) {
-        const f64 w = P.w0;
-        for (int i = 0; i < 32; i++) q += w * col[i];
+        for (int i = 0; i < 32; i++) q += col[i];
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
     // ---- group 1: once with w1, once more with w2 (quirk Q3) ----
     if (hi) {
+        const f64 w = P.w1;
 #pragma unroll
-        for (int a = 0; a < LOB_N_ACTIONS; a++) vals[a * LOB_QSTRIDE + j] = ta[a];
+        for (int a = 0; a < LOB_N_ACTIONS; a++) vals[a * LOB_QSTRIDE + j] = w * tA[a];
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
     if (lane < LOB_N_ACTIONS) {
-        f64 w = P.w1;
-        for (int i = 0; i < 32; i++) q += w * col[i];
-        w = P.w2;
-        for (int i = 0; i < 32; i++) q += w * col[i];
+        for (int i = 0; i < 32; i++) q += col[i];
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    // ---- group 2 ----
-    if (!hi) {
-#pragma unroll
-        for (int a = 0; a < LOB_N_ACTIONS; a++) vals[a * LOB_QSTRIDE + j] = tb[a];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    if (lane < LOB_N_ACTIONS) {
+    if (hi) {
         const f64 w = P.w2;
-        for (int i = 0; i < 32; i++) q += w * col[i];
+#pragma unroll
+        for (int a = 0; a < LOB_N_ACTIONS; a++) vals[a * LOB_QSTRIDE + j] = w * tA[a];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < LOB_N_ACTIONS) {
+        for (int i = 0; i < 32; i++) q += col[i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    // ---- group 2: both halves stage their actions ----
+    {
+        const f64 w = P.w2;
+        const int a0 = hi ? NB : 0;
+#pragma unroll
+        for (int k = 0; k < NB; k++)
+            if (k < 4 || !hi) vals[(a0 + k) * LOB_QSTRIDE + j] = w * tB[k];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < LOB_N_ACTIONS) {
+        for (int i = 0; i < 32; i++) q += col[i];
     }
 #pragma unroll
     for (int a = 0; a < LOB_N_ACTIONS; a++) out_q[a] = __shfl(q, a);
