@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(256) clear_inventory_kernel(const DevParams* _
 struct LearnLds {
     uint32_t rnd[2048];                                   // hash_UNH table
     uint32_t act_terms[32];                               // trailing-coordinate terms [group][action] mod M (27 used)
-    f64 vals[LOB_WAVES_PER_BLOCK][LOB_HSLOTS / 2];  // 4 KB per wave: one group's gathered theta (9 x 33 f64) / trace hash set (aliased)
+    f64 vals[LOB_WAVES_PER_BLOCK][LOB_HSLOTS];      // 4 KB per wave: one group's gathered theta (9 x 33 f64) / trace hash set (aliased)
     f32 vars[LOB_WAVES_PER_BLOCK][3][16];
     uint32_t newf[LOB_NZ_FILTER];                         // act only: filter of the weights first written by the previous update
 };
@@ -392,19 +392,24 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
     // hash set of the 288 current tiles; a live older entry that appears in it
     // is either cleared (other action) or re-set to 1 (chosen action): in both
     // cases it leaves its old generation.
-    i32* tab = reinterpret_cast<i32*>(L.vals[w]);
-    for (int i = lane; i < LOB_HSLOTS; i += 64) tab[i] = -1;
+    // Slot = tile index (high word) | rank (low word), rank(a, j) = 32 a + (31 - j): the map keeps,
+    // per tile, the largest rank among the (action, tiling) pairs that produce it.
+    u64* tab = reinterpret_cast<u64*>(L.vals[w]);
+    constexpr u64 EMPTY = ~0ull;
+    for (int i = lane; i < LOB_HSLOTS; i += 64) tab[i] = EMPTY;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int k = 0; k < 5; k++) {
         const int a = half + 2 * k;
         if (a < LOB_N_ACTIONS) {
-            const i32 x = F[k];
-            unsigned s = ((unsigned)x * 2654435761u) >> 22;
+            const uint32_t x = (uint32_t)F[k];
+            const u64 key = ((u64)x << 32) | (uint32_t)(a * 32 + 31 - j);
+            unsigned s = (x * 2654435761u) >> 23;
             while (true) {
-                i32 old = atomicCAS(&tab[s], -1, x);
-                if (old == -1 || old == x) break;
+                const u64 old = atomicCAS((unsigned long long*)&tab[s], (unsigned long long)EMPTY, (unsigned long long)key);
+                if (old == EMPTY) break;
+                if ((uint32_t)(old >> 32) == x) { atomicMax((unsigned long long*)&tab[s], (unsigned long long)key); break; }
                 s = (s + 1) & (LOB_HSLOTS - 1);
             }
         }
@@ -421,12 +426,12 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
             slot = (head - k + 2 * LOB_TRACE_GENS) % LOB_TRACE_GENS;
             alive = (tr_alive[slot] >> j) & 1u;
             if (alive) {
-                const i32 x = tr_idx[slot * 32 + j];
-                unsigned s = ((unsigned)x * 2654435761u) >> 22;
+                const uint32_t x = (uint32_t)tr_idx[slot * 32 + j];
+                unsigned s = (x * 2654435761u) >> 23;
                 while (true) {
-                    i32 v = tab[s];
-                    if (v == x) { alive = false; break; }
-                    if (v == -1) break;
+                    const u64 v = tab[s];
+                    if ((uint32_t)(v >> 32) == x) { alive = false; break; }
+                    if (v == EMPTY) break;
                     s = (s + 1) & (LOB_HSLOTS - 1);
                 }
             }
@@ -439,22 +444,19 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
     // only overwrites its eligibility).
     {
         const i32 N = __shfl(sel5(F, action >> 1), (action & 1) * 32 + j);
-        bool dead = false;
-#pragma unroll
-        for (int ap = 0; ap < LOB_N_ACTIONS; ap++) {
-            if (ap > action) {
-                const i32 fk = F[ap >> 1];
-#pragma unroll 8
-                for (int jj = 0; jj < 32; jj++) {
-                    const i32 v = __shfl(fk, (ap & 1) * 32 + jj);
-                    dead |= (v == N);
-                }
+        // dead <=> some (a', j') with the same tile outranks (action, j): a later action clears it
+        // again, or an earlier tiling of the chosen action already holds it
+        bool dead;
+        {
+            const uint32_t x = (uint32_t)N;
+            unsigned s = (x * 2654435761u) >> 23;
+            u64 v;
+            while (true) {
+                v = tab[s];
+                if ((uint32_t)(v >> 32) == x || v == EMPTY) break;
+                s = (s + 1) & (LOB_HSLOTS - 1);
             }
-        }
-#pragma unroll 8
-        for (int jj = 0; jj < 32; jj++) {
-            const i32 v = __shfl(N, jj);
-            dead |= (jj < j) && (v == N);
+            dead = (uint32_t)v > (uint32_t)(action * 32 + 31 - j);
         }
         const int nh = (head + 1) % LOB_TRACE_GENS;
         const u64 m = __ballot(!dead && half == 0);

@@ -14,7 +14,7 @@
 #include "lob_stream.h"
 
 #define LOB_QSTRIDE 33  // 32 tiles of one group + 1 pad double: lanes a=0..8 read column i without bank conflicts
-#define LOB_HSLOTS 1024 // per-wave LDS hash set for the 288 "current" tiles
+#define LOB_HSLOTS 512  // per-wave LDS hash map (64-bit slots: tile index | rank) of the 288 "current" tiles
 
 // S % M for S < 2^37, M < 2^31 through a double reciprocal (+-1 fix-up).
 __device__ inline i32 mod_m(u64 s, i64 M, f64 inv_M) {
