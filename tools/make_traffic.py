@@ -1,0 +1,29 @@
+"""profiles/<tag>_pmc.csv -> profiles/pmc_traffic.json (what bench.py reports as roofline.traffic).
+HBM bytes per launch = (FETCH_SIZE + WRITE_SIZE) KiB x 1024.  The guide's x2 correction for wide
+streaming kernels is NOT applied: these kernels move 4-8 byte gathers, and FETCH_SIZE agrees with
+TCC_MISS x 64 B (checked per kernel below and recorded as `fetch_over_miss64`)."""
+import csv, json, os, sys
+
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join(root, "profiles", tag + "_pmc.csv")
+rows = {}
+with open(src) as fh:
+    for r in csv.DictReader(l for l in fh if not l.startswith("#")):
+        k = r["kernel"].split("<")[0]
+        rows.setdefault(k, {})[r["counter"]] = float(r["avg_per_launch"])
+out = {}
+for k, c in sorted(rows.items()):
+    if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+        continue
+    e = {"hbm_bytes_per_launch": (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0, "fetch_kib": c["FETCH_SIZE"],
+         "write_kib": c["WRITE_SIZE"], "source": "profiles/%s_pmc.csv" % tag}
+    for n in ("TCC_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum"):
+        if n in c:
+            e[n.lower()] = c[n]
+    if c.get("TCC_MISS_sum"):
+        e["fetch_over_miss64"] = round(c["FETCH_SIZE"] * 1024.0 / (c["TCC_MISS_sum"] * 64.0), 3)
+    out[k] = e
+json.dump(out, open(os.path.join(root, "profiles", "pmc_traffic.json"), "w"), indent=1)
+for k, e in out.items():
+    print(k, round(e["hbm_bytes_per_launch"] / 1e6, 1), "MB/launch", e.get("fetch_over_miss64"))
