@@ -39,9 +39,15 @@ struct EnvSlot {
 static_assert(sizeof(EnvSlot) % 8 == 0 && (sizeof(EnvSlot) / 8) % 2 == 1, "odd 8-byte stride");
 static_assert(sizeof(EnvSlot) * 256 <= 160 * 1024, "one 256-lane block per CU must fit in LDS");
 
+// 4 books (waves) per block: 26 KB of LDS -> 6 waves per SIMD.  16 per block (75 KB, hash table
+// staged once per 16 books, 8 waves per SIMD) measured the same for act and slower for learn
+// (register pressure at the higher occupancy target): these kernels are issue-bound, not
+// occupancy-bound.  Any value >= 8 builds (-DLOB_WAVES_PER_BLOCK=..); 4 needs the two-load staging.
+#ifndef LOB_WAVES_PER_BLOCK
 #define LOB_WAVES_PER_BLOCK 4
+#endif
 #define LOB_BLOCK (64 * LOB_WAVES_PER_BLOCK)
-static_assert(LOB_BLOCK == LOB_NZ_WORDS, "learn_kernel block 0 clears one nz_new buffer, a word per thread");
+static_assert(LOB_BLOCK >= LOB_NZ_WORDS && 512 % LOB_BLOCK == 0 || LOB_BLOCK % 512 == 0, "block 0 clears one nz_new buffer; the block stages the 512 x 16 B hash table");
 
 // ---------------------------------------------------------------------------
 __global__ void gen_events_kernel(lob_gen_params g, int D, int T, u64 first_book, int B, uint32_t* out) {
@@ -241,12 +247,16 @@ __device__ inline void learn_lds_init(const uint32_t* __restrict__ rnd_g, const 
                                       LearnLds& L, const i32* __restrict__ nz_buf = nullptr) {
     const uint4* src = reinterpret_cast<const uint4*>(rnd_g);
     uint4* dst = reinterpret_cast<uint4*>(L.rnd);
-    const uint4 r0 = src[threadIdx.x], r1 = src[threadIdx.x + LOB_BLOCK];
+    constexpr int PER = LOB_BLOCK >= 512 ? 1 : 512 / LOB_BLOCK;  // 512 x 16 B = the 8 KB table
+    uint4 r[PER];
+#pragma unroll
+    for (int i = 0; i < PER; i++) r[i] = (threadIdx.x + i * LOB_BLOCK < 512) ? src[threadIdx.x + i * LOB_BLOCK] : uint4{0, 0, 0, 0};
     f32 vv = 0.0f;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (have_book && lane < 48) vv = vars_b[lane];
-    dst[threadIdx.x] = r0;
-    dst[threadIdx.x + LOB_BLOCK] = r1;
+#pragma unroll
+    for (int i = 0; i < PER; i++)
+        if (threadIdx.x + i * LOB_BLOCK < 512) dst[threadIdx.x + i * LOB_BLOCK] = r[i];
     if (threadIdx.x < 27) L.act_terms[threadIdx.x] = rnd_g[2048 + threadIdx.x];
     if (lane < 48) (&L.vars[w][0][0])[lane] = vv;
     if (nz_buf && threadIdx.x < LOB_NZ_FILTER) L.newf[threadIdx.x] = (uint32_t)nz_buf[LOB_NZ_FILTER + threadIdx.x];
@@ -345,7 +355,7 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
                                                           int b0, int nb, int par) {
     __shared__ LearnLds L;
     // this step's update appends to nz_new[par]; the list act reads is nz_new[par ^ 1]
-    if (blockIdx.x == 0) S.nz_new[par * LOB_NZ_WORDS + threadIdx.x] = 0;  // LOB_BLOCK == LOB_NZ_WORDS
+    if (blockIdx.x == 0 && threadIdx.x < LOB_NZ_WORDS) S.nz_new[par * LOB_NZ_WORDS + threadIdx.x] = 0;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int t = __builtin_amdgcn_readfirstlane(blockIdx.x * LOB_WAVES_PER_BLOCK + w);
     const int b = b0 + t;
