@@ -92,7 +92,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--books", type=int, default=65536, help="books per GPU")
     ap.add_argument("--depth", type=int, default=10)
-    ap.add_argument("--algo", default="q_lambda", choices=["q_lambda", "sarsa"])
+    ap.add_argument("--algo", default="q_lambda", choices=["q_lambda", "sarsa", "double_q"])
     ap.add_argument("--memory-size", type=int, default=20000000)
     ap.add_argument("--events", type=int, default=0, help="events per book (0 = 64 warm-up + 2048)")
     ap.add_argument("--replay", type=int, default=0, metavar="N_TOTAL",
@@ -124,7 +124,7 @@ def main():
 
     p = engine.default_params()
     p.depth, p.max_trades = args.depth, 2
-    p.algo = abi.ALGO_QLAMBDA if args.algo == "q_lambda" else abi.ALGO_SARSA
+    p.algo = {"q_lambda": abi.ALGO_QLAMBDA, "sarsa": abi.ALGO_SARSA, "double_q": abi.ALGO_DOUBLE_Q}[args.algo]
     p.theta_mode = abi.THETA_SHARED
     p.memory_size = args.memory_size
     p.book_id_offset = rank * args.books
@@ -244,7 +244,7 @@ def main():
                               if args.replay else "C3: %d parallel synthetic %d-level books per GPU, %s with eligibility traces, ") +
                              "tile-coded linear Q (32 tilings x 3 groups x 9 actions), memory_size %d, "
                              "shared theta, synchronous-batch TD") % (args.books, args.depth,
-                                                                   "Q(lambda)" if args.algo == "q_lambda" else "SARSA(lambda)",
+                                                                   {"q_lambda": "Q(lambda)", "sarsa": "SARSA(lambda)", "double_q": "double Q(lambda)"}[args.algo],
                                                                    args.memory_size),
                 "books_per_gpu": args.books, "depth": args.depth, "events_per_book": g.n_events,
                 "events_per_step": round(eps, 4), "live_traces_per_book": round(n_live, 1),

@@ -337,6 +337,7 @@ int lob_get_counters(lob_engine* e, int64_t out[4]);
  *   lob_delta_begin : dev_delta[i] = theta[i] - theta_sync[i]
  *   (caller: all-reduce SUM dev_delta over ranks)
  *   lob_delta_apply : theta = theta_sync + dev_delta ; theta_sync = theta
+ * `count` = memory_size, or 2 x memory_size for LOB_ALGO_DOUBLE_Q (theta then theta_b).
  */
 int lob_delta_init(lob_engine* e);
 int lob_delta_begin(lob_engine* e, double** dev_delta, int64_t* count);

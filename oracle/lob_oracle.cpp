@@ -4,6 +4,7 @@
 // Nothing here is shared with the HIP engine under rl_markets_amd/csrc/.
 #include "lob_oracle.h"
 
+#include <limits.h>
 #include <math.h>
 #include <string.h>
 
@@ -517,14 +518,21 @@ void tiles(int* the_tiles, int num_tilings, int memory_size, const float* floats
     int num_coordinates = num_floats + 1 + 1;
     coordinates[num_floats + 1] = h1;
     for (int i = 0; i < num_floats; i++) {
-        qstate[i] = (int)floor(floats[i] * num_tilings);  // float multiply, double floor
+        // float multiply, double floor; the conversion is x86 `cvttsd2si`: NaN / out of range -> INT_MIN
+        // (the reference does feed NaN through here: vwap over a window without trades is 0/0)
+        double fd = floor(floats[i] * num_tilings);
+        qstate[i] = (fd >= -2147483648.0 && fd < 2147483648.0) ? (int)fd : INT_MIN;
         base[i] = 0;
     }
     for (int j = 0; j < num_tilings; j++) {
         int i;
         for (i = 0; i < num_floats; i++) {
-            if (qstate[i] >= base[i]) coordinates[i] = qstate[i] - ((qstate[i] - base[i]) % num_tilings);
-            else coordinates[i] = qstate[i] + 1 + ((base[i] - qstate[i] - 1) % num_tilings) - num_tilings;
+            // tiles.cpp:61-64.  With qstate = INT_MIN the subtractions overflow; the compiled reference
+            // wraps (two's complement) and takes a signed remainder -- pinned by
+            // tests/golden/kat_nonfinite.npz -- so that is spelt out here instead of left to the optimiser.
+            const uint32_t q = (uint32_t)qstate[i], bs = (uint32_t)base[i], nt = (uint32_t)num_tilings;
+            if (qstate[i] >= base[i]) coordinates[i] = (int)(q - (uint32_t)((int)(q - bs) % num_tilings));
+            else coordinates[i] = (int)(q + 1u + (uint32_t)((int)(bs - q - 1u) % num_tilings) - nt);
             base[i] += 1 + (2 * i);
         }
         coordinates[i] = j;

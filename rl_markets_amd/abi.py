@@ -32,12 +32,22 @@ ALGO_SARSA, ALGO_QLAMBDA, ALGO_DOUBLE_Q = 0, 1, 2
 THETA_SHARED, THETA_PRIVATE = 0, 1
 
 
-class Market(C.Structure):
+class _Strict(C.Structure):
+    """ctypes.Structure that refuses attributes the C struct does not have (a misspelt field
+    would otherwise be accepted silently and leave the real one at its default)."""
+
+    def __setattr__(self, name, value):
+        if not any(name == f[0] for f in self._fields_):
+            raise AttributeError("%s has no field %r" % (type(self).__name__, name))
+        super().__setattr__(name, value)
+
+
+class Market(_Strict):
     _fields_ = [("open_ms", C.c_int64), ("close_ms", C.c_int64), ("n_bands", C.c_int32), ("_pad", C.c_int32),
                 ("band_lb", C.c_double * LOB_MAX_BANDS), ("band_tick", C.c_double * LOB_MAX_BANDS)]
 
 
-class Params(C.Structure):
+class Params(_Strict):
     _fields_ = [
         ("abi_version", C.c_int32), ("depth", C.c_int32), ("max_trades", C.c_int32), ("n_vars", C.c_int32),
         ("vars", C.c_int32 * LOB_MAX_VARS),
@@ -55,7 +65,7 @@ class Params(C.Structure):
     ]
 
 
-class GenParams(C.Structure):
+class GenParams(_Strict):
     _fields_ = [("seed", C.c_uint64)] + [(n, C.c_int32) for n in (
         "n_events", "t0_ms", "dt_ms", "start_ticks", "min_ticks", "max_ticks", "move_prob_q16",
         "spread2_prob_q16", "trade_prob_q16", "trade2_prob_q16", "touch_prob_q16", "vol_min", "vol_max",

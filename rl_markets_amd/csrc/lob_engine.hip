@@ -750,40 +750,52 @@ int lob_get_counters(lob_engine* e, int64_t out[4]) {
     return LOB_OK;
 }
 
+// Double Q carries two weight vectors: sync / delta buffers hold [theta | theta_b] back to back and
+// one all-reduce of 2M doubles exchanges both.
+static int delta_vectors(const lob_engine* e) { return e->P.algo == LOB_ALGO_DOUBLE_Q ? 2 : 1; }
+
 int lob_delta_init(lob_engine* e) {
     if (!e) return LOB_EINVAL;
     if (e->P.theta_private) { lob_set_error("lob_delta_*: shared theta only"); return LOB_EINVAL; }
-    if (e->P.algo == LOB_ALGO_DOUBLE_Q) { lob_set_error("lob_delta_*: not implemented for double Q yet"); return LOB_EINVAL; }
     HIPCHK(hipSetDevice(e->device));
+    const size_t M = (size_t)e->P.M;
+    const int nv = delta_vectors(e);
     if (!e->S.theta_sync) {
-        int rc = dev_alloc(e, &e->S.theta_sync, (size_t)e->P.M);
-        if (rc == LOB_OK) rc = dev_alloc(e, &e->S.delta, (size_t)e->P.M);
+        int rc = dev_alloc(e, &e->S.theta_sync, M * nv);
+        if (rc == LOB_OK) rc = dev_alloc(e, &e->S.delta, M * nv);
         if (rc != LOB_OK) return rc;
     }
-    HIPCHK(hipMemcpyAsync(e->S.theta_sync, e->S.theta, (size_t)e->P.M * 8, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->S.theta_sync, e->S.theta, M * 8, hipMemcpyDeviceToDevice, e->stream));
+    if (nv == 2) HIPCHK(hipMemcpyAsync(e->S.theta_sync + M, e->S.theta_b, M * 8, hipMemcpyDeviceToDevice, e->stream));
     return LOB_OK;
 }
 int lob_delta_begin(lob_engine* e, double** dev_delta, int64_t* count) {
     if (!e || !dev_delta || !count) return LOB_EINVAL;
     if (!e->S.theta_sync) { lob_set_error("lob_delta_begin: call lob_delta_init first"); return LOB_ESTATE; }
     HIPCHK(hipSetDevice(e->device));
-    {
+    const size_t M = (size_t)e->P.M;
+    const int nv = delta_vectors(e);
+    for (int v = 0; v < nv; v++) {
         TimedLaunch t(e, "delta_begin_kernel");
-        hipLaunchKernelGGL(delta_begin_kernel, dim3(2048), dim3(256), 0, e->stream, (const f64*)e->S.theta, (const f64*)e->S.theta_sync, e->S.delta, e->P.M);
+        hipLaunchKernelGGL(delta_begin_kernel, dim3(2048), dim3(256), 0, e->stream, (const f64*)(v ? e->S.theta_b : e->S.theta),
+                           (const f64*)(e->S.theta_sync + v * M), e->S.delta + v * M, e->P.M);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(e->stream));
     *dev_delta = e->S.delta;
-    *count = e->P.M;
+    *count = (int64_t)(M * nv);
     return LOB_OK;
 }
 int lob_delta_apply(lob_engine* e) {
     if (!e) return LOB_EINVAL;
     if (!e->S.theta_sync) { lob_set_error("lob_delta_apply: call lob_delta_init first"); return LOB_ESTATE; }
     HIPCHK(hipSetDevice(e->device));
-    {
+    const size_t M = (size_t)e->P.M;
+    const int nv = delta_vectors(e);
+    for (int v = 0; v < nv; v++) {
         TimedLaunch t(e, "delta_apply_kernel");
-        hipLaunchKernelGGL(delta_apply_kernel, dim3(2048), dim3(256), 0, e->stream, e->S.theta, e->S.theta_sync, (const f64*)e->S.delta, e->S.theta_nz, e->S.nz_epoch, e->P.M);
+        hipLaunchKernelGGL(delta_apply_kernel, dim3(2048), dim3(256), 0, e->stream, v ? e->S.theta_b : e->S.theta, e->S.theta_sync + v * M,
+                           (const f64*)(e->S.delta + v * M), v ? e->S.theta_b_nz : e->S.theta_nz, e->S.nz_epoch, e->P.M);
     }
     HIPCHK(hipGetLastError());
     return LOB_OK;

@@ -715,9 +715,12 @@ struct MarketR {
     i64 records;
 };
 
+// utilities/maths.h:4-8: max(min(val, ub), lb) with std::min(a, b) = (b < a) ? b : a and
+// std::max(a, b) = (a < b) ? b : a -- a NaN `val` (e.g. vwap over a window without trades: 0/0)
+// comes back as NaN, exactly as in the reference.
 __device__ inline f64 ulb(f64 val, f64 lb, f64 ub) {
-    f64 m = val < ub ? val : ub;    // std::min(val, ub)
-    return m < lb ? lb : m;         // std::max(., lb)
+    const f64 m = (ub < val) ? ub : val;
+    return (m < lb) ? lb : m;
 }
 
 // Book::ApplyChanges (book.cpp:64-99) without the order part.

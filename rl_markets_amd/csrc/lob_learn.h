@@ -32,12 +32,15 @@ __device__ inline i32 mod_m(u64 s, i64 M, f64 inv_M) {
 __device__ inline u64 tile_base(const f32* v, int nf, int j, const uint32_t* rnd) {
     u64 sum = 0;
     for (int i = 0; i < nf; i++) {
-        int q = (int)floorf(v[i] * 32.0f);  // (int) floor(floats[i] * num_tilings)
-        int base = j * (1 + 2 * i);
+        // (int) floor(floats[i] * num_tilings): x86 `cvttsd2si` semantics, a NaN or out-of-range
+        // state variable becomes INT_MIN (the reference feeds NaN through here, see ulb() in lob_env.h)
+        const f32 fq = floorf(v[i] * 32.0f);
+        const int q = (fq >= -2147483648.0f && fq < 2147483648.0f) ? (int)fq : (int)0x80000000;
+        const int base = j * (1 + 2 * i);
         int c;
-        // tiles.cpp:61-64, both operands of % are non-negative in their branch
-        if (q >= base) c = q - ((q - base) & 31);
-        else c = q + 1 + ((base - q - 1) & 31) - 32;
+        // tiles.cpp:61-64; two's-complement wrap-around like the compiled reference when q = INT_MIN
+        if (q >= base) c = (int)((uint32_t)q - (uint32_t)((int)((uint32_t)q - (uint32_t)base) % 32));
+        else c = (int)((uint32_t)q + 1u + (uint32_t)((int)((uint32_t)base - (uint32_t)q - 1u) % 32) - 32u);
         sum += (u64)rnd[(c + 449 * i) & 2047];
     }
     sum += (u64)rnd[(j + 449 * nf) & 2047];

@@ -47,7 +47,39 @@ TRAJ_CASES = [
     ("sarsa_spread_b15", "sarsa", 400, 15, {"reward": "spread"}, {"reward_measure": abi.REWARD_SPREAD}),
     ("qlearn_mm_div_b16", "q_learn", 400, 16, {"reward": "mm_div"}, {"reward_measure": abi.REWARD_MM_DIV}),
     ("sarsa_lovol_b18", "sarsa", 400, 18, {"reward": "lovol"}, {"reward_measure": abi.REWARD_LOVOL}),
+    # a NaN state variable: vwap over a window without trades is 0/0, ulb() passes the NaN on, the
+    # tile coder turns it into INT_MIN coordinates (x86 conversion) -- inside group 0, i.e. in the traces
+    ("qlearn_vwap_nan_b19", "q_learn", 420, 19,
+     {"vars": '"pos", "spd", "vwap", "imb", "svl", "vol", "a_dist", "b_dist"', "lb_vwap": 3},
+     {"vars": [abi.VAR_POS, abi.VAR_SPD, abi.VAR_VWAP, abi.VAR_IMB, abi.VAR_SVL, abi.VAR_VOL, abi.VAR_A_DIST, abi.VAR_B_DIST],
+      "lb_vwap": 3, "_gen": {"trade_prob_q16": 3277}}),
 ]
+
+
+def gen_for(n_events, over):
+    """Stream generator parameters of a trajectory case (`_gen` in its override dict)."""
+    g = engine.default_gen_params()
+    g.n_events = n_events
+    for k, v in over.get("_gen", {}).items():
+        setattr(g, k, v)
+    return g
+
+
+def nonfinite_vectors():
+    """State vectors with NaN / +-inf / huge entries for the tile-coder known answers."""
+    rng = np.random.default_rng(77)
+    v = rng.uniform(-5, 5, size=(48, 8)).astype(np.float32)
+    for i in range(16):
+        v[i, rng.integers(0, 8)] = np.nan
+    v[16:20, 2] = np.nan
+    v[20:24, 0] = np.inf
+    v[24:28, 5] = -np.inf
+    v[28:32, 1] = 1e20
+    v[32:36, 4] = -3e30
+    v[36:40, 7] = np.nan
+    v[40:44, 3] = 6.7e7      # floor(x * 32) just inside int range
+    v[44:48, 6] = -6.8e7     # ... and just outside
+    return v
 
 
 # name, algo, n_events, book id, harness args (episodes, per-episode step cap)
@@ -92,6 +124,17 @@ def main():
         run([HARNESS, "tiles", "--mem", "20000000", "--nvars", "5", "--in", vin, "--out", vout])
         tiles5 = np.fromfile(vout, dtype=np.int32).reshape(40, 9, 96)
 
+        vn = nonfinite_vectors()
+        vin, vout = os.path.join(td, "vn.f32"), os.path.join(td, "tn.i32")
+        vn.tofile(vin)
+        tiles_n = {}
+        for mem in (20000000, 4099):
+            run([HARNESS, "tiles", "--mem", str(mem), "--nvars", "8", "--in", vin, "--out", vout])
+            tiles_n[mem] = np.fromfile(vout, dtype=np.int32).reshape(vn.shape[0], 9, 96)
+        np.savez_compressed(os.path.join(HERE, "kat_nonfinite.npz"), vars=vn, **{"tiles_%d" % m: t for m, t in tiles_n.items()})
+        if "--only-nonfinite" in sys.argv:
+            return
+
         # ---- tick conversion known answers: Market::ToTicks / ToPrice / tick_size ----
         ticks = {}
         for ticker, lo, hi in (("HSBA.L", 0.5, 12000.0), ("BAES.L", 0.3, 12000.0), ("AIRF.PA", 0.01, 400.0),
@@ -115,8 +158,9 @@ def main():
         # ---- full trajectories through Intraday + Agent ----
         g = engine.default_gen_params()
         for name, algo, n_events, book, extra, _over in TRAJ_CASES:
-            g.n_events = n_events
-            rec = engine.gen_stream_host(g, 5, 2, book, 1)
+            if "--only" in sys.argv and name not in sys.argv:
+                continue
+            rec = engine.gen_stream_host(gen_for(n_events, _over), 5, 2, book, 1)
             traj, info, theta = ol.run_ref_episode(rec[0], algo=algo, mem=1 << 20, rng_stream=book, extra=extra)
             np.savez_compressed(os.path.join(HERE, "traj_%s.npz" % name), traj=traj, theta_idx=theta[0],
                                 theta_val=theta[1], steps=info["steps"], end=info["end"], rng_ctr=info["rng_ctr"])

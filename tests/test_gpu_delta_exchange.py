@@ -24,17 +24,19 @@ def test_delta_exchange_two_shards_one_gpu():
     assert "DELTA-EXCHANGE-OK" in out.stdout
 
 
-def main():
-    import torch
-    assert torch.cuda.is_available()
+def exchange(torch, algo):
+    """Two shards, one device: train, exchange, compare with the oracle doing the same."""
     total, world, steps, sync = 12, 2, 48, 16
+    M = 1 << 16
+    nv = 2 if algo == abi.ALGO_DOUBLE_Q else 1
     g = engine.default_gen_params()
     g.n_events = 200
     engs, orcs, backs = [], [], []
     for r in range(world):
         first, n = shard_books(total, world, r)
         p = engine.default_params()
-        p.memory_size = 1 << 16
+        p.memory_size = M
+        p.algo = algo
         p.book_id_offset = first
         rec = engine.gen_stream_host(g, p.depth, p.max_trades, first, n)
         e = engine.Engine(p, n)
@@ -46,13 +48,14 @@ def main():
         engs.append(e)
         orcs.append(o)
         backs.append(EngineBackend(e, torch, "cuda:0"))
-    osync = np.zeros(1 << 16)
+    vecs = [lambda o: o.theta(0)] + ([lambda o: o.theta_b(0)] if nv == 2 else [])
+    osync = [np.zeros(M) for _ in vecs]
     for s0 in range(0, steps, sync):
         for e, o in zip(engs, orcs):
             e.td_step(sync)
             o.td_step(sync)
         ts = [b.delta_tensor() for b in backs]
-        assert ts[0].dtype == torch.float64 and ts[0].is_cuda and ts[0].numel() == 1 << 16
+        assert ts[0].dtype == torch.float64 and ts[0].is_cuda and ts[0].numel() == nv * M
         tot = ts[0] + ts[1]          # stands in for all_reduce(SUM)
         for t in ts:
             t.copy_(tot)
@@ -60,14 +63,24 @@ def main():
             b.after_all_reduce()   # staged tensor -> the engine's buffer
         for e in engs:
             e.delta_apply()
-        ototal = sum(o.theta(0) - osync for o in orcs)
-        for o in orcs:
-            o.theta(0)[:] = osync + ototal
-        osync = orcs[0].theta(0).copy()
-    t0, t1 = engs[0].theta(), engs[1].theta()
-    np.testing.assert_array_equal(t0, t1)
-    np.testing.assert_allclose(t0, orcs[0].theta(0), rtol=1e-9, atol=1e-15)
-    assert np.count_nonzero(t0) > 100
+        for v, get in enumerate(vecs):
+            ototal = sum(get(o) - osync[v] for o in orcs)
+            for o in orcs:
+                get(o)[:] = osync[v] + ototal
+            osync[v] = get(orcs[0]).copy()
+    for v, get in enumerate(vecs):
+        t0, t1 = engs[0].theta(v), engs[1].theta(v)
+        np.testing.assert_array_equal(t0, t1)
+        np.testing.assert_allclose(t0, get(orcs[0]), rtol=1e-9, atol=1e-15)
+        assert np.count_nonzero(t0) > 100
+    return engs, backs
+
+
+def main():
+    import torch
+    assert torch.cuda.is_available()
+    exchange(torch, abi.ALGO_DOUBLE_Q)
+    engs, backs = exchange(torch, abi.ALGO_SARSA)
     # RCCL itself (one rank: the only collective a 1-GPU box can run): f64 all-reduce on the staged
     # tensor and on the engine's own hipMalloc'ed buffer
     import torch.distributed as dist

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from rl_markets_amd import abi, engine
-from tests.golden.make_golden import TRAJ_CASES
+from tests.golden.make_golden import TRAJ_CASES, gen_for
 from tests.parity import dumps_to_np
 from tests.test_oracle_golden import GOLD, KAT, _params_for
 
@@ -22,9 +22,7 @@ def test_engine_reproduces_reference_trajectory(case):
     name, algo, n_events, book, _extra, over = case
     fx = np.load(os.path.join(GOLD, "traj_%s.npz" % name))
     traj = fx["traj"]
-    g = engine.default_gen_params()
-    g.n_events = n_events
-    rec = engine.gen_stream_host(g, 5, 2, book, 1)
+    rec = engine.gen_stream_host(gen_for(n_events, over), 5, 2, book, 1)
     p = _params_for(over, algo, book)
     eng = engine.Engine(p, 1)
     eng.load_events(rec)
@@ -64,6 +62,15 @@ def test_engine_tiles_match_reference(mem):
     p.memory_size = mem
     eng = engine.Engine(p, 1)
     np.testing.assert_array_equal(eng.features(KAT["tiles_vars"]), KAT["tiles_%d" % mem])
+
+
+@pytest.mark.parametrize("mem", [20000000, 4099])
+def test_engine_tiles_nonfinite_inputs(mem):
+    fx = np.load(os.path.join(GOLD, "kat_nonfinite.npz"))
+    p = engine.default_params()
+    p.memory_size = mem
+    eng = engine.Engine(p, 1)
+    np.testing.assert_array_equal(eng.features(np.ascontiguousarray(fx["vars"])), fx["tiles_%d" % mem])
 
 
 def test_engine_tiles_five_vars():

@@ -29,7 +29,7 @@ def replay_params(reward, algo=abi.ALGO_QLAMBDA, mem=1 << 20):
     p = engine.default_params()
     p.depth, p.max_trades = 10, 2
     p.algo, p.theta_mode, p.memory_size = algo, abi.THETA_SHARED, mem
-    p.reward = reward
+    p.reward_measure = reward
     if reward == abi.REWARD_MM_LINEAR:
         p.pos_weight = 0.5  # the inventory-penalised variant
     return p

@@ -12,7 +12,7 @@ import pytest
 
 from rl_markets_amd import abi, engine
 from tests import oracle_lib as ol
-from tests.golden.make_golden import TRAJ_CASES
+from tests.golden.make_golden import TRAJ_CASES, gen_for
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 KAT = np.load(os.path.join(GOLD, "kat_reference.npz"))
@@ -31,6 +31,17 @@ def test_tiles_match_reference(mem):
     out = np.zeros((v.shape[0], 9, 96), np.int32)
     ol.load().oracle_tiles(mem, ol.ptr(v), 8, v.shape[0], ol.ptr(out))
     np.testing.assert_array_equal(out, KAT["tiles_%d" % mem])
+
+
+@pytest.mark.parametrize("mem", [20000000, 4099])
+def test_tiles_nonfinite_inputs(mem):
+    """NaN / inf / out-of-range state variables: the compiled reference converts them with x86
+    `cvttsd2si` (INT_MIN) and wraps; the oracle states that behaviour explicitly."""
+    fx = np.load(os.path.join(GOLD, "kat_nonfinite.npz"))
+    v = np.ascontiguousarray(fx["vars"])
+    got = np.zeros((v.shape[0], 9, 96), np.int32)
+    ol.load().oracle_tiles(mem, ol.ptr(v), 8, v.shape[0], ol.ptr(got))
+    np.testing.assert_array_equal(got, fx["tiles_%d" % mem])
 
 
 def test_tiles_five_vars():
@@ -73,6 +84,8 @@ def _params_for(over, algo, book):
     p.algo = abi.ALGO_SARSA if algo == "sarsa" else abi.ALGO_QLAMBDA
     p.book_id_offset = book
     for k, v in over.items():
+        if k.startswith("_"):
+            continue  # not an engine parameter (e.g. _gen: stream generator overrides)
         if k == "vars":
             for i, x in enumerate(v):
                 p.vars[i] = x
@@ -101,9 +114,7 @@ def test_oracle_reproduces_reference_trajectory(case):
     name, algo, n_events, book, _extra, over = case
     fx = np.load(os.path.join(GOLD, "traj_%s.npz" % name))
     traj = fx["traj"]
-    g = engine.default_gen_params()
-    g.n_events = n_events
-    rec = engine.gen_stream_host(g, 5, 2, book, 1)
+    rec = engine.gen_stream_host(gen_for(n_events, over), 5, 2, book, 1)
     p = _params_for(over, algo, book)
     o = ol.Oracle(p, rec)
     o.reset()
