@@ -2,6 +2,8 @@
 surface the C ABI accepts (depth, trade slots, state-variable sets and order, rewards, quoting and
 target-price modes, bounds, look-backs, weights, learning constants, algorithm, theta mode, table
 size, stream statistics).  Each case is fully determined by its seed, printed on failure."""
+import os
+
 import numpy as np
 import pytest
 
@@ -61,7 +63,8 @@ def random_case(seed):
     return p, g, B
 
 
-@pytest.mark.parametrize("seed", range(32))
+# LOB_FUZZ_SEEDS=n widens the sweep (a few hundred cases take well under a minute)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("LOB_FUZZ_SEEDS", "32"))))
 def test_random_configuration(seed):
     p, g, B = random_case(1000 + seed)
     rec = engine.gen_stream_host(g, p.depth, p.max_trades, p.book_id_offset, B)
