@@ -42,7 +42,8 @@ extern "C" {
 #define LOB_MAX_BANDS 20
 #define LOB_MAX_VARS 13
 #define LOB_MAX_WINDOW 256
-#define LOB_TRACE_GENS 32 /* ring capacity, generations of 32 tiles */
+#define LOB_TRACE_GENS 64 /* largest trace ring, in generations of 32 tiles: gamma*lambda up to ~0.93;
+                             the engine allocates 32 when the decay allows (example.yaml: 25 generations) */
 
 enum {
     LOB_OK = 0,

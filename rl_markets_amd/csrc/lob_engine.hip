@@ -230,8 +230,9 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
         P.trace_pow[k] = P.trace_pow[k - 1] * P.trace_rate;
         if (P.trace_kmax < 0 && P.trace_pow[k] < 0.01f) P.trace_kmax = k;
     }
+    P.trace_gens = P.trace_kmax <= 32 ? 32 : LOB_TRACE_GENS;
     if (P.trace_kmax < 0 || P.trace_kmax > LOB_TRACE_GENS) {
-        lob_set_error("lob_create: gamma*lambda too close to 1 for the trace ring (LOB_TRACE_GENS generations)");
+        lob_set_error("lob_create: gamma*lambda too close to 1 for the trace ring (LOB_TRACE_GENS = 64 generations, gamma*lambda <= ~0.93)");
         delete e;
         return LOB_EINVAL;
     }
@@ -283,8 +284,8 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     if (rc == LOB_OK) rc = dev_alloc(e, &S.k_stop, B);
     if (rc == LOB_OK) rc = dev_alloc(e, &S.vars, B * 3 * 16);
     if (rc == LOB_OK) rc = dev_alloc(e, &S.qs_last, B * LOB_N_ACTIONS);
-    if (rc == LOB_OK) rc = dev_alloc(e, &S.tr_idx, B * LOB_TRACE_GENS * 32);
-    if (rc == LOB_OK) rc = dev_alloc(e, &S.tr_alive, B * LOB_TRACE_GENS);
+    if (rc == LOB_OK) rc = dev_alloc(e, &S.tr_idx, B * (size_t)P.trace_gens * 32);
+    if (rc == LOB_OK) rc = dev_alloc(e, &S.tr_alive, B * (size_t)P.trace_gens);
     if (rc == LOB_OK) rc = dev_alloc(e, &S.theta, (size_t)P.M * (P.theta_private ? B : 1));
     if (rc == LOB_OK) rc = dev_alloc(e, &S.theta_nz, LOB_NZ_NWORDS(P.M) * (P.theta_private ? B : 1));
     if (p->algo == LOB_ALGO_DOUBLE_Q) {
@@ -710,11 +711,12 @@ int lob_get_learner_state(lob_engine* e, float* host_out) {
 int lob_get_traces(lob_engine* e, int32_t book, int32_t* idx, float* elig, int32_t cap, int32_t* n) {
     if (!e || book < 0 || book >= e->B || !n) return LOB_EINVAL;
     HIPCHK(hipSetDevice(e->device));
-    std::vector<i32> ti(LOB_TRACE_GENS * 32);
-    std::vector<uint32_t> al(LOB_TRACE_GENS);
+    const int G = e->P.trace_gens;
+    std::vector<i32> ti((size_t)G * 32);
+    std::vector<uint32_t> al(G);
     i32 head = 0, ng = 0;
-    HIPCHK(hipMemcpyAsync(ti.data(), e->S.tr_idx + (size_t)book * LOB_TRACE_GENS * 32, ti.size() * 4, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(al.data(), e->S.tr_alive + (size_t)book * LOB_TRACE_GENS, al.size() * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(ti.data(), e->S.tr_idx + (size_t)book * G * 32, ti.size() * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(al.data(), e->S.tr_alive + (size_t)book * G, al.size() * 4, hipMemcpyDeviceToHost, e->stream));
     LHdr hb;
     HIPCHK(hipMemcpyAsync(&hb, e->S.hdr + book, sizeof hb, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -722,7 +724,7 @@ int lob_get_traces(lob_engine* e, int32_t book, int32_t* idx, float* elig, int32
     ng = hb.tr_n;
     int k = 0;
     for (int age = 0; age < ng; age++) {
-        int slot = (head - age + 2 * LOB_TRACE_GENS) % LOB_TRACE_GENS;
+        int slot = (head - age + G) & (G - 1);
         for (int j = 0; j < 32; j++)
             if ((al[slot] >> j) & 1u) {
                 if (k < cap) {

@@ -426,14 +426,15 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    i32* tr_idx = S.tr_idx + (size_t)b * LOB_TRACE_GENS * 32;
-    uint32_t* tr_alive = S.tr_alive + (size_t)b * LOB_TRACE_GENS;
+    const int G = P.trace_gens;  // ring size, a power of two
+    i32* tr_idx = S.tr_idx + (size_t)b * G * 32;
+    uint32_t* tr_alive = S.tr_alive + (size_t)b * G;
     for (int k0 = 0; k0 < n_old; k0 += 2) {
         const int k = k0 + half;  // old age (before this step's decay) of the generation this half-wave scans
         bool alive = false;
         int slot = 0;
         if (k < n_old) {
-            slot = (head - k + 2 * LOB_TRACE_GENS) % LOB_TRACE_GENS;
+            slot = (head - k + G) & (G - 1);
             alive = (tr_alive[slot] >> j) & 1u;
             if (alive) {
                 const uint32_t x = (uint32_t)tr_idx[slot * 32 + j];
@@ -468,7 +469,7 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
             }
             dead = (uint32_t)v > (uint32_t)(action * 32 + 31 - j);
         }
-        const int nh = (head + 1) % LOB_TRACE_GENS;
+        const int nh = (head + 1) & (G - 1);
         const u64 m = __ballot(!dead && half == 0);
         if (half == 0) tr_idx[nh * 32 + j] = N;
         if (lane == 0) {
@@ -545,41 +546,45 @@ __global__ void __launch_bounds__(LOB_BLOCK) update_kernel(DevParams P, DevState
     const f64 scaled = h.upd / (f64)LOB_N_TILINGS;
     f64* theta = (h.stepped == 2 ? S.theta_b : S.theta) + (P.theta_private ? (size_t)b * (size_t)P.M : 0);
     uint32_t* nz = (h.stepped == 2 ? S.theta_b_nz : S.theta_nz) + (P.theta_private ? (size_t)b * LOB_NZ_NWORDS(P.M) : 0);
-    const i32* tr_idx = S.tr_idx + (size_t)b * LOB_TRACE_GENS * 32;
-    const uint32_t* tr_alive = S.tr_alive + (size_t)b * LOB_TRACE_GENS;
+    const int G = P.trace_gens;
+    const i32* tr_idx = S.tr_idx + (size_t)b * G * 32;
+    const uint32_t* tr_alive = S.tr_alive + (size_t)b * G;
     const int j = lane & 31, half = lane >> 5;
-    // Three phases, each with all of its loads in flight at once (the kernel is a chain of
-    // dependent memory round trips otherwise): alive masks -> trace indices -> adds + bitmap words.
-    const uint32_t my_alive = tr_alive[j];  // lane j (and j + 32) holds generation slot j's mask
-    constexpr int NIT = LOB_TRACE_GENS / 2;
-    i32 f[NIT];
+    // 32 generations per round (one round unless gamma*lambda > 0.86), three phases per round, each
+    // with all of its loads in flight at once: alive masks -> trace indices -> adds + map words.
+    for (int c0 = 0; c0 < n; c0 += 32) {
+        const int ka = c0 + j;  // lane j (and j + 32) holds the mask of the generation of age c0 + j
+        const uint32_t my_alive = ka < n ? tr_alive[(head - ka + G) & (G - 1)] : 0u;
+        constexpr int NIT = 16;
+        i32 f[NIT];
 #pragma unroll
-    for (int it = 0; it < NIT; it++) {
-        const int k = 2 * it + half;  // age
-        const int slot = (head - k + 2 * LOB_TRACE_GENS) % LOB_TRACE_GENS;
-        const uint32_t alive = __shfl(my_alive, slot);
-        f[it] = (k < n && ((alive >> j) & 1u)) ? tr_idx[slot * 32 + j] : -1;
-    }
-    uint32_t word[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; it++) {
-        word[it] = 0xffffffffu;
-        if (f[it] >= 0) {
-            const f64 val = scaled * (f64)P.trace_pow[2 * it + half];
-            __hip_atomic_fetch_add(&theta[f[it]], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            word[it] = nz[LOB_NZ_WORD(f[it])];
+        for (int it = 0; it < NIT; it++) {
+            const int k = c0 + 2 * it + half;  // age
+            const int slot = (head - k + G) & (G - 1);
+            const uint32_t alive = __shfl(my_alive, 2 * it + half);
+            f[it] = (k < n && ((alive >> j) & 1u)) ? tr_idx[slot * 32 + j] : -1;
         }
-    }
+        uint32_t word[NIT];
 #pragma unroll
-    for (int it = 0; it < NIT; it++) {
-        if (f[it] < 0) continue;
-        const uint32_t bit = LOB_NZ_BIT(f[it]);
-        if (!(word[it] & bit)) {  // monotone: set once, then a plain L2 hit
-            const uint32_t old = atomicOr(&nz[LOB_NZ_WORD(f[it])], bit);
-            if (!(old & bit) && !P.theta_private && h.stepped != 2) {  // this lane flipped it: tell the next act_kernel
-                i32* nz_new = S.nz_new + par * LOB_NZ_WORDS;
-                atomicAdd(&nz_new[0], 1);
-                atomicOr((uint32_t*)&nz_new[LOB_NZ_FILTER + (LOB_NZ_WORD(f[it]) & (LOB_NZ_FILTER - 1))], bit);  // keyed like the map: by group of weights
+        for (int it = 0; it < NIT; it++) {
+            word[it] = 0xffffffffu;
+            if (f[it] >= 0) {
+                const f64 val = scaled * (f64)P.trace_pow[c0 + 2 * it + half];
+                __hip_atomic_fetch_add(&theta[f[it]], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                word[it] = nz[LOB_NZ_WORD(f[it])];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            if (f[it] < 0) continue;
+            const uint32_t bit = LOB_NZ_BIT(f[it]);
+            if (!(word[it] & bit)) {  // monotone: set once, then a plain L2 hit
+                const uint32_t old = atomicOr(&nz[LOB_NZ_WORD(f[it])], bit);
+                if (!(old & bit) && !P.theta_private && h.stepped != 2) {  // this lane flipped it: tell the next act_kernel
+                    i32* nz_new = S.nz_new + par * LOB_NZ_WORDS;
+                    atomicAdd(&nz_new[0], 1);
+                    atomicOr((uint32_t*)&nz_new[LOB_NZ_FILTER + (LOB_NZ_WORD(f[it]) & (LOB_NZ_FILTER - 1))], bit);  // keyed like the map
+                }
             }
         }
     }
@@ -729,8 +734,8 @@ __global__ void dump_kernel(const DevParams* __restrict__ Pp, DevState S, int fi
     {
         const int ng = S.hdr[b].tr_n, head = S.hdr[b].tr_head;
         for (int k = 0; k < ng; k++) {
-            const int slot = (head - k + 2 * LOB_TRACE_GENS) % LOB_TRACE_GENS;
-            n_tr += __popc(S.tr_alive[(size_t)b * LOB_TRACE_GENS + slot]);
+            const int slot = (head - k + P.trace_gens) & (P.trace_gens - 1);
+            n_tr += __popc(S.tr_alive[(size_t)b * P.trace_gens + slot]);
         }
     }
     d.n_traces = n_tr;

@@ -180,8 +180,8 @@ struct DevState {
     LHdr* hdr;      // [B]
     f32* vars;      // [B][3][16]  the two rl::State objects' state_vars + the latest getState()
     f64* qs_last;   // [B][9] Q(last_state, .) of the current step
-    i32* tr_idx;    // [B][LOB_TRACE_GENS][32]
-    uint32_t* tr_alive;  // [B][LOB_TRACE_GENS]
+    i32* tr_idx;    // [B][P.trace_gens][32]
+    uint32_t* tr_alive;  // [B][P.trace_gens]
 
     f64* theta;       // [M] or [B][M]
     f64* theta_b;        // DoubleAgent::theta_b (LOB_ALGO_DOUBLE_Q), same shape as theta, or null
@@ -225,6 +225,7 @@ struct DevParams {
     f32 trace_rate;                   // (float)(gamma*lambda)
     f32 trace_pow[LOB_TRACE_GENS + 1];  // eligibility by age, iterated float products
     i32 trace_kmax;                   // first age whose eligibility < tolerance
+    i32 trace_gens;                   // ring size in generations: 32 or 64 (power of two >= trace_kmax)
     i32 algo, theta_private;
     i32 carry_verdicts;  // 0 with LOB_NO_CARRY=1 in the environment (A/B switch for the verdict carry-over)
     u64 seed, book_id_offset;

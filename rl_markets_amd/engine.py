@@ -225,10 +225,11 @@ class Engine:
         return out
 
     def traces(self, book):
-        idx = np.zeros(1024, np.int32)
-        e = np.zeros(1024, np.float32)
+        cap = 64 * 32  # LOB_TRACE_GENS generations of 32 tiles
+        idx = np.zeros(cap, np.int32)
+        e = np.zeros(cap, np.float32)
         n = C.c_int32()
-        self._check(self.lib.lob_get_traces(self.h, book, _ptr(idx), _ptr(e), 1024, C.byref(n)))
+        self._check(self.lib.lob_get_traces(self.h, book, _ptr(idx), _ptr(e), cap, C.byref(n)))
         return idx[:n.value].copy(), e[:n.value].copy()
 
     def counters(self):

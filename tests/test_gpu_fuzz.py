@@ -42,7 +42,8 @@ def random_case(seed):
     for i in range(3):
         p.group_weights[i] = float(w[i] / w.sum())
     p.gamma = float(r.uniform(0.8, 1.0))
-    p.lambda_ = float(r.uniform(0.0, 0.85))  # gamma*lambda <= 0.85: the 32-generation trace ring (lob_create rejects more)
+    # gamma*lambda <= 0.93: the trace ring holds at most LOB_TRACE_GENS = 64 generations (lob_create rejects more)
+    p.lambda_ = float(r.uniform(0.0, min(0.95, 0.93 / p.gamma)))
     p.alpha = float(r.choice([0.0, 1e-4, 1e-2, 0.3]))
     p.epsilon = float(r.choice([0.0, 0.1, 0.8, 1.0]))
     p.algo = int(r.integers(0, 3))

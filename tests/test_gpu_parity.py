@@ -8,7 +8,7 @@ import pytest
 
 from rl_markets_amd import abi, engine
 from tests import oracle_lib as ol
-from tests.parity import compare_env, compare_learner_step
+from tests.parity import compare_env, compare_learner_step, dumps_to_np
 
 pytestmark = pytest.mark.gpu
 
@@ -361,3 +361,28 @@ def test_config2_full_size_against_oracle():
     th, oth = eng.theta(), orc.theta()
     assert np.array_equal(th != 0, oth != 0)
     np.testing.assert_allclose(th, oth, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("algo", [abi.ALGO_SARSA, abi.ALGO_QLAMBDA])
+def test_long_traces_use_the_64_generation_ring(algo):
+    """gamma*lambda = 0.92: eligibilities stay above the 0.01 tolerance for 56 steps, beyond the
+    32-generation ring the default configuration (25 generations) gets."""
+    B = 4
+    p, g, rec, eng, orc = make(depth=5, n_events=500, B=B, algo=algo, theta_mode=abi.THETA_PRIVATE, mem=1 << 16,
+                               gamma=1.0, lambda_=0.92, epsilon=0.05)
+    eng.reset()
+    orc.reset()
+    most = 0
+    for step in range(150):
+        eng.td_step(1)
+        orc.td_step(1)
+        compare_learner_step(eng, orc, "long traces step %d" % step, exact=True)
+        most = max(most, int(dumps_to_np(eng.get_books())["n_traces"].max()))
+    assert most > 32 * 32  # more live traces than 32 generations could hold
+    for b in range(B):
+        ei, ee = eng.traces(b)
+        oi, oe = orc.traces(b)
+        assert dict(zip(ei.tolist(), ee.tolist())) == dict(zip(oi.tolist(), oe.tolist()))
+        np.testing.assert_array_equal(eng.theta(b), orc.theta(b))
+    with pytest.raises(engine.LobError):
+        make(B=1, gamma=1.0, lambda_=0.95)   # 90 generations: more than the ring holds
