@@ -1168,7 +1168,7 @@ int oracle_eval_step(oracle_learner* o, int32_t n_steps) {  // Backtester::_step
             if (e.isTerminal()) { o->done[b] = 1; continue; }
             o->new_state(b);
             int a = o->action(b, o->feats[b], true);
-            if (!e.performAction(a)) { o->done[b] = 2; continue; }
+            if (!e.performAction(a)) { o->done[b] = 2; e.fill(o->recs[b].book); continue; }
             o->n_steps_done++;
             o->record(b, a, e.getReward(), 0.0);
         }

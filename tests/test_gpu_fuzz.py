@@ -91,3 +91,36 @@ def test_random_configuration(seed):
             np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-12)
     eng.close()
     orc.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("LOB_FUZZ_SEEDS", "32")) // 2))
+def test_random_configuration_env_only(seed):
+    """The environment interface alone (lob_step with caller-chosen actions, then greedy
+    evaluation steps) on random configurations, run until every stream is exhausted."""
+    from tests.parity import compare_env
+    p, g, B = random_case(5000 + seed)
+    g.n_events = 260
+    rec = engine.gen_stream_host(g, p.depth, p.max_trades, p.book_id_offset, B)
+    eng = engine.Engine(p, B)
+    eng.load_events(rec)
+    orc = ol.Oracle(p, rec)
+    eng.reset()
+    orc.reset()
+    compare_env(eng, orc, "seed %d reset" % seed)
+    rng = np.random.default_rng(seed)
+    for step in range(400):
+        if step % 7 == 6:
+            eng.eval_step(1)
+            orc.eval_step(1)
+        else:
+            acts = rng.integers(0, 9, size=B).astype(np.int32)
+            eng.step(acts)
+            orc.env_step(acts)
+        compare_env(eng, orc, "seed %d step %d" % (seed, step))
+        live = eng.get_terminal() == 0  # books that have just stepped (the others keep their last reward)
+        np.testing.assert_array_equal(eng.get_reward()[live], orc.recs()["reward"][live], err_msg="seed %d step %d reward" % (seed, step))
+        if (eng.get_terminal() != 0).all():
+            break
+    assert (eng.get_terminal() != 0).all(), "streams of 260 events end within 400 steps"
+    eng.close()
+    orc.close()
