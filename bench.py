@@ -40,6 +40,10 @@ def algorithmic_bytes(kernel, depth, trades, n_vars, n_live, events_per_step):
         return hdr + 192 + 9 * 8 + 9 * 96 * 8 + n_live * 4 + 32 * 4 + 26 * 4 + 32
     if kernel == "update_kernel":     # per live trace: index (4) + theta read-modify-write (8 + 8); header + masks
         return hdr + n_live * (4 + 8 + 8) + 26 * 4
+    if kernel in ("accumulate_kernel", "apply_kernel"):
+        # the combined update: per live trace the same index + theta read-modify-write as update_kernel;
+        # summing per distinct generation first only changes how many atomics reach theta
+        return (hdr + n_live * (4 + 8 + 8) + 26 * 4) / 2.0
     if kernel == "env_kernel":        # per event: track entry (96) + trade slots + the two snapshots' levels at the order
         per_event = 96 + 2 * trades * 4 + 2 * 2 * depth * 8
         return 2 * 232 + hdr + events_per_step * per_event + 2 * 96 + 3 * 4 * n_vars   # agent scalars r/w + quotes + vars out
@@ -180,7 +184,8 @@ def main():
 
     ktimes = {}
     if not args.no_kernel_timing:
-        for k in ("act_kernel", "env_kernel", "learn_kernel", "update_kernel", "delta_begin_kernel", "delta_apply_kernel"):
+        for k in ("act_kernel", "env_kernel", "learn_kernel", "update_kernel", "accumulate_kernel", "apply_kernel",
+                  "delta_begin_kernel", "delta_apply_kernel"):
             ms, n = eng.kernel_time_ms(k)
             if n:
                 ktimes[k] = {"avg_ms": ms, "launches": n}

@@ -238,6 +238,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     }
     P.algo = p->algo; P.theta_private = p->theta_mode == LOB_THETA_PRIVATE;
     { const char* nc = getenv("LOB_NO_CARRY"); P.carry_verdicts = !(nc && nc[0] == '1'); }
+    { const char* nc = getenv("LOB_NO_COMBINE"); P.combine = !P.theta_private && !(nc && nc[0] == '1'); }
     P.seed = p->seed; P.book_id_offset = p->book_id_offset;
 
     // ---- DevState ----
@@ -294,6 +295,19 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
         if (rc == LOB_OK) rc = dev_alloc(e, &S.qs_last_b, B * LOB_N_ACTIONS);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.mt_state, B * LOB_MT_N);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.mt_idx, B);
+    }
+    if (rc == LOB_OK) rc = dev_alloc(e, &S.tr_sig, B * (size_t)P.trace_gens * 4);
+    {
+        int slots = 1024;
+        while ((size_t)slots < 4 * B && slots < (1 << 20)) slots <<= 1;
+        S.cb_slots = slots;
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.cb_key, (size_t)slots);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.cb_ident, (size_t)slots * 8);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.cb_acc, (size_t)slots * 2);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.cb_touch, (size_t)slots);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.cb_list, (size_t)slots);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.cb_count, 1);
+        if (rc == LOB_OK && hipMemsetAsync(S.cb_key, 0xff, (size_t)slots * 8, e->stream) != hipSuccess) rc = LOB_EHIP;
     }
     if (rc == LOB_OK) rc = dev_alloc(e, &S.verdict, B * LOB_VD_STRIDE);
     if (rc == LOB_OK) rc = dev_alloc(e, &S.nz_new, 2 * LOB_NZ_WORDS);
@@ -583,7 +597,17 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode) {
             HIPCHK(hipEventRecord(e->ev_join, e->stream2));
             HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join, 0));
         }
-        if (mode == 0) {
+        if (mode == 0 && e->P.combine) {
+            {
+                TimedLaunch t(e, "accumulate_kernel");
+                hipLaunchKernelGGL(accumulate_kernel, dim3(grid_waves(e->B)), dim3(LOB_BLOCK), 0, e->stream, e->P, e->S, par);
+            }
+            {
+                TimedLaunch t(e, "apply_kernel");
+                const int blocks = std::min(2048, std::max(1, (e->S.cb_slots + 3) / 4));
+                hipLaunchKernelGGL(apply_kernel, dim3(blocks), dim3(256), 0, e->stream, e->P, e->S, par);
+            }
+        } else if (mode == 0) {
             TimedLaunch t(e, "update_kernel");
             hipLaunchKernelGGL(update_kernel, dim3(grid_waves(e->B)), dim3(LOB_BLOCK), 0, e->stream, e->P, e->S, par);
         }

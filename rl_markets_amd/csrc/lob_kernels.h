@@ -287,6 +287,7 @@ __global__ void __launch_bounds__(LOB_BLOCK) act_kernel(DevParams P, DevState S,
     const uint32_t ep = (uint32_t)S.nz_epoch[0];
     const u64 tag = *(const u64*)(vd + 64);  // {epoch, slot, valid} in one load
     uint32_t my_vd = vd[lane];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && b0 == 0) S.cb_count[0] = 0;  // the previous step's apply_kernel has consumed the list
     learn_lds_init(rnd_g, S.vars + (size_t)bb * 48, have, L, nz_new);
     if (!have) return;
     LHdr* hp = S.hdr + b;
@@ -429,6 +430,8 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
     const int G = P.trace_gens;  // ring size, a power of two
     i32* tr_idx = S.tr_idx + (size_t)b * G * 32;
     uint32_t* tr_alive = S.tr_alive + (size_t)b * G;
+    i32* tr_sig = S.tr_sig + (size_t)b * G * 4;
+    const bool combine = P.combine != 0;
     for (int k0 = 0; k0 < n_old; k0 += 2) {
         const int k = k0 + half;  // old age (before this step's decay) of the generation this half-wave scans
         bool alive = false;
@@ -448,7 +451,14 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
             }
         }
         const u64 m = __ballot(alive);
-        if (k < n_old && j == 0) tr_alive[slot] = half ? (uint32_t)(m >> 32) : (uint32_t)m;
+        if (k < n_old && j == 0) {
+            const uint32_t mine = half ? (uint32_t)(m >> 32) : (uint32_t)m;
+            tr_alive[slot] = mine;
+            if (combine && mine) {  // the generation keeps live tiles: make sure its (identity, mask) has a slot
+                const int4 sg = *reinterpret_cast<const int4*>(tr_sig + slot * 4);
+                cb_claim(S, sg.x, sg.y, sg.z, sg.w, mine, b * G + slot);
+            }
+        }
     }
     // new generation: the chosen action's tiles, minus those a later action
     // clears again and minus duplicates inside the list (set() of a live tile
@@ -476,6 +486,14 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
             tr_alive[nh] = (uint32_t)m;
             hp->tr_head = nh;
             hp->tr_n = n_old + 1;
+            if (combine) {
+                // identity of the generation: the quantised group-0 coordinates + the action fix all 32 tiles
+                const int q0 = zero_last ? 0 : tile_quant(vars_from[0]), q1 = zero_last ? 0 : tile_quant(vars_from[1]),
+                          q2 = zero_last ? 0 : tile_quant(vars_from[2]);
+                const int code = action | (zero_last ? 256 : 0);
+                *reinterpret_cast<int4*>(tr_sig + nh * 4) = make_int4(q0, q1, q2, code);
+                if ((uint32_t)m) cb_claim(S, q0, q1, q2, code, (uint32_t)m, b * G + nh);
+            }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -586,6 +604,121 @@ __global__ void __launch_bounds__(LOB_BLOCK) update_kernel(DevParams P, DevState
                     atomicOr((uint32_t*)&nz_new[LOB_NZ_FILTER + (LOB_NZ_WORD(f[it]) & (LOB_NZ_FILTER - 1))], bit);  // keyed like the map
                 }
             }
+        }
+    }
+}
+
+// ---- combined update (shared theta) --------------------------------------------------------------
+// accumulate_kernel: wave per book, ONE LANE per trace generation.  Each live generation finds the
+// slot learn_kernel claimed for its (identity, alive mask) and adds its update alpha*delta/32 * e
+// there: one atomic per generation instead of one per trace (32x fewer, and the slot array is small).
+// A generation without a slot (table crowded, or a 64-bit hash shared by two identities) is applied
+// directly, tile by tile, like update_kernel does.
+__global__ void __launch_bounds__(LOB_BLOCK) accumulate_kernel(DevParams P, DevState S, int par) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = __builtin_amdgcn_readfirstlane(blockIdx.x * LOB_WAVES_PER_BLOCK + w);
+    if (b >= S.B) return;
+    const LHdr h = S.hdr[b];
+    if (!h.stepped) return;
+    const int n = h.tr_n, head = h.tr_head;
+    const int G = P.trace_gens;
+    const f64 scaled = h.upd / (f64)LOB_N_TILINGS;
+    const int target = h.stepped == 2 ? 1 : 0;
+    const uint32_t* tr_alive = S.tr_alive + (size_t)b * G;
+    const i32* tr_sig = S.tr_sig + (size_t)b * G * 4;
+    // lane = age (G <= 64)
+    const int slot = (head - lane + G) & (G - 1);
+    uint32_t mask = 0;
+    int4 sg = make_int4(0, 0, 0, 0);
+    if (lane < n) {
+        mask = tr_alive[slot];
+        sg = *reinterpret_cast<const int4*>(tr_sig + slot * 4);
+    }
+    bool direct = false;
+    if (mask) {
+        const u64 hsh = cb_hash(sg.x, sg.y, sg.z, sg.w, mask);
+        uint32_t s = (uint32_t)hsh & (uint32_t)(S.cb_slots - 1);
+        bool found = false;
+        for (int probe = 0; probe < LOB_CB_PROBES; probe++) {
+            const u64 kk = S.cb_key[s];
+            if (kk == hsh) {
+                const i32* id = S.cb_ident + (size_t)s * 8;
+                found = id[0] == sg.x && id[1] == sg.y && id[2] == sg.z && id[3] == sg.w && (uint32_t)id[4] == mask;
+                break;  // the first slot with this hash is the only one claim can have made
+            }
+            if (kk == LOB_CB_EMPTY) break;
+            s = (s + 1) & (uint32_t)(S.cb_slots - 1);
+        }
+        if (found) {
+            __hip_atomic_fetch_add(&S.cb_acc[(size_t)s * 2 + target], scaled * (f64)P.trace_pow[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!(S.cb_touch[s] & (1u << target))) atomicOr(&S.cb_touch[s], 1u << target);
+        } else {
+            direct = true;
+        }
+    }
+    u64 todo = __ballot(direct);
+    if (todo) {  // rare: apply these generations tile by tile
+        f64* theta = target ? S.theta_b : S.theta;
+        uint32_t* nz = target ? S.theta_b_nz : S.theta_nz;
+        const i32* tr_idx = S.tr_idx + (size_t)b * G * 32;
+        const int j = lane & 31;
+        while (todo) {
+            const int age = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int sl = (head - age + G) & (G - 1);
+            const uint32_t m = __shfl(mask, age);
+            if (lane < 32 && ((m >> j) & 1u)) {
+                const i32 f = tr_idx[sl * 32 + j];
+                __hip_atomic_fetch_add(&theta[f], scaled * (f64)P.trace_pow[age], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t bit = LOB_NZ_BIT(f);
+                if (!(nz[LOB_NZ_WORD(f)] & bit)) {
+                    const uint32_t old = atomicOr(&nz[LOB_NZ_WORD(f)], bit);
+                    if (!(old & bit) && !target) {
+                        i32* nz_new = S.nz_new + par * LOB_NZ_WORDS;
+                        atomicAdd(&nz_new[0], 1);
+                        atomicOr((uint32_t*)&nz_new[LOB_NZ_FILTER + (LOB_NZ_WORD(f) & (LOB_NZ_FILTER - 1))], bit);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// apply_kernel: one wave per claimed slot: theta[tile] += summed update for the live tiles of the
+// representative generation, maintain the written-weights map and the carry-over filter, free the slot.
+__global__ void __launch_bounds__(256) apply_kernel(DevParams P, DevState S, int par) {
+    const int lane = threadIdx.x & 63, j = lane & 31;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+    const int count = S.cb_count[0];
+    for (int i = wave; i < count; i += n_waves) {
+        const int s = S.cb_list[i];
+        const i32* id = S.cb_ident + (size_t)s * 8;
+        const uint32_t mask = (uint32_t)id[4];
+        const int src = id[5];
+        const uint32_t touch = S.cb_touch[s];
+        const f64 v0 = S.cb_acc[(size_t)s * 2], v1 = S.cb_acc[(size_t)s * 2 + 1];
+        const i32 f = S.tr_idx[(size_t)src * 32 + j];
+        // lanes 0-31 serve theta, lanes 32-63 theta_b (double Q)
+        const int t = lane >> 5;
+        if (((touch >> t) & 1u) && ((mask >> j) & 1u)) {
+            f64* theta = t ? S.theta_b : S.theta;
+            uint32_t* nz = t ? S.theta_b_nz : S.theta_nz;
+            __hip_atomic_fetch_add(&theta[f], t ? v1 : v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t bit = LOB_NZ_BIT(f);
+            if (!(nz[LOB_NZ_WORD(f)] & bit)) {
+                const uint32_t old = atomicOr(&nz[LOB_NZ_WORD(f)], bit);
+                if (!(old & bit) && !t) {  // tell the next act_kernel (verdict carry-over)
+                    i32* nz_new = S.nz_new + par * LOB_NZ_WORDS;
+                    atomicAdd(&nz_new[0], 1);
+                    atomicOr((uint32_t*)&nz_new[LOB_NZ_FILTER + (LOB_NZ_WORD(f) & (LOB_NZ_FILTER - 1))], bit);
+                }
+            }
+        }
+        if (lane == 0) {
+            S.cb_key[s] = LOB_CB_EMPTY;
+            S.cb_acc[(size_t)s * 2] = 0.0;
+            S.cb_acc[(size_t)s * 2 + 1] = 0.0;
+            S.cb_touch[s] = 0;
         }
     }
 }

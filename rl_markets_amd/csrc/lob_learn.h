@@ -25,6 +25,13 @@ __device__ inline i32 mod_m(u64 s, i64 M, f64 inv_M) {
     return (i32)r;
 }
 
+// (int) floor(x * num_tilings) with x86 `cvttsd2si` semantics (NaN / out of range -> INT_MIN), the
+// quantised coordinate of tiles.cpp:50-53.
+__device__ inline int tile_quant(f32 x) {
+    const f32 fq = floorf(x * 32.0f);
+    return (fq >= -2147483648.0f && fq < 2147483648.0f) ? (int)fq : (int)0x80000000;
+}
+
 // Sum of the table terms of tiling j of group g that do not depend on the
 // action: the nf float coordinates and the tiling index (tiles.cpp:50-70).
 // `v` = the group's float sub-array (State::populateFeatures passes
@@ -34,8 +41,7 @@ __device__ inline u64 tile_base(const f32* v, int nf, int j, const uint32_t* rnd
     for (int i = 0; i < nf; i++) {
         // (int) floor(floats[i] * num_tilings): x86 `cvttsd2si` semantics, a NaN or out-of-range
         // state variable becomes INT_MIN (the reference feeds NaN through here, see ulb() in lob_env.h)
-        const f32 fq = floorf(v[i] * 32.0f);
-        const int q = (fq >= -2147483648.0f && fq < 2147483648.0f) ? (int)fq : (int)0x80000000;
+        const int q = tile_quant(v[i]);
         const int base = j * (1 + 2 * i);
         int c;
         // tiles.cpp:61-64; two's-complement wrap-around like the compiled reference when q = INT_MIN
@@ -97,6 +103,35 @@ __device__ inline int argmax_ties(const f64* qs, Rng& g) {
         }
     }
     return index;
+}
+
+// ---- generation combining (lob_state.h) -------------------------------------
+#define LOB_CB_EMPTY (~0ull)
+#define LOB_CB_PROBES 64
+__device__ inline u64 cb_hash(int q0, int q1, int q2, int code, uint32_t mask) {
+    u64 h = lob_mix64((u64)(uint32_t)code ^ ((u64)mask << 32));
+    h = lob_mix64(h + (u64)(uint32_t)q2);
+    h = lob_mix64(h + (u64)(uint32_t)q1);
+    h = lob_mix64(h + (u64)(uint32_t)q0);
+    return h == LOB_CB_EMPTY ? 0 : h;
+}
+// One lane claims a slot for (signature, mask) unless somebody already has: the identity is written
+// by the winner only and read by later kernels only, so no cross-wave publication is needed here.
+__device__ inline void cb_claim(const DevState& S, int q0, int q1, int q2, int code, uint32_t mask, int src) {
+    const u64 h = cb_hash(q0, q1, q2, code, mask);
+    uint32_t s = (uint32_t)h & (uint32_t)(S.cb_slots - 1);
+    for (int probe = 0; probe < LOB_CB_PROBES; probe++) {
+        const u64 old = atomicCAS((unsigned long long*)&S.cb_key[s], (unsigned long long)LOB_CB_EMPTY, (unsigned long long)h);
+        if (old == LOB_CB_EMPTY) {
+            i32* id = S.cb_ident + (size_t)s * 8;
+            id[0] = q0; id[1] = q1; id[2] = q2; id[3] = code; id[4] = (i32)mask; id[5] = src;
+            const int pos = atomicAdd(S.cb_count, 1);
+            S.cb_list[pos] = (i32)s;  // pos < cb_slots: every slot is listed at most once
+            return;
+        }
+        if (old == h) return;
+        s = (s + 1) & (uint32_t)(S.cb_slots - 1);
+    }
 }
 
 // (base + term) mod M with both operands already reduced: one add, one compare, one select.

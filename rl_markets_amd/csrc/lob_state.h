@@ -189,6 +189,17 @@ struct DevState {
     f64* qs_last_b;      // [B][9] Qb(last_state, .)
     u64* mt_state;       // [B][312] std::mt19937_64 state of each book's Agent::gen (DoubleQLearn coin)
     i32* mt_idx;         // [B]
+    // Combined update (shared theta; DESIGN.md "generation combining"): many books hold the SAME trace
+    // generation -- the live tiles one (group-0 state, action) left behind -- so their updates are
+    // summed per distinct (generation identity, alive mask) first and applied to theta once.
+    i32* tr_sig;         // [B][trace_gens][4]: q0, q1, q2 (= (int)floor(32 x) of the three group-0 variables), action | zero << 8
+    u64* cb_key;         // [cb_slots] 64-bit hash of (signature, mask), ~0 = empty
+    i32* cb_ident;       // [cb_slots][8]: q0, q1, q2, code, mask, representative (book * trace_gens + slot), -, -
+    f64* cb_acc;         // [cb_slots][2]: summed update for theta / theta_b
+    uint32_t* cb_touch;  // [cb_slots] bit 0: theta gets an update, bit 1: theta_b
+    i32* cb_list;        // [cb_slots] occupied slots, in claim order
+    i32* cb_count;       // [1]
+    i32 cb_slots;        // power of two
     // Verdict carry-over: learn(t) saves, per book, which group-1/2 tiles of s' hit a written
     // weight (9 bits per tiling); act(t+1) evaluates the same state and reuses them instead of 576
     // bitmap look-ups, OR-ed with a small filter of the bits the update in between newly set.
@@ -227,6 +238,7 @@ struct DevParams {
     i32 trace_kmax;                   // first age whose eligibility < tolerance
     i32 trace_gens;                   // ring size in generations: 32 or 64 (power of two >= trace_kmax)
     i32 algo, theta_private;
+    i32 combine;         // shared theta: sum the updates per distinct trace generation first (0 with LOB_NO_COMBINE=1)
     i32 carry_verdicts;  // 0 with LOB_NO_CARRY=1 in the environment (A/B switch for the verdict carry-over)
     u64 seed, book_id_offset;
 };

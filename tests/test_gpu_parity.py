@@ -386,3 +386,32 @@ def test_long_traces_use_the_64_generation_ring(algo):
         np.testing.assert_array_equal(eng.theta(b), orc.theta(b))
     with pytest.raises(engine.LobError):
         make(B=1, gamma=1.0, lambda_=0.95)   # 90 generations: more than the ring holds
+
+
+@pytest.mark.parametrize("algo", [abi.ALGO_SARSA, abi.ALGO_QLAMBDA, abi.ALGO_DOUBLE_Q])
+def test_combined_update_on_off_identical(monkeypatch, algo):
+    """Shared theta sums the updates per distinct trace generation before touching theta
+    (accumulate_kernel + apply_kernel); LOB_NO_COMBINE=1 applies them trace by trace (update_kernel).
+    Same books, same actions; weights equal up to the order of the f64 additions.  A tiny weight
+    table and many books in lock-step make shared generations the rule."""
+    B = 64
+    out = []
+    for off in ("1", "0"):
+        monkeypatch.setenv("LOB_NO_COMBINE", off)
+        p, g, rec, eng, orc = make(depth=5, n_events=400, B=B, algo=algo, theta_mode=abi.THETA_SHARED, mem=1 << 13,
+                                   epsilon=0.3)
+        orc.close()
+        eng.reset()
+        trail = []
+        for _ in range(80):
+            eng.td_step(1)
+            trail.append((eng.last_actions().copy(), bytes(eng.get_books())))
+        out.append((trail, eng.theta(), eng.theta(1) if algo == abi.ALGO_DOUBLE_Q else None))
+        eng.close()
+    for k, ((a0, b0), (a1, b1)) in enumerate(zip(out[0][0], out[1][0])):
+        np.testing.assert_array_equal(a0, a1, err_msg="actions, step %d" % k)
+        assert b0 == b1, "books differ at step %d" % k
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-9, atol=1e-12)
+    assert np.array_equal(out[0][1] != 0, out[1][1] != 0)
+    if algo == abi.ALGO_DOUBLE_Q:
+        np.testing.assert_allclose(out[0][2], out[1][2], rtol=1e-9, atol=1e-12)
