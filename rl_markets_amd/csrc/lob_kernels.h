@@ -432,15 +432,31 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
     uint32_t* tr_alive = S.tr_alive + (size_t)b * G;
     i32* tr_sig = S.tr_sig + (size_t)b * G * 4;
     const bool combine = P.combine != 0;
-    for (int k0 = 0; k0 < n_old; k0 += 2) {
-        const int k = k0 + half;  // old age (before this step's decay) of the generation this half-wave scans
-        bool alive = false;
-        int slot = 0;
-        if (k < n_old) {
-            slot = (head - k + G) & (G - 1);
-            alive = (tr_alive[slot] >> j) & 1u;
+    // Old generations.  Lane l keeps the alive mask of the generation of (old) age l: loaded in one go,
+    // rewritten in registers as the scan proceeds, stored and claimed (one lane per generation, all
+    // CAS in flight together) after the scan.  The scan itself takes 8 generations per round: four
+    // index loads per lane in flight, then the LDS probes.
+    uint32_t my_mask = 0;   // lane = age
+    int my_slot = 0;
+    if (lane < n_old) {
+        my_slot = (head - lane + G) & (G - 1);
+        my_mask = tr_alive[my_slot];
+    }
+    for (int k0 = 0; k0 < n_old; k0 += 8) {
+        i32 xs[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int k = k0 + 2 * u + half;  // old age (before this step's decay) this half-wave scans
+            const uint32_t am = __shfl(my_mask, k & 63);
+            const int slot = (head - k + G) & (G - 1);
+            xs[u] = (k < n_old && ((am >> j) & 1u)) ? tr_idx[slot * 32 + j] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (k0 + 2 * u >= n_old) break;  // wave-uniform
+            bool alive = xs[u] >= 0;
             if (alive) {
-                const uint32_t x = (uint32_t)tr_idx[slot * 32 + j];
+                const uint32_t x = (uint32_t)xs[u];
                 unsigned s = (x * 2654435761u) >> 23;
                 while (true) {
                     const u64 v = tab[s];
@@ -449,15 +465,16 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
                     s = (s + 1) & (LOB_HSLOTS - 1);
                 }
             }
+            const u64 m = __ballot(alive);
+            if (lane == k0 + 2 * u) my_mask = (uint32_t)m;
+            if (lane == k0 + 2 * u + 1) my_mask = (uint32_t)(m >> 32);
         }
-        const u64 m = __ballot(alive);
-        if (k < n_old && j == 0) {
-            const uint32_t mine = half ? (uint32_t)(m >> 32) : (uint32_t)m;
-            tr_alive[slot] = mine;
-            if (combine && mine) {  // the generation keeps live tiles: make sure its (identity, mask) has a slot
-                const int4 sg = *reinterpret_cast<const int4*>(tr_sig + slot * 4);
-                cb_claim(S, sg.x, sg.y, sg.z, sg.w, mine, b * G + slot);
-            }
+    }
+    if (lane < n_old) {
+        tr_alive[my_slot] = my_mask;
+        if (combine && my_mask) {  // the generation keeps live tiles: make sure its (identity, mask) has a slot
+            const int4 sg = *reinterpret_cast<const int4*>(tr_sig + my_slot * 4);
+            cb_claim(S, sg.x, sg.y, sg.z, sg.w, my_mask, b * G + my_slot);
         }
     }
     // new generation: the chosen action's tiles, minus those a later action

@@ -415,3 +415,22 @@ def test_combined_update_on_off_identical(monkeypatch, algo):
     assert np.array_equal(out[0][1] != 0, out[1][1] != 0)
     if algo == abi.ALGO_DOUBLE_Q:
         np.testing.assert_allclose(out[0][2], out[1][2], rtol=1e-9, atol=1e-12)
+
+
+def test_combined_update_table_overflow():
+    """More distinct trace generations than the claim table has slots (300 books x up to 56 live
+    generations against 2 048 slots): the generations that find no slot are applied directly."""
+    B = 300
+    p, g, rec, eng, orc = make(depth=5, n_events=330, B=B, algo=abi.ALGO_SARSA, theta_mode=abi.THETA_SHARED, mem=1 << 16,
+                               gamma=1.0, lambda_=0.92, epsilon=0.6)
+    eng.reset()
+    orc.reset()
+    for step in range(90):
+        eng.td_step(1)
+        orc.td_step(1)
+        if step % 10 == 9 or step < 3:
+            compare_learner_step(eng, orc, "overflow step %d" % step, exact=False, rtol=1e-9)
+    assert int(dumps_to_np(eng.get_books())["n_traces"].sum()) > 60 * 2048  # far more live generations than slots... times 32 tiles
+    th, oth = eng.theta(), orc.theta()
+    assert np.array_equal(th != 0, oth != 0)
+    np.testing.assert_allclose(th, oth, rtol=1e-9, atol=1e-12)
