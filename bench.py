@@ -81,9 +81,30 @@ def cpu_baseline():
             return {"error": out.stderr[-300:]}
         info = json.loads(out.stdout.strip().splitlines()[-1])
         best, steps = info["best_sec"], info["steps_per_episode"]
-    if not best:
-        return None
-    return {"value": steps / best, "unit": "env-steps/s", "cores": 1, "kind": "reference",
+        if not best:
+            return None
+        # whole-host figure: one independent reference process per host core, 3 episodes
+        # each, all started together; value = total steps / slowest process' wall time
+        ncores = min(os.cpu_count() or 1, 64)
+        host = None
+        if ncores > 1:
+            t0 = time.perf_counter()
+            procs = [subprocess.Popen([harness, "learner", "--stream", sp, "--events", str(g.n_events), "--book", "0",
+                                       "--algo", "q_learn", "--mem", "20000000", "--episodes", "3",
+                                       "--tmp", os.path.join(td, "h%d" % i)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+                     for i in range(ncores)]
+            done = 0
+            for pr in procs:
+                try:
+                    o, _ = pr.communicate(timeout=300)
+                    if pr.returncode == 0:
+                        done += 3 * json.loads(o.strip().splitlines()[-1])["steps_per_episode"]
+                except subprocess.TimeoutExpired:
+                    pr.kill()
+            wall = time.perf_counter() - t0
+            if done:
+                host = {"value": done / wall, "cores": ncores, "note": "N independent single-thread reference processes, wall time incl. process start and CSV writing"}
+    return {"value": steps / best, "unit": "env-steps/s", "cores": 1, "kind": "reference", "whole_host": host,
             "sample": "C1 slice: 1 book, 5-level (reference maximum), %d-event synthetic day, Q(lambda) rl::QLearn, "
                       "memory_size 20M, Learner::RunEpisode incl. CSV parsing, best of %d episodes (%d steps each)"
                       % (g.n_events, episodes, steps)}
