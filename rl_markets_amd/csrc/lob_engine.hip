@@ -449,6 +449,14 @@ int lob_gen_events_device(lob_engine* e, const lob_gen_params* g) {
     return LOB_OK;
 }
 
+// env_kernel with 64 books per wave, or 16 when the batch is too small to give every SIMD a wave
+static void launch_env(lob_engine* e, hipStream_t st, const i32* actions, int count_updates, int b0, int nb) {
+    if (e->B <= 16384)
+        hipLaunchKernelGGL(env_kernel<16>, dim3((nb + 15) / 16), dim3(16), 0, st, (const DevParams*)e->P_dev, e->S, actions, count_updates, b0, nb);
+    else
+        hipLaunchKernelGGL(env_kernel<64>, dim3((nb + 63) / 64), dim3(64), 0, st, (const DevParams*)e->P_dev, e->S, actions, count_updates, b0, nb);
+}
+
 int lob_reset(lob_engine* e) {
     if (!e) return LOB_EINVAL;
     if (!e->have_events) { lob_set_error("lob_reset: no event stream loaded"); return LOB_ESTATE; }
@@ -480,7 +488,7 @@ int lob_step(lob_engine* e, const int32_t* host_actions) {
     HIPCHK(hipMemcpyAsync(e->actions_dev, host_actions, (size_t)e->B * 4, hipMemcpyHostToDevice, e->stream));
     {
         TimedLaunch t(e, "env_kernel");
-        hipLaunchKernelGGL(env_kernel, dim3((e->B + LOB_ENV_BLOCK - 1) / LOB_ENV_BLOCK), dim3(LOB_ENV_BLOCK), 0, e->stream, (const DevParams*)e->P_dev, e->S, (const i32*)e->actions_dev, 0, 0, e->B);
+        launch_env(e, e->stream, (const i32*)e->actions_dev, 0, 0, e->B);
     }
     HIPCHK(hipGetLastError());
     return check_device_errors(e);
@@ -584,7 +592,7 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode) {
             if (G > 1 && g == 0) HIPCHK(hipEventRecord(e->ev_stagger, st));
             {
                 TimedLaunch t(e, "env_kernel", st);
-                hipLaunchKernelGGL(env_kernel, dim3((nb + LOB_ENV_BLOCK - 1) / LOB_ENV_BLOCK), dim3(LOB_ENV_BLOCK), 0, st, (const DevParams*)e->P_dev, e->S, (const i32*)nullptr, mode == 0 ? 1 : 0, b0, nb);
+                launch_env(e, st, (const i32*)nullptr, mode == 0 ? 1 : 0, b0, nb);
             }
             if (mode == 0) {
                 TimedLaunch t(e, "learn_kernel", st);

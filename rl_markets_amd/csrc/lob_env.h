@@ -235,19 +235,50 @@ __device__ inline f64 rec_price(const EnvCtx& c, int rec, int side, int l) {
     const uint32_t* r = c.row(rec);
     return (f64)__uint_as_float(r[(side == 0 ? lob_rec_ask_px(c.P.D, c.P.T) : lob_rec_bid_px(c.P.D, c.P.T)) + l]);
 }
-// Book::volume(price) / last_volume(price) (book.cpp:200-214) on the snapshot held by record `rec`
+// Book::volume(price) / last_volume(price) (book.cpp:200-214) on the snapshot held by record `rec`.
+// All level prices are fetched before the first compare (the kernel is a chain of dependent loads
+// otherwise: a scan that waits for each level in turn costs D memory round trips per look-up).
+__device__ inline int book_level_of(const uint32_t* px, int D, f64 k) {
+    f32 p[LOB_MAX_DEPTH];
+#pragma unroll
+    for (int l = 0; l < LOB_MAX_DEPTH; l++) p[l] = l < D ? __uint_as_float(px[l]) : 0.0f;
+    int hit = -1;
+#pragma unroll
+    for (int l = 0; l < LOB_MAX_DEPTH; l++)
+        if (p[l] != 0.0f && key4((f64)p[l]) == k) hit = l;  // price keys are unique per side (lob_validate_stream)
+    return hit;
+}
 __device__ inline i64 book_volume(const EnvCtx& c, int rec, int side, f64 price) {
     if (rec < 0) return 0;
     const uint32_t* r = c.row(rec);
     const uint32_t* px = r + (side == 0 ? lob_rec_ask_px(c.P.D, c.P.T) : lob_rec_bid_px(c.P.D, c.P.T));
     const uint32_t* vol = r + (side == 0 ? lob_rec_ask_vol(c.P.D, c.P.T) : lob_rec_bid_vol(c.P.D, c.P.T));
+    const int hit = book_level_of(px, c.P.D, key4(price));
+    return hit >= 0 ? (i64)(i32)vol[hit] : 0;
+}
+// volume at `price` in two snapshots at once (UpdateOrder needs last_volume and volume): both
+// level scans in flight together
+__device__ inline void book_volume2(const EnvCtx& c, int rec_a, int rec_b, int side, f64 price, i64& va, i64& vb) {
+    const int opx = side == 0 ? lob_rec_ask_px(c.P.D, c.P.T) : lob_rec_bid_px(c.P.D, c.P.T);
+    const int ovol = side == 0 ? lob_rec_ask_vol(c.P.D, c.P.T) : lob_rec_bid_vol(c.P.D, c.P.T);
+    const uint32_t* ra = c.row(rec_a < 0 ? 0 : rec_a);
+    const uint32_t* rb = c.row(rec_b < 0 ? 0 : rec_b);
+    const int D = c.P.D;
     const f64 k = key4(price);
-    i64 v = 0;
-    for (int l = 0; l < c.P.D; l++) {
-        f32 p = __uint_as_float(px[l]);
-        if (p != 0.0f && key4((f64)p) == k) v = (i64)(i32)vol[l];
+    f32 pa[LOB_MAX_DEPTH], pb[LOB_MAX_DEPTH];
+#pragma unroll
+    for (int l = 0; l < LOB_MAX_DEPTH; l++) {
+        pa[l] = l < D ? __uint_as_float(ra[opx + l]) : 0.0f;
+        pb[l] = l < D ? __uint_as_float(rb[opx + l]) : 0.0f;
     }
-    return v;
+    int ha = -1, hb = -1;
+#pragma unroll
+    for (int l = 0; l < LOB_MAX_DEPTH; l++) {
+        if (pa[l] != 0.0f && key4((f64)pa[l]) == k) ha = l;
+        if (pb[l] != 0.0f && key4((f64)pb[l]) == k) hb = l;
+    }
+    va = (rec_a >= 0 && ha >= 0) ? (i64)(i32)ra[ovol + ha] : 0;
+    vb = (rec_b >= 0 && hb >= 0) ? (i64)(i32)rb[ovol + hb] : 0;
 }
 
 // RiskManager::CheckOrders (src/environment/risk_manager.cpp:26-32)
@@ -431,9 +462,9 @@ __device__ inline void update_order(const EnvCtx& c, EnvR& e, int side, int last
         if (side == 0) e.a_on = 0; else e.b_on = 0;
         return;
     }
-    i64 lv = book_volume(c, last_rec, side, opx);
+    i64 lv, v;
+    book_volume2(c, last_rec, row_rec, side, opx, lv, v);
     if (lv == 0) return;
-    i64 v = book_volume(c, row_rec, side, opx);
     if (v == 0) {
         o.qh = 0; o.qt = 0;
     } else {

@@ -158,7 +158,12 @@ __global__ void __launch_bounds__(256) get_state_kernel(const DevParams* __restr
 // performAction for every book that has an action pending (S.stepped).
 // mode 0: learner step (new vars go to `state` = slot_cur); mode 1: host
 // supplied actions (lob_step).
-#define LOB_ENV_BLOCK 64  // one wave per block: 23.5 KB of LDS slots, small enough to share a CU with learner blocks
+// LOB_ENV_BLOCK books per block = per wave.  64: 23.5 KB of LDS slots, small enough to share a CU with
+// learner blocks.  The kernel is a serial chain per lane and a wave pays for the longest of its
+// lanes' event loops, so when the batch cannot fill the chip anyway (<= 16 384 books: at most one
+// wave per SIMD) 16 books per wave spread the work over 4x the waves: 0.139 -> see DESIGN.md at 4 096
+// books; at 65 536 books the same choice is slower (0.31 vs 0.19 ms).
+template <int LOB_ENV_BLOCK>
 __global__ void __launch_bounds__(LOB_ENV_BLOCK) env_kernel(const DevParams* __restrict__ Pp, DevState S, const i32* host_actions, int count_updates, int b0, int nb) {
     const DevParams& P = *Pp;  // parameters read through the scalar cache, never copied to scratch
     __shared__ EnvSlot lds_env[LOB_ENV_BLOCK];
