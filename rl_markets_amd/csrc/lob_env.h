@@ -281,6 +281,40 @@ __device__ inline void book_volume2(const EnvCtx& c, int rec_a, int rec_b, int s
     vb = (rec_b >= 0 && hb >= 0) ? (i64)(i32)rb[ovol + hb] : 0;
 }
 
+// The four look-ups of one applied depth row -- last_volume and volume at the ask order's price, the
+// same at the bid order's -- with all 4 x D level prices in flight together.
+__device__ inline void order_volumes(const EnvCtx& c, const EnvR& e, int last_rec, int row_rec, i64& a_lv, i64& a_v,
+                                     i64& b_lv, i64& b_v) {
+    a_lv = a_v = b_lv = b_v = 0;
+    const int D = c.P.D;
+    const int apx = lob_rec_ask_px(D, c.P.T), avol = lob_rec_ask_vol(D, c.P.T);
+    const int bpx = lob_rec_bid_px(D, c.P.T), bvol = lob_rec_bid_vol(D, c.P.T);
+    const uint32_t* rl = c.row(last_rec < 0 ? 0 : last_rec);
+    const uint32_t* rr = c.row(row_rec < 0 ? 0 : row_rec);
+    const bool a_on = e.a_on != 0, b_on = e.b_on != 0;
+    f32 pal[LOB_MAX_DEPTH], par[LOB_MAX_DEPTH], pbl[LOB_MAX_DEPTH], pbr[LOB_MAX_DEPTH];
+#pragma unroll
+    for (int l = 0; l < LOB_MAX_DEPTH; l++) {
+        pal[l] = (a_on && l < D) ? __uint_as_float(rl[apx + l]) : 0.0f;
+        par[l] = (a_on && l < D) ? __uint_as_float(rr[apx + l]) : 0.0f;
+        pbl[l] = (b_on && l < D) ? __uint_as_float(rl[bpx + l]) : 0.0f;
+        pbr[l] = (b_on && l < D) ? __uint_as_float(rr[bpx + l]) : 0.0f;
+    }
+    const f64 ka = key4(e.a_opx), kb = key4(e.b_opx);
+    int hal = -1, har = -1, hbl = -1, hbr = -1;
+#pragma unroll
+    for (int l = 0; l < LOB_MAX_DEPTH; l++) {
+        if (pal[l] != 0.0f && key4((f64)pal[l]) == ka) hal = l;
+        if (par[l] != 0.0f && key4((f64)par[l]) == ka) har = l;
+        if (pbl[l] != 0.0f && key4((f64)pbl[l]) == kb) hbl = l;
+        if (pbr[l] != 0.0f && key4((f64)pbr[l]) == kb) hbr = l;
+    }
+    if (last_rec >= 0 && hal >= 0) a_lv = (i64)(i32)rl[avol + hal];
+    if (row_rec >= 0 && har >= 0) a_v = (i64)(i32)rr[avol + har];
+    if (last_rec >= 0 && hbl >= 0) b_lv = (i64)(i32)rl[bvol + hbl];
+    if (row_rec >= 0 && hbr >= 0) b_v = (i64)(i32)rr[bvol + hbr];
+}
+
 // RiskManager::CheckOrders (src/environment/risk_manager.cpp:26-32)
 __device__ inline void check_orders(const DevParams& P, EnvR& e) {
     if (e.position >= P.pos_ub) e.b_on = 0;
@@ -449,8 +483,7 @@ __device__ inline f64 get_reward(const EnvCtx& c, const EnvR& e) {
 
 // Book::UpdateOrder (book.cpp:102-141) of one side for ONE applied depth row:
 // `last_rec` = the stashed snapshot, `row_rec` = the row just applied.
-__device__ inline void update_order(const EnvCtx& c, EnvR& e, int side, int last_rec, int row_rec, const f64* tp,
-                                    const i64* tv) {
+__device__ inline void update_order(const EnvCtx& c, EnvR& e, int side, i64 lv, i64 v, const f64* tp, const i64* tv) {
     const DevParams& P = c.P;
     i32 on = side == 0 ? e.a_on : e.b_on;
     if (!on) return;
@@ -462,8 +495,6 @@ __device__ inline void update_order(const EnvCtx& c, EnvR& e, int side, int last
         if (side == 0) e.a_on = 0; else e.b_on = 0;
         return;
     }
-    i64 lv, v;
-    book_volume2(c, last_rec, row_rec, side, opx, lv, v);
     if (lv == 0) return;
     if (v == 0) {
         o.qh = 0; o.qt = 0;
@@ -588,8 +619,10 @@ __device__ inline bool next_state(const EnvCtx& c, EnvR& e) {
             match_orders(c, e, tp, tv, e.mid, au_vol, au_proxy, au_value, bu_vol, bu_proxy, bu_value);
             // rows applied before the stream ran dry still update the queue model
             for (int r = M.ex_first; r <= M.ex_cur && M.ex_cur >= M.ex_first; r++) {
-                update_order(c, e, 0, M.ex_last, r, tp, tv);
-                update_order(c, e, 1, M.ex_last, r, tp, tv);
+                i64 a_lv, a_v, b_lv, b_v;
+                order_volumes(c, e, M.ex_last, r, a_lv, a_v, b_lv, b_v);
+                update_order(c, e, 0, a_lv, a_v, tp, tv);
+                update_order(c, e, 1, b_lv, b_v, tp, tv);
             }
         }
         e.rec_cur = M.ex_cur; e.rec_last = M.ex_last; e.time_ms = M.ex_time;
@@ -606,8 +639,10 @@ __device__ inline bool next_state(const EnvCtx& c, EnvR& e) {
     // UpdateBookProfiles: StashState, then ApplyChanges (-> UpdateOrder) for every applied row
     const int last_rec = e.rec_cur;
     for (int r = t.rec_first; r <= t.rec_last; r++) {
-        update_order(c, e, 0, last_rec, r, tp, tv);
-        update_order(c, e, 1, last_rec, r, tp, tv);
+        i64 a_lv, a_v, b_lv, b_v;
+        order_volumes(c, e, last_rec, r, a_lv, a_v, b_lv, b_v);
+        update_order(c, e, 0, a_lv, a_v, tp, tv);
+        update_order(c, e, 1, b_lv, b_v, tp, tv);
     }
     e.rec_last = last_rec;
     e.rec_cur = t.rec_last;
@@ -684,9 +719,11 @@ __device__ inline bool perform_action(const EnvCtx& c, EnvR& e, int action) {
 
 // Intraday::getVariable (intraday.cpp:316-409): market variables come from the
 // track entry of the last completed event, agent variables are computed here.
-__device__ inline f64 get_variable(const EnvCtx& c, const EnvR& e, int v) {
+// `t` = state_track(c, e), fetched ONCE by the caller (by value: six 16-byte loads in flight) rather
+// than once per variable.
+__device__ inline Track state_track(const EnvCtx& c, const EnvR& e) { return c.track(e.k > 0 ? e.k - 1 : 0); }
+__device__ inline f64 get_variable(const EnvCtx& c, const EnvR& e, int v, const Track& t) {
     const DevParams& P = c.P;
-    const Track& t = c.track(e.k > 0 ? e.k - 1 : 0);
     switch (v) {
         case LOB_VAR_POS: return (f64)e.position / (f64)P.order_size;
         case LOB_VAR_SPD: return (f64)t.mv[LOB_MV_SPD];

@@ -106,8 +106,9 @@ __global__ void __launch_bounds__(256, 1) reset_kernel(const DevParams* __restri
         const int last = h.slot_cur ^ 1;
         f32* v = S.vars + ((size_t)b * 3 + last) * 16;
         f32* vf = S.vars + ((size_t)b * 3 + 2) * 16;
+        const Track tk = state_track(c, e);
         for (int i = 0; i < P.V; i++) {
-            v[i] = (f32)get_variable(c, e, P.vars[i]);
+            v[i] = (f32)get_variable(c, e, P.vars[i], tk);
             vf[i] = v[i];
         }
         h.zero_mask &= ~(1 << last);
@@ -150,8 +151,10 @@ __global__ void __launch_bounds__(256) get_state_kernel(const DevParams* __restr
     EnvCtx c(P, S, b);
     EnvR e;
     env_load(S, b, e);
-    if (out)
-        for (int i = 0; i < P.V; i++) out[(size_t)b * P.V + i] = (f32)get_variable(c, e, P.vars[i]);
+    if (out) {
+        const Track tk = state_track(c, e);
+        for (int i = 0; i < P.V; i++) out[(size_t)b * P.V + i] = (f32)get_variable(c, e, P.vars[i], tk);
+    }
     if (reward) reward[b] = get_reward(c, e);
 }
 
@@ -193,8 +196,9 @@ __global__ void __launch_bounds__(LOB_ENV_BLOCK) env_kernel(const DevParams* __r
                 const int cur = h.slot_cur;
                 f32* v = S.vars + ((size_t)b * 3 + cur) * 16;
                 f32* vf = S.vars + ((size_t)b * 3 + 2) * 16;
+                const Track tk = state_track(c, e);
                 for (int i = 0; i < P.V; i++) {
-                    v[i] = (f32)get_variable(c, e, P.vars[i]);
+                    v[i] = (f32)get_variable(c, e, P.vars[i], tk);
                     vf[i] = v[i];
                 }
                 h.zero_mask &= ~(1 << cur);
