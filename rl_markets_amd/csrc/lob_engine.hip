@@ -451,7 +451,10 @@ int lob_gen_events_device(lob_engine* e, const lob_gen_params* g) {
 
 // env_kernel with 64 books per wave, or 16 when the batch is too small to give every SIMD a wave
 static void launch_env(lob_engine* e, hipStream_t st, const i32* actions, int count_updates, int b0, int nb) {
-    if (e->B <= 16384)
+    static const int force = getenv("LOB_ENV_LANES") ? atoi(getenv("LOB_ENV_LANES")) : 0;  // experiment switch
+    if (force == 32)
+        hipLaunchKernelGGL(env_kernel<32>, dim3((nb + 31) / 32), dim3(32), 0, st, (const DevParams*)e->P_dev, e->S, actions, count_updates, b0, nb);
+    else if (force == 16 || (force == 0 && e->B <= 16384))
         hipLaunchKernelGGL(env_kernel<16>, dim3((nb + 15) / 16), dim3(16), 0, st, (const DevParams*)e->P_dev, e->S, actions, count_updates, b0, nb);
     else
         hipLaunchKernelGGL(env_kernel<64>, dim3((nb + 63) / 64), dim3(64), 0, st, (const DevParams*)e->P_dev, e->S, actions, count_updates, b0, nb);
