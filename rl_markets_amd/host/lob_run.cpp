@@ -5,6 +5,8 @@
 //
 //   lob_run -c config/example.yaml [-n books] [-e episodes] [-a sarsa|q_learn|double_q_learn] [--events N] [--depth D]
 //           [--theta out.bin] [--profit-log profit_log.csv]
+//           [--md depth.csv --tas trades.csv | --lobster orderbook.csv message.csv LEVELS]   (a recorded day, replayed
+//            by every book from evenly spread starting records; default: synthetic streams)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -13,7 +15,8 @@
 #include "lob_host.hpp"
 
 int main(int argc, char** argv) {
-    std::string cfg_path, algo, theta_out, profit_log;
+    std::string cfg_path, algo, theta_out, profit_log, md, tas, lob_ob, lob_msg;
+    int lob_levels = 0;
     int books = 1, episodes = 1, events = 2112, depth = 5;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -26,6 +29,9 @@ int main(int argc, char** argv) {
         else if (a == "--depth") depth = atoi(next().c_str());
         else if (a == "--theta") theta_out = next();
         else if (a == "--profit-log") profit_log = next();
+        else if (a == "--md") md = next();
+        else if (a == "--tas") tas = next();
+        else if (a == "--lobster") { lob_ob = next(); lob_msg = next(); lob_levels = atoi(next().c_str()); }
         else { fprintf(stderr, "unknown flag %s\n", a.c_str()); return 1; }
     }
     try {
@@ -35,11 +41,24 @@ int main(int argc, char** argv) {
         std::string ticker = c.has("data.symbols") ? c.list("data.symbols").at(0) : "HSBA.L";
         lob_params p = c.to_params(ticker, depth, 2);
         lob::BatchedIntraday env(p, books);
-        lob_gen_params g;
-        lob_default_gen_params(&g);
-        g.n_events = events;
-        g.seed = p.seed;
-        env.LoadSynthetic(g);
+        if (!md.empty() || !lob_ob.empty()) {
+            // the reference's data files (Intraday::LoadData reads the CSV pair, intraday.cpp:141-150)
+            uint32_t* rec = nullptr;
+            int32_t n = 0;
+            if (!md.empty()) lob::check(lob_convert_csv(md.c_str(), tas.c_str(), p.max_trades, &rec, &n), "LoadData");
+            else lob::check(lob_convert_lobster(lob_ob.c_str(), lob_msg.c_str(), lob_levels, depth, p.max_trades, &rec, &n), "LoadData");
+            const int window = events < n ? events : n;
+            std::vector<int64_t> phase(books);
+            for (int b = 0; b < books; b++) phase[b] = books > 1 ? (int64_t)(n - window) * b / (books - 1) : 0;
+            env.LoadReplay(rec, n, phase, window);
+            lob_free(rec);
+        } else {
+            lob_gen_params g;
+            lob_default_gen_params(&g);
+            g.n_events = events;
+            g.seed = p.seed;
+            env.LoadSynthetic(g);
+        }
         lob::Agent agent(env, c);
         lob::Learner learner(env, 8);
         printf("episode,episode_id,reward,pnl,n_steps,epsilon\n");

@@ -91,3 +91,33 @@ def test_lob_run_backtest_profit_log(tmp_path):
         last_bandh = r["book"]["episode_bandh"]
         n += 1
     assert n == len(rows) - 1 and n > 50
+
+
+def test_lob_run_on_reference_csv_pair():
+    """lob_run --md/--tas: the reference's own two CSV formats (crafted Q14 day: same-timestamp rows,
+    a crossed book) converted and replayed; one book, one episode, against the oracle on the same
+    converted records."""
+    exe = os.path.join(ROOT, "rl_markets_amd", "host", "lob_run")
+    gold = os.path.join(ROOT, "tests", "golden")
+    md, tas = os.path.join(gold, "q14_md.csv"), os.path.join(gold, "q14_tas.csv")
+    rec = engine.convert_csv(md, tas, 2)
+    n = rec.shape[1]
+    out = subprocess.run([exe, "-c", os.path.join(ROOT, "config", "example.yaml"), "-a", "sarsa", "-n", "1", "-e", "1",
+                          "--events", str(n), "--md", md, "--tas", tas], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    ep, _id, reward, pnl, n_steps, eps = out.stdout.strip().splitlines()[1].split(",")
+    p = engine.default_params()
+    p.algo = abi.ALGO_SARSA
+    orc = ol.Oracle(p, rec)
+    orc.reset()
+    for _ in range(n):
+        orc.td_step(1)
+    orc.clear_inventory()
+    r = orc.rec(0)
+    assert int(n_steps) == r["book"]["total_ticks"] > 50
+    assert float(reward) == pytest.approx(r["book"]["episode_reward"], rel=1e-9)
+    assert float(pnl) == pytest.approx(r["book"]["episode_pnl"], rel=1e-9)
+    # a missing file is an error, not a silent fall-back to synthetic data
+    bad = subprocess.run([exe, "-c", os.path.join(ROOT, "config", "example.yaml"), "--md", md, "--tas", md + ".nope"],
+                         capture_output=True, text=True)
+    assert bad.returncode == 2 and "Unhandled Exception" in bad.stderr
