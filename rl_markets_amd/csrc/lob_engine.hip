@@ -310,7 +310,8 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
         if (rc == LOB_OK && hipMemsetAsync(S.cb_key, 0xff, (size_t)slots * 8, e->stream) != hipSuccess) rc = LOB_EHIP;
     }
     if (rc == LOB_OK) rc = dev_alloc(e, &S.verdict, B * LOB_VD_STRIDE);
-    if (rc == LOB_OK) rc = dev_alloc(e, &S.nz_new, 2 * LOB_NZ_WORDS);
+    if (rc == LOB_OK) rc = dev_alloc(e, &S.nz_new, 4 * LOB_NZ_WORDS);
+    if (rc == LOB_OK) rc = dev_alloc(e, &S.verdict_b, p->algo == LOB_ALGO_DOUBLE_Q ? B * 64 : 1);
     if (rc == LOB_OK) rc = dev_alloc(e, &S.nz_epoch, 1);
     if (rc == LOB_OK) rc = dev_alloc(e, &S.counters, 8);
     if (rc == LOB_OK) rc = dev_alloc(e, &S.error_flag, 1);

@@ -247,7 +247,7 @@ struct LearnLds {
     uint32_t act_terms[32];                               // trailing-coordinate terms [group][action] mod M (27 used)
     f64 vals[LOB_WAVES_PER_BLOCK][LOB_HSLOTS];      // 4 KB per wave: one group's gathered theta (9 x 33 f64) / trace hash set (aliased)
     f32 vars[LOB_WAVES_PER_BLOCK][3][16];
-    uint32_t newf[LOB_NZ_FILTER];                         // act only: filter of the weights first written by the previous update
+    uint32_t newf[2][LOB_NZ_FILTER];                      // act only: filters of the map bits first set by the previous update (theta, theta_b)
 };
 
 // Stage the hash table (8 KB, two 16-byte loads per thread), the 27 action terms
@@ -268,7 +268,10 @@ __device__ inline void learn_lds_init(const uint32_t* __restrict__ rnd_g, const 
         if (threadIdx.x + i * LOB_BLOCK < 512) dst[threadIdx.x + i * LOB_BLOCK] = r[i];
     if (threadIdx.x < 27) L.act_terms[threadIdx.x] = rnd_g[2048 + threadIdx.x];
     if (lane < 48) (&L.vars[w][0][0])[lane] = vv;
-    if (nz_buf && threadIdx.x < LOB_NZ_FILTER) L.newf[threadIdx.x] = (uint32_t)nz_buf[LOB_NZ_FILTER + threadIdx.x];
+    if (nz_buf && threadIdx.x < 2 * LOB_NZ_FILTER) {  // [target][parity][LOB_NZ_WORDS]: the two targets are 2 * LOB_NZ_WORDS apart
+        const int tg = threadIdx.x / LOB_NZ_FILTER, i = threadIdx.x % LOB_NZ_FILTER;
+        L.newf[tg][i] = (uint32_t)nz_buf[tg * 2 * LOB_NZ_WORDS + LOB_NZ_FILTER + i];
+    }
     __syncthreads();
 }
 
@@ -292,10 +295,11 @@ __global__ void __launch_bounds__(LOB_BLOCK) act_kernel(DevParams P, DevState S,
     const i32* nz_new = S.nz_new + (par ^ 1) * LOB_NZ_WORDS;  // written by the previous step's update
     // everything the verdict carry-over needs is loaded up front, beside the header and the LDS staging
     const uint16_t* vd = S.verdict + (size_t)bb * LOB_VD_STRIDE;
-    const int n_new = nz_new[0];
+    const int n_new = ALGO == LOB_ALGO_DOUBLE_Q ? max(nz_new[0], nz_new[2 * LOB_NZ_WORDS]) : nz_new[0];
     const uint32_t ep = (uint32_t)S.nz_epoch[0];
     const u64 tag = *(const u64*)(vd + 64);  // {epoch, slot, valid} in one load
     uint32_t my_vd = vd[lane];
+    uint32_t my_vd_b = ALGO == LOB_ALGO_DOUBLE_Q ? S.verdict_b[(size_t)bb * 64 + lane] : 0;
     if (blockIdx.x == 0 && threadIdx.x == 0 && b0 == 0) S.cb_count[0] = 0;  // the previous step's apply_kernel has consumed the list
     learn_lds_init(rnd_g, S.vars + (size_t)bb * 48, have, L, nz_new);
     if (!have) return;
@@ -314,21 +318,24 @@ __global__ void __launch_bounds__(LOB_BLOCK) act_kernel(DevParams P, DevState S,
     f64 qs[LOB_N_ACTIONS];
     const size_t nz_off = P.theta_private ? (size_t)b * LOB_NZ_NWORDS(P.M) : 0;
     const uint32_t* nz = S.theta_nz + nz_off;
+    bool reuse;
     {
         // learn(t) of this book evaluated the very same State: take over its "weight is zero"
         // verdicts if nothing but update(t) touched theta since (epoch) and that update set only a
         // few new bits (kept in a 4096-bit filter, staged in LDS above).
-        const bool reuse = ALGO != LOB_ALGO_DOUBLE_Q && mode == 0 && !zero && !P.theta_private && P.carry_verdicts && n_new <= LOB_NZ_NEW_MAX &&
-                           tag == vd_tag(ep, src);
-        if (reuse) q_values(P, theta, nz, L.vars[w][src], zero, L.rnd, L.act_terms, L.vals[w], lane, qs, 2, &my_vd, L.newf);
+        reuse = mode == 0 && !zero && !P.theta_private && P.carry_verdicts && n_new <= LOB_NZ_NEW_MAX && tag == vd_tag(ep, src);
+        if (reuse) q_values(P, theta, nz, L.vars[w][src], zero, L.rnd, L.act_terms, L.vals[w], lane, qs, 2, &my_vd, L.newf[0]);
         else q_values(P, theta, nz, L.vars[w][src], zero, L.rnd, L.act_terms, L.vals[w], lane, qs);
     }
     if (lane < LOB_N_ACTIONS) S.qs_last[(size_t)b * LOB_N_ACTIONS + lane] = qs[lane];
     if (ALGO == LOB_ALGO_DOUBLE_Q) {
         // DoubleAgent::action (agent.cpp:196-204): qs[a] = (getQ + getQb) / 2.0f
         f64 qb[LOB_N_ACTIONS];
-        q_values(P, S.theta_b + (P.theta_private ? (size_t)b * (size_t)P.M : 0), S.theta_b_nz + nz_off, L.vars[w][src], zero,
-                 L.rnd, L.act_terms, L.vals[w], lane, qb);
+        if (reuse)
+            q_values(P, S.theta_b, S.theta_b_nz, L.vars[w][src], zero, L.rnd, L.act_terms, L.vals[w], lane, qb, 2, &my_vd_b, L.newf[1]);
+        else
+            q_values(P, S.theta_b + (P.theta_private ? (size_t)b * (size_t)P.M : 0), S.theta_b_nz + nz_off, L.vars[w][src], zero,
+                     L.rnd, L.act_terms, L.vals[w], lane, qb);
         if (lane < LOB_N_ACTIONS) S.qs_last_b[(size_t)b * LOB_N_ACTIONS + lane] = qb[lane];
 #pragma unroll
         for (int a = 0; a < LOB_N_ACTIONS; a++) qs[a] = (qs[a] + qb[a]) / 2.0;
@@ -365,7 +372,10 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
                                                           int b0, int nb, int par) {
     __shared__ LearnLds L;
     // this step's update appends to nz_new[par]; the list act reads is nz_new[par ^ 1]
-    if (blockIdx.x == 0 && threadIdx.x < LOB_NZ_WORDS) S.nz_new[par * LOB_NZ_WORDS + threadIdx.x] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < LOB_NZ_WORDS) {
+        S.nz_new[par * LOB_NZ_WORDS + threadIdx.x] = 0;
+        S.nz_new[(2 + par) * LOB_NZ_WORDS + threadIdx.x] = 0;  // theta_b's (double Q)
+    }
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int t = __builtin_amdgcn_readfirstlane(blockIdx.x * LOB_WAVES_PER_BLOCK + w);
     const int b = b0 + t;
@@ -545,8 +555,10 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
     if (ALGO == LOB_ALGO_DOUBLE_Q) {
         // DoubleQLearn::UpdateWeights (agent.cpp:329-353)
         f64 qb_to[LOB_N_ACTIONS];
+        uint32_t my_vd_b = 0;
         q_values(P, S.theta_b + (P.theta_private ? (size_t)b * (size_t)P.M : 0), S.theta_b_nz + nz_off, vars_to, false, L.rnd,
-                 L.act_terms, L.vals[w], lane, qb_to);
+                 L.act_terms, L.vals[w], lane, qb_to, 1, &my_vd_b);
+        S.verdict_b[(size_t)b * 64 + lane] = (uint16_t)my_vd_b;
         // the coin: unif_dist(gen) > 0.5 on the agent's own std::mt19937_64
         u64* mt = S.mt_state + (size_t)b * LOB_MT_N;
         int mi = S.mt_idx[b];
@@ -624,8 +636,8 @@ __global__ void __launch_bounds__(LOB_BLOCK) update_kernel(DevParams P, DevState
             const uint32_t bit = LOB_NZ_BIT(f[it]);
             if (!(word[it] & bit)) {  // monotone: set once, then a plain L2 hit
                 const uint32_t old = atomicOr(&nz[LOB_NZ_WORD(f[it])], bit);
-                if (!(old & bit) && !P.theta_private && h.stepped != 2) {  // this lane flipped it: tell the next act_kernel
-                    i32* nz_new = S.nz_new + par * LOB_NZ_WORDS;
+                if (!(old & bit) && !P.theta_private) {  // this lane flipped it: tell the next act_kernel
+                    i32* nz_new = S.nz_new + ((h.stepped == 2 ? 2 : 0) + par) * LOB_NZ_WORDS;
                     atomicAdd(&nz_new[0], 1);
                     atomicOr((uint32_t*)&nz_new[LOB_NZ_FILTER + (LOB_NZ_WORD(f[it]) & (LOB_NZ_FILTER - 1))], bit);  // keyed like the map
                 }
@@ -699,8 +711,8 @@ __global__ void __launch_bounds__(LOB_BLOCK) accumulate_kernel(DevParams P, DevS
                 const uint32_t bit = LOB_NZ_BIT(f);
                 if (!(nz[LOB_NZ_WORD(f)] & bit)) {
                     const uint32_t old = atomicOr(&nz[LOB_NZ_WORD(f)], bit);
-                    if (!(old & bit) && !target) {
-                        i32* nz_new = S.nz_new + par * LOB_NZ_WORDS;
+                    if (!(old & bit)) {
+                        i32* nz_new = S.nz_new + (2 * target + par) * LOB_NZ_WORDS;
                         atomicAdd(&nz_new[0], 1);
                         atomicOr((uint32_t*)&nz_new[LOB_NZ_FILTER + (LOB_NZ_WORD(f) & (LOB_NZ_FILTER - 1))], bit);
                     }
@@ -733,8 +745,8 @@ __global__ void __launch_bounds__(256) apply_kernel(DevParams P, DevState S, int
             const uint32_t bit = LOB_NZ_BIT(f);
             if (!(nz[LOB_NZ_WORD(f)] & bit)) {
                 const uint32_t old = atomicOr(&nz[LOB_NZ_WORD(f)], bit);
-                if (!(old & bit) && !t) {  // tell the next act_kernel (verdict carry-over)
-                    i32* nz_new = S.nz_new + par * LOB_NZ_WORDS;
+                if (!(old & bit)) {  // tell the next act_kernel (verdict carry-over)
+                    i32* nz_new = S.nz_new + (2 * t + par) * LOB_NZ_WORDS;
                     atomicAdd(&nz_new[0], 1);
                     atomicOr((uint32_t*)&nz_new[LOB_NZ_FILTER + (LOB_NZ_WORD(f) & (LOB_NZ_FILTER - 1))], bit);
                 }

@@ -204,7 +204,8 @@ struct DevState {
     // weight (9 bits per tiling); act(t+1) evaluates the same state and reuses them instead of 576
     // bitmap look-ups, OR-ed with a small filter of the bits the update in between newly set.
     uint16_t* verdict;   // [B][LOB_VD_STRIDE] u16: [2 groups][32 tilings], then epoch (2 x u16), slot, valid
-    i32* nz_new;         // [2 parities][LOB_NZ_WORDS]: count + filter of the weights whose bit flipped 0 -> 1 in an update
+    uint16_t* verdict_b; // [B][64]: the same for theta_b (double Q; shares the tag of `verdict`)
+    i32* nz_new;         // [2 targets: theta, theta_b][2 parities][LOB_NZ_WORDS]: count + filter of the map bits an update set for the first time
     i32* nz_epoch;       // [1] bumped whenever theta / the bitmap change outside update_kernel
     uint32_t* theta_nz;  // bitmap, bit i set once theta[i] has ever been written: clear bit => theta[i] == +0.0
     f64* theta_sync;  // [M] (multi-GPU) or null

@@ -321,7 +321,8 @@ def test_verdict_carry_over_is_invalidated(algo):
     np.testing.assert_allclose(eng.theta(), orc.theta(), rtol=1e-9, atol=1e-12)
 
 
-def test_verdict_carry_over_on_off_identical(monkeypatch):
+@pytest.mark.parametrize("algo", [abi.ALGO_QLAMBDA, abi.ALGO_DOUBLE_Q])
+def test_verdict_carry_over_on_off_identical(monkeypatch, algo):
     """Same run with the carry-over switched off (LOB_NO_CARRY=1, read by lob_create): identical
     books, actions and weights, also across evaluation steps in the middle of training (a
     sequence the reference never produces, so there is no oracle for it)."""
@@ -329,7 +330,7 @@ def test_verdict_carry_over_on_off_identical(monkeypatch):
     out = []
     for off in ("1", "0"):
         monkeypatch.setenv("LOB_NO_CARRY", off)
-        p, g, rec, eng, orc = make(depth=5, n_events=500, B=B, algo=abi.ALGO_QLAMBDA, theta_mode=abi.THETA_SHARED, mem=1 << 13)
+        p, g, rec, eng, orc = make(depth=5, n_events=500, B=B, algo=algo, theta_mode=abi.THETA_SHARED, mem=1 << 13)
         orc.close()
         eng.reset()
         trail = []
