@@ -134,7 +134,13 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
     dist = torch = None
-    if world > 1:
+    force_dist = os.environ.get("LOB_FORCE_DIST") == "1"   # run the N > 1 code path with one rank (1-GPU boxes)
+    if force_dist and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29543")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force_dist:
         # torch first: it brings its own HIP runtime and must be the one liblob_engine.so binds to
         import torch
         import torch.distributed as dist
@@ -175,14 +181,14 @@ def main():
     reset_ms = (time.perf_counter() - t_reset) * 1e3
 
     from rl_markets_amd.parallel import EngineBackend, ShardedLearner
-    learner = ShardedLearner(EngineBackend(eng, torch, "cuda:%d" % local_rank), dist, sync_every=SYNC_EVERY)
+    learner = ShardedLearner(EngineBackend(eng, torch, "cuda:%d" % local_rank), dist, sync_every=SYNC_EVERY, single_rank_sync=force_dist)
 
     def run(n_steps, first):
         learner.run(n_steps)
 
     def barrier():
         eng.sync()
-        if world > 1:
+        if world > 1 or force_dist:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -214,7 +220,7 @@ def main():
     books = eng.get_books(0, min(args.books, 4096))
     n_live = float(sum(b.n_traces for b in books)) / len(books)
 
-    if world > 1:
+    if world > 1 or force_dist:
         t = torch.tensor([elapsed, float(steps_done), float(events_done)], dtype=torch.float64, device="cuda:%d" % local_rank)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -274,17 +280,33 @@ def main():
                                                                    args.memory_size),
                 "books_per_gpu": args.books, "depth": args.depth, "events_per_book": g.n_events,
                 "events_per_step": round(eps, 4), "live_traces_per_book": round(n_live, 1),
-                "env_steps": steps_done, "reset_ms_per_episode": round(reset_ms, 2), "sync_every": SYNC_EVERY if world > 1 else None,
+                "env_steps": steps_done, "reset_ms_per_episode": round(reset_ms, 2), "sync_every": SYNC_EVERY if (world > 1 or force_dist) else None,
                 "parallelism": "%d book shard(s), dense RCCL all-reduce of delta-theta" % world if world > 1 else "1 shard",
             },
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
-    if world > 1:
+        result = json.dumps(out)
+    if world > 1 or force_dist:
+        try:
+            ctypes.CDLL(None).fflush(None)   # every rank: whatever RCCL buffered on stdout goes out before the barrier
+        except OSError:
+            pass
+        sys.stdout.flush()
         dist.barrier()
         dist.destroy_process_group()
     eng.close()
+    if rank == 0:
+        # last, after RCCL is torn down (it prints a version banner on stdout): the JSON line is the
+        # final line of output
+        # (RCCL writes it through C stdio, which is block-buffered on a pipe and would otherwise be
+        # flushed at process exit, after this line)
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        sys.stdout.flush()
+        print(result, flush=True)
 
 
 if __name__ == "__main__":

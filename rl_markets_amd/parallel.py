@@ -25,9 +25,12 @@ def shard_books(total_books, world_size, rank):
 
 
 class ShardedLearner:
-    def __init__(self, backend, dist=None, sync_every=64):
+    def __init__(self, backend, dist=None, sync_every=64, single_rank_sync=False):
+        """`single_rank_sync` keeps the exchange on even with one rank (a 1-GPU box can then run the
+        whole multi-GPU code path of bench.py: delta kernels, staging, RCCL all-reduce)."""
         self.backend = backend
-        self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size() > 1) else None
+        self.dist = dist if (dist is not None and dist.is_initialized() and
+                             (dist.get_world_size() > 1 or single_rank_sync)) else None
         self.sync_every = int(sync_every)
         self.steps = 0
         self.n_syncs = 0

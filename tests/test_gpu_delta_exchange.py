@@ -108,3 +108,17 @@ if __name__ == "__main__":
     from tests import oracle_lib as ol
     main()
     print("DELTA-EXCHANGE-OK")
+
+
+def test_bench_multi_gpu_code_path_on_one_rank():
+    """bench.py with LOB_FORCE_DIST=1: the N > 1 code path (torch first, RCCL process group, delta
+    kernels, staged all-reduce every 64 steps, max/sum reductions of the timings) on a single rank."""
+    import json
+    env = dict(os.environ, LOB_FORCE_DIST="1", MASTER_PORT="29547")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--books", "2048", "--steps", "130", "--warmup", "10",
+                          "--no-cpu-baseline"], capture_output=True, text=True, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    d = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["config"]["sync_every"] == 64 and d["value"] > 0
+    ks = d["roofline"]["all_kernels_avg_ms"]
+    assert "delta_begin_kernel" in ks and "delta_apply_kernel" in ks
