@@ -489,11 +489,13 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
             if (lane == k0 + 2 * u + 1) my_mask = (uint32_t)(m >> 32);
         }
     }
+    CbPending pend;
+    pend.active = false;
     if (lane < n_old) {
         tr_alive[my_slot] = my_mask;
         if (combine && my_mask) {  // the generation keeps live tiles: make sure its (identity, mask) has a slot
             const int4 sg = *reinterpret_cast<const int4*>(tr_sig + my_slot * 4);
-            cb_claim(S, sg.x, sg.y, sg.z, sg.w, my_mask, b * G + my_slot);
+            cb_claim_issue(S, pend, sg.x, sg.y, sg.z, sg.w, my_mask, b * G + my_slot);
         }
     }
     // new generation: the chosen action's tiles, minus those a later action
@@ -522,13 +524,15 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
             tr_alive[nh] = (uint32_t)m;
             hp->tr_head = nh;
             hp->tr_n = n_old + 1;
+        }
+        if (lane == 63) {  // n_old <= 63: this lane has no old generation to claim for
             if (combine) {
                 // identity of the generation: the quantised group-0 coordinates + the action fix all 32 tiles
                 const int q0 = zero_last ? 0 : tile_quant(vars_from[0]), q1 = zero_last ? 0 : tile_quant(vars_from[1]),
                           q2 = zero_last ? 0 : tile_quant(vars_from[2]);
                 const int code = action | (zero_last ? 256 : 0);
                 *reinterpret_cast<int4*>(tr_sig + nh * 4) = make_int4(q0, q1, q2, code);
-                if ((uint32_t)m) cb_claim(S, q0, q1, q2, code, (uint32_t)m, b * G + nh);
+                if ((uint32_t)m) cb_claim_issue(S, pend, q0, q1, q2, code, (uint32_t)m, b * G + nh);
             }
         }
     }
@@ -589,6 +593,7 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
         hp->upd = P.alpha * delta;
         hp->rng_ctr = g.ctr;
     }
+    cb_claim_finish(S, pend);  // the CAS was issued before Q(s', .): its answer has long arrived
 }
 
 // Agent::updateQ (agent.cpp:137-142): theta[f] += (alpha*delta / N_TILINGS) * e[f]

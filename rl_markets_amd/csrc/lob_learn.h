@@ -117,20 +117,36 @@ __device__ inline u64 cb_hash(int q0, int q1, int q2, int code, uint32_t mask) {
 }
 // One lane claims a slot for (signature, mask) unless somebody already has: the identity is written
 // by the winner only and read by later kernels only, so no cross-wave publication is needed here.
-__device__ inline void cb_claim(const DevState& S, int q0, int q1, int q2, int code, uint32_t mask, int src) {
-    const u64 h = cb_hash(q0, q1, q2, code, mask);
-    uint32_t s = (uint32_t)h & (uint32_t)(S.cb_slots - 1);
+// The claim is split in two so that the CAS round trip overlaps the Q(s', .) evaluation:
+// cb_claim_issue fires the first probe's CAS, cb_claim_finish (much later) looks at the answer,
+// writes the identity if it won, and only then walks on along the probe sequence if it has to.
+struct CbPending {
+    u64 h, old;
+    uint32_t s, mask;
+    int q0, q1, q2, code, src;
+    bool active;
+};
+__device__ inline void cb_claim_issue(const DevState& S, CbPending& c, int q0, int q1, int q2, int code, uint32_t mask, int src) {
+    c.q0 = q0; c.q1 = q1; c.q2 = q2; c.code = code; c.mask = mask; c.src = src; c.active = true;
+    c.h = cb_hash(q0, q1, q2, code, mask);
+    c.s = (uint32_t)c.h & (uint32_t)(S.cb_slots - 1);
+    c.old = atomicCAS((unsigned long long*)&S.cb_key[c.s], (unsigned long long)LOB_CB_EMPTY, (unsigned long long)c.h);
+}
+__device__ inline void cb_claim_finish(const DevState& S, const CbPending& c) {
+    if (!c.active) return;
+    u64 old = c.old;
+    uint32_t s = c.s;
     for (int probe = 0; probe < LOB_CB_PROBES; probe++) {
-        const u64 old = atomicCAS((unsigned long long*)&S.cb_key[s], (unsigned long long)LOB_CB_EMPTY, (unsigned long long)h);
         if (old == LOB_CB_EMPTY) {
             i32* id = S.cb_ident + (size_t)s * 8;
-            id[0] = q0; id[1] = q1; id[2] = q2; id[3] = code; id[4] = (i32)mask; id[5] = src;
+            id[0] = c.q0; id[1] = c.q1; id[2] = c.q2; id[3] = c.code; id[4] = (i32)c.mask; id[5] = c.src;
             const int pos = atomicAdd(S.cb_count, 1);
             S.cb_list[pos] = (i32)s;  // pos < cb_slots: every slot is listed at most once
             return;
         }
-        if (old == h) return;
+        if (old == c.h) return;
         s = (s + 1) & (uint32_t)(S.cb_slots - 1);
+        old = atomicCAS((unsigned long long*)&S.cb_key[s], (unsigned long long)LOB_CB_EMPTY, (unsigned long long)c.h);
     }
 }
 
