@@ -1,3 +1,4 @@
+"""Debugging aid (test infrastructure: it drives the oracle beside the engine); run from the repository root."""
 import sys
 sys.path.insert(0, '.')
 import numpy as np
