@@ -253,7 +253,7 @@ def main():
                         "avg_launch_ms": round(ktimes[dom]["avg_ms"], 4),
                         "all_kernels_avg_ms": {k: round(v["avg_ms"], 4) for k, v in ktimes.items()}}
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only (the contract); N > 1 runs report null
             try:
                 cpu = cpu_baseline()
             except Exception as ex:  # the baseline is reported, never required
