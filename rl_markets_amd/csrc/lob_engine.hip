@@ -213,7 +213,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     lobh::TickTable tt;
     lobh::build_tick_table(p->market, tt);
     P.n_bands = tt.n;
-    for (int i = 0; i < LOB_MAX_BANDS; i++) { P.band_lb[i] = tt.lb[i]; P.band_tick[i] = tt.tick[i]; P.band_cum[i] = tt.cum[i]; }
+    for (int i = 0; i < LOB_MAX_BANDS; i++) { P.band_lb[i] = tt.lb[i]; P.band_tick[i] = tt.tick[i]; P.band_cum[i] = tt.cum[i]; P.band_pt[i] = tt.pt[i]; P.band_pp[i] = tt.pp[i]; }
     P.open_ms = p->market.open_ms; P.close_ms = p->market.close_ms;
     P.order_size = p->order_size; P.reward_measure = p->reward_measure;
     P.pos_lb = p->pos_lb; P.pos_ub = p->pos_ub;
@@ -468,7 +468,10 @@ int lob_reset(lob_engine* e) {
     { int rc = finalize_episode(e); if (rc) return rc; }
     {
         TimedLaunch t(e, "reset_kernel");
-        hipLaunchKernelGGL(reset_kernel, dim3(grid_lanes(e->B)), dim3(256), 0, e->stream, (const DevParams*)e->P_dev, e->S);
+        static const int rb = getenv("LOB_RESET_LANES") ? atoi(getenv("LOB_RESET_LANES")) : 64;  // experiment switch
+        if (rb == 32) hipLaunchKernelGGL(reset_kernel<32>, dim3((e->B + 31) / 32), dim3(32), 0, e->stream, (const DevParams*)e->P_dev, e->S);
+        else if (rb == 16) hipLaunchKernelGGL(reset_kernel<16>, dim3((e->B + 15) / 16), dim3(16), 0, e->stream, (const DevParams*)e->P_dev, e->S);
+        else hipLaunchKernelGGL(reset_kernel<64>, dim3((e->B + 63) / 64), dim3(64), 0, e->stream, (const DevParams*)e->P_dev, e->S);
     }
     HIPCHK(hipGetLastError());
     e->was_reset = true;

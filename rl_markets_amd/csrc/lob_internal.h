@@ -22,6 +22,11 @@ struct TickTable {
     double lb[LOB_MAX_BANDS];
     double tick[LOB_MAX_BANDS];
     int64_t cum[LOB_MAX_BANDS];  // tts_ keys: cumulative ticks at each band's lower bound
+    // What the reference's loops have accumulated when they REACH band i, having walked through the
+    // full bands below it -- independent of the argument, so ToTicks / ToPrice can start at the
+    // argument's own band (one or two divisions instead of one per band below the price):
+    int pt[LOB_MAX_BANDS];       // ToTicks: `int ticks += double` over bands 0..i-1
+    double pp[LOB_MAX_BANDS];    // ToPrice: `double price +=` over bands 0..i-1
 };
 
 LOB_HD void build_tick_table(const lob_market& m, TickTable& t) {
@@ -37,6 +42,18 @@ LOB_HD void build_tick_table(const lob_market& m, TickTable& t) {
         acc = (int64_t)((double)acc + (m.band_lb[i] - m.band_lb[i - 1]) / m.band_tick[i - 1]);
         t.cum[i] = acc;
     }
+    t.pt[0] = 0;
+    t.pp[0] = 0.0;
+    for (int i = 1; i < LOB_MAX_BANDS; i++) {
+        if (i < m.n_bands) {
+            // the loop bodies of to_ticks_t / to_price_t for a full band i-1 (ub = next lower bound)
+            t.pt[i] = (int)((double)t.pt[i - 1] + (t.lb[i] - t.lb[i - 1]) / t.tick[i - 1]);
+            t.pp[i] = t.pp[i - 1] + ((double)t.cum[i] - (double)t.cum[i - 1]) * t.tick[i - 1];
+        } else {
+            t.pt[i] = t.pt[i - 1];
+            t.pp[i] = t.pp[i - 1];
+        }
+    }
 }
 
 template <class TT> LOB_HD double tick_size_t(const TT& t, double price) {
@@ -48,9 +65,16 @@ template <class TT> LOB_HD double tick_size_t(const TT& t, double price) {
 }
 
 template <class TT> LOB_HD int to_ticks_t(const TT& t, double price) {
-    int ticks = 0;
-    const double half = tick_size_t(t, price) / 2.0;
-    for (int i = 0; i < t.n; i++) {
+    // i0: the last band whose lower bound is <= price.  Every band below it is a full band for this
+    // price (the loop condition holds and ub = the next lower bound), so the loop can start at i0
+    // with the prefix it would have accumulated; bands i0, i0 + 1, ... then run exactly as written
+    // in the reference (src/market/market.cpp:78-102).  A NaN price gives i0 = 0 and breaks at once.
+    int i0 = 0;
+    for (int i = 1; i < t.n; i++)
+        if (t.lb[i] <= price) i0 = i;
+    const double half = t.tick[i0] / 2.0;  // tick_size(price) / 2
+    int ticks = t.pt[i0];
+    for (int i = i0; i < t.n; i++) {
         const double lb = t.lb[i], tk = t.tick[i];
         if (!(price + tk / 2.0 > lb)) break;
         double ub;
@@ -62,8 +86,12 @@ template <class TT> LOB_HD int to_ticks_t(const TT& t, double price) {
 }
 
 template <class TT> LOB_HD double to_price_t(const TT& t, int ticks) {
-    double price = 0.0;
-    for (int i = 0; i < t.n; i++) {
+    // same idea: bands whose upper tick count is <= ticks are full, start after them
+    int i0 = 0;
+    for (int i = 1; i < t.n; i++)
+        if (t.cum[i] <= (int64_t)ticks) i0 = i;
+    double price = t.pp[i0];
+    for (int i = i0; i < t.n; i++) {
         if (!((int64_t)ticks > t.cum[i])) break;
         double ub;
         if (i == t.n - 1 || (int64_t)ticks < t.cum[i + 1]) ub = (double)ticks;

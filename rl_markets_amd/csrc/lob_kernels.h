@@ -20,8 +20,10 @@ struct TickView {
     const f64* lb;
     const f64* tick;
     const i64* cum;
+    const i32* pt;
+    const f64* pp;
 };
-__device__ inline TickView P_tick(const DevParams& P) { return TickView{P.n_bands, P.band_lb, P.band_tick, P.band_cum}; }
+__device__ inline TickView P_tick(const DevParams& P) { return TickView{P.n_bands, P.band_lb, P.band_tick, P.band_cum, P.band_pt, P.band_pp}; }
 
 #include "lob_env.h"
 #include "lob_learn.h"
@@ -72,12 +74,15 @@ __global__ void gen_events_kernel(lob_gen_params g, int D, int T, u64 first_book
 // whole stream once and leaves the per-event Track; the agent side of
 // Initialise is then: zero the books' agent state, jump to the end of the
 // warm-up, place the (1,1) quotes.
-__global__ void __launch_bounds__(256, 1) reset_kernel(const DevParams* __restrict__ Pp, DevState S) {
+// RB books per block (= per wave when RB <= 64): the kernel needs the whole register file of a lane,
+// so at most two waves share a SIMD; with 32 books per wave those two hide each other's latency.
+template <int RB>
+__global__ void __launch_bounds__(RB) reset_kernel(const DevParams* __restrict__ Pp, DevState S) {
     const DevParams& P = *Pp;
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= S.B) return;
     EnvCtx c(P, S, b);
-    __shared__ EnvSlot lds_env[256];
+    __shared__ EnvSlot lds_env[RB];
     EnvR& e = lds_env[threadIdx.x].e;
     env_load(S, b, e);  // position, pnl_step, quote levels etc. persist across episodes
     const i64 ev0 = e.events;

@@ -223,6 +223,8 @@ struct DevParams {
     f64 band_lb[LOB_MAX_BANDS];
     f64 band_tick[LOB_MAX_BANDS];
     i64 band_cum[LOB_MAX_BANDS];
+    f64 band_pp[LOB_MAX_BANDS];  // lobh::TickTable::pp / pt: what ToPrice / ToTicks have accumulated on reaching band i
+    i32 band_pt[LOB_MAX_BANDS];
     i64 open_ms, close_ms;
     i32 order_size, reward_measure;
     i64 pos_lb, pos_ub;
