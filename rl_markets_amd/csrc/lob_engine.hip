@@ -575,7 +575,7 @@ int lob_get_book(lob_engine* e, int32_t book, lob_book_dump* out) { return lob_g
 // books runs on the main stream after both groups have joined.
 static int run_steps(lob_engine* e, int32_t n_steps, int mode) {
     HIPCHK(hipSetDevice(e->device));
-    const int G = e->n_groups;
+    const int G = e->B >= 1024 ? e->n_groups : 1;  // small batches: one group (an empty group would be an empty launch)
     const uint32_t* rnd = (const uint32_t*)e->rnd_dev;
     for (int s = 0; s < n_steps; s++) {
         // double-buffered list of newly written weights (verdict carry-over, lob_state.h)
