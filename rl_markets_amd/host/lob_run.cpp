@@ -3,7 +3,7 @@
 // n episodes on synthetic streams, evaluate greedily, print the per-episode
 // rows of the reference's training_log (serial.cpp:81-88) for book 0.
 //
-//   lob_run -c config/example.yaml [-n books] [-e episodes] [-a sarsa|q_learn|double_q_learn] [--events N] [--depth D]
+//   lob_run -c config/engine.yaml [-n books] [-e episodes] [-a sarsa|q_learn|double_q_learn] [--events N] [--depth D]
 //           [--theta out.bin] [--profit-log profit_log.csv]
 //           [--md depth.csv --tas trades.csv | --lobster orderbook.csv message.csv LEVELS]   (a recorded day, replayed
 //            by every book from evenly spread starting records; default: synthetic streams)

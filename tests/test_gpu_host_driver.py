@@ -1,6 +1,6 @@
 """The C++ host adaptors (rl_markets_amd/host/lob_host.hpp: Config, BatchedIntraday,
 Agent, Learner with the reference's class shapes) driven through the lob_run
-executable on config/example.yaml, checked against the oracle."""
+executable on config/engine.yaml (the reference's example.yaml keys and defaults), checked against the oracle."""
 import os
 import subprocess
 
@@ -18,14 +18,14 @@ def test_lob_run_single_book_matches_oracle(tmp_path):
     exe = os.path.join(ROOT, "rl_markets_amd", "host", "lob_run")
     theta_file = str(tmp_path / "theta.bin")
     events = 500
-    out = subprocess.run([exe, "-c", os.path.join(ROOT, "config", "example.yaml"), "-a", "q_learn", "-n", "1", "-e", "1",
+    out = subprocess.run([exe, "-c", os.path.join(ROOT, "config", "engine.yaml"), "-a", "q_learn", "-n", "1", "-e", "1",
                           "--events", str(events), "--theta", theta_file], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     rows = out.stdout.strip().splitlines()
     assert rows[0] == "episode,episode_id,reward,pnl,n_steps,epsilon"
     ep, _id, reward, pnl, n_steps, eps = rows[1].split(",")
 
-    p = engine.default_params()        # == config/example.yaml
+    p = engine.default_params()        # == config/engine.yaml (the reference defaults)
     p.algo = abi.ALGO_QLAMBDA
     g = engine.default_gen_params()
     g.n_events = events
@@ -49,7 +49,7 @@ def test_lob_run_errors_like_the_reference():
     exe = os.path.join(ROOT, "rl_markets_amd", "host", "lob_run")
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 2 and "Unhandled Exception" in out.stderr
-    out = subprocess.run([exe, "-c", os.path.join(ROOT, "config", "example.yaml"), "-a", "r_learn"], capture_output=True, text=True)
+    out = subprocess.run([exe, "-c", os.path.join(ROOT, "config", "engine.yaml"), "-a", "r_learn"], capture_output=True, text=True)
     assert out.returncode == 2 and "Unknown learning algorithm" in out.stderr
 
 
@@ -59,7 +59,7 @@ def test_lob_run_backtest_profit_log(tmp_path):
     exe = os.path.join(ROOT, "rl_markets_amd", "host", "lob_run")
     log = str(tmp_path / "profit_log.csv")
     events = 400
-    out = subprocess.run([exe, "-c", os.path.join(ROOT, "config", "example.yaml"), "-a", "sarsa", "-n", "1", "-e", "1",
+    out = subprocess.run([exe, "-c", os.path.join(ROOT, "config", "engine.yaml"), "-a", "sarsa", "-n", "1", "-e", "1",
                           "--events", str(events), "--profit-log", log], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     rows = open(log).read().strip().splitlines()
@@ -102,7 +102,7 @@ def test_lob_run_on_reference_csv_pair():
     md, tas = os.path.join(gold, "q14_md.csv"), os.path.join(gold, "q14_tas.csv")
     rec = engine.convert_csv(md, tas, 2)
     n = rec.shape[1]
-    out = subprocess.run([exe, "-c", os.path.join(ROOT, "config", "example.yaml"), "-a", "sarsa", "-n", "1", "-e", "1",
+    out = subprocess.run([exe, "-c", os.path.join(ROOT, "config", "engine.yaml"), "-a", "sarsa", "-n", "1", "-e", "1",
                           "--events", str(n), "--md", md, "--tas", tas], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     ep, _id, reward, pnl, n_steps, eps = out.stdout.strip().splitlines()[1].split(",")
@@ -118,6 +118,6 @@ def test_lob_run_on_reference_csv_pair():
     assert float(reward) == pytest.approx(r["book"]["episode_reward"], rel=1e-9)
     assert float(pnl) == pytest.approx(r["book"]["episode_pnl"], rel=1e-9)
     # a missing file is an error, not a silent fall-back to synthetic data
-    bad = subprocess.run([exe, "-c", os.path.join(ROOT, "config", "example.yaml"), "--md", md, "--tas", md + ".nope"],
+    bad = subprocess.run([exe, "-c", os.path.join(ROOT, "config", "engine.yaml"), "--md", md, "--tas", md + ".nope"],
                          capture_output=True, text=True)
     assert bad.returncode == 2 and "Unhandled Exception" in bad.stderr
