@@ -228,3 +228,16 @@ def test_oracle_double_q_matches_reference(case):
     _check_sparse(o.theta(0), fx["theta_idx"], fx["theta_val"])
     _check_sparse(o.theta_b(0), fx["theta_b_idx"], fx["theta_b_val"])
     assert len(fx["theta_b_idx"]) > 100
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(ol.REF_HARNESS), "ref_tests")),
+                    reason="oracle/_ref/ref_tests not built (make -C oracle reftests, needs the reference checkout)")
+def test_reference_build_passes_the_references_own_unit_tests():
+    """oracle/_ref is only as good as its build: the reference's own test/test_{Order,Book,Market,
+    Accumulators}.cpp, compiled unmodified against the same objects through a minimal Catch stand-in
+    (oracle/ref_harness/shims/catch/catch.hpp), must all pass."""
+    import subprocess
+    out = subprocess.run([os.path.join(os.path.dirname(ol.REF_HARNESS), "ref_tests")], capture_output=True, text=True, timeout=120)
+    last = out.stdout.strip().splitlines()[-1]
+    assert out.returncode == 0 and last.startswith("mini-catch: 17 test cases") and last.endswith(" 0 failed"), out.stdout[-2000:]
+    assert int(last.split(",")[1].split()[0]) >= 281   # every REQUIRE* of the four files was reached
