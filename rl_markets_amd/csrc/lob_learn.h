@@ -38,16 +38,25 @@ __device__ inline int tile_quant(f32 x) {
 // &state_vars[0] or &state_vars[3]).
 __device__ inline u64 tile_base(const f32* v, int nf, int j, const uint32_t* rnd) {
     u64 sum = 0;
+    int base = j;  // j * (1 + 2 i), built up by adding 2 j per coordinate
     for (int i = 0; i < nf; i++) {
         // (int) floor(floats[i] * num_tilings): x86 `cvttsd2si` semantics, a NaN or out-of-range
         // state variable becomes INT_MIN (the reference feeds NaN through here, see ulb() in lob_env.h)
         const int q = tile_quant(v[i]);
-        const int base = j * (1 + 2 * i);
         int c;
-        // tiles.cpp:61-64; two's-complement wrap-around like the compiled reference when q = INT_MIN
-        if (q >= base) c = (int)((uint32_t)q - (uint32_t)((int)((uint32_t)q - (uint32_t)base) % 32));
-        else c = (int)((uint32_t)q + 1u + (uint32_t)((int)((uint32_t)base - (uint32_t)q - 1u) % 32) - 32u);
+        // tiles.cpp:61-64:  q >= base: q - ((q - base) % 32);  else: q + 1 + ((base - q - 1) % 32) - 32.
+        // Without overflow both branches are base + 32 floor((q - base) / 32) = base + ((q - base) & ~31)
+        // (write base - q - 1 = 32 m + r in the second).  base <= 31 * 25, so the subtractions can only
+        // overflow for q within 1024 of INT_MIN -- in practice q == INT_MIN, a NaN variable -- and there
+        // the compiled reference wraps (two's complement) and takes a signed remainder: spelt out.
+        if (__builtin_expect(q < (int)0x80000400, 0)) {
+            if (q >= base) c = (int)((uint32_t)q - (uint32_t)((int)((uint32_t)q - (uint32_t)base) % 32));
+            else c = (int)((uint32_t)q + 1u + (uint32_t)((int)((uint32_t)base - (uint32_t)q - 1u) % 32) - 32u);
+        } else {
+            c = base + ((q - base) & ~31);
+        }
         sum += (u64)rnd[(c + 449 * i) & 2047];
+        base += 2 * j;
     }
     sum += (u64)rnd[(j + 449 * nf) & 2047];
     return sum;
