@@ -336,11 +336,13 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
         make_rndseq(rnd);
         // (reduced mod M: hash_UNH's single final reduction distributes over the sum)
         uint32_t* terms = rnd + 2048;
+        std::vector<uint32_t> raw(rnd, rnd + 2048);  // the action terms below index the unreduced table
         for (int g = 0; g < 3; g++) {
             const int nf = g == 0 ? 3 : (g == 1 ? P.V - 3 : P.V);
             for (int a = 0; a < LOB_N_ACTIONS; a++)
-                terms[g * LOB_N_ACTIONS + a] = (uint32_t)((uint64_t)rnd[((g * LOB_N_ACTIONS + a) + 449 * (nf + 1)) & 2047] % (uint64_t)P.M);
+                terms[g * LOB_N_ACTIONS + a] = (uint32_t)((uint64_t)raw[((g * LOB_N_ACTIONS + a) + 449 * (nf + 1)) & 2047] % (uint64_t)P.M);
         }
+        for (int k = 0; k < 2048; k++) rnd[k] = (uint32_t)((uint64_t)rnd[k] % (uint64_t)P.M);  // the device only ever sums the table mod M
         HIPCHK(hipMemcpyAsync(e->rnd_dev, rnd, sizeof rnd, hipMemcpyHostToDevice, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
     }

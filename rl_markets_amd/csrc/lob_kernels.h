@@ -248,7 +248,7 @@ __global__ void __launch_bounds__(256) clear_inventory_kernel(const DevParams* _
 // ---------------------------------------------------------------------------
 // Shared LDS image of a learner block.
 struct LearnLds {
-    uint32_t rnd[2048];                                   // hash_UNH table
+    uint32_t rnd[2048];                                   // hash_UNH table, every entry reduced mod M
     uint32_t act_terms[32];                               // trailing-coordinate terms [group][action] mod M (27 used)
     f64 vals[LOB_WAVES_PER_BLOCK][LOB_HSLOTS];      // 4 KB per wave: one group's gathered theta (9 x 33 f64) / trace hash set (aliased)
     f32 vars[LOB_WAVES_PER_BLOCK][3][16];
@@ -405,7 +405,7 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
     const int j = lane & 31, half = lane >> 5;
     i32 F[5];
     {
-        const uint32_t base = zero_last ? 0 : tile_base_m(P, vars_from, 3, j, L.rnd);
+        const uint32_t base = zero_last ? 0 : tile_base_wave<0>((uint32_t)P.M, tile_quant(vars_from[lane & 15]), 3, j, L.rnd);
 #pragma unroll
         for (int k = 0; k < 5; k++) {
             const int a = half + 2 * k;
@@ -803,7 +803,7 @@ __global__ void __launch_bounds__(LOB_BLOCK) features_kernel(DevParams P, const 
             const int g = p >> 5, j = p & 31;
             const int nf = g == 0 ? 3 : (g == 1 ? P.V - 3 : P.V);
             const f32* v = g == 1 ? L.vars[w][0] + 3 : L.vars[w][0];
-            const uint32_t base = tile_base_m(P, v, nf, j, L.rnd);
+            const uint32_t base = tile_base_m((uint32_t)P.M, v, nf, j, L.rnd);
             for (int a = 0; a < LOB_N_ACTIONS; a++)
                 out_idx[((size_t)s * LOB_N_ACTIONS + a) * 96 + p] = tile_index(base, L.act_terms[g * LOB_N_ACTIONS + a], (uint32_t)P.M);
         }

@@ -16,13 +16,14 @@
 #define LOB_QSTRIDE 33  // 32 tiles of one group + 1 pad double: lanes a=0..8 read column i without bank conflicts
 #define LOB_HSLOTS 512  // per-wave LDS hash map (64-bit slots: tile index | rank) of the 288 "current" tiles
 
-// S % M for S < 2^37, M < 2^31 through a double reciprocal (+-1 fix-up).
-__device__ inline i32 mod_m(u64 s, i64 M, f64 inv_M) {
-    i64 q = (i64)((f64)s * inv_M);
-    i64 r = (i64)s - q * M;
-    if (r < 0) r += M;
-    if (r >= M) r -= M;
-    return (i32)r;
+// The hash of tiles.cpp:152-168 is (sum of table terms) mod M.  The table is stored already reduced
+// mod M (lob_engine.hip), and the running sum is kept reduced: s, x < M < 2^31, so s + x fits 32 bits
+// and one conditional subtraction (min with the wrapped difference) restores s < M.  Same residue as
+// reducing the 64-bit sum once, no 64-bit arithmetic and no division on the device.
+__device__ inline uint32_t mod_add(uint32_t s, uint32_t x, uint32_t M) {
+    s += x;
+    const uint32_t d = s - M;  // wraps to >= 2^31 when s < M
+    return d < s ? d : s;
 }
 
 // (int) floor(x * num_tilings) with x86 `cvttsd2si` semantics (NaN / out of range -> INT_MIN), the
@@ -32,38 +33,45 @@ __device__ inline int tile_quant(f32 x) {
     return (fq >= -2147483648.0f && fq < 2147483648.0f) ? (int)fq : (int)0x80000000;
 }
 
-// Sum of the table terms of tiling j of group g that do not depend on the
-// action: the nf float coordinates and the tiling index (tiles.cpp:50-70).
-// `v` = the group's float sub-array (State::populateFeatures passes
-// &state_vars[0] or &state_vars[3]).
-__device__ inline u64 tile_base(const f32* v, int nf, int j, const uint32_t* rnd) {
-    u64 sum = 0;
+// Coordinate of quantised value q in the tiling whose offset for this variable is `base`
+// (tiles.cpp:61-64):  q >= base: q - ((q - base) % 32);  else: q + 1 + ((base - q - 1) % 32) - 32.
+// Without overflow both branches are base + 32 floor((q - base) / 32) = base + ((q - base) & ~31)
+// (write base - q - 1 = 32 m + r in the second).  base <= 31 * 25, so the subtractions can only
+// overflow for q within 1024 of INT_MIN -- in practice q == INT_MIN, a NaN variable -- and there the
+// compiled reference wraps (two's complement) and takes a signed remainder: spelt out.
+__device__ inline int tile_coord(int q, int base) {
+    if (__builtin_expect(q < (int)0x80000400, 0)) {
+        if (q >= base) return (int)((uint32_t)q - (uint32_t)((int)((uint32_t)q - (uint32_t)base) % 32));
+        return (int)((uint32_t)q + 1u + (uint32_t)((int)((uint32_t)base - (uint32_t)q - 1u) % 32) - 32u);
+    }
+    return base + ((q - base) & ~31);
+}
+
+// Reduced sum of the table terms of tiling j that do not depend on the action: the nf float
+// coordinates and the tiling index (tiles.cpp:50-70).  `v` = the group's float sub-array
+// (State::populateFeatures passes &state_vars[0] or &state_vars[3]); `rndM` = the table mod M.
+// General form (any lane, any group): used where speed does not matter.
+__device__ inline uint32_t tile_base_m(uint32_t M, const f32* v, int nf, int j, const uint32_t* rndM) {
+    uint32_t sum = 0;
     int base = j;  // j * (1 + 2 i), built up by adding 2 j per coordinate
     for (int i = 0; i < nf; i++) {
-        // (int) floor(floats[i] * num_tilings): x86 `cvttsd2si` semantics, a NaN or out-of-range
-        // state variable becomes INT_MIN (the reference feeds NaN through here, see ulb() in lob_env.h)
-        const int q = tile_quant(v[i]);
-        int c;
-        // tiles.cpp:61-64:  q >= base: q - ((q - base) % 32);  else: q + 1 + ((base - q - 1) % 32) - 32.
-        // Without overflow both branches are base + 32 floor((q - base) / 32) = base + ((q - base) & ~31)
-        // (write base - q - 1 = 32 m + r in the second).  base <= 31 * 25, so the subtractions can only
-        // overflow for q within 1024 of INT_MIN -- in practice q == INT_MIN, a NaN variable -- and there
-        // the compiled reference wraps (two's complement) and takes a signed remainder: spelt out.
-        if (__builtin_expect(q < (int)0x80000400, 0)) {
-            if (q >= base) c = (int)((uint32_t)q - (uint32_t)((int)((uint32_t)q - (uint32_t)base) % 32));
-            else c = (int)((uint32_t)q + 1u + (uint32_t)((int)((uint32_t)base - (uint32_t)q - 1u) % 32) - 32u);
-        } else {
-            c = base + ((q - base) & ~31);
-        }
-        sum += (u64)rnd[(c + 449 * i) & 2047];
+        sum = mod_add(sum, rndM[(tile_coord(tile_quant(v[i]), base) + 449 * i) & 2047], M);
         base += 2 * j;
     }
-    sum += (u64)rnd[(j + 449 * nf) & 2047];
-    return sum;
+    return mod_add(sum, rndM[(j + 449 * nf) & 2047], M);
 }
-// table term of the trailing integer coordinate (the action code)
-__device__ inline u64 tile_action_term(int nf, int code, const uint32_t* rnd) {
-    return (u64)rnd[(code + 449 * (nf + 1)) & 2047];
+// Wave form: `qv` holds, in lane i, the quantised variable i of the state (computed once per wave);
+// the coordinates [first, first + nf) are read back as wave-uniform scalars.
+template <int FIRST>
+__device__ inline uint32_t tile_base_wave(uint32_t M, int qv, int nf, int j, const uint32_t* rndM) {
+    uint32_t sum = 0;
+    int base = j;
+    for (int i = 0; i < nf; i++) {  // nf is wave-uniform
+        const int q = __builtin_amdgcn_readlane(qv, FIRST + i);
+        sum = mod_add(sum, rndM[(tile_coord(q, base) + 449 * i) & 2047], M);
+        base += 2 * j;
+    }
+    return mod_add(sum, rndM[(j + 449 * nf) & 2047], M);
 }
 
 // ---- policy RNG (counter-based; DESIGN.md "RNG") ----------------------------
@@ -162,9 +170,6 @@ __device__ inline void cb_claim_finish(const DevState& S, const CbPending& c) {
 // (base + term) mod M with both operands already reduced: one add, one compare, one select.
 // hash_UNH sums the table terms and reduces once (tiles.cpp:165-168); reducing the
 // action-independent partial sum and the action term separately gives the same residue.
-__device__ inline uint32_t tile_base_m(const DevParams& P, const f32* v, int nf, int j, const uint32_t* rnd) {
-    return (uint32_t)mod_m(tile_base(v, nf, j, rnd), P.M, P.inv_M);
-}
 __device__ inline i32 tile_index(uint32_t base_m, uint32_t term_m, uint32_t M) {
     const uint32_t s = base_m + term_m;  // < 2^32: M < 2^31
     return (i32)(s >= M ? s - M : s);
@@ -173,6 +178,7 @@ __device__ inline i32 tile_index(uint32_t base_m, uint32_t term_m, uint32_t M) {
 // Q(s, a) for all 9 actions of one state, one wave.
 //   vars      : V floats of the state (LDS), ignored if `zero`
 //   zero      : the rl::State still holds its constructor zeros (all tiles 0)
+//   rnd       : LDS, the 2048-entry hash table reduced mod M
 //   terms     : LDS, [3][9] table terms of the trailing (action code) coordinate, reduced mod M
 //   vals      : per-wave LDS scratch [9][LOB_QSTRIDE] doubles (one tile GROUP at a time)
 //   out_q[9]  : every lane returns all nine Q values
@@ -206,8 +212,10 @@ __device__ inline void q_values(const DevParams& P, const f64* __restrict__ thet
     {
         uint32_t baseA = 0, baseB = 0;
         if (!zero) {
-            baseA = tile_base_m(P, hi ? vars + 3 : vars, hi ? P.V - 3 : 3, j, rnd);
-            baseB = tile_base_m(P, vars, P.V, j, rnd);
+            const int qv = tile_quant(vars[lane & 15]);  // lane i < V: quantised variable i (slots >= V hold 0)
+            if (hi) baseA = tile_base_wave<3>(M, qv, P.V - 3, j, rnd);
+            else baseA = tile_base_wave<0>(M, qv, 3, j, rnd);
+            baseB = tile_base_wave<0>(M, qv, P.V, j, rnd);
         }
         const uint32_t* tA = terms + (hi ? LOB_N_ACTIONS : 0);
         const uint32_t* tB = terms + 2 * LOB_N_ACTIONS + (hi ? NB : 0);
