@@ -435,3 +435,20 @@ def test_combined_update_table_overflow():
     th, oth = eng.theta(), orc.theta()
     assert np.array_equal(th != 0, oth != 0)
     np.testing.assert_allclose(th, oth, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("mem", [1, 2, 2147483647])
+def test_features_at_extreme_table_sizes(mem):
+    """The device keeps the hash sum reduced mod M in 32 bits (s, x < M, s + x < 2^32): exercise the
+    largest table lob_create accepts (2^31 - 1 weights, 17 GB) and the degenerate ones."""
+    p = engine.default_params()
+    p.memory_size = mem
+    eng = engine.Engine(p, 1)
+    rng = np.random.default_rng(3)
+    v = rng.uniform(-20, 20, size=(64, 8)).astype(np.float32)
+    got = eng.features(v)
+    want = np.zeros_like(got)
+    ol.load().oracle_tiles(mem, ol.ptr(v), 8, v.shape[0], ol.ptr(want))
+    np.testing.assert_array_equal(got, want)
+    assert got.min() >= 0 and got.max() < mem
+    eng.close()
