@@ -220,7 +220,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     P.damping_factor = p->damping_factor; P.pos_weight = p->pos_weight; P.trd_weight = p->trd_weight; P.pnl_weight = p->pnl_weight;
     P.target_price = p->target_price; P.quote_mode = p->quote_mode;
     P.ewma_alpha = 2.0 / ((double)(size_t)p->lb_rsi + 1.0);
-    P.M = p->memory_size; P.inv_M = 1.0 / (double)p->memory_size;
+    P.M = p->memory_size;
     P.w0 = p->group_weights[0]; P.w1 = p->group_weights[1]; P.w2 = p->group_weights[2];
     P.gamma = p->gamma; P.alpha = p->alpha; P.epsilon = p->epsilon;
     P.trace_rate = (float)(p->gamma * p->lambda);  // Traces::decay(float rate), quirk Q15

@@ -233,7 +233,6 @@ struct DevParams {
     f64 ewma_alpha;
     // learning
     i64 M;
-    f64 inv_M;
     f64 w0, w1, w2;
     f64 gamma, alpha, epsilon;
     f32 trace_rate;                   // (float)(gamma*lambda)
