@@ -432,7 +432,7 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
     u64* tab = reinterpret_cast<u64*>(L.vals[w]);
     constexpr u64 EMPTY = ~0ull;
     for (int i = lane; i < LOB_HSLOTS; i += 64) tab[i] = EMPTY;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int k = 0; k < 5; k++) {
@@ -449,7 +449,7 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
             }
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local");
     __builtin_amdgcn_wave_barrier();
     const int G = P.trace_gens;  // ring size, a power of two
     i32* tr_idx = S.tr_idx + (size_t)b * G * 32;
@@ -541,7 +541,7 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
             }
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local");
     __builtin_amdgcn_wave_barrier();
 
     // ---- UpdateWeights: TD error under theta_t ----
@@ -796,7 +796,7 @@ __global__ void __launch_bounds__(LOB_BLOCK) features_kernel(DevParams P, const 
     learn_lds_init(rnd_g, (const f32*)nullptr, false, L);
     if (s >= n) return;
     if (lane < 16) L.vars[w][0][lane] = lane < P.V ? vars[(size_t)s * P.V + lane] : 0.0f;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local");
     __builtin_amdgcn_wave_barrier();
     if (out_idx) {
         for (int p = lane; p < 96; p += 64) {

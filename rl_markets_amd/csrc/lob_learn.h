@@ -272,12 +272,12 @@ __device__ inline void q_values(const DevParams& P, const f64* __restrict__ thet
 #pragma unroll
         for (int a = 0; a < LOB_N_ACTIONS; a++) vals[a * LOB_QSTRIDE + j] = w * tA[a];
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local");
     __builtin_amdgcn_wave_barrier();
     if (lane < LOB_N_ACTIONS) {
         for (int i = 0; i < 32; i++) q += col[i];
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local");
     __builtin_amdgcn_wave_barrier();
     // ---- group 1: once with w1, once more with w2 (quirk Q3) ----
     if (hi) {
@@ -285,24 +285,24 @@ __device__ inline void q_values(const DevParams& P, const f64* __restrict__ thet
 #pragma unroll
         for (int a = 0; a < LOB_N_ACTIONS; a++) vals[a * LOB_QSTRIDE + j] = w * tA[a];
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local");
     __builtin_amdgcn_wave_barrier();
     if (lane < LOB_N_ACTIONS) {
         for (int i = 0; i < 32; i++) q += col[i];
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local");
     __builtin_amdgcn_wave_barrier();
     if (hi) {
         const f64 w = P.w2;
 #pragma unroll
         for (int a = 0; a < LOB_N_ACTIONS; a++) vals[a * LOB_QSTRIDE + j] = w * tA[a];
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local");
     __builtin_amdgcn_wave_barrier();
     if (lane < LOB_N_ACTIONS) {
         for (int i = 0; i < 32; i++) q += col[i];
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local");
     __builtin_amdgcn_wave_barrier();
     // ---- group 2: both halves stage their actions ----
     {
@@ -312,14 +312,14 @@ __device__ inline void q_values(const DevParams& P, const f64* __restrict__ thet
         for (int k = 0; k < NB; k++)
             if (k < 4 || !hi) vals[(a0 + k) * LOB_QSTRIDE + j] = w * tB[k];
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local");
     __builtin_amdgcn_wave_barrier();
     if (lane < LOB_N_ACTIONS) {
         for (int i = 0; i < 32; i++) q += col[i];
     }
 #pragma unroll
     for (int a = 0; a < LOB_N_ACTIONS; a++) out_q[a] = __shfl(q, a);
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local");
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -342,7 +342,7 @@ __device__ inline u64 mt64_mix(u64 xi, u64 xi1, u64 xm) {
 // afterwards): three phases, every phase reads all its inputs before writing.
 __device__ inline void mt64_twist_wave(u64* gstate, u64* lds, int lane) {
     for (int i = lane; i < LOB_MT_N; i += 64) lds[i] = gstate[i];
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local");
     __builtin_amdgcn_wave_barrier();
     u64 r[3];
 #pragma unroll
@@ -350,34 +350,34 @@ __device__ inline void mt64_twist_wave(u64* gstate, u64* lds, int lane) {
         const int i = lane + 64 * k;
         r[k] = i < LOB_MT_M ? mt64_mix(lds[i], lds[i + 1], lds[i + LOB_MT_M]) : 0;
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const int i = lane + 64 * k;
         if (i < LOB_MT_M) lds[i] = r[k];
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const int i = LOB_MT_M + lane + 64 * k;
         r[k] = i < LOB_MT_N - 1 ? mt64_mix(lds[i], lds[i + 1], lds[i - LOB_MT_M]) : 0;
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const int i = LOB_MT_M + lane + 64 * k;
         if (i < LOB_MT_N - 1) lds[i] = r[k];
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local");
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) lds[LOB_MT_N - 1] = mt64_mix(lds[LOB_MT_N - 1], lds[0], lds[LOB_MT_M - 1]);
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local");
     __builtin_amdgcn_wave_barrier();
     for (int i = lane; i < LOB_MT_N; i += 64) gstate[i] = lds[i];
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local");
     __builtin_amdgcn_wave_barrier();
 }
 __device__ inline u64 mt64_temper(u64 z) {
