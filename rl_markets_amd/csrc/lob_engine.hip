@@ -40,6 +40,8 @@ struct lob_engine {
     hipStream_t stream2 = nullptr;  // second book group of the step pipeline
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_stagger = nullptr;
     int n_groups = 1;
+    int env_lanes = 0;     // books per env_kernel wave: 0 = by batch size, or 16 / 32 / 64 (LOB_ENV_LANES, read by lob_create)
+    int reset_lanes = 64;  // books per reset_kernel wave (LOB_RESET_LANES)
     int td_parity = 0;
     std::vector<void*> allocs;
     uint32_t* rnd_dev = nullptr;
@@ -184,6 +186,21 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
         if (w < 1 || w > LOB_MAX_WINDOW) { lob_set_error("lob_create: lookbacks must be in [1,256]"); return LOB_EINVAL; }
     if (p->order_size < 1) { lob_set_error("lob_create: order_size"); return LOB_EINVAL; }
 
+    // Traces::decay(float rate), quirk Q15: eligibility by age as iterated float products; checked before
+    // any HIP resource exists
+    float trace_pow[LOB_TRACE_GENS + 1];
+    int trace_kmax = -1;
+    const float trace_rate = (float)(p->gamma * p->lambda);
+    trace_pow[0] = 1.0f;
+    for (int k = 1; k <= LOB_TRACE_GENS; k++) {
+        trace_pow[k] = trace_pow[k - 1] * trace_rate;
+        if (trace_kmax < 0 && trace_pow[k] < 0.01f) trace_kmax = k;
+    }
+    if (trace_kmax < 0 || trace_kmax > LOB_TRACE_GENS) {
+        lob_set_error("lob_create: gamma*lambda too close to 1 for the trace ring (LOB_TRACE_GENS = 64 generations, gamma*lambda <= ~0.93)");
+        return LOB_EINVAL;
+    }
+
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || device < 0 || device >= ndev) {
         lob_set_error("lob_create: no usable HIP device (the engine has no CPU fallback)");
@@ -194,16 +211,29 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     e->device = device;
     e->B = n_books;
     e->params = *p;
-    HIPCHK(hipStreamCreate(&e->stream));
-    HIPCHK(hipStreamCreate(&e->stream2));
-    HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming | hipEventDisableSystemFence));
-    HIPCHK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming | hipEventDisableSystemFence));
-    HIPCHK(hipEventCreateWithFlags(&e->ev_stagger, hipEventDisableTiming | hipEventDisableSystemFence));
+    // from here on every failure path releases what exists so far (lob_destroy copes with null members)
+#define HIPCHK_E(expr)                                                                       \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            lob_set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                \
+            lob_destroy(e);                                                                  \
+            return LOB_EHIP;                                                                 \
+        }                                                                                    \
+    } while (0)
+    HIPCHK_E(hipStreamCreate(&e->stream));
+    HIPCHK_E(hipStreamCreate(&e->stream2));
+    HIPCHK_E(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming | hipEventDisableSystemFence));
+    HIPCHK_E(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming | hipEventDisableSystemFence));
+    HIPCHK_E(hipEventCreateWithFlags(&e->ev_stagger, hipEventDisableTiming | hipEventDisableSystemFence));
     // Optional (LOB_GROUPS=2): two book groups pipelined on two streams so that the latency-bound env
     // kernel of one group runs beside a gather kernel of the other.  It paid 7 % before the market
     // track made the env kernel cheap; now one group is as fast and gives clean per-kernel timings.
     e->n_groups = 1;
     if (const char* g = getenv("LOB_GROUPS")) { int v = atoi(g); if (v >= 1 && v <= 2) e->n_groups = v; }
+    // experiment / test switches for the books-per-wave choice of the lane-per-book kernels
+    if (const char* g = getenv("LOB_ENV_LANES")) { int v = atoi(g); if (v == 16 || v == 32 || v == 64) e->env_lanes = v; }
+    if (const char* g = getenv("LOB_RESET_LANES")) { int v = atoi(g); if (v == 16 || v == 32 || v == 64) e->reset_lanes = v; }
 
     // ---- DevParams ----
     DevParams& P = e->P;
@@ -223,19 +253,10 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     P.M = p->memory_size;
     P.w0 = p->group_weights[0]; P.w1 = p->group_weights[1]; P.w2 = p->group_weights[2];
     P.gamma = p->gamma; P.alpha = p->alpha; P.epsilon = p->epsilon;
-    P.trace_rate = (float)(p->gamma * p->lambda);  // Traces::decay(float rate), quirk Q15
-    P.trace_pow[0] = 1.0f;
-    P.trace_kmax = -1;
-    for (int k = 1; k <= LOB_TRACE_GENS; k++) {
-        P.trace_pow[k] = P.trace_pow[k - 1] * P.trace_rate;
-        if (P.trace_kmax < 0 && P.trace_pow[k] < 0.01f) P.trace_kmax = k;
-    }
+    P.trace_rate = trace_rate;
+    for (int k = 0; k <= LOB_TRACE_GENS; k++) P.trace_pow[k] = trace_pow[k];
+    P.trace_kmax = trace_kmax;
     P.trace_gens = P.trace_kmax <= 32 ? 32 : LOB_TRACE_GENS;
-    if (P.trace_kmax < 0 || P.trace_kmax > LOB_TRACE_GENS) {
-        lob_set_error("lob_create: gamma*lambda too close to 1 for the trace ring (LOB_TRACE_GENS = 64 generations, gamma*lambda <= ~0.93)");
-        delete e;
-        return LOB_EINVAL;
-    }
     P.algo = p->algo; P.theta_private = p->theta_mode == LOB_THETA_PRIVATE;
     { const char* nc = getenv("LOB_NO_CARRY"); P.carry_verdicts = !(nc && nc[0] == '1'); }
     { const char* nc = getenv("LOB_NO_COMBINE"); P.combine = !P.theta_private && !(nc && nc[0] == '1'); }
@@ -323,12 +344,12 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     // the two rl::State objects start with constructor zeros (src/rl/state.cpp:10-19)
     {
         std::vector<f64> neg1(B, -1.0);
-        HIPCHK(hipMemcpyAsync(S.tp_val, neg1.data(), B * sizeof(f64), hipMemcpyHostToDevice, e->stream));
-        HIPCHK(hipStreamSynchronize(e->stream));
+        HIPCHK_E(hipMemcpyAsync(S.tp_val, neg1.data(), B * sizeof(f64), hipMemcpyHostToDevice, e->stream));
+        HIPCHK_E(hipStreamSynchronize(e->stream));
         std::vector<LHdr> hdr(B);
         memset(hdr.data(), 0, B * sizeof(LHdr));
         for (size_t b = 0; b < B; b++) hdr[b].zero_mask = 3;
-        HIPCHK(hipMemcpyAsync(S.hdr, hdr.data(), B * sizeof(LHdr), hipMemcpyHostToDevice, e->stream));
+        HIPCHK_E(hipMemcpyAsync(S.hdr, hdr.data(), B * sizeof(LHdr), hipMemcpyHostToDevice, e->stream));
         // hash table followed by the 27 trailing-coordinate (action code) terms
         // rndseq[(code + 449*(nf+1)) & 2047], code = group*9 + action (state.cpp:56-63, tiles.cpp:46,152-163)
         uint32_t rnd[2048 + 64];
@@ -343,14 +364,15 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
                 terms[g * LOB_N_ACTIONS + a] = (uint32_t)((uint64_t)raw[((g * LOB_N_ACTIONS + a) + 449 * (nf + 1)) & 2047] % (uint64_t)P.M);
         }
         for (int k = 0; k < 2048; k++) rnd[k] = (uint32_t)((uint64_t)rnd[k] % (uint64_t)P.M);  // the device only ever sums the table mod M
-        HIPCHK(hipMemcpyAsync(e->rnd_dev, rnd, sizeof rnd, hipMemcpyHostToDevice, e->stream));
-        HIPCHK(hipStreamSynchronize(e->stream));
+        HIPCHK_E(hipMemcpyAsync(e->rnd_dev, rnd, sizeof rnd, hipMemcpyHostToDevice, e->stream));
+        HIPCHK_E(hipStreamSynchronize(e->stream));
     }
     if (p->algo == LOB_ALGO_DOUBLE_Q) {
         hipLaunchKernelGGL(mt_init_kernel, dim3(grid_lanes(e->B)), dim3(256), 0, e->stream, e->P, e->S);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(e->stream));
+        HIPCHK_E(hipGetLastError());
+        HIPCHK_E(hipStreamSynchronize(e->stream));
     }
+#undef HIPCHK_E
     *out = e;
     return LOB_OK;
 }
@@ -387,15 +409,27 @@ static int finalize_episode(lob_engine* e) {
 // n_rows: records to allocate (B * n_events for per-book streams, the stream length for a replayed one)
 static int set_records(lob_engine* e, int32_t n_events, size_t n_rows) {
     { int rc = finalize_episode(e); if (rc) return rc; }  // needs the old stream
+    // the old stream is gone from here on, whatever happens below: no kernel may see a freed pointer
+    e->have_events = false;
+    e->was_reset = false;
+    e->S.records = nullptr;
+    e->S.track = nullptr;
+    e->S.rec_phase = nullptr;
+    e->S.n_events = 0;
     if (e->records_dev) { hipFree(e->records_dev); e->records_dev = nullptr; }
     if (e->phase_dev) { hipFree(e->phase_dev); e->phase_dev = nullptr; }
-    e->S.rec_phase = nullptr;
+    if (e->track_dev) { hipFree(e->track_dev); e->track_dev = nullptr; }
     size_t bytes = n_rows * e->P.W * 4;
     hipError_t err = hipMalloc((void**)&e->records_dev, bytes);
-    if (err != hipSuccess) { lob_set_error("hipMalloc(records) failed"); return LOB_ENOMEM; }
-    if (e->track_dev) { hipFree(e->track_dev); e->track_dev = nullptr; }
+    if (err != hipSuccess) { e->records_dev = nullptr; lob_set_error("hipMalloc(records) failed"); return LOB_ENOMEM; }
     err = hipMalloc((void**)&e->track_dev, (size_t)e->B * n_events * sizeof(Track));
-    if (err != hipSuccess) { lob_set_error("hipMalloc(track) failed"); return LOB_ENOMEM; }
+    if (err != hipSuccess) {
+        e->track_dev = nullptr;
+        hipFree(e->records_dev);
+        e->records_dev = nullptr;
+        lob_set_error("hipMalloc(track) failed");
+        return LOB_ENOMEM;
+    }
     e->S.track = e->track_dev;
     e->S.records = e->records_dev;
     e->S.n_events = n_events;
@@ -454,7 +488,7 @@ int lob_gen_events_device(lob_engine* e, const lob_gen_params* g) {
 
 // env_kernel with 64 books per wave, or 16 when the batch is too small to give every SIMD a wave
 static void launch_env(lob_engine* e, hipStream_t st, const i32* actions, int count_updates, int b0, int nb) {
-    static const int force = getenv("LOB_ENV_LANES") ? atoi(getenv("LOB_ENV_LANES")) : 0;  // experiment switch
+    const int force = e->env_lanes;
     if (force == 32)
         hipLaunchKernelGGL(env_kernel<32>, dim3((nb + 31) / 32), dim3(32), 0, st, (const DevParams*)e->P_dev, e->S, actions, count_updates, b0, nb);
     else if (force == 16 || (force == 0 && e->B <= 16384))
@@ -470,7 +504,7 @@ int lob_reset(lob_engine* e) {
     { int rc = finalize_episode(e); if (rc) return rc; }
     {
         TimedLaunch t(e, "reset_kernel");
-        static const int rb = getenv("LOB_RESET_LANES") ? atoi(getenv("LOB_RESET_LANES")) : 64;  // experiment switch
+        const int rb = e->reset_lanes;
         if (rb == 32) hipLaunchKernelGGL(reset_kernel<32>, dim3((e->B + 31) / 32), dim3(32), 0, e->stream, (const DevParams*)e->P_dev, e->S);
         else if (rb == 16) hipLaunchKernelGGL(reset_kernel<16>, dim3((e->B + 15) / 16), dim3(16), 0, e->stream, (const DevParams*)e->P_dev, e->S);
         else hipLaunchKernelGGL(reset_kernel<64>, dim3((e->B + 63) / 64), dim3(64), 0, e->stream, (const DevParams*)e->P_dev, e->S);
@@ -707,6 +741,13 @@ int lob_theta_set(lob_engine* e, int32_t which, const double* host_in, int64_t c
     if (rc) return rc;
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipMemcpyAsync(th, host_in, (size_t)count * 8, hipMemcpyHostToDevice, e->stream));
+    if (e->S.theta_sync) {
+        // multi-GPU exchange already initialised: the loaded weights are the new common base, not a local
+        // delta (every rank loads the same checkpoint); otherwise the next all-reduce would add
+        // world_size x (loaded - sync)
+        f64* sync = e->S.theta_sync + (th == e->S.theta_b ? (size_t)e->P.M : 0);
+        HIPCHK(hipMemcpyAsync(sync, th, (size_t)count * 8, hipMemcpyDeviceToDevice, e->stream));
+    }
     hipLaunchKernelGGL(rebuild_nz_kernel, dim3(1024), dim3(256), 0, e->stream, (const f64*)th, nz, e->S.nz_epoch, e->P.M);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(e->stream));

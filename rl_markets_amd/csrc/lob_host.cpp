@@ -1,5 +1,6 @@
 // Host-only part of the C ABI (no GPU needed): parameter defaults, venue tick
 // tables, host tick maths, synthetic stream generation and stream validation.
+#include <limits.h>
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
@@ -308,6 +309,7 @@ int emit_records(const std::vector<Snap>& snaps, const std::vector<Trade>& trade
             auto it = agg.find(key);
             if (it == agg.end()) agg[key] = {t.price, t.size};
             else it->second.second += t.size;
+            if (it != agg.end() && it->second.second > INT32_MAX) { free(rec); lob_set_error("convert: aggregated trade volume outside int32"); return LOB_EDATA; }
         }
         if ((int)agg.size() > T) {
             free(rec);
@@ -341,13 +343,13 @@ int lob_convert_csv(const char* md_path, const char* tas_path, int32_t T, uint32
     std::string line;
     std::vector<std::string> c;
     std::vector<Snap> snaps;
-    int date0 = 0;
+    int date0 = 0, skipped_md = 0, skipped_tas = 0;
     std::getline(md, line);  // header
     while (std::getline(md, line)) {
         if (!line.empty() && line.back() == '\r') line.pop_back();
         if (line.empty()) continue;
         split_csv(line, c);
-        if (c.size() != 22) { lob_set_error("lob_convert_csv: depth row without 22 columns"); return LOB_EDATA; }
+        if (c.size() != 22) { skipped_md++; continue; }  // MarketDepth::_LoadRow skips rows that do not have 22 columns (basic.cpp:31-43)
         Snap s;
         int date = atoi(c[0].c_str());
         if (!date0) date0 = date;
@@ -358,8 +360,13 @@ int lob_convert_csv(const char* md_path, const char* tas_path, int32_t T, uint32
             s.ap[i] = strtof(c[2 + i].c_str(), nullptr);   // stof: float32 prices (quirk Q8)
             s.bp[i] = strtof(c[12 + i].c_str(), nullptr);
             if (s.ap[i] <= 0.0f || s.bp[i] <= 0.0f) { ok = false; break; }  // row dropped (basic.cpp:54-58)
-            s.av[i] = (int32_t)atol(c[7 + i].c_str());
-            s.bv[i] = (int32_t)atol(c[17 + i].c_str());
+            const long av = atol(c[7 + i].c_str()), bv = atol(c[17 + i].c_str());
+            if (av > INT32_MAX || bv > INT32_MAX || av < INT32_MIN || bv < INT32_MIN) {
+                lob_set_error("lob_convert_csv: level volume outside int32 (records carry 32-bit volumes)");
+                return LOB_EDATA;
+            }
+            s.av[i] = (int32_t)av;
+            s.bv[i] = (int32_t)bv;
         }
         if (ok) snaps.push_back(s);
     }
@@ -369,15 +376,22 @@ int lob_convert_csv(const char* md_path, const char* tas_path, int32_t T, uint32
         if (!line.empty() && line.back() == '\r') line.pop_back();
         if (line.empty()) continue;
         split_csv(line, c);
-        if (c.size() != 4) { lob_set_error("lob_convert_csv: trade row without 4 columns"); return LOB_EDATA; }
+        if (c.size() != 4) { skipped_tas++; continue; }  // TimeAndSales::_LoadRow (basic.cpp:138-150)
         Trade t;
         if (!parse_time(c[1], t.time)) { lob_set_error("lob_convert_csv: bad time"); return LOB_EDATA; }
         t.price = strtof(c[2].c_str(), nullptr);
         t.size = atol(c[3].c_str());
+        if (t.size > INT32_MAX) { lob_set_error("lob_convert_csv: trade size outside int32 (records carry 32-bit volumes)"); return LOB_EDATA; }
         if (t.price > 0.0f && t.size > 0) trades.push_back(t);  // basic.cpp:156-157
     }
-    std::stable_sort(trades.begin(), trades.end(), [](const Trade& a, const Trade& b) { return a.time < b.time; });
-    return emit_records(snaps, trades, 5, T, out, n);
+    // Trades are consumed in FILE order, as TimeAndSales::_LoadNext does (basic.cpp:164-181): no sort.
+    int rc = emit_records(snaps, trades, 5, T, out, n);
+    if (rc == LOB_OK && (skipped_md || skipped_tas)) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "lob_convert_csv: skipped %d depth row(s) without 22 columns and %d trade row(s) without 4 (as the reference does)", skipped_md, skipped_tas);
+        lob_set_error(buf);  // informational: the call succeeded, lob_last_error() carries the note
+    }
+    return rc;
 }
 
 int lob_convert_lobster(const char* ob_path, const char* msg_path, int32_t L, int32_t D, int32_t T, uint32_t** out, int32_t* n) {

@@ -163,8 +163,10 @@ public:
         p.lb_rsi = lb("state.lookback.rsi", 0);
         p.lb_spread = lb("policy.spread_lookback", 10);
         p.lb_pnl = lb("reward.pnl_lookback", 0);
+        // Latency::make (src/market/latency.cpp:9-22) accepts fixed / normal / lognormal and throws on anything
+        // else; the sample only feeds a variable nothing reads (base.cpp:258), so every accepted type is the same here
         std::string lt = str("market.latency.type", "fixed");
-        if (lt != "fixed") throw std::invalid_argument("latency type " + lt + " is outside the hot path (SURVEY.md row 4)");
+        if (lt != "fixed" && lt != "normal" && lt != "lognormal") throw std::invalid_argument("Unknown latency type: " + lt);
         // quirk Q5 (base.cpp:101-112): "midprice" builds MicroPrice, anything else MidPrice
         std::string tp = str("market.target_price.type", "midprice");
         p.target_price = (tp != "midprice") ? LOB_TP_MIDPRICE : LOB_TP_MICROPRICE;
@@ -182,7 +184,14 @@ public:
         p.gamma = num("learning.gamma");
         p.lambda = num("learning.lambda");
         p.alpha = num("learning.alpha_start", 0.2);
-        p.epsilon = num("policy.eps_init", 0.0);
+        // policy factory of src/main.cpp:140-165.  eps_init / eps_floor are read as float there
+        // (policy.cpp:58-67): 0.8 is 0.800000011920929 in every comparison and in the schedule.
+        std::string pt = str("policy.type", "");
+        if (pt == "greedy") p.epsilon = 0.0;
+        else if (pt == "epsilon_greedy") p.epsilon = (double)(float)num("policy.eps_init", 0.0);
+        else if (pt == "random") p.epsilon = 1.0;   // RandomPolicy::Sample = the uniform branch of EpsilonGreedy, always taken
+        else if (pt == "boltzmann") throw std::invalid_argument("policy.type boltzmann is not supported (SURVEY.md §8f N4)");
+        else throw std::runtime_error("Please specify a valid policy!");  // main.cpp:164-165
         std::string algo = str("learning.algorithm", "sarsa");
         if (algo == "sarsa") p.algo = LOB_ALGO_SARSA;
         else if (algo == "q_learn") p.algo = LOB_ALGO_QLAMBDA;
@@ -276,13 +285,15 @@ class Agent {
     BatchedIntraday& env_;
     double alpha_start_, alpha_floor_, omega_;
     double eps_init_, eps_floor_, eps_T_;
+    bool eps_schedule_;  // only EpsilonGreedy::HandleTerminal moves epsilon (policy.cpp:19,79-82)
     bool greedy_ = false;
 
 public:
     Agent(BatchedIntraday& env, const Config& c)
         : env_(env), alpha_start_(c.num("learning.alpha_start", 0.2)), alpha_floor_(c.num("learning.alpha_floor", 0.001)),
-          omega_(c.num("learning.omega", 1.0)), eps_init_(c.num("policy.eps_init", 0.0)),
-          eps_floor_(c.num("policy.eps_floor", 0.0)), eps_T_(c.num("policy.eps_T", 1.0)) {}
+          omega_(c.num("learning.omega", 1.0)), eps_init_((double)(float)c.num("policy.eps_init", 0.0)),
+          eps_floor_((double)(float)c.num("policy.eps_floor", 0.0)), eps_T_(c.num("policy.eps_T", 1.0)),  // float in main.cpp:149-150
+          eps_schedule_(c.str("policy.type", "") == "epsilon_greedy") {}
     void GoGreedy() { greedy_ = true; }
     bool greedy() const { return greedy_; }
     // Agent::HandleTerminal (agent.cpp:103-109) + EpsilonGreedy::HandleTerminal (policy.cpp:79-82)
@@ -290,9 +301,11 @@ public:
         check(lob_handle_terminal(env_.handle()), "HandleTerminal");
         double alpha = std::max(alpha_floor_, alpha_start_ * std::pow(omega_, (double)episode));
         check(lob_set_alpha(env_.handle(), alpha), "HandleTerminal");
-        double eps = eps_init_ * std::pow(eps_floor_ / eps_init_, (double)episode / eps_T_);
-        check(lob_set_epsilon(env_.handle(), eps), "HandleTerminal");
-        epsilon_ = eps;
+        if (eps_schedule_) {
+            double eps = eps_init_ * std::pow(eps_floor_ / eps_init_, (double)episode / eps_T_);
+            check(lob_set_epsilon(env_.handle(), eps), "HandleTerminal");
+            epsilon_ = eps;
+        }
     }
     double epsilon_ = -1.0;
     // Agent::write_theta (agent.cpp:176-181): raw double[MEMORY_SIZE]
