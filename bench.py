@@ -9,7 +9,11 @@ TD update).  Workload at N=1 = BASELINE.json configs[2] (C3, the configuration
 the metric is quoted on): 65 536 parallel synthetic 10-level books, Q(lambda)
 with eligibility traces, memory_size 20 M, on one MI355X.  For N>1 every rank
 owns its own 65 536-book shard (weak scaling, C4) and the shared weight vector
-is exchanged by an RCCL all-reduce of delta-theta every SYNC_EVERY steps.
+is exchanged by an RCCL all-reduce of delta-theta every SYNC_EVERY steps
+(liblob_comm.so, in place on the engine's buffer and stream; no torch in this
+process).  Without a launcher `--gpus N` starts the N ranks itself; under
+`python -m torch.distributed.run` it takes RANK / LOCAL_RANK / WORLD_SIZE from
+the environment.
 
 Prints ONE JSON line (rank 0).  `value` counts env-steps actually performed
 (device counter), inputs are generated in HBM before the timed region.
@@ -47,6 +51,8 @@ def algorithmic_bytes(kernel, depth, trades, n_vars, n_live, events_per_step):
     if kernel == "env_kernel":        # per event: track entry (96) + trade slots + the two snapshots' levels at the order
         per_event = 96 + 2 * trades * 4 + 2 * 2 * depth * 8
         return 2 * 232 + hdr + events_per_step * per_event + 2 * 96 + 3 * 4 * n_vars   # agent scalars r/w + quotes + vars out
+    if kernel == "reset_kernel":      # per event of the stream: the record in, the track entry out (events_per_step = events per book here)
+        return events_per_step * (rec + 96) + 2 * 232
     return 0
 
 
@@ -127,31 +133,35 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    from rl_markets_amd import launch
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: be one.  N ranks of this very command, one GPU each; rank 0 prints the line.
+        sys.exit(launch.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
+    rank, local_rank, world = launch.rank_env()
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world > 1:
+        sys.stderr.write("bench.py rank %d of %d on GPU %d\n" % (rank, world, local_rank))
+        sys.stderr.flush()
 
-    dist = torch = None
-    force_dist = os.environ.get("LOB_FORCE_DIST") == "1"   # run the N > 1 code path with one rank (1-GPU boxes)
-    if force_dist and world == 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29543")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-    if world > 1 or force_dist:
-        # torch first: it brings its own HIP runtime and must be the one liblob_engine.so binds to
-        import torch
-        import torch.distributed as dist
-        local_rank = local_rank % max(torch.cuda.device_count(), 1)
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-
-    import __graft_entry__ as ge
-    if not os.path.exists(os.path.join(ROOT, "rl_markets_amd", "csrc", "liblob_engine.so")):
-        ge.build()
+    libs = [os.path.join(ROOT, "rl_markets_amd", "csrc", n) for n in ("liblob_engine.so", "liblob_comm.so")]
+    if not all(os.path.exists(f) for f in libs):
+        if rank == 0:
+            import __graft_entry__ as ge
+            ge.build()
+        for _ in range(3000):                       # the other ranks wait for rank 0's build
+            if all(os.path.exists(f) for f in libs):
+                break
+            time.sleep(0.1)
     from rl_markets_amd import abi, engine
+
+    # run the N > 1 code path with one rank (1-GPU boxes): delta kernels + a one-rank RCCL all-reduce
+    force_dist = os.environ.get("LOB_FORCE_DIST") == "1" and world == 1
+    comm = None
+    if world > 1 or force_dist:
+        from rl_markets_amd.comm import MAX, SUM, RcclComm
+        rdzv = launch.rendezvous_path() if world > 1 else os.path.join(tempfile.gettempdir(), "lob_rdzv_single_%d" % os.getpid())
+        comm = RcclComm(rdzv, rank, world, local_rank)
 
     p = engine.default_params()
     p.depth, p.max_trades = args.depth, 2
@@ -175,33 +185,28 @@ def main():
         eng.load_events_shared(day, phase, g.n_events)
     else:
         eng.gen_events(g)   # synthetic streams generated directly in HBM (never timed)
-    t_reset = time.perf_counter()
+    eng.kernel_timing(True)
     eng.reset()             # Initialise(): includes the once-per-episode market pre-pass over the whole stream
     eng.sync()
-    reset_ms = (time.perf_counter() - t_reset) * 1e3
+    reset_ms, _ = eng.kernel_time_ms("reset_kernel")
+    eng.kernel_timing(False)
 
     from rl_markets_amd.parallel import EngineBackend, ShardedLearner
-    learner = ShardedLearner(EngineBackend(eng, torch, "cuda:%d" % local_rank), dist, sync_every=SYNC_EVERY, single_rank_sync=force_dist)
-
-    def run(n_steps, first):
-        learner.run(n_steps)
+    learner = ShardedLearner(EngineBackend(eng), comm, sync_every=SYNC_EVERY)
 
     def barrier():
         eng.sync()
-        if world > 1 or force_dist:
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
-        else:
-            hip_device_sync()
+        hip_device_sync()
+        if comm is not None:
+            comm.barrier()
 
-    run(args.warmup, 0)
+    learner.run(args.warmup)
     barrier()
     c0 = eng.counters()
     if not args.no_kernel_timing:
         eng.kernel_timing(True)
     t0 = time.perf_counter()
-    run(args.steps, args.warmup)
+    learner.run(args.steps)
     barrier()
     t1 = time.perf_counter()
     c1 = eng.counters()
@@ -211,8 +216,7 @@ def main():
 
     ktimes = {}
     if not args.no_kernel_timing:
-        for k in ("act_kernel", "env_kernel", "learn_kernel", "update_kernel", "accumulate_kernel", "apply_kernel",
-                  "delta_begin_kernel", "delta_apply_kernel"):
+        for k in KERNELS:
             ms, n = eng.kernel_time_ms(k)
             if n:
                 ktimes[k] = {"avg_ms": ms, "launches": n}
@@ -220,44 +224,57 @@ def main():
     books = eng.get_books(0, min(args.books, 4096))
     n_live = float(sum(b.n_traces for b in books)) / len(books)
 
-    if world > 1 or force_dist:
-        t = torch.tensor([elapsed, float(steps_done), float(events_done)], dtype=torch.float64, device="cuda:%d" % local_rank)
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = t.clone()
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        elapsed = float(tmax[0])
-        steps_done = int(tsum[1])
-        events_done = int(tsum[2])
+    if comm is not None:
+        elapsed = comm.reduce([elapsed], MAX)[0]          # the slowest rank's clock
+        steps_done, events_done = (int(v) for v in comm.reduce([steps_done, events_done], SUM))
 
+    result = None
     if rank == 0:
         eps = events_done / max(steps_done, 1)
+        steps_per_episode = max((g.n_events - 64) / max(eps, 1e-9), 1.0)   # an episode = the stream after the 64-event warm-up
+        traffic_file = {}
+        tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tf):
+            try:
+                traffic_file = json.load(open(tf))
+            except Exception:
+                traffic_file = {}
         roofline = None
         if ktimes:
-            dom = max((k for k in ktimes if k.endswith("_kernel") and not k.startswith("delta")),
-                      key=lambda k: ktimes[k]["avg_ms"])
-            per_book = algorithmic_bytes(dom, args.depth, 2, p.n_vars, n_live, eps)
-            live_books = steps_done / world / ktimes[dom]["launches"]   # books one launch of that kernel covers
-            bytes_per_launch = per_book * live_books
-            achieved = bytes_per_launch / (ktimes[dom]["avg_ms"] * 1e-3) / 1e9
-            traffic = None
-            tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(tf):
-                try:
-                    traffic = json.load(open(tf)).get(dom, {}).get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                        "algorithmic_bytes_per_book": round(per_book, 1), "books_per_launch": round(live_books, 1),
-                        "avg_launch_ms": round(ktimes[dom]["avg_ms"], 4),
-                        "all_kernels_avg_ms": {k: round(v["avg_ms"], 4) for k, v in ktimes.items()}}
+            per_kernel = {}
+            for k, v in ktimes.items():
+                if k.startswith("delta"):
+                    continue
+                per_book = algorithmic_bytes(k, args.depth, 2, p.n_vars, n_live, eps)
+                live_books = steps_done / world / max(ktimes["env_kernel"]["launches"], 1)   # books one launch covers
+                ach = per_book * live_books / (v["avg_ms"] * 1e-3) / 1e9
+                tr = traffic_file.get(k, {}).get("hbm_bytes_per_launch")
+                per_kernel[k] = {"avg_ms": round(v["avg_ms"], 4), "launches": v["launches"],
+                                 "algorithmic_bytes_per_book": round(per_book, 1), "achieved_GBps": round(ach, 1),
+                                 "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": tr,
+                                 "counter_GBps": round(tr / (v["avg_ms"] * 1e-3) / 1e9, 1) if tr else None}
+            per_kernel["reset_kernel"] = {
+                "avg_ms": round(reset_ms, 3), "launches": 1, "note": "once per episode, outside `value`; see value_amortised",
+                "algorithmic_bytes_per_book": round(algorithmic_bytes("reset_kernel", args.depth, 2, p.n_vars, 0, g.n_events), 1),
+                "achieved_GBps": round(algorithmic_bytes("reset_kernel", args.depth, 2, p.n_vars, 0, g.n_events) * args.books / (reset_ms * 1e-3) / 1e9, 1) if reset_ms else None,
+                "traffic": traffic_file.get("reset_kernel", {}).get("hbm_bytes_per_launch")}
+            dom = max((k for k in ktimes if not k.startswith("delta")), key=lambda k: ktimes[k]["avg_ms"])
+            d = per_kernel[dom]
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": d["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": d["frac"], "traffic": d["traffic"],
+                        "traffic_source": traffic_file.get("_source", "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command; static file, not measured in this run)") if d["traffic"] else None,
+                        "algorithmic_bytes_per_book": d["algorithmic_bytes_per_book"],
+                        "books_per_launch": round(steps_done / world / max(ktimes["env_kernel"]["launches"], 1), 1),
+                        "avg_launch_ms": d["avg_ms"],
+                        "all_kernels_avg_ms": {k: round(v["avg_ms"], 4) for k, v in ktimes.items()},
+                        "per_kernel": per_kernel}
         cpu = None
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only (the contract); N > 1 runs report null
             try:
                 cpu = cpu_baseline()
             except Exception as ex:  # the baseline is reported, never required
                 cpu = {"error": str(ex)}
+        ms_per_step = elapsed / args.steps * 1e3
         out = {
             "metric": "env-steps/sec (whole node) at 65 536 parallel books",
             "value": steps_done / elapsed,
@@ -265,12 +282,15 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": ms_per_step,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
+            # the same throughput with the once-per-episode lob_reset (market pre-pass) spread over the
+            # episode's steps: what a run of whole episodes sustains
+            "value_amortised": steps_done / (elapsed * (1.0 + (reset_ms / steps_per_episode) / ms_per_step)) if ms_per_step > 0 else None,
             "config": {
                 "workload": (("C5: %d books replaying one recorded %d-level stream from per-book phases, reward pnl_damped, %s, "
                               if args.replay else "C3: %d parallel synthetic %d-level books per GPU, %s with eligibility traces, ") +
@@ -280,27 +300,22 @@ def main():
                                                                    args.memory_size),
                 "books_per_gpu": args.books, "depth": args.depth, "events_per_book": g.n_events,
                 "events_per_step": round(eps, 4), "live_traces_per_book": round(n_live, 1),
-                "env_steps": steps_done, "reset_ms_per_episode": round(reset_ms, 2), "sync_every": SYNC_EVERY if (world > 1 or force_dist) else None,
-                "parallelism": "%d book shard(s), dense RCCL all-reduce of delta-theta" % world if world > 1 else "1 shard",
+                "env_steps": steps_done, "reset_ms_per_episode": round(reset_ms, 2), "steps_per_episode": round(steps_per_episode, 1),
+                "sync_every": SYNC_EVERY if comm is not None else None,
+                "parallelism": ("%d book shard(s), one process per GPU, dense RCCL all-reduce of delta-theta every %d steps" % (world, SYNC_EVERY))
+                               if comm is not None else "1 shard",
             },
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
         result = json.dumps(out)
-    if world > 1 or force_dist:
-        try:
-            ctypes.CDLL(None).fflush(None)   # every rank: whatever RCCL buffered on stdout goes out before the barrier
-        except OSError:
-            pass
-        sys.stdout.flush()
-        dist.barrier()
-        dist.destroy_process_group()
+    if comm is not None:
+        comm.barrier()
+        comm.close()
     eng.close()
     if rank == 0:
-        # last, after RCCL is torn down (it prints a version banner on stdout): the JSON line is the
-        # final line of output
-        # (RCCL writes it through C stdio, which is block-buffered on a pipe and would otherwise be
-        # flushed at process exit, after this line)
+        # last line of output, after RCCL is torn down (it may print through C stdio, which is
+        # block-buffered on a pipe): flush that first
         try:
             ctypes.CDLL(None).fflush(None)
         except OSError:
@@ -308,6 +323,9 @@ def main():
         sys.stdout.flush()
         print(result, flush=True)
 
+
+KERNELS = ("act_kernel", "env_kernel", "learn_kernel", "update_kernel", "accumulate_kernel", "apply_kernel",
+           "memo_kernel", "delta_begin_kernel", "delta_apply_kernel")
 
 if __name__ == "__main__":
     main()

@@ -332,16 +332,20 @@ int lob_get_traces(lob_engine* e, int32_t book, int32_t* idx, float* elig, int32
 int lob_get_counters(lob_engine* e, int64_t out[4]);
 
 /* ---- multi-GPU weight exchange ---------------------------
- * The engine never calls a collective itself: it exposes the dense delta
- * buffer so the launcher can all-reduce it over RCCL/xGMI.
- *   lob_delta_init  : theta_sync = theta (call once, right after create / theta_set)
- *   lob_delta_begin : dev_delta[i] = theta[i] - theta_sync[i]
+ * The engine library never calls a collective itself: it exposes the dense
+ * delta buffer, and include/lob_comm.h (liblob_comm.so, RCCL) all-reduces it
+ * in place over xGMI on the engine's stream (lob_theta_allreduce) -- the batched
+ * stand-in for the reference's shared Agent* of src/main.cpp:196-206.
+ *   lob_delta_init  : theta_sync = theta (call once, after create; lob_theta_set keeps it in step)
+ *   lob_delta_begin : dev_delta[i] = theta[i] - theta_sync[i]   (then waits for the stream;
+ *                     lob_delta_begin_async only enqueues it)
  *   (caller: all-reduce SUM dev_delta over ranks)
  *   lob_delta_apply : theta = theta_sync + dev_delta ; theta_sync = theta
  * `count` = memory_size, or 2 x memory_size for LOB_ALGO_DOUBLE_Q (theta then theta_b).
  */
 int lob_delta_init(lob_engine* e);
 int lob_delta_begin(lob_engine* e, double** dev_delta, int64_t* count);
+int lob_delta_begin_async(lob_engine* e, double** dev_delta, int64_t* count);
 int lob_delta_apply(lob_engine* e);
 
 /* Synchronise the engine's stream / expose it (hipStream_t as void*). */

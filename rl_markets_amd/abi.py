@@ -118,8 +118,9 @@ def load():
             "%s not found: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
             "There is no CPU fallback." % LIB_PATH)
     # NB: PyTorch-ROCm bundles its own libamdhip64.so.7.  Exactly one HIP runtime may live
-    # in a process: whoever needs torch as well (multi-GPU bench) must `import torch`
-    # BEFORE this call so that the library below resolves to the runtime torch loaded.
+    # in a process: a process that needs torch as well must `import torch` BEFORE this call so
+    # that the library below resolves to the runtime torch loaded.  (Nothing in the product does:
+    # the multi-GPU exchange is liblob_comm.so / RCCL, rl_markets_amd/comm.py.)
     lib = C.CDLL(LIB_PATH)
     P = C.POINTER
     vp = C.c_void_p
@@ -170,6 +171,7 @@ def load():
         "lob_get_counters": (C.c_int, [vp, vp]),
         "lob_delta_init": (C.c_int, [vp]),
         "lob_delta_begin": (C.c_int, [vp, P(vp), P(C.c_int64)]),
+        "lob_delta_begin_async": (C.c_int, [vp, P(vp), P(C.c_int64)]),
         "lob_delta_apply": (C.c_int, [vp]),
         "lob_sync": (C.c_int, [vp]),
         "lob_stream": (vp, [vp]),

@@ -1,0 +1,163 @@
+// Multi-GPU weight exchange (include/lob_comm.h): RCCL communicator per process and the
+// all-reduce of the engine's delta-theta buffer over xGMI.  Host code only; the collective runs on
+// the engine's own HIP stream, between the engine's delta kernels.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <stdio.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <string>
+#include <thread>
+
+#include "../../include/lob_comm.h"
+#include "lob_internal.h"
+
+static_assert(sizeof(ncclUniqueId) == LOB_COMM_ID_BYTES, "rendezvous token size");
+
+struct lob_comm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1, device = 0;
+    hipStream_t stream = nullptr;  // for the small host-side reductions
+    double* scratch = nullptr;     // 64 doubles in HBM
+};
+
+#define NCCLCHK(expr)                                                                         \
+    do {                                                                                      \
+        ncclResult_t _r = (expr);                                                             \
+        if (_r != ncclSuccess) {                                                              \
+            lob_set_error(std::string(#expr) + ": " + ncclGetErrorString(_r));                \
+            return LOB_EHIP;                                                                  \
+        }                                                                                     \
+    } while (0)
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            lob_set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                 \
+            return LOB_EHIP;                                                                  \
+        }                                                                                     \
+    } while (0)
+
+extern "C" {
+
+int lob_comm_get_id(uint8_t id[LOB_COMM_ID_BYTES]) {
+    if (!id) return LOB_EINVAL;
+    ncclUniqueId u;
+    NCCLCHK(ncclGetUniqueId(&u));
+    memcpy(id, &u, sizeof u);
+    return LOB_OK;
+}
+
+int lob_comm_create(const uint8_t id[LOB_COMM_ID_BYTES], int32_t rank, int32_t world, int32_t device, lob_comm** out) {
+    if (!id || !out || world < 1 || rank < 0 || rank >= world) { lob_set_error("lob_comm_create: bad argument"); return LOB_EINVAL; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        lob_set_error("lob_comm_create: no such HIP device (one process per GPU; RCCL refuses two ranks on one device)");
+        return LOB_ENODEV;
+    }
+    HIPCHK(hipSetDevice(device));
+    lob_comm* c = new lob_comm();
+    c->rank = rank; c->world = world; c->device = device;
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof u);
+    ncclResult_t r = ncclCommInitRank(&c->comm, world, u, rank);
+    if (r != ncclSuccess) {
+        lob_set_error(std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
+        delete c;
+        return LOB_EHIP;
+    }
+    if (hipStreamCreate(&c->stream) != hipSuccess || hipMalloc((void**)&c->scratch, 64 * sizeof(double)) != hipSuccess) {
+        lob_set_error("lob_comm_create: stream / scratch allocation failed");
+        lob_comm_destroy(c);
+        return LOB_EHIP;
+    }
+    *out = c;
+    return LOB_OK;
+}
+
+int lob_comm_create_file(const char* path, int32_t rank, int32_t world, int32_t device, int32_t timeout_s, lob_comm** out) {
+    if (!path || !out || world < 1 || rank < 0 || rank >= world) { lob_set_error("lob_comm_create_file: bad argument"); return LOB_EINVAL; }
+    uint8_t id[LOB_COMM_ID_BYTES];
+    if (rank == 0) {
+        int rc = lob_comm_get_id(id);
+        if (rc) return rc;
+        const std::string tmp = std::string(path) + ".tmp";
+        FILE* f = fopen(tmp.c_str(), "wb");
+        if (!f || fwrite(id, 1, sizeof id, f) != sizeof id) {
+            if (f) fclose(f);
+            lob_set_error(std::string("lob_comm_create_file: cannot write ") + tmp);
+            return LOB_EINVAL;
+        }
+        fclose(f);
+        if (rename(tmp.c_str(), path) != 0) { lob_set_error(std::string("lob_comm_create_file: cannot publish ") + path); return LOB_EINVAL; }
+    } else {
+        const auto t0 = std::chrono::steady_clock::now();
+        while (true) {
+            struct stat st;
+            if (stat(path, &st) == 0 && st.st_size == (off_t)sizeof id) {
+                FILE* f = fopen(path, "rb");
+                const bool ok = f && fread(id, 1, sizeof id, f) == sizeof id;
+                if (f) fclose(f);
+                if (ok) break;
+            }
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > (double)timeout_s) {
+                lob_set_error(std::string("lob_comm_create_file: rank 0 never published ") + path);
+                return LOB_ESTATE;
+            }
+            std::this_thread::sleep_for(std::chrono::milliseconds(20));
+        }
+    }
+    int rc = lob_comm_create(id, rank, world, device, out);
+    if (rc == LOB_OK && rank == 0) unlink(path);  // ncclCommInitRank returned on rank 0: every rank has read the token
+    return rc;
+}
+
+void lob_comm_destroy(lob_comm* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); }
+    if (c->scratch) hipFree(c->scratch);
+    if (c->comm) ncclCommDestroy(c->comm);
+    delete c;
+}
+
+int32_t lob_comm_rank(const lob_comm* c) { return c ? c->rank : -1; }
+int32_t lob_comm_world(const lob_comm* c) { return c ? c->world : 0; }
+
+int lob_comm_allreduce_f64(lob_comm* c, double* dev_buf, int64_t count, void* hip_stream) {
+    if (!c || !dev_buf || count < 0) { lob_set_error("lob_comm_allreduce_f64: bad argument"); return LOB_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    NCCLCHK(ncclAllReduce(dev_buf, dev_buf, (size_t)count, ncclDouble, ncclSum, c->comm, (hipStream_t)hip_stream));
+    return LOB_OK;
+}
+
+int lob_comm_reduce_host_f64(lob_comm* c, double* vals, int32_t n, int32_t op) {
+    if (!c || !vals || n < 1 || n > 64 || (op != LOB_COMM_SUM && op != LOB_COMM_MAX)) { lob_set_error("lob_comm_reduce_host_f64: bad argument"); return LOB_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(c->scratch, vals, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    NCCLCHK(ncclAllReduce(c->scratch, c->scratch, (size_t)n, ncclDouble, op == LOB_COMM_SUM ? ncclSum : ncclMax, c->comm, c->stream));
+    HIPCHK(hipMemcpyAsync(vals, c->scratch, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return LOB_OK;
+}
+
+int lob_comm_barrier(lob_comm* c) {
+    double z = 0.0;
+    return lob_comm_reduce_host_f64(c, &z, 1, LOB_COMM_SUM);
+}
+
+int lob_theta_allreduce(lob_engine* e, lob_comm* c) {
+    if (!e || !c) { lob_set_error("lob_theta_allreduce: bad argument"); return LOB_EINVAL; }
+    double* delta = nullptr;
+    int64_t count = 0;
+    int rc = lob_delta_begin_async(e, &delta, &count);  // delta = theta - theta_sync, on the engine stream
+    if (rc) return rc;
+    rc = lob_comm_allreduce_f64(c, delta, count, lob_stream(e));
+    if (rc) return rc;
+    return lob_delta_apply(e);                          // theta = theta_sync + sum(delta); theta_sync = theta
+}
+
+}  // extern "C"

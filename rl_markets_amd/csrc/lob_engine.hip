@@ -853,7 +853,7 @@ int lob_delta_init(lob_engine* e) {
     if (nv == 2) HIPCHK(hipMemcpyAsync(e->S.theta_sync + M, e->S.theta_b, M * 8, hipMemcpyDeviceToDevice, e->stream));
     return LOB_OK;
 }
-int lob_delta_begin(lob_engine* e, double** dev_delta, int64_t* count) {
+int lob_delta_begin_async(lob_engine* e, double** dev_delta, int64_t* count) {
     if (!e || !dev_delta || !count) return LOB_EINVAL;
     if (!e->S.theta_sync) { lob_set_error("lob_delta_begin: call lob_delta_init first"); return LOB_ESTATE; }
     HIPCHK(hipSetDevice(e->device));
@@ -865,9 +865,14 @@ int lob_delta_begin(lob_engine* e, double** dev_delta, int64_t* count) {
                            (const f64*)(e->S.theta_sync + v * M), e->S.delta + v * M, e->P.M);
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(e->stream));
     *dev_delta = e->S.delta;
     *count = (int64_t)(M * nv);
+    return LOB_OK;
+}
+int lob_delta_begin(lob_engine* e, double** dev_delta, int64_t* count) {
+    int rc = lob_delta_begin_async(e, dev_delta, count);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(e->stream));
     return LOB_OK;
 }
 int lob_delta_apply(lob_engine* e) {

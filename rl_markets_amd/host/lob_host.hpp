@@ -34,6 +34,7 @@
 #include <string>
 #include <vector>
 
+#include "../../include/lob_comm.h"
 #include "../../include/lob_engine.h"
 
 namespace lob {
@@ -351,18 +352,39 @@ class Learner : public Runner {
     int steps_per_call_;
     unsigned long _step_counter = 0;
     int _episode_counter = 0;
+    lob_comm* comm_ = nullptr;  // multi-GPU: the shared Agent* of main.cpp:196-206 becomes a periodic all-reduce
+    int sync_every_ = 64;
+    unsigned long since_sync_ = 0;
 
 protected:
     bool _step(Agent*) override {
-        check(lob_td_step(environment.handle(), steps_per_call_), "Learner::_step");
+        int n = steps_per_call_;
+        if (comm_ && since_sync_ + n > (unsigned long)sync_every_) n = (int)(sync_every_ - since_sync_);
+        check(lob_td_step(environment.handle(), n), "Learner::_step");
         environment.invalidate();
-        _step_counter += steps_per_call_;
-        return n_live() == 0;
+        _step_counter += n;
+        if (!comm_) return n_live() == 0;
+        since_sync_ += n;
+        if (since_sync_ < (unsigned long)sync_every_) return false;
+        since_sync_ = 0;
+        check(lob_theta_allreduce(environment.handle(), comm_), "Learner::_step (weight exchange)");
+        // every rank keeps stepping (a no-op for finished books) until NO rank has a live book:
+        // the exchange is a collective, all ranks must leave the episode at the same sync point
+        double live = (double)n_live();
+        check(lob_comm_reduce_host_f64(comm_, &live, 1, LOB_COMM_SUM), "Learner::_step (live books)");
+        return live == 0.0;
     }
 
 public:
     // steps_per_call: how many env-steps of every book are enqueued per host round trip
     Learner(BatchedIntraday& env, int steps_per_call = 1) : Runner(env), steps_per_call_(steps_per_call) {}
+    // one process per GPU: exchange delta-theta over `comm` every `sync_every` steps
+    void set_comm(lob_comm* comm, int sync_every = 64) {
+        comm_ = comm;
+        sync_every_ = sync_every < 1 ? 1 : sync_every;
+        since_sync_ = 0;
+        if (comm_) check(lob_delta_init(environment.handle()), "Learner::set_comm");
+    }
     unsigned long step_counter() const { return _step_counter; }
     bool RunEpisode(Agent* m) override {  // serial.cpp:72-93
         _step_counter = 0;

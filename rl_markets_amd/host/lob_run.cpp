@@ -5,8 +5,14 @@
 //
 //   lob_run -c config/engine.yaml [-n books] [-e episodes] [-a sarsa|q_learn|double_q_learn] [--events N] [--depth D]
 //           [--theta out.bin] [--profit-log profit_log.csv]
+//           [--gpus N [--sync-every K]]   one process per GPU (forked here), -n books EACH, book ids rank * n ..,
+//            delta-theta all-reduced over RCCL/xGMI every K steps (include/lob_comm.h): the stand-in for the
+//            reference's N training threads on one shared Agent (src/main.cpp:196-206)
 //           [--md depth.csv --tas trades.csv | --lobster orderbook.csv message.csv LEVELS]   (a recorded day, replayed
 //            by every book from evenly spread starting records; default: synthetic streams)
+#include <sys/wait.h>
+#include <unistd.h>
+
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -14,10 +20,41 @@
 
 #include "lob_host.hpp"
 
+static int run(int argc, char** argv, int rank, int world, const std::string& rdzv);
+
 int main(int argc, char** argv) {
+    int gpus = 1;
+    for (int i = 1; i + 1 < argc; i++)
+        if (!strcmp(argv[i], "--gpus")) gpus = atoi(argv[i + 1]);
+    char rdzv[128];
+    snprintf(rdzv, sizeof rdzv, "/tmp/lob_run_rdzv_%d", (int)getpid());
+    unlink(rdzv);
+    // LOB_FORCE_DIST=1: the whole exchange path with a one-rank communicator (a 1-GPU box can run it)
+    const char* fd = getenv("LOB_FORCE_DIST");
+    if (gpus <= 1) return run(argc, argv, 0, 1, (fd && fd[0] == '1') ? rdzv : "");
+    // one process per GPU, forked before anything touches the HIP runtime
+    std::vector<pid_t> kids;
+    for (int r = 0; r < gpus; r++) {
+        pid_t pid = fork();
+        if (pid < 0) { perror("fork"); return 2; }
+        if (pid == 0) _exit(run(argc, argv, r, gpus, rdzv));
+        kids.push_back(pid);
+    }
+    int rc = 0;
+    for (pid_t k : kids) {
+        int st = 0;
+        waitpid(k, &st, 0);
+        const int code = WIFEXITED(st) ? WEXITSTATUS(st) : 2;
+        if (code && !rc) rc = code;
+    }
+    unlink(rdzv);
+    return rc;
+}
+
+static int run(int argc, char** argv, int rank, int world, const std::string& rdzv) {
     std::string cfg_path, algo, theta_out, profit_log, md, tas, lob_ob, lob_msg;
     int lob_levels = 0;
-    int books = 1, episodes = 1, events = 2112, depth = 5;
+    int books = 1, episodes = 1, events = 2112, depth = 5, sync_every = 64;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto next = [&]() { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(1); } return std::string(argv[++i]); };
@@ -32,6 +69,8 @@ int main(int argc, char** argv) {
         else if (a == "--md") md = next();
         else if (a == "--tas") tas = next();
         else if (a == "--lobster") { lob_ob = next(); lob_msg = next(); lob_levels = atoi(next().c_str()); }
+        else if (a == "--gpus") next();
+        else if (a == "--sync-every") sync_every = atoi(next().c_str());
         else { fprintf(stderr, "unknown flag %s\n", a.c_str()); return 1; }
     }
     try {
@@ -40,7 +79,10 @@ int main(int argc, char** argv) {
         if (!algo.empty()) c.set("learning.algorithm", algo);  // CLI override, main.cpp:342-347
         std::string ticker = c.has("data.symbols") ? c.list("data.symbols").at(0) : "HSBA.L";
         lob_params p = c.to_params(ticker, depth, 2);
-        lob::BatchedIntraday env(p, books);
+        p.book_id_offset = (uint64_t)rank * (uint64_t)books;  // global book ids: streams and RNG draws do not depend on the sharding
+        lob::BatchedIntraday env(p, books, rank);
+        lob_comm* comm = nullptr;
+        if (!rdzv.empty()) lob::check(lob_comm_create_file(rdzv.c_str(), rank, world, rank, 300, &comm), "lob_comm_create_file");
         if (!md.empty() || !lob_ob.empty()) {
             // the reference's data files (Intraday::LoadData reads the CSV pair, intraday.cpp:141-150)
             uint32_t* rec = nullptr;
@@ -61,19 +103,21 @@ int main(int argc, char** argv) {
         }
         lob::Agent agent(env, c);
         lob::Learner learner(env, 8);
-        printf("episode,episode_id,reward,pnl,n_steps,epsilon\n");
+        if (comm) learner.set_comm(comm, sync_every);
+        if (rank == 0) printf("episode,episode_id,reward,pnl,n_steps,epsilon\n");
         for (int ep = 0; ep < episodes; ep++) {
             auto t0 = std::chrono::steady_clock::now();
             if (!learner.RunEpisode(&agent)) { fprintf(stderr, "[!] no data\n"); return 2; }
             double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             int64_t cnt[4];
             lob::check(lob_get_counters(env.handle(), cnt), "counters");
-            printf("%d,%s,%.10g,%.10g,%d,%.6g\n", ep + 1, env.getEpisodeId().c_str(), env.getEpisodeReward(0), env.getEpisodePnL(0),
+            if (rank == 0) printf("%d,%s,%.10g,%.10g,%d,%.6g\n", ep + 1, env.getEpisodeId().c_str(), env.getEpisodeReward(0), env.getEpisodePnL(0),
                    env.book(0).total_ticks, agent.epsilon_);
-            fprintf(stderr, "episode %d: %lld env-steps over %d books in %.3f s\n", ep + 1, (long long)cnt[0], books, sec);
+            fprintf(stderr, "[rank %d/%d] episode %d: %lld env-steps over %d books in %.3f s\n", rank, world, ep + 1, (long long)cnt[0], books, sec);
         }
-        if (!theta_out.empty()) agent.write_theta(theta_out);
-        if (!profit_log.empty()) {
+        if (!theta_out.empty() && rank == 0) agent.write_theta(theta_out);  // replicas agree after the last exchange
+        if (comm) { lob_comm_barrier(comm); lob_comm_destroy(comm); comm = nullptr; }
+        if (!profit_log.empty() && rank == 0) {
             // src/main.cpp:217-239: GoGreedy() then one Backtester episode with profit logging (book 0)
             agent.GoGreedy();
             lob::Backtester bt(env);

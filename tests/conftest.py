@@ -20,11 +20,15 @@ def _built():
     yield
 
 
-def has_gpu():
+def gpu_count():
     try:
         import ctypes
         hip = ctypes.CDLL("libamdhip64.so")
         n = ctypes.c_int(0)
-        return hip.hipGetDeviceCount(ctypes.byref(n)) == 0 and n.value > 0
+        return n.value if hip.hipGetDeviceCount(ctypes.byref(n)) == 0 else 0
     except OSError:
-        return False
+        return 0
+
+
+def has_gpu():
+    return gpu_count() > 0

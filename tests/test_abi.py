@@ -30,6 +30,19 @@ def test_every_declared_symbol_is_exported():
     assert set(names) == set(lib._declared)
 
 
+def test_comm_library_exports_its_header():
+    """include/lob_comm.h (multi-GPU weight exchange, RCCL) against liblob_comm.so and its ctypes mirror."""
+    from rl_markets_amd import comm
+    src = open(os.path.join(ROOT, "include", "lob_comm.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = sorted(set(re.findall(r"\b(lob_[a-z_0-9]+)\s*\(", src)))
+    lib = comm.load()
+    assert "lob_theta_allreduce" in names and len(names) >= 10
+    for n in names:
+        assert hasattr(lib, n), "liblob_comm.so does not export %s" % n
+    assert set(names) == set(lib._declared)
+
+
 def test_struct_sizes_match_header():
     # compile a probe with the real header and compare sizeof with the ctypes mirror
     import subprocess

@@ -1,7 +1,9 @@
-"""N > 1 path on CPU: two gloo ranks, each driving its shard of books through
-rl_markets_amd.parallel.ShardedLearner with the ORACLE as the compute backend
-(tests may use the oracle; the product never does).  The result must equal a
-single process that steps all books with the same sync schedule."""
+"""N > 1 path on CPU: two gloo ranks, started by rl_markets_amd.launch.spawn_ranks
+(the launcher `bench.py --gpus N` uses when nobody else set WORLD_SIZE), each
+driving its shard of books through rl_markets_amd.parallel.ShardedLearner with
+the ORACLE as the compute backend (tests may use the oracle; the product never
+does).  The result must equal a single process that steps all books with the
+same sync schedule."""
 import os
 import socket
 import sys
@@ -62,22 +64,25 @@ def _make(first, n):
     return o
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(out_dir):
+    """One rank, as spawn_ranks starts it: RANK / WORLD_SIZE / LOB_RDZV in the environment."""
     sys.path.insert(0, ROOT)
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
     import torch
     import torch.distributed as dist
-    from rl_markets_amd.parallel import ShardedLearner, shard_books
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rl_markets_amd import launch
+    from rl_markets_amd.parallel import ShardedLearner, TorchComm, shard_books
+    rank, local_rank, world = launch.rank_env()
+    assert local_rank == rank and "LOB_RDZV" in os.environ
+    dist.init_process_group("gloo", init_method="file://" + launch.rendezvous_path() + ".gloo", rank=rank, world_size=world)
     first, n = shard_books(TOTAL_BOOKS, world, rank)
     o = _make(first, n)
-    sl = ShardedLearner(OracleBackend(o, torch), dist, sync_every=SYNC)
+    sl = ShardedLearner(OracleBackend(o, torch), TorchComm(dist), sync_every=SYNC)
     sl.run(STEPS)
     np.save(os.path.join(out_dir, "theta_%d.npy" % rank), o.theta(0))
     np.save(os.path.join(out_dir, "steps_%d.npy" % rank), o.counters())
     dist.barrier()
     dist.destroy_process_group()
+    print("rank %d of %d done" % (rank, world))
 
 
 def test_shard_books_partition():
@@ -91,10 +96,10 @@ def test_shard_books_partition():
 
 
 def test_two_rank_gloo_matches_single_process(tmp_path):
-    import torch.multiprocessing as mp
+    from rl_markets_amd import launch
     world = 2
-    port = _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    rc = launch.spawn_ranks([sys.executable, os.path.abspath(__file__), "worker", str(tmp_path)], world, timeout=600)
+    assert rc == 0
     t0 = np.load(tmp_path / "theta_0.npy")
     t1 = np.load(tmp_path / "theta_1.npy")
     np.testing.assert_array_equal(t0, t1)  # replicas agree after the last sync... 
@@ -120,3 +125,35 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
         pass
     steps = sum(int(np.load(tmp_path / ("steps_%d.npy" % r))[0]) for r in range(world))
     assert steps == sum(int(o.counters()[0]) for o in shards)
+
+
+def test_spawn_ranks_stops_everyone_when_one_rank_fails(tmp_path, capfd):
+    from rl_markets_amd import launch
+    code = "import os,sys,time\nr=int(os.environ['RANK'])\nprint('hello from', r, os.environ['WORLD_SIZE'], flush=True)\n" \
+           "sys.exit(3) if r == 1 else time.sleep(60)"
+    rc = launch.spawn_ranks([sys.executable, "-c", code], 3, timeout=120)
+    out = capfd.readouterr()
+    assert rc == 3
+    assert "hello from 0 3" in out.out                      # rank 0's stdout is the launcher's stdout
+    assert "[rank 1] hello from 1 3" in out.err and "[rank 2] hello from 2 3" in out.err
+    assert "rank 1 exited with 3" in out.err
+
+
+def test_bench_gpus_2_starts_two_ranks():
+    """`bench.py --gpus 2` without a launcher starts TWO ranks itself (it used to run one and report
+    n_gpus 1).  Without two GPUs each rank must fail loudly -- there is no CPU path -- naming its rank."""
+    import subprocess
+    from tests.conftest import gpu_count
+    if gpu_count() >= 2:
+        pytest.skip("needs a box with fewer than 2 GPUs: with 2 the bench would really run")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--books", "64", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+    assert out.returncode != 0
+    assert "[rank 0] bench.py rank 0 of 2 on GPU 0" in out.stderr and "[rank 1] bench.py rank 1 of 2 on GPU 1" in out.stderr
+    assert "[launch] rank" in out.stderr   # a rank failed and the launcher stopped the other
+    assert '"n_gpus": 1' not in out.stdout
+
+
+if __name__ == "__main__" and len(sys.argv) == 3 and sys.argv[1] == "worker":
+    _worker(sys.argv[2])

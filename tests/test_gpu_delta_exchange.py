@@ -1,37 +1,51 @@
-"""Multi-GPU weight exchange pieces on ONE GPU: two engines (= two book shards)
-on the same device, the delta buffers handed to torch through
-__cuda_array_interface__ exactly as bench.py does for the RCCL all-reduce, the
-all-reduce itself emulated by a torch sum.  Checked against the oracle running
-the same two-shard schedule.
-
-Runs in a fresh interpreter that imports torch BEFORE liblob_engine.so is
-loaded (as bench.py does for N > 1): torch bundles its own libamdhip64 with the
-same SONAME as /opt/rocm's, and whichever HIP runtime is loaded first must be
-the only one in the process."""
+"""Multi-GPU weight exchange pieces on ONE GPU (a 1-GPU box cannot host two RCCL ranks: RCCL
+refuses duplicate devices): two engines (= two book shards) on the same device exchanging their
+delta buffers exactly as lob_theta_allreduce does, the sum over ranks formed on the host; the
+RCCL all-reduce itself on a one-rank communicator, in place on the engine's buffer and stream
+(rl_markets_amd.comm.RcclComm -> liblob_comm.so).  Checked against the oracle running the same
+two-shard schedule.  No torch anywhere on this path."""
+import ctypes as C
+import json
 import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
+
+from rl_markets_amd import abi, engine
+from rl_markets_amd.parallel import EngineBackend, ShardedLearner, shard_books
+from tests import oracle_lib as ol
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-
-def test_delta_exchange_two_shards_one_gpu():
-    out = subprocess.run([sys.executable, os.path.abspath(__file__)], capture_output=True, text=True, cwd=ROOT)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    assert "DELTA-EXCHANGE-OK" in out.stdout
+_hip = None
 
 
-def exchange(torch, algo):
-    """Two shards, one device: train, exchange, compare with the oracle doing the same."""
-    total, world, steps, sync = 12, 2, 48, 16
-    M = 1 << 16
-    nv = 2 if algo == abi.ALGO_DOUBLE_Q else 1
+def hip():
+    global _hip
+    if _hip is None:
+        _hip = C.CDLL("libamdhip64.so")
+        _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    return _hip
+
+
+def d2h(ptr, n):
+    out = np.empty(n, np.float64)
+    assert hip().hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), n * 8, 2) == 0
+    return out
+
+
+def h2d(ptr, arr):
+    a = np.ascontiguousarray(arr, np.float64)
+    assert hip().hipMemcpy(C.c_void_p(ptr), a.ctypes.data_as(C.c_void_p), a.size * 8, 1) == 0
+
+
+def make_shards(algo, total=12, world=2, M=1 << 16, n_events=200):
     g = engine.default_gen_params()
-    g.n_events = 200
-    engs, orcs, backs = [], [], []
+    g.n_events = n_events
+    engs, orcs = [], []
     for r in range(world):
         first, n = shard_books(total, world, r)
         p = engine.default_params()
@@ -47,22 +61,31 @@ def exchange(torch, algo):
         o.reset()
         engs.append(e)
         orcs.append(o)
-        backs.append(EngineBackend(e, torch, "cuda:0"))
+    return engs, orcs
+
+
+def host_allreduce(engs):
+    """What lob_theta_allreduce does on every rank, the sum over ranks formed on the host."""
+    bufs = [e.delta_begin() for e in engs]
+    tot = sum(d2h(ptr, n) for ptr, n in bufs)
+    for (ptr, n), e in zip(bufs, engs):
+        h2d(ptr, tot)
+        e.delta_apply()
+
+
+@pytest.mark.parametrize("algo", [abi.ALGO_SARSA, abi.ALGO_QLAMBDA, abi.ALGO_DOUBLE_Q])
+def test_delta_exchange_two_shards_one_gpu(algo):
+    M, steps, sync = 1 << 16, 48, 16
+    engs, orcs = make_shards(algo, M=M)
+    nv = 2 if algo == abi.ALGO_DOUBLE_Q else 1
     vecs = [lambda o: o.theta(0)] + ([lambda o: o.theta_b(0)] if nv == 2 else [])
     osync = [np.zeros(M) for _ in vecs]
     for s0 in range(0, steps, sync):
         for e, o in zip(engs, orcs):
             e.td_step(sync)
             o.td_step(sync)
-        ts = [b.delta_tensor() for b in backs]
-        assert ts[0].dtype == torch.float64 and ts[0].is_cuda and ts[0].numel() == nv * M
-        tot = ts[0] + ts[1]          # stands in for all_reduce(SUM)
-        for t in ts:
-            t.copy_(tot)
-        for b in backs:
-            b.after_all_reduce()   # staged tensor -> the engine's buffer
-        for e in engs:
-            e.delta_apply()
+        assert engs[0].delta_begin()[1] == nv * M
+        host_allreduce(engs)
         for v, get in enumerate(vecs):
             ototal = sum(get(o) - osync[v] for o in orcs)
             for o in orcs:
@@ -73,48 +96,62 @@ def exchange(torch, algo):
         np.testing.assert_array_equal(t0, t1)
         np.testing.assert_allclose(t0, get(orcs[0]), rtol=1e-9, atol=1e-15)
         assert np.count_nonzero(t0) > 100
-    return engs, backs
+    for e in engs:
+        e.close()
 
 
-def main():
-    import torch
-    assert torch.cuda.is_available()
-    exchange(torch, abi.ALGO_DOUBLE_Q)
-    engs, backs = exchange(torch, abi.ALGO_SARSA)
-    # RCCL itself (one rank: the only collective a 1-GPU box can run): f64 all-reduce on the staged
-    # tensor and on the engine's own hipMalloc'ed buffer
-    import torch.distributed as dist
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29541")
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    engs[0].td_step(4)
-    t = backs[0].delta_tensor()
-    want = t.clone()
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    dist.all_reduce(backs[0].view, op=dist.ReduceOp.SUM)
-    torch.cuda.synchronize()
-    assert torch.equal(t, want) and torch.equal(backs[0].view, want) and int((want != 0).sum()) > 0
-    backs[0].after_all_reduce()
-    engs[0].delta_apply()
-    dist.destroy_process_group()
+def test_checkpoint_loaded_after_delta_init_is_not_scaled_by_world_size():
+    """lob_theta_set after lob_delta_init (ShardedLearner's constructor ran, then a checkpoint is
+    loaded on every rank): the loaded weights are the new common base.  Before the fix every rank
+    contributed (loaded - sync) and theta came out as sync + world * (loaded - sync)."""
+    engs, orcs = make_shards(abi.ALGO_SARSA)
+    for e in engs:
+        e.td_step(8)
+    host_allreduce(engs)
+    loaded = np.random.default_rng(5).standard_normal(engs[0].M) * 1e-3
+    for e in engs:
+        e.set_theta(loaded)
+    host_allreduce(engs)          # nobody stepped: the sum of the deltas must be zero
+    for e in engs:
+        np.testing.assert_array_equal(e.theta(), loaded)
+    for e in engs:
+        e.td_step(4)
+    host_allreduce(engs)
+    np.testing.assert_array_equal(engs[0].theta(), engs[1].theta())
+    assert np.abs(engs[0].theta() - loaded).max() < 1.0   # a few small TD updates on top of the checkpoint, not 2 x checkpoint
+    for e in engs:
+        e.close()
 
 
-if __name__ == "__main__":
-    sys.path.insert(0, ROOT)
-    import torch  # noqa: F401  (first: see module docstring)
-    import numpy as np
-    from rl_markets_amd import abi, engine
-    from rl_markets_amd.parallel import EngineBackend, shard_books
-    from tests import oracle_lib as ol
-    main()
-    print("DELTA-EXCHANGE-OK")
+def test_rccl_allreduce_in_place_on_the_engine_buffer(tmp_path):
+    """The product's exchange: lob_theta_allreduce = delta kernel -> RCCL all-reduce (f64, SUM) in place
+    on the engine's own buffer, on the engine's stream -> apply kernel.  One rank: the sum over ranks is
+    the rank's own delta, so the weights must come out bit-identical, and stay in step with the oracle."""
+    from rl_markets_amd.comm import MAX, SUM, RcclComm
+    comm = RcclComm(str(tmp_path / "rdzv"), 0, 1, 0)
+    assert not (tmp_path / "rdzv").exists()          # rank 0 removes the token once everybody has joined
+    engs, orcs = make_shards(abi.ALGO_QLAMBDA, total=16, world=1)
+    eng, orc = engs[0], orcs[0]
+    learner = ShardedLearner(EngineBackend(eng), comm, sync_every=8)
+    learner.run(40)
+    orc.td_step(40)
+    eng.sync()
+    assert learner.n_syncs == 5
+    np.testing.assert_allclose(eng.theta(), orc.theta(), rtol=1e-9, atol=1e-15)
+    before = eng.theta()
+    comm.sync_weights(EngineBackend(eng))
+    eng.sync()
+    np.testing.assert_array_equal(eng.theta(), before)
+    assert comm.reduce([1.5, -2.0], MAX) == [1.5, -2.0] and comm.reduce([3.0], SUM) == [3.0]
+    comm.barrier()
+    comm.close()
+    eng.close()
 
 
 def test_bench_multi_gpu_code_path_on_one_rank():
-    """bench.py with LOB_FORCE_DIST=1: the N > 1 code path (torch first, RCCL process group, delta
-    kernels, staged all-reduce every 64 steps, max/sum reductions of the timings) on a single rank."""
-    import json
-    env = dict(os.environ, LOB_FORCE_DIST="1", MASTER_PORT="29547")
+    """bench.py with LOB_FORCE_DIST=1: the N > 1 code path (RCCL communicator, delta kernels, in-place
+    all-reduce every 64 steps, max/sum reductions of the timings over ranks) on a single rank."""
+    env = dict(os.environ, LOB_FORCE_DIST="1")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--books", "2048", "--steps", "130", "--warmup", "10",
                           "--no-cpu-baseline"], capture_output=True, text=True, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
@@ -122,3 +159,24 @@ def test_bench_multi_gpu_code_path_on_one_rank():
     assert d["n_gpus"] == 1 and d["config"]["sync_every"] == 64 and d["value"] > 0
     ks = d["roofline"]["all_kernels_avg_ms"]
     assert "delta_begin_kernel" in ks and "delta_apply_kernel" in ks
+    assert "torch" not in out.stderr.lower()
+
+
+def test_lob_run_multi_gpu_path_on_one_rank(tmp_path):
+    """The C++ driver's --gpus path (fork per GPU, file rendezvous, Learner::_step exchanging through
+    lob_theta_allreduce, global live-book count deciding the end of the episode) with one rank."""
+    exe = os.path.join(ROOT, "rl_markets_amd", "host", "lob_run")
+    cfg = os.path.join(ROOT, "config", "engine.yaml")
+    th = [str(tmp_path / "a.bin"), str(tmp_path / "b.bin")]
+    outs = []
+    for force, path in (("1", th[0]), ("0", th[1])):
+        env = dict(os.environ, LOB_FORCE_DIST=force)
+        out = subprocess.run([exe, "-c", cfg, "-n", "64", "-e", "1", "--events", "400", "--sync-every", "16", "--theta", path],
+                             capture_output=True, text=True, env=env)
+        assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+        outs.append(out.stdout)
+    # same books, same weights: one rank's exchange is the identity (up to the float order of theta_sync + delta)
+    assert outs[0].splitlines()[:2] == outs[1].splitlines()[:2]
+    a, b = np.fromfile(th[0]), np.fromfile(th[1])
+    np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-15)
+    assert np.count_nonzero(a) > 100

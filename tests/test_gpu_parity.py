@@ -452,3 +452,58 @@ def test_features_at_extreme_table_sizes(mem):
     np.testing.assert_array_equal(got, want)
     assert got.min() >= 0 and got.max() < mem
     eng.close()
+
+
+# ---- BASELINE's headline configuration against the oracle, at full size -----------------------------
+def test_config3_full_size_against_oracle():
+    """BASELINE config 3 -- the configuration bench.py times -- at its full size: 65 536 parallel
+    10-level books, Q(lambda) with eligibility traces, ONE shared 20M-weight table.  Exactly the
+    kernels and launch shapes of the timed run (env_kernel<64>, the shared-theta learner path with
+    its claim / accumulate / apply update) followed step by step by the oracle: every book bit-exact
+    (all 65 536 dumps, actions, rewards, state variables, RNG counters), TD errors and weights within
+    1e-9 relative (f64 atomic ordering; north-star allows 1e-5)."""
+    B = 65536
+    p, g, rec, eng, orc = make(depth=10, n_events=160, B=B, algo=abi.ALGO_QLAMBDA, theta_mode=abi.THETA_SHARED, mem=20000000)
+    eng.reset()
+    orc.reset()
+    for step in range(12):
+        eng.td_step(1)
+        orc.td_step(1)
+        compare_learner_step(eng, orc, "C3 step %d" % step, exact=False, rtol=1e-9)
+    assert eng.counters()[0] == 12 * B
+    th, oth = eng.theta(), orc.theta()
+    assert np.array_equal(th != 0, oth != 0) and np.count_nonzero(th) > 50000
+    np.testing.assert_allclose(th, oth, rtol=1e-9, atol=1e-12)
+    eng.close()
+    orc.close()
+
+
+@pytest.mark.parametrize("groups", [1, 2])
+@pytest.mark.parametrize("reset_lanes", [16, 32, 64])
+@pytest.mark.parametrize("env_lanes", [16, 32, 64])
+def test_books_per_wave_and_group_choices(monkeypatch, env_lanes, reset_lanes, groups):
+    """Every instantiation of the lane-per-book kernels (env_kernel<16|32|64>, reset_kernel<16|32|64>)
+    and both step pipelines (one group / two groups on two streams) against the oracle on 10-level
+    books: the launch shape must not show in the results.  (lob_create reads the switches.)"""
+    monkeypatch.setenv("LOB_ENV_LANES", str(env_lanes))
+    monkeypatch.setenv("LOB_RESET_LANES", str(reset_lanes))
+    monkeypatch.setenv("LOB_GROUPS", str(groups))
+    B = 1100  # >= 1024: the two-group pipeline only splits batches of that size; not a multiple of any wave shape
+    p, g, rec, eng, orc = make(depth=10, n_events=150, B=B, algo=abi.ALGO_QLAMBDA, theta_mode=abi.THETA_SHARED, mem=1 << 20)
+    eng.reset()
+    orc.reset()
+    for step in range(10):
+        eng.td_step(1)
+        orc.td_step(1)
+        compare_learner_step(eng, orc, "lanes %d/%d groups %d step %d" % (env_lanes, reset_lanes, groups, step), exact=False, rtol=1e-9)
+    # a second episode on the same streams: finalize_kernel + the pre-pass again
+    eng.clear_inventory(); orc.clear_inventory()
+    eng.handle_terminal(); orc.handle_terminal()
+    eng.reset(); orc.reset()
+    for step in range(4):
+        eng.td_step(1)
+        orc.td_step(1)
+        compare_learner_step(eng, orc, "lanes %d/%d groups %d episode 2 step %d" % (env_lanes, reset_lanes, groups, step), exact=False, rtol=1e-9)
+    np.testing.assert_allclose(eng.theta(), orc.theta(), rtol=1e-9, atol=1e-12)
+    eng.close()
+    orc.close()

@@ -122,3 +122,29 @@ def test_config5_full_size(tmp_path):
     assert eng.counters()[0] == 2 * steps * B
     th = eng.theta()
     assert np.isfinite(th).all() and np.count_nonzero(th) > 1000
+
+
+def test_config5_full_size_against_oracle(tmp_path):
+    """BASELINE config 5 at its full size WITH learning on: 65 536 books replaying one LOBSTER-format
+    day from their own phases, risk-averse reward pnl_damped, Q(lambda), one shared 20M-weight table,
+    followed step by step by the oracle (which gets every book's window as a private copy)."""
+    B, n_total, n_events, steps = 65536, 4000, 150, 10
+    day = lobster_day(tmp_path, n_total)
+    rng = np.random.default_rng(11)
+    phase = rng.integers(0, n_total - n_events + 1, size=B)
+    p = replay_params(abi.REWARD_PNL_DAMPED, mem=20000000)
+    eng = engine.Engine(p, B)
+    eng.load_events_shared(day, phase, n_events)
+    windows = day[phase[:, None] + np.arange(n_events)[None, :]]
+    orc = ol.Oracle(p, windows)
+    eng.reset()
+    orc.reset()
+    for step in range(steps):
+        eng.td_step(1)
+        orc.td_step(1)
+        compare_learner_step(eng, orc, "C5 full size step %d" % step, exact=False, rtol=1e-9)
+    th, oth = eng.theta(), orc.theta()
+    assert np.array_equal(th != 0, oth != 0) and np.count_nonzero(th) > 10000
+    np.testing.assert_allclose(th, oth, rtol=1e-9, atol=1e-12)
+    eng.close()
+    orc.close()
