@@ -43,6 +43,8 @@ struct lob_engine {
     int env_lanes = 0;     // books per env_kernel wave: 0 = by batch size, or 16 / 32 / 64 (LOB_ENV_LANES, read by lob_create)
     int reset_lanes = 64;  // books per reset_kernel wave (LOB_RESET_LANES)
     int td_parity = 0;
+    int step_id = 0;            // stamps the memo claims of one step
+    uint64_t theta_ver = 1;     // bumped whenever theta changes: memo records carry the version they were computed under
     std::vector<void*> allocs;
     uint32_t* rnd_dev = nullptr;
     uint32_t* records_dev = nullptr;
@@ -260,6 +262,10 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     P.algo = p->algo; P.theta_private = p->theta_mode == LOB_THETA_PRIVATE;
     { const char* nc = getenv("LOB_NO_CARRY"); P.carry_verdicts = !(nc && nc[0] == '1'); }
     { const char* nc = getenv("LOB_NO_COMBINE"); P.combine = !P.theta_private && !(nc && nc[0] == '1'); }
+    {   // group-0 memo: shared theta, one weight vector, one book group
+        const char* nc = getenv("LOB_NO_MEMO");
+        P.memo = !P.theta_private && p->algo != LOB_ALGO_DOUBLE_Q && e->n_groups == 1 && !(nc && nc[0] == '1');
+    }
     P.seed = p->seed; P.book_id_offset = p->book_id_offset;
 
     // ---- DevState ----
@@ -329,6 +335,19 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
         if (rc == LOB_OK) rc = dev_alloc(e, &S.cb_list, (size_t)slots);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.cb_count, 1);
         if (rc == LOB_OK && hipMemsetAsync(S.cb_key, 0xff, (size_t)slots * 8, e->stream) != hipSuccess) rc = LOB_EHIP;
+    }
+    {
+        S.mk_slots = 1 << 16;
+        const size_t ms = (size_t)S.mk_slots;
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.mk_hash, ms);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.mk_ident, ms * 4);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.mk_stamp, ms);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.mk_list, 2 * ms);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.mk_count, 2);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.mk_rec, 2 * ms * LOB_MK_REC);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.mk_slot, B);
+        if (rc == LOB_OK && hipMemsetAsync(S.mk_hash, 0xff, ms * 8, e->stream) != hipSuccess) rc = LOB_EHIP;
+        if (rc == LOB_OK && hipMemsetAsync(S.mk_slot, 0xff, B * 4, e->stream) != hipSuccess) rc = LOB_EHIP;
     }
     if (rc == LOB_OK) rc = dev_alloc(e, &S.verdict, B * LOB_VD_STRIDE);
     if (rc == LOB_OK) rc = dev_alloc(e, &S.nz_new, 4 * LOB_NZ_WORDS);
@@ -487,14 +506,21 @@ int lob_gen_events_device(lob_engine* e, const lob_gen_params* g) {
 }
 
 // env_kernel with 64 books per wave, or 16 when the batch is too small to give every SIMD a wave
-static void launch_env(lob_engine* e, hipStream_t st, const i32* actions, int count_updates, int b0, int nb) {
+static void launch_env(lob_engine* e, hipStream_t st, const i32* actions, int count_updates, int b0, int nb, int par) {
     const int force = e->env_lanes;
+    const int sid = e->step_id;
     if (force == 32)
-        hipLaunchKernelGGL(env_kernel<32>, dim3((nb + 31) / 32), dim3(32), 0, st, (const DevParams*)e->P_dev, e->S, actions, count_updates, b0, nb);
+        hipLaunchKernelGGL(env_kernel<32>, dim3((nb + 31) / 32), dim3(32), 0, st, (const DevParams*)e->P_dev, e->S, actions, count_updates, b0, nb, sid, par);
     else if (force == 16 || (force == 0 && e->B <= 16384))
-        hipLaunchKernelGGL(env_kernel<16>, dim3((nb + 15) / 16), dim3(16), 0, st, (const DevParams*)e->P_dev, e->S, actions, count_updates, b0, nb);
+        hipLaunchKernelGGL(env_kernel<16>, dim3((nb + 15) / 16), dim3(16), 0, st, (const DevParams*)e->P_dev, e->S, actions, count_updates, b0, nb, sid, par);
     else
-        hipLaunchKernelGGL(env_kernel<64>, dim3((nb + 63) / 64), dim3(64), 0, st, (const DevParams*)e->P_dev, e->S, actions, count_updates, b0, nb);
+        hipLaunchKernelGGL(env_kernel<64>, dim3((nb + 63) / 64), dim3(64), 0, st, (const DevParams*)e->P_dev, e->S, actions, count_updates, b0, nb, sid, par);
+}
+// S0 of every group-0 triple on this step's list (lob_kernels.h memo_kernel): `which` 0 = for learn_kernel
+// (theta_t), 1 = for the next act_kernel (after the update)
+static void launch_memo(lob_engine* e, int par, int which) {
+    TimedLaunch t(e, "memo_kernel");
+    hipLaunchKernelGGL(memo_kernel, dim3(256), dim3(256), 0, e->stream, e->P, e->S, (const uint32_t*)e->rnd_dev, par, which, (u64)e->theta_ver);
 }
 
 int lob_reset(lob_engine* e) {
@@ -502,6 +528,8 @@ int lob_reset(lob_engine* e) {
     if (!e->have_events) { lob_set_error("lob_reset: no event stream loaded"); return LOB_ESTATE; }
     HIPCHK(hipSetDevice(e->device));
     { int rc = finalize_episode(e); if (rc) return rc; }
+    // the memo table starts empty every episode (reset_kernel voids every book's slot)
+    HIPCHK(hipMemsetAsync(e->S.mk_hash, 0xff, (size_t)e->S.mk_slots * 8, e->stream));
     {
         TimedLaunch t(e, "reset_kernel");
         const int rb = e->reset_lanes;
@@ -529,9 +557,11 @@ int lob_step(lob_engine* e, const int32_t* host_actions) {
         if (host_actions[b] < 0 || host_actions[b] >= LOB_N_ACTIONS) { lob_set_error("lob_step: action out of range"); return LOB_EINVAL; }
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipMemcpyAsync(e->actions_dev, host_actions, (size_t)e->B * 4, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemsetAsync(e->S.mk_count, 0, 2 * sizeof(i32), e->stream));  // claims of this step go on a fresh list (nobody evaluates it)
+    e->step_id++;
     {
         TimedLaunch t(e, "env_kernel");
-        launch_env(e, e->stream, (const i32*)e->actions_dev, 0, 0, e->B);
+        launch_env(e, e->stream, (const i32*)e->actions_dev, 0, 0, e->B, 0);
     }
     HIPCHK(hipGetLastError());
     return check_device_errors(e);
@@ -616,6 +646,8 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode) {
     for (int s = 0; s < n_steps; s++) {
         // double-buffered list of newly written weights (verdict carry-over, lob_state.h)
         const int par = mode == 0 ? (e->td_parity ^= 1) : 0;
+        e->step_id++;
+        const u64 ver = (u64)e->theta_ver;
         if (G > 1) {
             HIPCHK(hipEventRecord(e->ev_fork, e->stream));
             HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
@@ -629,19 +661,20 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode) {
             if (G > 1 && g == 1) HIPCHK(hipStreamWaitEvent(st, e->ev_stagger, 0));
             {
                 TimedLaunch t(e, "act_kernel", st);
-                if (e->P.algo == LOB_ALGO_DOUBLE_Q) hipLaunchKernelGGL(act_kernel<LOB_ALGO_DOUBLE_Q>, dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, mode, b0, nb, par);
-                else hipLaunchKernelGGL(act_kernel<LOB_ALGO_SARSA>, dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, mode, b0, nb, par);
+                if (e->P.algo == LOB_ALGO_DOUBLE_Q) hipLaunchKernelGGL(act_kernel<LOB_ALGO_DOUBLE_Q>, dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, mode, b0, nb, par, ver);
+                else hipLaunchKernelGGL(act_kernel<LOB_ALGO_SARSA>, dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, mode, b0, nb, par, ver);
             }
             if (G > 1 && g == 0) HIPCHK(hipEventRecord(e->ev_stagger, st));
             {
                 TimedLaunch t(e, "env_kernel", st);
-                launch_env(e, st, (const i32*)nullptr, mode == 0 ? 1 : 0, b0, nb);
+                launch_env(e, st, (const i32*)nullptr, mode == 0 ? 1 : 0, b0, nb, par);
             }
+            if (e->P.memo) launch_memo(e, par, mode == 0 ? 0 : 1);  // learner: S0 under theta_t for learn_kernel; backtester: for the next act
             if (mode == 0) {
                 TimedLaunch t(e, "learn_kernel", st);
-                if (e->P.algo == LOB_ALGO_DOUBLE_Q) hipLaunchKernelGGL(learn_kernel<LOB_ALGO_DOUBLE_Q>, dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, b0, nb, par);
-                else if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL(learn_kernel<LOB_ALGO_QLAMBDA>, dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, b0, nb, par);
-                else hipLaunchKernelGGL(learn_kernel<LOB_ALGO_SARSA>, dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, b0, nb, par);
+                if (e->P.algo == LOB_ALGO_DOUBLE_Q) hipLaunchKernelGGL(learn_kernel<LOB_ALGO_DOUBLE_Q>, dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, b0, nb, par, ver);
+                else if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL(learn_kernel<LOB_ALGO_QLAMBDA>, dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, b0, nb, par, ver);
+                else hipLaunchKernelGGL(learn_kernel<LOB_ALGO_SARSA>, dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, b0, nb, par, ver);
             }
         }
         if (G > 1) {
@@ -661,6 +694,10 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode) {
         } else if (mode == 0) {
             TimedLaunch t(e, "update_kernel");
             hipLaunchKernelGGL(update_kernel, dim3(grid_waves(e->B)), dim3(LOB_BLOCK), 0, e->stream, e->P, e->S, par);
+        }
+        if (mode == 0) {
+            e->theta_ver++;                          // theta_{t+1}
+            if (e->P.memo) launch_memo(e, par, 1);   // the same triples again, for the next act_kernel
         }
     }
     HIPCHK(hipGetLastError());
@@ -748,6 +785,7 @@ int lob_theta_set(lob_engine* e, int32_t which, const double* host_in, int64_t c
         f64* sync = e->S.theta_sync + (th == e->S.theta_b ? (size_t)e->P.M : 0);
         HIPCHK(hipMemcpyAsync(sync, th, (size_t)count * 8, hipMemcpyDeviceToDevice, e->stream));
     }
+    e->theta_ver++;  // memo records computed under the old weights are void
     hipLaunchKernelGGL(rebuild_nz_kernel, dim3(1024), dim3(256), 0, e->stream, (const f64*)th, nz, e->S.nz_epoch, e->P.M);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -881,6 +919,7 @@ int lob_delta_apply(lob_engine* e) {
     HIPCHK(hipSetDevice(e->device));
     const size_t M = (size_t)e->P.M;
     const int nv = delta_vectors(e);
+    e->theta_ver++;  // memo records computed under the pre-exchange weights are void
     for (int v = 0; v < nv; v++) {
         TimedLaunch t(e, "delta_apply_kernel");
         hipLaunchKernelGGL(delta_apply_kernel, dim3(2048), dim3(256), 0, e->stream, v ? e->S.theta_b : e->S.theta, e->S.theta_sync + v * M,

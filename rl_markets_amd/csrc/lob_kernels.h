@@ -129,6 +129,7 @@ __global__ void __launch_bounds__(RB) reset_kernel(const DevParams* __restrict__
     S.hdr[b].stepped = 0;
     S.hdr[b].done = e.done;
     S.hdr[b].time_ms = e.time_ms;
+    S.mk_slot[b] = -1;  // the memo table is emptied at every reset: the first act of the episode takes the general path
     env_store(S, b, e);
     atomicAdd((u64*)&S.counters[1], (u64)(e.events - ev0));  // warm-up events count as consumed
 }
@@ -172,7 +173,8 @@ __global__ void __launch_bounds__(256) get_state_kernel(const DevParams* __restr
 // wave per SIMD) 16 books per wave spread the work over 4x the waves: 0.139 -> see DESIGN.md at 4 096
 // books; at 65 536 books the same choice is slower (0.31 vs 0.19 ms).
 template <int LOB_ENV_BLOCK>
-__global__ void __launch_bounds__(LOB_ENV_BLOCK) env_kernel(const DevParams* __restrict__ Pp, DevState S, const i32* host_actions, int count_updates, int b0, int nb) {
+__global__ void __launch_bounds__(LOB_ENV_BLOCK) env_kernel(const DevParams* __restrict__ Pp, DevState S, const i32* host_actions, int count_updates, int b0, int nb,
+                                                            int step_id, int par) {
     const DevParams& P = *Pp;  // parameters read through the scalar cache, never copied to scratch
     __shared__ EnvSlot lds_env[LOB_ENV_BLOCK];
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -202,10 +204,14 @@ __global__ void __launch_bounds__(LOB_ENV_BLOCK) env_kernel(const DevParams* __r
                 f32* v = S.vars + ((size_t)b * 3 + cur) * 16;
                 f32* vf = S.vars + ((size_t)b * 3 + 2) * 16;
                 const Track tk = state_track(c, e);
+                int qg[3] = {0, 0, 0};
                 for (int i = 0; i < P.V; i++) {
                     v[i] = (f32)get_variable(c, e, P.vars[i], tk);
                     vf[i] = v[i];
+                    if (i < 3) qg[i] = tile_quant(v[i]);
                 }
+                // group-0 memo: the new state's triple gets (or finds) its slot and goes on this step's list
+                if (P.memo) S.mk_slot[b] = mk_claim(S, qg[0], qg[1], qg[2], step_id, par);
                 h.zero_mask &= ~(1 << cur);
                 S.verdict[(size_t)b * LOB_VD_STRIDE + 67] = 0;  // a State changed: saved verdicts are void until learn saves new ones
                 h.reward = get_reward(c, e);
@@ -280,6 +286,12 @@ __device__ inline void learn_lds_init(const uint32_t* __restrict__ rnd_g, const 
     __syncthreads();
 }
 
+struct MemoRec {  // one record of DevState::mk_rec
+    f64 s0[LOB_N_ACTIONS];
+    u64 ver;
+};
+static_assert(sizeof(MemoRec) == LOB_MK_REC * 8, "memo record layout");
+
 // mode 0: Learner::_step prologue (swap, terminal check, epsilon-greedy action)
 // mode 1: Backtester::_step prologue (no swap, greedy action on the current state)
 // ALGO is a compile-time parameter: the double-Q path needs a second weight vector and more
@@ -289,7 +301,7 @@ __device__ inline u64 vd_tag(uint32_t epoch, int slot) { return (u64)epoch | ((u
 
 template <int ALGO>
 __global__ void __launch_bounds__(LOB_BLOCK) act_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g,
-                                                        int mode, int b0, int nb, int par) {
+                                                        int mode, int b0, int nb, int par, u64 ver) {
     __shared__ LearnLds L;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int t = __builtin_amdgcn_readfirstlane(blockIdx.x * LOB_WAVES_PER_BLOCK + w);
@@ -305,7 +317,15 @@ __global__ void __launch_bounds__(LOB_BLOCK) act_kernel(DevParams P, DevState S,
     const u64 tag = *(const u64*)(vd + 64);  // {epoch, slot, valid} in one load
     uint32_t my_vd = vd[lane];
     uint32_t my_vd_b = ALGO == LOB_ALGO_DOUBLE_Q ? S.verdict_b[(size_t)bb * 64 + lane] : 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && b0 == 0) S.cb_count[0] = 0;  // the previous step's apply_kernel has consumed the list
+    if (blockIdx.x == 0 && threadIdx.x == 0 && b0 == 0) {
+        S.cb_count[0] = 0;  // the previous step's apply_kernel has consumed the list
+        S.mk_count[par] = 0;  // this step's env_kernel starts a new list of memo slots (the one of two steps ago is spent)
+    }
+    // group-0 memo record of this book's latest state (valid only if its identity and theta version match, below)
+    const int mslot = (ALGO != LOB_ALGO_DOUBLE_Q && P.memo) ? S.mk_slot[bb] : -1;
+    const int ms = mslot >= 0 ? mslot : 0;
+    const int4 mid = *reinterpret_cast<const int4*>(S.mk_ident + (size_t)ms * 4);
+    MemoRec mrec = *reinterpret_cast<const MemoRec*>(S.mk_rec + ((size_t)S.mk_slots + ms) * LOB_MK_REC);  // [1]: under theta after the last update
     learn_lds_init(rnd_g, S.vars + (size_t)bb * 48, have, L, nz_new);
     if (!have) return;
     LHdr* hp = S.hdr + b;
@@ -329,7 +349,11 @@ __global__ void __launch_bounds__(LOB_BLOCK) act_kernel(DevParams P, DevState S,
         // verdicts if nothing but update(t) touched theta since (epoch) and that update set only a
         // few new bits (kept in a 4096-bit filter, staged in LDS above).
         reuse = mode == 0 && !zero && !P.theta_private && P.carry_verdicts && n_new <= LOB_NZ_NEW_MAX && tag == vd_tag(ep, src);
-        if (reuse) q_values(P, theta, nz, L.vars[w][src], zero, L.rnd, L.act_terms, L.vals[w], lane, qs, 2, &my_vd, L.newf[0]);
+        const int qv = tile_quant(L.vars[w][src][lane & 15]);
+        const bool memo = mslot >= 0 && !zero && mrec.ver == ver && mid.x == __builtin_amdgcn_readlane(qv, 0) &&
+                          mid.y == __builtin_amdgcn_readlane(qv, 1) && mid.z == __builtin_amdgcn_readlane(qv, 2);
+        if (memo) q_values_memo(P, theta, nz, qv, L.rnd, L.act_terms, lane, mrec.s0, qs);
+        else if (reuse) q_values(P, theta, nz, L.vars[w][src], zero, L.rnd, L.act_terms, L.vals[w], lane, qs, 2, &my_vd, L.newf[0]);
         else q_values(P, theta, nz, L.vars[w][src], zero, L.rnd, L.act_terms, L.vals[w], lane, qs);
     }
     if (lane < LOB_N_ACTIONS) S.qs_last[(size_t)b * LOB_N_ACTIONS + lane] = qs[lane];
@@ -374,7 +398,7 @@ __device__ inline i32 sel5(const i32* f, int k) {
 // the TD error of UpdateWeights (agent.cpp:86-115, 268-311).
 template <int ALGO>
 __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g,
-                                                          int b0, int nb, int par) {
+                                                          int b0, int nb, int par, u64 ver) {
     __shared__ LearnLds L;
     // this step's update appends to nz_new[par]; the list act reads is nz_new[par ^ 1]
     if (blockIdx.x == 0 && threadIdx.x < LOB_NZ_WORDS) {
@@ -390,6 +414,10 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
     f64 qs_last[LOB_N_ACTIONS];
 #pragma unroll
     for (int a = 0; a < LOB_N_ACTIONS; a++) qs_last[a] = S.qs_last[(size_t)bb * LOB_N_ACTIONS + a];
+    const int mslot = (ALGO != LOB_ALGO_DOUBLE_Q && P.memo) ? S.mk_slot[bb] : -1;
+    const int ms = mslot >= 0 ? mslot : 0;
+    const int4 mid = *reinterpret_cast<const int4*>(S.mk_ident + (size_t)ms * 4);
+    MemoRec mrec = *reinterpret_cast<const MemoRec*>(S.mk_rec + (size_t)ms * LOB_MK_REC);  // [0]: under theta_t
     learn_lds_init(rnd_g, S.vars + (size_t)bb * 48, have, L);
     if (!have) return;
     if (!h.stepped) return;
@@ -552,10 +580,17 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
     {
         uint16_t* vd = S.verdict + (size_t)b * LOB_VD_STRIDE;
         const uint32_t ep = (uint32_t)S.nz_epoch[0];
-        uint32_t my_vd = 0;
-        q_values(P, theta, nz, vars_to, false, L.rnd, L.act_terms, L.vals[w], lane, qs_to, 1, &my_vd);
-        vd[lane] = (uint16_t)my_vd;
-        if (lane == 0) *(u64*)(vd + 64) = vd_tag(ep, cur);
+        const int qv = tile_quant(vars_to[lane & 15]);
+        const bool memo = mslot >= 0 && mrec.ver == ver && mid.x == __builtin_amdgcn_readlane(qv, 0) &&
+                          mid.y == __builtin_amdgcn_readlane(qv, 1) && mid.z == __builtin_amdgcn_readlane(qv, 2);
+        if (memo) {
+            q_values_memo(P, theta, nz, qv, L.rnd, L.act_terms, lane, mrec.s0, qs_to);  // (no verdicts saved: the next act has its own memo record)
+        } else {
+            uint32_t my_vd = 0;
+            q_values(P, theta, nz, vars_to, false, L.rnd, L.act_terms, L.vals[w], lane, qs_to, 1, &my_vd);
+            vd[lane] = (uint16_t)my_vd;
+            if (lane == 0) *(u64*)(vd + 64) = vd_tag(ep, cur);
+        }
     }
     const f64 reward = h.reward;
     f64 delta;
@@ -768,6 +803,57 @@ __global__ void __launch_bounds__(256) apply_kernel(DevParams P, DevState S, int
             S.cb_acc[(size_t)s * 2 + 1] = 0.0;
             S.cb_touch[s] = 0;
         }
+    }
+}
+
+// Group-0 memo: S0(a) = the first 32 terms of Agent::getQ (agent.cpp:117-135), sum over the tilings of
+// w0 * theta[group-0 tile], in the reference's order, for every triple on this step's list.  One wave
+// per triple: lanes 0-31 (tiling j) fetch actions 0-4, lanes 32-63 actions 5-8; the products go
+// through LDS and nine lanes add them up sequentially, exactly as q_values does.  `which` 0: under
+// theta_t, read by learn_kernel; 1: after the update, read by the next act_kernel.  A few hundred
+// triples per step: the hash table is read from global memory (8 KB, cache-resident), no staging.
+__global__ void __launch_bounds__(256) memo_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g, int par, int which, u64 ver) {
+    __shared__ f64 vals[4][LOB_N_ACTIONS * LOB_QSTRIDE];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31;
+    const bool hi = lane >= 32;
+    const int wave = blockIdx.x * 4 + w, n_waves = gridDim.x * 4;
+    const uint32_t M = (uint32_t)P.M;
+    int count = S.mk_count[par];
+    if (count > S.mk_slots) count = S.mk_slots;
+    f64* v = vals[w];
+    for (int i = wave; i < count; i += n_waves) {
+        const int s = S.mk_list[(size_t)par * S.mk_slots + i];
+        const int4 id = *reinterpret_cast<const int4*>(S.mk_ident + (size_t)s * 4);
+        uint32_t sum = 0;
+        {
+            int base = j;
+            sum = mod_add(sum, rnd_g[(tile_coord(id.x, base) + 449 * 0) & 2047], M); base += 2 * j;
+            sum = mod_add(sum, rnd_g[(tile_coord(id.y, base) + 449 * 1) & 2047], M); base += 2 * j;
+            sum = mod_add(sum, rnd_g[(tile_coord(id.z, base) + 449 * 2) & 2047], M);
+            sum = mod_add(sum, rnd_g[(j + 449 * 3) & 2047], M);
+        }
+        f64 t[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int a = (hi ? 5 : 0) + k;
+            t[k] = a < LOB_N_ACTIONS ? S.theta[tile_index(sum, rnd_g[2048 + (a < LOB_N_ACTIONS ? a : 0)], M)] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int a = (hi ? 5 : 0) + k;
+            if (a < LOB_N_ACTIONS) v[a * LOB_QSTRIDE + j] = P.w0 * t[k];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local");
+        __builtin_amdgcn_wave_barrier();
+        f64 q = 0.0;
+        if (lane < LOB_N_ACTIONS) {
+            for (int k = 0; k < 32; k++) q += v[lane * LOB_QSTRIDE + k];
+        }
+        f64* rec = S.mk_rec + ((size_t)which * S.mk_slots + s) * LOB_MK_REC;
+        if (lane < LOB_N_ACTIONS) rec[lane] = q;
+        if (lane == LOB_N_ACTIONS) reinterpret_cast<u64*>(rec)[LOB_N_ACTIONS] = ver;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 

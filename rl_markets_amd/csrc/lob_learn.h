@@ -324,6 +324,108 @@ __device__ inline void q_values(const DevParams& P, const f64* __restrict__ thet
 }
 
 
+// ---- group-0 memo (lob_state.h) ---------------------------------------------------------------------
+#define LOB_MK_EMPTY (~0ull)
+__device__ inline u64 mk_hash3(int q0, int q1, int q2) {
+    u64 h = lob_mix64((u64)(uint32_t)q0 | ((u64)(uint32_t)q1 << 32));
+    h = lob_mix64(h + (u64)(uint32_t)q2 * 0x9E3779B97F4A7C15ull);
+    return h == LOB_MK_EMPTY ? 0 : h;
+}
+// env_kernel, one lane per book: find or make the slot of the book's new group-0 triple and put it on
+// this step's list (once per slot and step).  The 64-bit hash picks and marks the slot; the identity
+// is written by the claim winner only and compared in full by the readers in LATER kernels (no
+// cross-wave publication inside this one).  -1: table crowded, the book takes the general path.
+__device__ inline int mk_claim(const DevState& S, int q0, int q1, int q2, int step_id, int par) {
+    const u64 h = mk_hash3(q0, q1, q2);
+    const uint32_t mask = (uint32_t)(S.mk_slots - 1);
+    uint32_t s = (uint32_t)h & mask;
+    for (int probe = 0; probe < LOB_MK_PROBES; probe++) {
+        u64 k = S.mk_hash[s];
+        if (k == LOB_MK_EMPTY) {
+            k = atomicCAS((unsigned long long*)&S.mk_hash[s], (unsigned long long)LOB_MK_EMPTY, (unsigned long long)h);
+            if (k == LOB_MK_EMPTY) {
+                *reinterpret_cast<int4*>(S.mk_ident + (size_t)s * 4) = make_int4(q0, q1, q2, 0);
+                k = h;
+            }
+        }
+        if (k == h) {
+            if (S.mk_stamp[s] != step_id) {
+                const int old = atomicExch(&S.mk_stamp[s], step_id);
+                if (old != step_id) {
+                    const int pos = atomicAdd(&S.mk_count[par], 1);
+                    if (pos < S.mk_slots) S.mk_list[(size_t)par * S.mk_slots + pos] = (i32)s;
+                }
+            }
+            return (int)s;
+        }
+        s = (s + 1) & mask;
+    }
+    return -1;
+}
+
+__device__ inline f64 readlane_f64(f64 x, int l) {  // l wave-uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+    return __hiloint2double(hi, lo);
+}
+
+// Q(s, .) continued from the memoised group-0 partial sums `s0` (wave-uniform, computed by
+// memo_kernel in the reference's order under the same theta).  Lane l < 32: tiling l of group 1
+// (variables 3..V), lane 32 + l: tiling l of group 2 (all V variables); nine actions each: 9 map
+// look-ups per lane and a fetch only where the map says "written".  The remaining 96 terms of
+// Agent::getQ (group 1 with w1, group 1 again and group 2 with w2: quirk Q3) are then added IN THE
+// REFERENCE'S ORDER, skipping exact zeros: q is never -0.0 (the sum starts at +0.0), so adding
+// w * (+-0.0) leaves every bit of q unchanged and only the non-zero weights need visiting.
+// `qv`: lane i holds the quantised variable i (tile_quant), as in q_values.
+__device__ inline void q_values_memo(const DevParams& P, const f64* __restrict__ theta, const uint32_t* __restrict__ nz,
+                                     int qv, const uint32_t* rnd, const uint32_t* terms, int lane, const f64* s0, f64* out_q) {
+    const int j = lane & 31;
+    const bool hi = lane >= 32;
+    const uint32_t M = (uint32_t)P.M;
+    const int first = hi ? 0 : 3, nf = hi ? P.V : P.V - 3;
+    uint32_t sum = 0;
+    {
+        int base = j;
+        for (int i = 0; i < P.V; i++) {  // wave-uniform trip count; group-1 lanes sit out the last three
+            const int q = __shfl(qv, first + i);
+            const uint32_t t = rnd[(tile_coord(q, base) + 449 * i) & 2047];
+            if (i < nf) sum = mod_add(sum, t, M);
+            base += 2 * j;
+        }
+        sum = mod_add(sum, rnd[(j + 449 * nf) & 2047], M);
+    }
+    const uint32_t* tg = terms + (hi ? 2 * LOB_N_ACTIONS : LOB_N_ACTIONS);
+    i32 idx[LOB_N_ACTIONS];
+    uint32_t w[LOB_N_ACTIONS];
+#pragma unroll
+    for (int a = 0; a < LOB_N_ACTIONS; a++) idx[a] = tile_index(sum, tg[a], M);
+#pragma unroll
+    for (int a = 0; a < LOB_N_ACTIONS; a++) w[a] = nz[LOB_NZ_WORD(idx[a])];
+    f64 v[LOB_N_ACTIONS];
+    bool any = false;
+#pragma unroll
+    for (int a = 0; a < LOB_N_ACTIONS; a++) {
+        v[a] = 0.0;
+        if (w[a] & LOB_NZ_BIT(idx[a])) v[a] = theta[idx[a]];
+        any |= v[a] != 0.0;
+    }
+#pragma unroll
+    for (int a = 0; a < LOB_N_ACTIONS; a++) out_q[a] = s0[a];
+    if (__ballot(any) == 0) return;  // nothing written among the 576 group-1/2 tiles: Q = S0 exactly
+    const f64 w1 = P.w1, w2 = P.w2;
+#pragma unroll
+    for (int a = 0; a < LOB_N_ACTIONS; a++) {
+        const u64 m = __ballot(v[a] != 0.0);
+        if (m == 0) continue;
+        f64 q = out_q[a];
+        for (uint32_t mm = (uint32_t)m; mm; mm &= mm - 1) q += w1 * readlane_f64(v[a], __builtin_ctz(mm));
+        for (uint32_t mm = (uint32_t)m; mm; mm &= mm - 1) q += w2 * readlane_f64(v[a], __builtin_ctz(mm));
+        for (uint32_t mm = (uint32_t)(m >> 32); mm; mm &= mm - 1) q += w2 * readlane_f64(v[a], 32 + __builtin_ctz(mm));
+        out_q[a] = q;
+    }
+}
+
+
 // ---- std::mt19937_64 (the reference's Agent::gen, include/rl/agent.h:37; C++ standard
 // [rand.predef]: w=64 n=312 m=156 r=31 a=0xB5026F5AA96619E9 u=29 d=0x5555555555555555 s=17
 // b=0x71D67FFFEDA60000 t=37 c=0xFFF7EEE000000000 l=43 f=6364136223846793005) ----------------

@@ -123,6 +123,8 @@ struct __attribute__((aligned(64))) LHdr {
 };
 
 #define LOB_PERSIST_N 32
+#define LOB_MK_REC 10         /* doubles per memo record: S0 of the nine actions + the theta version it was computed under */
+#define LOB_MK_PROBES 16
 #define LOB_VD_STRIDE 72      /* u16 per book: 64 verdicts + epoch lo/hi + slot + valid, padded to 144 B */
 /* theta's "ever written" map: one bit per LOB_NZ_GRAN = 8 consecutive weights (312 KB at M = 20M, so
  * it stays L2-resident under the streaming traffic; one bit per weight, 2.5 MB, did not).  A set
@@ -208,6 +210,20 @@ struct DevState {
     i32* nz_new;         // [2 targets: theta, theta_b][2 parities][LOB_NZ_WORDS]: count + filter of the map bits an update set for the first time
     i32* nz_epoch;       // [1] bumped whenever theta / the bitmap change outside update_kernel
     uint32_t* theta_nz;  // bitmap, bit i set once theta[i] has ever been written: clear bit => theta[i] == +0.0
+    // Group-0 memo (shared theta; DESIGN.md "group-0 memo"): the first 32 of Q's 128 ordered terms --
+    // the group-0 partial sum S0(a) = sum_j w0 * theta[tile(q0, q1, q2, a, j)] -- depend on the state
+    // only through the three quantised group-0 variables (inventory, quote distances: a few hundred
+    // distinct triples among 65 536 books), and the ordered sum STARTS with them.  So S0 is
+    // evaluated once per distinct triple and theta version (memo_kernel) and every book continues
+    // the sum from its triple's S0 with whatever group-1/2 weights are non-zero.
+    u64* mk_hash;        // [mk_slots] 64-bit hash of the triple, ~0 = empty (claimed by env_kernel)
+    i32* mk_ident;       // [mk_slots][4]: q0, q1, q2, - (written by the claim winner, compared in full by the readers)
+    i32* mk_stamp;       // [mk_slots] step id of the last claim: first toucher of a step appends the slot to the list
+    i32* mk_list;        // [2 parities][mk_slots] slots in use this step
+    i32* mk_count;       // [2]
+    f64* mk_rec;         // [2: theta_t for learn, theta_{t+1} for the next act][mk_slots][LOB_MK_REC]: S0[9], theta version tag
+    i32* mk_slot;        // [B] slot of the book's latest state (-1: none)
+    i32 mk_slots;        // power of two
     f64* theta_sync;  // [M] (multi-GPU) or null
     f64* delta;       // [M] scratch for the all-reduce or null
     i64* counters;    // [8] device counters
@@ -242,6 +258,7 @@ struct DevParams {
     i32 algo, theta_private;
     i32 combine;         // shared theta: sum the updates per distinct trace generation first (0 with LOB_NO_COMBINE=1)
     i32 carry_verdicts;  // 0 with LOB_NO_CARRY=1 in the environment (A/B switch for the verdict carry-over)
+    i32 memo;            // group-0 memo on (shared theta, SARSA / Q(lambda), one book group; 0 with LOB_NO_MEMO=1)
     u64 seed, book_id_offset;
 };
 

@@ -174,9 +174,10 @@ def test_lob_run_multi_gpu_path_on_one_rank(tmp_path):
         out = subprocess.run([exe, "-c", cfg, "-n", "64", "-e", "1", "--events", "400", "--sync-every", "16", "--theta", path],
                              capture_output=True, text=True, env=env)
         assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
-        outs.append(out.stdout)
+        # (RCCL prints a version banner on stdout when the communicator comes up)
+        outs.append([l for l in out.stdout.splitlines() if l.startswith("episode,") or l[:1].isdigit()])
     # same books, same weights: one rank's exchange is the identity (up to the float order of theta_sync + delta)
-    assert outs[0].splitlines()[:2] == outs[1].splitlines()[:2]
+    assert len(outs[0]) == 2 and outs[0] == outs[1]
     a, b = np.fromfile(th[0]), np.fromfile(th[1])
     np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-15)
     assert np.count_nonzero(a) > 100

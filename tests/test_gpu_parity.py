@@ -507,3 +507,47 @@ def test_books_per_wave_and_group_choices(monkeypatch, env_lanes, reset_lanes, g
     np.testing.assert_allclose(eng.theta(), orc.theta(), rtol=1e-9, atol=1e-12)
     eng.close()
     orc.close()
+
+
+@pytest.mark.parametrize("algo", [abi.ALGO_SARSA, abi.ALGO_QLAMBDA])
+def test_group0_memo_on_off_identical(monkeypatch, algo):
+    """Shared theta evaluates the group-0 part of Q once per distinct (inventory, quote distances)
+    triple and continues every book's ordered sum from there (memo_kernel + q_values_memo);
+    LOB_NO_MEMO=1 evaluates all 128 terms per book and action (q_values).  Both are the reference's
+    sum term by term, so everything must agree bit for bit except theta's f64 atomic ordering --
+    also across evaluation steps, external actions, a weight load and a second episode.  A small
+    table makes hash collisions between group-0 and group-1/2 tiles the rule, which is what the
+    sparse continuation has to get right."""
+    B = 96
+    out = []
+    for off in ("1", "0"):
+        monkeypatch.setenv("LOB_NO_MEMO", off)
+        p, g, rec, eng, orc = make(depth=5, n_events=600, B=B, algo=algo, theta_mode=abi.THETA_SHARED, mem=1 << 12, epsilon=0.3)
+        orc.close()
+        eng.reset()
+        trail = []
+        rng = np.random.default_rng(17)
+        for phase in range(3):
+            for _ in range(25):
+                eng.td_step(1)
+                trail.append((eng.last_actions().copy(), eng.last_td().copy(), bytes(eng.get_books())))
+            eng.eval_step(3)
+            trail.append((eng.last_actions().copy(), None, bytes(eng.get_books())))
+            eng.step(rng.integers(0, 9, size=B).astype(np.int32))
+            th = eng.theta()
+            th[rng.integers(0, th.size, size=50)] += 1e-3
+            eng.set_theta(th)
+        eng.clear_inventory()
+        eng.handle_terminal()
+        eng.reset()
+        for _ in range(20):
+            eng.td_step(1)
+            trail.append((eng.last_actions().copy(), eng.last_td().copy(), bytes(eng.get_books())))
+        out.append((trail, eng.theta()))
+        eng.close()
+    for k, ((a0, t0, b0), (a1, t1, b1)) in enumerate(zip(out[0][0], out[1][0])):
+        np.testing.assert_array_equal(a0, a1, err_msg="actions, record %d" % k)
+        assert b0 == b1, "books differ at record %d" % k
+        if t0 is not None:
+            np.testing.assert_allclose(t0, t1, rtol=1e-9, atol=1e-12, err_msg="td, record %d" % k)
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-9, atol=1e-12)
