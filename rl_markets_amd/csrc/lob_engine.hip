@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "lob_internal.h"
+#include "lob_fast.h"
 #include "lob_kernels.h"
 
 #define HIPCHK(expr)                                                                         \
@@ -44,6 +45,9 @@ struct lob_engine {
     int reset_lanes = 64;  // books per reset_kernel wave (LOB_RESET_LANES)
     int td_parity = 0;
     int step_id = 0;            // stamps the memo claims of one step
+    int list_par = 0;           // parity of the fast path's work lists
+    int last_par = 0;           // `par` of the most recent step (its memo list is the current one)
+    int n_cus = 256;            // compute units: the persistent learner kernels run one block on each
     uint64_t theta_ver = 1;     // bumped whenever theta changes: memo records carry the version they were computed under
     std::vector<void*> allocs;
     uint32_t* rnd_dev = nullptr;
@@ -349,12 +353,36 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
         if (rc == LOB_OK && hipMemsetAsync(S.mk_hash, 0xff, ms * 8, e->stream) != hipSuccess) rc = LOB_EHIP;
         if (rc == LOB_OK && hipMemsetAsync(S.mk_slot, 0xff, B * 4, e->stream) != hipSuccess) rc = LOB_EHIP;
     }
+    {
+        // coarse written-weights map of the fast path: the finest granularity whose image fits 80 KB of LDS
+        int cs = 5;
+        while ((((size_t)P.M >> cs) + 31) / 32 > 20480) cs++;
+        P.cshift = cs;
+        const size_t cwords = (((size_t)P.M >> cs) + 32) / 32;
+        P.cwords4 = (int)((cwords + 3) / 4);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.theta_nzx, P.memo ? (size_t)P.M / 32 + 1 : 1);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.theta_nzc, (size_t)P.cwords4 * 4);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.slow_list, 2 * B);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.slow_n, 4);
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) e->n_cus = prop.multiProcessorCount;
+        if (P.memo) {
+            const int act_lds = (int)fast_lds_bytes(P.cwords4, false), learn_lds = (int)fast_lds_bytes(P.cwords4, true);
+            hipError_t er = hipFuncSetAttribute((const void*)act_fast_kernel<LOB_ALGO_SARSA>, hipFuncAttributeMaxDynamicSharedMemorySize, act_lds);
+            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_fast_kernel<LOB_ALGO_SARSA>, hipFuncAttributeMaxDynamicSharedMemorySize, learn_lds);
+            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_fast_kernel<LOB_ALGO_QLAMBDA>, hipFuncAttributeMaxDynamicSharedMemorySize, learn_lds);
+            if (er != hipSuccess && rc == LOB_OK) { lob_set_error(std::string("hipFuncSetAttribute(dynamic LDS): ") + hipGetErrorString(er)); rc = LOB_EHIP; }
+        }
+    }
     if (rc == LOB_OK) rc = dev_alloc(e, &S.verdict, B * LOB_VD_STRIDE);
     if (rc == LOB_OK) rc = dev_alloc(e, &S.nz_new, 4 * LOB_NZ_WORDS);
     if (rc == LOB_OK) rc = dev_alloc(e, &S.verdict_b, p->algo == LOB_ALGO_DOUBLE_Q ? B * 64 : 1);
     if (rc == LOB_OK) rc = dev_alloc(e, &S.nz_epoch, 1);
     if (rc == LOB_OK) rc = dev_alloc(e, &S.counters, 8);
     if (rc == LOB_OK) rc = dev_alloc(e, &S.error_flag, 1);
+#ifdef LOB_PROF
+    if (rc == LOB_OK) rc = dev_alloc(e, &S.prof, B * LOB_PROF_N);
+#endif
     if (rc == LOB_OK) rc = dev_alloc(e, &e->rnd_dev, 2048 + 64);
     if (rc == LOB_OK) rc = dev_alloc(e, &e->actions_dev, B);
     if (rc == LOB_OK) rc = dev_alloc(e, &e->P_dev, 1);
@@ -652,29 +680,56 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode) {
             HIPCHK(hipEventRecord(e->ev_fork, e->stream));
             HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
         }
+        const bool fast = e->P.memo != 0;  // (implies one group)
+        const int lpar = (e->list_par ^= 1);
+        e->last_par = par;
         for (int g = 0; g < G; g++) {
             hipStream_t st = g == 0 ? e->stream : e->stream2;
             const int b0 = (int)((long long)e->B * g / G), nb = (int)((long long)e->B * (g + 1) / G) - b0;
-            const int gw = grid_waves(nb), gl = grid_lanes(nb);
+            const int gw = grid_waves(nb);
+            // the persistent kernels: one 16-wave block per CU; the general kernels then serve the books handed back
+            const int gf = std::min(e->n_cus, (nb + LOB_FAST_WAVES - 1) / LOB_FAST_WAVES), gl = 2 * e->n_cus;
+            const i32* act_list = e->S.slow_list, *learn_list = e->S.slow_list + e->B;
+            const i32* act_n = e->S.slow_n + lpar * 2, *learn_n = e->S.slow_n + lpar * 2 + 1;
             // stagger: group 1 starts acting when group 0 has finished acting, so that the
             // latency-bound env kernel of one group runs beside a gather kernel of the other
             if (G > 1 && g == 1) HIPCHK(hipStreamWaitEvent(st, e->ev_stagger, 0));
-            {
+            if (fast) {
+                {
+                    TimedLaunch t(e, "act_kernel", st);
+                    hipLaunchKernelGGL(act_fast_kernel<LOB_ALGO_SARSA>, dim3(gf), dim3(LOB_FAST_BLOCK), fast_lds_bytes(e->P.cwords4, false), st, e->P, e->S, rnd, mode, par, lpar, ver);
+                }
+                {
+                    TimedLaunch t(e, "act_rest_kernel", st);
+                    hipLaunchKernelGGL((act_kernel<LOB_ALGO_SARSA, true>), dim3(gl), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, mode, 0, e->B, par, act_list, act_n);
+                }
+            } else {
                 TimedLaunch t(e, "act_kernel", st);
-                if (e->P.algo == LOB_ALGO_DOUBLE_Q) hipLaunchKernelGGL(act_kernel<LOB_ALGO_DOUBLE_Q>, dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, mode, b0, nb, par, ver);
-                else hipLaunchKernelGGL(act_kernel<LOB_ALGO_SARSA>, dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, mode, b0, nb, par, ver);
+                if (e->P.algo == LOB_ALGO_DOUBLE_Q) hipLaunchKernelGGL((act_kernel<LOB_ALGO_DOUBLE_Q, false>), dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, mode, b0, nb, par, (const i32*)nullptr, (const i32*)nullptr);
+                else hipLaunchKernelGGL((act_kernel<LOB_ALGO_SARSA, false>), dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, mode, b0, nb, par, (const i32*)nullptr, (const i32*)nullptr);
             }
             if (G > 1 && g == 0) HIPCHK(hipEventRecord(e->ev_stagger, st));
             {
                 TimedLaunch t(e, "env_kernel", st);
                 launch_env(e, st, (const i32*)nullptr, mode == 0 ? 1 : 0, b0, nb, par);
             }
-            if (e->P.memo) launch_memo(e, par, mode == 0 ? 0 : 1);  // learner: S0 under theta_t for learn_kernel; backtester: for the next act
-            if (mode == 0) {
+            if (fast) launch_memo(e, par, mode == 0 ? 0 : 1);  // learner: S0 under theta_t for learn_kernel; backtester: for the next act
+            if (mode == 0 && fast) {
+                {
+                    TimedLaunch t(e, "learn_kernel", st);
+                    if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL(learn_fast_kernel<LOB_ALGO_QLAMBDA>, dim3(gf), dim3(LOB_FAST_BLOCK), fast_lds_bytes(e->P.cwords4, true), st, e->P, e->S, rnd, par, lpar, ver);
+                    else hipLaunchKernelGGL(learn_fast_kernel<LOB_ALGO_SARSA>, dim3(gf), dim3(LOB_FAST_BLOCK), fast_lds_bytes(e->P.cwords4, true), st, e->P, e->S, rnd, par, lpar, ver);
+                }
+                {
+                    TimedLaunch t(e, "learn_rest_kernel", st);
+                    if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL((learn_kernel<LOB_ALGO_QLAMBDA, true>), dim3(gl), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, 0, e->B, par, learn_list, learn_n);
+                    else hipLaunchKernelGGL((learn_kernel<LOB_ALGO_SARSA, true>), dim3(gl), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, 0, e->B, par, learn_list, learn_n);
+                }
+            } else if (mode == 0) {
                 TimedLaunch t(e, "learn_kernel", st);
-                if (e->P.algo == LOB_ALGO_DOUBLE_Q) hipLaunchKernelGGL(learn_kernel<LOB_ALGO_DOUBLE_Q>, dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, b0, nb, par, ver);
-                else if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL(learn_kernel<LOB_ALGO_QLAMBDA>, dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, b0, nb, par, ver);
-                else hipLaunchKernelGGL(learn_kernel<LOB_ALGO_SARSA>, dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, b0, nb, par, ver);
+                if (e->P.algo == LOB_ALGO_DOUBLE_Q) hipLaunchKernelGGL((learn_kernel<LOB_ALGO_DOUBLE_Q, false>), dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, b0, nb, par, (const i32*)nullptr, (const i32*)nullptr);
+                else if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL((learn_kernel<LOB_ALGO_QLAMBDA, false>), dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, b0, nb, par, (const i32*)nullptr, (const i32*)nullptr);
+                else hipLaunchKernelGGL((learn_kernel<LOB_ALGO_SARSA, false>), dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, b0, nb, par, (const i32*)nullptr, (const i32*)nullptr);
             }
         }
         if (G > 1) {
@@ -787,6 +842,12 @@ int lob_theta_set(lob_engine* e, int32_t which, const double* host_in, int64_t c
     }
     e->theta_ver++;  // memo records computed under the old weights are void
     hipLaunchKernelGGL(rebuild_nz_kernel, dim3(1024), dim3(256), 0, e->stream, (const f64*)th, nz, e->S.nz_epoch, e->P.M);
+    if (e->P.memo && th == e->S.theta) {
+        HIPCHK(hipMemsetAsync(e->S.theta_nzx, 0, ((size_t)e->P.M / 32 + 1) * 4, e->stream));
+        HIPCHK(hipMemsetAsync(e->S.theta_nzc, 0, (size_t)e->P.cwords4 * 16, e->stream));
+        hipLaunchKernelGGL(rebuild_nzx_kernel, dim3(2048), dim3(256), 0, e->stream, (const f64*)th, e->S.theta_nzx, e->S.theta_nzc, e->P.cshift, e->P.M);
+        launch_memo(e, e->last_par, 1);  // the current triples under the loaded weights: the next act stays on the fast path
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(e->stream));
     return LOB_OK;
@@ -923,8 +984,10 @@ int lob_delta_apply(lob_engine* e) {
     for (int v = 0; v < nv; v++) {
         TimedLaunch t(e, "delta_apply_kernel");
         hipLaunchKernelGGL(delta_apply_kernel, dim3(2048), dim3(256), 0, e->stream, v ? e->S.theta_b : e->S.theta, e->S.theta_sync + v * M,
-                           (const f64*)(e->S.delta + v * M), v ? e->S.theta_b_nz : e->S.theta_nz, e->S.nz_epoch, e->P.M);
+                           (const f64*)(e->S.delta + v * M), v ? e->S.theta_b_nz : e->S.theta_nz, e->S.nz_epoch, e->P.M,
+                           (v == 0 && e->P.memo) ? e->S.theta_nzx : (uint32_t*)nullptr, e->S.theta_nzc, e->P.cshift);
     }
+    if (e->P.memo) launch_memo(e, e->last_par, 1);  // the current triples under the exchanged weights
     HIPCHK(hipGetLastError());
     return LOB_OK;
 }
@@ -958,6 +1021,21 @@ int lob_kernel_time_ms(lob_engine* e, const char* kernel, double* avg_ms, int64_
 }
 
 }  // extern "C"
+
+// Diagnostics (not part of include/lob_engine.h): phase clocks of a -DLOB_PROF build, summed over books
+// (tools/exp_prof.py); LOB_ESTATE on a regular build.
+extern "C" int lob_debug_prof(lob_engine* e, int64_t out[LOB_PROF_N]) {
+    if (!e || !out) return LOB_EINVAL;
+    if (!e->S.prof) { lob_set_error("lob_debug_prof: not a -DLOB_PROF build"); return LOB_ESTATE; }
+    HIPCHK(hipSetDevice(e->device));
+    std::vector<i64> h((size_t)e->B * LOB_PROF_N);
+    HIPCHK(hipMemcpyAsync(h.data(), e->S.prof, h.size() * 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (int i = 0; i < LOB_PROF_N; i++) out[i] = 0;
+    for (size_t b = 0; b < (size_t)e->B; b++)
+        for (int i = 0; i < LOB_PROF_N; i++) out[i] += h[b * LOB_PROF_N + i];
+    return LOB_OK;
+}
 
 // Diagnostics (not part of include/lob_engine.h): how many weights the last two updates wrote for
 // the first time -- the quantity that decides whether act_kernel can reuse learn_kernel's verdicts.

@@ -261,73 +261,60 @@ struct LearnLds {
     uint32_t newf[2][LOB_NZ_FILTER];                      // act only: filters of the map bits first set by the previous update (theta, theta_b)
 };
 
-// Stage the hash table (8 KB, two 16-byte loads per thread), the 27 action terms
-// and this wave's three state-variable slots; ONE barrier.
-__device__ inline void learn_lds_init(const uint32_t* __restrict__ rnd_g, const f32* __restrict__ vars_b, bool have_book,
-                                      LearnLds& L, const i32* __restrict__ nz_buf = nullptr) {
+// Stage the hash table (8 KB, two 16-byte loads per thread), the 27 action terms and, for act, the
+// carry-over filters; ONE block barrier.
+__device__ inline void learn_stage_table(const uint32_t* __restrict__ rnd_g, LearnLds& L, const i32* __restrict__ nz_buf = nullptr) {
     const uint4* src = reinterpret_cast<const uint4*>(rnd_g);
     uint4* dst = reinterpret_cast<uint4*>(L.rnd);
     constexpr int PER = LOB_BLOCK >= 512 ? 1 : 512 / LOB_BLOCK;  // 512 x 16 B = the 8 KB table
     uint4 r[PER];
 #pragma unroll
     for (int i = 0; i < PER; i++) r[i] = (threadIdx.x + i * LOB_BLOCK < 512) ? src[threadIdx.x + i * LOB_BLOCK] : uint4{0, 0, 0, 0};
-    f32 vv = 0.0f;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (have_book && lane < 48) vv = vars_b[lane];
 #pragma unroll
     for (int i = 0; i < PER; i++)
         if (threadIdx.x + i * LOB_BLOCK < 512) dst[threadIdx.x + i * LOB_BLOCK] = r[i];
     if (threadIdx.x < 27) L.act_terms[threadIdx.x] = rnd_g[2048 + threadIdx.x];
-    if (lane < 48) (&L.vars[w][0][0])[lane] = vv;
     if (nz_buf && threadIdx.x < 2 * LOB_NZ_FILTER) {  // [target][parity][LOB_NZ_WORDS]: the two targets are 2 * LOB_NZ_WORDS apart
         const int tg = threadIdx.x / LOB_NZ_FILTER, i = threadIdx.x % LOB_NZ_FILTER;
         L.newf[tg][i] = (uint32_t)nz_buf[tg * 2 * LOB_NZ_WORDS + LOB_NZ_FILTER + i];
     }
     __syncthreads();
 }
+__device__ inline void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local");
+    __builtin_amdgcn_wave_barrier();
+}
+// This wave's three state-variable slots (the two rl::State objects + the latest getState()) into its
+// own LDS row; wave-level hand-over only.
+__device__ inline void learn_stage_vars(const f32* __restrict__ vars_b, f32* dst, int lane) {
+    const f32 vv = lane < 48 ? vars_b[lane] : 0.0f;
+    wave_lds_fence();  // the previous book's readers are done with the row
+    if (lane < 48) dst[lane] = vv;
+    wave_lds_fence();
+}
 
-struct MemoRec {  // one record of DevState::mk_rec
-    f64 s0[LOB_N_ACTIONS];
-    u64 ver;
-};
-static_assert(sizeof(MemoRec) == LOB_MK_REC * 8, "memo record layout");
-
-// mode 0: Learner::_step prologue (swap, terminal check, epsilon-greedy action)
-// mode 1: Backtester::_step prologue (no swap, greedy action on the current state)
-// ALGO is a compile-time parameter: the double-Q path needs a second weight vector and more
-// registers; keeping it out of the SARSA / Q(lambda) instantiations keeps them at 90 VGPRs.
 // tag of a verdict row: theta epoch | State slot | valid (u16 words 64..67 of the row)
 __device__ inline u64 vd_tag(uint32_t epoch, int slot) { return (u64)epoch | ((u64)(uint16_t)slot << 32) | (1ull << 48); }
 
+// ---- the general learner path: every term of Q per book (q_values).  It serves private theta, double Q,
+// two book groups and LOB_NO_MEMO=1 over the whole batch, and -- over a work list -- the few books the
+// fast path (lob_fast.h) hands back (no valid memo record: first step of an episode, constructor-zero
+// State, weights just loaded).
+// mode 0: Learner::_step prologue (swap, terminal check, epsilon-greedy action)
+// mode 1: Backtester::_step prologue (no swap, greedy action on the current state)
+// ALGO is a compile-time parameter: the double-Q path needs a second weight vector and more
+// registers; keeping it out of the SARSA / Q(lambda) instantiations keeps them small.
 template <int ALGO>
-__global__ void __launch_bounds__(LOB_BLOCK) act_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g,
-                                                        int mode, int b0, int nb, int par, u64 ver) {
-    __shared__ LearnLds L;
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int t = __builtin_amdgcn_readfirstlane(blockIdx.x * LOB_WAVES_PER_BLOCK + w);
-    const int b = b0 + t;
-    const bool have = t < nb;
-    const int bb = have ? b : 0;
-    const LHdr h = S.hdr[bb];  // one scalar 64-byte load, issued before the LDS staging
+__device__ __forceinline__ void act_book(const DevParams& P, const DevState& S, LearnLds& L, int w, int lane, int b, int mode, int par) {
+    const LHdr h = S.hdr[b];  // one scalar 64-byte load
     const i32* nz_new = S.nz_new + (par ^ 1) * LOB_NZ_WORDS;  // written by the previous step's update
-    // everything the verdict carry-over needs is loaded up front, beside the header and the LDS staging
-    const uint16_t* vd = S.verdict + (size_t)bb * LOB_VD_STRIDE;
+    const uint16_t* vd = S.verdict + (size_t)b * LOB_VD_STRIDE;
     const int n_new = ALGO == LOB_ALGO_DOUBLE_Q ? max(nz_new[0], nz_new[2 * LOB_NZ_WORDS]) : nz_new[0];
     const uint32_t ep = (uint32_t)S.nz_epoch[0];
     const u64 tag = *(const u64*)(vd + 64);  // {epoch, slot, valid} in one load
     uint32_t my_vd = vd[lane];
-    uint32_t my_vd_b = ALGO == LOB_ALGO_DOUBLE_Q ? S.verdict_b[(size_t)bb * 64 + lane] : 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && b0 == 0) {
-        S.cb_count[0] = 0;  // the previous step's apply_kernel has consumed the list
-        S.mk_count[par] = 0;  // this step's env_kernel starts a new list of memo slots (the one of two steps ago is spent)
-    }
-    // group-0 memo record of this book's latest state (valid only if its identity and theta version match, below)
-    const int mslot = (ALGO != LOB_ALGO_DOUBLE_Q && P.memo) ? S.mk_slot[bb] : -1;
-    const int ms = mslot >= 0 ? mslot : 0;
-    const int4 mid = *reinterpret_cast<const int4*>(S.mk_ident + (size_t)ms * 4);
-    MemoRec mrec = *reinterpret_cast<const MemoRec*>(S.mk_rec + ((size_t)S.mk_slots + ms) * LOB_MK_REC);  // [1]: under theta after the last update
-    learn_lds_init(rnd_g, S.vars + (size_t)bb * 48, have, L, nz_new);
-    if (!have) return;
+    uint32_t my_vd_b = ALGO == LOB_ALGO_DOUBLE_Q ? S.verdict_b[(size_t)b * 64 + lane] : 0;
+    learn_stage_vars(S.vars + (size_t)b * 48, &L.vars[w][0][0], lane);
     LHdr* hp = S.hdr + b;
     if (h.done) { if (lane == 0) hp->stepped = 0; return; }
     int cur = h.slot_cur;
@@ -343,19 +330,12 @@ __global__ void __launch_bounds__(LOB_BLOCK) act_kernel(DevParams P, DevState S,
     f64 qs[LOB_N_ACTIONS];
     const size_t nz_off = P.theta_private ? (size_t)b * LOB_NZ_NWORDS(P.M) : 0;
     const uint32_t* nz = S.theta_nz + nz_off;
-    bool reuse;
-    {
-        // learn(t) of this book evaluated the very same State: take over its "weight is zero"
-        // verdicts if nothing but update(t) touched theta since (epoch) and that update set only a
-        // few new bits (kept in a 4096-bit filter, staged in LDS above).
-        reuse = mode == 0 && !zero && !P.theta_private && P.carry_verdicts && n_new <= LOB_NZ_NEW_MAX && tag == vd_tag(ep, src);
-        const int qv = tile_quant(L.vars[w][src][lane & 15]);
-        const bool memo = mslot >= 0 && !zero && mrec.ver == ver && mid.x == __builtin_amdgcn_readlane(qv, 0) &&
-                          mid.y == __builtin_amdgcn_readlane(qv, 1) && mid.z == __builtin_amdgcn_readlane(qv, 2);
-        if (memo) q_values_memo(P, theta, nz, qv, L.rnd, L.act_terms, lane, mrec.s0, qs);
-        else if (reuse) q_values(P, theta, nz, L.vars[w][src], zero, L.rnd, L.act_terms, L.vals[w], lane, qs, 2, &my_vd, L.newf[0]);
-        else q_values(P, theta, nz, L.vars[w][src], zero, L.rnd, L.act_terms, L.vals[w], lane, qs);
-    }
+    // learn(t) of this book evaluated the very same State: take over its "weight is zero"
+    // verdicts if nothing but update(t) touched theta since (epoch) and that update set only a
+    // few new bits (kept in a 4096-bit filter, staged in LDS).
+    const bool reuse = mode == 0 && !zero && !P.theta_private && P.carry_verdicts && n_new <= LOB_NZ_NEW_MAX && tag == vd_tag(ep, src);
+    if (reuse) q_values(P, theta, nz, L.vars[w][src], zero, L.rnd, L.act_terms, L.vals[w], lane, qs, 2, &my_vd, L.newf[0]);
+    else q_values(P, theta, nz, L.vars[w][src], zero, L.rnd, L.act_terms, L.vals[w], lane, qs);
     if (lane < LOB_N_ACTIONS) S.qs_last[(size_t)b * LOB_N_ACTIONS + lane] = qs[lane];
     if (ALGO == LOB_ALGO_DOUBLE_Q) {
         // DoubleAgent::action (agent.cpp:196-204): qs[a] = (getQ + getQb) / 2.0f
@@ -379,6 +359,31 @@ __global__ void __launch_bounds__(LOB_BLOCK) act_kernel(DevParams P, DevState S,
     }
 }
 
+// Whole batch (`list` null: wave t handles book b0 + t) or a work list of book ids (`list`, `*list_n`
+// entries; a fixed grid strides over it).
+template <int ALGO, bool LIST>
+__global__ void __launch_bounds__(LOB_BLOCK) act_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g,
+                                                        int mode, int b0, int nb, int par, const i32* __restrict__ list,
+                                                        const i32* __restrict__ list_n) {
+    __shared__ LearnLds L;
+    if (LIST && *list_n == 0) return;  // nothing handed back by the fast path: the usual case
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (!LIST && blockIdx.x == 0 && threadIdx.x == 0 && b0 == 0) {
+        S.cb_count[0] = 0;    // the previous step's apply_kernel has consumed the list
+        S.mk_count[par] = 0;  // this step's env_kernel starts a new list of memo slots
+    }
+    learn_stage_table(rnd_g, L, S.nz_new + (par ^ 1) * LOB_NZ_WORDS);
+    const int t0 = __builtin_amdgcn_readfirstlane(blockIdx.x * LOB_WAVES_PER_BLOCK + w);
+    if (!LIST) {
+        if (t0 < nb) act_book<ALGO>(P, S, L, w, lane, b0 + t0, mode, par);
+    } else {
+        const int n = *list_n;
+#pragma unroll 1
+        for (int i = t0; i < n; i += gridDim.x * LOB_WAVES_PER_BLOCK)
+            act_book<ALGO>(P, S, L, w, lane, __builtin_amdgcn_readfirstlane(list[i]), mode, par);
+    }
+}
+
 __device__ inline f64 sel9(const f64* q, int k) {
     f64 r = q[0];
 #pragma unroll
@@ -394,52 +399,29 @@ __device__ inline i32 sel5(const i32* f, int k) {
     return r;
 }
 
-// Agent::HandleTransition up to (not including) updateQ: UpdateTraces +
-// the TD error of UpdateWeights (agent.cpp:86-115, 268-311).
+// Agent::UpdateTraces (agent.cpp:86-101 -> traces.cpp:30-50; QLearn / DoubleQLearn: 272-280, 319-327)
+// for one book, one wave: decay, clear / replace against the 288 group-0 tiles of last_state, new
+// generation, and the slot claims of the combined update (issued here, resolved by the caller at the
+// end of its kernel).  `tab`: this wave's LDS hash map (LOB_HSLOTS 64-bit slots); `vars_from`: the
+// State acted on (LDS); shared by the general and the fast learner kernel.
 template <int ALGO>
-__global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g,
-                                                          int b0, int nb, int par, u64 ver) {
-    __shared__ LearnLds L;
-    // this step's update appends to nz_new[par]; the list act reads is nz_new[par ^ 1]
-    if (blockIdx.x == 0 && threadIdx.x < LOB_NZ_WORDS) {
-        S.nz_new[par * LOB_NZ_WORDS + threadIdx.x] = 0;
-        S.nz_new[(2 + par) * LOB_NZ_WORDS + threadIdx.x] = 0;  // theta_b's (double Q)
-    }
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int t = __builtin_amdgcn_readfirstlane(blockIdx.x * LOB_WAVES_PER_BLOCK + w);
-    const int b = b0 + t;
-    const bool have = t < nb;
-    const int bb = have ? b : 0;
-    const LHdr h = S.hdr[bb];
-    f64 qs_last[LOB_N_ACTIONS];
-#pragma unroll
-    for (int a = 0; a < LOB_N_ACTIONS; a++) qs_last[a] = S.qs_last[(size_t)bb * LOB_N_ACTIONS + a];
-    const int mslot = (ALGO != LOB_ALGO_DOUBLE_Q && P.memo) ? S.mk_slot[bb] : -1;
-    const int ms = mslot >= 0 ? mslot : 0;
-    const int4 mid = *reinterpret_cast<const int4*>(S.mk_ident + (size_t)ms * 4);
-    MemoRec mrec = *reinterpret_cast<const MemoRec*>(S.mk_rec + (size_t)ms * LOB_MK_REC);  // [0]: under theta_t
-    learn_lds_init(rnd_g, S.vars + (size_t)bb * 48, have, L);
-    if (!have) return;
-    if (!h.stepped) return;
+__device__ __forceinline__ void learn_traces(const DevParams& P, const DevState& S, int b, const LHdr& h, const uint32_t* rnd, const uint32_t* act_terms,
+                                    u64* tab, const f32* vars_from, bool zero_last, const f64* qs_last, Rng& g, int lane,
+                                    CbPending& pend, Prof& pf) {
     LHdr* hp = S.hdr + b;
-    const int cur = h.slot_cur, last = cur ^ 1;
-    const bool zero_last = (h.zero_mask >> last) & 1;
-    const f32* vars_to = L.vars[w][cur];
-    const f32* vars_from = L.vars[w][last];
     const int action = h.action;
-    Rng g{P.seed, P.book_id_offset + (u64)b, h.rng_ctr};
-
     // ---- group-0 tiles of last_state for all nine actions: lane -> (a = half + 2k, j) ----
     const int j = lane & 31, half = lane >> 5;
     i32 F[5];
     {
-        const uint32_t base = zero_last ? 0 : tile_base_wave<0>((uint32_t)P.M, tile_quant(vars_from[lane & 15]), 3, j, L.rnd);
+        const uint32_t base = zero_last ? 0 : tile_base_wave<0>((uint32_t)P.M, tile_quant(vars_from[lane & 15]), 3, j, rnd);
 #pragma unroll
         for (int k = 0; k < 5; k++) {
             const int a = half + 2 * k;
-            F[k] = (a < LOB_N_ACTIONS && !zero_last) ? tile_index(base, L.act_terms[a < LOB_N_ACTIONS ? a : 0], (uint32_t)P.M) : 0;
+            F[k] = (a < LOB_N_ACTIONS && !zero_last) ? tile_index(base, act_terms[a < LOB_N_ACTIONS ? a : 0], (uint32_t)P.M) : 0;
         }
     }
+    pf.mark(9);  // group-0 tiles of s
 
     // ---- Traces::decay (traces.cpp:30-38) ----
     int n_old = h.tr_n;
@@ -457,11 +439,9 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
     // cases it leaves its old generation.
     // Slot = tile index (high word) | rank (low word), rank(a, j) = 32 a + (31 - j): the map keeps,
     // per tile, the largest rank among the (action, tiling) pairs that produce it.
-    u64* tab = reinterpret_cast<u64*>(L.vals[w]);
     constexpr u64 EMPTY = ~0ull;
     for (int i = lane; i < LOB_HSLOTS; i += 64) tab[i] = EMPTY;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local");
-    __builtin_amdgcn_wave_barrier();
+    wave_lds_fence();
 #pragma unroll
     for (int k = 0; k < 5; k++) {
         const int a = half + 2 * k;
@@ -477,8 +457,8 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
             }
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local");
-    __builtin_amdgcn_wave_barrier();
+    wave_lds_fence();
+    pf.mark(10);  // argmax(qs_last), LDS map: init + 288 inserts
     const int G = P.trace_gens;  // ring size, a power of two
     i32* tr_idx = S.tr_idx + (size_t)b * G * 32;
     uint32_t* tr_alive = S.tr_alive + (size_t)b * G;
@@ -522,7 +502,6 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
             if (lane == k0 + 2 * u + 1) my_mask = (uint32_t)(m >> 32);
         }
     }
-    CbPending pend;
     pend.active = false;
     if (lane < n_old) {
         tr_alive[my_slot] = my_mask;
@@ -531,6 +510,7 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
             cb_claim_issue(S, pend, sg.x, sg.y, sg.z, sg.w, my_mask, b * G + my_slot);
         }
     }
+    pf.mark(11);  // old generations: scan, stores, claim issue
     // new generation: the chosen action's tiles, minus those a later action
     // clears again and minus duplicates inside the list (set() of a live tile
     // only overwrites its eligibility).
@@ -569,8 +549,52 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
             }
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local");
-    __builtin_amdgcn_wave_barrier();
+    wave_lds_fence();
+    pf.mark(12);  // new generation + claim issue
+}
+
+// UpdateWeights of SARSA / QLearn (agent.cpp:282-311) once Q(to_state, .) is known: the TD error and
+// the header stores.
+template <int ALGO>
+__device__ __forceinline__ void learn_delta_single(const DevParams& P, LHdr* hp, const LHdr& h, const f64* qs_to, const f64* qs_last, Rng& g, int lane) {
+    static_assert(ALGO != LOB_ALGO_DOUBLE_Q, "two weight vectors: see learn_book");
+    const f64 F_term = P.gamma * 0.0 - 0.0;  // potentials are identically 0 (base.cpp:239-242)
+    f64 delta;
+    if (ALGO == LOB_ALGO_QLAMBDA) {
+        const int am2 = argmax_ties(qs_to, g);  // maxQ(to_state)
+        delta = h.reward + F_term + P.gamma * sel9(qs_to, am2) - sel9(qs_last, h.action);
+    } else {
+        const int a2 = policy_sample(qs_to, P.epsilon, false, g);  // this->action(to_state), quirk Q9
+        delta = h.reward + F_term + P.gamma * sel9(qs_to, a2) - sel9(qs_last, h.action);
+    }
+    if (lane == 0) {
+        hp->td = delta;
+        hp->upd = P.alpha * delta;
+        hp->rng_ctr = g.ctr;
+    }
+}
+
+// Agent::HandleTransition up to (not including) updateQ: UpdateTraces +
+// the TD error of UpdateWeights (agent.cpp:86-115, 268-311).
+template <int ALGO>
+__device__ __forceinline__ void learn_book(const DevParams& P, const DevState& S, LearnLds& L, int w, int lane, int b) {
+    const LHdr h = S.hdr[b];
+    f64 qs_last[LOB_N_ACTIONS];
+#pragma unroll
+    for (int a = 0; a < LOB_N_ACTIONS; a++) qs_last[a] = S.qs_last[(size_t)b * LOB_N_ACTIONS + a];
+    if (!h.stepped) return;
+    learn_stage_vars(S.vars + (size_t)b * 48, &L.vars[w][0][0], lane);
+    Prof pf;
+    pf.start(S.prof, b, lane);
+    LHdr* hp = S.hdr + b;
+    const int cur = h.slot_cur, last = cur ^ 1;
+    const bool zero_last = (h.zero_mask >> last) & 1;
+    const f32* vars_to = L.vars[w][cur];
+    const f32* vars_from = L.vars[w][last];
+    const int action = h.action;
+    Rng g{P.seed, P.book_id_offset + (u64)b, h.rng_ctr};
+    CbPending pend;
+    learn_traces<ALGO>(P, S, b, h, L.rnd, L.act_terms, reinterpret_cast<u64*>(L.vals[w]), vars_from, zero_last, qs_last, g, lane, pend, pf);
 
     // ---- UpdateWeights: TD error under theta_t ----
     const f64* theta = S.theta + (P.theta_private ? (size_t)b * (size_t)P.M : 0);
@@ -580,24 +604,17 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
     {
         uint16_t* vd = S.verdict + (size_t)b * LOB_VD_STRIDE;
         const uint32_t ep = (uint32_t)S.nz_epoch[0];
-        const int qv = tile_quant(vars_to[lane & 15]);
-        const bool memo = mslot >= 0 && mrec.ver == ver && mid.x == __builtin_amdgcn_readlane(qv, 0) &&
-                          mid.y == __builtin_amdgcn_readlane(qv, 1) && mid.z == __builtin_amdgcn_readlane(qv, 2);
-        if (memo) {
-            q_values_memo(P, theta, nz, qv, L.rnd, L.act_terms, lane, mrec.s0, qs_to);  // (no verdicts saved: the next act has its own memo record)
-        } else {
-            uint32_t my_vd = 0;
-            q_values(P, theta, nz, vars_to, false, L.rnd, L.act_terms, L.vals[w], lane, qs_to, 1, &my_vd);
-            vd[lane] = (uint16_t)my_vd;
-            if (lane == 0) *(u64*)(vd + 64) = vd_tag(ep, cur);
-        }
+        uint32_t my_vd = 0;
+        q_values(P, theta, nz, vars_to, false, L.rnd, L.act_terms, L.vals[w], lane, qs_to, 1, &my_vd);
+        vd[lane] = (uint16_t)my_vd;
+        if (lane == 0) *(u64*)(vd + 64) = vd_tag(ep, cur);
     }
-    const f64 reward = h.reward;
-    f64 delta;
-    int target = 1;
-    const f64 F_term = P.gamma * 0.0 - 0.0;  // potentials are identically 0 (base.cpp:239-242)
     if (ALGO == LOB_ALGO_DOUBLE_Q) {
         // DoubleQLearn::UpdateWeights (agent.cpp:329-353)
+        const f64 reward = h.reward;
+        const f64 F_term = P.gamma * 0.0 - 0.0;  // potentials are identically 0 (base.cpp:239-242)
+        f64 delta;
+        int target = 1;
         f64 qb_to[LOB_N_ACTIONS];
         uint32_t my_vd_b = 0;
         q_values(P, S.theta_b + (P.theta_private ? (size_t)b * (size_t)P.M : 0), S.theta_b_nz + nz_off, vars_to, false, L.rnd,
@@ -620,20 +637,52 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
             delta = reward + F_term + P.gamma * sel9(qs_to, am) - sel9(qb_last, action);
             target = 2;
         }
-    } else if (ALGO == LOB_ALGO_QLAMBDA) {
-        const int am2 = argmax_ties(qs_to, g);  // maxQ(to_state)
-        delta = reward + F_term + P.gamma * qs_to[am2] - qs_last[action];
+        if (lane == 0 && target == 2) hp->stepped = 2;  // update_kernel scatters into theta_b
+        if (lane == 0) {
+            hp->td = delta;
+            hp->upd = P.alpha * delta;
+            hp->rng_ctr = g.ctr;
+        }
     } else {
-        const int a2 = policy_sample(qs_to, P.epsilon, false, g);  // this->action(to_state), quirk Q9
-        delta = reward + F_term + P.gamma * qs_to[a2] - qs_last[action];
+        learn_delta_single<ALGO == LOB_ALGO_DOUBLE_Q ? LOB_ALGO_SARSA : ALGO>(P, hp, h, qs_to, qs_last, g, lane);
     }
-    if (lane == 0 && target == 2) hp->stepped = 2;  // update_kernel scatters into theta_b
-    if (lane == 0) {
-        hp->td = delta;
-        hp->upd = P.alpha * delta;
-        hp->rng_ctr = g.ctr;
-    }
+    pf.mark(17);  // argmax / delta / header stores
     cb_claim_finish(S, pend);  // the CAS was issued before Q(s', .): its answer has long arrived
+    pf.mark(18);  // claim finish
+}
+
+template <int ALGO, bool LIST>
+__global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g,
+                                                          int b0, int nb, int par, const i32* __restrict__ list, const i32* __restrict__ list_n) {
+    __shared__ LearnLds L;
+    if (LIST && *list_n == 0) return;
+    // this step's update appends to nz_new[par]; the list act reads is nz_new[par ^ 1]
+    if (!LIST && blockIdx.x == 0 && threadIdx.x < LOB_NZ_WORDS) {
+        S.nz_new[par * LOB_NZ_WORDS + threadIdx.x] = 0;
+        S.nz_new[(2 + par) * LOB_NZ_WORDS + threadIdx.x] = 0;  // theta_b's (double Q)
+    }
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    learn_stage_table(rnd_g, L);
+    const int t0 = __builtin_amdgcn_readfirstlane(blockIdx.x * LOB_WAVES_PER_BLOCK + w);
+    if (!LIST) {
+        if (t0 < nb) learn_book<ALGO>(P, S, L, w, lane, b0 + t0);
+    } else {
+        const int n = *list_n;
+#pragma unroll 1
+        for (int i = t0; i < n; i += gridDim.x * LOB_WAVES_PER_BLOCK)
+            learn_book<ALGO>(P, S, L, w, lane, __builtin_amdgcn_readfirstlane(list[i]));
+    }
+}
+
+// First write of weight f of the shared theta: the exact map and its coarse image (lob_fast.h); monotone bits.
+__device__ inline void nzx_mark(const DevParams& P, const DevState& S, i32 f) {
+    const uint32_t xb = 1u << ((uint32_t)f & 31);
+    if (!(S.theta_nzx[(uint32_t)f >> 5] & xb)) {
+        atomicOr(&S.theta_nzx[(uint32_t)f >> 5], xb);
+        const uint32_t c = (uint32_t)f >> P.cshift;
+        const uint32_t cb = 1u << (c & 31);
+        if (!(S.theta_nzc[c >> 5] & cb)) atomicOr(&S.theta_nzc[c >> 5], cb);
+    }
 }
 
 // Agent::updateQ (agent.cpp:137-142): theta[f] += (alpha*delta / N_TILINGS) * e[f]
@@ -673,6 +722,7 @@ __global__ void __launch_bounds__(LOB_BLOCK) update_kernel(DevParams P, DevState
                 const f64 val = scaled * (f64)P.trace_pow[c0 + 2 * it + half];
                 __hip_atomic_fetch_add(&theta[f[it]], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 word[it] = nz[LOB_NZ_WORD(f[it])];
+                if (P.memo && h.stepped != 2) nzx_mark(P, S, f[it]);
             }
         }
 #pragma unroll
@@ -753,6 +803,7 @@ __global__ void __launch_bounds__(LOB_BLOCK) accumulate_kernel(DevParams P, DevS
             if (lane < 32 && ((m >> j) & 1u)) {
                 const i32 f = tr_idx[sl * 32 + j];
                 __hip_atomic_fetch_add(&theta[f], scaled * (f64)P.trace_pow[age], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (P.memo && !target) nzx_mark(P, S, f);
                 const uint32_t bit = LOB_NZ_BIT(f);
                 if (!(nz[LOB_NZ_WORD(f)] & bit)) {
                     const uint32_t old = atomicOr(&nz[LOB_NZ_WORD(f)], bit);
@@ -787,6 +838,7 @@ __global__ void __launch_bounds__(256) apply_kernel(DevParams P, DevState S, int
             f64* theta = t ? S.theta_b : S.theta;
             uint32_t* nz = t ? S.theta_b_nz : S.theta_nz;
             __hip_atomic_fetch_add(&theta[f], t ? v1 : v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (P.memo && !t) nzx_mark(P, S, f);
             const uint32_t bit = LOB_NZ_BIT(f);
             if (!(nz[LOB_NZ_WORD(f)] & bit)) {
                 const uint32_t old = atomicOr(&nz[LOB_NZ_WORD(f)], bit);
@@ -879,11 +931,10 @@ __global__ void __launch_bounds__(LOB_BLOCK) features_kernel(DevParams P, const 
     __shared__ LearnLds L;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int s = blockIdx.x * LOB_WAVES_PER_BLOCK + w;
-    learn_lds_init(rnd_g, (const f32*)nullptr, false, L);
+    learn_stage_table(rnd_g, L);
     if (s >= n) return;
     if (lane < 16) L.vars[w][0][lane] = lane < P.V ? vars[(size_t)s * P.V + lane] : 0.0f;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local");
-    __builtin_amdgcn_wave_barrier();
+    wave_lds_fence();
     if (out_idx) {
         for (int p = lane; p < 96; p += 64) {
             const int g = p >> 5, j = p & 31;
@@ -907,7 +958,8 @@ __global__ void delta_begin_kernel(const f64* __restrict__ theta, const f64* __r
     const i64 stride = (i64)gridDim.x * blockDim.x;
     for (; i < M; i += stride) delta[i] = theta[i] - sync[i];
 }
-__global__ void delta_apply_kernel(f64* theta, f64* sync, const f64* __restrict__ delta, uint32_t* nz, i32* nz_epoch, i64 M) {
+__global__ void delta_apply_kernel(f64* theta, f64* sync, const f64* __restrict__ delta, uint32_t* nz, i32* nz_epoch, i64 M,
+                                   uint32_t* nzx, uint32_t* nzc, int cshift) {
     i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) atomicAdd(nz_epoch, 1);  // verdicts saved before this exchange are stale
     const i64 stride = (i64)gridDim.x * blockDim.x;
@@ -919,6 +971,24 @@ __global__ void delta_apply_kernel(f64* theta, f64* sync, const f64* __restrict_
         if (d != 0.0) {  // written on some rank: from now on the weight must be fetched
             const uint32_t bit = LOB_NZ_BIT(i);
             if (!(nz[LOB_NZ_WORD(i)] & bit)) atomicOr(&nz[LOB_NZ_WORD(i)], bit);
+            if (nzx) {  // the fast path's maps (theta only)
+                const uint32_t xb = 1u << ((uint32_t)i & 31);
+                if (!(nzx[(uint32_t)i >> 5] & xb)) atomicOr(&nzx[(uint32_t)i >> 5], xb);
+                const uint32_t c = (uint32_t)i >> cshift;
+                if (!(nzc[c >> 5] & (1u << (c & 31)))) atomicOr(&nzc[c >> 5], 1u << (c & 31));
+            }
+        }
+    }
+}
+// the fast path's maps after lob_theta_set (both cleared by the caller first): bit = (theta != +0.0 bitwise)
+__global__ void rebuild_nzx_kernel(const f64* __restrict__ theta, uint32_t* nzx, uint32_t* nzc, int cshift, i64 M) {
+    i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (; i < M; i += stride) {
+        if (__double_as_longlong(theta[i]) != 0) {
+            atomicOr(&nzx[(uint32_t)i >> 5], 1u << ((uint32_t)i & 31));
+            const uint32_t c = (uint32_t)i >> cshift;
+            atomicOr(&nzc[c >> 5], 1u << (c & 31));
         }
     }
 }

@@ -13,6 +13,26 @@
 #include "lob_state.h"
 #include "lob_stream.h"
 
+// Phase clocks of the wave-per-book kernels: -DLOB_PROF builds stamp clock64 at phase boundaries (lane 0
+// of every wave adds the elapsed clocks to its book's row); a regular build compiles them away.
+#ifdef LOB_PROF
+struct Prof {
+    long long t;
+    i64* row;
+    __device__ void start(i64* prof, int book, int lane) { row = (prof && lane == 0) ? prof + (size_t)book * LOB_PROF_N : nullptr; t = clock64(); }
+    __device__ void mark(int i) {
+        const long long n = clock64();
+        if (row) row[i] += n - t;
+        t = n;
+    }
+};
+#else
+struct Prof {
+    __device__ void start(i64*, int, int) {}
+    __device__ void mark(int) {}
+};
+#endif
+
 #define LOB_QSTRIDE 33  // 32 tiles of one group + 1 pad double: lanes a=0..8 read column i without bank conflicts
 #define LOB_HSLOTS 512  // per-wave LDS hash map (64-bit slots: tile index | rank) of the 288 "current" tiles
 
@@ -369,62 +389,11 @@ __device__ inline f64 readlane_f64(f64 x, int l) {  // l wave-uniform
     return __hiloint2double(hi, lo);
 }
 
-// Q(s, .) continued from the memoised group-0 partial sums `s0` (wave-uniform, computed by
-// memo_kernel in the reference's order under the same theta).  Lane l < 32: tiling l of group 1
-// (variables 3..V), lane 32 + l: tiling l of group 2 (all V variables); nine actions each: 9 map
-// look-ups per lane and a fetch only where the map says "written".  The remaining 96 terms of
-// Agent::getQ (group 1 with w1, group 1 again and group 2 with w2: quirk Q3) are then added IN THE
-// REFERENCE'S ORDER, skipping exact zeros: q is never -0.0 (the sum starts at +0.0), so adding
-// w * (+-0.0) leaves every bit of q unchanged and only the non-zero weights need visiting.
-// `qv`: lane i holds the quantised variable i (tile_quant), as in q_values.
-__device__ inline void q_values_memo(const DevParams& P, const f64* __restrict__ theta, const uint32_t* __restrict__ nz,
-                                     int qv, const uint32_t* rnd, const uint32_t* terms, int lane, const f64* s0, f64* out_q) {
-    const int j = lane & 31;
-    const bool hi = lane >= 32;
-    const uint32_t M = (uint32_t)P.M;
-    const int first = hi ? 0 : 3, nf = hi ? P.V : P.V - 3;
-    uint32_t sum = 0;
-    {
-        int base = j;
-        for (int i = 0; i < P.V; i++) {  // wave-uniform trip count; group-1 lanes sit out the last three
-            const int q = __shfl(qv, first + i);
-            const uint32_t t = rnd[(tile_coord(q, base) + 449 * i) & 2047];
-            if (i < nf) sum = mod_add(sum, t, M);
-            base += 2 * j;
-        }
-        sum = mod_add(sum, rnd[(j + 449 * nf) & 2047], M);
-    }
-    const uint32_t* tg = terms + (hi ? 2 * LOB_N_ACTIONS : LOB_N_ACTIONS);
-    i32 idx[LOB_N_ACTIONS];
-    uint32_t w[LOB_N_ACTIONS];
-#pragma unroll
-    for (int a = 0; a < LOB_N_ACTIONS; a++) idx[a] = tile_index(sum, tg[a], M);
-#pragma unroll
-    for (int a = 0; a < LOB_N_ACTIONS; a++) w[a] = nz[LOB_NZ_WORD(idx[a])];
-    f64 v[LOB_N_ACTIONS];
-    bool any = false;
-#pragma unroll
-    for (int a = 0; a < LOB_N_ACTIONS; a++) {
-        v[a] = 0.0;
-        if (w[a] & LOB_NZ_BIT(idx[a])) v[a] = theta[idx[a]];
-        any |= v[a] != 0.0;
-    }
-#pragma unroll
-    for (int a = 0; a < LOB_N_ACTIONS; a++) out_q[a] = s0[a];
-    if (__ballot(any) == 0) return;  // nothing written among the 576 group-1/2 tiles: Q = S0 exactly
-    const f64 w1 = P.w1, w2 = P.w2;
-#pragma unroll
-    for (int a = 0; a < LOB_N_ACTIONS; a++) {
-        const u64 m = __ballot(v[a] != 0.0);
-        if (m == 0) continue;
-        f64 q = out_q[a];
-        for (uint32_t mm = (uint32_t)m; mm; mm &= mm - 1) q += w1 * readlane_f64(v[a], __builtin_ctz(mm));
-        for (uint32_t mm = (uint32_t)m; mm; mm &= mm - 1) q += w2 * readlane_f64(v[a], __builtin_ctz(mm));
-        for (uint32_t mm = (uint32_t)(m >> 32); mm; mm &= mm - 1) q += w2 * readlane_f64(v[a], 32 + __builtin_ctz(mm));
-        out_q[a] = q;
-    }
-}
-
+struct MemoRec {  // one record of DevState::mk_rec
+    f64 s0[LOB_N_ACTIONS];
+    u64 ver;
+};
+static_assert(sizeof(MemoRec) == LOB_MK_REC * 8, "memo record layout");
 
 // ---- std::mt19937_64 (the reference's Agent::gen, include/rl/agent.h:37; C++ standard
 // [rand.predef]: w=64 n=312 m=156 r=31 a=0xB5026F5AA96619E9 u=29 d=0x5555555555555555 s=17

@@ -123,6 +123,7 @@ struct __attribute__((aligned(64))) LHdr {
 };
 
 #define LOB_PERSIST_N 32
+#define LOB_PROF_N 32
 #define LOB_MK_REC 10         /* doubles per memo record: S0 of the nine actions + the theta version it was computed under */
 #define LOB_MK_PROBES 16
 #define LOB_VD_STRIDE 72      /* u16 per book: 64 verdicts + epoch lo/hi + slot + valid, padded to 144 B */
@@ -224,9 +225,17 @@ struct DevState {
     f64* mk_rec;         // [2: theta_t for learn, theta_{t+1} for the next act][mk_slots][LOB_MK_REC]: S0[9], theta version tag
     i32* mk_slot;        // [B] slot of the book's latest state (-1: none)
     i32 mk_slots;        // power of two
+    // Fast learner path (lob_fast.h): exact "ever written" map of the shared theta (one bit per weight) and
+    // its coarse image (one bit per 2^cshift weights) that every CU keeps in LDS; work lists of the books
+    // the fast kernels hand back to the general ones.
+    uint32_t* theta_nzx; // [M / 32 + 1]
+    uint32_t* theta_nzc; // [cwords4 * 4]
+    i32* slow_list;      // [2 kinds: act, learn][B]
+    i32* slow_n;         // [2 parities][2 kinds]
     f64* theta_sync;  // [M] (multi-GPU) or null
     f64* delta;       // [M] scratch for the all-reduce or null
     i64* counters;    // [8] device counters
+    i64* prof;        // [B][LOB_PROF_N] clock64 per phase of the learner kernels (-DLOB_PROF builds only, tools/exp_prof.py), else null
     i32* error_flag;  // [1] bits: reference-would-throw conditions
 };
 
@@ -258,7 +267,8 @@ struct DevParams {
     i32 algo, theta_private;
     i32 combine;         // shared theta: sum the updates per distinct trace generation first (0 with LOB_NO_COMBINE=1)
     i32 carry_verdicts;  // 0 with LOB_NO_CARRY=1 in the environment (A/B switch for the verdict carry-over)
-    i32 memo;            // group-0 memo on (shared theta, SARSA / Q(lambda), one book group; 0 with LOB_NO_MEMO=1)
+    i32 memo;            // group-0 memo + fast learner kernels on (shared theta, SARSA / Q(lambda), one book group; 0 with LOB_NO_MEMO=1)
+    i32 cshift, cwords4; // coarse map: bit = weight index >> cshift; size in 16-byte units
     u64 seed, book_id_offset;
 };
 
