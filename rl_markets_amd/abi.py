@@ -98,7 +98,8 @@ class BookDump(C.Structure):
 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "liblob_engine.so")
+# LOB_ENGINE_LIB: an experiment build of the same library (tools/exp_prof.py, tools/exp_variants.sh)
+LIB_PATH = os.environ.get("LOB_ENGINE_LIB") or os.path.join(_HERE, "csrc", "liblob_engine.so")
 
 
 class EngineLibraryMissing(RuntimeError):

@@ -367,10 +367,12 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) e->n_cus = prop.multiProcessorCount;
         if (P.memo) {
-            const int act_lds = (int)fast_lds_bytes(P.cwords4, false), learn_lds = (int)fast_lds_bytes(P.cwords4, true);
-            hipError_t er = hipFuncSetAttribute((const void*)act_fast_kernel<LOB_ALGO_SARSA>, hipFuncAttributeMaxDynamicSharedMemorySize, act_lds);
-            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_fast_kernel<LOB_ALGO_SARSA>, hipFuncAttributeMaxDynamicSharedMemorySize, learn_lds);
-            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_fast_kernel<LOB_ALGO_QLAMBDA>, hipFuncAttributeMaxDynamicSharedMemorySize, learn_lds);
+            const int q_lds = (int)fast_lds_bytes(P.cwords4, LOB_FAST_NB, false), tr_lds = (int)trace_lds_bytes();
+            hipError_t er = hipFuncSetAttribute((const void*)act_fast_kernel<LOB_FAST_NB>, hipFuncAttributeMaxDynamicSharedMemorySize, q_lds);
+            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_fast_kernel<LOB_ALGO_SARSA, LOB_FAST_NB>, hipFuncAttributeMaxDynamicSharedMemorySize, q_lds);
+            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_fast_kernel<LOB_ALGO_QLAMBDA, LOB_FAST_NB>, hipFuncAttributeMaxDynamicSharedMemorySize, q_lds);
+            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)trace_fast_kernel<LOB_ALGO_SARSA>, hipFuncAttributeMaxDynamicSharedMemorySize, tr_lds);
+            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)trace_fast_kernel<LOB_ALGO_QLAMBDA>, hipFuncAttributeMaxDynamicSharedMemorySize, tr_lds);
             if (er != hipSuccess && rc == LOB_OK) { lob_set_error(std::string("hipFuncSetAttribute(dynamic LDS): ") + hipGetErrorString(er)); rc = LOB_EHIP; }
         }
     }
@@ -688,7 +690,7 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode) {
             const int b0 = (int)((long long)e->B * g / G), nb = (int)((long long)e->B * (g + 1) / G) - b0;
             const int gw = grid_waves(nb);
             // the persistent kernels: one 16-wave block per CU; the general kernels then serve the books handed back
-            const int gf = std::min(e->n_cus, (nb + LOB_FAST_WAVES - 1) / LOB_FAST_WAVES), gl = 2 * e->n_cus;
+            const int gf = std::min(e->n_cus, (nb + LOB_FAST_WAVES * LOB_FAST_NB - 1) / (LOB_FAST_WAVES * LOB_FAST_NB)), gl = 2 * e->n_cus;
             const i32* act_list = e->S.slow_list, *learn_list = e->S.slow_list + e->B;
             const i32* act_n = e->S.slow_n + lpar * 2, *learn_n = e->S.slow_n + lpar * 2 + 1;
             // stagger: group 1 starts acting when group 0 has finished acting, so that the
@@ -697,7 +699,7 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode) {
             if (fast) {
                 {
                     TimedLaunch t(e, "act_kernel", st);
-                    hipLaunchKernelGGL(act_fast_kernel<LOB_ALGO_SARSA>, dim3(gf), dim3(LOB_FAST_BLOCK), fast_lds_bytes(e->P.cwords4, false), st, e->P, e->S, rnd, mode, par, lpar, ver);
+                    hipLaunchKernelGGL(act_fast_kernel<LOB_FAST_NB>, dim3(gf), dim3(LOB_FAST_BLOCK), fast_lds_bytes(e->P.cwords4, LOB_FAST_NB, false), st, e->P, e->S, rnd, mode, par, lpar, ver);
                 }
                 {
                     TimedLaunch t(e, "act_rest_kernel", st);
@@ -716,14 +718,20 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode) {
             if (fast) launch_memo(e, par, mode == 0 ? 0 : 1);  // learner: S0 under theta_t for learn_kernel; backtester: for the next act
             if (mode == 0 && fast) {
                 {
+                    TimedLaunch t(e, "trace_kernel", st);
+                    const int gt = std::min(2 * e->n_cus, (nb + LOB_FAST_WAVES - 1) / LOB_FAST_WAVES);
+                    if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL(trace_fast_kernel<LOB_ALGO_QLAMBDA>, dim3(gt), dim3(LOB_FAST_BLOCK), trace_lds_bytes(), st, e->P, e->S, rnd, par);
+                    else hipLaunchKernelGGL(trace_fast_kernel<LOB_ALGO_SARSA>, dim3(gt), dim3(LOB_FAST_BLOCK), trace_lds_bytes(), st, e->P, e->S, rnd, par);
+                }
+                {
                     TimedLaunch t(e, "learn_kernel", st);
-                    if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL(learn_fast_kernel<LOB_ALGO_QLAMBDA>, dim3(gf), dim3(LOB_FAST_BLOCK), fast_lds_bytes(e->P.cwords4, true), st, e->P, e->S, rnd, par, lpar, ver);
-                    else hipLaunchKernelGGL(learn_fast_kernel<LOB_ALGO_SARSA>, dim3(gf), dim3(LOB_FAST_BLOCK), fast_lds_bytes(e->P.cwords4, true), st, e->P, e->S, rnd, par, lpar, ver);
+                    if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL((learn_q_fast_kernel<LOB_ALGO_QLAMBDA, LOB_FAST_NB>), dim3(gf), dim3(LOB_FAST_BLOCK), fast_lds_bytes(e->P.cwords4, LOB_FAST_NB, false), st, e->P, e->S, rnd, lpar, ver);
+                    else hipLaunchKernelGGL((learn_q_fast_kernel<LOB_ALGO_SARSA, LOB_FAST_NB>), dim3(gf), dim3(LOB_FAST_BLOCK), fast_lds_bytes(e->P.cwords4, LOB_FAST_NB, false), st, e->P, e->S, rnd, lpar, ver);
                 }
                 {
                     TimedLaunch t(e, "learn_rest_kernel", st);
-                    if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL((learn_kernel<LOB_ALGO_QLAMBDA, true>), dim3(gl), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, 0, e->B, par, learn_list, learn_n);
-                    else hipLaunchKernelGGL((learn_kernel<LOB_ALGO_SARSA, true>), dim3(gl), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, 0, e->B, par, learn_list, learn_n);
+                    if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL(learn_q_rest_kernel<LOB_ALGO_QLAMBDA>, dim3(gl), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, learn_list, learn_n);
+                    else hipLaunchKernelGGL(learn_q_rest_kernel<LOB_ALGO_SARSA>, dim3(gl), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, learn_list, learn_n);
                 }
             } else if (mode == 0) {
                 TimedLaunch t(e, "learn_kernel", st);

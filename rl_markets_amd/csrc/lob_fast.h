@@ -22,9 +22,12 @@
 #define LOB_FAST_WAVES 16
 #define LOB_FAST_BLOCK (64 * LOB_FAST_WAVES)
 
-// dynamic LDS image: [rnd 2048][act_terms 32][coarse cwords4 * 4][vars NW x 48 f32]([tab NW x LOB_HSLOTS u64])
-__host__ __device__ inline size_t fast_lds_bytes(int cwords4, bool with_tab) {
-    return (size_t)(2048 + 32 + cwords4 * 4) * 4 + (size_t)LOB_FAST_WAVES * 48 * 4 + (with_tab ? (size_t)LOB_FAST_WAVES * LOB_HSLOTS * 8 : 0);
+#ifndef LOB_FAST_NB
+#define LOB_FAST_NB 2  /* books a wave of the Q kernels takes through the stages together */
+#endif
+// dynamic LDS image: [rnd 2048][act_terms 32][coarse cwords4 * 4][vars NW x rows x 48 f32]([tab NW x LOB_HSLOTS u64])
+__host__ __device__ inline size_t fast_lds_bytes(int cwords4, int rows, bool with_tab) {
+    return (size_t)(2048 + 32 + cwords4 * 4) * 4 + (size_t)LOB_FAST_WAVES * rows * 48 * 4 + (with_tab ? (size_t)LOB_FAST_WAVES * LOB_HSLOTS * 8 : 0);
 }
 
 struct FastLds {
@@ -35,15 +38,15 @@ struct FastLds {
     u64* tab;   // this wave's hash map (learn) or null
 };
 
-__device__ inline FastLds fast_stage(unsigned char* raw, const DevParams& P, const DevState& S, const uint32_t* __restrict__ rnd_g, bool with_tab) {
+__device__ inline FastLds fast_stage(unsigned char* raw, const DevParams& P, const DevState& S, const uint32_t* __restrict__ rnd_g, int rows, bool with_tab) {
     FastLds L;
     L.rnd = reinterpret_cast<uint32_t*>(raw);
     L.act_terms = L.rnd + 2048;
     L.coarse = L.act_terms + 32;
     f32* vars_all = reinterpret_cast<f32*>(L.coarse + (size_t)P.cwords4 * 4);
     const int w = threadIdx.x >> 6;
-    L.vars = vars_all + w * 48;
-    L.tab = with_tab ? reinterpret_cast<u64*>(vars_all + LOB_FAST_WAVES * 48) + (size_t)w * LOB_HSLOTS : nullptr;
+    L.vars = vars_all + w * rows * 48;
+    L.tab = with_tab ? reinterpret_cast<u64*>(vars_all + LOB_FAST_WAVES * rows * 48) + (size_t)w * LOB_HSLOTS : nullptr;
     {
         const uint4* src = reinterpret_cast<const uint4*>(rnd_g);
         uint4* dst = reinterpret_cast<uint4*>(L.rnd);
@@ -84,67 +87,114 @@ __device__ __forceinline__ uint32_t fast_base(const DevParams& P, int qv, int la
     return sum;
 }
 
-// Q(s, .) for the nine actions, continued from the memoised group-0 sums `s0` (wave-uniform).
-__device__ __forceinline__ void q_values_fast(const DevParams& P, const DevState& S, const FastLds& L, int qv, int lane, const f64* s0, f64* out_q,
-                                     Prof& pf, int pf0) {
+// Q(s, .) for the nine actions of NB books at once, continued from the memoised group-0 sums (wave-uniform).
+// The books of a batch go through every stage together, so that a stage's LDS reads / map words / weights
+// of ALL of them are in flight before the first is consumed: the kernel is a chain of dependent
+// look-ups per book and a CU holds only 16 waves (the LDS image), so the parallelism has to come from
+// inside the wave.  No branches on per-book conditions in here: a book that is not `go` computes on
+// whatever its (valid) inputs are and its result is ignored by the caller.
+template <int NB>
+__device__ __forceinline__ void q_values_fast(const DevParams& P, const DevState& S, const FastLds& L, const int* qv, int lane,
+                                              const MemoRec* rec, f64 (*out_q)[LOB_N_ACTIONS], Prof& pf, int pf0) {
     const bool hi = lane >= 32;
     const uint32_t M = (uint32_t)P.M;
-    const uint32_t sum = fast_base(P, qv, lane, L.rnd);
+    uint32_t sum[NB];
+#pragma unroll
+    for (int k = 0; k < NB; k++) sum[k] = fast_base(P, qv[k], lane, L.rnd);
     pf.mark(pf0);  // tile hashing
     const uint32_t* tg = L.act_terms + (hi ? 2 * LOB_N_ACTIONS : LOB_N_ACTIONS);
-    i32 idx[LOB_N_ACTIONS];
-    uint32_t cw[LOB_N_ACTIONS];
+    uint32_t term[LOB_N_ACTIONS];
 #pragma unroll
-    for (int a = 0; a < LOB_N_ACTIONS; a++) idx[a] = tile_index(sum, tg[a], M);
+    for (int a = 0; a < LOB_N_ACTIONS; a++) term[a] = tg[a];
+    i32 idx[NB][LOB_N_ACTIONS];
+    uint32_t cw[NB][LOB_N_ACTIONS];
     const int cs = P.cshift;
 #pragma unroll
-    for (int a = 0; a < LOB_N_ACTIONS; a++) cw[a] = L.coarse[(uint32_t)idx[a] >> (cs + 5)];
-    uint32_t maybe = 0;
+    for (int k = 0; k < NB; k++)
 #pragma unroll
-    for (int a = 0; a < LOB_N_ACTIONS; a++) maybe |= ((cw[a] >> (((uint32_t)idx[a] >> cs) & 31)) & 1u) << a;
+        for (int a = 0; a < LOB_N_ACTIONS; a++) {
+            idx[k][a] = tile_index(sum[k], term[a], M);
+            cw[k][a] = L.coarse[(uint32_t)idx[k][a] >> (cs + 5)];
+        }
+    uint32_t maybe[NB];
+    bool any_maybe = false;
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+        maybe[k] = 0;
+#pragma unroll
+        for (int a = 0; a < LOB_N_ACTIONS; a++) maybe[k] |= ((cw[k][a] >> (((uint32_t)idx[k][a] >> cs) & 31)) & 1u) << a;
+        any_maybe |= maybe[k] != 0;
+    }
     pf.mark(pf0 + 1);  // coarse filter (LDS)
 #pragma unroll
-    for (int a = 0; a < LOB_N_ACTIONS; a++) out_q[a] = s0[a];
-    if (__ballot(maybe != 0) == 0) { pf.mark(pf0 + 2); return; }
-    uint32_t xw[LOB_N_ACTIONS];
+    for (int k = 0; k < NB; k++)
 #pragma unroll
-    for (int a = 0; a < LOB_N_ACTIONS; a++) {
-        xw[a] = 0;
-        if ((maybe >> a) & 1u) xw[a] = S.theta_nzx[(uint32_t)idx[a] >> 5];
+        for (int a = 0; a < LOB_N_ACTIONS; a++) out_q[k][a] = rec[k].s0[a];
+    if (__ballot(any_maybe) == 0) { pf.mark(pf0 + 2); return; }
+    uint32_t hit[NB];
+    bool any_hit = false;
+    {
+        uint32_t xw[NB][LOB_N_ACTIONS];
+#pragma unroll
+        for (int k = 0; k < NB; k++)
+#pragma unroll
+            for (int a = 0; a < LOB_N_ACTIONS; a++) {
+                xw[k][a] = 0;
+                if ((maybe[k] >> a) & 1u) xw[k][a] = S.theta_nzx[(uint32_t)idx[k][a] >> 5];
+            }
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            hit[k] = 0;
+#pragma unroll
+            for (int a = 0; a < LOB_N_ACTIONS; a++) hit[k] |= ((xw[k][a] >> ((uint32_t)idx[k][a] & 31)) & 1u) << a;
+            any_hit |= hit[k] != 0;
+        }
     }
-    uint32_t hit = 0;
-#pragma unroll
-    for (int a = 0; a < LOB_N_ACTIONS; a++) hit |= ((xw[a] >> ((uint32_t)idx[a] & 31)) & 1u) << a;
-    const bool none = __ballot(hit != 0) == 0;
+    const bool none = __ballot(any_hit) == 0;
     pf.mark(pf0 + 2);  // exact map for the coarse hits
     if (none) return;
-    f64 v[LOB_N_ACTIONS];
-#pragma unroll
-    for (int a = 0; a < LOB_N_ACTIONS; a++) {
-        v[a] = 0.0;
-        if ((hit >> a) & 1u) v[a] = S.theta[idx[a]];
-    }
+    // A lane rarely has more than one written weight among its 9 x NB tiles: fetch the first two of each
+    // book up front (in flight together), anything beyond that on demand.
     const f64 w1 = P.w1, w2 = P.w2;
+    f64 v0[NB], v1[NB];
+    int a0[NB], a1[NB];
 #pragma unroll
-    for (int a = 0; a < LOB_N_ACTIONS; a++) {
-        const u64 m = __ballot(v[a] != 0.0);
-        if (m == 0) continue;
-        // group 1 with w1, group 1 again with w2 (quirk Q3), group 2 with w2: tilings in ascending order
-        f64 q = out_q[a];
-        for (uint32_t mm = (uint32_t)m; mm; mm &= mm - 1) q += w1 * readlane_f64(v[a], __builtin_ctz(mm));
-        for (uint32_t mm = (uint32_t)m; mm; mm &= mm - 1) q += w2 * readlane_f64(v[a], __builtin_ctz(mm));
-        for (uint32_t mm = (uint32_t)(m >> 32); mm; mm &= mm - 1) q += w2 * readlane_f64(v[a], 32 + __builtin_ctz(mm));
-        out_q[a] = q;
+    for (int k = 0; k < NB; k++) {
+        a0[k] = hit[k] ? __builtin_ctz(hit[k]) : -1;
+        const uint32_t r = hit[k] & (hit[k] - 1);
+        a1[k] = r ? __builtin_ctz(r) : -1;
+        i32 i0 = 0, i1 = 0;
+#pragma unroll
+        for (int a = 0; a < LOB_N_ACTIONS; a++) { i0 = a0[k] == a ? idx[k][a] : i0; i1 = a1[k] == a ? idx[k][a] : i1; }
+        v0[k] = 0.0; v1[k] = 0.0;
+        if (a0[k] >= 0) v0[k] = S.theta[i0];
+        if (a1[k] >= 0) v1[k] = S.theta[i1];
+    }
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+        if (__ballot(hit[k] != 0) == 0) continue;
+#pragma unroll
+        for (int a = 0; a < LOB_N_ACTIONS; a++) {
+            const bool mine = (hit[k] >> a) & 1u;
+            if (__ballot(mine) == 0) continue;
+            f64 v = 0.0;
+            if (mine) v = a0[k] == a ? v0[k] : (a1[k] == a ? v1[k] : S.theta[idx[k][a]]);
+            const u64 m = __ballot(v != 0.0);
+            if (m == 0) continue;
+            // group 1 with w1, group 1 again with w2 (quirk Q3), group 2 with w2: tilings in ascending order
+            f64 q = out_q[k][a];
+            for (uint32_t mm = (uint32_t)m; mm; mm &= mm - 1) q += w1 * readlane_f64(v, __builtin_ctz(mm));
+            for (uint32_t mm = (uint32_t)m; mm; mm &= mm - 1) q += w2 * readlane_f64(v, __builtin_ctz(mm));
+            for (uint32_t mm = (uint32_t)(m >> 32); mm; mm &= mm - 1) q += w2 * readlane_f64(v, 32 + __builtin_ctz(mm));
+            out_q[k][a] = q;
+        }
     }
     pf.mark(pf0 + 3);  // written weights + ordered continuation
 }
 
-// Does the book's memo record (`which` 0: under theta_t, 1: after the last update) belong to the
-// State whose quantised variables are in `qv`, and to the current weights?
-__device__ inline bool fast_memo_ok(const DevState& S, int mslot, int which, u64 ver, int qv, MemoRec& rec) {
-    const int ms = mslot >= 0 ? mslot : 0;
-    const int4 mid = *reinterpret_cast<const int4*>(S.mk_ident + (size_t)ms * 4);
-    rec = *reinterpret_cast<const MemoRec*>(S.mk_rec + ((size_t)which * S.mk_slots + ms) * LOB_MK_REC);
+// Does the memo record `rec` of slot `mslot` (`ident` its triple) belong to the State whose quantised
+// variables are in `qv`, and to the current weights?
+__device__ inline bool fast_memo_ok(int mslot, const int4& mid, const MemoRec& rec, u64 ver, int qv) {
     return mslot >= 0 && rec.ver == ver && mid.x == __builtin_amdgcn_readlane(qv, 0) && mid.y == __builtin_amdgcn_readlane(qv, 1) &&
            mid.z == __builtin_amdgcn_readlane(qv, 2);
 }
@@ -155,9 +205,9 @@ __device__ inline void fast_hand_back(const DevState& S, int kind, int lpar, int
     }
 }
 
-// Learner::_step / Backtester::_step prologue for every book (see act_book).  `lpar`: parity of the
-// work lists of this step.
-template <int ALGO>
+// Learner::_step / Backtester::_step prologue for every book (see act_book), NB books of a wave at a time.
+// `lpar`: parity of the work lists of this step.
+template <int NB>
 __global__ void __launch_bounds__(LOB_FAST_BLOCK) act_fast_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g, int mode,
                                                                   int par, int lpar, u64 ver) {
     extern __shared__ __align__(16) unsigned char fast_lds_raw[];
@@ -167,61 +217,104 @@ __global__ void __launch_bounds__(LOB_FAST_BLOCK) act_fast_kernel(DevParams P, D
         S.slow_n[(lpar ^ 1) * 2 + 0] = 0;  // the next step's work lists
         S.slow_n[(lpar ^ 1) * 2 + 1] = 0;
     }
-    const FastLds L = fast_stage(fast_lds_raw, P, S, rnd_g, false);
+    const FastLds L = fast_stage(fast_lds_raw, P, S, rnd_g, NB, false);
     const int w = threadIdx.x >> 6;
+    const int stride = gridDim.x * LOB_FAST_WAVES;
     int lane_ = threadIdx.x & 63;
 #pragma unroll 1
-    for (int t = blockIdx.x * LOB_FAST_WAVES + w; t < S.B; t += gridDim.x * LOB_FAST_WAVES) {
-        asm volatile("" : "+v"(lane_));  // nothing lane-dependent is carried (kept in registers) across books
+    for (int t0 = blockIdx.x * LOB_FAST_WAVES + w; t0 < S.B; t0 += stride * NB) {
+        asm volatile("" : "+v"(lane_));  // nothing lane-dependent is carried (kept in registers) across iterations
         const int lane = lane_;
-        const int b = __builtin_amdgcn_readfirstlane(t);
-        const LHdr h = S.hdr[b];
-        const int mslot = S.mk_slot[b];
+        int b[NB], mslot[NB];
+        bool go[NB];
+        LHdr h[NB];
+        f32 vv[NB];
         Prof pf;
-        pf.start(S.prof, b, lane);
-        learn_stage_vars(S.vars + (size_t)b * 48, L.vars, lane);
-        LHdr* hp = S.hdr + b;
-        if (h.done) { if (lane == 0) hp->stepped = 0; continue; }
-        int cur = h.slot_cur;
-        if (mode == 0) cur ^= 1;  // swap(state, last_state)
-        if (!is_open(P, h.time_ms)) {  // environment.isTerminal()
-            if (lane == 0) { hp->slot_cur = cur; hp->done = 1; hp->stepped = 0; S.done[b] = 1; }
-            continue;
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            const int t = __builtin_amdgcn_readfirstlane(t0 + k * stride);
+            go[k] = t < S.B;
+            b[k] = go[k] ? t : 0;
+            h[k] = S.hdr[b[k]];
+            mslot[k] = S.mk_slot[b[k]];
+            vv[k] = lane < 48 ? S.vars[(size_t)b[k] * 48 + lane] : 0.0f;
         }
-        const int src = mode == 0 ? (cur ^ 1) : 2;
-        const bool zero = mode == 0 && ((h.zero_mask >> src) & 1);
-        const int qv = tile_quant(L.vars[src * 16 + (lane & 15)]);
-        MemoRec rec;
-        if (!fast_memo_ok(S, zero ? -1 : mslot, 1, ver, qv, rec)) { fast_hand_back(S, 0, lpar, b, lane); continue; }
+        pf.start(S.prof, b[0], lane);
+        wave_lds_fence();  // the previous batch's readers are done with the rows
+#pragma unroll
+        for (int k = 0; k < NB; k++)
+            if (lane < 48) L.vars[k * 48 + lane] = vv[k];
+        wave_lds_fence();
+        int cur[NB], qv[NB];
+        int4 mid[NB];
+        MemoRec rec[NB];
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            LHdr* hp = S.hdr + b[k];
+            cur[k] = h[k].slot_cur ^ (mode == 0 ? 1 : 0);  // swap(state, last_state)
+            if (go[k] && h[k].done) { if (lane == 0) hp->stepped = 0; go[k] = false; }
+            if (go[k] && !is_open(P, h[k].time_ms)) {  // environment.isTerminal()
+                if (lane == 0) { hp->slot_cur = cur[k]; hp->done = 1; hp->stepped = 0; S.done[b[k]] = 1; }
+                go[k] = false;
+            }
+            // the State the action is computed from: last_state (learner) / latest getState() (backtester)
+            const int src = mode == 0 ? (cur[k] ^ 1) : 2;
+            const bool zero = mode == 0 && ((h[k].zero_mask >> src) & 1);
+            if (zero) mslot[k] = -1;
+            qv[k] = tile_quant(L.vars[k * 48 + src * 16 + (lane & 15)]);
+            const int ms = mslot[k] >= 0 ? mslot[k] : 0;
+            mid[k] = *reinterpret_cast<const int4*>(S.mk_ident + (size_t)ms * 4);
+            rec[k] = *reinterpret_cast<const MemoRec*>(S.mk_rec + ((size_t)S.mk_slots + ms) * LOB_MK_REC);  // [1]: after the last update
+        }
+#pragma unroll
+        for (int k = 0; k < NB; k++)
+            if (go[k] && !fast_memo_ok(mslot[k], mid[k], rec[k], ver, qv[k])) { fast_hand_back(S, 0, lpar, b[k], lane); go[k] = false; }
         pf.mark(0);  // header, memo record, state variables
-        f64 qs[LOB_N_ACTIONS];
-        q_values_fast(P, S, L, qv, lane, rec.s0, qs, pf, 1);
-        if (lane < LOB_N_ACTIONS) S.qs_last[(size_t)b * LOB_N_ACTIONS + lane] = qs[lane];
-        Rng g{P.seed, P.book_id_offset + (u64)b, h.rng_ctr};
-        const int action = policy_sample(qs, P.epsilon, mode == 1, g);
-        if (lane == 0) {
-            hp->slot_cur = cur;
-            hp->action = action;
-            hp->stepped = 1;
-            hp->rng_ctr = g.ctr;
+        f64 qs[NB][LOB_N_ACTIONS];
+        q_values_fast<NB>(P, S, L, qv, lane, rec, qs, pf, 1);
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            if (!go[k]) continue;
+            if (lane < LOB_N_ACTIONS) S.qs_last[(size_t)b[k] * LOB_N_ACTIONS + lane] = sel9(qs[k], lane);
+            Rng g{P.seed, P.book_id_offset + (u64)b[k], h[k].rng_ctr};
+            const int action = policy_sample(qs[k], P.epsilon, mode == 1, g);
+            if (lane == 0) {
+                LHdr* hp = S.hdr + b[k];
+                hp->slot_cur = cur[k];
+                hp->action = action;
+                hp->stepped = 1;
+                hp->rng_ctr = g.ctr;
+            }
         }
         pf.mark(5);  // policy + stores
     }
 }
 
-// Agent::HandleTransition up to updateQ for every book that stepped (see learn_book).
+// Agent::UpdateTraces for every book that stepped (learn_traces), the first half of learn_book; leaves
+// Q(s, a) in LHdr::td and the RNG counter after its draws in LHdr::rng_ctr for the second half
+// (learn_q_fast_kernel).  Persistent 16-wave blocks, two per CU (75 KB of LDS each: the hash table and a
+// 4 KB tile map per wave).  A book's slot claims are resolved one book later, so that their CAS round
+// trips overlap the next book's work.
 template <int ALGO>
-__global__ void __launch_bounds__(LOB_FAST_BLOCK) learn_fast_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g, int par,
-                                                                    int lpar, u64 ver) {
-    static_assert(ALGO == LOB_ALGO_SARSA || ALGO == LOB_ALGO_QLAMBDA, "one weight vector");
+__global__ void __launch_bounds__(LOB_FAST_BLOCK, 8) trace_fast_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g, int par) {
     extern __shared__ __align__(16) unsigned char fast_lds_raw[];
     // this step's update appends to nz_new[par]; the list the general act path reads is nz_new[par ^ 1]
     if (blockIdx.x == 0 && threadIdx.x < LOB_NZ_WORDS) {
         S.nz_new[par * LOB_NZ_WORDS + threadIdx.x] = 0;
         S.nz_new[(2 + par) * LOB_NZ_WORDS + threadIdx.x] = 0;
     }
-    const FastLds L = fast_stage(fast_lds_raw, P, S, rnd_g, true);
+    uint32_t* rnd = reinterpret_cast<uint32_t*>(fast_lds_raw);
+    uint32_t* act_terms = rnd + 2048;
     const int w = threadIdx.x >> 6;
+    f32* vars = reinterpret_cast<f32*>(act_terms + 32) + w * 48;
+    u64* tab = reinterpret_cast<u64*>(reinterpret_cast<f32*>(act_terms + 32) + LOB_FAST_WAVES * 48) + (size_t)w * LOB_HSLOTS;
+    if (threadIdx.x < 512) reinterpret_cast<uint4*>(rnd)[threadIdx.x] = reinterpret_cast<const uint4*>(rnd_g)[threadIdx.x];
+    if (threadIdx.x < 27) act_terms[threadIdx.x] = rnd_g[2048 + threadIdx.x];
+    for (int i = threadIdx.x & 63; i < LOB_TSLOTS / 4; i += 64)  // every wave's tile set starts (and is handed on) empty
+        reinterpret_cast<uint4*>(tab)[i] = make_uint4(LOB_NOTILE, LOB_NOTILE, LOB_NOTILE, LOB_NOTILE);
+    __syncthreads();
+    CbPending prev;
+    prev.active = false;
     int lane_ = threadIdx.x & 63;
 #pragma unroll 1
     for (int t = blockIdx.x * LOB_FAST_WAVES + w; t < S.B; t += gridDim.x * LOB_FAST_WAVES) {
@@ -229,32 +322,90 @@ __global__ void __launch_bounds__(LOB_FAST_BLOCK) learn_fast_kernel(DevParams P,
         const int lane = lane_;
         const int b = __builtin_amdgcn_readfirstlane(t);
         const LHdr h = S.hdr[b];
-        const int mslot = S.mk_slot[b];
         f64 qs_last[LOB_N_ACTIONS];
 #pragma unroll
         for (int a = 0; a < LOB_N_ACTIONS; a++) qs_last[a] = S.qs_last[(size_t)b * LOB_N_ACTIONS + a];
         if (!h.stepped) continue;
         Prof pf;
         pf.start(S.prof, b, lane);
-        learn_stage_vars(S.vars + (size_t)b * 48, L.vars, lane);
-        LHdr* hp = S.hdr + b;
-        const int cur = h.slot_cur, last = cur ^ 1;
+        learn_stage_vars(S.vars + (size_t)b * 48, vars, lane);
+        pf.mark(8);  // header, Q(s, .), state variables
+        const int last = h.slot_cur ^ 1;
         const bool zero_last = (h.zero_mask >> last) & 1;
-        const f32* vars_to = L.vars + cur * 16;
-        const f32* vars_from = L.vars + last * 16;
-        const int qv = tile_quant(vars_to[lane & 15]);
-        MemoRec rec;
-        if (!fast_memo_ok(S, mslot, 0, ver, qv, rec)) { fast_hand_back(S, 1, lpar, b, lane); continue; }  // before anything is modified
-        pf.mark(8);  // header, Q(s, .), memo record, state variables
         Rng g{P.seed, P.book_id_offset + (u64)b, h.rng_ctr};
         CbPending pend;
-        learn_traces<ALGO>(P, S, b, h, L.rnd, L.act_terms, L.tab, vars_from, zero_last, qs_last, g, lane, pend, pf);
-        f64 qs_to[LOB_N_ACTIONS];
-        q_values_fast(P, S, L, qv, lane, rec.s0, qs_to, pf, 13);
-        learn_delta_single<ALGO>(P, hp, h, qs_to, qs_last, g, lane);
-        pf.mark(17);  // argmax / delta / header stores
-        cb_claim_finish(S, pend);
-        pf.mark(18);  // claim finish
+        learn_traces<ALGO>(P, S, b, h, rnd, act_terms, tab, false, vars + last * 16, zero_last, qs_last, g, lane, pend, pf);
+        if (lane == 0) {
+            LHdr* hp = S.hdr + b;
+            hp->td = sel9(qs_last, h.action);  // Q(s, a), for the TD error
+            hp->rng_ctr = g.ctr;
+        }
+        cb_claim_finish(S, prev);
+        prev = pend;
+        pf.mark(18);  // header stores, previous book's claims
+    }
+    cb_claim_finish(S, prev);
+}
+__host__ __device__ inline size_t trace_lds_bytes() { return (size_t)(2048 + 32) * 4 + (size_t)LOB_FAST_WAVES * 48 * 4 + (size_t)LOB_FAST_WAVES * LOB_HSLOTS * 8; }
+
+// The second half of learn_book: Q(to_state, .), the TD error of SARSA / QLearn::UpdateWeights (agent.cpp:282-311).
+template <int ALGO, int NB>
+__global__ void __launch_bounds__(LOB_FAST_BLOCK) learn_q_fast_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g, int lpar,
+                                                                      u64 ver) {
+    static_assert(ALGO == LOB_ALGO_SARSA || ALGO == LOB_ALGO_QLAMBDA, "one weight vector");
+    extern __shared__ __align__(16) unsigned char fast_lds_raw[];
+    const FastLds L = fast_stage(fast_lds_raw, P, S, rnd_g, NB, false);
+    const int w = threadIdx.x >> 6;
+    const int stride = gridDim.x * LOB_FAST_WAVES;
+    int lane_ = threadIdx.x & 63;
+#pragma unroll 1
+    for (int t0 = blockIdx.x * LOB_FAST_WAVES + w; t0 < S.B; t0 += stride * NB) {
+        asm volatile("" : "+v"(lane_));
+        const int lane = lane_;
+        int b[NB], mslot[NB];
+        bool go[NB];
+        LHdr h[NB];
+        f32 vv[NB];
+        Prof pf;
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            const int t = __builtin_amdgcn_readfirstlane(t0 + k * stride);
+            go[k] = t < S.B;
+            b[k] = go[k] ? t : 0;
+            h[k] = S.hdr[b[k]];
+            mslot[k] = S.mk_slot[b[k]];
+            vv[k] = lane < 48 ? S.vars[(size_t)b[k] * 48 + lane] : 0.0f;
+            go[k] = go[k] && h[k].stepped != 0;
+        }
+        pf.start(S.prof, b[0], lane);
+        wave_lds_fence();
+#pragma unroll
+        for (int k = 0; k < NB; k++)
+            if (lane < 48) L.vars[k * 48 + lane] = vv[k];
+        wave_lds_fence();
+        int qv[NB];
+        int4 mid[NB];
+        MemoRec rec[NB];
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            qv[k] = tile_quant(L.vars[k * 48 + h[k].slot_cur * 16 + (lane & 15)]);
+            const int ms = mslot[k] >= 0 ? mslot[k] : 0;
+            mid[k] = *reinterpret_cast<const int4*>(S.mk_ident + (size_t)ms * 4);
+            rec[k] = *reinterpret_cast<const MemoRec*>(S.mk_rec + (size_t)ms * LOB_MK_REC);  // [0]: under theta_t
+        }
+#pragma unroll
+        for (int k = 0; k < NB; k++)
+            if (go[k] && !fast_memo_ok(mslot[k], mid[k], rec[k], ver, qv[k])) { fast_hand_back(S, 1, lpar, b[k], lane); go[k] = false; }
+        pf.mark(13);  // header, memo record, state variables
+        f64 qs[NB][LOB_N_ACTIONS];
+        q_values_fast<NB>(P, S, L, qv, lane, rec, qs, pf, 14);
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            if (!go[k]) continue;
+            Rng g{P.seed, P.book_id_offset + (u64)b[k], h[k].rng_ctr};
+            learn_delta_single<ALGO>(P, S.hdr + b[k], h[k], qs[k], h[k].td, g, lane);
+        }
+        pf.mark(19);  // argmax / delta / header stores
     }
 }
 

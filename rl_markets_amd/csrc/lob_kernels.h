@@ -384,29 +384,48 @@ __global__ void __launch_bounds__(LOB_BLOCK) act_kernel(DevParams P, DevState S,
     }
 }
 
+// q[k] / f[k] for a run-time k without run-time indexing.  Each element passes through an opaque
+// register copy first: left alone, the optimiser folds the select chain back into ONE load at a
+// computed address, which pins the whole array in scratch memory.
 __device__ inline f64 sel9(const f64* q, int k) {
     f64 r = q[0];
+    asm volatile("" : "+v"(r));
 #pragma unroll
-    for (int a = 1; a < LOB_N_ACTIONS; a++) r = k == a ? q[a] : r;
+    for (int a = 1; a < LOB_N_ACTIONS; a++) {
+        f64 x = q[a];
+        asm volatile("" : "+v"(x));
+        r = k == a ? x : r;
+    }
     return r;
 }
 __device__ inline i32 sel5(const i32* f, int k) {
     i32 r = f[0];
-    r = k == 1 ? f[1] : r;
-    r = k == 2 ? f[2] : r;
-    r = k == 3 ? f[3] : r;
-    r = k == 4 ? f[4] : r;
+    asm volatile("" : "+v"(r));
+#pragma unroll
+    for (int a = 1; a < 5; a++) {
+        i32 x = f[a];
+        asm volatile("" : "+v"(x));
+        r = k == a ? x : r;
+    }
     return r;
 }
+
+// per-wave set of the current group-0 tiles (learn_traces): LOB_TSLOTS 32-bit slots in the wave's 4 KB of LDS
+#define LOB_TSLOTS 1024
+#define LOB_NOTILE 0xffffffffu /* tile indices are < M < 2^31 */
+static_assert(LOB_TSLOTS * 4 == LOB_HSLOTS * 8, "the tile set aliases the wave's Q staging area");
+__device__ inline unsigned trace_slot(uint32_t x) { return (x * 2654435761u) >> 22; }
+__device__ inline unsigned trace_step(uint32_t x) { return ((x >> 9) ^ (x << 3) | 1u) & (LOB_TSLOTS - 1); }  // odd: visits every slot
 
 // Agent::UpdateTraces (agent.cpp:86-101 -> traces.cpp:30-50; QLearn / DoubleQLearn: 272-280, 319-327)
 // for one book, one wave: decay, clear / replace against the 288 group-0 tiles of last_state, new
 // generation, and the slot claims of the combined update (issued here, resolved by the caller at the
-// end of its kernel).  `tab`: this wave's LDS hash map (LOB_HSLOTS 64-bit slots); `vars_from`: the
-// State acted on (LDS); shared by the general and the fast learner kernel.
+// end of its kernel).  `tab`: this wave's 4 KB of LDS for the tile set (`init_tab`: it may hold anything
+// on entry; otherwise it is all-NOTILE on entry and on exit); `vars_from`: the State acted on (LDS);
+// shared by the general and the fast learner kernel.
 template <int ALGO>
 __device__ __forceinline__ void learn_traces(const DevParams& P, const DevState& S, int b, const LHdr& h, const uint32_t* rnd, const uint32_t* act_terms,
-                                    u64* tab, const f32* vars_from, bool zero_last, const f64* qs_last, Rng& g, int lane,
+                                    u64* tab, bool init_tab, const f32* vars_from, bool zero_last, const f64* qs_last, Rng& g, int lane,
                                     CbPending& pend, Prof& pf) {
     LHdr* hp = S.hdr + b;
     const int action = h.action;
@@ -434,29 +453,45 @@ __device__ __forceinline__ void learn_traces(const DevParams& P, const DevState&
     if (n_old > kmax - 1) n_old = kmax - 1;        // generations whose eligibility fell below tolerance
 
     // ---- Traces::update (traces.cpp:40-50) ----
-    // hash set of the 288 current tiles; a live older entry that appears in it
-    // is either cleared (other action) or re-set to 1 (chosen action): in both
-    // cases it leaves its old generation.
-    // Slot = tile index (high word) | rank (low word), rank(a, j) = 32 a + (31 - j): the map keeps,
-    // per tile, the largest rank among the (action, tiling) pairs that produce it.
-    constexpr u64 EMPTY = ~0ull;
-    for (int i = lane; i < LOB_HSLOTS; i += 64) tab[i] = EMPTY;
-    wave_lds_fence();
+    // Set of the 288 current tiles: a live older entry that appears in it is either cleared (other
+    // action) or re-set to 1 (chosen action): in both cases it leaves its old generation.
+    // 1024 32-bit slots (load 0.28, double hashing: probe sequences stay short -- the kernel is bound by
+    // the number of LDS instructions a wave issues, and a wave walks on until its unluckiest lane is
+    // done), 32-bit compare-and-swap, tile index only.  The table is all-NOTILE between books: every key
+    // clears its slot at the end (5 stores instead of re-initialising 4 KB).
+    uint32_t* tt = reinterpret_cast<uint32_t*>(tab);
+    if (init_tab) {
+        for (int i = lane; i < LOB_TSLOTS / 4; i += 64) reinterpret_cast<uint4*>(tt)[i] = make_uint4(LOB_NOTILE, LOB_NOTILE, LOB_NOTILE, LOB_NOTILE);
+        wave_lds_fence();
+    }
+    unsigned sl[5];
+    bool dupl = false;  // two of the 288 (action, tiling) pairs produce the same tile: only through a hash collision
+    {
+        bool todo[5];
 #pragma unroll
-    for (int k = 0; k < 5; k++) {
-        const int a = half + 2 * k;
-        if (a < LOB_N_ACTIONS) {
-            const uint32_t x = (uint32_t)F[k];
-            const u64 key = ((u64)x << 32) | (uint32_t)(a * 32 + 31 - j);
-            unsigned s = (x * 2654435761u) >> 23;
-            while (true) {
-                const u64 old = atomicCAS((unsigned long long*)&tab[s], (unsigned long long)EMPTY, (unsigned long long)key);
-                if (old == EMPTY) break;
-                if ((uint32_t)(old >> 32) == x) { atomicMax((unsigned long long*)&tab[s], (unsigned long long)key); break; }
-                s = (s + 1) & (LOB_HSLOTS - 1);
+        for (int k = 0; k < 5; k++) {
+            sl[k] = trace_slot((uint32_t)F[k]);
+            todo[k] = half + 2 * k < LOB_N_ACTIONS;
+        }
+        while (true) {
+            uint32_t old[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                old[k] = 0;
+                if (todo[k]) old[k] = atomicCAS(&tt[sl[k]], LOB_NOTILE, (uint32_t)F[k]);  // a round's CAS are in flight together
             }
+            bool more = false;
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                if (!todo[k]) continue;
+                if (old[k] == LOB_NOTILE) todo[k] = false;                                // placed
+                else if (old[k] == (uint32_t)F[k]) { todo[k] = false; dupl = true; }      // ANOTHER pair put this very tile there
+                else { sl[k] = (sl[k] + trace_step((uint32_t)F[k])) & (LOB_TSLOTS - 1); more = true; }
+            }
+            if (__ballot(more) == 0) break;
         }
     }
+    const bool any_dup = __ballot(dupl) != 0;
     wave_lds_fence();
     pf.mark(10);  // argmax(qs_last), LDS map: init + 288 inserts
     const int G = P.trace_gens;  // ring size, a power of two
@@ -489,12 +524,12 @@ __device__ __forceinline__ void learn_traces(const DevParams& P, const DevState&
             bool alive = xs[u] >= 0;
             if (alive) {
                 const uint32_t x = (uint32_t)xs[u];
-                unsigned s = (x * 2654435761u) >> 23;
+                unsigned s = trace_slot(x);
                 while (true) {
-                    const u64 v = tab[s];
-                    if ((uint32_t)(v >> 32) == x) { alive = false; break; }
-                    if (v == EMPTY) break;
-                    s = (s + 1) & (LOB_HSLOTS - 1);
+                    const uint32_t tv = tt[s];
+                    if (tv == x) { alive = false; break; }
+                    if (tv == LOB_NOTILE) break;
+                    s = (s + trace_step(x)) & (LOB_TSLOTS - 1);
                 }
             }
             const u64 m = __ballot(alive);
@@ -516,19 +551,22 @@ __device__ __forceinline__ void learn_traces(const DevParams& P, const DevState&
     // only overwrites its eligibility).
     {
         const i32 N = __shfl(sel5(F, action >> 1), (action & 1) * 32 + j);
-        // dead <=> some (a', j') with the same tile outranks (action, j): a later action clears it
-        // again, or an earlier tiling of the chosen action already holds it
-        bool dead;
-        {
-            const uint32_t x = (uint32_t)N;
-            unsigned s = (x * 2654435761u) >> 23;
-            u64 v;
-            while (true) {
-                v = tab[s];
-                if ((uint32_t)(v >> 32) == x || v == EMPTY) break;
-                s = (s + 1) & (LOB_HSLOTS - 1);
+        // dead <=> some (a', j') with the same tile outranks (action, j), rank(a, j) = 32 a + (31 - j): a later
+        // action clears it again, or an earlier tiling of the chosen action already holds it.  Only
+        // possible when two of the 288 pairs share a tile, which the inserts above have detected; then --
+        // rarely: M is 20 M -- every pair is compared with every new tile.
+        bool dead = false;
+        if (any_dup) {
+            const uint32_t myrank = (uint32_t)(action * 32 + 31 - j);
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                for (int l = 0; l < 64; l++) {
+                    const int a2 = (l >> 5) + 2 * k;
+                    if (a2 >= LOB_N_ACTIONS) break;
+                    const i32 t2 = __builtin_amdgcn_readlane(F[k], l);
+                    dead |= t2 == N && (uint32_t)(a2 * 32 + 31 - (l & 31)) > myrank;
+                }
             }
-            dead = (uint32_t)v > (uint32_t)(action * 32 + 31 - j);
         }
         const int nh = (head + 1) & (G - 1);
         const u64 m = __ballot(!dead && half == 0);
@@ -549,6 +587,11 @@ __device__ __forceinline__ void learn_traces(const DevParams& P, const DevState&
             }
         }
     }
+    if (!init_tab) {  // leave the set empty for the next book
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+            if (half + 2 * k < LOB_N_ACTIONS) tt[sl[k]] = LOB_NOTILE;
+    }
     wave_lds_fence();
     pf.mark(12);  // new generation + claim issue
 }
@@ -556,16 +599,16 @@ __device__ __forceinline__ void learn_traces(const DevParams& P, const DevState&
 // UpdateWeights of SARSA / QLearn (agent.cpp:282-311) once Q(to_state, .) is known: the TD error and
 // the header stores.
 template <int ALGO>
-__device__ __forceinline__ void learn_delta_single(const DevParams& P, LHdr* hp, const LHdr& h, const f64* qs_to, const f64* qs_last, Rng& g, int lane) {
+__device__ __forceinline__ void learn_delta_single(const DevParams& P, LHdr* hp, const LHdr& h, const f64* qs_to, f64 q_sa, Rng& g, int lane) {
     static_assert(ALGO != LOB_ALGO_DOUBLE_Q, "two weight vectors: see learn_book");
     const f64 F_term = P.gamma * 0.0 - 0.0;  // potentials are identically 0 (base.cpp:239-242)
     f64 delta;
     if (ALGO == LOB_ALGO_QLAMBDA) {
         const int am2 = argmax_ties(qs_to, g);  // maxQ(to_state)
-        delta = h.reward + F_term + P.gamma * sel9(qs_to, am2) - sel9(qs_last, h.action);
+        delta = h.reward + F_term + P.gamma * sel9(qs_to, am2) - q_sa;
     } else {
         const int a2 = policy_sample(qs_to, P.epsilon, false, g);  // this->action(to_state), quirk Q9
-        delta = h.reward + F_term + P.gamma * sel9(qs_to, a2) - sel9(qs_last, h.action);
+        delta = h.reward + F_term + P.gamma * sel9(qs_to, a2) - q_sa;
     }
     if (lane == 0) {
         hp->td = delta;
@@ -594,7 +637,7 @@ __device__ __forceinline__ void learn_book(const DevParams& P, const DevState& S
     const int action = h.action;
     Rng g{P.seed, P.book_id_offset + (u64)b, h.rng_ctr};
     CbPending pend;
-    learn_traces<ALGO>(P, S, b, h, L.rnd, L.act_terms, reinterpret_cast<u64*>(L.vals[w]), vars_from, zero_last, qs_last, g, lane, pend, pf);
+    learn_traces<ALGO>(P, S, b, h, L.rnd, L.act_terms, reinterpret_cast<u64*>(L.vals[w]), true, vars_from, zero_last, qs_last, g, lane, pend, pf);
 
     // ---- UpdateWeights: TD error under theta_t ----
     const f64* theta = S.theta + (P.theta_private ? (size_t)b * (size_t)P.M : 0);
@@ -644,11 +687,45 @@ __device__ __forceinline__ void learn_book(const DevParams& P, const DevState& S
             hp->rng_ctr = g.ctr;
         }
     } else {
-        learn_delta_single<ALGO == LOB_ALGO_DOUBLE_Q ? LOB_ALGO_SARSA : ALGO>(P, hp, h, qs_to, qs_last, g, lane);
+        learn_delta_single<ALGO == LOB_ALGO_DOUBLE_Q ? LOB_ALGO_SARSA : ALGO>(P, hp, h, qs_to, sel9(qs_last, action), g, lane);
     }
     pf.mark(17);  // argmax / delta / header stores
     cb_claim_finish(S, pend);  // the CAS was issued before Q(s', .): its answer has long arrived
     pf.mark(18);  // claim finish
+}
+
+// The second half of learn_book alone, for the books the fast path's learn_q kernel hands back: its trace
+// kernel has already run UpdateTraces for them, left Q(s, a) in LHdr::td and the RNG counter after the
+// trace step's draws in LHdr::rng_ctr.
+template <int ALGO>
+__device__ __forceinline__ void learn_q_book(const DevParams& P, const DevState& S, LearnLds& L, int w, int lane, int b) {
+    static_assert(ALGO != LOB_ALGO_DOUBLE_Q, "one weight vector");
+    const LHdr h = S.hdr[b];
+    if (!h.stepped) return;
+    learn_stage_vars(S.vars + (size_t)b * 48, &L.vars[w][0][0], lane);
+    LHdr* hp = S.hdr + b;
+    const int cur = h.slot_cur;
+    Rng g{P.seed, P.book_id_offset + (u64)b, h.rng_ctr};
+    f64 qs_to[LOB_N_ACTIONS];
+    uint16_t* vd = S.verdict + (size_t)b * LOB_VD_STRIDE;
+    const uint32_t ep = (uint32_t)S.nz_epoch[0];
+    uint32_t my_vd = 0;
+    q_values(P, S.theta, S.theta_nz, L.vars[w][cur], false, L.rnd, L.act_terms, L.vals[w], lane, qs_to, 1, &my_vd);
+    vd[lane] = (uint16_t)my_vd;
+    if (lane == 0) *(u64*)(vd + 64) = vd_tag(ep, cur);
+    learn_delta_single<ALGO>(P, hp, h, qs_to, h.td, g, lane);
+}
+template <int ALGO>
+__global__ void __launch_bounds__(LOB_BLOCK) learn_q_rest_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g,
+                                                                 const i32* __restrict__ list, const i32* __restrict__ list_n) {
+    __shared__ LearnLds L;
+    if (*list_n == 0) return;  // nothing handed back: the usual case
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    learn_stage_table(rnd_g, L);
+    const int n = *list_n;
+#pragma unroll 1
+    for (int i = __builtin_amdgcn_readfirstlane(blockIdx.x * LOB_WAVES_PER_BLOCK + w); i < n; i += gridDim.x * LOB_WAVES_PER_BLOCK)
+        learn_q_book<ALGO>(P, S, L, w, lane, __builtin_amdgcn_readfirstlane(list[i]));
 }
 
 template <int ALGO, bool LIST>

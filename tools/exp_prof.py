@@ -37,15 +37,16 @@ N = 100
 eng.td_step(N); eng.sync()
 assert eng.lib.lob_debug_prof(eng.h, out) == 0
 d = [(y - x) / (N * B) for x, y in zip(a, list(out))]
-names = {0: "act: header, memo record, LDS staging, barrier", 1: "act: tile hashing", 2: "act: map words", 3: "act: weights of the maybe-written tiles",
-         4: "act: ordered continuation", 5: "act: policy + stores",
-         8: "learn: header, Q(s,.), memo record, LDS staging, barrier", 9: "learn: group-0 tiles of s", 10: "learn: argmax + LDS map (288 inserts)",
-         11: "learn: old generations (scan, stores, claim issue)", 12: "learn: new generation + claim issue", 13: "learn: tile hashing",
-         14: "learn: map words", 15: "learn: weights of the maybe-written tiles", 16: "learn: ordered continuation",
-         17: "learn: argmax / delta / header stores", 18: "learn: claim finish"}
-for lo, hi, nm in ((0, 8, "act_kernel"), (8, 20, "learn_kernel")):
-    tot = sum(d[lo:hi])
+names = {0: "act: headers, memo records, state variables", 1: "act: tile hashing", 2: "act: coarse filter (LDS)", 3: "act: exact map for the coarse hits",
+         4: "act: written weights + ordered continuation", 5: "act: policy + stores",
+         8: "trace: header, Q(s,.), state variables", 9: "trace: group-0 tiles of s", 10: "trace: argmax + LDS map (288 inserts)",
+         11: "trace: old generations (scan, stores, claim issue)", 12: "trace: new generation + claim issue", 18: "trace: header stores, previous book's claims",
+         13: "learn_q: headers, memo records, state variables", 14: "learn_q: tile hashing", 15: "learn_q: coarse filter (LDS)",
+         16: "learn_q: exact map for the coarse hits", 17: "learn_q: written weights + ordered continuation", 19: "learn_q: argmax / delta / header stores"}
+print("(clocks per wave ITERATION: the Q kernels take LOB_FAST_NB books per iteration and stamp the batch on its first book's row)")
+for lo, hi, nm, idx in ((0, 8, "act_kernel", range(0, 8)), (8, 20, "trace_kernel", (8, 9, 10, 11, 12, 18)), (13, 20, "learn_q kernel", (13, 14, 15, 16, 17, 19))):
+    tot = sum(d[i] for i in idx)
     print("%s: %.0f clocks per wave" % (nm, tot))
-    for i in range(lo, hi):
+    for i in idx:
         if i in names:
             print("  %-58s %8.0f  %5.1f %%" % (names[i], d[i], 100.0 * d[i] / max(tot, 1e-9)))
