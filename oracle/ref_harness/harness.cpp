@@ -24,6 +24,11 @@
 //   learner  : same inputs through the reference's own Learner::RunEpisode
 //              (src/experiment/serial.cpp:72-93); prints steps and seconds
 //              (CPU baseline) and optionally dumps theta.
+//   dropin   : (ref_dropin binary, -DLOB_DROPIN, links liblob_engine.so) the reference's UNMODIFIED
+//              Learner::RunEpisode + rl::Agent driving environment::GpuIntraday
+//              (rl_markets_amd/host/ref_binding/gpu_intraday.h), a subclass of the reference's own
+//              environment::Base backed by one book of the GPU engine; writes the same trajectory file
+//              as `episode` (minus the post-reset record).
 //   tiles    : rl::State::newState(vector<float>&) known-answer vectors.
 //   ticks    : Market::ToTicks / ToPrice known-answer vectors.
 #include <unistd.h>
@@ -75,6 +80,9 @@
 
 #include "../../rl_markets_amd/csrc/lob_stream.h"  // record layout + lob_rng (inputs only)
 #include "../lob_oracle.h"                          // oracle_step_rec layout only
+#ifdef LOB_DROPIN
+#include "../../rl_markets_amd/host/ref_binding/gpu_intraday.h"  // the thing under test in `dropin` mode
+#endif
 
 // ---------------------------------------------------------------------------
 // RNG injection
@@ -440,6 +448,57 @@ static int run_learner(const Args& a, Config& c, ProbeEnv& env) {
     return 0;
 }
 
+#ifdef LOB_DROPIN
+// The agent records a trajectory row from inside the reference's own HandleTransition (UpdateWeights is
+// its last RNG-drawing stage): the Learner driving it is the reference's, untouched.
+template <class A> class RecordingAgent : public ProbeAgent<A> {
+public:
+    environment::GpuIntraday* env = nullptr;
+    FILE* out = nullptr;
+    long steps = 0;
+    RecordingAgent(std::unique_ptr<rl::Policy> p, Config& c) : ProbeAgent<A>(std::move(p), c) {}
+    double UpdateWeights(rl::State& f, int a, double r, rl::State& t) override {
+        const double d = ProbeAgent<A>::UpdateWeights(f, a, r, t);
+        StepRec rec;
+        memset(&rec, 0, sizeof rec);
+        rec.action = a;
+        rec.reward = r;
+        rec.td = d;
+        auto& v = t.toVector();
+        rec.n_vars = (int)v.size();
+        for (size_t i = 0; i < v.size() && i < LOB_MAX_VARS; i++) rec.vars[i] = v[i];
+        rec.rng_ctr = g_ctr;
+        rec.book = env->book();
+        rec.book.n_traces = this->traces_ref().n_nonzero_traces;
+        fwrite(&rec, sizeof rec, 1, out);
+        steps++;
+        return d;
+    }
+};
+template <class AGENT>
+static int run_dropin(const Args& a, Config& c, environment::GpuIntraday& env, const std::string& out_path) {
+    RecordingAgent<AGENT> agent(std::unique_ptr<rl::Policy>(new ReplayPolicy(9, a.getd("eps", 0.8))), c);
+    agent.env = &env;
+    agent.out = fopen(out_path.c_str(), "wb");
+    if (!agent.out) { perror("out"); return 2; }
+    experiment::serial::Learner learner(c, env);           // the reference's runner, unmodified
+    const bool ok = learner.RunEpisode(&agent);            // Initialise -> _step ... -> ClearInventory -> HandleTerminal
+    fclose(agent.out);
+    if (a.kv.count("theta_out")) {
+        FILE* f = fopen(a.get("theta_out").c_str(), "wb");
+        int64_t n = 0;
+        for (long i = 0; i < agent.mem(); i++) if (agent.theta_ptr()[i] != 0.0) n++;
+        fwrite(&n, 8, 1, f);
+        for (long i = 0; i < agent.mem(); i++)
+            if (agent.theta_ptr()[i] != 0.0) { int64_t idx = i; fwrite(&idx, 8, 1, f); fwrite(&agent.theta_ptr()[i], 8, 1, f); }
+        fclose(f);
+    }
+    printf("{\"steps\": %ld, \"ok\": %d, \"rng_ctr\": %llu, \"sizeof_steprec\": %zu, \"episode_reward\": %.17g, \"episode_pnl\": %.17g}\n",
+           agent.steps, ok ? 1 : 0, (unsigned long long)g_ctr, sizeof(StepRec), env.getEpisodeReward(), env.getEpisodePnL());
+    return 0;
+}
+#endif
+
 int main(int argc, char** argv) {
     if (argc < 2) { fprintf(stderr, "usage: ref_harness <episode|learner|tiles|ticks> --key value ...\n"); return 1; }
     std::string mode = argv[1];
@@ -523,6 +582,20 @@ int main(int argc, char** argv) {
     a.kv["tas"] = tas;
     make_yaml(a, yaml);
     Config c(yaml);
+#ifdef LOB_DROPIN
+    if (mode == "dropin") {
+        environment::GpuIntraday genv(c);
+        genv.LoadData(a.get("ticker", "HSBA.L"), md, tas);   // the call site of src/main.cpp:55 with the class swapped
+        const std::string algo = a.get("algo", "sarsa");
+        int rc = 2;
+        if (algo == "sarsa") rc = run_dropin<rl::SARSA>(a, c, genv, a.get("out", tmp + ".traj"));
+        else if (algo == "q_learn") rc = run_dropin<rl::QLearn>(a, c, genv, a.get("out", tmp + ".traj"));
+        else if (algo == "double_q_learn") rc = run_dropin<rl::DoubleQLearn>(a, c, genv, a.get("out", tmp + ".traj"));
+        if (!a.geti("keep", 0) && a.kv.count("stream")) { remove(md.c_str()); remove(tas.c_str()); }
+        remove(yaml.c_str());
+        return rc;
+    }
+#endif
     ProbeEnv env(c);
     env.LoadData(a.get("ticker", "HSBA.L"), md, tas);
     std::string algo = a.get("algo", "sarsa");
