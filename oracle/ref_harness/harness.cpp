@@ -482,6 +482,7 @@ static int run_dropin(const Args& a, Config& c, environment::GpuIntraday& env, c
     agent.out = fopen(out_path.c_str(), "wb");
     if (!agent.out) { perror("out"); return 2; }
     experiment::serial::Learner learner(c, env);           // the reference's runner, unmodified
+    g_ctr = 0;  // (bringing up the HIP runtime goes through the interposed rand() too)
     const bool ok = learner.RunEpisode(&agent);            // Initialise -> _step ... -> ClearInventory -> HandleTerminal
     fclose(agent.out);
     if (a.kv.count("theta_out")) {

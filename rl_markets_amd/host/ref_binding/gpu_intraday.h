@@ -22,12 +22,18 @@
 // them: getReward() then evaluates the reference's own formula on the engine's numbers.  That covers
 // the rewards built from those members (none, pnl, pnl_damped, lovol, mm_linear, mm_div); `spread` and
 // `normed` read Base's rolling windows, which live on the GPU here: the constructor rejects them unless
-// the one-line change of INTEGRATION.md (`virtual` on Base::getReward) is applied.  ClearInventory()
-// called through a Base& runs the reference's code on Base's own (empty) books, a no-op: call
-// GpuIntraday::ClearInventory() (or make it virtual, same one-line change).
+// the one-line change of INTEGRATION.md (`virtual` on Base::getReward) is applied.  Base::ClearInventory()
+// (non-virtual too; Runner::RunEpisode's epilogue calls it through a Base&) runs the REFERENCE's market
+// order on Base's own books: so the current snapshot and the position are mirrored into them as well,
+// the reference code computes the same fill from the same levels, and the engine is brought in step
+// (lob_clear_inventory) before its next call.  (Base's books only see one snapshot per step, so their
+// cumulative total_volume_ -- the abort test of WalkTheBook, quirk Q1 -- is smaller than the engine's;
+// both exceed any reachable inventory by orders of magnitude.)
 #ifndef LOB_REF_BINDING_GPU_INTRADAY_H
 #define LOB_REF_BINDING_GPU_INTRADAY_H
 
+#include <array>
+#include <cstring>
 #include <map>
 #include <stdexcept>
 #include <string>
@@ -60,10 +66,34 @@ class GpuIntraday : public Base {
         ask_quote = last_.ask_quote;
         bid_quote = last_.bid_quote;
         risk_manager_.Update((long)last_.position - risk_manager_.exposure());
+        // the current snapshot into Base's own books (what Base::ClearInventory walks)
+        std::array<double, 5> ap, bp;
+        std::array<long, 5> av, bv;
+        bool whole = true;
+        for (int l = 0; l < 5; l++) {
+            ap[l] = last_.ask_px[l]; av[l] = (long)last_.ask_vol[l];
+            bp[l] = last_.bid_px[l]; bv[l] = (long)last_.bid_vol[l];
+            whole = whole && ap[l] > 0.0 && bp[l] > 0.0 && av[l] > 0 && bv[l] > 0;
+        }
+        if (whole) {
+            ask_book_.StashState(); ask_book_.ApplyChanges(ap, av);
+            bid_book_.StashState(); bid_book_.ApplyChanges(bp, bv);
+        }
         episode_stats.reward = last_.episode_reward;
         episode_stats.pnl = last_.episode_pnl;
         episode_stats.bandh = last_.episode_bandh;
         tick_stats.total_ticks = last_.total_ticks;
+    }
+
+    // Base::ClearInventory ran on the mirror (the reference's runner calls it through a Base&): same market
+    // order on the engine's side
+    void sync_inventory() {
+        if (engine_ && have_data_ && risk_manager_.exposure() != (long)last_.position) {
+            const long after = risk_manager_.exposure();
+            check(lob_clear_inventory(engine_), "ClearInventory");
+            check(lob_get_book(engine_, 0, &last_), "GpuIntraday");
+            if ((long)last_.position != after) throw std::runtime_error("GpuIntraday: the engine's inventory disagrees with Base's after ClearInventory");
+        }
     }
 
 protected:
@@ -78,6 +108,7 @@ public:
     // src/environment/intraday.cpp:37-82) folded into lob_params; Base(c) itself still runs (its own
     // books and windows stay empty).
     explicit GpuIntraday(Config& c, int device = 0) : Base(c), device_(device) {
+        memset(&last_, 0, sizeof last_);
         lob_default_params(&params_);
         static const std::map<std::string, int> v2i = {
             {"pos", LOB_VAR_POS}, {"spd", LOB_VAR_SPD}, {"mpm", LOB_VAR_MPM}, {"imb", LOB_VAR_IMB},
@@ -139,6 +170,7 @@ public:
 
     bool Initialise() override {  // Intraday::Initialise (intraday.cpp:103-138); false: ran out of data before the windows filled
         if (!have_data_) return false;
+        sync_inventory();
         Base::Initialise();
         check(lob_reset(engine_), "Initialise");
         mirror();
@@ -147,6 +179,7 @@ public:
     }
     bool performAction(int action) override {  // false: the depth stream is exhausted (base.cpp:254-337)
         const int32_t a = action;
+        sync_inventory();
         check(lob_step(engine_, &a), "performAction");
         mirror();
         return last_.terminal != 2;
@@ -158,7 +191,8 @@ public:
     }
     bool isTerminal() override { return last_.terminal != 0; }
     std::string getEpisodeId() override { return std::to_string(init_date_); }
-    void ClearInventory() {  // hides Base::ClearInventory (non-virtual, base.cpp:339-349)
+    void ClearInventory() {  // hides Base::ClearInventory (non-virtual, base.cpp:339-349) for callers that hold a GpuIntraday
+        sync_inventory();
         check(lob_clear_inventory(engine_), "ClearInventory");
         mirror();
     }
