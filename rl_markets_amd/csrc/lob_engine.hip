@@ -41,7 +41,7 @@ struct lob_engine {
     hipStream_t stream2 = nullptr;  // second book group of the step pipeline
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_stagger = nullptr;
     int n_groups = 1;
-    int env_lanes = 0;     // books per env_kernel wave: 0 = by batch size, or 16 / 32 / 64 (LOB_ENV_LANES, read by lob_create)
+    int env_lanes = 0;     // books per env_kernel wave: 0 = by batch size, or 16 / 32 / 64; 256 = env_compact_kernel (LOB_ENV_LANES, read by lob_create)
     int reset_lanes = 64;  // books per reset_kernel wave (LOB_RESET_LANES)
     int td_parity = 0;
     int step_id = 0;            // stamps the memo claims of one step
@@ -238,7 +238,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     e->n_groups = 1;
     if (const char* g = getenv("LOB_GROUPS")) { int v = atoi(g); if (v >= 1 && v <= 2) e->n_groups = v; }
     // experiment / test switches for the books-per-wave choice of the lane-per-book kernels
-    if (const char* g = getenv("LOB_ENV_LANES")) { int v = atoi(g); if (v == 16 || v == 32 || v == 64) e->env_lanes = v; }
+    if (const char* g = getenv("LOB_ENV_LANES")) { int v = atoi(g); if (v == 16 || v == 32 || v == 64 || v == 256) e->env_lanes = v; }
     if (const char* g = getenv("LOB_RESET_LANES")) { int v = atoi(g); if (v == 16 || v == 32 || v == 64) e->reset_lanes = v; }
 
     // ---- DevParams ----
@@ -539,6 +539,14 @@ int lob_gen_events_device(lob_engine* e, const lob_gen_params* g) {
 static void launch_env(lob_engine* e, hipStream_t st, const i32* actions, int count_updates, int b0, int nb, int par) {
     const int force = e->env_lanes;
     const int sid = e->step_id;
+    // learner / backtester steps with the event loop compacted across 256-book blocks
+    // (opt-in: measured no faster than env_kernel<64> -- DESIGN.md "env kernel" -- because a step is a chain of
+    // dependent look-ups per event and the block keeps its LDS until its unluckiest book is done)
+    if (!actions && force == 256) {
+        hipLaunchKernelGGL(env_compact_kernel, dim3((nb + LOB_ENVC_BLOCK - 1) / LOB_ENVC_BLOCK), dim3(LOB_ENVC_BLOCK), 0, st,
+                           (const DevParams*)e->P_dev, e->S, count_updates, b0, nb, sid, par);
+        return;
+    }
     if (force == 32)
         hipLaunchKernelGGL(env_kernel<32>, dim3((nb + 31) / 32), dim3(32), 0, st, (const DevParams*)e->P_dev, e->S, actions, count_updates, b0, nb, sid, par);
     else if (force == 16 || (force == 0 && e->B <= 16384))

@@ -47,6 +47,7 @@ struct EnvCtx {
         const size_t first = s.rec_phase ? (size_t)s.rec_phase[book] : (size_t)book * (size_t)s.n_events;
         rows = s.records + first * (size_t)p.W;
     }
+    __device__ EnvCtx(const DevParams& p, const DevState& s, int book, const uint32_t* rows_) : P(p), S(s), b(book), rows(rows_) {}
     __device__ void err(int bit) const { atomicOr(S.error_flag, bit); }
     __device__ const uint32_t* row(int i) const { return rows + (size_t)i * (size_t)P.W; }
     __device__ const Track& track(int k) const { return S.track[(size_t)b * (size_t)S.n_events + (size_t)k]; }
@@ -681,8 +682,14 @@ __device__ inline bool next_state(const EnvCtx& c, EnvR& e) {
     return true;
 }
 
-// Base::performAction (base.cpp:254-337)
-__device__ inline bool perform_action(const EnvCtx& c, EnvR& e, int action) {
+// Base::performAction (base.cpp:254-337) in three pieces, so that the event loop can be driven either by
+// the lane that owns the book (perform_action) or by whichever lane of the block is free
+// (env_compact_kernel): the running sums of the loop live in `StepAgg`.
+struct StepAgg {
+    f64 r, pnl, mpm;
+};
+// up to the first NextState: DoAction, CheckOrders, UpdateStats, the reward of the action itself
+__device__ inline void step_prologue(const EnvCtx& c, EnvR& e, int action, StepAgg& g) {
     const DevParams& P = c.P;
     e.last_action = action;
     e.lo_vol_step = 0;
@@ -691,20 +698,26 @@ __device__ inline bool perform_action(const EnvCtx& c, EnvR& e, int action) {
     do_action(c, e, action);
     check_orders(P, e);
     e.total_ticks++;  // UpdateStats
-    f64 agg_r = get_reward(c, e);
-    f64 agg_pnl = e.pnl_step;
-    f64 agg_mpm = 0.0;
-    do {
-        e.pnl_step = 0.0;
-        if (!next_state(c, e)) return false;
-        f64 mpm = e.mid - e.mid_prev;
-        e.pnl_step += (f64)e.position * mpm;
-        e.momentum_pnl_step += (f64)e.position * mpm;
-        agg_r += get_reward(c, e);
-        agg_pnl += e.pnl_step;
-        agg_mpm += mpm;
-    } while (is_open(P, e.time_ms) && fabs(agg_mpm) < 1e-5);
-    e.pnl_step = agg_pnl;
+    g.r = get_reward(c, e);
+    g.pnl = e.pnl_step;
+    g.mpm = 0.0;
+}
+// one pass of the do-while: 0 = another event follows, 1 = the step is complete, 2 = out of data
+__device__ inline int step_event(const EnvCtx& c, EnvR& e, StepAgg& g) {
+    const DevParams& P = c.P;
+    e.pnl_step = 0.0;
+    if (!next_state(c, e)) return 2;
+    const f64 mpm = e.mid - e.mid_prev;
+    e.pnl_step += (f64)e.position * mpm;
+    e.momentum_pnl_step += (f64)e.position * mpm;
+    g.r += get_reward(c, e);
+    g.pnl += e.pnl_step;
+    g.mpm += mpm;
+    return (is_open(P, e.time_ms) && fabs(g.mpm) < 1e-5) ? 0 : 1;
+}
+// after the loop: PnL windows, episode totals
+__device__ inline void step_epilogue(const EnvCtx& c, EnvR& e, const StepAgg& g) {
+    e.pnl_step = g.pnl;
     {
         RMReg wu, wd;
         rm_load(c.S.pnl_ups, c.b, wu); rm_load(c.S.pnl_downs, c.b, wd);
@@ -712,8 +725,16 @@ __device__ inline bool perform_action(const EnvCtx& c, EnvR& e, int action) {
         rm_apply(c.S.pnl_ups, c.S.B, c.b, wu, 0.0 > e.pnl_step ? 0.0 : e.pnl_step);
         rm_apply(c.S.pnl_downs, c.S.B, c.b, wd, fabs(0.0 < e.pnl_step ? 0.0 : e.pnl_step));
     }
-    e.ep_reward += agg_r;
-    e.ep_bandh += agg_mpm;
+    e.ep_reward += g.r;
+    e.ep_bandh += g.mpm;
+}
+__device__ inline bool perform_action(const EnvCtx& c, EnvR& e, int action) {
+    StepAgg g;
+    step_prologue(c, e, action, g);
+    int st;
+    do { st = step_event(c, e, g); } while (st == 0);
+    if (st == 2) return false;
+    step_epilogue(c, e, g);
     return true;
 }
 

@@ -239,6 +239,129 @@ __global__ void __launch_bounds__(LOB_ENV_BLOCK) env_kernel(const DevParams* __r
     }
 }
 
+// The same step with the event loop COMPACTED across a 256-book block.  How many market events a step
+// consumes is data dependent (it ends when the midprice has moved: 1.68 events on average, 5-6 for the
+// unluckiest of 64 books), and in env_kernel a wave iterates until its slowest lane is done -- 70 % of
+// its loop time is spent waiting for that lane.  Here a book's whole step state lives in its
+// LDS slot (EnvSlot + the running sums of the loop), so ANY lane can carry it through its next event:
+// after every pass the books that need another event are packed (wave ballot + prefix sum, one LDS
+// atomic per wave for the block offset) into a work list, lanes 0..n-1 take entry n each, and waves
+// beyond the list go idle at the block barrier instead of spinning.  Prologue and epilogue are
+// lane = book as before.  Same arithmetic in the same order per book: results cannot differ.
+#define LOB_ENVC_BLOCK 256
+struct EnvCompactSlot {
+    EnvSlot s;
+    StepAgg agg;
+    const uint32_t* rows;  // EnvCtx::rows of the book
+};
+static_assert(sizeof(EnvCompactSlot) * LOB_ENVC_BLOCK + 2 * 2 * LOB_ENVC_BLOCK + LOB_ENVC_BLOCK + 64 <= 80 * 1024, "two blocks per CU");
+
+__global__ void __launch_bounds__(LOB_ENVC_BLOCK) env_compact_kernel(const DevParams* __restrict__ Pp, DevState S, int count_updates, int b0, int nb,
+                                                                     int step_id, int par) {
+    const DevParams& P = *Pp;  // parameters read through the scalar cache, never copied to scratch
+    __shared__ EnvCompactSlot slots[LOB_ENVC_BLOCK];
+    __shared__ uint16_t work[2][LOB_ENVC_BLOCK];
+    __shared__ int cnt[3];
+    __shared__ uint8_t status[LOB_ENVC_BLOCK];  // 0: still in the loop, 1: step complete, 2: out of data, 3: no action pending
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * LOB_ENVC_BLOCK + threadIdx.x;
+    const int b = b0 + t;
+    if (threadIdx.x < 3) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    // ---- prologue: lane = book ----
+    bool go = false;
+    i64 ev0 = 0;
+    if (t < nb) {
+        LHdr& h = S.hdr[b];
+        go = h.stepped != 0;
+        if (go) {
+            EnvCtx c(P, S, b);
+            EnvCompactSlot& sl = slots[threadIdx.x];
+            EnvR& e = sl.s.e;
+            env_load(S, b, e);
+            ev0 = e.events;
+            sl.rows = c.rows;
+            step_prologue(c, e, h.action, sl.agg);
+        } else {
+            h.stepped = 0;
+        }
+    }
+    status[threadIdx.x] = go ? 0 : 3;
+    {
+        const u64 m = __ballot(go);
+        int base = 0;
+        if (lane == 0 && m) base = atomicAdd(&cnt[0], __popcll(m));
+        base = __shfl(base, 0);
+        if (go) work[0][base + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)threadIdx.x;
+    }
+    __syncthreads();
+    // ---- the event loop, one event of every pending book per pass ----
+    for (int it = 0;; it++) {
+        const int n = cnt[it % 3];
+        if (n == 0) break;
+        if (threadIdx.x == 0) cnt[(it + 2) % 3] = 0;
+        bool again = false;
+        int slot = 0;
+        if ((int)threadIdx.x < n) {
+            slot = work[it & 1][threadIdx.x];
+            EnvCompactSlot& sl = slots[slot];
+            EnvCtx c(P, S, b0 + blockIdx.x * LOB_ENVC_BLOCK + slot, sl.rows);
+            const int st = step_event(c, sl.s.e, sl.agg);
+            again = st == 0;
+            if (!again) status[slot] = (uint8_t)st;
+        }
+        const u64 m = __ballot(again);
+        int base = 0;
+        if (lane == 0 && m) base = atomicAdd(&cnt[(it + 1) % 3], __popcll(m));
+        base = __shfl(base, 0);
+        if (again) work[(it + 1) & 1][base + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)slot;
+        __syncthreads();
+    }
+    // ---- epilogue: lane = book ----
+    i64 d_steps = 0, d_events = 0;
+    if (go) {
+        LHdr& h = S.hdr[b];
+        EnvCompactSlot& sl = slots[threadIdx.x];
+        EnvR& e = sl.s.e;
+        EnvCtx c(P, S, b, sl.rows);
+        const bool ok = status[threadIdx.x] == 1;
+        if (ok) {
+            step_epilogue(c, e, sl.agg);
+            const int cur = h.slot_cur;
+            f32* v = S.vars + ((size_t)b * 3 + cur) * 16;
+            f32* vf = S.vars + ((size_t)b * 3 + 2) * 16;
+            const Track tk = state_track(c, e);
+            int qg[3] = {0, 0, 0};
+            for (int i = 0; i < P.V; i++) {
+                v[i] = (f32)get_variable(c, e, P.vars[i], tk);
+                vf[i] = v[i];
+                if (i < 3) qg[i] = tile_quant(v[i]);
+            }
+            if (P.memo) S.mk_slot[b] = mk_claim(S, qg[0], qg[1], qg[2], step_id, par);
+            h.zero_mask &= ~(1 << cur);
+            S.verdict[(size_t)b * LOB_VD_STRIDE + 67] = 0;
+            h.reward = get_reward(c, e);
+            h.stepped = 1;
+            d_steps = 1;
+        } else {
+            h.stepped = 0;
+        }
+        d_events = e.events - ev0;
+        h.done = e.done;
+        h.time_ms = e.time_ms;
+        env_store(S, b, e);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        d_steps += __shfl_down(d_steps, off);
+        d_events += __shfl_down(d_events, off);
+    }
+    if (lane == 0 && (d_steps | d_events)) {
+        atomicAdd((u64*)&S.counters[0], (u64)d_steps);
+        atomicAdd((u64*)&S.counters[1], (u64)d_events);
+        if (count_updates) atomicAdd((u64*)&S.counters[3], (u64)d_steps);  // every stepped book gets one TD update
+    }
+}
+
 // Base::ClearInventory for every book (Runner::RunEpisode epilogue, serial.cpp:31)
 __global__ void __launch_bounds__(256) clear_inventory_kernel(const DevParams* __restrict__ Pp, DevState S) {
     const DevParams& P = *Pp;  // parameters read through the scalar cache, never copied to scratch

@@ -480,9 +480,10 @@ def test_config3_full_size_against_oracle():
 
 @pytest.mark.parametrize("groups", [1, 2])
 @pytest.mark.parametrize("reset_lanes", [16, 32, 64])
-@pytest.mark.parametrize("env_lanes", [16, 32, 64])
+@pytest.mark.parametrize("env_lanes", [16, 32, 64, 256])
 def test_books_per_wave_and_group_choices(monkeypatch, env_lanes, reset_lanes, groups):
-    """Every instantiation of the lane-per-book kernels (env_kernel<16|32|64>, reset_kernel<16|32|64>)
+    """Every instantiation of the lane-per-book kernels (env_kernel<16|32|64>, env_compact_kernel = 256,
+    reset_kernel<16|32|64>)
     and both step pipelines (one group / two groups on two streams) against the oracle on 10-level
     books: the launch shape must not show in the results.  (lob_create reads the switches.)"""
     monkeypatch.setenv("LOB_ENV_LANES", str(env_lanes))
