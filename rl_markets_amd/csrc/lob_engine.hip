@@ -48,6 +48,10 @@ struct lob_engine {
     int list_par = 0;           // parity of the fast path's work lists
     int last_par = 0;           // `par` of the most recent step (its memo list is the current one)
     int n_cus = 256;            // compute units: the persistent learner kernels run one block on each
+    int track_ring = 4096;      // longest resident market track, in events per book; longer streams keep a ring of this many (LOB_TRACK_RING)
+    int track_refill = 64;      // steps between refills of the ring (LOB_TRACK_REFILL)
+    bool chunked = false;       // the loaded stream is longer than the ring
+    int steps_since_fill = 0;
     uint64_t theta_ver = 1;     // bumped whenever theta changes: memo records carry the version they were computed under
     std::vector<void*> allocs;
     uint32_t* rnd_dev = nullptr;
@@ -163,6 +167,7 @@ int check_device_errors(lob_engine* e) {
         if (flag & LOB_ERR_BAD_LEVEL) m += " [level price/volume <= 0]";
         if (flag & LOB_ERR_UNDEF_PRICE) m += " [undefined book price]";
         if (flag & LOB_ERR_TRADE_OVERFLOW) m += " [more trade price levels in one event than max_trades]";
+        if (flag & LOB_ERR_TRACK_UNDERRUN) m += " [market-track ring underrun: raise LOB_TRACK_RING or lower LOB_TRACK_REFILL]";
         lob_set_error(m);
         return LOB_EDATA;
     }
@@ -239,6 +244,8 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     if (const char* g = getenv("LOB_GROUPS")) { int v = atoi(g); if (v >= 1 && v <= 2) e->n_groups = v; }
     // experiment / test switches for the books-per-wave choice of the lane-per-book kernels
     if (const char* g = getenv("LOB_ENV_LANES")) { int v = atoi(g); if (v == 16 || v == 32 || v == 64 || v == 256) e->env_lanes = v; }
+    if (const char* g = getenv("LOB_TRACK_RING")) { int v = atoi(g); if (v >= 256 && v <= (1 << 20) && (v & (v - 1)) == 0) e->track_ring = v; }
+    if (const char* g = getenv("LOB_TRACK_REFILL")) { int v = atoi(g); if (v >= 1) e->track_refill = v; }
     if (const char* g = getenv("LOB_RESET_LANES")) { int v = atoi(g); if (v == 16 || v == 32 || v == 64) e->reset_lanes = v; }
 
     // ---- DevParams ----
@@ -309,6 +316,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     alloc_acc(S.f_vwap_numer, p->lb_vwap);
     alloc_acc(S.f_vwap_denom, p->lb_vwap);
     if (rc == LOB_OK) rc = dev_alloc(e, &S.meta, B);
+    if (rc == LOB_OK) rc = dev_alloc(e, &S.prep, B);
     if (rc == LOB_OK) rc = dev_alloc(e, &S.ewma_up, B);
     if (rc == LOB_OK) rc = dev_alloc(e, &S.ewma_down, B);
     if (rc == LOB_OK) rc = dev_alloc(e, &S.tp_val, B);
@@ -471,7 +479,11 @@ static int set_records(lob_engine* e, int32_t n_events, size_t n_rows) {
     size_t bytes = n_rows * e->P.W * 4;
     hipError_t err = hipMalloc((void**)&e->records_dev, bytes);
     if (err != hipSuccess) { e->records_dev = nullptr; lob_set_error("hipMalloc(records) failed"); return LOB_ENOMEM; }
-    err = hipMalloc((void**)&e->track_dev, (size_t)e->B * n_events * sizeof(Track));
+    // market track: resident (one entry per event) up to track_ring events per book, a ring of that many beyond
+    e->chunked = n_events > e->track_ring;
+    e->S.track_len = e->chunked ? e->track_ring : n_events;
+    e->S.track_mask = e->chunked ? e->track_ring - 1 : 0x7fffffff;
+    err = hipMalloc((void**)&e->track_dev, (size_t)e->B * e->S.track_len * sizeof(Track));
     if (err != hipSuccess) {
         e->track_dev = nullptr;
         hipFree(e->records_dev);
@@ -554,6 +566,13 @@ static void launch_env(lob_engine* e, hipStream_t st, const i32* actions, int co
     else
         hipLaunchKernelGGL(env_kernel<64>, dim3((nb + 63) / 64), dim3(64), 0, st, (const DevParams*)e->P_dev, e->S, actions, count_updates, b0, nb, sid, par);
 }
+// Long streams: let the pre-pass run on every `track_refill` steps (lob_kernels.h prepass_extend_kernel)
+static void maybe_refill_track(lob_engine* e) {
+    if (!e->chunked || ++e->steps_since_fill < e->track_refill) return;
+    e->steps_since_fill = 0;
+    TimedLaunch t(e, "prepass_extend_kernel");
+    hipLaunchKernelGGL(prepass_extend_kernel, dim3((e->B + 63) / 64), dim3(64), 0, e->stream, (const DevParams*)e->P_dev, e->S);
+}
 // S0 of every group-0 triple on this step's list (lob_kernels.h memo_kernel): `which` 0 = for learn_kernel
 // (theta_t), 1 = for the next act_kernel (after the update)
 static void launch_memo(lob_engine* e, int par, int which) {
@@ -578,6 +597,7 @@ int lob_reset(lob_engine* e) {
     HIPCHK(hipGetLastError());
     e->was_reset = true;
     e->episode_open = true;
+    e->steps_since_fill = 0;
     return check_device_errors(e);
 }
 
@@ -601,6 +621,7 @@ int lob_step(lob_engine* e, const int32_t* host_actions) {
         TimedLaunch t(e, "env_kernel");
         launch_env(e, e->stream, (const i32*)e->actions_dev, 0, 0, e->B, 0);
     }
+    maybe_refill_track(e);
     HIPCHK(hipGetLastError());
     return check_device_errors(e);
 }
@@ -770,6 +791,7 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode) {
             e->theta_ver++;                          // theta_{t+1}
             if (e->P.memo) launch_memo(e, par, 1);   // the same triples again, for the next act_kernel
         }
+        maybe_refill_track(e);
     }
     HIPCHK(hipGetLastError());
     return LOB_OK;

@@ -50,8 +50,8 @@ struct EnvCtx {
     __device__ EnvCtx(const DevParams& p, const DevState& s, int book, const uint32_t* rows_) : P(p), S(s), b(book), rows(rows_) {}
     __device__ void err(int bit) const { atomicOr(S.error_flag, bit); }
     __device__ const uint32_t* row(int i) const { return rows + (size_t)i * (size_t)P.W; }
-    __device__ const Track& track(int k) const { return S.track[(size_t)b * (size_t)S.n_events + (size_t)k]; }
-    __device__ Track& track_w(int k) const { return S.track[(size_t)b * (size_t)S.n_events + (size_t)k]; }
+    __device__ const Track& track(int k) const { return S.track[(size_t)b * (size_t)S.track_len + (size_t)(k & S.track_mask)]; }
+    __device__ Track& track_w(int k) const { return S.track[(size_t)b * (size_t)S.track_len + (size_t)(k & S.track_mask)]; }
 };
 
 __device__ inline f64 key4(f64 p) { return rint(p * 10000.0); }  // utilities/comparison.h:4-34
@@ -614,6 +614,8 @@ __device__ inline bool next_state(const EnvCtx& c, EnvR& e) {
     i64 tv[LOB_MAX_TRADES];
     i64 au_vol, bu_vol; f64 au_proxy, au_value, bu_proxy, bu_value;
     if (e.k >= M.n_track) {
+        // the ring of a long stream ran dry before its next refill: the run is void (reported as LOB_ESTATE)
+        if (!M.complete) c.err(LOB_ERR_TRACK_UNDERRUN);
         // out of data inside this event (Streamer::LoadNext fails, src/data/streamer.cpp:42-49)
         if (M.ex_first >= 0) {
             load_trades(c, (e.k > 0 ? c.track(e.k - 1).rec_first : M.rec_cur0) + 1, M.ex_first, tp, tv);
@@ -903,15 +905,15 @@ __device__ inline void persist_io(const DevState& S, int b, bool save) {
     }
 }
 
-// The whole agent-independent evolution of one book: Initialise's skip to market
-// open, then one Track entry per NextState until the stream runs dry.
-// `replay` > 0: only re-run the window arithmetic of the first `replay` events
-// (no track writes) to recover the exact window sums at the point where the
-// previous episode stopped (quirk Q7: sums survive ClearWindows()).
-__device__ inline void market_prepass(const EnvCtx& c, int replay) {
+// The agent-independent evolution of one book, resumable: `prepass_begin` is Initialise's ClearWindows
+// and skip to market open; `prepass_run` then writes one Track entry per NextState until `k_stop`
+// events exist or the stream runs dry, and leaves its registers in `st` for the next call
+// (prepass_extend_kernel).  `write_track` false: only the window arithmetic (finalize_kernel's replay
+// of the events an episode consumed, quirk Q7: sums survive ClearWindows()).
+__device__ inline void prepass_begin(const EnvCtx& c, PrepState& st, BookMeta& M) {
     const DevParams& P = c.P;
     const DevState& S = c.S;
-    const int b = c.b, B = S.B;
+    const int b = c.b;
     MarketR m;
     m.cursor = 0; m.time_ms = 0; m.rec_cur = -1; m.rec_last = -1;
     m.ap0 = m.bp0 = m.lap0 = m.lbp0 = 0.0;
@@ -924,18 +926,36 @@ __device__ inline void market_prepass(const EnvCtx& c, int replay) {
     LOB_ROLLING_MEANS(X)
     LOB_ACCUMULATORS(X)
 #undef X
-    BookMeta M;
-    M.n_track = 0; M.k_warm = -1; M.init_ok = 0;
+    M.n_track = 0; M.k_warm = -1; M.init_ok = 0; M.complete = 0; M._pad = 0;
     M.ex_first = -1; M.ex_cur = -1; M.ex_last = -1; M.ex_time = 0; M.ex_records = 0;
     bool ok = true;
     while (ok && !is_open(P, m.time_ms)) ok = mk_update_book_profiles(c, m);
     M.rec_cur0 = m.rec_cur; M.rec_last0 = m.rec_last; M.time0 = m.time_ms;
     M.mid0 = (m.ap0 + m.bp0) / 2.0; M.mid_prev0 = (m.lap0 + m.lbp0) / 2.0;
-    if (!ok) { M.ex_cur = m.rec_cur; M.ex_last = m.rec_last; M.ex_time = m.time_ms; }
-    int k = 0;
-    int prev_first = m.rec_cur;  // Initialise: time_and_sales.SkipUntil(market time) drops everything up to here
-    while (ok) {
-        if (replay > 0 && k >= replay) break;
+    if (!ok) { M.ex_cur = m.rec_cur; M.ex_last = m.rec_last; M.ex_time = m.time_ms; M.complete = 1; }
+    st.cursor = m.cursor; st.time_ms = m.time_ms; st.rec_cur = m.rec_cur; st.rec_last = m.rec_last;
+    st.ap0 = m.ap0; st.bp0 = m.bp0; st.lap0 = m.lap0; st.lbp0 = m.lbp0;
+    st.a_tv = m.a_tv; st.b_tv = m.b_tv;
+    st.ewma_up = m.ewma_up; st.ewma_down = m.ewma_down; st.tp_val = m.tp_val;
+    st.records = m.records;
+    st.k = 0;
+    st.prev_first = m.rec_cur;  // Initialise: time_and_sales.SkipUntil(market time) drops everything up to here
+}
+
+__device__ inline void prepass_run(const EnvCtx& c, PrepState& st, BookMeta& M, int k_stop, bool write_track) {
+    const DevParams& P = c.P;
+    const DevState& S = c.S;
+    const int b = c.b, B = S.B;
+    MarketR m;
+    m.cursor = st.cursor; m.time_ms = st.time_ms; m.rec_cur = st.rec_cur; m.rec_last = st.rec_last;
+    m.ap0 = st.ap0; m.bp0 = st.bp0; m.lap0 = st.lap0; m.lbp0 = st.lbp0;
+    m.a_tv = st.a_tv; m.b_tv = st.b_tv;
+    m.a_obsval = m.b_obsval = 0.0; m.a_obsvol = m.b_obsvol = 0;
+    m.ewma_up = st.ewma_up; m.ewma_down = st.ewma_down; m.tp_val = st.tp_val;
+    m.records = st.records;
+    int k = st.k;
+    int prev_first = st.prev_first;
+    while (!M.complete && k < k_stop) {
         const int first = m.cursor;
         f64 tp[LOB_MAX_TRADES];
         i64 tv[LOB_MAX_TRADES];
@@ -963,6 +983,7 @@ __device__ inline void market_prepass(const EnvCtx& c, int replay) {
         if (!mk_update_book_profiles(c, m)) {
             M.ex_first = first; M.ex_cur = m.rec_cur; M.ex_last = m.rec_last; M.ex_time = m.time_ms;
             M.ex_records = m.records - rec0;
+            M.complete = 1;
             break;
         }
         if (m.lap0 == 0.0 || m.lbp0 == 0.0) c.err(LOB_ERR_UNDEF_PRICE);
@@ -1002,7 +1023,7 @@ __device__ inline void market_prepass(const EnvCtx& c, int replay) {
         rm_apply(S.f_ask_tx, B, b, w_atx, (f64)m.a_obsvol);
         rm_apply(S.f_bid_tx, B, b, w_btx, (f64)m.b_obsvol);
 
-        if (replay <= 0) {
+        if (write_track) {
             Track t;
             t.rec_first = first; t.rec_last = m.rec_cur; t.time_ms = m.time_ms;
             t.tick_ap0 = tick_ap0; t.tick_bp0 = tick_bp0; t._pad = 0;
@@ -1041,11 +1062,17 @@ __device__ inline void market_prepass(const EnvCtx& c, int replay) {
         }
         k++;
     }
+    st.cursor = m.cursor; st.time_ms = m.time_ms; st.rec_cur = m.rec_cur; st.rec_last = m.rec_last;
+    st.ap0 = m.ap0; st.bp0 = m.bp0; st.lap0 = m.lap0; st.lbp0 = m.lbp0;
+    st.a_tv = m.a_tv; st.b_tv = m.b_tv;
+    st.ewma_up = m.ewma_up; st.ewma_down = m.ewma_down; st.tp_val = m.tp_val;
+    st.records = m.records;
+    st.k = k;
+    st.prev_first = prev_first;
     S.ewma_up[b] = m.ewma_up; S.ewma_down[b] = m.ewma_down; S.tp_val[b] = m.tp_val;
-    if (replay <= 0) {
+    if (write_track) {
         M.n_track = k;
         M.init_ok = M.k_warm > 0 ? 1 : 0;
-        S.meta[b] = M;
     }
 }
 

@@ -25,6 +25,7 @@ struct TickView {
 };
 __device__ inline TickView P_tick(const DevParams& P) { return TickView{P.n_bands, P.band_lb, P.band_tick, P.band_cum, P.band_pt, P.band_pp}; }
 
+#define LOB_TRACK_MARGIN 4
 #include "lob_env.h"
 #include "lob_learn.h"
 
@@ -87,8 +88,15 @@ __global__ void __launch_bounds__(RB) reset_kernel(const DevParams* __restrict__
     env_load(S, b, e);  // position, pnl_step, quote levels etc. persist across episodes
     const i64 ev0 = e.events;
     persist_io(S, b, true);  // sums as of this episode's start
-    market_prepass(c, 0);
-    const BookMeta M = S.meta[b];
+    BookMeta M;
+    {
+        // the whole stream when its track is resident, else the first ring-full (prepass_extend_kernel goes on from there)
+        PrepState st;
+        prepass_begin(c, st, M);
+        prepass_run(c, st, M, S.track_mask == 0x7fffffff ? 0x7fffffff : S.track_len - LOB_TRACK_MARGIN, true);
+        S.meta[b] = M;
+        S.prep[b] = st;
+    }
     e.done = 0;
     e.ask_quote = 0.0; e.bid_quote = 0.0;
     e.a_ntr = 0; e.a_on = 0; e.b_ntr = 0; e.b_on = 0;
@@ -146,7 +154,32 @@ __global__ void __launch_bounds__(256, 1) finalize_kernel(const DevParams* __res
     EnvCtx c(P, S, b);
     persist_io(S, b, false);
     const int k = S.k[b];
-    if (k > 0) market_prepass(c, k);
+    if (k > 0) {
+        PrepState st;
+        BookMeta M;
+        prepass_begin(c, st, M);
+        prepass_run(c, st, M, k, false);
+    }
+}
+
+// Long streams (a recorded day: tens of thousands of events per book, more than a resident track of
+// 96 B per event and book leaves room for at 65 536 books): the track is a ring of the latest
+// `track_len` entries per book, and every few steps this kernel lets every book's pre-pass run on from
+// where it stopped until the ring is full again -- up to LOB_TRACK_MARGIN entries short of overwriting
+// what the agent side may still look at (events k - 2 .. k).
+__global__ void __launch_bounds__(64) prepass_extend_kernel(const DevParams* __restrict__ Pp, DevState S) {
+    const DevParams& P = *Pp;
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= S.B) return;
+    BookMeta M = S.meta[b];
+    if (M.complete) return;
+    const int k_stop = S.k[b] + S.track_len - LOB_TRACK_MARGIN;
+    PrepState st = S.prep[b];
+    if (st.k >= k_stop) return;
+    EnvCtx c(P, S, b);
+    prepass_run(c, st, M, k_stop, true);
+    S.meta[b] = M;
+    S.prep[b] = st;
 }
 
 // Evaluate getState() for every book (lob_get_state): lane per book.

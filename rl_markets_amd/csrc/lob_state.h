@@ -94,7 +94,7 @@ struct __attribute__((aligned(16))) Track {
 
 // Per-book summary of the market pre-pass.
 struct BookMeta {
-    i32 n_track;    // complete events available
+    i32 n_track;    // events whose Track entry exists so far (all of them once `complete`)
     i32 k_warm;     // events consumed by Intraday::Initialise (windows full)
     i32 init_ok;    // 0: ran out of data during Initialise
     i32 rec_cur0, rec_last0, time0;  // state after the "skip to market open" phase
@@ -102,6 +102,20 @@ struct BookMeta {
     i32 ex_cur, ex_last, ex_time;    // snapshot records / time after that abandoned event
     i64 ex_records; // depth records consumed by the abandoned event
     f64 mid0, mid_prev0;
+    i32 complete;   // the pre-pass has reached the end of the stream (else it continues from `prep`: prepass_extend_kernel)
+    i32 _pad;
+};
+
+// Where the (resumable) pre-pass of a book stands: the agent-independent registers of
+// Intraday::NextState between two events.  The windows themselves are in DevState (rings in HBM).
+struct PrepState {
+    i32 cursor, time_ms, rec_cur, rec_last;
+    f64 ap0, bp0, lap0, lbp0;   // best prices of the current / stashed snapshot (0 = undefined)
+    i64 a_tv, b_tv;             // cumulative total_volume_ (quirk Q1)
+    f64 ewma_up, ewma_down, tp_val;
+    i64 records;
+    i32 k;            // events produced so far
+    i32 prev_first;   // record up to which the trades have been handed over
 };
 
 // Per-book learner header (Runner / Agent / Traces scalars), one 64-byte
@@ -172,8 +186,14 @@ struct DevState {
     LOB_ACCUMULATORS(X)
 #undef X
 
-    Track* track;      // [B][n_events] market track (pre-pass)
+    // Market track: one entry per NextState event, written by the pre-pass.  A stream of up to
+    // `track_len` events has its whole track resident (index = k); a longer one (a recorded day of
+    // tens of thousands of events) keeps a ring of the `track_len` (a power of two) latest entries per
+    // book, refilled every few steps (prepass_extend_kernel): index = k & track_mask.
+    Track* track;      // [B][track_len]
+    i32 track_len, track_mask;
     BookMeta* meta;    // [B]
+    PrepState* prep;   // [B]
     f64* ewma_up;      // [B] return_ups / return_downs EWMA means (persist across episodes)
     f64* ewma_down;
     f64* tp_val;       // [B] TargetPrice::val_ (persists)
@@ -275,6 +295,7 @@ struct DevParams {
 #define LOB_ERR_BAD_ORDER_PRICE 1  /* Order ctor would throw (src/market/order.cpp:22-27) */
 #define LOB_ERR_BAD_LEVEL 2        /* ApplyChanges would throw (src/market/book.cpp:74-77) */
 #define LOB_ERR_UNDEF_PRICE 4
+#define LOB_ERR_TRACK_UNDERRUN 16   /* a book consumed its market-track ring faster than it was refilled (LOB_TRACK_RING / LOB_TRACK_REFILL) */
 #define LOB_ERR_TRADE_OVERFLOW 8   /* more distinct trade price keys in one event than max_trades slots */      /* Book::price() would throw (src/market/book.cpp:171-173) */
 
 #endif

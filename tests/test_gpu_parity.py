@@ -552,3 +552,59 @@ def test_group0_memo_on_off_identical(monkeypatch, algo):
         if t0 is not None:
             np.testing.assert_allclose(t0, t1, rtol=1e-9, atol=1e-12, err_msg="td, record %d" % k)
     np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-9, atol=1e-12)
+
+
+# ---- long streams: the market track as a ring, refilled while the episode runs ------------------------
+@pytest.mark.parametrize("ring,refill", [(256, 8), (512, 40)])
+def test_long_streams_use_a_track_ring(monkeypatch, ring, refill):
+    """A stream longer than LOB_TRACK_RING keeps only a ring of the latest track entries per book; the
+    pre-pass runs on every LOB_TRACK_REFILL steps (prepass_extend_kernel).  Nothing may show in the
+    results: every step against the oracle, through the end of the stream, a second episode (the window
+    sums replayed to where the first one stopped, quirk Q7) and external actions."""
+    monkeypatch.setenv("LOB_TRACK_RING", str(ring))
+    monkeypatch.setenv("LOB_TRACK_REFILL", str(refill))
+    B = 40
+    p, g, rec, eng, orc = make(depth=10, n_events=1400, B=B, algo=abi.ALGO_QLAMBDA, theta_mode=abi.THETA_SHARED, mem=1 << 18)
+    eng.reset()
+    orc.reset()
+    step = 0
+    while eng.counters()[2] > 0 and step < 1500:
+        n = 1 if step < 200 or step % 7 == 0 else 5
+        eng.td_step(n)
+        orc.td_step(n)
+        step += n
+        if n == 1:
+            compare_learner_step(eng, orc, "ring %d step %d" % (ring, step), exact=False, rtol=1e-9)
+    assert eng.counters()[2] == 0 and step > 400           # every book ran its stream dry, far beyond one ring
+    compare_env(eng, orc, "ring: end of episode 1")
+    eng.clear_inventory(); orc.clear_inventory()
+    eng.handle_terminal(); orc.handle_terminal()
+    eng.reset(); orc.reset()
+    rng = np.random.default_rng(1)
+    for step in range(60):
+        if step % 9 == 8:
+            a = rng.integers(0, 9, size=B).astype(np.int32)
+            eng.step(a)
+            orc.env_step(a)
+            compare_env(eng, orc, "ring: episode 2 external step %d" % step)
+        else:
+            eng.td_step(1)
+            orc.td_step(1)
+            compare_learner_step(eng, orc, "ring: episode 2 step %d" % step, exact=False, rtol=1e-9)
+    np.testing.assert_allclose(eng.theta(), orc.theta(), rtol=1e-9, atol=1e-12)
+    eng.close()
+    orc.close()
+
+
+def test_track_ring_underrun_is_reported(monkeypatch):
+    """A ring that is not refilled in time must not go unnoticed: the run is void and the next
+    synchronising call says so."""
+    monkeypatch.setenv("LOB_TRACK_RING", "256")
+    monkeypatch.setenv("LOB_TRACK_REFILL", "100000")
+    p, g, rec, eng, orc = make(depth=5, n_events=1200, B=8)
+    orc.close()
+    eng.reset()
+    with pytest.raises(engine.LobError, match="ring underrun"):
+        eng.td_step(400)
+        eng.sync()
+    eng.close()

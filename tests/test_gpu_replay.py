@@ -148,3 +148,47 @@ def test_config5_full_size_against_oracle(tmp_path):
     np.testing.assert_allclose(th, oth, rtol=1e-9, atol=1e-12)
     eng.close()
     orc.close()
+
+
+def test_config5_full_day_at_full_size(tmp_path, monkeypatch):
+    """BASELINE config 5 with a whole recorded day per book: 65 536 books x 50 000 events each of one
+    61 200-event LOBSTER-format day.  A resident market track would take 65 536 x 50 000 x 96 B = 315 GB;
+    the 4 096-entry ring takes 26 GB.  With alpha = 0 the books do not interact, so sampled books of the
+    big run must equal one-book engines given the same global book id and window -- whose tracks are
+    made RESIDENT (LOB_TRACK_RING above the stream length): ring against resident, 600 steps deep
+    (several ring refills)."""
+    B, n_total, n_events, steps = 65536, 61200, 50000, 600
+    day = lobster_day(tmp_path, n_total)
+    rng = np.random.default_rng(9)
+    phase = rng.integers(0, n_total - n_events + 1, size=B)
+    p = replay_params(abi.REWARD_PNL_DAMPED, mem=20000000)
+    p.alpha = 0.0
+    eng = engine.Engine(p, B)
+    eng.load_events_shared(day, phase, n_events)
+    eng.reset()
+    eng.td_step(steps)
+    cnt = eng.counters()
+    assert cnt[0] == steps * B and cnt[1] > 4096 * B / 4     # (events consumed incl. the skip to market open)
+    big = dumps_to_np(eng.get_books())
+    acts, rew = eng.last_actions(), eng.last_rewards()
+    monkeypatch.setenv("LOB_TRACK_RING", str(1 << 16))
+    for b in [0, 4097, 65535]:
+        p1 = replay_params(abi.REWARD_PNL_DAMPED, mem=20000000)
+        p1.alpha = 0.0
+        p1.book_id_offset = b
+        one = engine.Engine(p1, 1)
+        one.load_events(day[phase[b]:phase[b] + n_events][None])
+        one.reset()
+        one.td_step(steps)
+        d = dumps_to_np(one.get_books())
+        for name in d.dtype.names:
+            assert np.array_equal(d[name][0], big[name][b]), (b, name)
+        assert one.last_actions()[0] == acts[b] and one.last_rewards()[0] == rew[b]
+        one.close()
+    # and with learning on
+    eng.set_alpha(0.001)
+    eng.td_step(100)
+    assert eng.counters()[0] == (steps + 100) * B
+    th = eng.theta()
+    assert np.isfinite(th).all() and np.count_nonzero(th) > 1000
+    eng.close()
