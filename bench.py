@@ -325,7 +325,7 @@ def main():
 
 
 KERNELS = ("act_kernel", "act_rest_kernel", "env_kernel", "memo_kernel", "trace_kernel", "learn_kernel", "learn_rest_kernel",
-           "update_kernel", "accumulate_kernel", "apply_kernel", "delta_begin_kernel", "delta_apply_kernel")
+           "update_kernel", "accumulate_kernel", "apply_kernel", "prepass_extend_kernel", "delta_begin_kernel", "delta_apply_kernel")
 
 if __name__ == "__main__":
     main()

@@ -212,6 +212,34 @@ __device__ inline void rm_apply(const RMPtrs& r, int B, int b, RMReg& g, f64 val
     g.head = g.slot;
     r.cnt[b] = g.cnt; r.head[b] = g.head; r.sum[b] = g.sum; r.mean[b] = g.mean; r.s[b] = g.s;
 }
+// Register-resident variants for the pre-pass, whose event loop pushes into the same windows thousands of
+// times in a row: the running state (count, head, sum, mean, S) stays in registers from rm_load to
+// rm_store, only the ring slots go through memory.
+__device__ inline void rm_apply_reg(const RMPtrs& r, int B, int b, RMReg& g, f64 val) {
+    g.sum += val;
+    r.ring[(size_t)g.slot * B + b] = val;
+    if (g.cnt < r.w) {
+        g.cnt++;
+        f64 n = (f64)g.cnt;
+        f64 old_mean = g.mean;
+        g.mean += (val - g.mean) / n;
+        g.s += (val - g.mean) * (val - old_mean);
+    } else {
+        f64 n = (f64)(g.cnt + 1);
+        f64 old_mean = g.mean;
+        g.mean += (val - g.mean) / n;
+        g.s += (val - g.mean) * (val - old_mean);
+        g.sum -= g.old;
+        f64 n2 = (f64)g.cnt;
+        f64 old_mean2 = g.mean;
+        g.mean -= (g.old - g.mean) / n2;
+        g.s -= (g.old - g.mean) * (g.old - old_mean2);
+    }
+    g.head = g.slot;
+}
+__device__ inline void rm_store(const RMPtrs& r, int b, const RMReg& g) {
+    r.cnt[b] = g.cnt; r.head[b] = g.head; r.sum[b] = g.sum; r.mean[b] = g.mean; r.s[b] = g.s;
+}
 struct AccReg {
     i32 cnt, head, slot;
     f64 sum, old;
@@ -229,6 +257,15 @@ __device__ inline void acc_apply(const AccPtrs& r, int B, int b, AccReg& g, f64 
     g.head = g.slot;
     r.cnt[b] = g.cnt; r.head[b] = g.head; r.sum[b] = g.sum;
 }
+
+__device__ inline void acc_apply_reg(const AccPtrs& r, int B, int b, AccReg& g, f64 val) {
+    g.sum += val;
+    r.ring[(size_t)g.slot * B + b] = val;
+    if (g.cnt < r.w) g.cnt++;
+    else g.sum -= g.old;
+    g.head = g.slot;
+}
+__device__ inline void acc_store(const AccPtrs& r, int b, const AccReg& g) { r.cnt[b] = g.cnt; r.head[b] = g.head; r.sum[b] = g.sum; }
 
 // ---- snapshots are read straight from the (immutable) event records ---------
 __device__ inline f64 rec_price(const EnvCtx& c, int rec, int side, int l) {
@@ -955,6 +992,12 @@ __device__ inline void prepass_run(const EnvCtx& c, PrepState& st, BookMeta& M, 
     m.records = st.records;
     int k = st.k;
     int prev_first = st.prev_first;
+    // the ten windows of intraday.cpp:253-269: state in registers for the whole run
+    RMReg w_mid, w_vol, w_spr, w_tp, w_atx, w_btx;
+    AccReg w_vn, w_vd;
+    rm_load(S.f_midprice, b, w_mid); rm_load(S.f_volatility, b, w_vol); rm_load(S.spread_window, b, w_spr);
+    rm_load(S.tp_mp, b, w_tp); rm_load(S.f_ask_tx, b, w_atx); rm_load(S.f_bid_tx, b, w_btx);
+    acc_load(S.f_vwap_numer, b, w_vn); acc_load(S.f_vwap_denom, b, w_vd);
     while (!M.complete && k < k_stop) {
         const int first = m.cursor;
         f64 tp[LOB_MAX_TRADES];
@@ -991,20 +1034,15 @@ __device__ inline void prepass_run(const EnvCtx& c, PrepState& st, BookMeta& M, 
         const int tick_ap0 = lobh::to_ticks_t(P_tick(P), m.ap0), tick_bp0 = lobh::to_ticks_t(P_tick(P), m.bp0);
         const i64 mpt = (i64)lobh::to_ticks_t(P_tick(P), mid);
         const f64 mpm = mid - lmid, sp = m.ap0 - m.bp0;
-        // ten window pushes (intraday.cpp:253-269), batched: all loads, then all stores
-        RMReg w_mid, w_vol, w_spr, w_tp, w_atx, w_btx;
-        AccReg w_vn, w_vd;
-        rm_load(S.f_midprice, b, w_mid); rm_load(S.f_volatility, b, w_vol); rm_load(S.spread_window, b, w_spr);
-        rm_load(S.tp_mp, b, w_tp); rm_load(S.f_ask_tx, b, w_atx); rm_load(S.f_bid_tx, b, w_btx);
-        acc_load(S.f_vwap_numer, b, w_vn); acc_load(S.f_vwap_denom, b, w_vd);
+        // ten window pushes (intraday.cpp:253-269), batched: the ring slots that fall out are fetched together
         rm_prep(S.f_midprice, B, b, w_mid); rm_prep(S.f_volatility, B, b, w_vol); rm_prep(S.spread_window, B, b, w_spr);
         rm_prep(S.tp_mp, B, b, w_tp); rm_prep(S.f_ask_tx, B, b, w_atx); rm_prep(S.f_bid_tx, B, b, w_btx);
         acc_prep(S.f_vwap_numer, B, b, w_vn); acc_prep(S.f_vwap_denom, B, b, w_vd);
-        rm_apply(S.f_midprice, B, b, w_mid, (f64)mpt);
-        rm_apply(S.f_volatility, B, b, w_vol, (f64)mpt);
-        acc_apply(S.f_vwap_numer, B, b, w_vn, m.a_obsval + m.b_obsval);
-        acc_apply(S.f_vwap_denom, B, b, w_vd, (f64)(m.a_obsvol + m.b_obsvol));
-        rm_apply(S.spread_window, B, b, w_spr, 0.0 > sp ? 0.0 : sp);
+        rm_apply_reg(S.f_midprice, B, b, w_mid, (f64)mpt);
+        rm_apply_reg(S.f_volatility, B, b, w_vol, (f64)mpt);
+        acc_apply_reg(S.f_vwap_numer, B, b, w_vn, m.a_obsval + m.b_obsval);
+        acc_apply_reg(S.f_vwap_denom, B, b, w_vd, (f64)(m.a_obsvol + m.b_obsvol));
+        rm_apply_reg(S.spread_window, B, b, w_spr, 0.0 > sp ? 0.0 : sp);
         // TargetPrice::update (src/market/target_price.cpp:44-71)
         f64 micro;
         {   // measure::microprice (measures.h:40-55)
@@ -1012,7 +1050,7 @@ __device__ inline void prepass_run(const EnvCtx& c, PrepState& st, BookMeta& M, 
             f64 mpm_a = (f64)m.a_tv * m.bp0, mpm_b = m.ap0 * (f64)m.b_tv;
             micro = (mpm_a + mpm_b) / div;
         }
-        rm_apply(S.tp_mp, B, b, w_tp, P.target_price == LOB_TP_MICROPRICE ? micro : mid);
+        rm_apply_reg(S.tp_mp, B, b, w_tp, P.target_price == LOB_TP_MICROPRICE ? micro : mid);
         m.tp_val = w_tp.mean;
         {   // EWMA<double>::push (accumulators.cpp:157-163)
             f64 up = 0.0 > mpm ? 0.0 : mpm;
@@ -1020,8 +1058,8 @@ __device__ inline void prepass_run(const EnvCtx& c, PrepState& st, BookMeta& M, 
             m.ewma_up = (P.ewma_alpha * up) + ((1 - P.ewma_alpha) * m.ewma_up);
             m.ewma_down = (P.ewma_alpha * dn) + ((1 - P.ewma_alpha) * m.ewma_down);
         }
-        rm_apply(S.f_ask_tx, B, b, w_atx, (f64)m.a_obsvol);
-        rm_apply(S.f_bid_tx, B, b, w_btx, (f64)m.b_obsvol);
+        rm_apply_reg(S.f_ask_tx, B, b, w_atx, (f64)m.a_obsvol);
+        rm_apply_reg(S.f_bid_tx, B, b, w_btx, (f64)m.b_obsvol);
 
         if (write_track) {
             Track t;
@@ -1062,6 +1100,9 @@ __device__ inline void prepass_run(const EnvCtx& c, PrepState& st, BookMeta& M, 
         }
         k++;
     }
+    rm_store(S.f_midprice, b, w_mid); rm_store(S.f_volatility, b, w_vol); rm_store(S.spread_window, b, w_spr);
+    rm_store(S.tp_mp, b, w_tp); rm_store(S.f_ask_tx, b, w_atx); rm_store(S.f_bid_tx, b, w_btx);
+    acc_store(S.f_vwap_numer, b, w_vn); acc_store(S.f_vwap_denom, b, w_vd);
     st.cursor = m.cursor; st.time_ms = m.time_ms; st.rec_cur = m.rec_cur; st.rec_last = m.rec_last;
     st.ap0 = m.ap0; st.bp0 = m.bp0; st.lap0 = m.lap0; st.lbp0 = m.lbp0;
     st.a_tv = m.a_tv; st.b_tv = m.b_tv;
