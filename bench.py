@@ -38,6 +38,8 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 def algorithmic_bytes(kernel, depth, trades, n_vars, n_live, events_per_step):
     rec = 4 * ((2 + 4 * depth + 2 * trades + 3) // 4 * 4)
     hdr = 64                          # learner header, one 64-byte record per book
+    if kernel == "trace_kernel":      # header + state slots + Q(last,.) in; trace index list r/w, header out (the trace half of the former learn_kernel)
+        return hdr + 192 + 9 * 8 + n_live * 4 + 32 * 4 + 26 * 4 + 32
     if kernel == "act_kernel":        # header + 3 state slots in, 9*96 weights (f64), Q(last,.) + header out
         return hdr + 192 + 9 * 96 * 8 + 9 * 8 + 32
     if kernel == "learn_kernel":      # header + slots + Q(last,.) in, 9*96 weights, trace index list r/w, header out
@@ -54,6 +56,20 @@ def algorithmic_bytes(kernel, depth, trades, n_vars, n_live, events_per_step):
     if kernel == "reset_kernel":      # per event of the stream: the record in, the track entry out (events_per_step = events per book here)
         return events_per_step * (rec + 96) + 2 * 232
     return 0
+
+
+# timer name (lob_kernel_time_ms) -> kernel function(s) launched under it, as rocprofv3 names them
+TIMER_KERNELS = {"act_kernel": ("act_fast_kernel", "act_kernel"), "trace_kernel": ("trace_fast_kernel",),
+                 "learn_kernel": ("learn_q_fast_kernel", "learn_kernel"), "act_rest_kernel": (), "learn_rest_kernel": ()}
+
+
+def traffic_of(traffic_file, timer):
+    """HBM bytes per launch of the kernel behind a timer, from profiles/pmc_traffic.json (None if absent)."""
+    for fn in TIMER_KERNELS.get(timer, (timer,)):
+        v = traffic_file.get(fn, {}).get("hbm_bytes_per_launch") if isinstance(traffic_file.get(fn), dict) else None
+        if v:
+            return v
+    return None
 
 
 def hip_device_sync():
@@ -248,7 +264,7 @@ def main():
                 per_book = algorithmic_bytes(k, args.depth, 2, p.n_vars, n_live, eps)
                 live_books = steps_done / world / max(ktimes["env_kernel"]["launches"], 1)   # books one launch covers
                 ach = per_book * live_books / (v["avg_ms"] * 1e-3) / 1e9
-                tr = traffic_file.get(k, {}).get("hbm_bytes_per_launch")
+                tr = traffic_of(traffic_file, k)
                 per_kernel[k] = {"avg_ms": round(v["avg_ms"], 4), "launches": v["launches"],
                                  "algorithmic_bytes_per_book": round(per_book, 1), "achieved_GBps": round(ach, 1),
                                  "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": tr,
@@ -257,7 +273,7 @@ def main():
                 "avg_ms": round(reset_ms, 3), "launches": 1, "note": "once per episode, outside `value`; see value_amortised",
                 "algorithmic_bytes_per_book": round(algorithmic_bytes("reset_kernel", args.depth, 2, p.n_vars, 0, g.n_events), 1),
                 "achieved_GBps": round(algorithmic_bytes("reset_kernel", args.depth, 2, p.n_vars, 0, g.n_events) * args.books / (reset_ms * 1e-3) / 1e9, 1) if reset_ms else None,
-                "traffic": traffic_file.get("reset_kernel", {}).get("hbm_bytes_per_launch")}
+                "traffic": traffic_of(traffic_file, "reset_kernel")}
             dom = max((k for k in ktimes if not k.startswith("delta")), key=lambda k: ktimes[k]["avg_ms"])
             d = per_kernel[dom]
             roofline = {"bound": "hbm", "kernel": dom, "achieved": d["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

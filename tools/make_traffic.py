@@ -24,6 +24,9 @@ for k, c in sorted(rows.items()):
     if c.get("TCC_MISS_sum"):
         e["fetch_over_miss64"] = round(c["FETCH_SIZE"] * 1024.0 / (c["TCC_MISS_sum"] * 64.0), 3)
     out[k] = e
+out["_source"] = "profiles/%s_pmc.csv: rocprofv3 --pmc passes of the bench command (one counter group per pass), averages per launch; a static file, not measured in the bench run itself" % tag
 json.dump(out, open(os.path.join(root, "profiles", "pmc_traffic.json"), "w"), indent=1)
 for k, e in out.items():
+    if k.startswith("_"):
+        continue
     print(k, round(e["hbm_bytes_per_launch"] / 1e6, 1), "MB/launch", e.get("fetch_over_miss64"))

@@ -9,7 +9,9 @@ TAG=${1:-r01}; shift
 OUT=$REPO/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $REPO/bench.py --steps 40 --warmup 200 --no-cpu-baseline --no-kernel-timing"
+# the profiled command = the bench command itself (its own HIP-event timers off, no CPU baseline leg)
+CMD=${PROF_CMD:-"python $REPO/bench.py --gpus 1 --no-cpu-baseline --no-kernel-timing"}
+export PROF_CMD_STR="$CMD"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- $CMD > $OUT/${TAG}_stats.log 2>&1
 i=0
 for grp in "$@"; do

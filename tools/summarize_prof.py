@@ -20,7 +20,7 @@ for f in glob.glob(os.path.join(stats_dir, "**", "*kernel_stats.csv"), recursive
             rows.append((short(r["Name"]), int(r["Calls"]), float(r["TotalDurationNs"]), float(r["AverageNs"]), float(r["Percentage"])))
 rows.sort(key=lambda r: -r[2])
 with open(os.path.join(out_dir, tag + "_kernel_stats.csv"), "w") as fh:
-    fh.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 40 --warmup 200 --no-cpu-baseline --no-kernel-timing\n")
+    fh.write("# rocprofv3 --kernel-trace --stats -- %s\n" % os.environ.get("PROF_CMD_STR", "python bench.py --no-cpu-baseline --no-kernel-timing").replace(os.environ.get("GRAFT_REPO_ROOT", "/root/repo") + "/", ""))
     fh.write("kernel,calls,total_ms,avg_us,percent\n")
     for n, c, t, a, p in rows:
         fh.write("%s,%d,%.3f,%.2f,%.2f\n" % (n, c, t / 1e6, a / 1e3, p))
