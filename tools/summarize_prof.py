@@ -10,7 +10,7 @@ pmc_dirs = sys.argv[4:]
 
 def short(name):
     name = name.replace("void ", "")
-    return name.split("(")[0]
+    return name.split("(")[0].replace(", ", ";")   # template arguments must not break the CSV
 
 
 rows = []
