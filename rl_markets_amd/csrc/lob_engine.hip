@@ -191,7 +191,6 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     if (p->memory_size < 1 || p->memory_size >= (1LL << 31)) { lob_set_error("lob_create: memory_size out of range"); return LOB_EINVAL; }
     if (p->market.n_bands < 1 || p->market.n_bands > LOB_MAX_BANDS) { lob_set_error("lob_create: bad tick table"); return LOB_EINVAL; }
     if (p->algo < LOB_ALGO_SARSA || p->algo > LOB_ALGO_DOUBLE_Q) { lob_set_error("lob_create: unknown algorithm"); return LOB_EINVAL; }
-    if (p->reward_measure == LOB_REWARD_MM_EXP) { lob_set_error("lob_create: reward mm_exp not implemented (SURVEY.md §8f N4)"); return LOB_EINVAL; }
     const int lbs[] = {p->lb_mpm, p->lb_vlt, p->lb_svl, p->lb_vwap, p->lb_rsi, p->lb_spread, p->lb_pnl, p->lb_target};
     for (int w : lbs)
         if (w < 1 || w > LOB_MAX_WINDOW) { lob_set_error("lob_create: lookbacks must be in [1,256]"); return LOB_EINVAL; }

@@ -474,6 +474,43 @@ __device__ inline bool is_open(const DevParams& P, i32 t) {  // Market::IsOpen, 
     return ((i64)t > P.open_ms + 30 * 60000LL) && ((i64)t < P.close_ms - 30 * 60000LL);
 }
 
+// std::exp(float) as the reference's libm computes it (glibc 2.35 x86-64, sysdeps/ieee754/flt-32/e_expf.c,
+// the FMA build its ifunc selects on every CPU this runs beside): exp(x) = 2^(k/32) * 2^(r/32) with a
+// 32-entry table and a cubic in double precision, every multiply-add fused.  tools/check_expf.c compares
+// this restatement with libm's expf over ALL 2^32 - 2^24 non-NaN inputs: 0 differences.
+__device__ inline f32 expf_glibc(f32 x) {
+    static const u64 T[32] = {
+        0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, 0x3fef72b83c7d517bull,
+        0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull, 0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull,
+        0x3feedea64c123422ull, 0x3feece086061892dull, 0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull,
+        0x3feea47eb03a5585ull, 0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+        0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull, 0x3feee89f995ad3adull,
+        0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full,
+        0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+    const f64 N = 32.0;
+    const f64 InvLn2N = 0x1.71547652b82fep+0 * N, SHIFT = 0x1.8p+52;
+    const f64 C0 = 0x1.c6af84b912394p-5 / N / N / N, C1 = 0x1.ebfce50fac4f3p-3 / N / N, C2 = 0x1.62e42ff0c52d6p-1 / N;
+    const uint32_t ux = __float_as_uint(x), ax = ux & 0x7fffffffu;
+    if (ax >= 0x42b00000u) {  // |x| >= 88 or NaN
+        if (ux == 0xff800000u) return 0.0f;
+        if (ax >= 0x7f800000u) return x + x;
+        if (x > 0x1.62e42ep6f) return __uint_as_float(0x7f800000u);
+        if (x < -0x1.9fe368p6f) return 0.0f;
+    }
+    const f64 xd = (f64)x;
+    f64 kd = fma(InvLn2N, xd, SHIFT);
+    const u64 ki = (u64)__double_as_longlong(kd);
+    kd -= SHIFT;
+    const f64 r = fma(InvLn2N, xd, -kd);
+    const f64 s = __longlong_as_double((long long)(T[ki % 32] + (ki << 47)));
+    const f64 z = fma(C0, r, C1);
+    const f64 r2 = r * r;
+    f64 y = fma(C2, r, 1.0);
+    y = fma(z, r2, y);
+    y = y * s;
+    return (f32)y;
+}
+
 // Base::getReward (base.cpp:166-237)
 __device__ inline f64 get_reward(const EnvCtx& c, const EnvR& e) {
     const DevParams& P = c.P;
@@ -514,7 +551,16 @@ __device__ inline f64 get_reward(const EnvCtx& c, const EnvR& e) {
             }
             break;
         }
-        default: break;  // mm_exp: not on the north-star path
+        case LOB_REWARD_MM_EXP: {
+            // -pow(1.0 - exp(r_pos_weight * abs_pos), 2) + r_pnl_weight * pnl_step: the product and the exp are float
+            // (std::exp(float)), pow(x, 2) is x * x in the compiled reference (and exactly rounded either way)
+            const f32 ex = expf_glibc(P.pos_weight * (f32)abs_pos);
+            const f64 t = 1.0 - (f64)ex;
+            r = -(t * t);
+            r += (f64)P.pnl_weight * e.pnl_step;
+            break;
+        }
+        default: break;
     }
     return r * 100;
 }

@@ -20,7 +20,7 @@
 // virtual in the reference; they read Base's protected members, so after every step this class
 // mirrors the engine's values (pnl_step, momentum_pnl_step, lo_vol_step, position, episode totals) into
 // them: getReward() then evaluates the reference's own formula on the engine's numbers.  That covers
-// the rewards built from those members (none, pnl, pnl_damped, lovol, mm_linear, mm_div); `spread` and
+// the rewards built from those members (none, pnl, pnl_damped, lovol, mm_linear, mm_exp, mm_div); `spread` and
 // `normed` read Base's rolling windows, which live on the GPU here: the constructor rejects them unless
 // the one-line change of INTEGRATION.md (`virtual` on Base::getReward) is applied.  Base::ClearInventory()
 // (non-virtual too; Runner::RunEpisode's epilogue calls it through a Base&) runs the REFERENCE's market
@@ -126,7 +126,7 @@ public:
         params_.pos_ub = c["market"]["pos_ub"].as<long>();
         static const std::map<std::string, int> r2i = {
             {"none", LOB_REWARD_NONE}, {"pnl", LOB_REWARD_PNL}, {"pnl_damped", LOB_REWARD_PNL_DAMPED},
-            {"lovol", LOB_REWARD_LOVOL}, {"mm_linear", LOB_REWARD_MM_LINEAR}, {"mm_div", LOB_REWARD_MM_DIV}};
+            {"lovol", LOB_REWARD_LOVOL}, {"mm_linear", LOB_REWARD_MM_LINEAR}, {"mm_exp", LOB_REWARD_MM_EXP}, {"mm_div", LOB_REWARD_MM_DIV}};
         const std::string rm = c["reward"]["measure"].as<std::string>("pnl");
         if (!r2i.count(rm))
             throw std::runtime_error("GpuIntraday: reward measure " + rm + " reads Base's windows through the non-virtual getReward(); "

@@ -47,6 +47,9 @@ TRAJ_CASES = [
     ("sarsa_spread_b15", "sarsa", 400, 15, {"reward": "spread"}, {"reward_measure": abi.REWARD_SPREAD}),
     ("qlearn_mm_div_b16", "q_learn", 400, 16, {"reward": "mm_div"}, {"reward_measure": abi.REWARD_MM_DIV}),
     ("sarsa_lovol_b18", "sarsa", 400, 18, {"reward": "lovol"}, {"reward_measure": abi.REWARD_LOVOL}),
+    # mm_exp: -(1 - exp(pos_weight * |position|))^2 with the float std::exp of the reference's libm
+    ("sarsa_mm_exp_b20", "sarsa", 500, 20, {"reward": "mm_exp", "pos_weight": "0.05", "eps": "0.5"},
+     {"reward_measure": abi.REWARD_MM_EXP, "pos_weight": 0.05, "epsilon": 0.5}),
     # a NaN state variable: vwap over a window without trades is 0/0, ulb() passes the NaN on, the
     # tile coder turns it into INT_MIN coordinates (x86 conversion) -- inside group 0, i.e. in the traces
     ("qlearn_vwap_nan_b19", "q_learn", 420, 19,
