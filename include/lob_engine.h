@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LOB_ABI_VERSION 1
+#define LOB_ABI_VERSION 2
 
 #define LOB_N_ACTIONS 9   /* reference Intraday::DoAction table, src/environment/intraday.cpp:181-219 */
 #define LOB_N_TILINGS 32  /* config/example.yaml:18 (compile-time in the kernels) */
@@ -90,6 +90,13 @@ enum { LOB_ALGO_SARSA = 0, LOB_ALGO_QLAMBDA = 1, LOB_ALGO_DOUBLE_Q = 2 };
  * single-book reference; used for exact parity tests). */
 enum { LOB_THETA_SHARED = 0, LOB_THETA_PRIVATE = 1 };
 
+/* Behaviour policy: rl::EpsilonGreedy (src/rl/policy.cpp:58-82; epsilon 0 = rl::Greedy, 1 = rl::Random's
+ * uniform action) or rl::Boltzmann (policy.cpp:85-122): P(a) ~ exp(Q(a) / tau), one uniform draw.
+ * The exponential is the device's double-precision exp (<= 1 ulp from libm's): the sampled action can
+ * differ from the reference's only when the draw falls within ~1e-15 of a cumulative-probability
+ * boundary. */
+enum { LOB_POLICY_EPS_GREEDY = 0, LOB_POLICY_BOLTZMANN = 1 };
+
 /* Venue description: reference market::Market (include/market/market.h:13-52).
  * Bands ascending by lower bound, as std::map<double,double> pts_ iterates. */
 typedef struct lob_market {
@@ -137,6 +144,9 @@ typedef struct lob_params {
     int32_t theta_mode;         /* LOB_THETA_* */
     uint64_t seed;              /* counter-based policy RNG seed (DESIGN.md "RNG") */
     uint64_t book_id_offset;    /* global id of local book 0 (multi-GPU shards) */
+    int32_t policy;             /* LOB_POLICY_* */
+    int32_t _pad_policy;
+    double tau;                 /* Boltzmann temperature (schedule host-side, lob_set_tau) */
 } lob_params;
 
 /* Synthetic event-stream generator. */
@@ -303,6 +313,7 @@ int lob_eval_step(lob_engine* e, int32_t n_steps);
 int lob_handle_terminal(lob_engine* e);
 int lob_set_alpha(lob_engine* e, double alpha);
 int lob_set_epsilon(lob_engine* e, double epsilon);
+int lob_set_tau(lob_engine* e, double tau);
 
 /* State::newState(vector<float>&) + getFeatures (src/rl/state.cpp:45-70):
  * n states of n_vars floats -> int32[n][9][96] tile indices. */

@@ -948,7 +948,7 @@ struct oracle_learner {
     std::vector<uint64_t> rng_ctr;
     std::vector<int> done;  // 0 live, 1 terminal, 2 out of data
     std::vector<oracle_step_rec> recs;
-    double alpha, epsilon;
+    double alpha, epsilon, tau;
     int64_t n_steps_done = 0, n_updates = 0;
 
     double* th(int b) { return theta[P.theta_mode == LOB_THETA_PRIVATE ? b : 0].data(); }
@@ -996,6 +996,20 @@ struct oracle_learner {
         return argmax;
     }
     int policy_sample(int b, const double* qs, bool greedy) {  // EpsilonGreedy::Sample, policy.cpp:69-75
+        if (!greedy && P.policy == LOB_POLICY_BOLTZMANN) {  // Boltzmann::Sample, policy.cpp:98-117
+            double prob[9], z = 0.0;
+            for (int a = 0; a < 9; a++) {
+                prob[a] = std::exp(qs[a] / tau);
+                z += prob[a];
+            }
+            double acc = 0.0;
+            const double r = (double)(raw(b) >> 11) * (1.0 / 9007199254740992.0);
+            for (int a = 0; a < 9; a++) {
+                acc += prob[a] / z;
+                if (r < acc) return a;
+            }
+            return 8;
+        }
         if (!greedy) {
             double u = (double)(raw(b) >> 11) * (1.0 / 9007199254740992.0);
             if (u < epsilon) return (int)(((raw(b) >> 32) * 9ull) >> 32);
@@ -1060,6 +1074,7 @@ oracle_learner* oracle_create(const lob_params* p, int32_t n_books, const uint32
     o->recs.resize(n_books);
     o->alpha = p->alpha;
     o->epsilon = p->epsilon;
+    o->tau = p->tau;
     return o;
 }
 void oracle_destroy(oracle_learner* o) { delete o; }
@@ -1201,6 +1216,7 @@ int oracle_handle_terminal(oracle_learner* o) {
 }
 void oracle_set_alpha(oracle_learner* o, double a) { o->alpha = a; }
 void oracle_set_epsilon(oracle_learner* o, double e) { o->epsilon = e; }
+void oracle_set_tau(oracle_learner* o, double t) { o->tau = t; }
 void oracle_get_rec(oracle_learner* o, int32_t book, oracle_step_rec* out) { *out = o->recs[book]; }
 double* oracle_theta(oracle_learner* o, int32_t which) { return o->theta[which].data(); }
 double* oracle_theta_b(oracle_learner* o, int32_t which) { return o->theta_b.empty() ? nullptr : o->theta_b[which].data(); }

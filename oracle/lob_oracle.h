@@ -56,6 +56,7 @@ int oracle_clear_inventory(oracle_learner* o);
 int oracle_handle_terminal(oracle_learner* o);
 void oracle_set_alpha(oracle_learner* o, double a);
 void oracle_set_epsilon(oracle_learner* o, double e);
+void oracle_set_tau(oracle_learner* o, double t);
 /* last step's record for `book` */
 void oracle_get_rec(oracle_learner* o, int32_t book, oracle_step_rec* out);
 double* oracle_theta(oracle_learner* o, int32_t which);

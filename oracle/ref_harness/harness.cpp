@@ -104,6 +104,26 @@ public:
     double descr() override { return eps; }
 };
 
+// rl::Boltzmann (src/rl/policy.cpp:85-122) with its one uniform draw injected: Sample restated only as far
+// as the draw forces (the probabilities and the cumulative scan are the reference's own arithmetic).
+class ReplayBoltzmann : public rl::Boltzmann {
+public:
+    ReplayBoltzmann(unsigned n_actions, double tau) : rl::Boltzmann(n_actions, tau, tau, 1, 1) {}
+    unsigned int Sample(std::vector<double>& qs) override {
+        double z = 0.0;
+        for (int a = 0; a < N_ACTIONS; a++) {
+            probabilities[a] = std::exp(qs[a] / tau);
+            z += probabilities[a];
+        }
+        double acc = 0.0;
+        double r = (double)(next_raw() >> 11) * (1.0 / 9007199254740992.0);
+        for (int a = 0; a < N_ACTIONS; a++) {
+            acc += probabilities[a] / z;
+            if (r < acc) return a;
+        }
+        return N_ACTIONS - 1;
+    }
+};
 // ---------------------------------------------------------------------------
 // Expose protected state of the reference classes (no behaviour change).
 class ProbeEnv : public environment::Intraday<> {
@@ -203,6 +223,11 @@ static Args parse(int argc, char** argv, int from) {
         a.kv[k] = argv[i + 1];
     }
     return a;
+}
+
+static std::unique_ptr<rl::Policy> make_policy(const Args& a) {
+    if (a.get("policy", "epsilon_greedy") == "boltzmann") return std::unique_ptr<rl::Policy>(new ReplayBoltzmann(9, a.getd("tau", 1.0)));
+    return std::unique_ptr<rl::Policy>(new ReplayPolicy(9, a.getd("eps", 0.8)));
 }
 
 // Write the reference's two CSV formats (include/data/basic.h:17-24,49-52)
@@ -309,9 +334,8 @@ template <class A> static void dump_theta_b(A& ag, const std::string& path) {
 
 template <class AGENT>
 static int run_episode(const Args& a, Config& c, ProbeEnv& env, const std::string& out_path) {
-    double eps = a.getd("eps", 0.8);
     long max_steps = a.geti("steps", 1L << 40);
-    ProbeAgent<AGENT> agent(std::unique_ptr<rl::Policy>(new ReplayPolicy(9, eps)), c);
+    ProbeAgent<AGENT> agent(make_policy(a), c);
     if (a.kv.count("theta_in")) {
         FILE* f = fopen(a.get("theta_in").c_str(), "rb");
         if (!f || fread(agent.theta_ptr(), 8, agent.mem(), f) != (size_t)agent.mem()) { fprintf(stderr, "theta_in\n"); return 2; }
@@ -477,7 +501,7 @@ public:
 };
 template <class AGENT>
 static int run_dropin(const Args& a, Config& c, environment::GpuIntraday& env, const std::string& out_path) {
-    RecordingAgent<AGENT> agent(std::unique_ptr<rl::Policy>(new ReplayPolicy(9, a.getd("eps", 0.8))), c);
+    RecordingAgent<AGENT> agent(make_policy(a), c);
     agent.env = &env;
     agent.out = fopen(out_path.c_str(), "wb");
     if (!agent.out) { perror("out"); return 2; }

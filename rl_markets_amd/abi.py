@@ -30,6 +30,7 @@ TP_MIDPRICE, TP_MICROPRICE = 0, 1
 QUOTE_TARGET, QUOTE_BOOK = 0, 1
 ALGO_SARSA, ALGO_QLAMBDA, ALGO_DOUBLE_Q = 0, 1, 2
 THETA_SHARED, THETA_PRIVATE = 0, 1
+POLICY_EPS_GREEDY, POLICY_BOLTZMANN = 0, 1
 
 
 class _Strict(C.Structure):
@@ -62,6 +63,7 @@ class Params(_Strict):
         ("group_weights", C.c_double * 3), ("gamma", C.c_double), ("lambda_", C.c_double),
         ("alpha", C.c_double), ("epsilon", C.c_double),
         ("algo", C.c_int32), ("theta_mode", C.c_int32), ("seed", C.c_uint64), ("book_id_offset", C.c_uint64),
+        ("policy", C.c_int32), ("_pad_policy", C.c_int32), ("tau", C.c_double),
     ]
 
 
@@ -158,6 +160,7 @@ def load():
         "lob_handle_terminal": (C.c_int, [vp]),
         "lob_set_alpha": (C.c_int, [vp, C.c_double]),
         "lob_set_epsilon": (C.c_int, [vp, C.c_double]),
+        "lob_set_tau": (C.c_int, [vp, C.c_double]),
         "lob_features": (C.c_int, [vp, vp, C.c_int32, vp]),
         "lob_q_values": (C.c_int, [vp, vp, C.c_int32, vp]),
         "lob_theta_get": (C.c_int, [vp, C.c_int32, vp, C.c_int64]),

@@ -191,6 +191,8 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     if (p->memory_size < 1 || p->memory_size >= (1LL << 31)) { lob_set_error("lob_create: memory_size out of range"); return LOB_EINVAL; }
     if (p->market.n_bands < 1 || p->market.n_bands > LOB_MAX_BANDS) { lob_set_error("lob_create: bad tick table"); return LOB_EINVAL; }
     if (p->algo < LOB_ALGO_SARSA || p->algo > LOB_ALGO_DOUBLE_Q) { lob_set_error("lob_create: unknown algorithm"); return LOB_EINVAL; }
+    if (p->policy != LOB_POLICY_EPS_GREEDY && p->policy != LOB_POLICY_BOLTZMANN) { lob_set_error("lob_create: unknown policy"); return LOB_EINVAL; }
+    if (p->policy == LOB_POLICY_BOLTZMANN && !(p->tau > 0.0)) { lob_set_error("lob_create: Boltzmann temperature must be positive"); return LOB_EINVAL; }
     const int lbs[] = {p->lb_mpm, p->lb_vlt, p->lb_svl, p->lb_vwap, p->lb_rsi, p->lb_spread, p->lb_pnl, p->lb_target};
     for (int w : lbs)
         if (w < 1 || w > LOB_MAX_WINDOW) { lob_set_error("lob_create: lookbacks must be in [1,256]"); return LOB_EINVAL; }
@@ -265,6 +267,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     P.M = p->memory_size;
     P.w0 = p->group_weights[0]; P.w1 = p->group_weights[1]; P.w2 = p->group_weights[2];
     P.gamma = p->gamma; P.alpha = p->alpha; P.epsilon = p->epsilon;
+    P.policy = p->policy; P.tau = p->tau;
     P.trace_rate = trace_rate;
     for (int k = 0; k <= LOB_TRACE_GENS; k++) P.trace_pow[k] = trace_pow[k];
     P.trace_kmax = trace_kmax;
@@ -817,6 +820,7 @@ int lob_handle_terminal(lob_engine* e) {
     return LOB_OK;
 }
 int lob_set_alpha(lob_engine* e, double alpha) { if (!e) return LOB_EINVAL; e->P.alpha = alpha; e->params.alpha = alpha; hipSetDevice(e->device); return push_params(e); }
+int lob_set_tau(lob_engine* e, double tau) { if (!e || !(tau > 0.0)) return LOB_EINVAL; e->P.tau = tau; e->params.tau = tau; hipSetDevice(e->device); return push_params(e); }
 int lob_set_epsilon(lob_engine* e, double eps) { if (!e) return LOB_EINVAL; e->P.epsilon = eps; e->params.epsilon = eps; hipSetDevice(e->device); return push_params(e); }
 
 static int features_impl(lob_engine* e, const float* host_vars, int32_t n, int32_t* out_idx, double* out_q) {

@@ -277,7 +277,7 @@ __global__ void __launch_bounds__(LOB_FAST_BLOCK) act_fast_kernel(DevParams P, D
             if (!go[k]) continue;
             if (lane < LOB_N_ACTIONS) S.qs_last[(size_t)b[k] * LOB_N_ACTIONS + lane] = sel9(qs[k], lane);
             Rng g{P.seed, P.book_id_offset + (u64)b[k], h[k].rng_ctr};
-            const int action = policy_sample(qs[k], P.epsilon, mode == 1, g);
+            const int action = policy_sample(P, qs[k], mode == 1, g);
             if (lane == 0) {
                 LHdr* hp = S.hdr + b[k];
                 hp->slot_cur = cur[k];

@@ -158,6 +158,8 @@ void lob_default_params(lob_params* p) {
     p->theta_mode = LOB_THETA_SHARED;
     p->seed = 1994;
     p->book_id_offset = 0;
+    p->policy = LOB_POLICY_EPS_GREEDY;
+    p->tau = 1.0;
 }
 
 void lob_default_gen_params(lob_gen_params* g) {

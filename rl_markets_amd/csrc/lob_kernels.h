@@ -506,7 +506,7 @@ __device__ __forceinline__ void act_book(const DevParams& P, const DevState& S, 
         for (int a = 0; a < LOB_N_ACTIONS; a++) qs[a] = (qs[a] + qb[a]) / 2.0;
     }
     Rng g{P.seed, P.book_id_offset + (u64)b, h.rng_ctr};
-    const int action = policy_sample(qs, P.epsilon, mode == 1, g);
+    const int action = policy_sample(P, qs, mode == 1, g);
     if (lane == 0) {
         hp->slot_cur = cur;
         hp->action = action;
@@ -763,7 +763,7 @@ __device__ __forceinline__ void learn_delta_single(const DevParams& P, LHdr* hp,
         const int am2 = argmax_ties(qs_to, g);  // maxQ(to_state)
         delta = h.reward + F_term + P.gamma * sel9(qs_to, am2) - q_sa;
     } else {
-        const int a2 = policy_sample(qs_to, P.epsilon, false, g);  // this->action(to_state), quirk Q9
+        const int a2 = policy_sample(P, qs_to, false, g);  // this->action(to_state), quirk Q9
         delta = h.reward + F_term + P.gamma * sel9(qs_to, a2) - q_sa;
     }
     if (lane == 0) {

@@ -116,11 +116,32 @@ __device__ inline int greedy_sample(const f64* qs, Rng& g) {
     }
     return argmax;
 }
-// EpsilonGreedy::Sample (policy.cpp:69-75)
-__device__ inline int policy_sample(const f64* qs, f64 eps, bool greedy, Rng& g) {
+// Boltzmann::Sample (policy.cpp:98-117): probabilities exp(Q / tau) / z, one uniform draw, first action whose
+// cumulative probability exceeds it.
+__device__ inline int boltzmann_sample(const f64* qs, f64 tau, Rng& g) {
+    f64 p[LOB_N_ACTIONS], z = 0.0;
+#pragma unroll
+    for (int a = 0; a < LOB_N_ACTIONS; a++) {
+        p[a] = exp(qs[a] / tau);
+        z += p[a];
+    }
+    const f64 r = (f64)(g.raw() >> 11) * (1.0 / 9007199254740992.0);
+    f64 acc = 0.0;
+    int act = LOB_N_ACTIONS - 1;
+    bool found = false;
+#pragma unroll
+    for (int a = 0; a < LOB_N_ACTIONS; a++) {
+        acc += p[a] / z;
+        if (!found && r < acc) { act = a; found = true; }
+    }
+    return act;
+}
+// The behaviour policy: EpsilonGreedy::Sample (policy.cpp:69-75) or Boltzmann; `greedy`: Agent::GoGreedy().
+__device__ inline int policy_sample(const DevParams& P, const f64* qs, bool greedy, Rng& g) {
     if (!greedy) {
+        if (P.policy == LOB_POLICY_BOLTZMANN) return boltzmann_sample(qs, P.tau, g);
         f64 u = (f64)(g.raw() >> 11) * (1.0 / 9007199254740992.0);
-        if (u < eps) return (int)(((g.raw() >> 32) * 9ull) >> 32);
+        if (u < P.epsilon) return (int)(((g.raw() >> 32) * 9ull) >> 32);
     }
     return greedy_sample(qs, g);
 }

@@ -280,6 +280,8 @@ struct DevParams {
     i64 M;
     f64 w0, w1, w2;
     f64 gamma, alpha, epsilon;
+    i32 policy;                       // LOB_POLICY_*
+    f64 tau;                          // Boltzmann temperature
     f32 trace_rate;                   // (float)(gamma*lambda)
     f32 trace_pow[LOB_TRACE_GENS + 1];  // eligibility by age, iterated float products
     i32 trace_kmax;                   // first age whose eligibility < tolerance

@@ -177,6 +177,9 @@ class Engine:
     def set_epsilon(self, e):
         self._check(self.lib.lob_set_epsilon(self.h, e))
 
+    def set_tau(self, t):
+        self._check(self.lib.lob_set_tau(self.h, t))
+
     def features(self, vars_):
         v = np.ascontiguousarray(vars_, dtype=np.float32).reshape(-1, self.V)
         out = np.zeros((v.shape[0], 9, 96), np.int32)

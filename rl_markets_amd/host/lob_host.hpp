@@ -191,7 +191,7 @@ public:
         if (pt == "greedy") p.epsilon = 0.0;
         else if (pt == "epsilon_greedy") p.epsilon = (double)(float)num("policy.eps_init", 0.0);
         else if (pt == "random") p.epsilon = 1.0;   // RandomPolicy::Sample = the uniform branch of EpsilonGreedy, always taken
-        else if (pt == "boltzmann") throw std::invalid_argument("policy.type boltzmann is not supported (SURVEY.md §8f N4)");
+        else if (pt == "boltzmann") { p.policy = LOB_POLICY_BOLTZMANN; p.tau = (double)(float)num("policy.tau_init"); }  // float in main.cpp:156-157
         else throw std::runtime_error("Please specify a valid policy!");  // main.cpp:164-165
         std::string algo = str("learning.algorithm", "sarsa");
         if (algo == "sarsa") p.algo = LOB_ALGO_SARSA;
@@ -287,6 +287,8 @@ class Agent {
     double alpha_start_, alpha_floor_, omega_;
     double eps_init_, eps_floor_, eps_T_;
     bool eps_schedule_;  // only EpsilonGreedy::HandleTerminal moves epsilon (policy.cpp:19,79-82)
+    bool tau_schedule_;  // Boltzmann::HandleTerminal (policy.cpp:119-122)
+    double tau_init_ = 1.0, tau_floor_ = 1.0, tau_T_ = 1.0;
     bool greedy_ = false;
 
 public:
@@ -294,7 +296,13 @@ public:
         : env_(env), alpha_start_(c.num("learning.alpha_start", 0.2)), alpha_floor_(c.num("learning.alpha_floor", 0.001)),
           omega_(c.num("learning.omega", 1.0)), eps_init_((double)(float)c.num("policy.eps_init", 0.0)),
           eps_floor_((double)(float)c.num("policy.eps_floor", 0.0)), eps_T_(c.num("policy.eps_T", 1.0)),  // float in main.cpp:149-150
-          eps_schedule_(c.str("policy.type", "") == "epsilon_greedy") {}
+          eps_schedule_(c.str("policy.type", "") == "epsilon_greedy"), tau_schedule_(c.str("policy.type", "") == "boltzmann") {
+        if (tau_schedule_) {
+            tau_init_ = (double)(float)c.num("policy.tau_init");
+            tau_floor_ = (double)(float)c.num("policy.tau_floor");
+            tau_T_ = c.num("policy.tau_T", 1.0);
+        }
+    }
     void GoGreedy() { greedy_ = true; }
     bool greedy() const { return greedy_; }
     // Agent::HandleTerminal (agent.cpp:103-109) + EpsilonGreedy::HandleTerminal (policy.cpp:79-82)
@@ -306,6 +314,11 @@ public:
             double eps = eps_init_ * std::pow(eps_floor_ / eps_init_, (double)episode / eps_T_);
             check(lob_set_epsilon(env_.handle(), eps), "HandleTerminal");
             epsilon_ = eps;
+        }
+        if (tau_schedule_) {
+            double tau = tau_init_ * std::pow(tau_floor_ / tau_init_, (double)episode / tau_T_);
+            check(lob_set_tau(env_.handle(), tau), "HandleTerminal");
+            epsilon_ = tau;  // Policy::descr() of the training log
         }
     }
     double epsilon_ = -1.0;

@@ -48,6 +48,8 @@ TRAJ_CASES = [
     ("qlearn_mm_div_b16", "q_learn", 400, 16, {"reward": "mm_div"}, {"reward_measure": abi.REWARD_MM_DIV}),
     ("sarsa_lovol_b18", "sarsa", 400, 18, {"reward": "lovol"}, {"reward_measure": abi.REWARD_LOVOL}),
     # mm_exp: -(1 - exp(pos_weight * |position|))^2 with the float std::exp of the reference's libm
+    # rl::Boltzmann behaviour policy (SARSA also draws its bootstrap action from it, quirk Q9)
+    ("sarsa_boltzmann_b23", "sarsa", 500, 23, {"policy": "boltzmann", "tau": "25.0"}, {"policy": abi.POLICY_BOLTZMANN, "tau": 25.0}),
     ("sarsa_mm_exp_b20", "sarsa", 500, 20, {"reward": "mm_exp", "pos_weight": "0.05", "eps": "0.5"},
      {"reward_measure": abi.REWARD_MM_EXP, "pos_weight": 0.05, "epsilon": 0.5}),
     # a NaN state variable: vwap over a window without trades is 0/0, ulb() passes the NaN on, the

@@ -24,7 +24,7 @@ DROPIN = os.path.join(ROOT, "oracle", "_ref", "ref_dropin")
 
 # the fixtures whose reward Base::getReward() can compute from mirrored members, default state variables
 CASES = [c for c in TRAJ_CASES if c[0] in ("sarsa_b0", "qlearn_b3", "sarsa_mm_linear_b11", "sarsa_tight_bounds_b7", "sarsa_book_quotes_b9",
-                                          "qlearn_mm_div_b16", "sarsa_lovol_b18", "sarsa_mm_exp_b20")]
+                                          "qlearn_mm_div_b16", "sarsa_lovol_b18", "sarsa_mm_exp_b20", "sarsa_boltzmann_b23")]
 
 
 @pytest.mark.skipif(not os.path.exists(DROPIN), reason="oracle/_ref/ref_dropin is built where the reference checkout is (make -C oracle dropin)")
