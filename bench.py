@@ -38,12 +38,12 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 def algorithmic_bytes(kernel, depth, trades, n_vars, n_live, events_per_step):
     rec = 4 * ((2 + 4 * depth + 2 * trades + 3) // 4 * 4)
     hdr = 64                          # learner header, one 64-byte record per book
-    if kernel == "trace_kernel":      # header + state slots + Q(last,.) in; trace index list r/w, header out (the trace half of the former learn_kernel)
+    if kernel == "trace_kernel":      # UpdateTraces: header + state slots + Q(last,.) in; trace index list r/w, new generation + masks, header out
         return hdr + 192 + 9 * 8 + n_live * 4 + 32 * 4 + 26 * 4 + 32
     if kernel == "act_kernel":        # header + 3 state slots in, 9*96 weights (f64), Q(last,.) + header out
         return hdr + 192 + 9 * 96 * 8 + 9 * 8 + 32
-    if kernel == "learn_kernel":      # header + slots + Q(last,.) in, 9*96 weights, trace index list r/w, header out
-        return hdr + 192 + 9 * 8 + 9 * 96 * 8 + n_live * 4 + 32 * 4 + 26 * 4 + 32
+    if kernel == "learn_kernel":      # Q(s', .) + TD error: header + slots in, 9*96 weights, header out (the traces are trace_kernel's)
+        return hdr + 192 + 9 * 96 * 8 + 32
     if kernel == "update_kernel":     # per live trace: index (4) + theta read-modify-write (8 + 8); header + masks
         return hdr + n_live * (4 + 8 + 8) + 26 * 4
     if kernel in ("accumulate_kernel", "apply_kernel"):
