@@ -252,7 +252,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     // ---- DevParams ----
     DevParams& P = e->P;
     memset(&P, 0, sizeof P);
-    P.D = p->depth; P.T = p->max_trades; P.W = lob_rec_words(p->depth, p->max_trades); P.V = p->n_vars;
+    P.D = p->depth; P.T = p->max_trades; P.W = lob_rec_words(p->depth, p->max_trades); P.Wd = drec_words(p->depth, p->max_trades); P.V = p->n_vars;
     for (int i = 0; i < LOB_MAX_VARS; i++) P.vars[i] = p->vars[i];
     lobh::TickTable tt;
     lobh::build_tick_table(p->market, tt);
@@ -478,7 +478,7 @@ static int set_records(lob_engine* e, int32_t n_events, size_t n_rows) {
     if (e->records_dev) { hipFree(e->records_dev); e->records_dev = nullptr; }
     if (e->phase_dev) { hipFree(e->phase_dev); e->phase_dev = nullptr; }
     if (e->track_dev) { hipFree(e->track_dev); e->track_dev = nullptr; }
-    size_t bytes = n_rows * e->P.W * 4;
+    size_t bytes = n_rows * e->P.Wd * 4;
     hipError_t err = hipMalloc((void**)&e->records_dev, bytes);
     if (err != hipSuccess) { e->records_dev = nullptr; lob_set_error("hipMalloc(records) failed"); return LOB_ENOMEM; }
     // market track: resident (one entry per event) up to track_ring events per book, a ring of that many beyond
@@ -501,6 +501,23 @@ static int set_records(lob_engine* e, int32_t n_events, size_t n_rows) {
     return LOB_OK;
 }
 
+// host ABI records -> HBM in the device layout (through a temporary device copy)
+static int upload_records(lob_engine* e, const uint32_t* host_records, size_t n_records) {
+    uint32_t* tmp = nullptr;
+    const size_t bytes = n_records * e->P.W * 4;
+    if (hipMalloc((void**)&tmp, bytes) != hipSuccess) { lob_set_error("hipMalloc(upload buffer) failed"); return LOB_ENOMEM; }
+    hipError_t err = hipMemcpyAsync(tmp, host_records, bytes, hipMemcpyHostToDevice, e->stream);
+    if (err == hipSuccess) {
+        hipLaunchKernelGGL(repack_kernel, dim3((unsigned)((n_records + 255) / 256)), dim3(256), 0, e->stream, (const uint32_t*)tmp, e->P.D, e->P.T,
+                           n_records, e->records_dev);
+        err = hipGetLastError();
+    }
+    if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+    hipFree(tmp);
+    if (err != hipSuccess) { lob_set_error(std::string("record upload: ") + hipGetErrorString(err)); return LOB_EHIP; }
+    return LOB_OK;
+}
+
 int lob_load_events(lob_engine* e, const uint32_t* host_records, int32_t n_events) {
     if (!e || !host_records || n_events < 2) { lob_set_error("lob_load_events: bad argument"); return LOB_EINVAL; }
     HIPCHK(hipSetDevice(e->device));
@@ -508,9 +525,7 @@ int lob_load_events(lob_engine* e, const uint32_t* host_records, int32_t n_event
     if (rc != LOB_OK) return rc;
     rc = set_records(e, n_events, (size_t)e->B * n_events);
     if (rc != LOB_OK) return rc;
-    HIPCHK(hipMemcpyAsync(e->records_dev, host_records, (size_t)e->B * n_events * e->P.W * 4, hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
-    return LOB_OK;
+    return upload_records(e, host_records, (size_t)e->B * n_events);
 }
 
 int lob_load_events_shared(lob_engine* e, const uint32_t* host_records, int64_t n_total, const int64_t* phase, int32_t n_events) {
@@ -530,7 +545,8 @@ int lob_load_events_shared(lob_engine* e, const uint32_t* host_records, int64_t 
     if (rc != LOB_OK) return rc;
     hipError_t err = hipMalloc((void**)&e->phase_dev, (size_t)e->B * sizeof(i64));
     if (err != hipSuccess) { lob_set_error("hipMalloc(phase) failed"); return LOB_ENOMEM; }
-    HIPCHK(hipMemcpyAsync(e->records_dev, host_records, (size_t)n_total * e->P.W * 4, hipMemcpyHostToDevice, e->stream));
+    rc = upload_records(e, host_records, (size_t)n_total);
+    if (rc != LOB_OK) return rc;
     HIPCHK(hipMemcpyAsync(e->phase_dev, phase, (size_t)e->B * sizeof(i64), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     e->S.rec_phase = e->phase_dev;

@@ -32,6 +32,53 @@
 #include "lob_internal.h"
 #include "lob_state.h"
 
+// ---- records in HBM: the device layout --------------------------------------------------------------
+// The ABI's record (lob_engine.h / lob_stream.h: time, flags, ask_px[D], ask_vol[D], bid_px[D], bid_vol[D],
+// trade_px[T], trade_vol[T]) is re-packed on the way into HBM so that every array starts on a 16-byte
+// boundary and the trades are (price, volume) pairs: a level array is ceil(D / 4) 16-byte loads instead of
+// D 4-byte ones.  The lane-per-book kernels are bound by the number of divergent loads a lane issues
+// (every book reads its own records), not by bytes.
+//   [0] time_ms [1] flags [2] 0 [3] 0 | ask_px[D4] | ask_vol[D4] | bid_px[D4] | bid_vol[D4] | (trade_px, trade_vol)[T] padded to 4
+LOB_HD int drec_pad4(int n) { return (n + 3) & ~3; }
+LOB_HD int drec_words(int D, int T) { return 4 + 4 * drec_pad4(D) + drec_pad4(2 * T); }
+LOB_HD int drec_ask_px(int, int) { return 4; }
+LOB_HD int drec_ask_vol(int D, int) { return 4 + drec_pad4(D); }
+LOB_HD int drec_bid_px(int D, int) { return 4 + 2 * drec_pad4(D); }
+LOB_HD int drec_bid_vol(int D, int) { return 4 + 3 * drec_pad4(D); }
+LOB_HD int drec_trades(int D, int) { return 4 + 4 * drec_pad4(D); }
+// ABI record -> device record (host upload path: repack_kernel; the synthetic generator writes it directly)
+LOB_HD void drec_from_abi(const uint32_t* src, int D, int T, uint32_t* dst) {
+    const int Wd = drec_words(D, T);
+    for (int i = 0; i < Wd; i++) dst[i] = 0;
+    dst[0] = src[LOB_REC_TIME];
+    dst[1] = src[LOB_REC_FLAGS];
+    for (int l = 0; l < D; l++) {
+        dst[drec_ask_px(D, T) + l] = src[lob_rec_ask_px(D, T) + l];
+        dst[drec_ask_vol(D, T) + l] = src[lob_rec_ask_vol(D, T) + l];
+        dst[drec_bid_px(D, T) + l] = src[lob_rec_bid_px(D, T) + l];
+        dst[drec_bid_vol(D, T) + l] = src[lob_rec_bid_vol(D, T) + l];
+    }
+    for (int i = 0; i < T; i++) {
+        dst[drec_trades(D, T) + 2 * i] = src[lob_rec_trade_px(D, T) + i];
+        dst[drec_trades(D, T) + 2 * i + 1] = src[lob_rec_trade_vol(D, T) + i];
+    }
+}
+#if defined(__HIPCC__)
+// One level array (16-byte aligned, D <= LOB_MAX_DEPTH words used) in ceil(D / 4) loads; entries >= D come back 0.
+__device__ inline void drec_levels(const uint32_t* arr, int D, uint32_t* out) {
+    const uint4* a4 = reinterpret_cast<const uint4*>(arr);
+#pragma unroll
+    for (int q = 0; q < (LOB_MAX_DEPTH + 3) / 4; q++) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (q * 4 < D) v = a4[q];  // wave-uniform
+        if (q * 4 + 0 < LOB_MAX_DEPTH) out[q * 4 + 0] = v.x;
+        if (q * 4 + 1 < LOB_MAX_DEPTH) out[q * 4 + 1] = v.y;
+        if (q * 4 + 2 < LOB_MAX_DEPTH) out[q * 4 + 2] = v.z;
+        if (q * 4 + 3 < LOB_MAX_DEPTH) out[q * 4 + 3] = v.w;
+    }
+}
+#endif
+
 struct EnvR {
 #define X(t, n) t n;
     LOB_ENV_FIELDS(X)
@@ -43,13 +90,23 @@ struct EnvCtx {
     const DevState& S;
     int b;
     const uint32_t* rows;  // this book's first record: its own stream, or its window of the replayed one
+#ifdef LOB_PROF
+    // phase clocks of the lane-per-book kernels (tools/exp_prof.py): the first lane of a wave stamps for the wave
+    mutable long long pt_ = 0;
+    mutable i64* prow_ = nullptr;
+    __device__ void prof_start(i64* prof, int lane) const { prow_ = (prof && lane == 0) ? prof + (size_t)b * LOB_PROF_N : nullptr; pt_ = clock64(); }
+    __device__ void mark(int i) const { const long long n = clock64(); if (prow_) prow_[i] += n - pt_; pt_ = n; }
+#else
+    __device__ void prof_start(i64*, int) const {}
+    __device__ void mark(int) const {}
+#endif
     __device__ EnvCtx(const DevParams& p, const DevState& s, int book) : P(p), S(s), b(book) {
         const size_t first = s.rec_phase ? (size_t)s.rec_phase[book] : (size_t)book * (size_t)s.n_events;
-        rows = s.records + first * (size_t)p.W;
+        rows = s.records + first * (size_t)p.Wd;
     }
     __device__ EnvCtx(const DevParams& p, const DevState& s, int book, const uint32_t* rows_) : P(p), S(s), b(book), rows(rows_) {}
     __device__ void err(int bit) const { atomicOr(S.error_flag, bit); }
-    __device__ const uint32_t* row(int i) const { return rows + (size_t)i * (size_t)P.W; }
+    __device__ const uint32_t* row(int i) const { return rows + (size_t)i * (size_t)P.Wd; }
     __device__ const Track& track(int k) const { return S.track[(size_t)b * (size_t)S.track_len + (size_t)(k & S.track_mask)]; }
     __device__ Track& track_w(int k) const { return S.track[(size_t)b * (size_t)S.track_len + (size_t)(k & S.track_mask)]; }
 };
@@ -271,15 +328,17 @@ __device__ inline void acc_store(const AccPtrs& r, int b, const AccReg& g) { r.c
 __device__ inline f64 rec_price(const EnvCtx& c, int rec, int side, int l) {
     if (rec < 0) return 0.0;
     const uint32_t* r = c.row(rec);
-    return (f64)__uint_as_float(r[(side == 0 ? lob_rec_ask_px(c.P.D, c.P.T) : lob_rec_bid_px(c.P.D, c.P.T)) + l]);
+    return (f64)__uint_as_float(r[(side == 0 ? drec_ask_px(c.P.D, c.P.T) : drec_bid_px(c.P.D, c.P.T)) + l]);
 }
 // Book::volume(price) / last_volume(price) (book.cpp:200-214) on the snapshot held by record `rec`.
 // All level prices are fetched before the first compare (the kernel is a chain of dependent loads
 // otherwise: a scan that waits for each level in turn costs D memory round trips per look-up).
 __device__ inline int book_level_of(const uint32_t* px, int D, f64 k) {
+    uint32_t w[LOB_MAX_DEPTH];
+    drec_levels(px, D, w);
     f32 p[LOB_MAX_DEPTH];
 #pragma unroll
-    for (int l = 0; l < LOB_MAX_DEPTH; l++) p[l] = l < D ? __uint_as_float(px[l]) : 0.0f;
+    for (int l = 0; l < LOB_MAX_DEPTH; l++) p[l] = l < D ? __uint_as_float(w[l]) : 0.0f;
     int hit = -1;
 #pragma unroll
     for (int l = 0; l < LOB_MAX_DEPTH; l++)
@@ -289,25 +348,28 @@ __device__ inline int book_level_of(const uint32_t* px, int D, f64 k) {
 __device__ inline i64 book_volume(const EnvCtx& c, int rec, int side, f64 price) {
     if (rec < 0) return 0;
     const uint32_t* r = c.row(rec);
-    const uint32_t* px = r + (side == 0 ? lob_rec_ask_px(c.P.D, c.P.T) : lob_rec_bid_px(c.P.D, c.P.T));
-    const uint32_t* vol = r + (side == 0 ? lob_rec_ask_vol(c.P.D, c.P.T) : lob_rec_bid_vol(c.P.D, c.P.T));
+    const uint32_t* px = r + (side == 0 ? drec_ask_px(c.P.D, c.P.T) : drec_bid_px(c.P.D, c.P.T));
+    const uint32_t* vol = r + (side == 0 ? drec_ask_vol(c.P.D, c.P.T) : drec_bid_vol(c.P.D, c.P.T));
     const int hit = book_level_of(px, c.P.D, key4(price));
     return hit >= 0 ? (i64)(i32)vol[hit] : 0;
 }
 // volume at `price` in two snapshots at once (UpdateOrder needs last_volume and volume): both
 // level scans in flight together
 __device__ inline void book_volume2(const EnvCtx& c, int rec_a, int rec_b, int side, f64 price, i64& va, i64& vb) {
-    const int opx = side == 0 ? lob_rec_ask_px(c.P.D, c.P.T) : lob_rec_bid_px(c.P.D, c.P.T);
-    const int ovol = side == 0 ? lob_rec_ask_vol(c.P.D, c.P.T) : lob_rec_bid_vol(c.P.D, c.P.T);
+    const int opx = side == 0 ? drec_ask_px(c.P.D, c.P.T) : drec_bid_px(c.P.D, c.P.T);
+    const int ovol = side == 0 ? drec_ask_vol(c.P.D, c.P.T) : drec_bid_vol(c.P.D, c.P.T);
     const uint32_t* ra = c.row(rec_a < 0 ? 0 : rec_a);
     const uint32_t* rb = c.row(rec_b < 0 ? 0 : rec_b);
     const int D = c.P.D;
     const f64 k = key4(price);
+    uint32_t wa[LOB_MAX_DEPTH], wb[LOB_MAX_DEPTH];
+    drec_levels(ra + opx, D, wa);
+    drec_levels(rb + opx, D, wb);
     f32 pa[LOB_MAX_DEPTH], pb[LOB_MAX_DEPTH];
 #pragma unroll
     for (int l = 0; l < LOB_MAX_DEPTH; l++) {
-        pa[l] = l < D ? __uint_as_float(ra[opx + l]) : 0.0f;
-        pb[l] = l < D ? __uint_as_float(rb[opx + l]) : 0.0f;
+        pa[l] = l < D ? __uint_as_float(wa[l]) : 0.0f;
+        pb[l] = l < D ? __uint_as_float(wb[l]) : 0.0f;
     }
     int ha = -1, hb = -1;
 #pragma unroll
@@ -325,18 +387,21 @@ __device__ inline void order_volumes(const EnvCtx& c, const EnvR& e, int last_re
                                      i64& b_lv, i64& b_v) {
     a_lv = a_v = b_lv = b_v = 0;
     const int D = c.P.D;
-    const int apx = lob_rec_ask_px(D, c.P.T), avol = lob_rec_ask_vol(D, c.P.T);
-    const int bpx = lob_rec_bid_px(D, c.P.T), bvol = lob_rec_bid_vol(D, c.P.T);
+    const int apx = drec_ask_px(D, c.P.T), avol = drec_ask_vol(D, c.P.T);
+    const int bpx = drec_bid_px(D, c.P.T), bvol = drec_bid_vol(D, c.P.T);
     const uint32_t* rl = c.row(last_rec < 0 ? 0 : last_rec);
     const uint32_t* rr = c.row(row_rec < 0 ? 0 : row_rec);
     const bool a_on = e.a_on != 0, b_on = e.b_on != 0;
+    uint32_t wal[LOB_MAX_DEPTH], war[LOB_MAX_DEPTH], wbl[LOB_MAX_DEPTH], wbr[LOB_MAX_DEPTH];
+    drec_levels(rl + apx, D, wal); drec_levels(rr + apx, D, war);
+    drec_levels(rl + bpx, D, wbl); drec_levels(rr + bpx, D, wbr);
     f32 pal[LOB_MAX_DEPTH], par[LOB_MAX_DEPTH], pbl[LOB_MAX_DEPTH], pbr[LOB_MAX_DEPTH];
 #pragma unroll
     for (int l = 0; l < LOB_MAX_DEPTH; l++) {
-        pal[l] = (a_on && l < D) ? __uint_as_float(rl[apx + l]) : 0.0f;
-        par[l] = (a_on && l < D) ? __uint_as_float(rr[apx + l]) : 0.0f;
-        pbl[l] = (b_on && l < D) ? __uint_as_float(rl[bpx + l]) : 0.0f;
-        pbr[l] = (b_on && l < D) ? __uint_as_float(rr[bpx + l]) : 0.0f;
+        pal[l] = (a_on && l < D) ? __uint_as_float(wal[l]) : 0.0f;
+        par[l] = (a_on && l < D) ? __uint_as_float(war[l]) : 0.0f;
+        pbl[l] = (b_on && l < D) ? __uint_as_float(wbl[l]) : 0.0f;
+        pbr[l] = (b_on && l < D) ? __uint_as_float(wbr[l]) : 0.0f;
     }
     const f64 ka = key4(e.a_opx), kb = key4(e.b_opx);
     int hal = -1, har = -1, hbl = -1, hbr = -1;
@@ -417,8 +482,8 @@ __device__ inline void market_order(const EnvCtx& c, EnvR& e, i64 size, i64& out
     i64 executed = 0;
     f64 proxy = 0.0, value = 0.0;
     const uint32_t* r = c.row(e.rec_cur);
-    const uint32_t* px = r + (side == 0 ? lob_rec_ask_px(c.P.D, c.P.T) : lob_rec_bid_px(c.P.D, c.P.T));
-    const uint32_t* vol = r + (side == 0 ? lob_rec_ask_vol(c.P.D, c.P.T) : lob_rec_bid_vol(c.P.D, c.P.T));
+    const uint32_t* px = r + (side == 0 ? drec_ask_px(c.P.D, c.P.T) : drec_bid_px(c.P.D, c.P.T));
+    const uint32_t* vol = r + (side == 0 ? drec_ask_vol(c.P.D, c.P.T) : drec_bid_vol(c.P.D, c.P.T));
     for (int l = 0; l < c.P.D; l++) {
         f32 pf = __uint_as_float(px[l]);
         if (pf == 0.0f) continue;
@@ -613,8 +678,8 @@ __device__ inline void load_trades(const EnvCtx& c, int lo, int hi, f64* tp, i64
     for (int rec = lo; rec <= hi; rec++) {
         const uint32_t* r = c.row(rec);
         for (int i = 0; i < P.T; i++) {
-            f32 p = __uint_as_float(r[lob_rec_trade_px(P.D, P.T) + i]);
-            i32 v = (i32)r[lob_rec_trade_vol(P.D, P.T) + i];
+            f32 p = __uint_as_float(r[drec_trades(P.D, P.T) + 2 * i]);
+            i32 v = (i32)r[drec_trades(P.D, P.T) + 2 * i + 1];
             if (!((p > 0.0f) && (v > 0))) continue;
             const f64 pd = (f64)p, k = key4(pd);
             // std::map<double,long,FloatComparator>::operator[] += : find the key or insert in order
@@ -720,8 +785,10 @@ __device__ inline bool next_state(const EnvCtx& c, EnvR& e) {
     }
     const Track t = c.track(e.k);
     load_trades(c, (e.k > 0 ? c.track(e.k - 1).rec_first : M.rec_cur0) + 1, t.rec_first, tp, tv);
+    c.mark(22);  // meta, track entries, trade slots
     const f64 mp = e.mid;
     match_orders(c, e, tp, tv, mp, au_vol, au_proxy, au_value, bu_vol, bu_proxy, bu_value);
+    c.mark(23);  // match_orders
     // UpdateBookProfiles: StashState, then ApplyChanges (-> UpdateOrder) for every applied row
     const int last_rec = e.rec_cur;
     for (int r = t.rec_first; r <= t.rec_last; r++) {
@@ -730,6 +797,7 @@ __device__ inline bool next_state(const EnvCtx& c, EnvR& e) {
         update_order(c, e, 0, a_lv, a_v, tp, tv);
         update_order(c, e, 1, b_lv, b_v, tp, tv);
     }
+    c.mark(24);  // order_volumes + update_order
     e.rec_last = last_rec;
     e.rec_cur = t.rec_last;
     e.mid_prev = e.mid;
@@ -764,6 +832,7 @@ __device__ inline bool next_state(const EnvCtx& c, EnvR& e) {
     e.ep_pnl += au_value + bu_value + ad_value;
     e.position += bu_vol + au_vol + ad_vol;  // RiskManager::Update
     check_orders(P, e);
+    c.mark(25);  // adverse selection, PnL, position
     return true;
 }
 
@@ -782,6 +851,7 @@ __device__ inline void step_prologue(const EnvCtx& c, EnvR& e, int action, StepA
     e.momentum_pnl_step = 0.0;
     do_action(c, e, action);
     check_orders(P, e);
+    c.mark(21);  // DoAction: quotes, tick conversions, queue position
     e.total_ticks++;  // UpdateStats
     g.r = get_reward(c, e);
     g.pnl = e.pnl_step;
@@ -798,6 +868,8 @@ __device__ inline int step_event(const EnvCtx& c, EnvR& e, StepAgg& g) {
     g.r += get_reward(c, e);
     g.pnl += e.pnl_step;
     g.mpm += mpm;
+    c.mark(26);  // reward, loop bookkeeping
+    c.mark(31);  // (count of passes: ~0 clocks each)
     return (is_open(P, e.time_ms) && fabs(g.mpm) < 1e-5) ? 0 : 1;
 }
 // after the loop: PnL windows, episode totals
@@ -812,6 +884,7 @@ __device__ inline void step_epilogue(const EnvCtx& c, EnvR& e, const StepAgg& g)
     }
     e.ep_reward += g.r;
     e.ep_bandh += g.mpm;
+    c.mark(27);  // PnL windows
 }
 __device__ inline bool perform_action(const EnvCtx& c, EnvR& e, int action) {
     StepAgg g;
@@ -901,20 +974,21 @@ __device__ inline f64 ulb(f64 val, f64 lb, f64 ub) {
 __device__ inline void mk_apply_row(const EnvCtx& c, MarketR& m, int rec) {
     const DevParams& P = c.P;
     const uint32_t* r = c.row(rec);
-    const uint32_t* apx = r + lob_rec_ask_px(P.D, P.T);
-    const uint32_t* avl = r + lob_rec_ask_vol(P.D, P.T);
-    const uint32_t* bpx = r + lob_rec_bid_px(P.D, P.T);
-    const uint32_t* bvl = r + lob_rec_bid_vol(P.D, P.T);
-    // the whole row is fetched before it is looked at (4 x D loads in flight instead of D round trips)
+    // the whole row is fetched before it is looked at, every level array in 16-byte loads
+    uint32_t wpa[LOB_MAX_DEPTH], wpb[LOB_MAX_DEPTH], wva[LOB_MAX_DEPTH], wvb[LOB_MAX_DEPTH];
+    drec_levels(r + drec_ask_px(P.D, P.T), P.D, wpa);
+    drec_levels(r + drec_ask_vol(P.D, P.T), P.D, wva);
+    drec_levels(r + drec_bid_px(P.D, P.T), P.D, wpb);
+    drec_levels(r + drec_bid_vol(P.D, P.T), P.D, wvb);
     f32 pa[LOB_MAX_DEPTH], pb[LOB_MAX_DEPTH];
     i32 va[LOB_MAX_DEPTH], vb[LOB_MAX_DEPTH];
 #pragma unroll
     for (int l = 0; l < LOB_MAX_DEPTH; l++) {
         const bool in = l < P.D;
-        pa[l] = in ? __uint_as_float(apx[l]) : 1.0f;
-        pb[l] = in ? __uint_as_float(bpx[l]) : 1.0f;
-        va[l] = in ? (i32)avl[l] : 0;
-        vb[l] = in ? (i32)bvl[l] : 0;
+        pa[l] = in ? __uint_as_float(wpa[l]) : 1.0f;
+        pb[l] = in ? __uint_as_float(wpb[l]) : 1.0f;
+        va[l] = in ? (i32)wva[l] : 0;
+        vb[l] = in ? (i32)wvb[l] : 0;
     }
     bool bad = false;
 #pragma unroll

@@ -56,16 +56,28 @@ static_assert(LOB_BLOCK >= LOB_NZ_WORDS && 512 % LOB_BLOCK == 0 || LOB_BLOCK % 5
 __global__ void gen_events_kernel(lob_gen_params g, int D, int T, u64 first_book, int B, uint32_t* out) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    const int W = lob_rec_words(D, T);
+    const int Wd = drec_words(D, T);
     lob_gen_state s;
     lob_gen_init(g, s);
-    uint32_t rec[64];
+    uint32_t rec[64], drec[80];
     for (int e = 0; e < g.n_events; e++) {
         lob_gen_event(g, D, T, first_book + (u64)b, e, s, rec);
-        uint32_t* dst = out + ((size_t)b * g.n_events + e) * W;
-        for (int i = 0; i < W; i += 4)
-            *reinterpret_cast<uint4*>(dst + i) = make_uint4(rec[i], rec[i + 1], rec[i + 2], rec[i + 3]);
+        drec_from_abi(rec, D, T, drec);  // straight into the device layout (lob_env.h)
+        uint32_t* dst = out + ((size_t)b * g.n_events + e) * Wd;
+        for (int i = 0; i < Wd; i += 4)
+            *reinterpret_cast<uint4*>(dst + i) = make_uint4(drec[i], drec[i + 1], drec[i + 2], drec[i + 3]);
     }
+}
+// Uploaded streams: ABI records (lob_engine.h) -> device records, one thread per record.
+__global__ void repack_kernel(const uint32_t* __restrict__ src, int D, int T, size_t n_records, uint32_t* dst) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_records) return;
+    const int W = lob_rec_words(D, T), Wd = drec_words(D, T);
+    uint32_t rec[64], drec[80];
+    for (int k = 0; k < W; k++) rec[k] = src[i * W + k];
+    drec_from_abi(rec, D, T, drec);
+    for (int k = 0; k < Wd; k += 4)
+        *reinterpret_cast<uint4*>(dst + i * Wd + k) = make_uint4(drec[k], drec[k + 1], drec[k + 2], drec[k + 3]);
 }
 
 // ---------------------------------------------------------------------------
@@ -227,8 +239,10 @@ __global__ void __launch_bounds__(LOB_ENV_BLOCK) env_kernel(const DevParams* __r
         }
         if (go) {
             EnvCtx c(P, S, b);
+            c.prof_start(S.prof, threadIdx.x & 63);
             EnvR& e = lds_env[threadIdx.x].e;
             env_load(S, b, e);
+            c.mark(20);  // agent scalars in
             i64 ev0 = e.events;
             bool ok = perform_action(c, e, action);
             d_events = e.events - ev0;
@@ -253,9 +267,11 @@ __global__ void __launch_bounds__(LOB_ENV_BLOCK) env_kernel(const DevParams* __r
             } else {
                 h.stepped = 0;
             }
+            c.mark(28);  // state variables, memo claim
             h.done = e.done;
             h.time_ms = e.time_ms;
             env_store(S, b, e);
+            c.mark(29);  // agent scalars out
         } else {
             h.stepped = 0;
         }

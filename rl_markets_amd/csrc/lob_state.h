@@ -173,7 +173,7 @@ struct DevState {
     i32 B;
     i32 D, T, W;       // depth, trade slots, record words
     i32 n_events;
-    const uint32_t* records;  // [B][n_events][W], or one replayed stream [n_total][W] when rec_phase is set
+    const uint32_t* records;  // device layout: [B][n_events][Wd], or one replayed stream [n_total][Wd] when rec_phase is set
     const i64* rec_phase;     // [B] first record of each book's n_events-long window (lob_load_events_shared), else null
 
 #define X(t, n) t* n;
@@ -262,6 +262,7 @@ struct DevState {
 // Parameters copied to the device once (kernel argument, uniform).
 struct DevParams {
     i32 D, T, W, V;
+    i32 Wd;          // words per record in the device layout (lob_env.h drec_*)
     i32 vars[LOB_MAX_VARS];
     // tick table
     i32 n_bands;

@@ -37,14 +37,19 @@ N = 100
 eng.td_step(N); eng.sync()
 assert eng.lib.lob_debug_prof(eng.h, out) == 0
 d = [(y - x) / (N * B) for x, y in zip(a, list(out))]
+for i in range(20, 32):
+    d[i] *= 64.0   # the lane kernels stamp once per 64-book wave
 names = {0: "act: headers, memo records, state variables", 1: "act: tile hashing", 2: "act: coarse filter (LDS)", 3: "act: exact map for the coarse hits",
          4: "act: written weights + ordered continuation", 5: "act: policy + stores",
          8: "trace: header, Q(s,.), state variables", 9: "trace: group-0 tiles of s", 10: "trace: argmax + LDS map (288 inserts)",
          11: "trace: old generations (scan, stores, claim issue)", 12: "trace: new generation + claim issue", 18: "trace: header stores, previous book's claims",
          13: "learn_q: headers, memo records, state variables", 14: "learn_q: tile hashing", 15: "learn_q: coarse filter (LDS)",
          16: "learn_q: exact map for the coarse hits", 17: "learn_q: written weights + ordered continuation", 19: "learn_q: argmax / delta / header stores"}
+names.update({20: "env: agent scalars in", 21: "env: DoAction (quotes, tick conversions, queue position)", 22: "env: per pass: meta, track entries, trade slots",
+              23: "env: per pass: match_orders", 24: "env: per pass: order_volumes + update_order", 25: "env: per pass: adverse selection, PnL, position",
+              26: "env: per pass: reward, loop bookkeeping", 27: "env: PnL windows", 28: "env: state variables, memo claim", 29: "env: agent scalars out"})
 print("(clocks per wave ITERATION: the Q kernels take LOB_FAST_NB books per iteration and stamp the batch on its first book's row)")
-for lo, hi, nm, idx in ((0, 8, "act_kernel", range(0, 8)), (8, 20, "trace_kernel", (8, 9, 10, 11, 12, 18)), (13, 20, "learn_q kernel", (13, 14, 15, 16, 17, 19))):
+for lo, hi, nm, idx in ((20, 30, "env_kernel (per WAVE-step: 64 books; the per-pass rows are summed over the wave's passes)", range(20, 30)), (0, 8, "act_kernel", range(0, 8)), (8, 20, "trace_kernel", (8, 9, 10, 11, 12, 18)), (13, 20, "learn_q kernel", (13, 14, 15, 16, 17, 19))):
     tot = sum(d[i] for i in idx)
     print("%s: %.0f clocks per wave" % (nm, tot))
     for i in idx:
