@@ -90,6 +90,7 @@ struct EnvCtx {
     const DevState& S;
     int b;
     const uint32_t* rows;  // this book's first record: its own stream, or its window of the replayed one
+    const TickLds* tk;     // the venue's tick table (LDS)
 #ifdef LOB_PROF
     // phase clocks of the lane-per-book kernels (tools/exp_prof.py): the first lane of a wave stamps for the wave
     mutable long long pt_ = 0;
@@ -100,11 +101,11 @@ struct EnvCtx {
     __device__ void prof_start(i64*, int) const {}
     __device__ void mark(int) const {}
 #endif
-    __device__ EnvCtx(const DevParams& p, const DevState& s, int book) : P(p), S(s), b(book) {
+    __device__ EnvCtx(const DevParams& p, const DevState& s, int book, const TickLds* t) : P(p), S(s), b(book), tk(t) {
         const size_t first = s.rec_phase ? (size_t)s.rec_phase[book] : (size_t)book * (size_t)s.n_events;
         rows = s.records + first * (size_t)p.Wd;
     }
-    __device__ EnvCtx(const DevParams& p, const DevState& s, int book, const uint32_t* rows_) : P(p), S(s), b(book), rows(rows_) {}
+    __device__ EnvCtx(const DevParams& p, const DevState& s, int book, const TickLds* t, const uint32_t* rows_) : P(p), S(s), b(book), rows(rows_), tk(t) {}
     __device__ void err(int bit) const { atomicOr(S.error_flag, bit); }
     __device__ const uint32_t* row(int i) const { return rows + (size_t)i * (size_t)P.Wd; }
     __device__ const Track& track(int k) const { return S.track[(size_t)b * (size_t)S.track_len + (size_t)(k & S.track_mask)]; }
@@ -446,21 +447,21 @@ __device__ inline void place_orders(const EnvCtx& c, EnvR& e, int al, int bl) {
     if (P.quote_mode == LOB_QUOTE_BOOK) {
         const f64 ap0 = rec_price(c, e.rec_cur, 0, 0), bp0 = rec_price(c, e.rec_cur, 1, 0);
         if (ap0 == 0.0 || bp0 == 0.0) c.err(LOB_ERR_UNDEF_PRICE);
-        ta = lobh::to_ticks_t(P_tick(P), ap0) + al;
-        tb = lobh::to_ticks_t(P_tick(P), bp0) - bl;
+        ta = lobh::to_ticks_t((*c.tk), ap0) + al;
+        tb = lobh::to_ticks_t((*c.tk), bp0) - bl;
     } else {
         const Track& t = c.track(e.k - 1);
         f64 tp = t.tp_val;
         f64 half = t.spread_mean / 2.0;
         f64 half_spd = 0.0 > half ? 0.0 : half;  // std::max(0.0, x)
-        ta = lobh::to_ticks_t(P_tick(P), tp + (f64)al * half_spd);
-        tb = lobh::to_ticks_t(P_tick(P), tp - (f64)bl * half_spd);
+        ta = lobh::to_ticks_t((*c.tk), tp + (f64)al * half_spd);
+        tb = lobh::to_ticks_t((*c.tk), tp - (f64)bl * half_spd);
     }
-    e.ask_quote = lobh::to_price_t(P_tick(P), ta);
-    e.bid_quote = lobh::to_price_t(P_tick(P), tb);
+    e.ask_quote = lobh::to_price_t((*c.tk), ta);
+    e.bid_quote = lobh::to_price_t((*c.tk), tb);
     // a_dist / b_dist need ToTicks(order price): computed once, here
-    place_one(c, e, 0, e.ask_quote, lobh::to_ticks_t(P_tick(P), e.ask_quote));
-    place_one(c, e, 1, e.bid_quote, lobh::to_ticks_t(P_tick(P), e.bid_quote));
+    place_one(c, e, 0, e.ask_quote, lobh::to_ticks_t((*c.tk), e.ask_quote));
+    place_one(c, e, 1, e.bid_quote, lobh::to_ticks_t((*c.tk), e.bid_quote));
 }
 
 // AskBook/BidBook::WalkTheBook via BookUtils::MarketOrder (book.cpp:431-456,514-539,595-610)
@@ -755,18 +756,21 @@ __device__ inline void match_orders(const EnvCtx& c, EnvR& e, const f64* tp, con
 // Agent-dependent part of Intraday::NextState (intraday.cpp:225-272) for event e.k.
 // Returns false when the stream is exhausted (the abandoned event still matches
 // its trades and stashes the books, like the reference).
-__device__ inline bool next_state(const EnvCtx& c, EnvR& e) {
+// `t` = the track entry of event e.k, fetched by the caller (one pass ahead where it can: the entries are
+// agent-independent, and a pass is a chain of dependent look-ups: track entry -> rows -> volumes);
+// `n_track` / `complete`: BookMeta's, fetched once per step.
+__device__ inline bool next_state(const EnvCtx& c, EnvR& e, const Track& t, int n_track, int complete) {
     const DevParams& P = c.P;
-    const BookMeta& M = c.S.meta[c.b];
     f64 tp[LOB_MAX_TRADES];
     i64 tv[LOB_MAX_TRADES];
     i64 au_vol, bu_vol; f64 au_proxy, au_value, bu_proxy, bu_value;
-    if (e.k >= M.n_track) {
+    if (e.k >= n_track) {
+        const BookMeta& M = c.S.meta[c.b];
         // the ring of a long stream ran dry before its next refill: the run is void (reported as LOB_ESTATE)
-        if (!M.complete) c.err(LOB_ERR_TRACK_UNDERRUN);
+        if (!complete) c.err(LOB_ERR_TRACK_UNDERRUN);
         // out of data inside this event (Streamer::LoadNext fails, src/data/streamer.cpp:42-49)
         if (M.ex_first >= 0) {
-            load_trades(c, (e.k > 0 ? c.track(e.k - 1).rec_first : M.rec_cur0) + 1, M.ex_first, tp, tv);
+            load_trades(c, e.pf + 1, M.ex_first, tp, tv);
             match_orders(c, e, tp, tv, e.mid, au_vol, au_proxy, au_value, bu_vol, bu_proxy, bu_value);
             // rows applied before the stream ran dry still update the queue model
             for (int r = M.ex_first; r <= M.ex_cur && M.ex_cur >= M.ex_first; r++) {
@@ -783,9 +787,9 @@ __device__ inline bool next_state(const EnvCtx& c, EnvR& e) {
         e.done = 2;
         return false;
     }
-    const Track t = c.track(e.k);
-    load_trades(c, (e.k > 0 ? c.track(e.k - 1).rec_first : M.rec_cur0) + 1, t.rec_first, tp, tv);
-    c.mark(22);  // meta, track entries, trade slots
+    load_trades(c, e.pf + 1, t.rec_first, tp, tv);
+    e.pf = t.rec_first;
+    c.mark(22);  // track entry, trade slots
     const f64 mp = e.mid;
     match_orders(c, e, tp, tv, mp, au_vol, au_proxy, au_value, bu_vol, bu_proxy, bu_value);
     c.mark(23);  // match_orders
@@ -841,10 +845,16 @@ __device__ inline bool next_state(const EnvCtx& c, EnvR& e) {
 // (env_compact_kernel): the running sums of the loop live in `StepAgg`.
 struct StepAgg {
     f64 r, pnl, mpm;
+    i32 n_track, complete;  // BookMeta's, as of this step
 };
 // up to the first NextState: DoAction, CheckOrders, UpdateStats, the reward of the action itself
 __device__ inline void step_prologue(const EnvCtx& c, EnvR& e, int action, StepAgg& g) {
     const DevParams& P = c.P;
+    {
+        const BookMeta& M = c.S.meta[c.b];
+        g.n_track = M.n_track;
+        g.complete = M.complete;
+    }
     e.last_action = action;
     e.lo_vol_step = 0;
     e.pnl_step = 0.0;
@@ -858,10 +868,10 @@ __device__ inline void step_prologue(const EnvCtx& c, EnvR& e, int action, StepA
     g.mpm = 0.0;
 }
 // one pass of the do-while: 0 = another event follows, 1 = the step is complete, 2 = out of data
-__device__ inline int step_event(const EnvCtx& c, EnvR& e, StepAgg& g) {
+__device__ inline int step_event(const EnvCtx& c, EnvR& e, StepAgg& g, const Track& t) {
     const DevParams& P = c.P;
     e.pnl_step = 0.0;
-    if (!next_state(c, e)) return 2;
+    if (!next_state(c, e, t, g.n_track, g.complete)) return 2;
     const f64 mpm = e.mid - e.mid_prev;
     e.pnl_step += (f64)e.position * mpm;
     e.momentum_pnl_step += (f64)e.position * mpm;
@@ -886,11 +896,20 @@ __device__ inline void step_epilogue(const EnvCtx& c, EnvR& e, const StepAgg& g)
     e.ep_bandh += g.mpm;
     c.mark(27);  // PnL windows
 }
-__device__ inline bool perform_action(const EnvCtx& c, EnvR& e, int action) {
+// `t_out`: the track entry of the last completed event (what the state extraction after the step reads).
+__device__ inline bool perform_action(const EnvCtx& c, EnvR& e, int action, Track& t_out) {
+    // the first pass's track entry is on its way while DoAction computes the quotes; from then on every pass
+    // fetches the NEXT event's entry before it starts on its own (wasted once per step, hidden every time)
+    Track t = c.track(e.k);
     StepAgg g;
     step_prologue(c, e, action, g);
     int st;
-    do { st = step_event(c, e, g); } while (st == 0);
+    do {
+        const Track tn = c.track(e.k + 1);
+        st = step_event(c, e, g, t);
+        if (st != 2) t_out = t;
+        t = tn;
+    } while (st == 0);
     if (st == 2) return false;
     step_epilogue(c, e, g);
     return true;
@@ -1151,8 +1170,8 @@ __device__ inline void prepass_run(const EnvCtx& c, PrepState& st, BookMeta& M, 
         }
         if (m.lap0 == 0.0 || m.lbp0 == 0.0) c.err(LOB_ERR_UNDEF_PRICE);
         const f64 mid = (m.ap0 + m.bp0) / 2.0, lmid = (m.lap0 + m.lbp0) / 2.0;
-        const int tick_ap0 = lobh::to_ticks_t(P_tick(P), m.ap0), tick_bp0 = lobh::to_ticks_t(P_tick(P), m.bp0);
-        const i64 mpt = (i64)lobh::to_ticks_t(P_tick(P), mid);
+        const int tick_ap0 = lobh::to_ticks_t((*c.tk), m.ap0), tick_bp0 = lobh::to_ticks_t((*c.tk), m.bp0);
+        const i64 mpt = (i64)lobh::to_ticks_t((*c.tk), mid);
         const f64 mpm = mid - lmid, sp = m.ap0 - m.bp0;
         // ten window pushes (intraday.cpp:253-269), batched: the ring slots that fall out are fetched together
         rm_prep(S.f_midprice, B, b, w_mid); rm_prep(S.f_volatility, B, b, w_vol); rm_prep(S.spread_window, B, b, w_spr);
@@ -1194,7 +1213,7 @@ __device__ inline void prepass_run(const EnvCtx& c, PrepState& st, BookMeta& M, 
                 i32 bi = w_mid.head - w_mid.cnt + 1;
                 if (bi < 0) bi += S.f_midprice.w;
                 const f64 back = S.f_midprice.ring[(size_t)bi * B + b];
-                t.mv[LOB_MV_MPM] = (f32)ulb((f64)(lobh::to_ticks_t(P_tick(P), front) - lobh::to_ticks_t(P_tick(P), back)), -10.0, 10.0);
+                t.mv[LOB_MV_MPM] = (f32)ulb((f64)(lobh::to_ticks_t((*c.tk), front) - lobh::to_ticks_t((*c.tk), back)), -10.0, 10.0);
             }
             {
                 f64 v_a = (f64)m.a_tv, v_b = (f64)m.b_tv;

@@ -15,15 +15,25 @@
 #include "lob_state.h"
 #include "lob_stream.h"
 
-struct TickView {
+// The venue's tick table for the lane-per-book kernels, in LDS: Market::ToTicks / ToPrice index it with a
+// per-lane band, and a chain of such look-ups from global memory (six conversions per DoAction, four or
+// five dependent loads each) was a sixth of env_kernel's time.
+struct TickLds {
     int n;
-    const f64* lb;
-    const f64* tick;
-    const i64* cum;
-    const i32* pt;
-    const f64* pp;
+    f64 lb[LOB_MAX_BANDS];
+    f64 tick[LOB_MAX_BANDS];
+    i64 cum[LOB_MAX_BANDS];
+    f64 pp[LOB_MAX_BANDS];
+    i32 pt[LOB_MAX_BANDS];
 };
-__device__ inline TickView P_tick(const DevParams& P) { return TickView{P.n_bands, P.band_lb, P.band_tick, P.band_cum, P.band_pt, P.band_pp}; }
+// all threads of the block call this (ends with a block barrier)
+__device__ inline void stage_ticks(const DevParams& P, TickLds& t) {
+    for (int i = threadIdx.x; i < LOB_MAX_BANDS; i += blockDim.x) {
+        t.lb[i] = P.band_lb[i]; t.tick[i] = P.band_tick[i]; t.cum[i] = P.band_cum[i]; t.pp[i] = P.band_pp[i]; t.pt[i] = P.band_pt[i];
+    }
+    if (threadIdx.x == 0) t.n = P.n_bands;
+    __syncthreads();
+}
 
 #define LOB_TRACK_MARGIN 4
 #include "lob_env.h"
@@ -92,9 +102,11 @@ __global__ void repack_kernel(const uint32_t* __restrict__ src, int D, int T, si
 template <int RB>
 __global__ void __launch_bounds__(RB) reset_kernel(const DevParams* __restrict__ Pp, DevState S) {
     const DevParams& P = *Pp;
+    __shared__ TickLds tick_lds;
+    stage_ticks(P, tick_lds);
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= S.B) return;
-    EnvCtx c(P, S, b);
+    EnvCtx c(P, S, b, &tick_lds);
     __shared__ EnvSlot lds_env[RB];
     EnvR& e = lds_env[threadIdx.x].e;
     env_load(S, b, e);  // position, pnl_step, quote levels etc. persist across episodes
@@ -118,6 +130,7 @@ __global__ void __launch_bounds__(RB) reset_kernel(const DevParams* __restrict__
         const int k = M.k_warm;
         const Track t1 = c.track(k - 1);
         e.k = k;
+        e.pf = t1.rec_first;
         e.rec_cur = t1.rec_last;
         e.mid = t1.mid;
         e.time_ms = t1.time_ms;
@@ -141,6 +154,7 @@ __global__ void __launch_bounds__(RB) reset_kernel(const DevParams* __restrict__
     } else {
         // Initialise() == false: out of data before the windows filled
         e.k = M.n_track;
+        e.pf = M.rec_cur0;
         e.rec_cur = M.ex_cur; e.rec_last = M.ex_last; e.time_ms = M.ex_time;
         e.mid = 0.0; e.mid_prev = 0.0;
         e.events += (i64)(S.n_events > 0 ? S.n_events - 1 : 0);
@@ -161,9 +175,11 @@ __global__ void __launch_bounds__(RB) reset_kernel(const DevParams* __restrict__
 // episode inherits (quirk Q7).
 __global__ void __launch_bounds__(256, 1) finalize_kernel(const DevParams* __restrict__ Pp, DevState S) {
     const DevParams& P = *Pp;
+    __shared__ TickLds tick_lds;
+    stage_ticks(P, tick_lds);
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= S.B) return;
-    EnvCtx c(P, S, b);
+    EnvCtx c(P, S, b, &tick_lds);
     persist_io(S, b, false);
     const int k = S.k[b];
     if (k > 0) {
@@ -181,6 +197,8 @@ __global__ void __launch_bounds__(256, 1) finalize_kernel(const DevParams* __res
 // what the agent side may still look at (events k - 2 .. k).
 __global__ void __launch_bounds__(64) prepass_extend_kernel(const DevParams* __restrict__ Pp, DevState S) {
     const DevParams& P = *Pp;
+    __shared__ TickLds tick_lds;
+    stage_ticks(P, tick_lds);
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= S.B) return;
     BookMeta M = S.meta[b];
@@ -188,7 +206,7 @@ __global__ void __launch_bounds__(64) prepass_extend_kernel(const DevParams* __r
     const int k_stop = S.k[b] + S.track_len - LOB_TRACK_MARGIN;
     PrepState st = S.prep[b];
     if (st.k >= k_stop) return;
-    EnvCtx c(P, S, b);
+    EnvCtx c(P, S, b, &tick_lds);
     prepass_run(c, st, M, k_stop, true);
     S.meta[b] = M;
     S.prep[b] = st;
@@ -197,9 +215,11 @@ __global__ void __launch_bounds__(64) prepass_extend_kernel(const DevParams* __r
 // Evaluate getState() for every book (lob_get_state): lane per book.
 __global__ void __launch_bounds__(256) get_state_kernel(const DevParams* __restrict__ Pp, DevState S, f32* out /*[B][V]*/, f64* reward /*[B] or null*/) {
     const DevParams& P = *Pp;  // parameters read through the scalar cache, never copied to scratch
+    __shared__ TickLds tick_lds;
+    stage_ticks(P, tick_lds);
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= S.B) return;
-    EnvCtx c(P, S, b);
+    EnvCtx c(P, S, b, &tick_lds);
     EnvR e;
     env_load(S, b, e);
     if (out) {
@@ -221,6 +241,8 @@ template <int LOB_ENV_BLOCK>
 __global__ void __launch_bounds__(LOB_ENV_BLOCK) env_kernel(const DevParams* __restrict__ Pp, DevState S, const i32* host_actions, int count_updates, int b0, int nb,
                                                             int step_id, int par) {
     const DevParams& P = *Pp;  // parameters read through the scalar cache, never copied to scratch
+    __shared__ TickLds tick_lds;
+    stage_ticks(P, tick_lds);
     __shared__ EnvSlot lds_env[LOB_ENV_BLOCK];
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = b0 + t;
@@ -238,19 +260,19 @@ __global__ void __launch_bounds__(LOB_ENV_BLOCK) env_kernel(const DevParams* __r
             action = h.action;
         }
         if (go) {
-            EnvCtx c(P, S, b);
+            EnvCtx c(P, S, b, &tick_lds);
             c.prof_start(S.prof, threadIdx.x & 63);
             EnvR& e = lds_env[threadIdx.x].e;
             env_load(S, b, e);
             c.mark(20);  // agent scalars in
             i64 ev0 = e.events;
-            bool ok = perform_action(c, e, action);
+            Track tk;  // the last completed event's entry: Intraday::getState reads the market through it
+            bool ok = perform_action(c, e, action, tk);
             d_events = e.events - ev0;
             if (ok) {
                 const int cur = h.slot_cur;
                 f32* v = S.vars + ((size_t)b * 3 + cur) * 16;
                 f32* vf = S.vars + ((size_t)b * 3 + 2) * 16;
-                const Track tk = state_track(c, e);
                 int qg[3] = {0, 0, 0};
                 for (int i = 0; i < P.V; i++) {
                     v[i] = (f32)get_variable(c, e, P.vars[i], tk);
@@ -288,7 +310,7 @@ __global__ void __launch_bounds__(LOB_ENV_BLOCK) env_kernel(const DevParams* __r
     }
 }
 
-// The same step with the event loop COMPACTED across a 256-book block.  How many market events a step
+// The same step with the event loop COMPACTED across a 192-book block.  How many market events a step
 // consumes is data dependent (it ends when the midprice has moved: 1.68 events on average, 5-6 for the
 // unluckiest of 64 books), and in env_kernel a wave iterates until its slowest lane is done -- 70 % of
 // its loop time is spent waiting for that lane.  Here a book's whole step state lives in its
@@ -297,7 +319,7 @@ __global__ void __launch_bounds__(LOB_ENV_BLOCK) env_kernel(const DevParams* __r
 // atomic per wave for the block offset) into a work list, lanes 0..n-1 take entry n each, and waves
 // beyond the list go idle at the block barrier instead of spinning.  Prologue and epilogue are
 // lane = book as before.  Same arithmetic in the same order per book: results cannot differ.
-#define LOB_ENVC_BLOCK 256
+#define LOB_ENVC_BLOCK 192
 struct EnvCompactSlot {
     EnvSlot s;
     StepAgg agg;
@@ -308,6 +330,8 @@ static_assert(sizeof(EnvCompactSlot) * LOB_ENVC_BLOCK + 2 * 2 * LOB_ENVC_BLOCK +
 __global__ void __launch_bounds__(LOB_ENVC_BLOCK) env_compact_kernel(const DevParams* __restrict__ Pp, DevState S, int count_updates, int b0, int nb,
                                                                      int step_id, int par) {
     const DevParams& P = *Pp;  // parameters read through the scalar cache, never copied to scratch
+    __shared__ TickLds tick_lds;
+    stage_ticks(P, tick_lds);
     __shared__ EnvCompactSlot slots[LOB_ENVC_BLOCK];
     __shared__ uint16_t work[2][LOB_ENVC_BLOCK];
     __shared__ int cnt[3];
@@ -324,7 +348,7 @@ __global__ void __launch_bounds__(LOB_ENVC_BLOCK) env_compact_kernel(const DevPa
         LHdr& h = S.hdr[b];
         go = h.stepped != 0;
         if (go) {
-            EnvCtx c(P, S, b);
+            EnvCtx c(P, S, b, &tick_lds);
             EnvCompactSlot& sl = slots[threadIdx.x];
             EnvR& e = sl.s.e;
             env_load(S, b, e);
@@ -354,8 +378,9 @@ __global__ void __launch_bounds__(LOB_ENVC_BLOCK) env_compact_kernel(const DevPa
         if ((int)threadIdx.x < n) {
             slot = work[it & 1][threadIdx.x];
             EnvCompactSlot& sl = slots[slot];
-            EnvCtx c(P, S, b0 + blockIdx.x * LOB_ENVC_BLOCK + slot, sl.rows);
-            const int st = step_event(c, sl.s.e, sl.agg);
+            EnvCtx c(P, S, b0 + blockIdx.x * LOB_ENVC_BLOCK + slot, &tick_lds, sl.rows);
+            const Track t = c.track(sl.s.e.k);
+            const int st = step_event(c, sl.s.e, sl.agg, t);
             again = st == 0;
             if (!again) status[slot] = (uint8_t)st;
         }
@@ -372,7 +397,7 @@ __global__ void __launch_bounds__(LOB_ENVC_BLOCK) env_compact_kernel(const DevPa
         LHdr& h = S.hdr[b];
         EnvCompactSlot& sl = slots[threadIdx.x];
         EnvR& e = sl.s.e;
-        EnvCtx c(P, S, b, sl.rows);
+        EnvCtx c(P, S, b, &tick_lds, sl.rows);
         const bool ok = status[threadIdx.x] == 1;
         if (ok) {
             step_epilogue(c, e, sl.agg);
@@ -414,9 +439,11 @@ __global__ void __launch_bounds__(LOB_ENVC_BLOCK) env_compact_kernel(const DevPa
 // Base::ClearInventory for every book (Runner::RunEpisode epilogue, serial.cpp:31)
 __global__ void __launch_bounds__(256) clear_inventory_kernel(const DevParams* __restrict__ Pp, DevState S) {
     const DevParams& P = *Pp;  // parameters read through the scalar cache, never copied to scratch
+    __shared__ TickLds tick_lds;
+    stage_ticks(P, tick_lds);
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= S.B) return;
-    EnvCtx c(P, S, b);
+    EnvCtx c(P, S, b, &tick_lds);
     EnvR e;
     env_load(S, b, e);
     clear_inventory(c, e);
@@ -1260,10 +1287,12 @@ __global__ void rebuild_nz_kernel(const f64* __restrict__ theta, uint32_t* nz, i
 // ---- parity dump -------------------------------------------------------------
 __global__ void dump_kernel(const DevParams* __restrict__ Pp, DevState S, int first, int n, lob_book_dump* out) {
     const DevParams& P = *Pp;  // parameters read through the scalar cache, never copied to scratch
+    __shared__ TickLds tick_lds;
+    stage_ticks(P, tick_lds);
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const int b = first + t;
-    EnvCtx c(P, S, b);
+    EnvCtx c(P, S, b, &tick_lds);
     EnvR e;
     env_load(S, b, e);
     lob_book_dump d;

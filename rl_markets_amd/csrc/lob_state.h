@@ -47,6 +47,7 @@ typedef float f32;
     X(i32, time_ms)   /* Market::time_ */                                                                      \
     X(i32, rec_cur)   /* record holding the current depth snapshot (-1: none) */                              \
     X(i32, rec_last)  /* record holding the stashed snapshot (Book::StashState) (-1: none) */                  \
+    X(i32, pf)        /* record up to which the trades have been handed over (= rec_first of event k - 1) */   \
     X(f64, mid)       /* midprice of the current snapshot */                                                   \
     X(f64, mid_prev)  /* midprice of the stashed snapshot */                                                   \
     X(i64, position)  /* RiskManager::position_ */                                                             \
