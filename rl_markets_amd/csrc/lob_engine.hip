@@ -360,8 +360,10 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
         if (rc == LOB_OK) rc = dev_alloc(e, &S.mk_count, 2);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.mk_rec, 2 * ms * LOB_MK_REC);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.mk_slot, B);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.mk_slot_last, B);
         if (rc == LOB_OK && hipMemsetAsync(S.mk_hash, 0xff, ms * 8, e->stream) != hipSuccess) rc = LOB_EHIP;
         if (rc == LOB_OK && hipMemsetAsync(S.mk_slot, 0xff, B * 4, e->stream) != hipSuccess) rc = LOB_EHIP;
+        if (rc == LOB_OK && hipMemsetAsync(S.mk_slot_last, 0xff, B * 4, e->stream) != hipSuccess) rc = LOB_EHIP;
     }
     {
         // coarse written-weights map of the fast path: the finest granularity whose image fits 80 KB of LDS

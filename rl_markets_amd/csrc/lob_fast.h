@@ -322,19 +322,27 @@ __global__ void __launch_bounds__(LOB_FAST_BLOCK, 8) trace_fast_kernel(DevParams
         const int lane = lane_;
         const int b = __builtin_amdgcn_readfirstlane(t);
         const LHdr h = S.hdr[b];
+        const int lslot = P.memo ? S.mk_slot_last[b] : -1;  // memo slot of last_state's group-0 triple (checked below)
         f64 qs_last[LOB_N_ACTIONS];
 #pragma unroll
         for (int a = 0; a < LOB_N_ACTIONS; a++) qs_last[a] = S.qs_last[(size_t)b * LOB_N_ACTIONS + a];
         if (!h.stepped) continue;
+        const int4 lid = *reinterpret_cast<const int4*>(S.mk_ident + (size_t)(lslot >= 0 ? lslot : 0) * 4);
         Prof pf;
         pf.start(S.prof, b, lane);
         learn_stage_vars(S.vars + (size_t)b * 48, vars, lane);
         pf.mark(8);  // header, Q(s, .), state variables
         const int last = h.slot_cur ^ 1;
         const bool zero_last = (h.zero_mask >> last) & 1;
+        // is that slot really last_state's triple?  then its "288 tiles distinct" flag may be used / learnt
+        const int qvl = tile_quant(vars[last * 16 + (lane & 15)]);
+        const bool lmatch = lslot >= 0 && !zero_last && lid.x == __builtin_amdgcn_readlane(qvl, 0) && lid.y == __builtin_amdgcn_readlane(qvl, 1) &&
+                            lid.z == __builtin_amdgcn_readlane(qvl, 2);
         Rng g{P.seed, P.book_id_offset + (u64)b, h.rng_ctr};
         CbPending pend;
-        learn_traces<ALGO>(P, S, b, h, rnd, act_terms, tab, false, vars + last * 16, zero_last, qs_last, g, lane, pend, pf);
+        bool dup = false;
+        learn_traces<ALGO>(P, S, b, h, rnd, act_terms, tab, false, vars + last * 16, zero_last, qs_last, g, lane, pend, pf, lmatch ? lid.w : 0, &dup);
+        if (lmatch && lid.w == 0 && lane == 0) S.mk_ident[(size_t)lslot * 4 + 3] = dup ? 2 : 1;  // (every wave that gets here writes the same value)
         if (lane == 0) {
             LHdr* hp = S.hdr + b;
             hp->td = sel9(qs_last, h.action);  // Q(s, a), for the TD error

@@ -164,6 +164,7 @@ __global__ void __launch_bounds__(RB) reset_kernel(const DevParams* __restrict__
     S.hdr[b].done = e.done;
     S.hdr[b].time_ms = e.time_ms;
     S.mk_slot[b] = -1;  // the memo table is emptied at every reset: the first act of the episode takes the general path
+    S.mk_slot_last[b] = -1;
     env_store(S, b, e);
     atomicAdd((u64*)&S.counters[1], (u64)(e.events - ev0));  // warm-up events count as consumed
 }
@@ -280,7 +281,10 @@ __global__ void __launch_bounds__(LOB_ENV_BLOCK) env_kernel(const DevParams* __r
                     if (i < 3) qg[i] = tile_quant(v[i]);
                 }
                 // group-0 memo: the new state's triple gets (or finds) its slot and goes on this step's list
-                if (P.memo) S.mk_slot[b] = mk_claim(S, qg[0], qg[1], qg[2], step_id, par);
+                if (P.memo) {
+                    S.mk_slot_last[b] = S.mk_slot[b];
+                    S.mk_slot[b] = mk_claim(S, qg[0], qg[1], qg[2], step_id, par);
+                }
                 h.zero_mask &= ~(1 << cur);
                 S.verdict[(size_t)b * LOB_VD_STRIDE + 67] = 0;  // a State changed: saved verdicts are void until learn saves new ones
                 h.reward = get_reward(c, e);
@@ -411,7 +415,10 @@ __global__ void __launch_bounds__(LOB_ENVC_BLOCK) env_compact_kernel(const DevPa
                 vf[i] = v[i];
                 if (i < 3) qg[i] = tile_quant(v[i]);
             }
-            if (P.memo) S.mk_slot[b] = mk_claim(S, qg[0], qg[1], qg[2], step_id, par);
+            if (P.memo) {
+                S.mk_slot_last[b] = S.mk_slot[b];
+                S.mk_slot[b] = mk_claim(S, qg[0], qg[1], qg[2], step_id, par);
+            }
             h.zero_mask &= ~(1 << cur);
             S.verdict[(size_t)b * LOB_VD_STRIDE + 67] = 0;
             h.reward = get_reward(c, e);
@@ -625,7 +632,7 @@ __device__ inline unsigned trace_step(uint32_t x) { return ((x >> 9) ^ (x << 3) 
 template <int ALGO>
 __device__ __forceinline__ void learn_traces(const DevParams& P, const DevState& S, int b, const LHdr& h, const uint32_t* rnd, const uint32_t* act_terms,
                                     u64* tab, bool init_tab, const f32* vars_from, bool zero_last, const f64* qs_last, Rng& g, int lane,
-                                    CbPending& pend, Prof& pf) {
+                                    CbPending& pend, Prof& pf, int dup_flag = 0, bool* dup_out = nullptr) {
     LHdr* hp = S.hdr + b;
     const int action = h.action;
     // ---- group-0 tiles of last_state for all nine actions: lane -> (a = half + 2k, j) ----
@@ -659,13 +666,17 @@ __device__ __forceinline__ void learn_traces(const DevParams& P, const DevState&
     // done), 32-bit compare-and-swap, tile index only.  The table is all-NOTILE between books: every key
     // clears its slot at the end (5 stores instead of re-initialising 4 KB).
     uint32_t* tt = reinterpret_cast<uint32_t*>(tab);
+    // No older generation survives this step (Watkins cut, or the first step) and this triple's 288 tiles are
+    // known to be distinct (`dup_flag` 1, learnt the first time the triple's set was built): nothing would
+    // be looked up in the set -- the new generation is the chosen action's 32 tiles, all alive.
+    const bool skip_set = !init_tab && n_old == 0 && dup_flag == 1;
     if (init_tab) {
         for (int i = lane; i < LOB_TSLOTS / 4; i += 64) reinterpret_cast<uint4*>(tt)[i] = make_uint4(LOB_NOTILE, LOB_NOTILE, LOB_NOTILE, LOB_NOTILE);
         wave_lds_fence();
     }
     unsigned sl[5];
     bool dupl = false;  // two of the 288 (action, tiling) pairs produce the same tile: only through a hash collision
-    {
+    if (!skip_set) {
         bool todo[5];
 #pragma unroll
         for (int k = 0; k < 5; k++) {
@@ -691,6 +702,7 @@ __device__ __forceinline__ void learn_traces(const DevParams& P, const DevState&
         }
     }
     const bool any_dup = __ballot(dupl) != 0;
+    if (dup_out) *dup_out = any_dup;
     wave_lds_fence();
     pf.mark(10);  // argmax(qs_last), LDS map: init + 288 inserts
     const int G = P.trace_gens;  // ring size, a power of two
@@ -786,7 +798,7 @@ __device__ __forceinline__ void learn_traces(const DevParams& P, const DevState&
             }
         }
     }
-    if (!init_tab) {  // leave the set empty for the next book
+    if (!init_tab && !skip_set) {  // leave the set empty for the next book
 #pragma unroll
         for (int k = 0; k < 5; k++)
             if (half + 2 * k < LOB_N_ACTIONS) tt[sl[k]] = LOB_NOTILE;

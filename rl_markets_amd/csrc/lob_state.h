@@ -239,12 +239,14 @@ struct DevState {
     // evaluated once per distinct triple and theta version (memo_kernel) and every book continues
     // the sum from its triple's S0 with whatever group-1/2 weights are non-zero.
     u64* mk_hash;        // [mk_slots] 64-bit hash of the triple, ~0 = empty (claimed by env_kernel)
-    i32* mk_ident;       // [mk_slots][4]: q0, q1, q2, - (written by the claim winner, compared in full by the readers)
+    i32* mk_ident;       // [mk_slots][4]: q0, q1, q2 (written by the claim winner, compared in full by the readers), and whether two of
+                         //   the triple's 288 group-0 tiles coincide: 0 not known yet, 1 no, 2 yes (learnt by the trace kernel)
     i32* mk_stamp;       // [mk_slots] step id of the last claim: first toucher of a step appends the slot to the list
     i32* mk_list;        // [2 parities][mk_slots] slots in use this step
     i32* mk_count;       // [2]
     f64* mk_rec;         // [2: theta_t for learn, theta_{t+1} for the next act][mk_slots][LOB_MK_REC]: S0[9], theta version tag
     i32* mk_slot;        // [B] slot of the book's latest state (-1: none)
+    i32* mk_slot_last;   // [B] slot of the state before that (the learner's last_state in the next step)
     i32 mk_slots;        // power of two
     // Fast learner path (lob_fast.h): exact "ever written" map of the shared theta (one bit per weight) and
     // its coarse image (one bit per 2^cshift weights) that every CU keeps in LDS; work lists of the books
