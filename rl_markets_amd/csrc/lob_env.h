@@ -109,6 +109,7 @@ struct EnvCtx {
     __device__ void err(int bit) const { atomicOr(S.error_flag, bit); }
     __device__ const uint32_t* row(int i) const { return rows + (size_t)i * (size_t)P.Wd; }
     __device__ const Track& track(int k) const { return S.track[(size_t)b * (size_t)S.track_len + (size_t)(k & S.track_mask)]; }
+    __device__ const TrackHead& track_head(int k) const { return *reinterpret_cast<const TrackHead*>(&track(k)); }
     __device__ Track& track_w(int k) const { return S.track[(size_t)b * (size_t)S.track_len + (size_t)(k & S.track_mask)]; }
 };
 
@@ -759,7 +760,7 @@ __device__ inline void match_orders(const EnvCtx& c, EnvR& e, const f64* tp, con
 // `t` = the track entry of event e.k, fetched by the caller (one pass ahead where it can: the entries are
 // agent-independent, and a pass is a chain of dependent look-ups: track entry -> rows -> volumes);
 // `n_track` / `complete`: BookMeta's, fetched once per step.
-__device__ inline bool next_state(const EnvCtx& c, EnvR& e, const Track& t, int n_track, int complete) {
+__device__ inline bool next_state(const EnvCtx& c, EnvR& e, const TrackHead& t, int n_track, int complete) {
     const DevParams& P = c.P;
     f64 tp[LOB_MAX_TRADES];
     i64 tv[LOB_MAX_TRADES];
@@ -868,7 +869,7 @@ __device__ inline void step_prologue(const EnvCtx& c, EnvR& e, int action, StepA
     g.mpm = 0.0;
 }
 // one pass of the do-while: 0 = another event follows, 1 = the step is complete, 2 = out of data
-__device__ inline int step_event(const EnvCtx& c, EnvR& e, StepAgg& g, const Track& t) {
+__device__ inline int step_event(const EnvCtx& c, EnvR& e, StepAgg& g, const TrackHead& t) {
     const DevParams& P = c.P;
     e.pnl_step = 0.0;
     if (!next_state(c, e, t, g.n_track, g.complete)) return 2;
@@ -896,18 +897,18 @@ __device__ inline void step_epilogue(const EnvCtx& c, EnvR& e, const StepAgg& g)
     e.ep_bandh += g.mpm;
     c.mark(27);  // PnL windows
 }
-// `t_out`: the track entry of the last completed event (what the state extraction after the step reads).
-__device__ inline bool perform_action(const EnvCtx& c, EnvR& e, int action, Track& t_out) {
-    // the first pass's track entry is on its way while DoAction computes the quotes; from then on every pass
-    // fetches the NEXT event's entry before it starts on its own (wasted once per step, hidden every time)
-    Track t = c.track(e.k);
+__device__ inline bool perform_action(const EnvCtx& c, EnvR& e, int action) {
+    // the first pass's track entry (its first 32 bytes: all a pass reads) is on its way while DoAction computes
+    // the quotes; from then on every pass fetches the NEXT event's before it starts on its own (wasted once
+    // per step, hidden every time).  The lane kernels are bound by the number of divergent requests a lane
+    // issues, so a pass asks for no more than it needs.
+    TrackHead t = c.track_head(e.k);
     StepAgg g;
     step_prologue(c, e, action, g);
     int st;
     do {
-        const Track tn = c.track(e.k + 1);
+        const TrackHead tn = c.track_head(e.k + 1);
         st = step_event(c, e, g, t);
-        if (st != 2) t_out = t;
         t = tn;
     } while (st == 0);
     if (st == 2) return false;

@@ -267,13 +267,13 @@ __global__ void __launch_bounds__(LOB_ENV_BLOCK) env_kernel(const DevParams* __r
             env_load(S, b, e);
             c.mark(20);  // agent scalars in
             i64 ev0 = e.events;
-            Track tk;  // the last completed event's entry: Intraday::getState reads the market through it
-            bool ok = perform_action(c, e, action, tk);
+            bool ok = perform_action(c, e, action);
             d_events = e.events - ev0;
             if (ok) {
                 const int cur = h.slot_cur;
                 f32* v = S.vars + ((size_t)b * 3 + cur) * 16;
                 f32* vf = S.vars + ((size_t)b * 3 + 2) * 16;
+                const Track tk = state_track(c, e);
                 int qg[3] = {0, 0, 0};
                 for (int i = 0; i < P.V; i++) {
                     v[i] = (f32)get_variable(c, e, P.vars[i], tk);
@@ -383,7 +383,7 @@ __global__ void __launch_bounds__(LOB_ENVC_BLOCK) env_compact_kernel(const DevPa
             slot = work[it & 1][threadIdx.x];
             EnvCompactSlot& sl = slots[slot];
             EnvCtx c(P, S, b0 + blockIdx.x * LOB_ENVC_BLOCK + slot, &tick_lds, sl.rows);
-            const Track t = c.track(sl.s.e.k);
+            const TrackHead t = c.track_head(sl.s.e.k);
             const int st = step_event(c, sl.s.e, sl.agg, t);
             again = st == 0;
             if (!again) status[slot] = (uint8_t)st;

@@ -85,6 +85,14 @@ struct __attribute__((aligned(16))) Track {
     i64 a_tv, b_tv;   // cumulative total_volume_ (quirk Q1)
     f32 mv[8];        // spd, mpm, imb, svl, vol, rsi, vwap (Intraday::getVariable), [7] unused
 };
+// The first 32 bytes of a Track entry: all an event pass reads of it (the rest feeds the state extraction
+// after the step).
+struct __attribute__((aligned(16))) TrackHead {
+    i32 rec_first, rec_last, time_ms, tick_ap0;
+    i32 tick_bp0, _pad;
+    f64 mid;
+};
+static_assert(sizeof(TrackHead) == 32 && sizeof(Track) == 96, "TrackHead is a prefix of Track");
 #define LOB_MV_SPD 0
 #define LOB_MV_MPM 1
 #define LOB_MV_IMB 2
