@@ -64,6 +64,7 @@ struct lob_engine {
     bool have_events = false, was_reset = false;
     bool episode_open = false;  // a pre-pass ran and its window sums have not been rolled back to the stop point yet
     bool timing = false;
+    int timing_period = 1;  // kernels of every n-th step are timed (two event records per launch are not free: 9 % at n = 1)
     std::map<std::string, KTimer> timers;
     std::vector<hipEvent_t> event_pool;
 };
@@ -122,8 +123,9 @@ struct TimedLaunch {
     KTimer* t = nullptr;
     hipEvent_t a = nullptr, b = nullptr;
     hipStream_t st;
-    TimedLaunch(lob_engine* e_, const char* name, hipStream_t s = nullptr) : e(e_), st(s ? s : e_->stream) {
-        if (!e->timing) return;
+    // `always`: kernels that do not run every step (reset, weight exchange, ring refill) are timed whenever timing is on
+    TimedLaunch(lob_engine* e_, const char* name, hipStream_t s = nullptr, bool always = false) : e(e_), st(s ? s : e_->stream) {
+        if (!e->timing || (!always && e->timing_period > 1 && e->step_id % e->timing_period != 0)) return;
         t = &e->timers[name];
         auto get = [&]() {
             hipEvent_t ev;
@@ -590,7 +592,7 @@ static void launch_env(lob_engine* e, hipStream_t st, const i32* actions, int co
 static void maybe_refill_track(lob_engine* e) {
     if (!e->chunked || ++e->steps_since_fill < e->track_refill) return;
     e->steps_since_fill = 0;
-    TimedLaunch t(e, "prepass_extend_kernel");
+    TimedLaunch t(e, "prepass_extend_kernel", nullptr, true);
     hipLaunchKernelGGL(prepass_extend_kernel, dim3((e->B + 63) / 64), dim3(64), 0, e->stream, (const DevParams*)e->P_dev, e->S);
 }
 // S0 of every group-0 triple on this step's list (lob_kernels.h memo_kernel): `which` 0 = for learn_kernel
@@ -608,7 +610,7 @@ int lob_reset(lob_engine* e) {
     // the memo table starts empty every episode (reset_kernel voids every book's slot)
     HIPCHK(hipMemsetAsync(e->S.mk_hash, 0xff, (size_t)e->S.mk_slots * 8, e->stream));
     {
-        TimedLaunch t(e, "reset_kernel");
+        TimedLaunch t(e, "reset_kernel", nullptr, true);
         const int rb = e->reset_lanes;
         if (rb == 32) hipLaunchKernelGGL(reset_kernel<32>, dim3((e->B + 31) / 32), dim3(32), 0, e->stream, (const DevParams*)e->P_dev, e->S);
         else if (rb == 16) hipLaunchKernelGGL(reset_kernel<16>, dim3((e->B + 15) / 16), dim3(16), 0, e->stream, (const DevParams*)e->P_dev, e->S);
@@ -1018,7 +1020,7 @@ int lob_delta_begin_async(lob_engine* e, double** dev_delta, int64_t* count) {
     const size_t M = (size_t)e->P.M;
     const int nv = delta_vectors(e);
     for (int v = 0; v < nv; v++) {
-        TimedLaunch t(e, "delta_begin_kernel");
+        TimedLaunch t(e, "delta_begin_kernel", nullptr, true);
         hipLaunchKernelGGL(delta_begin_kernel, dim3(2048), dim3(256), 0, e->stream, (const f64*)(v ? e->S.theta_b : e->S.theta),
                            (const f64*)(e->S.theta_sync + v * M), e->S.delta + v * M, e->P.M);
     }
@@ -1041,7 +1043,7 @@ int lob_delta_apply(lob_engine* e) {
     const int nv = delta_vectors(e);
     e->theta_ver++;  // memo records computed under the pre-exchange weights are void
     for (int v = 0; v < nv; v++) {
-        TimedLaunch t(e, "delta_apply_kernel");
+        TimedLaunch t(e, "delta_apply_kernel", nullptr, true);
         hipLaunchKernelGGL(delta_apply_kernel, dim3(2048), dim3(256), 0, e->stream, v ? e->S.theta_b : e->S.theta, e->S.theta_sync + v * M,
                            (const f64*)(e->S.delta + v * M), v ? e->S.theta_b_nz : e->S.theta_nz, e->S.nz_epoch, e->P.M,
                            (v == 0 && e->P.memo) ? e->S.theta_nzx : (uint32_t*)nullptr, e->S.theta_nzc, e->P.cshift);
@@ -1066,6 +1068,7 @@ int lob_kernel_timing(lob_engine* e, int32_t enable) {
     drain_timers(e);
     e->timers.clear();
     e->timing = enable != 0;
+    e->timing_period = enable > 1 ? enable : 1;
     return LOB_OK;
 }
 int lob_kernel_time_ms(lob_engine* e, const char* kernel, double* avg_ms, int64_t* launches) {

@@ -257,7 +257,8 @@ class Engine:
         self._check(self.lib.lob_sync(self.h))
 
     def kernel_timing(self, enable=True):
-        self._check(self.lib.lob_kernel_timing(self.h, 1 if enable else 0))
+        """False / 0: off; True / 1: every launch; n > 1: the launches of every n-th step."""
+        self._check(self.lib.lob_kernel_timing(self.h, int(enable)))
 
     def kernel_time_ms(self, name):
         ms = C.c_double()
