@@ -64,6 +64,7 @@ struct lob_engine {
     bool have_events = false, was_reset = false;
     bool episode_open = false;  // a pre-pass ran and its window sums have not been rolled back to the stop point yet
     bool timing = false;
+    int acc_shift = -1;     // accumulate_kernel lanes per book (log2); -1: chosen from the algorithm and epsilon
     int timing_period = 1;  // kernels of every n-th step are timed (two event records per launch are not free: 9 % at n = 1)
     std::map<std::string, KTimer> timers;
     std::vector<hipEvent_t> event_pool;
@@ -249,6 +250,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     if (const char* g = getenv("LOB_ENV_LANES")) { int v = atoi(g); if (v == 16 || v == 32 || v == 64 || v == 256) e->env_lanes = v; }
     if (const char* g = getenv("LOB_TRACK_RING")) { int v = atoi(g); if (v >= 256 && v <= (1 << 20) && (v & (v - 1)) == 0) e->track_ring = v; }
     if (const char* g = getenv("LOB_TRACK_REFILL")) { int v = atoi(g); if (v >= 1) e->track_refill = v; }
+    if (const char* g = getenv("LOB_ACC_LANES")) { int v = atoi(g); if (v == 8 || v == 16 || v == 32 || v == 64) e->acc_shift = v == 8 ? 3 : v == 16 ? 4 : v == 32 ? 5 : 6; }
     if (const char* g = getenv("LOB_RESET_LANES")) { int v = atoi(g); if (v == 16 || v == 32 || v == 64) e->reset_lanes = v; }
 
     // ---- DevParams ----
@@ -275,11 +277,13 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     P.trace_kmax = trace_kmax;
     P.trace_gens = P.trace_kmax <= 32 ? 32 : LOB_TRACE_GENS;
     P.algo = p->algo; P.theta_private = p->theta_mode == LOB_THETA_PRIVATE;
-    { const char* nc = getenv("LOB_NO_CARRY"); P.carry_verdicts = !(nc && nc[0] == '1'); }
+    { const char* nc = getenv("LOB_NO_CARRY"); P.carry_verdicts = !P.theta_private && !(nc && nc[0] == '1'); }
     { const char* nc = getenv("LOB_NO_COMBINE"); P.combine = !P.theta_private && !(nc && nc[0] == '1'); }
     {   // group-0 memo: shared theta, one weight vector, one book group
         const char* nc = getenv("LOB_NO_MEMO");
         P.memo = !P.theta_private && p->algo != LOB_ALGO_DOUBLE_Q && e->n_groups == 1 && !(nc && nc[0] == '1');
+        // the memo path never reads the carry-over filter, and its hot counter serialises first writes
+        if (P.memo) P.carry_verdicts = 0;
     }
     P.seed = p->seed; P.book_id_offset = p->book_id_offset;
 
@@ -581,12 +585,17 @@ static void launch_env(lob_engine* e, hipStream_t st, const i32* actions, int co
                            (const DevParams*)e->P_dev, e->S, count_updates, b0, nb, sid, par);
         return;
     }
-    if (force == 32)
-        hipLaunchKernelGGL(env_kernel<32>, dim3((nb + 31) / 32), dim3(32), 0, st, (const DevParams*)e->P_dev, e->S, actions, count_updates, b0, nb, sid, par);
-    else if (force == 16 || (force == 0 && e->B <= 16384))
-        hipLaunchKernelGGL(env_kernel<16>, dim3((nb + 15) / 16), dim3(16), 0, st, (const DevParams*)e->P_dev, e->S, actions, count_updates, b0, nb, sid, par);
-    else
-        hipLaunchKernelGGL(env_kernel<64>, dim3((nb + 63) / 64), dim3(64), 0, st, (const DevParams*)e->P_dev, e->S, actions, count_updates, b0, nb, sid, par);
+    const DevParams* Pd = (const DevParams*)e->P_dev;
+    const bool t2 = e->P.T <= 2;  // the merged trade list of a pass in 2 register slots instead of LOB_MAX_TRADES
+#define LOB_ENV_LAUNCH(L, TM) hipLaunchKernelGGL((env_kernel<L, TM>), dim3((nb + L - 1) / L), dim3(L), 0, st, Pd, e->S, actions, count_updates, b0, nb, sid, par)
+    if (force == 32) {
+        if (t2) LOB_ENV_LAUNCH(32, 2); else LOB_ENV_LAUNCH(32, LOB_MAX_TRADES);
+    } else if (force == 16 || (force == 0 && e->B <= 16384)) {
+        if (t2) LOB_ENV_LAUNCH(16, 2); else LOB_ENV_LAUNCH(16, LOB_MAX_TRADES);
+    } else {
+        if (t2) LOB_ENV_LAUNCH(64, 2); else LOB_ENV_LAUNCH(64, LOB_MAX_TRADES);
+    }
+#undef LOB_ENV_LAUNCH
 }
 // Long streams: let the pre-pass run on every `track_refill` steps (lob_kernels.h prepass_extend_kernel)
 static void maybe_refill_track(lob_engine* e) {
@@ -720,6 +729,14 @@ int lob_get_book(lob_engine* e, int32_t book, lob_book_dump* out) { return lob_g
 // groups, each running act -> env -> learn on its own stream; both groups only
 // READ theta, so the synchronous-batch semantic is unchanged.  The update of all
 // books runs on the main stream after both groups have joined.
+// accumulate_kernel's lanes per book (log2): one lane per trace generation.  Two books per wave measured
+// best for both SARSA(lambda) (all trace_kmax generations alive) and Watkins's Q(lambda) at eps = 0.8 (1-2
+// alive; 8 lanes per book: 0.035 ms, 16: 0.030, 32: 0.029, 64: 0.036).  LOB_ACC_LANES=8|16|32|64 overrides.
+static int acc_lanes_shift(const lob_engine* e) {
+    if (e->acc_shift >= 0) return e->acc_shift;
+    return 5;
+}
+
 static int run_steps(lob_engine* e, int32_t n_steps, int mode) {
     HIPCHK(hipSetDevice(e->device));
     const int G = e->B >= 1024 ? e->n_groups : 1;  // small batches: one group (an empty group would be an empty launch)
@@ -770,9 +787,9 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode) {
             if (mode == 0 && fast) {
                 {
                     TimedLaunch t(e, "trace_kernel", st);
-                    const int gt = std::min(2 * e->n_cus, (nb + LOB_FAST_WAVES - 1) / LOB_FAST_WAVES);
-                    if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL(trace_fast_kernel<LOB_ALGO_QLAMBDA>, dim3(gt), dim3(LOB_FAST_BLOCK), trace_lds_bytes(), st, e->P, e->S, rnd, par);
-                    else hipLaunchKernelGGL(trace_fast_kernel<LOB_ALGO_SARSA>, dim3(gt), dim3(LOB_FAST_BLOCK), trace_lds_bytes(), st, e->P, e->S, rnd, par);
+                    const int gt = std::min((4 * LOB_TRACE_OCC / LOB_TRACE_WAVES) * e->n_cus, (nb + LOB_TRACE_WAVES - 1) / LOB_TRACE_WAVES);
+                    if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL(trace_fast_kernel<LOB_ALGO_QLAMBDA>, dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, e->P, e->S, rnd, par);
+                    else hipLaunchKernelGGL(trace_fast_kernel<LOB_ALGO_SARSA>, dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, e->P, e->S, rnd, par);
                 }
                 {
                     TimedLaunch t(e, "learn_kernel", st);
@@ -798,7 +815,9 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode) {
         if (mode == 0 && e->P.combine) {
             {
                 TimedLaunch t(e, "accumulate_kernel");
-                hipLaunchKernelGGL(accumulate_kernel, dim3(grid_waves(e->B)), dim3(LOB_BLOCK), 0, e->stream, e->P, e->S, par);
+                const int sh = acc_lanes_shift(e);
+                const int waves = (e->B + (64 >> sh) - 1) / (64 >> sh);
+                hipLaunchKernelGGL(accumulate_kernel, dim3((waves + LOB_WAVES_PER_BLOCK - 1) / LOB_WAVES_PER_BLOCK), dim3(LOB_BLOCK), 0, e->stream, e->P, e->S, par, sh);
             }
             {
                 TimedLaunch t(e, "apply_kernel");

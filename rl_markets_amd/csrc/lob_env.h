@@ -420,6 +420,56 @@ __device__ inline void order_volumes(const EnvCtx& c, const EnvR& e, int last_re
     if (row_rec >= 0 && hbr >= 0) b_v = (i64)(i32)rr[bvol + hbr];
 }
 
+// The level prices of ONE applied depth row, requested together at the top of an event pass (with the trade
+// slots: one memory round trip), and the volumes resting at the two order prices in it.  The matching
+// last_volume()s are not looked up again: inside a step the order prices do not change, and the stashed
+// snapshot of one event is the current snapshot of the event before, so last_volume(price) of this pass is
+// volume(price) of the previous one (StepAgg::cv_*; at the first pass of a step: the displayed volume the
+// order was queued behind, Book::PlaceOrder).
+struct RowLevels {
+    uint32_t apx[LOB_MAX_DEPTH], bpx[LOB_MAX_DEPTH];
+#ifdef LOB_ENV_VOL_UPFRONT
+    uint32_t avol[LOB_MAX_DEPTH], bvol[LOB_MAX_DEPTH];
+#endif
+};
+__device__ inline void row_levels_load(const EnvCtx& c, int rec, RowLevels& L) {
+    const int D = c.P.D;
+    const uint32_t* r = c.row(rec);
+    drec_levels(r + drec_ask_px(D, c.P.T), D, L.apx);
+    drec_levels(r + drec_bid_px(D, c.P.T), D, L.bpx);
+#ifdef LOB_ENV_VOL_UPFRONT
+    drec_levels(r + drec_ask_vol(D, c.P.T), D, L.avol);
+    drec_levels(r + drec_bid_vol(D, c.P.T), D, L.bvol);
+#endif
+}
+__device__ inline void row_volumes(const EnvCtx& c, const EnvR& e, int rec, const RowLevels& L, i64& a_v, i64& b_v) {
+    const int D = c.P.D;
+    const bool a_on = e.a_on != 0, b_on = e.b_on != 0;
+    const f64 ka = key4(e.a_opx), kb = key4(e.b_opx);
+    int ha = -1, hb = -1;
+#pragma unroll
+    for (int l = 0; l < LOB_MAX_DEPTH; l++) {
+        const f32 pa = (a_on && l < D) ? __uint_as_float(L.apx[l]) : 0.0f;
+        const f32 pb = (b_on && l < D) ? __uint_as_float(L.bpx[l]) : 0.0f;
+        if (pa != 0.0f && key4((f64)pa) == ka) ha = l;  // price keys are unique per side (lob_validate_stream)
+        if (pb != 0.0f && key4((f64)pb) == kb) hb = l;
+    }
+#ifdef LOB_ENV_VOL_UPFRONT
+    uint32_t va = 0, vb = 0;
+#pragma unroll
+    for (int l = 0; l < LOB_MAX_DEPTH; l++) {
+        if (l == ha) va = L.avol[l];
+        if (l == hb) vb = L.bvol[l];
+    }
+    a_v = ha >= 0 ? (i64)(i32)va : 0;
+    b_v = hb >= 0 ? (i64)(i32)vb : 0;
+#else
+    const uint32_t* r = c.row(rec);
+    a_v = ha >= 0 ? (i64)(i32)r[drec_ask_vol(D, c.P.T) + ha] : 0;
+    b_v = hb >= 0 ? (i64)(i32)r[drec_bid_vol(D, c.P.T) + hb] : 0;
+#endif
+}
+
 // RiskManager::CheckOrders (src/environment/risk_manager.cpp:26-32)
 __device__ inline void check_orders(const DevParams& P, EnvR& e) {
     if (e.position >= P.pos_ub) e.b_on = 0;
@@ -672,23 +722,30 @@ __device__ inline void update_order(const EnvCtx& c, EnvR& e, int side, i64 lv, 
 // yet, merged per 1e-4 price key.  Rows carry the trades of their own interval,
 // so an event whose predecessor swallowed several rows (same timestamp, invalid
 // states) merges the slots of rows lo..hi; normally lo == hi.
+template <int TM>
 __device__ inline void load_trades(const EnvCtx& c, int lo, int hi, f64* tp, i64* tv) {
     const DevParams& P = c.P;
 #pragma unroll
-    for (int i = 0; i < LOB_MAX_TRADES; i++) { tp[i] = 0.0; tv[i] = 0; }
+    for (int i = 0; i < TM; i++) { tp[i] = 0.0; tv[i] = 0; }
     int n = 0;
     for (int rec = lo; rec <= hi; rec++) {
-        const uint32_t* r = c.row(rec);
-        for (int i = 0; i < P.T; i++) {
-            f32 p = __uint_as_float(r[drec_trades(P.D, P.T) + 2 * i]);
-            i32 v = (i32)r[drec_trades(P.D, P.T) + 2 * i + 1];
+        const uint4* r4 = reinterpret_cast<const uint4*>(c.row(rec) + drec_trades(P.D, P.T));  // 16-byte aligned: two (price, volume) pairs per load
+        uint4 w4[(TM + 1) / 2];
+#pragma unroll
+        for (int q = 0; q < (TM + 1) / 2; q++) w4[q] = 2 * q < P.T ? r4[q] : make_uint4(0, 0, 0, 0);  // wave-uniform; the pad reads as "no trade"
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+            if (i >= P.T) continue;
+            const uint4 w = w4[i >> 1];
+            f32 p = __uint_as_float((i & 1) ? w.z : w.x);
+            i32 v = (i32)((i & 1) ? w.w : w.y);
             if (!((p > 0.0f) && (v > 0))) continue;
             const f64 pd = (f64)p, k = key4(pd);
             // std::map<double,long,FloatComparator>::operator[] += : find the key or insert in order
             int pos = 0;
             bool found = false;
 #pragma unroll
-            for (int q = 0; q < LOB_MAX_TRADES; q++) {
+            for (int q = 0; q < TM; q++) {
                 if (q < n) {
                     const f64 kq = key4(tp[q]);
                     if (kq == k) { tv[q] += (i64)v; found = true; }
@@ -698,11 +755,11 @@ __device__ inline void load_trades(const EnvCtx& c, int lo, int hi, f64* tp, i64
             if (found) continue;
             if (n >= P.T) { c.err(LOB_ERR_TRADE_OVERFLOW); continue; }
 #pragma unroll
-            for (int q = LOB_MAX_TRADES - 1; q > 0; q--) {
+            for (int q = TM - 1; q > 0; q--) {
                 if (q > pos && q <= n) { tp[q] = tp[q - 1]; tv[q] = tv[q - 1]; }
             }
 #pragma unroll
-            for (int q = 0; q < LOB_MAX_TRADES; q++)
+            for (int q = 0; q < TM; q++)
                 if (q == pos) { tp[q] = pd; tv[q] = (i64)v; }
             n++;
         }
@@ -712,12 +769,13 @@ __device__ inline void load_trades(const EnvCtx& c, int lo, int hi, f64* tp, i64
 // AskBook / BidBook::ApplyTransactions (book.cpp:383-427, 468-510) for the agent's
 // orders (the observed-volume bookkeeping of the same functions is agent
 // independent and lives in the pre-pass).
+template <int TM>
 __device__ inline void match_orders(const EnvCtx& c, EnvR& e, const f64* tp, const i64* tv, f64 mp, i64& au_vol,
                                     f64& au_proxy, f64& au_value, i64& bu_vol, f64& bu_proxy, f64& bu_value) {
     const DevParams& P = c.P;
     au_vol = 0; au_proxy = 0.0; au_value = 0.0;
 #pragma unroll
-    for (int i = 0; i < LOB_MAX_TRADES; i++) {
+    for (int i = 0; i < TM; i++) {
         if (i >= P.T || tv[i] <= 0) continue;
         if (tp[i] < mp) continue;
         i64 vol = tv[i];
@@ -735,8 +793,8 @@ __device__ inline void match_orders(const EnvCtx& c, EnvR& e, const f64* tp, con
     }
     bu_vol = 0; bu_proxy = 0.0; bu_value = 0.0;
 #pragma unroll
-    for (int ii = 0; ii < LOB_MAX_TRADES; ii++) {
-        const int i = LOB_MAX_TRADES - 1 - ii;
+    for (int ii = 0; ii < TM; ii++) {
+        const int i = TM - 1 - ii;
         if (i >= P.T || tv[i] <= 0) continue;
         if (tp[i] > mp) continue;
         i64 vol = tv[i];
@@ -754,16 +812,25 @@ __device__ inline void match_orders(const EnvCtx& c, EnvR& e, const f64* tp, con
     }
 }
 
+struct StepAgg {
+    f64 r, pnl, mpm;
+    i32 n_track, complete;  // BookMeta's, as of this step
+    // volume(order price) in the current snapshot, per side: the next pass's last_volume (row_volumes)
+    i64 cv_a, cv_b;
+    i32 cv_valid, _pad;
+};
 // Agent-dependent part of Intraday::NextState (intraday.cpp:225-272) for event e.k.
 // Returns false when the stream is exhausted (the abandoned event still matches
 // its trades and stashes the books, like the reference).
 // `t` = the track entry of event e.k, fetched by the caller (one pass ahead where it can: the entries are
 // agent-independent, and a pass is a chain of dependent look-ups: track entry -> rows -> volumes);
 // `n_track` / `complete`: BookMeta's, fetched once per step.
-__device__ inline bool next_state(const EnvCtx& c, EnvR& e, const TrackHead& t, int n_track, int complete) {
+template <int TM>
+__device__ inline bool next_state(const EnvCtx& c, EnvR& e, const TrackHead& t, StepAgg& g) {
+    const int n_track = g.n_track, complete = g.complete;
     const DevParams& P = c.P;
-    f64 tp[LOB_MAX_TRADES];
-    i64 tv[LOB_MAX_TRADES];
+    f64 tp[TM];
+    i64 tv[TM];
     i64 au_vol, bu_vol; f64 au_proxy, au_value, bu_proxy, bu_value;
     if (e.k >= n_track) {
         const BookMeta& M = c.S.meta[c.b];
@@ -771,8 +838,8 @@ __device__ inline bool next_state(const EnvCtx& c, EnvR& e, const TrackHead& t, 
         if (!complete) c.err(LOB_ERR_TRACK_UNDERRUN);
         // out of data inside this event (Streamer::LoadNext fails, src/data/streamer.cpp:42-49)
         if (M.ex_first >= 0) {
-            load_trades(c, e.pf + 1, M.ex_first, tp, tv);
-            match_orders(c, e, tp, tv, e.mid, au_vol, au_proxy, au_value, bu_vol, bu_proxy, bu_value);
+            load_trades<TM>(c, e.pf + 1, M.ex_first, tp, tv);
+            match_orders<TM>(c, e, tp, tv, e.mid, au_vol, au_proxy, au_value, bu_vol, bu_proxy, bu_value);
             // rows applied before the stream ran dry still update the queue model
             for (int r = M.ex_first; r <= M.ex_cur && M.ex_cur >= M.ex_first; r++) {
                 i64 a_lv, a_v, b_lv, b_v;
@@ -788,21 +855,34 @@ __device__ inline bool next_state(const EnvCtx& c, EnvR& e, const TrackHead& t, 
         e.done = 2;
         return false;
     }
-    load_trades(c, e.pf + 1, t.rec_first, tp, tv);
+    // everything this pass reads of the record stream is requested here, together: the level prices of its
+    // (first) row and the trade slots
+    RowLevels L;
+    row_levels_load(c, t.rec_first, L);
+    load_trades<TM>(c, e.pf + 1, t.rec_first, tp, tv);
     e.pf = t.rec_first;
     c.mark(22);  // track entry, trade slots
     const f64 mp = e.mid;
-    match_orders(c, e, tp, tv, mp, au_vol, au_proxy, au_value, bu_vol, bu_proxy, bu_value);
+    match_orders<TM>(c, e, tp, tv, mp, au_vol, au_proxy, au_value, bu_vol, bu_proxy, bu_value);
     c.mark(23);  // match_orders
     // UpdateBookProfiles: StashState, then ApplyChanges (-> UpdateOrder) for every applied row
     const int last_rec = e.rec_cur;
+    i64 a_lv = g.cv_a, b_lv = g.cv_b;
+    if (!g.cv_valid) {  // no order was placed this step (an action outside 0..8): look the stashed snapshot up
+        i64 a_v0, b_v0;
+        order_volumes(c, e, last_rec, t.rec_first, a_lv, a_v0, b_lv, b_v0);
+    }
     for (int r = t.rec_first; r <= t.rec_last; r++) {
-        i64 a_lv, a_v, b_lv, b_v;
-        order_volumes(c, e, last_rec, r, a_lv, a_v, b_lv, b_v);
+        if (r != t.rec_first) row_levels_load(c, r, L);
+        i64 a_v, b_v;
+        row_volumes(c, e, r, L, a_v, b_v);
         update_order(c, e, 0, a_lv, a_v, tp, tv);
         update_order(c, e, 1, b_lv, b_v, tp, tv);
+        g.cv_a = a_v;
+        g.cv_b = b_v;
     }
-    c.mark(24);  // order_volumes + update_order
+    g.cv_valid = 1;
+    c.mark(24);  // order volumes + update_order
     e.rec_last = last_rec;
     e.rec_cur = t.rec_last;
     e.mid_prev = e.mid;
@@ -811,10 +891,10 @@ __device__ inline bool next_state(const EnvCtx& c, EnvR& e, const TrackHead& t, 
     e.events += (i64)(t.rec_last - t.rec_first + 1);
     e.k++;
 
-    // BookUtils::HandleAdverseSelection (book.cpp:551-592)
+    // BookUtils::HandleAdverseSelection (book.cpp:551-592); the best prices of the new snapshot are L's
     i64 ad_vol = 0; f64 ad_proxy = 0.0, ad_value = 0.0;
     if (e.a_on || e.b_on) {
-        const f64 bap = rec_price(c, e.rec_cur, 0, 0), bbp = rec_price(c, e.rec_cur, 1, 0), rp = e.mid_prev;
+        const f64 bap = (f64)__uint_as_float(L.apx[0]), bbp = (f64)__uint_as_float(L.bpx[0]), rp = e.mid_prev;
         if (e.a_on && e.a_opx <= bbp) {
             OrderR o{e.a_osz, e.a_oqh, e.a_oqt, e.a_oex};
             i64 rem = ord_remaining(o);
@@ -844,10 +924,6 @@ __device__ inline bool next_state(const EnvCtx& c, EnvR& e, const TrackHead& t, 
 // Base::performAction (base.cpp:254-337) in three pieces, so that the event loop can be driven either by
 // the lane that owns the book (perform_action) or by whichever lane of the block is free
 // (env_compact_kernel): the running sums of the loop live in `StepAgg`.
-struct StepAgg {
-    f64 r, pnl, mpm;
-    i32 n_track, complete;  // BookMeta's, as of this step
-};
 // up to the first NextState: DoAction, CheckOrders, UpdateStats, the reward of the action itself
 __device__ inline void step_prologue(const EnvCtx& c, EnvR& e, int action, StepAgg& g) {
     const DevParams& P = c.P;
@@ -861,6 +937,11 @@ __device__ inline void step_prologue(const EnvCtx& c, EnvR& e, int action, StepA
     e.pnl_step = 0.0;
     e.momentum_pnl_step = 0.0;
     do_action(c, e, action);
+    // Book::PlaceOrder queued both orders behind the displayed volume at their prices (oiq): that is
+    // last_volume(order price) of the first event of this step
+    g.cv_valid = action >= 0 && action <= 8;
+    g.cv_a = e.a_oiq;
+    g.cv_b = e.b_oiq;
     check_orders(P, e);
     c.mark(21);  // DoAction: quotes, tick conversions, queue position
     e.total_ticks++;  // UpdateStats
@@ -869,10 +950,11 @@ __device__ inline void step_prologue(const EnvCtx& c, EnvR& e, int action, StepA
     g.mpm = 0.0;
 }
 // one pass of the do-while: 0 = another event follows, 1 = the step is complete, 2 = out of data
+template <int TM>
 __device__ inline int step_event(const EnvCtx& c, EnvR& e, StepAgg& g, const TrackHead& t) {
     const DevParams& P = c.P;
     e.pnl_step = 0.0;
-    if (!next_state(c, e, t, g.n_track, g.complete)) return 2;
+    if (!next_state<TM>(c, e, t, g)) return 2;
     const f64 mpm = e.mid - e.mid_prev;
     e.pnl_step += (f64)e.position * mpm;
     e.momentum_pnl_step += (f64)e.position * mpm;
@@ -897,18 +979,19 @@ __device__ inline void step_epilogue(const EnvCtx& c, EnvR& e, const StepAgg& g)
     e.ep_bandh += g.mpm;
     c.mark(27);  // PnL windows
 }
+template <int TM>
 __device__ inline bool perform_action(const EnvCtx& c, EnvR& e, int action) {
     // the first pass's track entry (its first 32 bytes: all a pass reads) is on its way while DoAction computes
     // the quotes; from then on every pass fetches the NEXT event's before it starts on its own (wasted once
-    // per step, hidden every time).  The lane kernels are bound by the number of divergent requests a lane
-    // issues, so a pass asks for no more than it needs.
+    // per step, hidden every time).  Touching the next pass's record as well (one dword per 64-byte sector, a
+    // pass ahead) bought nothing once a pass requested all it reads of the record in one go (next_state).
     TrackHead t = c.track_head(e.k);
     StepAgg g;
     step_prologue(c, e, action, g);
     int st;
     do {
         const TrackHead tn = c.track_head(e.k + 1);
-        st = step_event(c, e, g, t);
+        st = step_event<TM>(c, e, g, t);
         t = tn;
     } while (st == 0);
     if (st == 2) return false;
@@ -1142,7 +1225,7 @@ __device__ inline void prepass_run(const EnvCtx& c, PrepState& st, BookMeta& M, 
         const int first = m.cursor;
         f64 tp[LOB_MAX_TRADES];
         i64 tv[LOB_MAX_TRADES];
-        load_trades(c, prev_first + 1, first, tp, tv);
+        load_trades<LOB_MAX_TRADES>(c, prev_first + 1, first, tp, tv);
         prev_first = first;
         const f64 mp = (m.ap0 + m.bp0) / 2.0;
         // observed transaction value / volume of Ask/BidBook::ApplyTransactions (book.cpp:394-400, 479-485)

@@ -21,6 +21,17 @@
 
 #define LOB_FAST_WAVES 16
 #define LOB_FAST_BLOCK (64 * LOB_FAST_WAVES)
+/* trace_fast_kernel's block: waves per block, and the waves per SIMD its register budget is cut for.  The
+ * kernel wants 79 VGPRs: at 8 waves per SIMD (64 VGPRs) it spilled 72 bytes per lane.  Measured, Q(lambda),
+ * ms per launch: 16 waves x 2 blocks per CU (8 / SIMD) 0.115, 12 x 2 (6 / SIMD) 0.110, 8 x 3 (6 / SIMD) 0.105,
+ * 4 x 6 (6 / SIMD) 0.105, 6 x 4 (6 / SIMD, waves not a multiple of the 4 SIMDs) 0.137, 4 x 7 0.133, 14 x 2 0.138. */
+#ifndef LOB_TRACE_WAVES
+#define LOB_TRACE_WAVES 8
+#endif
+#ifndef LOB_TRACE_OCC
+#define LOB_TRACE_OCC 6
+#endif
+#define LOB_TRACE_BLOCK (64 * LOB_TRACE_WAVES)
 
 #ifndef LOB_FAST_NB
 #define LOB_FAST_NB 2  /* books a wave of the Q kernels takes through the stages together */
@@ -296,7 +307,7 @@ __global__ void __launch_bounds__(LOB_FAST_BLOCK) act_fast_kernel(DevParams P, D
 // 4 KB tile map per wave).  A book's slot claims are resolved one book later, so that their CAS round
 // trips overlap the next book's work.
 template <int ALGO>
-__global__ void __launch_bounds__(LOB_FAST_BLOCK, 8) trace_fast_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g, int par) {
+__global__ void __launch_bounds__(LOB_TRACE_BLOCK, LOB_TRACE_OCC) trace_fast_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g, int par) {
     extern __shared__ __align__(16) unsigned char fast_lds_raw[];
     // this step's update appends to nz_new[par]; the list the general act path reads is nz_new[par ^ 1]
     if (blockIdx.x == 0 && threadIdx.x < LOB_NZ_WORDS) {
@@ -307,8 +318,8 @@ __global__ void __launch_bounds__(LOB_FAST_BLOCK, 8) trace_fast_kernel(DevParams
     uint32_t* act_terms = rnd + 2048;
     const int w = threadIdx.x >> 6;
     f32* vars = reinterpret_cast<f32*>(act_terms + 32) + w * 48;
-    u64* tab = reinterpret_cast<u64*>(reinterpret_cast<f32*>(act_terms + 32) + LOB_FAST_WAVES * 48) + (size_t)w * LOB_HSLOTS;
-    if (threadIdx.x < 512) reinterpret_cast<uint4*>(rnd)[threadIdx.x] = reinterpret_cast<const uint4*>(rnd_g)[threadIdx.x];
+    u64* tab = reinterpret_cast<u64*>(reinterpret_cast<f32*>(act_terms + 32) + LOB_TRACE_WAVES * 48) + (size_t)w * LOB_HSLOTS;
+    for (int i = threadIdx.x; i < 512; i += LOB_TRACE_BLOCK) reinterpret_cast<uint4*>(rnd)[i] = reinterpret_cast<const uint4*>(rnd_g)[i];
     if (threadIdx.x < 27) act_terms[threadIdx.x] = rnd_g[2048 + threadIdx.x];
     for (int i = threadIdx.x & 63; i < LOB_TSLOTS / 4; i += 64)  // every wave's tile set starts (and is handed on) empty
         reinterpret_cast<uint4*>(tab)[i] = make_uint4(LOB_NOTILE, LOB_NOTILE, LOB_NOTILE, LOB_NOTILE);
@@ -317,7 +328,7 @@ __global__ void __launch_bounds__(LOB_FAST_BLOCK, 8) trace_fast_kernel(DevParams
     prev.active = false;
     int lane_ = threadIdx.x & 63;
 #pragma unroll 1
-    for (int t = blockIdx.x * LOB_FAST_WAVES + w; t < S.B; t += gridDim.x * LOB_FAST_WAVES) {
+    for (int t = blockIdx.x * LOB_TRACE_WAVES + w; t < S.B; t += gridDim.x * LOB_TRACE_WAVES) {
         asm volatile("" : "+v"(lane_));
         const int lane = lane_;
         const int b = __builtin_amdgcn_readfirstlane(t);
@@ -354,7 +365,7 @@ __global__ void __launch_bounds__(LOB_FAST_BLOCK, 8) trace_fast_kernel(DevParams
     }
     cb_claim_finish(S, prev);
 }
-__host__ __device__ inline size_t trace_lds_bytes() { return (size_t)(2048 + 32) * 4 + (size_t)LOB_FAST_WAVES * 48 * 4 + (size_t)LOB_FAST_WAVES * LOB_HSLOTS * 8; }
+__host__ __device__ inline size_t trace_lds_bytes() { return (size_t)(2048 + 32) * 4 + (size_t)LOB_TRACE_WAVES * 48 * 4 + (size_t)LOB_TRACE_WAVES * LOB_HSLOTS * 8; }
 
 // The second half of learn_book: Q(to_state, .), the TD error of SARSA / QLearn::UpdateWeights (agent.cpp:282-311).
 template <int ALGO, int NB>

@@ -238,7 +238,9 @@ __global__ void __launch_bounds__(256) get_state_kernel(const DevParams* __restr
 // lanes' event loops, so when the batch cannot fill the chip anyway (<= 16 384 books: at most one
 // wave per SIMD) 16 books per wave spread the work over 4x the waves: 0.139 -> see DESIGN.md at 4 096
 // books; at 65 536 books the same choice is slower (0.31 vs 0.19 ms).
-template <int LOB_ENV_BLOCK>
+// TM = compile-time bound of the trade slots per record (lob_params.max_trades <= TM): the merged trade
+// list of a pass lives in registers, and the engine's default of 2 slots should not carry arrays of 8.
+template <int LOB_ENV_BLOCK, int TM>
 __global__ void __launch_bounds__(LOB_ENV_BLOCK) env_kernel(const DevParams* __restrict__ Pp, DevState S, const i32* host_actions, int count_updates, int b0, int nb,
                                                             int step_id, int par) {
     const DevParams& P = *Pp;  // parameters read through the scalar cache, never copied to scratch
@@ -267,7 +269,7 @@ __global__ void __launch_bounds__(LOB_ENV_BLOCK) env_kernel(const DevParams* __r
             env_load(S, b, e);
             c.mark(20);  // agent scalars in
             i64 ev0 = e.events;
-            bool ok = perform_action(c, e, action);
+            bool ok = perform_action<TM>(c, e, action);
             d_events = e.events - ev0;
             if (ok) {
                 const int cur = h.slot_cur;
@@ -384,7 +386,7 @@ __global__ void __launch_bounds__(LOB_ENVC_BLOCK) env_compact_kernel(const DevPa
             EnvCompactSlot& sl = slots[slot];
             EnvCtx c(P, S, b0 + blockIdx.x * LOB_ENVC_BLOCK + slot, &tick_lds, sl.rows);
             const TrackHead t = c.track_head(sl.s.e.k);
-            const int st = step_event(c, sl.s.e, sl.agg, t);
+            const int st = step_event<LOB_MAX_TRADES>(c, sl.s.e, sl.agg, t);
             again = st == 0;
             if (!again) status[slot] = (uint8_t)st;
         }
@@ -1019,7 +1021,7 @@ __global__ void __launch_bounds__(LOB_BLOCK) update_kernel(DevParams P, DevState
             const uint32_t bit = LOB_NZ_BIT(f[it]);
             if (!(word[it] & bit)) {  // monotone: set once, then a plain L2 hit
                 const uint32_t old = atomicOr(&nz[LOB_NZ_WORD(f[it])], bit);
-                if (!(old & bit) && !P.theta_private) {  // this lane flipped it: tell the next act_kernel
+                if (!(old & bit) && P.carry_verdicts) {  // this lane flipped it: tell the next act_kernel
                     i32* nz_new = S.nz_new + ((h.stepped == 2 ? 2 : 0) + par) * LOB_NZ_WORDS;
                     atomicAdd(&nz_new[0], 1);
                     atomicOr((uint32_t*)&nz_new[LOB_NZ_FILTER + (LOB_NZ_WORD(f[it]) & (LOB_NZ_FILTER - 1))], bit);  // keyed like the map
@@ -1030,73 +1032,86 @@ __global__ void __launch_bounds__(LOB_BLOCK) update_kernel(DevParams P, DevState
 }
 
 // ---- combined update (shared theta) --------------------------------------------------------------
-// accumulate_kernel: wave per book, ONE LANE per trace generation.  Each live generation finds the
-// slot learn_kernel claimed for its (identity, alive mask) and adds its update alpha*delta/32 * e
-// there: one atomic per generation instead of one per trace (32x fewer, and the slot array is small).
-// A generation without a slot (table crowded, or a 64-bit hash shared by two identities) is applied
-// directly, tile by tile, like update_kernel does.
-__global__ void __launch_bounds__(LOB_BLOCK) accumulate_kernel(DevParams P, DevState S, int par) {
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int b = __builtin_amdgcn_readfirstlane(blockIdx.x * LOB_WAVES_PER_BLOCK + w);
-    if (b >= S.B) return;
-    const LHdr h = S.hdr[b];
-    if (!h.stepped) return;
-    const int n = h.tr_n, head = h.tr_head;
+// accumulate_kernel: ONE LANE per trace generation, `1 << lpb_shift` lanes per book (a book with more
+// generations than that walks them in rounds).  Each live generation finds the slot learn_kernel claimed
+// for its (identity, alive mask) and adds its update alpha*delta/32 * e there: one atomic per generation
+// instead of one per trace (32x fewer, and the slot array is small).  A generation without a slot (table
+// crowded, or a 64-bit hash shared by two identities) is applied directly, tile by tile, like
+// update_kernel does.  Watkins's Q(lambda) leaves 1-2 live generations per book at exploration rates
+// near 1, so a whole wave per book is a chain of four dependent look-ups run 65 536 times for two lanes of
+// work; 8 books per wave run the same chain 8 192 times.
+__global__ void __launch_bounds__(LOB_BLOCK) accumulate_kernel(DevParams P, DevState S, int par, int lpb_shift) {
+    const int lane = threadIdx.x & 63;
+    const int lpb = 1 << lpb_shift, sub = lane & (lpb - 1);
+    const int wave = blockIdx.x * LOB_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const int b = (wave << (6 - lpb_shift)) + (lane >> lpb_shift);
+    int n = 0, head = 0, target = 0;
+    f64 scaled = 0.0;
+    if (b < S.B) {
+        const LHdr& h = S.hdr[b];
+        if (h.stepped) {
+            n = h.tr_n;
+            head = h.tr_head;
+            scaled = h.upd / (f64)LOB_N_TILINGS;
+            target = h.stepped == 2 ? 1 : 0;
+        }
+    }
     const int G = P.trace_gens;
-    const f64 scaled = h.upd / (f64)LOB_N_TILINGS;
-    const int target = h.stepped == 2 ? 1 : 0;
-    const uint32_t* tr_alive = S.tr_alive + (size_t)b * G;
-    const i32* tr_sig = S.tr_sig + (size_t)b * G * 4;
-    // lane = age (G <= 64)
-    const int slot = (head - lane + G) & (G - 1);
-    uint32_t mask = 0;
-    int4 sg = make_int4(0, 0, 0, 0);
-    if (lane < n) {
-        mask = tr_alive[slot];
-        sg = *reinterpret_cast<const int4*>(tr_sig + slot * 4);
-    }
-    bool direct = false;
-    if (mask) {
-        const u64 hsh = cb_hash(sg.x, sg.y, sg.z, sg.w, mask);
-        uint32_t s = (uint32_t)hsh & (uint32_t)(S.cb_slots - 1);
-        bool found = false;
-        for (int probe = 0; probe < LOB_CB_PROBES; probe++) {
-            const u64 kk = S.cb_key[s];
-            if (kk == hsh) {
-                const i32* id = S.cb_ident + (size_t)s * 8;
-                found = id[0] == sg.x && id[1] == sg.y && id[2] == sg.z && id[3] == sg.w && (uint32_t)id[4] == mask;
-                break;  // the first slot with this hash is the only one claim can have made
+    const int bb = b < S.B ? b : 0;
+    const uint32_t* tr_alive = S.tr_alive + (size_t)bb * G;
+    const i32* tr_sig = S.tr_sig + (size_t)bb * G * 4;
+    for (int base = 0; base < G; base += lpb) {
+        const int age = base + sub;
+        if (!__any(age < n)) break;
+        const int slot = (head - age + G) & (G - 1);
+        uint32_t mask = 0;
+        int4 sg = make_int4(0, 0, 0, 0);
+        if (age < n) {
+            mask = tr_alive[slot];
+            sg = *reinterpret_cast<const int4*>(tr_sig + slot * 4);
+        }
+        bool direct = false;
+        if (mask) {
+            const u64 hsh = cb_hash(sg.x, sg.y, sg.z, sg.w, mask);
+            uint32_t s = (uint32_t)hsh & (uint32_t)(S.cb_slots - 1);
+            bool found = false;
+            for (int probe = 0; probe < LOB_CB_PROBES; probe++) {
+                const u64 kk = S.cb_key[s];
+                if (kk == hsh) {
+                    const i32* id = S.cb_ident + (size_t)s * 8;
+                    found = id[0] == sg.x && id[1] == sg.y && id[2] == sg.z && id[3] == sg.w && (uint32_t)id[4] == mask;
+                    break;  // the first slot with this hash is the only one claim can have made
+                }
+                if (kk == LOB_CB_EMPTY) break;
+                s = (s + 1) & (uint32_t)(S.cb_slots - 1);
             }
-            if (kk == LOB_CB_EMPTY) break;
-            s = (s + 1) & (uint32_t)(S.cb_slots - 1);
+            if (found) {
+                __hip_atomic_fetch_add(&S.cb_acc[(size_t)s * 2 + target], scaled * (f64)P.trace_pow[age], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!(S.cb_touch[s] & (1u << target))) atomicOr(&S.cb_touch[s], 1u << target);
+            } else {
+                direct = true;
+            }
         }
-        if (found) {
-            __hip_atomic_fetch_add(&S.cb_acc[(size_t)s * 2 + target], scaled * (f64)P.trace_pow[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (!(S.cb_touch[s] & (1u << target))) atomicOr(&S.cb_touch[s], 1u << target);
-        } else {
-            direct = true;
-        }
-    }
-    u64 todo = __ballot(direct);
-    if (todo) {  // rare: apply these generations tile by tile
-        f64* theta = target ? S.theta_b : S.theta;
-        uint32_t* nz = target ? S.theta_b_nz : S.theta_nz;
-        const i32* tr_idx = S.tr_idx + (size_t)b * G * 32;
-        const int j = lane & 31;
-        while (todo) {
-            const int age = __builtin_ctzll(todo);
+        u64 todo = __ballot(direct);
+        while (todo) {  // rare: apply these generations tile by tile, the whole wave per generation
+            const int src = __builtin_ctzll(todo);
             todo &= todo - 1;
-            const int sl = (head - age + G) & (G - 1);
-            const uint32_t m = __shfl(mask, age);
+            const int d_b = __shfl(bb, src), d_age = __shfl(age, src), d_head = __shfl(head, src), d_t = __shfl(target, src);
+            const uint32_t m = __shfl(mask, src);
+            const f64 d_scaled = readlane_f64(scaled, src);
+            f64* theta = d_t ? S.theta_b : S.theta;
+            uint32_t* nz = d_t ? S.theta_b_nz : S.theta_nz;
+            const int sl = (d_head - d_age + G) & (G - 1);
+            const int j = lane & 31;
             if (lane < 32 && ((m >> j) & 1u)) {
-                const i32 f = tr_idx[sl * 32 + j];
-                __hip_atomic_fetch_add(&theta[f], scaled * (f64)P.trace_pow[age], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (P.memo && !target) nzx_mark(P, S, f);
+                const i32 f = S.tr_idx[((size_t)d_b * G + sl) * 32 + j];
+                __hip_atomic_fetch_add(&theta[f], d_scaled * (f64)P.trace_pow[d_age], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (P.memo && !d_t) nzx_mark(P, S, f);
                 const uint32_t bit = LOB_NZ_BIT(f);
                 if (!(nz[LOB_NZ_WORD(f)] & bit)) {
                     const uint32_t old = atomicOr(&nz[LOB_NZ_WORD(f)], bit);
-                    if (!(old & bit)) {
-                        i32* nz_new = S.nz_new + (2 * target + par) * LOB_NZ_WORDS;
+                    if (!(old & bit) && P.carry_verdicts) {
+                        i32* nz_new = S.nz_new + (2 * d_t + par) * LOB_NZ_WORDS;
                         atomicAdd(&nz_new[0], 1);
                         atomicOr((uint32_t*)&nz_new[LOB_NZ_FILTER + (LOB_NZ_WORD(f) & (LOB_NZ_FILTER - 1))], bit);
                     }
@@ -1130,7 +1145,7 @@ __global__ void __launch_bounds__(256) apply_kernel(DevParams P, DevState S, int
             const uint32_t bit = LOB_NZ_BIT(f);
             if (!(nz[LOB_NZ_WORD(f)] & bit)) {
                 const uint32_t old = atomicOr(&nz[LOB_NZ_WORD(f)], bit);
-                if (!(old & bit)) {  // tell the next act_kernel (verdict carry-over)
+                if (!(old & bit) && P.carry_verdicts) {  // tell the next act_kernel (verdict carry-over)
                     i32* nz_new = S.nz_new + (2 * t + par) * LOB_NZ_WORDS;
                     atomicAdd(&nz_new[0], 1);
                     atomicOr((uint32_t*)&nz_new[LOB_NZ_FILTER + (LOB_NZ_WORD(f) & (LOB_NZ_FILTER - 1))], bit);

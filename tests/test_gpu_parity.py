@@ -418,9 +418,14 @@ def test_combined_update_on_off_identical(monkeypatch, algo):
         np.testing.assert_allclose(out[0][2], out[1][2], rtol=1e-9, atol=1e-12)
 
 
-def test_combined_update_table_overflow():
+@pytest.mark.parametrize("acc_lanes", [0, 8, 16, 64])
+def test_combined_update_table_overflow(monkeypatch, acc_lanes):
     """More distinct trace generations than the claim table has slots (300 books x up to 56 live
-    generations against 2 048 slots): the generations that find no slot are applied directly."""
+    generations against 2 048 slots): the generations that find no slot are applied directly.
+    accumulate_kernel's lanes per book (LOB_ACC_LANES; 0 = the engine's own choice) walk a book's
+    generations in rounds of 8 / 16 / 32 / 64: the shape must not show."""
+    if acc_lanes:
+        monkeypatch.setenv("LOB_ACC_LANES", str(acc_lanes))
     B = 300
     p, g, rec, eng, orc = make(depth=5, n_events=330, B=B, algo=abi.ALGO_SARSA, theta_mode=abi.THETA_SHARED, mem=1 << 16,
                                gamma=1.0, lambda_=0.92, epsilon=0.6)

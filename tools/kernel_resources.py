@@ -1,0 +1,31 @@
+"""Registers / scratch / LDS / occupancy of every kernel of the engine library, as the compiler reports
+them (-Rpass-analysis=kernel-resource-usage; device pass only, nothing is written next to the sources)."""
+import os
+import re
+import subprocess
+import sys
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "rl_markets_amd", "csrc")
+cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "--cuda-device-only", "-c",
+       "-Rpass-analysis=kernel-resource-usage", "-Wno-unused-value", "-o", "/dev/null", "lob_engine.hip"] + sys.argv[1:]
+out = subprocess.run(cmd, cwd=CSRC, stderr=subprocess.PIPE, stdout=subprocess.PIPE, text=True).stderr
+try:
+    filt = subprocess.run(["c++filt"], input=out, stdout=subprocess.PIPE, text=True).stdout
+except FileNotFoundError:
+    filt = out
+cur = {}
+for line in filt.splitlines():
+    m = re.search(r"remark: [^:]*:\d+:\d+: +(.*?)(?: \[-Rpass)", line) or re.search(r"remark: +(.*?)(?: \[-Rpass)", line)
+    if not m:
+        continue
+    t = m.group(1).strip()
+    if t.startswith("Function Name:"):
+        cur = {"name": t.split(":", 1)[1].strip()}
+    elif ":" in t:
+        k, v = t.split(":", 1)
+        cur[k.strip()] = v.strip()
+        if k.strip().startswith("LDS Size"):
+            name = re.sub(r"\(.*", "", cur["name"])
+            print("%-58s vgpr %4s agpr %3s sgpr %4s scratch %5s occ %2s lds %6s" % (
+                name[:58], cur.get("VGPRs"), cur.get("AGPRs"), cur.get("SGPRs"), cur.get("ScratchSize [bytes/lane]"),
+                cur.get("Occupancy [waves/SIMD]"), cur.get("LDS Size [bytes/block]")))
