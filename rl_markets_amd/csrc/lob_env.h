@@ -420,29 +420,33 @@ __device__ inline void order_volumes(const EnvCtx& c, const EnvR& e, int last_re
     if (row_rec >= 0 && hbr >= 0) b_v = (i64)(i32)rr[bvol + hbr];
 }
 
-// The level prices of ONE applied depth row, requested together at the top of an event pass (with the trade
-// slots: one memory round trip), and the volumes resting at the two order prices in it.  The matching
-// last_volume()s are not looked up again: inside a step the order prices do not change, and the stashed
-// snapshot of one event is the current snapshot of the event before, so last_volume(price) of this pass is
-// volume(price) of the previous one (StepAgg::cv_*; at the first pass of a step: the displayed volume the
-// order was queued behind, Book::PlaceOrder).
-struct RowLevels {
-    uint32_t apx[LOB_MAX_DEPTH], bpx[LOB_MAX_DEPTH];
-#ifdef LOB_ENV_VOL_UPFRONT
-    uint32_t avol[LOB_MAX_DEPTH], bvol[LOB_MAX_DEPTH];
-#endif
+// One snapshot's four level arrays in registers, ONE memory round trip (row_full_load).
+//  * DoAction reads the best prices, the displayed volume at both quotes and -- for a market order -- walks
+//    one side of the CURRENT snapshot (looked up one after the other they were three to twelve dependent
+//    round trips per step);
+//  * an event pass requests the arrays of the depth row it applies at its top, together with the trade slots,
+//    and finds the volumes resting at the two order prices in them (row_volumes; the volumes come with the
+//    prices: fetched after the level is known they are one more round trip, 0.103 -> 0.101 ms).  The matching
+//    last_volume()s are not looked up at all: inside a step the order prices do not change, and the stashed
+//    snapshot of one event is the current snapshot of the event before, so last_volume(price) of this pass is
+//    volume(price) of the previous one (StepAgg::cv_*; at the first pass of a step: the displayed volume the
+//    order was queued behind, Book::PlaceOrder).
+struct RowFull {
+    uint32_t apx[LOB_MAX_DEPTH], avol[LOB_MAX_DEPTH], bpx[LOB_MAX_DEPTH], bvol[LOB_MAX_DEPTH];
 };
-__device__ inline void row_levels_load(const EnvCtx& c, int rec, RowLevels& L) {
+__device__ inline void row_full_load(const EnvCtx& c, int rec, RowFull& R) {
     const int D = c.P.D;
-    const uint32_t* r = c.row(rec);
-    drec_levels(r + drec_ask_px(D, c.P.T), D, L.apx);
-    drec_levels(r + drec_bid_px(D, c.P.T), D, L.bpx);
-#ifdef LOB_ENV_VOL_UPFRONT
-    drec_levels(r + drec_ask_vol(D, c.P.T), D, L.avol);
-    drec_levels(r + drec_bid_vol(D, c.P.T), D, L.bvol);
-#endif
+    const uint32_t* r = c.row(rec < 0 ? 0 : rec);
+    drec_levels(r + drec_ask_px(D, c.P.T), D, R.apx);
+    drec_levels(r + drec_ask_vol(D, c.P.T), D, R.avol);
+    drec_levels(r + drec_bid_px(D, c.P.T), D, R.bpx);
+    drec_levels(r + drec_bid_vol(D, c.P.T), D, R.bvol);
+    if (rec < 0) {  // no snapshot: every price reads as "undefined" (0), like rec_price / book_volume
+#pragma unroll
+        for (int l = 0; l < LOB_MAX_DEPTH; l++) R.apx[l] = R.avol[l] = R.bpx[l] = R.bvol[l] = 0u;
+    }
 }
-__device__ inline void row_volumes(const EnvCtx& c, const EnvR& e, int rec, const RowLevels& L, i64& a_v, i64& b_v) {
+__device__ inline void row_volumes(const EnvCtx& c, const EnvR& e, const RowFull& L, i64& a_v, i64& b_v) {
     const int D = c.P.D;
     const bool a_on = e.a_on != 0, b_on = e.b_on != 0;
     const f64 ka = key4(e.a_opx), kb = key4(e.b_opx);
@@ -454,7 +458,6 @@ __device__ inline void row_volumes(const EnvCtx& c, const EnvR& e, int rec, cons
         if (pa != 0.0f && key4((f64)pa) == ka) ha = l;  // price keys are unique per side (lob_validate_stream)
         if (pb != 0.0f && key4((f64)pb) == kb) hb = l;
     }
-#ifdef LOB_ENV_VOL_UPFRONT
     uint32_t va = 0, vb = 0;
 #pragma unroll
     for (int l = 0; l < LOB_MAX_DEPTH; l++) {
@@ -463,11 +466,20 @@ __device__ inline void row_volumes(const EnvCtx& c, const EnvR& e, int rec, cons
     }
     a_v = ha >= 0 ? (i64)(i32)va : 0;
     b_v = hb >= 0 ? (i64)(i32)vb : 0;
-#else
-    const uint32_t* r = c.row(rec);
-    a_v = ha >= 0 ? (i64)(i32)r[drec_ask_vol(D, c.P.T) + ha] : 0;
-    b_v = hb >= 0 ? (i64)(i32)r[drec_bid_vol(D, c.P.T) + hb] : 0;
-#endif
+}
+
+// Book::volume(price) (book.cpp:200-214) on that snapshot
+__device__ inline i64 full_volume(const EnvCtx& c, const RowFull& R, int side, f64 price) {
+    const int D = c.P.D;
+    const f64 k = key4(price);
+    bool hit = false;
+    uint32_t v = 0;
+#pragma unroll
+    for (int l = 0; l < LOB_MAX_DEPTH; l++) {
+        const f32 p = l < D ? __uint_as_float(side == 0 ? R.apx[l] : R.bpx[l]) : 0.0f;
+        if (p != 0.0f && key4((f64)p) == k) { hit = true; v = side == 0 ? R.avol[l] : R.bvol[l]; }  // price keys are unique per side
+    }
+    return hit ? (i64)(i32)v : 0;
 }
 
 // RiskManager::CheckOrders (src/environment/risk_manager.cpp:26-32)
@@ -479,9 +491,9 @@ __device__ inline void check_orders(const DevParams& P, EnvR& e) {
 // RiskManager::PlaceOrder with ORDER_LIMIT == 1 (risk_manager.cpp:61-99) +
 // Book::PlaceOrder (book.cpp:250-261): cancel whatever rests, place a new
 // order queued behind the displayed volume at that price.
-__device__ inline void place_one(const EnvCtx& c, EnvR& e, int side, f64 price, i32 price_ticks) {
+__device__ inline void place_one(const EnvCtx& c, EnvR& e, int side, f64 price, i32 price_ticks, const RowFull& cur) {
     if (!(price > 0.0)) c.err(LOB_ERR_BAD_ORDER_PRICE);
-    i64 qh = book_volume(c, e.rec_cur, side, price);
+    i64 qh = full_volume(c, cur, side, price);
     if (side == 0) {
         e.a_on = 1; e.a_opx = price; e.a_osz = c.P.order_size; e.a_oqh = qh; e.a_oqt = 0; e.a_oex = 0; e.a_oiq = qh; e.a_otk = price_ticks;
     } else {
@@ -490,13 +502,14 @@ __device__ inline void place_one(const EnvCtx& c, EnvR& e, int side, f64 price, 
 }
 
 // Intraday::_place_orders + l2p_ (src/environment/intraday.cpp:64-82,164-173)
-__device__ inline void place_orders(const EnvCtx& c, EnvR& e, int al, int bl) {
+// `cur` = the level arrays of e.rec_cur (row_full_load)
+__device__ inline void place_orders(const EnvCtx& c, EnvR& e, int al, int bl, const RowFull& cur) {
     const DevParams& P = c.P;
     e.ask_level = al;
     e.bid_level = bl;
     int ta, tb;
     if (P.quote_mode == LOB_QUOTE_BOOK) {
-        const f64 ap0 = rec_price(c, e.rec_cur, 0, 0), bp0 = rec_price(c, e.rec_cur, 1, 0);
+        const f64 ap0 = (f64)__uint_as_float(cur.apx[0]), bp0 = (f64)__uint_as_float(cur.bpx[0]);
         if (ap0 == 0.0 || bp0 == 0.0) c.err(LOB_ERR_UNDEF_PRICE);
         ta = lobh::to_ticks_t((*c.tk), ap0) + al;
         tb = lobh::to_ticks_t((*c.tk), bp0) - bl;
@@ -511,12 +524,17 @@ __device__ inline void place_orders(const EnvCtx& c, EnvR& e, int al, int bl) {
     e.ask_quote = lobh::to_price_t((*c.tk), ta);
     e.bid_quote = lobh::to_price_t((*c.tk), tb);
     // a_dist / b_dist need ToTicks(order price): computed once, here
-    place_one(c, e, 0, e.ask_quote, lobh::to_ticks_t((*c.tk), e.ask_quote));
-    place_one(c, e, 1, e.bid_quote, lobh::to_ticks_t((*c.tk), e.bid_quote));
+    place_one(c, e, 0, e.ask_quote, lobh::to_ticks_t((*c.tk), e.ask_quote), cur);
+    place_one(c, e, 1, e.bid_quote, lobh::to_ticks_t((*c.tk), e.bid_quote), cur);
+}
+__device__ inline void place_orders(const EnvCtx& c, EnvR& e, int al, int bl) {
+    RowFull cur;
+    row_full_load(c, e.rec_cur, cur);
+    place_orders(c, e, al, bl, cur);
 }
 
 // AskBook/BidBook::WalkTheBook via BookUtils::MarketOrder (book.cpp:431-456,514-539,595-610)
-__device__ inline void market_order(const EnvCtx& c, EnvR& e, i64 size, i64& out_vol, f64& out_proxy, f64& out_value) {
+__device__ inline void market_order(const EnvCtx& c, EnvR& e, i64 size, i64& out_vol, f64& out_proxy, f64& out_value, const RowFull& cur) {
     out_vol = 0; out_proxy = 0.0; out_value = 0.0;
     if (e.rec_cur < 0) c.err(LOB_ERR_UNDEF_PRICE);
     const f64 mip = e.mid;
@@ -533,14 +551,13 @@ __device__ inline void market_order(const EnvCtx& c, EnvR& e, i64 size, i64& out
     if (abs_size > tv) return;
     i64 executed = 0;
     f64 proxy = 0.0, value = 0.0;
-    const uint32_t* r = c.row(e.rec_cur);
-    const uint32_t* px = r + (side == 0 ? drec_ask_px(c.P.D, c.P.T) : drec_bid_px(c.P.D, c.P.T));
-    const uint32_t* vol = r + (side == 0 ? drec_ask_vol(c.P.D, c.P.T) : drec_bid_vol(c.P.D, c.P.T));
-    for (int l = 0; l < c.P.D; l++) {
-        f32 pf = __uint_as_float(px[l]);
-        if (pf == 0.0f) continue;
+    bool filled = false;
+#pragma unroll
+    for (int l = 0; l < LOB_MAX_DEPTH; l++) {
+        const f32 pf = __uint_as_float(side == 0 ? cur.apx[l] : cur.bpx[l]);
+        if (l >= c.P.D || filled || pf == 0.0f) continue;
         f64 p = (f64)pf;
-        i64 lvol = (i64)(i32)vol[l];
+        i64 lvol = (i64)(i32)(side == 0 ? cur.avol[l] : cur.bvol[l]);
         i64 left = abs_size - executed;
         i64 l_ex = lvol < left ? lvol : left;
         executed += l_ex;
@@ -549,7 +566,7 @@ __device__ inline void market_order(const EnvCtx& c, EnvR& e, i64 size, i64& out
         else value += (f64)l_ex * p;
         if (executed >= abs_size) {
             if (side == 0) e.a_ntr++; else e.b_ntr++;
-            break;
+            filled = true;
         }
     }
     out_vol = side == 0 ? executed : -executed;
@@ -558,9 +575,9 @@ __device__ inline void market_order(const EnvCtx& c, EnvR& e, i64 size, i64& out
 }
 
 // Base::ClearInventory (base.cpp:339-349) + RiskManager::ClearInventory/MarketOrder
-__device__ inline void clear_inventory(const EnvCtx& c, EnvR& e) {
+__device__ inline void clear_inventory(const EnvCtx& c, EnvR& e, const RowFull& cur) {
     i64 v; f64 proxy, value;
-    market_order(c, e, -e.position, v, proxy, value);
+    market_order(c, e, -e.position, v, proxy, value, cur);
     e.position += v;
     e.pnl_step += proxy;
     e.lo_vol_step += (i32)(v < 0 ? -v : v);
@@ -568,13 +585,18 @@ __device__ inline void clear_inventory(const EnvCtx& c, EnvR& e) {
     if (v > 0) e.market_buys++;
     else if (v < 0) e.market_sells++;
 }
+__device__ inline void clear_inventory(const EnvCtx& c, EnvR& e) {
+    RowFull cur;
+    row_full_load(c, e.rec_cur, cur);
+    clear_inventory(c, e, cur);
+}
 
 // Intraday::DoAction (intraday.cpp:176-220)
-__device__ inline void do_action(const EnvCtx& c, EnvR& e, int action) {
+__device__ inline void do_action(const EnvCtx& c, EnvR& e, int action, const RowFull& cur) {
     int al, bl;
     switch (action) {
         case 0: al = 1; bl = 1; break;
-        case 1: clear_inventory(c, e); al = e.ask_level; bl = e.bid_level; break;
+        case 1: clear_inventory(c, e, cur); al = e.ask_level; bl = e.bid_level; break;
         case 2: al = 2; bl = 2; break;
         case 3: al = 3; bl = 3; break;
         case 4: al = 0; bl = 2; break;
@@ -584,7 +606,7 @@ __device__ inline void do_action(const EnvCtx& c, EnvR& e, int action) {
         case 8: al = 5; bl = 5; break;
         default: return;
     }
-    place_orders(c, e, al, bl);
+    place_orders(c, e, al, bl, cur);
 }
 
 __device__ inline bool is_open(const DevParams& P, i32 t) {  // Market::IsOpen, market.cpp:67-70
@@ -857,8 +879,8 @@ __device__ inline bool next_state(const EnvCtx& c, EnvR& e, const TrackHead& t, 
     }
     // everything this pass reads of the record stream is requested here, together: the level prices of its
     // (first) row and the trade slots
-    RowLevels L;
-    row_levels_load(c, t.rec_first, L);
+    RowFull L;
+    row_full_load(c, t.rec_first, L);
     load_trades<TM>(c, e.pf + 1, t.rec_first, tp, tv);
     e.pf = t.rec_first;
     c.mark(22);  // track entry, trade slots
@@ -873,9 +895,9 @@ __device__ inline bool next_state(const EnvCtx& c, EnvR& e, const TrackHead& t, 
         order_volumes(c, e, last_rec, t.rec_first, a_lv, a_v0, b_lv, b_v0);
     }
     for (int r = t.rec_first; r <= t.rec_last; r++) {
-        if (r != t.rec_first) row_levels_load(c, r, L);
+        if (r != t.rec_first) row_full_load(c, r, L);
         i64 a_v, b_v;
-        row_volumes(c, e, r, L, a_v, b_v);
+        row_volumes(c, e, L, a_v, b_v);
         update_order(c, e, 0, a_lv, a_v, tp, tv);
         update_order(c, e, 1, b_lv, b_v, tp, tv);
         g.cv_a = a_v;
@@ -925,7 +947,7 @@ __device__ inline bool next_state(const EnvCtx& c, EnvR& e, const TrackHead& t, 
 // the lane that owns the book (perform_action) or by whichever lane of the block is free
 // (env_compact_kernel): the running sums of the loop live in `StepAgg`.
 // up to the first NextState: DoAction, CheckOrders, UpdateStats, the reward of the action itself
-__device__ inline void step_prologue(const EnvCtx& c, EnvR& e, int action, StepAgg& g) {
+__device__ inline void step_prologue(const EnvCtx& c, EnvR& e, int action, StepAgg& g, const RowFull& cur) {
     const DevParams& P = c.P;
     {
         const BookMeta& M = c.S.meta[c.b];
@@ -936,7 +958,7 @@ __device__ inline void step_prologue(const EnvCtx& c, EnvR& e, int action, StepA
     e.lo_vol_step = 0;
     e.pnl_step = 0.0;
     e.momentum_pnl_step = 0.0;
-    do_action(c, e, action);
+    do_action(c, e, action, cur);
     // Book::PlaceOrder queued both orders behind the displayed volume at their prices (oiq): that is
     // last_volume(order price) of the first event of this step
     g.cv_valid = action >= 0 && action <= 8;
@@ -979,15 +1001,17 @@ __device__ inline void step_epilogue(const EnvCtx& c, EnvR& e, const StepAgg& g)
     e.ep_bandh += g.mpm;
     c.mark(27);  // PnL windows
 }
+// `t` = the track entry of event e.k, `cur` = the level arrays of e.rec_cur: requested by the caller from the
+// two scalars k and rec_cur BEFORE it loads the rest of the book's state, so that three round trips (state,
+// track entry, snapshot) overlap.
 template <int TM>
-__device__ inline bool perform_action(const EnvCtx& c, EnvR& e, int action) {
-    // the first pass's track entry (its first 32 bytes: all a pass reads) is on its way while DoAction computes
-    // the quotes; from then on every pass fetches the NEXT event's before it starts on its own (wasted once
-    // per step, hidden every time).  Touching the next pass's record as well (one dword per 64-byte sector, a
-    // pass ahead) bought nothing once a pass requested all it reads of the record in one go (next_state).
-    TrackHead t = c.track_head(e.k);
+__device__ inline bool perform_action(const EnvCtx& c, EnvR& e, int action, TrackHead t, const RowFull& cur) {
+    // From then on every pass fetches the NEXT event's track entry (its first 32 bytes: all a pass reads)
+    // before it starts on its own: wasted once per step, hidden every time.  Touching the next pass's record
+    // as well (one dword per 64-byte sector, a pass ahead) bought nothing once a pass requested all it reads
+    // of the record in one go (next_state).
     StepAgg g;
-    step_prologue(c, e, action, g);
+    step_prologue(c, e, action, g, cur);
     int st;
     do {
         const TrackHead tn = c.track_head(e.k + 1);

@@ -251,6 +251,7 @@ __global__ void __launch_bounds__(LOB_ENV_BLOCK) env_kernel(const DevParams* __r
     const int b = b0 + t;
     i64 d_steps = 0, d_events = 0;
     if (t < nb) {
+        const int k0 = S.k[b], rc0 = S.rec_cur[b];  // in flight together with the header
         LHdr& h = S.hdr[b];
         bool go;
         int action;
@@ -265,11 +266,15 @@ __global__ void __launch_bounds__(LOB_ENV_BLOCK) env_kernel(const DevParams* __r
         if (go) {
             EnvCtx c(P, S, b, &tick_lds);
             c.prof_start(S.prof, threadIdx.x & 63);
+            // the first event's track entry and the current snapshot are requested before the bulk of the state
+            const TrackHead t0 = c.track_head(k0);
+            RowFull cur;
+            row_full_load(c, rc0, cur);
             EnvR& e = lds_env[threadIdx.x].e;
             env_load(S, b, e);
             c.mark(20);  // agent scalars in
             i64 ev0 = e.events;
-            bool ok = perform_action<TM>(c, e, action);
+            bool ok = perform_action<TM>(c, e, action, t0, cur);
             d_events = e.events - ev0;
             if (ok) {
                 const int cur = h.slot_cur;
@@ -360,7 +365,9 @@ __global__ void __launch_bounds__(LOB_ENVC_BLOCK) env_compact_kernel(const DevPa
             env_load(S, b, e);
             ev0 = e.events;
             sl.rows = c.rows;
-            step_prologue(c, e, h.action, sl.agg);
+            RowFull cur;
+            row_full_load(c, e.rec_cur, cur);
+            step_prologue(c, e, h.action, sl.agg, cur);
         } else {
             h.stepped = 0;
         }
