@@ -466,7 +466,8 @@ void lob_destroy(lob_engine* e) {
 
 static int finalize_episode(lob_engine* e) {
     if (!e->episode_open) return LOB_OK;
-    hipLaunchKernelGGL(finalize_kernel, dim3(grid_lanes(e->B)), dim3(256), 0, e->stream, (const DevParams*)e->P_dev, e->S);
+    if (e->P.T <= 2) hipLaunchKernelGGL(finalize_kernel<2>, dim3(grid_lanes(e->B)), dim3(256), 0, e->stream, (const DevParams*)e->P_dev, e->S);
+    else hipLaunchKernelGGL(finalize_kernel<LOB_MAX_TRADES>, dim3(grid_lanes(e->B)), dim3(256), 0, e->stream, (const DevParams*)e->P_dev, e->S);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(e->stream));
     e->episode_open = false;
@@ -602,7 +603,8 @@ static void maybe_refill_track(lob_engine* e) {
     if (!e->chunked || ++e->steps_since_fill < e->track_refill) return;
     e->steps_since_fill = 0;
     TimedLaunch t(e, "prepass_extend_kernel", nullptr, true);
-    hipLaunchKernelGGL(prepass_extend_kernel, dim3((e->B + 63) / 64), dim3(64), 0, e->stream, (const DevParams*)e->P_dev, e->S);
+    if (e->P.T <= 2) hipLaunchKernelGGL(prepass_extend_kernel<2>, dim3((e->B + 63) / 64), dim3(64), 0, e->stream, (const DevParams*)e->P_dev, e->S);
+    else hipLaunchKernelGGL(prepass_extend_kernel<LOB_MAX_TRADES>, dim3((e->B + 63) / 64), dim3(64), 0, e->stream, (const DevParams*)e->P_dev, e->S);
 }
 // S0 of every group-0 triple on this step's list (lob_kernels.h memo_kernel): `which` 0 = for learn_kernel
 // (theta_t), 1 = for the next act_kernel (after the update)
@@ -621,9 +623,13 @@ int lob_reset(lob_engine* e) {
     {
         TimedLaunch t(e, "reset_kernel", nullptr, true);
         const int rb = e->reset_lanes;
-        if (rb == 32) hipLaunchKernelGGL(reset_kernel<32>, dim3((e->B + 31) / 32), dim3(32), 0, e->stream, (const DevParams*)e->P_dev, e->S);
-        else if (rb == 16) hipLaunchKernelGGL(reset_kernel<16>, dim3((e->B + 15) / 16), dim3(16), 0, e->stream, (const DevParams*)e->P_dev, e->S);
-        else hipLaunchKernelGGL(reset_kernel<64>, dim3((e->B + 63) / 64), dim3(64), 0, e->stream, (const DevParams*)e->P_dev, e->S);
+        const DevParams* Pd = (const DevParams*)e->P_dev;
+        const bool t2 = e->P.T <= 2;
+#define LOB_RESET_LAUNCH(L, TM) hipLaunchKernelGGL((reset_kernel<L, TM>), dim3((e->B + L - 1) / L), dim3(L), 0, e->stream, Pd, e->S)
+        if (rb == 32) { if (t2) LOB_RESET_LAUNCH(32, 2); else LOB_RESET_LAUNCH(32, LOB_MAX_TRADES); }
+        else if (rb == 16) { if (t2) LOB_RESET_LAUNCH(16, 2); else LOB_RESET_LAUNCH(16, LOB_MAX_TRADES); }
+        else { if (t2) LOB_RESET_LAUNCH(64, 2); else LOB_RESET_LAUNCH(64, LOB_MAX_TRADES); }
+#undef LOB_RESET_LAUNCH
     }
     HIPCHK(hipGetLastError());
     e->was_reset = true;

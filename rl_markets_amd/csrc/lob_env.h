@@ -1226,6 +1226,7 @@ __device__ inline void prepass_begin(const EnvCtx& c, PrepState& st, BookMeta& M
     st.prev_first = m.rec_cur;  // Initialise: time_and_sales.SkipUntil(market time) drops everything up to here
 }
 
+template <int TM>
 __device__ inline void prepass_run(const EnvCtx& c, PrepState& st, BookMeta& M, int k_stop, bool write_track) {
     const DevParams& P = c.P;
     const DevState& S = c.S;
@@ -1247,23 +1248,23 @@ __device__ inline void prepass_run(const EnvCtx& c, PrepState& st, BookMeta& M, 
     acc_load(S.f_vwap_numer, b, w_vn); acc_load(S.f_vwap_denom, b, w_vd);
     while (!M.complete && k < k_stop) {
         const int first = m.cursor;
-        f64 tp[LOB_MAX_TRADES];
-        i64 tv[LOB_MAX_TRADES];
-        load_trades<LOB_MAX_TRADES>(c, prev_first + 1, first, tp, tv);
+        f64 tp[TM];
+        i64 tv[TM];
+        load_trades<TM>(c, prev_first + 1, first, tp, tv);
         prev_first = first;
         const f64 mp = (m.ap0 + m.bp0) / 2.0;
         // observed transaction value / volume of Ask/BidBook::ApplyTransactions (book.cpp:394-400, 479-485)
         m.a_obsval = 0.0; m.a_obsvol = 0; m.b_obsval = 0.0; m.b_obsvol = 0;
 #pragma unroll
-        for (int i = 0; i < LOB_MAX_TRADES; i++) {
+        for (int i = 0; i < TM; i++) {
             if (i >= P.T || tv[i] <= 0) continue;
             if (tp[i] < mp) continue;
             m.a_obsval += tp[i] * (f64)tv[i];
             m.a_obsvol += tv[i];
         }
 #pragma unroll
-        for (int ii = 0; ii < LOB_MAX_TRADES; ii++) {
-            const int i = LOB_MAX_TRADES - 1 - ii;
+        for (int ii = 0; ii < TM; ii++) {
+            const int i = TM - 1 - ii;
             if (i >= P.T || tv[i] <= 0) continue;
             if (tp[i] > mp) continue;
             m.b_obsval += tp[i] * (f64)tv[i];

@@ -99,7 +99,7 @@ __global__ void repack_kernel(const uint32_t* __restrict__ src, int D, int T, si
 // warm-up, place the (1,1) quotes.
 // RB books per block (= per wave when RB <= 64): the kernel needs the whole register file of a lane,
 // so at most two waves share a SIMD; with 32 books per wave those two hide each other's latency.
-template <int RB>
+template <int RB, int TM>
 __global__ void __launch_bounds__(RB) reset_kernel(const DevParams* __restrict__ Pp, DevState S) {
     const DevParams& P = *Pp;
     __shared__ TickLds tick_lds;
@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(RB) reset_kernel(const DevParams* __restrict__
         // the whole stream when its track is resident, else the first ring-full (prepass_extend_kernel goes on from there)
         PrepState st;
         prepass_begin(c, st, M);
-        prepass_run(c, st, M, S.track_mask == 0x7fffffff ? 0x7fffffff : S.track_len - LOB_TRACK_MARGIN, true);
+        prepass_run<TM>(c, st, M, S.track_mask == 0x7fffffff ? 0x7fffffff : S.track_len - LOB_TRACK_MARGIN, true);
         S.meta[b] = M;
         S.prep[b] = st;
     }
@@ -174,6 +174,7 @@ __global__ void __launch_bounds__(RB) reset_kernel(const DevParams* __restrict__
 // window sums exactly as they stood after the `k` events the episode consumed
 // (restore the episode-start sums, replay k events) -- they are what the next
 // episode inherits (quirk Q7).
+template <int TM>
 __global__ void __launch_bounds__(256, 1) finalize_kernel(const DevParams* __restrict__ Pp, DevState S) {
     const DevParams& P = *Pp;
     __shared__ TickLds tick_lds;
@@ -187,7 +188,7 @@ __global__ void __launch_bounds__(256, 1) finalize_kernel(const DevParams* __res
         PrepState st;
         BookMeta M;
         prepass_begin(c, st, M);
-        prepass_run(c, st, M, k, false);
+        prepass_run<TM>(c, st, M, k, false);
     }
 }
 
@@ -196,6 +197,7 @@ __global__ void __launch_bounds__(256, 1) finalize_kernel(const DevParams* __res
 // `track_len` entries per book, and every few steps this kernel lets every book's pre-pass run on from
 // where it stopped until the ring is full again -- up to LOB_TRACK_MARGIN entries short of overwriting
 // what the agent side may still look at (events k - 2 .. k).
+template <int TM>
 __global__ void __launch_bounds__(64) prepass_extend_kernel(const DevParams* __restrict__ Pp, DevState S) {
     const DevParams& P = *Pp;
     __shared__ TickLds tick_lds;
@@ -208,7 +210,7 @@ __global__ void __launch_bounds__(64) prepass_extend_kernel(const DevParams* __r
     PrepState st = S.prep[b];
     if (st.k >= k_stop) return;
     EnvCtx c(P, S, b, &tick_lds);
-    prepass_run(c, st, M, k_stop, true);
+    prepass_run<TM>(c, st, M, k_stop, true);
     S.meta[b] = M;
     S.prep[b] = st;
 }
