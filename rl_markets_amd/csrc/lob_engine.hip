@@ -53,6 +53,9 @@ struct lob_engine {
     bool chunked = false;       // the loaded stream is longer than the ring
     int steps_since_fill = 0;
     uint64_t theta_ver = 1;     // bumped whenever theta changes: memo records carry the version they were computed under
+    bool hits_ok = false;       // the previous call was a fast-path learner step and nothing has touched weights, maps or states since:
+                                // the hit lists its learn kernel left are those of the States the next step acts on (act_light_kernel)
+    bool light = true;          // use them (LOB_NO_LIGHT=1: always the full act kernel, for A/B runs)
     std::vector<void*> allocs;
     uint32_t* rnd_dev = nullptr;
     uint32_t* records_dev = nullptr;
@@ -251,6 +254,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     if (const char* g = getenv("LOB_TRACK_RING")) { int v = atoi(g); if (v >= 256 && v <= (1 << 20) && (v & (v - 1)) == 0) e->track_ring = v; }
     if (const char* g = getenv("LOB_TRACK_REFILL")) { int v = atoi(g); if (v >= 1) e->track_refill = v; }
     if (const char* g = getenv("LOB_ACC_LANES")) { int v = atoi(g); if (v == 8 || v == 16 || v == 32 || v == 64) e->acc_shift = v == 8 ? 3 : v == 16 ? 4 : v == 32 ? 5 : 6; }
+    if (const char* g = getenv("LOB_NO_LIGHT")) e->light = !(g[0] == '1');
     if (const char* g = getenv("LOB_RESET_LANES")) { int v = atoi(g); if (v == 16 || v == 32 || v == 64) e->reset_lanes = v; }
 
     // ---- DevParams ----
@@ -382,6 +386,11 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
         if (rc == LOB_OK) rc = dev_alloc(e, &S.theta_nzc, (size_t)P.cwords4 * 4);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.slow_list, 2 * B);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.slow_n, 4);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.hl_ent, P.memo ? (size_t)LOB_HL_CAP * B : 1);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.hl_n, B);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.hl_dirty, 1);
+        if (rc == LOB_OK && hipMemsetAsync(S.hl_n, 0xff, B * 4, e->stream) != hipSuccess) rc = LOB_EHIP;
+        if (rc == LOB_OK && hipMemsetAsync(S.hl_dirty, 0xff, 4, e->stream) != hipSuccess) rc = LOB_EHIP;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) e->n_cus = prop.multiProcessorCount;
         if (P.memo) {
@@ -635,6 +644,7 @@ int lob_reset(lob_engine* e) {
     e->was_reset = true;
     e->episode_open = true;
     e->steps_since_fill = 0;
+    e->hits_ok = false;
     return check_device_errors(e);
 }
 
@@ -654,6 +664,7 @@ int lob_step(lob_engine* e, const int32_t* host_actions) {
     HIPCHK(hipMemcpyAsync(e->actions_dev, host_actions, (size_t)e->B * 4, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemsetAsync(e->S.mk_count, 0, 2 * sizeof(i32), e->stream));  // claims of this step go on a fresh list (nobody evaluates it)
     e->step_id++;
+    e->hits_ok = false;
     {
         TimedLaunch t(e, "env_kernel");
         launch_env(e, e->stream, (const i32*)e->actions_dev, 0, 0, e->B, 0);
@@ -711,6 +722,7 @@ int lob_clear_inventory(lob_engine* e) {
     if (rc) return rc;
     HIPCHK(hipSetDevice(e->device));
     hipLaunchKernelGGL(clear_inventory_kernel, dim3(grid_lanes(e->B)), dim3(256), 0, e->stream, (const DevParams*)e->P_dev, e->S);
+    e->hits_ok = false;
     HIPCHK(hipGetLastError());
     return check_device_errors(e);
 }
@@ -773,7 +785,10 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode) {
             if (fast) {
                 {
                     TimedLaunch t(e, "act_kernel", st);
-                    hipLaunchKernelGGL(act_fast_kernel<LOB_FAST_NB>, dim3(gf), dim3(LOB_FAST_BLOCK), fast_lds_bytes(e->P.cwords4, LOB_FAST_NB, false), st, e->P, e->S, rnd, mode, par, lpar, ver);
+                    if (mode == 0 && e->hits_ok && e->light)
+                        hipLaunchKernelGGL(act_light_kernel, dim3((nb + LOB_LIGHT_BLOCK - 1) / LOB_LIGHT_BLOCK), dim3(LOB_LIGHT_BLOCK), 0, st, e->P, e->S, par, lpar, ver, e->step_id - 1);
+                    else
+                        hipLaunchKernelGGL(act_fast_kernel<LOB_FAST_NB>, dim3(gf), dim3(LOB_FAST_BLOCK), fast_lds_bytes(e->P.cwords4, LOB_FAST_NB, false), st, e->P, e->S, rnd, mode, par, lpar, ver);
                 }
                 {
                     TimedLaunch t(e, "act_rest_kernel", st);
@@ -823,21 +838,22 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode) {
                 TimedLaunch t(e, "accumulate_kernel");
                 const int sh = acc_lanes_shift(e);
                 const int waves = (e->B + (64 >> sh) - 1) / (64 >> sh);
-                hipLaunchKernelGGL(accumulate_kernel, dim3((waves + LOB_WAVES_PER_BLOCK - 1) / LOB_WAVES_PER_BLOCK), dim3(LOB_BLOCK), 0, e->stream, e->P, e->S, par, sh);
+                hipLaunchKernelGGL(accumulate_kernel, dim3((waves + LOB_WAVES_PER_BLOCK - 1) / LOB_WAVES_PER_BLOCK), dim3(LOB_BLOCK), 0, e->stream, e->P, e->S, par, sh, e->step_id);
             }
             {
                 TimedLaunch t(e, "apply_kernel");
                 const int blocks = std::min(2048, std::max(1, (e->S.cb_slots + 3) / 4));
-                hipLaunchKernelGGL(apply_kernel, dim3(blocks), dim3(256), 0, e->stream, e->P, e->S, par);
+                hipLaunchKernelGGL(apply_kernel, dim3(blocks), dim3(256), 0, e->stream, e->P, e->S, par, e->step_id);
             }
         } else if (mode == 0) {
             TimedLaunch t(e, "update_kernel");
-            hipLaunchKernelGGL(update_kernel, dim3(grid_waves(e->B)), dim3(LOB_BLOCK), 0, e->stream, e->P, e->S, par);
+            hipLaunchKernelGGL(update_kernel, dim3(grid_waves(e->B)), dim3(LOB_BLOCK), 0, e->stream, e->P, e->S, par, e->step_id);
         }
         if (mode == 0) {
             e->theta_ver++;                          // theta_{t+1}
             if (e->P.memo) launch_memo(e, par, 1);   // the same triples again, for the next act_kernel
         }
+        e->hits_ok = mode == 0 && fast;              // learn_q_fast_kernel has left the hit lists of the States the next step acts on
         maybe_refill_track(e);
     }
     HIPCHK(hipGetLastError());
@@ -927,10 +943,11 @@ int lob_theta_set(lob_engine* e, int32_t which, const double* host_in, int64_t c
         HIPCHK(hipMemcpyAsync(sync, th, (size_t)count * 8, hipMemcpyDeviceToDevice, e->stream));
     }
     e->theta_ver++;  // memo records computed under the old weights are void
+    e->hits_ok = false;
     hipLaunchKernelGGL(rebuild_nz_kernel, dim3(1024), dim3(256), 0, e->stream, (const f64*)th, nz, e->S.nz_epoch, e->P.M);
     if (e->P.memo && th == e->S.theta) {
-        HIPCHK(hipMemsetAsync(e->S.theta_nzx, 0, ((size_t)e->P.M / 32 + 1) * 4, e->stream));
-        HIPCHK(hipMemsetAsync(e->S.theta_nzc, 0, (size_t)e->P.cwords4 * 16, e->stream));
+        // the maps keep the bits they have (monotone: the tiles of live trace generations stay marked, whatever the
+        // loaded value of their weights -- a set bit only means "fetch the weight") and gain those of the loaded non-zeros
         hipLaunchKernelGGL(rebuild_nzx_kernel, dim3(2048), dim3(256), 0, e->stream, (const f64*)th, e->S.theta_nzx, e->S.theta_nzc, e->P.cshift, e->P.M);
         launch_memo(e, e->last_par, 1);  // the current triples under the loaded weights: the next act stays on the fast path
     }
@@ -1067,6 +1084,7 @@ int lob_delta_apply(lob_engine* e) {
     const size_t M = (size_t)e->P.M;
     const int nv = delta_vectors(e);
     e->theta_ver++;  // memo records computed under the pre-exchange weights are void
+    e->hits_ok = false;
     for (int v = 0; v < nv; v++) {
         TimedLaunch t(e, "delta_apply_kernel", nullptr, true);
         hipLaunchKernelGGL(delta_apply_kernel, dim3(2048), dim3(256), 0, e->stream, v ? e->S.theta_b : e->S.theta, e->S.theta_sync + v * M,
@@ -1121,6 +1139,21 @@ extern "C" int lob_debug_prof(lob_engine* e, int64_t out[LOB_PROF_N]) {
     for (int i = 0; i < LOB_PROF_N; i++) out[i] = 0;
     for (size_t b = 0; b < (size_t)e->B; b++)
         for (int i = 0; i < LOB_PROF_N; i++) out[i] += h[b * LOB_PROF_N + i];
+    return LOB_OK;
+}
+
+// Diagnostics (not part of include/lob_engine.h): books whose action came from act_light_kernel so far, and the step id of
+// the last update that voided the hit lists (-1: never).
+extern "C" int lob_debug_light(lob_engine* e, int64_t out[2]) {
+    if (!e || !out) return LOB_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    i64 c[8];
+    i32 d = 0;
+    HIPCHK(hipMemcpyAsync(c, e->S.counters, sizeof c, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(&d, e->S.hl_dirty, sizeof d, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    out[0] = c[5];
+    out[1] = d;
     return LOB_OK;
 }
 

@@ -104,9 +104,12 @@ __device__ __forceinline__ uint32_t fast_base(const DevParams& P, int qv, int la
 // look-ups per book and a CU holds only 16 waves (the LDS image), so the parallelism has to come from
 // inside the wave.  No branches on per-book conditions in here: a book that is not `go` computes on
 // whatever its (valid) inputs are and its result is ignored by the caller.
-template <int NB>
+// WR: also return, per lane, the tile indices and which of them fall on a marked weight (`o_hit[k]` bit a), for
+// hit_list_write below.
+template <int NB, bool WR>
 __device__ __forceinline__ void q_values_fast(const DevParams& P, const DevState& S, const FastLds& L, const int* qv, int lane,
-                                              const MemoRec* rec, f64 (*out_q)[LOB_N_ACTIONS], Prof& pf, int pf0) {
+                                              const MemoRec* rec, f64 (*out_q)[LOB_N_ACTIONS], Prof& pf, int pf0,
+                                              i32 (*o_idx)[LOB_N_ACTIONS] = nullptr, uint32_t* o_hit = nullptr) {
     const bool hi = lane >= 32;
     const uint32_t M = (uint32_t)P.M;
     uint32_t sum[NB];
@@ -141,6 +144,14 @@ __device__ __forceinline__ void q_values_fast(const DevParams& P, const DevState
     for (int k = 0; k < NB; k++)
 #pragma unroll
         for (int a = 0; a < LOB_N_ACTIONS; a++) out_q[k][a] = rec[k].s0[a];
+    if (WR) {
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            o_hit[k] = 0;
+#pragma unroll
+            for (int a = 0; a < LOB_N_ACTIONS; a++) o_idx[k][a] = idx[k][a];
+        }
+    }
     if (__ballot(any_maybe) == 0) { pf.mark(pf0 + 2); return; }
     uint32_t hit[NB];
     bool any_hit = false;
@@ -164,6 +175,10 @@ __device__ __forceinline__ void q_values_fast(const DevParams& P, const DevState
     const bool none = __ballot(any_hit) == 0;
     pf.mark(pf0 + 2);  // exact map for the coarse hits
     if (none) return;
+    if (WR) {
+#pragma unroll
+        for (int k = 0; k < NB; k++) o_hit[k] = hit[k];
+    }
     // A lane rarely has more than one written weight among its 9 x NB tiles: fetch the first two of each
     // book up front (in flight together), anything beyond that on demand.
     const f64 w1 = P.w1, w2 = P.w2;
@@ -201,6 +216,43 @@ __device__ __forceinline__ void q_values_fast(const DevParams& P, const DevState
         }
     }
     pf.mark(pf0 + 3);  // written weights + ordered continuation
+}
+
+// The hit lists of NB books (lob_state.h) from what q_values_fast<NB, true> returned.  Order of the additions for
+// action a: group-1 tilings ascending with w1, the same again with w2, group-2 tilings ascending with w2 -- whether
+// or not the weight is non-zero YET: it is marked, the next update may write it.  `wr_b[k]`: the book, or -1.
+template <int NB>
+__device__ __forceinline__ void hit_list_write(const DevState& S, int lane, const i32 (*idx)[LOB_N_ACTIONS], const uint32_t* hit, const int* wr_b) {
+    const bool hi = lane >= 32;
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+        if (wr_b[k] < 0) continue;  // wave-uniform
+        int cnt = 0;                // (wave-uniform) additions listed so far
+        u64* dst = S.hl_ent + (size_t)wr_b[k];
+        if (__ballot(hit[k] != 0) != 0) {
+#pragma unroll
+            for (int a = 0; a < LOB_N_ACTIONS; a++) {
+                const bool mine = (hit[k] >> a) & 1u;
+                const u64 mb = __ballot(mine);
+                if (mb == 0) continue;
+                const uint32_t lo = (uint32_t)mb, hi_m = (uint32_t)(mb >> 32);
+                const int nlo = __builtin_popcount(lo);
+                if (mine) {
+                    const u64 ent = (u64)(uint32_t)idx[k][a] | ((u64)a << 32);
+                    if (!hi) {
+                        const int p1 = cnt + __builtin_popcount(lo & ((1u << lane) - 1u)), p2 = p1 + nlo;
+                        if (p1 < LOB_HL_CAP) dst[(uint32_t)p1 * (uint32_t)S.B] = ent;
+                        if (p2 < LOB_HL_CAP) dst[(uint32_t)p2 * (uint32_t)S.B] = ent | (1ull << 36);
+                    } else {
+                        const int p = cnt + 2 * nlo + __builtin_popcount(hi_m & ((1u << (lane - 32)) - 1u));
+                        if (p < LOB_HL_CAP) dst[(uint32_t)p * (uint32_t)S.B] = ent | (1ull << 36);
+                    }
+                }
+                cnt += 2 * nlo + __builtin_popcount(hi_m);
+            }
+        }
+        if (lane == 0) S.hl_n[wr_b[k]] = cnt <= LOB_HL_CAP ? cnt : -1;
+    }
 }
 
 // Does the memo record `rec` of slot `mslot` (`ident` its triple) belong to the State whose quantised
@@ -282,7 +334,7 @@ __global__ void __launch_bounds__(LOB_FAST_BLOCK) act_fast_kernel(DevParams P, D
             if (go[k] && !fast_memo_ok(mslot[k], mid[k], rec[k], ver, qv[k])) { fast_hand_back(S, 0, lpar, b[k], lane); go[k] = false; }
         pf.mark(0);  // header, memo record, state variables
         f64 qs[NB][LOB_N_ACTIONS];
-        q_values_fast<NB>(P, S, L, qv, lane, rec, qs, pf, 1);
+        q_values_fast<NB, false>(P, S, L, qv, lane, rec, qs, pf, 1);
 #pragma unroll
         for (int k = 0; k < NB; k++) {
             if (!go[k]) continue;
@@ -299,6 +351,74 @@ __global__ void __launch_bounds__(LOB_FAST_BLOCK) act_fast_kernel(DevParams P, D
         }
         pf.mark(5);  // policy + stores
     }
+}
+
+// The same prologue when every book still has the hit list the previous step's learn_q_fast_kernel left for this very
+// State (lob_state.h): Q(s, a) = the memoised group-0 sum under the new weights + the listed additions, in the listed
+// order.  No tile hashing, no map, no LDS image: one LANE per book.  A book without a (valid) list, whose memo record is
+// not of this weight version, or -- never in the steady state -- every book after an update set a map bit that the trace
+// kernel had not (`hl_dirty`), goes to the general kernel through the work list, like act_fast_kernel's hand-backs.
+#define LOB_LIGHT_BLOCK 256
+__global__ void __launch_bounds__(LOB_LIGHT_BLOCK) act_light_kernel(DevParams P, DevState S, int par, int lpar, u64 ver, int sid_prev) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        S.cb_count[0] = 0;    // (as act_fast_kernel)
+        S.mk_count[par] = 0;
+        S.slow_n[(lpar ^ 1) * 2 + 0] = 0;
+        S.slow_n[(lpar ^ 1) * 2 + 1] = 0;
+    }
+    const int b = blockIdx.x * LOB_LIGHT_BLOCK + threadIdx.x;
+    if (b >= S.B) return;
+    const bool dirty = S.hl_dirty[0] == sid_prev;
+    const LHdr h = S.hdr[b];
+    LHdr* hp = S.hdr + b;
+    const int n = S.hl_n[b];
+    const int mslot = S.mk_slot[b];
+    const int cur = h.slot_cur ^ 1;  // swap(state, last_state)
+    if (h.done) { hp->stepped = 0; return; }
+    if (!is_open(P, h.time_ms)) {  // environment.isTerminal()
+        hp->slot_cur = cur; hp->done = 1; hp->stepped = 0; S.done[b] = 1;
+        return;
+    }
+    bool ok = !dirty && !((h.zero_mask >> (cur ^ 1)) & 1) && mslot >= 0 && n >= 0;
+    f64 q[LOB_N_ACTIONS];
+    if (ok) {
+        const MemoRec rec = *reinterpret_cast<const MemoRec*>(S.mk_rec + ((size_t)S.mk_slots + mslot) * LOB_MK_REC);  // [1]: after the last update
+        ok = rec.ver == ver;
+#pragma unroll
+        for (int a = 0; a < LOB_N_ACTIONS; a++) q[a] = rec.s0[a];
+    }
+    if (!ok) {
+        const int pos = atomicAdd(&S.slow_n[lpar * 2 + 0], 1);
+        S.slow_list[pos] = b;
+        return;
+    }
+    const f64 w1 = P.w1, w2 = P.w2;
+    for (int i0 = 0; i0 < n; i0 += 4) {
+        u64 ent[4];
+        f64 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) ent[u] = i0 + u < n ? S.hl_ent[(size_t)(i0 + u) * S.B + b] : 0ull;
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = i0 + u < n ? S.theta[(uint32_t)ent[u]] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (v[u] == 0.0) continue;  // (+0.0 added to a sum that is never -0.0)
+            const int a = (int)(ent[u] >> 32) & 15;
+            const f64 x = ((ent[u] >> 36) & 1ull ? w2 : w1) * v[u];
+#pragma unroll
+            for (int c = 0; c < LOB_N_ACTIONS; c++) q[c] = a == c ? q[c] + x : q[c];
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < LOB_N_ACTIONS; a++) S.qs_last[(size_t)b * LOB_N_ACTIONS + a] = q[a];
+    Rng g{P.seed, P.book_id_offset + (u64)b, h.rng_ctr};
+    const int action = policy_sample(P, q, false, g);
+    hp->slot_cur = cur;
+    hp->action = action;
+    hp->stepped = 1;
+    hp->rng_ctr = g.ctr;
+    const u64 act = __ballot(1);
+    if ((int)(threadIdx.x & 63) == __builtin_ctzll(act)) atomicAdd((unsigned long long*)&S.counters[5], (unsigned long long)__builtin_popcountll(act));
 }
 
 // Agent::UpdateTraces for every book that stepped (learn_traces), the first half of learn_book; leaves
@@ -382,14 +502,14 @@ __global__ void __launch_bounds__(LOB_FAST_BLOCK) learn_q_fast_kernel(DevParams 
         asm volatile("" : "+v"(lane_));
         const int lane = lane_;
         int b[NB], mslot[NB];
-        bool go[NB];
+        bool go[NB], real[NB];
         LHdr h[NB];
         f32 vv[NB];
         Prof pf;
 #pragma unroll
         for (int k = 0; k < NB; k++) {
             const int t = __builtin_amdgcn_readfirstlane(t0 + k * stride);
-            go[k] = t < S.B;
+            go[k] = real[k] = t < S.B;
             b[k] = go[k] ? t : 0;
             h[k] = S.hdr[b[k]];
             mslot[k] = S.mk_slot[b[k]];
@@ -417,13 +537,23 @@ __global__ void __launch_bounds__(LOB_FAST_BLOCK) learn_q_fast_kernel(DevParams 
             if (go[k] && !fast_memo_ok(mslot[k], mid[k], rec[k], ver, qv[k])) { fast_hand_back(S, 1, lpar, b[k], lane); go[k] = false; }
         pf.mark(13);  // header, memo record, state variables
         f64 qs[NB][LOB_N_ACTIONS];
-        q_values_fast<NB>(P, S, L, qv, lane, rec, qs, pf, 14);
+        int wr_b[NB];
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            wr_b[k] = go[k] ? b[k] : -1;
+            if (!go[k] && real[k] && lane == 0) S.hl_n[b[k]] = -1;  // no list: the next act takes the general path for this book
+        }
+        i32 tidx[NB][LOB_N_ACTIONS];
+        uint32_t thit[NB];
+        q_values_fast<NB, true>(P, S, L, qv, lane, rec, qs, pf, 14, tidx, thit);
 #pragma unroll
         for (int k = 0; k < NB; k++) {
             if (!go[k]) continue;
             Rng g{P.seed, P.book_id_offset + (u64)b[k], h[k].rng_ctr};
             learn_delta_single<ALGO>(P, S.hdr + b[k], h[k], qs[k], h[k].td, g, lane);
         }
+        asm volatile("" ::: "memory");  // (the lists after everything else: the Q values' registers are free by now)
+        hit_list_write<NB>(S, lane, tidx, thit, wr_b);
         pf.mark(19);  // argmax / delta / header stores
     }
 }

@@ -627,6 +627,22 @@ __device__ inline i32 sel5(const i32* f, int k) {
     return r;
 }
 
+// Weight f of the shared theta is (about to be) written for the first time: the exact map and its coarse image
+// (lob_fast.h); monotone bits.  True if this call set the exact bit.
+__device__ inline bool nzx_mark(const DevParams& P, const DevState& S, i32 f) {
+    const uint32_t xb = 1u << ((uint32_t)f & 31);
+    if (S.theta_nzx[(uint32_t)f >> 5] & xb) return false;
+    const uint32_t old = atomicOr(&S.theta_nzx[(uint32_t)f >> 5], xb);
+    const uint32_t c = (uint32_t)f >> P.cshift;
+    const uint32_t cb = 1u << (c & 31);
+    if (!(S.theta_nzc[c >> 5] & cb)) atomicOr(&S.theta_nzc[c >> 5], cb);
+    return !(old & xb);
+}
+// ... after the learn kernels of step `sid` have looked at the maps: the hit lists they left are void (lob_state.h)
+__device__ inline void nzx_mark_late(const DevParams& P, const DevState& S, i32 f, int sid) {
+    if (nzx_mark(P, S, f)) S.hl_dirty[0] = sid;
+}
+
 // per-wave set of the current group-0 tiles (learn_traces): LOB_TSLOTS 32-bit slots in the wave's 4 KB of LDS
 #define LOB_TSLOTS 1024
 #define LOB_NOTILE 0xffffffffu /* tile indices are < M < 2^31 */
@@ -793,6 +809,10 @@ __device__ __forceinline__ void learn_traces(const DevParams& P, const DevState&
         const int nh = (head + 1) & (G - 1);
         const u64 m = __ballot(!dead && half == 0);
         if (half == 0) tr_idx[nh * 32 + j] = N;
+        // fast path: the tiles this generation will write are marked in the written-weights maps NOW, before the
+        // learn kernel evaluates Q(s', .) -- the set of group-1/2 tiles of s' that fall on a marked weight is then
+        // the same for that evaluation and for the next step's action selection (hit lists, lob_state.h)
+        if (P.memo && half == 0 && !dead) nzx_mark(P, S, N);
         if (lane == 0) {
             tr_alive[nh] = (uint32_t)m;
             hp->tr_head = nh;
@@ -973,19 +993,8 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
     }
 }
 
-// First write of weight f of the shared theta: the exact map and its coarse image (lob_fast.h); monotone bits.
-__device__ inline void nzx_mark(const DevParams& P, const DevState& S, i32 f) {
-    const uint32_t xb = 1u << ((uint32_t)f & 31);
-    if (!(S.theta_nzx[(uint32_t)f >> 5] & xb)) {
-        atomicOr(&S.theta_nzx[(uint32_t)f >> 5], xb);
-        const uint32_t c = (uint32_t)f >> P.cshift;
-        const uint32_t cb = 1u << (c & 31);
-        if (!(S.theta_nzc[c >> 5] & cb)) atomicOr(&S.theta_nzc[c >> 5], cb);
-    }
-}
-
 // Agent::updateQ (agent.cpp:137-142): theta[f] += (alpha*delta / N_TILINGS) * e[f]
-__global__ void __launch_bounds__(LOB_BLOCK) update_kernel(DevParams P, DevState S, int par) {
+__global__ void __launch_bounds__(LOB_BLOCK) update_kernel(DevParams P, DevState S, int par, int sid) {
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b = __builtin_amdgcn_readfirstlane(blockIdx.x * LOB_WAVES_PER_BLOCK + w);
     if (b >= S.B) return;
@@ -1021,7 +1030,7 @@ __global__ void __launch_bounds__(LOB_BLOCK) update_kernel(DevParams P, DevState
                 const f64 val = scaled * (f64)P.trace_pow[c0 + 2 * it + half];
                 __hip_atomic_fetch_add(&theta[f[it]], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 word[it] = nz[LOB_NZ_WORD(f[it])];
-                if (P.memo && h.stepped != 2) nzx_mark(P, S, f[it]);
+                if (P.memo && h.stepped != 2) nzx_mark_late(P, S, f[it], sid);
             }
         }
 #pragma unroll
@@ -1049,7 +1058,7 @@ __global__ void __launch_bounds__(LOB_BLOCK) update_kernel(DevParams P, DevState
 // update_kernel does.  Watkins's Q(lambda) leaves 1-2 live generations per book at exploration rates
 // near 1, so a whole wave per book is a chain of four dependent look-ups run 65 536 times for two lanes of
 // work; 8 books per wave run the same chain 8 192 times.
-__global__ void __launch_bounds__(LOB_BLOCK) accumulate_kernel(DevParams P, DevState S, int par, int lpb_shift) {
+__global__ void __launch_bounds__(LOB_BLOCK) accumulate_kernel(DevParams P, DevState S, int par, int lpb_shift, int sid) {
     const int lane = threadIdx.x & 63;
     const int lpb = 1 << lpb_shift, sub = lane & (lpb - 1);
     const int wave = blockIdx.x * LOB_WAVES_PER_BLOCK + (threadIdx.x >> 6);
@@ -1115,7 +1124,7 @@ __global__ void __launch_bounds__(LOB_BLOCK) accumulate_kernel(DevParams P, DevS
             if (lane < 32 && ((m >> j) & 1u)) {
                 const i32 f = S.tr_idx[((size_t)d_b * G + sl) * 32 + j];
                 __hip_atomic_fetch_add(&theta[f], d_scaled * (f64)P.trace_pow[d_age], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (P.memo && !d_t) nzx_mark(P, S, f);
+                if (P.memo && !d_t) nzx_mark_late(P, S, f, sid);
                 const uint32_t bit = LOB_NZ_BIT(f);
                 if (!(nz[LOB_NZ_WORD(f)] & bit)) {
                     const uint32_t old = atomicOr(&nz[LOB_NZ_WORD(f)], bit);
@@ -1132,7 +1141,7 @@ __global__ void __launch_bounds__(LOB_BLOCK) accumulate_kernel(DevParams P, DevS
 
 // apply_kernel: one wave per claimed slot: theta[tile] += summed update for the live tiles of the
 // representative generation, maintain the written-weights map and the carry-over filter, free the slot.
-__global__ void __launch_bounds__(256) apply_kernel(DevParams P, DevState S, int par) {
+__global__ void __launch_bounds__(256) apply_kernel(DevParams P, DevState S, int par, int sid) {
     const int lane = threadIdx.x & 63, j = lane & 31;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
     const int count = S.cb_count[0];
@@ -1150,7 +1159,7 @@ __global__ void __launch_bounds__(256) apply_kernel(DevParams P, DevState S, int
             f64* theta = t ? S.theta_b : S.theta;
             uint32_t* nz = t ? S.theta_b_nz : S.theta_nz;
             __hip_atomic_fetch_add(&theta[f], t ? v1 : v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (P.memo && !t) nzx_mark(P, S, f);
+            if (P.memo && !t) nzx_mark_late(P, S, f, sid);
             const uint32_t bit = LOB_NZ_BIT(f);
             if (!(nz[LOB_NZ_WORD(f)] & bit)) {
                 const uint32_t old = atomicOr(&nz[LOB_NZ_WORD(f)], bit);

@@ -559,6 +559,72 @@ def test_group0_memo_on_off_identical(monkeypatch, algo):
     np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-9, atol=1e-12)
 
 
+def _light_counts(eng):
+    """(books whose action came from act_light_kernel so far, step id of the last update that voided the hit lists)"""
+    import ctypes
+    out = (ctypes.c_int64 * 2)()
+    eng.lib.lob_debug_light.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)]
+    assert eng.lib.lob_debug_light(eng.h, out) == 0
+    return int(out[0]), int(out[1])
+
+
+@pytest.mark.parametrize("algo", [abi.ALGO_SARSA, abi.ALGO_QLAMBDA])
+@pytest.mark.parametrize("mem", [1 << 12, 1 << 16, 1 << 22])
+def test_hit_list_carry_on_off_identical(monkeypatch, algo, mem):
+    """learn_q_fast_kernel leaves, per book, the ordered list of additions beyond the memoised group-0 sum;
+    the next step's act_light_kernel replays it under the new weights instead of hashing and filtering the
+    576 group-1/2 tiles again (the trace kernel marks a new generation's tiles before the learn kernel
+    looks, so the set of tiles on a marked weight cannot change in between).  LOB_NO_LIGHT=1 keeps the full
+    act kernel: everything must agree bit for bit except theta's f64 atomic ordering -- across evaluation
+    steps, external actions, weight loads, a second episode.  Table sizes: 4 096 and 65 536 weights (most
+    lists overflow: general path), 4 M (short lists: the light path serves nearly every book)."""
+    B = 96
+    out = []
+    for off in ("1", "0"):
+        monkeypatch.setenv("LOB_NO_LIGHT", off)
+        p, g, rec, eng, orc = make(depth=5, n_events=700, B=B, algo=algo, theta_mode=abi.THETA_SHARED, mem=mem, epsilon=0.3)
+        orc.close()
+        eng.reset()
+        trail = []
+        rng = np.random.default_rng(23)
+        for phase in range(3):
+            for n in (1, 1, 3, 1, 7, 12):
+                eng.td_step(n)
+                trail.append((eng.last_actions().copy(), eng.last_td().copy(), bytes(eng.get_books())))
+            eng.eval_step(2)
+            trail.append((eng.last_actions().copy(), None, bytes(eng.get_books())))
+            eng.td_step(4)
+            trail.append((eng.last_actions().copy(), eng.last_td().copy(), bytes(eng.get_books())))
+            eng.step(rng.integers(0, 9, size=B).astype(np.int32))
+            eng.td_step(3)
+            th = eng.theta()
+            th[rng.integers(0, th.size, size=50)] += 1e-3
+            if phase == 1:
+                th[:] = 0.0  # every written weight back to +0.0: the maps must not forget the live traces' tiles
+            eng.set_theta(th)
+            eng.td_step(5)
+            trail.append((eng.last_actions().copy(), eng.last_td().copy(), bytes(eng.get_books())))
+        eng.clear_inventory()
+        eng.handle_terminal()
+        eng.reset()
+        for _ in range(20):
+            eng.td_step(1)
+            trail.append((eng.last_actions().copy(), eng.last_td().copy(), bytes(eng.get_books())))
+        light, dirty = _light_counts(eng)
+        out.append((trail, eng.theta(), light, dirty))
+        eng.close()
+    assert out[0][2] == 0, "LOB_NO_LIGHT=1 must never launch act_light_kernel"
+    assert out[1][3] == -1, "an update set a map bit the trace kernel had not: step %d" % out[1][3]
+    if mem >= 1 << 22:
+        assert out[1][2] > 40 * B, "the light path was hardly used: %d book-steps" % out[1][2]
+    for k, ((a0, t0, b0), (a1, t1, b1)) in enumerate(zip(out[0][0], out[1][0])):
+        np.testing.assert_array_equal(a0, a1, err_msg="actions, record %d" % k)
+        assert b0 == b1, "books differ at record %d" % k
+        if t0 is not None:
+            np.testing.assert_allclose(t0, t1, rtol=1e-9, atol=1e-12, err_msg="td, record %d" % k)
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-9, atol=1e-12)
+
+
 # ---- long streams: the market track as a ring, refilled while the episode runs ------------------------
 @pytest.mark.parametrize("ring,refill", [(256, 8), (512, 40)])
 def test_long_streams_use_a_track_ring(monkeypatch, ring, refill):
