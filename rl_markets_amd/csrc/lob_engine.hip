@@ -386,10 +386,9 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
         if (rc == LOB_OK) rc = dev_alloc(e, &S.theta_nzc, (size_t)P.cwords4 * 4);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.slow_list, 2 * B);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.slow_n, 4);
-        if (rc == LOB_OK) rc = dev_alloc(e, &S.hl_ent, P.memo ? (size_t)LOB_HL_CAP * B : 1);
-        if (rc == LOB_OK) rc = dev_alloc(e, &S.hl_n, B);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.hl_rec, P.memo ? (size_t)LOB_HL_REC * B : 1);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.hl_dirty, 1);
-        if (rc == LOB_OK && hipMemsetAsync(S.hl_n, 0xff, B * 4, e->stream) != hipSuccess) rc = LOB_EHIP;
+        if (rc == LOB_OK && hipMemsetAsync(S.hl_rec, 0xff, (P.memo ? (size_t)LOB_HL_REC * B : 1) * 8, e->stream) != hipSuccess) rc = LOB_EHIP;
         if (rc == LOB_OK && hipMemsetAsync(S.hl_dirty, 0xff, 4, e->stream) != hipSuccess) rc = LOB_EHIP;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) e->n_cus = prop.multiProcessorCount;

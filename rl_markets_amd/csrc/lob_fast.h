@@ -104,12 +104,15 @@ __device__ __forceinline__ uint32_t fast_base(const DevParams& P, int qv, int la
 // look-ups per book and a CU holds only 16 waves (the LDS image), so the parallelism has to come from
 // inside the wave.  No branches on per-book conditions in here: a book that is not `go` computes on
 // whatever its (valid) inputs are and its result is ignored by the caller.
-// WR: also return, per lane, the tile indices and which of them fall on a marked weight (`o_hit[k]` bit a), for
-// hit_list_write below.
+// WR: also put each book's hit list (lob_state.h) -- the additions made below, in their order -- into the wave's LDS
+// rows `buf` (NB x LOB_HL_REC u64: the staged state variables are not needed any more) and return the counts
+// (`o_cnt[k]`, above LOB_HL_CAP: no list); hit_list_store sends them to memory.  Order of the additions for action a:
+// group-1 tilings ascending with w1, the same again with w2, group-2 tilings ascending with w2 -- whether or not the
+// weight is non-zero YET: it is marked, the next update may write it.
 template <int NB, bool WR>
 __device__ __forceinline__ void q_values_fast(const DevParams& P, const DevState& S, const FastLds& L, const int* qv, int lane,
                                               const MemoRec* rec, f64 (*out_q)[LOB_N_ACTIONS], Prof& pf, int pf0,
-                                              i32 (*o_idx)[LOB_N_ACTIONS] = nullptr, uint32_t* o_hit = nullptr) {
+                                              u64* buf = nullptr, int* o_cnt = nullptr) {
     const bool hi = lane >= 32;
     const uint32_t M = (uint32_t)P.M;
     uint32_t sum[NB];
@@ -146,11 +149,7 @@ __device__ __forceinline__ void q_values_fast(const DevParams& P, const DevState
         for (int a = 0; a < LOB_N_ACTIONS; a++) out_q[k][a] = rec[k].s0[a];
     if (WR) {
 #pragma unroll
-        for (int k = 0; k < NB; k++) {
-            o_hit[k] = 0;
-#pragma unroll
-            for (int a = 0; a < LOB_N_ACTIONS; a++) o_idx[k][a] = idx[k][a];
-        }
+        for (int k = 0; k < NB; k++) o_cnt[k] = 0;
     }
     if (__ballot(any_maybe) == 0) { pf.mark(pf0 + 2); return; }
     uint32_t hit[NB];
@@ -175,10 +174,6 @@ __device__ __forceinline__ void q_values_fast(const DevParams& P, const DevState
     const bool none = __ballot(any_hit) == 0;
     pf.mark(pf0 + 2);  // exact map for the coarse hits
     if (none) return;
-    if (WR) {
-#pragma unroll
-        for (int k = 0; k < NB; k++) o_hit[k] = hit[k];
-    }
     // A lane rarely has more than one written weight among its 9 x NB tiles: fetch the first two of each
     // book up front (in flight together), anything beyond that on demand.
     const f64 w1 = P.w1, w2 = P.w2;
@@ -199,10 +194,26 @@ __device__ __forceinline__ void q_values_fast(const DevParams& P, const DevState
 #pragma unroll
     for (int k = 0; k < NB; k++) {
         if (__ballot(hit[k] != 0) == 0) continue;
+        int cnt = 0;  // (wave-uniform) additions listed so far
 #pragma unroll
         for (int a = 0; a < LOB_N_ACTIONS; a++) {
             const bool mine = (hit[k] >> a) & 1u;
-            if (__ballot(mine) == 0) continue;
+            const u64 mb = __ballot(mine);
+            if (mb == 0) continue;
+            if (WR) {
+                const uint32_t lo = (uint32_t)mb, hi_m = (uint32_t)(mb >> 32);
+                const int nlo = __builtin_popcount(lo), nhi = __builtin_popcount(hi_m);
+                // entries below this lane's among the action's: lanes < 32 come first (twice), then lanes >= 32
+                const int below = (int)__builtin_amdgcn_mbcnt_hi(hi_m, __builtin_amdgcn_mbcnt_lo(lo, 0u));  // set bits of mb below this lane
+                const int p = cnt + (hi ? nlo + below : below);
+                if (mine) {
+                    u64* row = buf + k * LOB_HL_REC + 1;
+                    const u64 ent = (u64)(uint32_t)idx[k][a] | ((u64)a << 32);
+                    if (p < LOB_HL_CAP) row[p] = hi ? ent | (1ull << 36) : ent;
+                    if (!hi && p + nlo < LOB_HL_CAP) row[p + nlo] = ent | (1ull << 36);
+                }
+                cnt += 2 * nlo + nhi;
+            }
             f64 v = 0.0;
             if (mine) v = a0[k] == a ? v0[k] : (a1[k] == a ? v1[k] : S.theta[idx[k][a]]);
             const u64 m = __ballot(v != 0.0);
@@ -214,44 +225,22 @@ __device__ __forceinline__ void q_values_fast(const DevParams& P, const DevState
             for (uint32_t mm = (uint32_t)(m >> 32); mm; mm &= mm - 1) q += w2 * readlane_f64(v, 32 + __builtin_ctz(mm));
             out_q[k][a] = q;
         }
+        if (WR) o_cnt[k] = cnt;
     }
     pf.mark(pf0 + 3);  // written weights + ordered continuation
 }
 
-// The hit lists of NB books (lob_state.h) from what q_values_fast<NB, true> returned.  Order of the additions for
-// action a: group-1 tilings ascending with w1, the same again with w2, group-2 tilings ascending with w2 -- whether
-// or not the weight is non-zero YET: it is marked, the next update may write it.  `wr_b[k]`: the book, or -1.
+// The hit lists q_values_fast<NB, true> left in the wave's LDS rows leave as ONE coalesced store of at most 192 bytes
+// per book; `wr_b[k]`: the book, or -1.
+#define LOB_HL_NONE (~0ull)
 template <int NB>
-__device__ __forceinline__ void hit_list_write(const DevState& S, int lane, const i32 (*idx)[LOB_N_ACTIONS], const uint32_t* hit, const int* wr_b) {
-    const bool hi = lane >= 32;
+__device__ __forceinline__ void hit_list_store(const DevState& S, int lane, const int* cnt, const int* wr_b, const u64* buf) {
+    wave_lds_fence();
 #pragma unroll
     for (int k = 0; k < NB; k++) {
         if (wr_b[k] < 0) continue;  // wave-uniform
-        int cnt = 0;                // (wave-uniform) additions listed so far
-        u64* dst = S.hl_ent + (size_t)wr_b[k];
-        if (__ballot(hit[k] != 0) != 0) {
-#pragma unroll
-            for (int a = 0; a < LOB_N_ACTIONS; a++) {
-                const bool mine = (hit[k] >> a) & 1u;
-                const u64 mb = __ballot(mine);
-                if (mb == 0) continue;
-                const uint32_t lo = (uint32_t)mb, hi_m = (uint32_t)(mb >> 32);
-                const int nlo = __builtin_popcount(lo);
-                if (mine) {
-                    const u64 ent = (u64)(uint32_t)idx[k][a] | ((u64)a << 32);
-                    if (!hi) {
-                        const int p1 = cnt + __builtin_popcount(lo & ((1u << lane) - 1u)), p2 = p1 + nlo;
-                        if (p1 < LOB_HL_CAP) dst[(uint32_t)p1 * (uint32_t)S.B] = ent;
-                        if (p2 < LOB_HL_CAP) dst[(uint32_t)p2 * (uint32_t)S.B] = ent | (1ull << 36);
-                    } else {
-                        const int p = cnt + 2 * nlo + __builtin_popcount(hi_m & ((1u << (lane - 32)) - 1u));
-                        if (p < LOB_HL_CAP) dst[(uint32_t)p * (uint32_t)S.B] = ent | (1ull << 36);
-                    }
-                }
-                cnt += 2 * nlo + __builtin_popcount(hi_m);
-            }
-        }
-        if (lane == 0) S.hl_n[wr_b[k]] = cnt <= LOB_HL_CAP ? cnt : -1;
+        const int n = cnt[k] <= LOB_HL_CAP ? cnt[k] : -1;
+        if (lane <= n || lane == 0) S.hl_rec[(size_t)wr_b[k] * LOB_HL_REC + lane] = lane == 0 ? (n < 0 ? LOB_HL_NONE : (u64)n) : buf[k * LOB_HL_REC + lane];
     }
 }
 
@@ -371,7 +360,9 @@ __global__ void __launch_bounds__(LOB_LIGHT_BLOCK) act_light_kernel(DevParams P,
     const bool dirty = S.hl_dirty[0] == sid_prev;
     const LHdr h = S.hdr[b];
     LHdr* hp = S.hdr + b;
-    const int n = S.hl_n[b];
+    // the first 64 bytes of the book's list -- the count and seven entries, the usual case in full -- with the header
+    const ulonglong2* lp = reinterpret_cast<const ulonglong2*>(S.hl_rec + (size_t)b * LOB_HL_REC);
+    const ulonglong2 l0 = lp[0], l1 = lp[1], l2 = lp[2], l3 = lp[3];
     const int mslot = S.mk_slot[b];
     const int cur = h.slot_cur ^ 1;  // swap(state, last_state)
     if (h.done) { hp->stepped = 0; return; }
@@ -379,6 +370,7 @@ __global__ void __launch_bounds__(LOB_LIGHT_BLOCK) act_light_kernel(DevParams P,
         hp->slot_cur = cur; hp->done = 1; hp->stepped = 0; S.done[b] = 1;
         return;
     }
+    const int n = l0.x == LOB_HL_NONE ? -1 : (int)l0.x;
     bool ok = !dirty && !((h.zero_mask >> (cur ^ 1)) & 1) && mslot >= 0 && n >= 0;
     f64 q[LOB_N_ACTIONS];
     if (ok) {
@@ -393,22 +385,32 @@ __global__ void __launch_bounds__(LOB_LIGHT_BLOCK) act_light_kernel(DevParams P,
         return;
     }
     const f64 w1 = P.w1, w2 = P.w2;
-    for (int i0 = 0; i0 < n; i0 += 4) {
-        u64 ent[4];
-        f64 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) ent[u] = i0 + u < n ? S.hl_ent[(size_t)(i0 + u) * S.B + b] : 0ull;
-#pragma unroll
-        for (int u = 0; u < 4; u++) v[u] = i0 + u < n ? S.theta[(uint32_t)ent[u]] : 0.0;
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            if (v[u] == 0.0) continue;  // (+0.0 added to a sum that is never -0.0)
-            const int a = (int)(ent[u] >> 32) & 15;
-            const f64 x = ((ent[u] >> 36) & 1ull ? w2 : w1) * v[u];
-#pragma unroll
-            for (int c = 0; c < LOB_N_ACTIONS; c++) q[c] = a == c ? q[c] + x : q[c];
-        }
+#define LOB_LIGHT_ADD(ENT, V)                                                              \
+    if ((V) != 0.0) { /* (+0.0 added to a sum that is never -0.0) */                       \
+        const int a_ = (int)((ENT) >> 32) & 15;                                            \
+        const f64 x_ = (((ENT) >> 36) & 1ull ? w2 : w1) * (V);                             \
+        _Pragma("unroll") for (int c = 0; c < LOB_N_ACTIONS; c++) q[c] = a_ == c ? q[c] + x_ : q[c]; \
     }
+    {
+        f64 v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0, v5 = 0.0, v6 = 0.0;
+        if (0 < n) v0 = S.theta[(uint32_t)l0.y];
+        if (1 < n) v1 = S.theta[(uint32_t)l1.x];
+        if (2 < n) v2 = S.theta[(uint32_t)l1.y];
+        if (3 < n) v3 = S.theta[(uint32_t)l2.x];
+        if (4 < n) v4 = S.theta[(uint32_t)l2.y];
+        if (5 < n) v5 = S.theta[(uint32_t)l3.x];
+        if (6 < n) v6 = S.theta[(uint32_t)l3.y];
+        LOB_LIGHT_ADD(l0.y, v0) LOB_LIGHT_ADD(l1.x, v1) LOB_LIGHT_ADD(l1.y, v2) LOB_LIGHT_ADD(l2.x, v3)
+        LOB_LIGHT_ADD(l2.y, v4) LOB_LIGHT_ADD(l3.x, v5) LOB_LIGHT_ADD(l3.y, v6)
+    }
+    for (int i0 = 7; i0 < n; i0 += 2) {
+        const u64 e0 = S.hl_rec[(size_t)b * LOB_HL_REC + 1 + i0], e1 = i0 + 1 < n ? S.hl_rec[(size_t)b * LOB_HL_REC + 2 + i0] : 0ull;
+        const f64 v0 = S.theta[(uint32_t)e0];
+        f64 v1 = 0.0;
+        if (i0 + 1 < n) v1 = S.theta[(uint32_t)e1];
+        LOB_LIGHT_ADD(e0, v0) LOB_LIGHT_ADD(e1, v1)
+    }
+#undef LOB_LIGHT_ADD
 #pragma unroll
     for (int a = 0; a < LOB_N_ACTIONS; a++) S.qs_last[(size_t)b * LOB_N_ACTIONS + a] = q[a];
     Rng g{P.seed, P.book_id_offset + (u64)b, h.rng_ctr};
@@ -487,6 +489,32 @@ __global__ void __launch_bounds__(LOB_TRACE_BLOCK, LOB_TRACE_OCC) trace_fast_ker
 }
 __host__ __device__ inline size_t trace_lds_bytes() { return (size_t)(2048 + 32) * 4 + (size_t)LOB_TRACE_WAVES * 48 * 4 + (size_t)LOB_TRACE_WAVES * LOB_HSLOTS * 8; }
 
+// What a wave of the persistent kernels fetches of a book one loop iteration AHEAD (the loads of the next batch are
+// issued before the current one is worked on, so their latency is not exposed at the top of the next iteration):
+// the 64-byte header spread over lanes (lane i & 15 holds dword i: one register for the lot, fields come back through
+// readlane), the memo slot, the three State rows (lane < 48).
+struct FastPre {
+    int hdw, mslot;
+    f32 vv;
+};
+template <int NB>
+__device__ __forceinline__ void fast_prefetch(const DevState& S, int t0, int stride, int lane, FastPre* p) {
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+        const int t = __builtin_amdgcn_readfirstlane(t0 + k * stride);
+        const int bb = t < S.B ? t : 0;
+        p[k].hdw = reinterpret_cast<const int*>(S.hdr + bb)[lane & 15];
+        p[k].mslot = S.mk_slot[bb];
+        p[k].vv = lane < 48 ? S.vars[(size_t)bb * 48 + lane] : 0.0f;
+    }
+}
+__device__ __forceinline__ u64 hdw_u64(int hdw, int i) {
+    return (u64)(uint32_t)__builtin_amdgcn_readlane(hdw, i) | ((u64)(uint32_t)__builtin_amdgcn_readlane(hdw, i + 1) << 32);
+}
+// (dword offsets of the LHdr fields: lob_state.h)
+static_assert(offsetof(LHdr, slot_cur) == 8 && offsetof(LHdr, stepped) == 20 && offsetof(LHdr, rng_ctr) == 32 && offsetof(LHdr, reward) == 40 &&
+              offsetof(LHdr, td) == 48, "LHdr layout");
+
 // The second half of learn_book: Q(to_state, .), the TD error of SARSA / QLearn::UpdateWeights (agent.cpp:282-311).
 template <int ALGO, int NB>
 __global__ void __launch_bounds__(LOB_FAST_BLOCK) learn_q_fast_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g, int lpar,
@@ -497,6 +525,8 @@ __global__ void __launch_bounds__(LOB_FAST_BLOCK) learn_q_fast_kernel(DevParams 
     const int w = threadIdx.x >> 6;
     const int stride = gridDim.x * LOB_FAST_WAVES;
     int lane_ = threadIdx.x & 63;
+    FastPre cur[NB];
+    fast_prefetch<NB>(S, blockIdx.x * LOB_FAST_WAVES + w, stride, lane_, cur);
 #pragma unroll 1
     for (int t0 = blockIdx.x * LOB_FAST_WAVES + w; t0 < S.B; t0 += stride * NB) {
         asm volatile("" : "+v"(lane_));
@@ -504,56 +534,56 @@ __global__ void __launch_bounds__(LOB_FAST_BLOCK) learn_q_fast_kernel(DevParams 
         int b[NB], mslot[NB];
         bool go[NB], real[NB];
         LHdr h[NB];
-        f32 vv[NB];
         Prof pf;
+        int4 mid[NB];
+        MemoRec rec[NB];
 #pragma unroll
         for (int k = 0; k < NB; k++) {
             const int t = __builtin_amdgcn_readfirstlane(t0 + k * stride);
             go[k] = real[k] = t < S.B;
             b[k] = go[k] ? t : 0;
-            h[k] = S.hdr[b[k]];
-            mslot[k] = S.mk_slot[b[k]];
-            vv[k] = lane < 48 ? S.vars[(size_t)b[k] * 48 + lane] : 0.0f;
+            h[k].slot_cur = __builtin_amdgcn_readlane(cur[k].hdw, 2);
+            h[k].stepped = __builtin_amdgcn_readlane(cur[k].hdw, 5);
+            h[k].rng_ctr = hdw_u64(cur[k].hdw, 8);
+            h[k].reward = __longlong_as_double((long long)hdw_u64(cur[k].hdw, 10));
+            h[k].td = __longlong_as_double((long long)hdw_u64(cur[k].hdw, 12));
+            mslot[k] = __builtin_amdgcn_readfirstlane(cur[k].mslot);
             go[k] = go[k] && h[k].stepped != 0;
+            // this batch's memo records first, then the next batch's rows: a wait for the former does not wait for the latter
+            const int ms = mslot[k] >= 0 ? mslot[k] : 0;
+            mid[k] = *reinterpret_cast<const int4*>(S.mk_ident + (size_t)ms * 4);
+            rec[k] = *reinterpret_cast<const MemoRec*>(S.mk_rec + (size_t)ms * LOB_MK_REC);  // [0]: under theta_t
         }
         pf.start(S.prof, b[0], lane);
         wave_lds_fence();
 #pragma unroll
         for (int k = 0; k < NB; k++)
-            if (lane < 48) L.vars[k * 48 + lane] = vv[k];
+            if (lane < 48) L.vars[k * 48 + lane] = cur[k].vv;
+        fast_prefetch<NB>(S, t0 + stride * NB, stride, lane, cur);
         wave_lds_fence();
         int qv[NB];
-        int4 mid[NB];
-        MemoRec rec[NB];
 #pragma unroll
-        for (int k = 0; k < NB; k++) {
-            qv[k] = tile_quant(L.vars[k * 48 + h[k].slot_cur * 16 + (lane & 15)]);
-            const int ms = mslot[k] >= 0 ? mslot[k] : 0;
-            mid[k] = *reinterpret_cast<const int4*>(S.mk_ident + (size_t)ms * 4);
-            rec[k] = *reinterpret_cast<const MemoRec*>(S.mk_rec + (size_t)ms * LOB_MK_REC);  // [0]: under theta_t
-        }
-#pragma unroll
-        for (int k = 0; k < NB; k++)
-            if (go[k] && !fast_memo_ok(mslot[k], mid[k], rec[k], ver, qv[k])) { fast_hand_back(S, 1, lpar, b[k], lane); go[k] = false; }
-        pf.mark(13);  // header, memo record, state variables
+        for (int k = 0; k < NB; k++) qv[k] = tile_quant(L.vars[k * 48 + h[k].slot_cur * 16 + (lane & 15)]);
+        pf.mark(13);  // header, state variables
         f64 qs[NB][LOB_N_ACTIONS];
+        int hcnt[NB];
+        u64* hbuf = reinterpret_cast<u64*>(L.vars);
+        // (a book that turns out to have no valid memo record is evaluated on whatever its -- valid -- inputs are)
+        q_values_fast<NB, true>(P, S, L, qv, lane, rec, qs, pf, 14, hbuf, hcnt);
         int wr_b[NB];
 #pragma unroll
         for (int k = 0; k < NB; k++) {
+            if (go[k] && !fast_memo_ok(mslot[k], mid[k], rec[k], ver, qv[k])) { fast_hand_back(S, 1, lpar, b[k], lane); go[k] = false; }
             wr_b[k] = go[k] ? b[k] : -1;
-            if (!go[k] && real[k] && lane == 0) S.hl_n[b[k]] = -1;  // no list: the next act takes the general path for this book
+            if (!go[k] && real[k] && lane == 0) S.hl_rec[(size_t)b[k] * LOB_HL_REC] = LOB_HL_NONE;  // no list: the next act takes the general path for this book
         }
-        i32 tidx[NB][LOB_N_ACTIONS];
-        uint32_t thit[NB];
-        q_values_fast<NB, true>(P, S, L, qv, lane, rec, qs, pf, 14, tidx, thit);
 #pragma unroll
         for (int k = 0; k < NB; k++) {
             if (!go[k]) continue;
             Rng g{P.seed, P.book_id_offset + (u64)b[k], h[k].rng_ctr};
             learn_delta_single<ALGO>(P, S.hdr + b[k], h[k], qs[k], h[k].td, g, lane);
         }
-        asm volatile("" ::: "memory");  // (the lists after everything else: the Q values' registers are free by now)
-        hit_list_write<NB>(S, lane, tidx, thit, wr_b);
+        hit_list_store<NB>(S, lane, hcnt, wr_b, hbuf);
         pf.mark(19);  // argmax / delta / header stores
     }
 }

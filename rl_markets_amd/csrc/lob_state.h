@@ -149,7 +149,8 @@ struct __attribute__((aligned(64))) LHdr {
 #define LOB_PROF_N 32
 #define LOB_MK_REC 10         /* doubles per memo record: S0 of the nine actions + the theta version it was computed under */
 #define LOB_MK_PROBES 16
-#define LOB_HL_CAP 24         /* additions per book a hit list can hold (the mean is 5-6 at 125 k written weights of 20 M) */
+#define LOB_HL_CAP 23         /* additions per book a hit list can hold (the mean is 5-6 at 125 k written weights of 20 M) */
+#define LOB_HL_REC 24         /* u64 per book: [0] the count, then the additions: 192 bytes */
 #define LOB_VD_STRIDE 72      /* u16 per book: 64 verdicts + epoch lo/hi + slot + valid, padded to 144 B */
 /* theta's "ever written" map: one bit per LOB_NZ_GRAN = 8 consecutive weights (312 KB at M = 20M, so
  * it stays L2-resident under the streaming traffic; one bit per weight, 2.5 MB, did not).  A set
@@ -269,8 +270,8 @@ struct DevState {
     // group-1/2 tiles fall on a written weight -- the trace kernel marks a new generation's tiles in the maps when it
     // creates the generation, before learn_q looks.  So learn_q leaves, per book, the ordered list of additions
     // Agent::getQ makes beyond the memoised group-0 sum: entry = tile index | action << 32 | (weight w2 ? 1 : 0) << 36.
-    u64* hl_ent;         // [LOB_HL_CAP][B]
-    i32* hl_n;           // [B] entries, or -1: no list (not evaluated by the fast learn kernel, or more than LOB_HL_CAP)
+    u64* hl_rec;         // [B][LOB_HL_REC]: [0] = number of entries, or ~0: no list (not evaluated by the fast learn kernel, or more
+                         //   than LOB_HL_CAP); [1 + i] = entry i
     i32* hl_dirty;       // [1] step id of the last update that set a map bit AFTER learn_q had looked (voids every list)
     f64* theta_sync;  // [M] (multi-GPU) or null
     f64* delta;       // [M] scratch for the all-reduce or null
