@@ -56,6 +56,8 @@ struct lob_engine {
     bool hits_ok = false;       // the previous call was a fast-path learner step and nothing has touched weights, maps or states since:
                                 // the hit lists its learn kernel left are those of the States the next step acts on (act_light_kernel)
     bool light = true;          // use them (LOB_NO_LIGHT=1: always the full act kernel, for A/B runs)
+    int q_lanes = -1;           // learn_q_lane_kernel (a lane per book) instead of learn_q_fast_kernel (a wave per book): -1 by batch size,
+                                // 0 / 1 forced (LOB_Q_LANES)
     std::vector<void*> allocs;
     uint32_t* rnd_dev = nullptr;
     uint32_t* records_dev = nullptr;
@@ -255,6 +257,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     if (const char* g = getenv("LOB_TRACK_REFILL")) { int v = atoi(g); if (v >= 1) e->track_refill = v; }
     if (const char* g = getenv("LOB_ACC_LANES")) { int v = atoi(g); if (v == 8 || v == 16 || v == 32 || v == 64) e->acc_shift = v == 8 ? 3 : v == 16 ? 4 : v == 32 ? 5 : 6; }
     if (const char* g = getenv("LOB_NO_LIGHT")) e->light = !(g[0] == '1');
+    if (const char* g = getenv("LOB_Q_LANES")) e->q_lanes = g[0] == '1' ? 1 : 0;
     if (const char* g = getenv("LOB_RESET_LANES")) { int v = atoi(g); if (v == 16 || v == 32 || v == 64) e->reset_lanes = v; }
 
     // ---- DevParams ----
@@ -397,6 +400,11 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
             hipError_t er = hipFuncSetAttribute((const void*)act_fast_kernel<LOB_FAST_NB>, hipFuncAttributeMaxDynamicSharedMemorySize, q_lds);
             if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_fast_kernel<LOB_ALGO_SARSA, LOB_FAST_NB>, hipFuncAttributeMaxDynamicSharedMemorySize, q_lds);
             if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_fast_kernel<LOB_ALGO_QLAMBDA, LOB_FAST_NB>, hipFuncAttributeMaxDynamicSharedMemorySize, q_lds);
+            const int ql_lds = (int)qlane_lds_bytes(P.cwords4);
+            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_lane_kernel<LOB_ALGO_SARSA, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, ql_lds);
+            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_lane_kernel<LOB_ALGO_QLAMBDA, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, ql_lds);
+            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_lane_kernel<LOB_ALGO_SARSA, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, ql_lds);
+            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_lane_kernel<LOB_ALGO_QLAMBDA, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, ql_lds);
             if (er == hipSuccess) er = hipFuncSetAttribute((const void*)trace_fast_kernel<LOB_ALGO_SARSA>, hipFuncAttributeMaxDynamicSharedMemorySize, tr_lds);
             if (er == hipSuccess) er = hipFuncSetAttribute((const void*)trace_fast_kernel<LOB_ALGO_QLAMBDA>, hipFuncAttributeMaxDynamicSharedMemorySize, tr_lds);
             if (er != hipSuccess && rc == LOB_OK) { lob_set_error(std::string("hipFuncSetAttribute(dynamic LDS): ") + hipGetErrorString(er)); rc = LOB_EHIP; }
@@ -813,7 +821,16 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode) {
                 }
                 {
                     TimedLaunch t(e, "learn_kernel", st);
-                    if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL((learn_q_fast_kernel<LOB_ALGO_QLAMBDA, LOB_FAST_NB>), dim3(gf), dim3(LOB_FAST_BLOCK), fast_lds_bytes(e->P.cwords4, LOB_FAST_NB, false), st, e->P, e->S, rnd, lpar, ver);
+                    // a lane per book once the batch gives every CU a full block of them; else a wave per book
+                    const bool lanes = e->q_lanes >= 0 ? e->q_lanes == 1 : nb >= LOB_QL_BLOCK * e->n_cus / 2;
+                    if (lanes) {
+                        const int gq = std::min(e->n_cus, (nb + LOB_QL_BLOCK - 1) / LOB_QL_BLOCK);
+                        const size_t lds = qlane_lds_bytes(e->P.cwords4);
+#define LOB_QL_LAUNCH(A, VT) hipLaunchKernelGGL((learn_q_lane_kernel<A, VT>), dim3(gq), dim3(LOB_QL_BLOCK), lds, st, e->P, e->S, rnd, lpar, ver)
+                        if (e->P.algo == LOB_ALGO_QLAMBDA) { if (e->P.V == 8) LOB_QL_LAUNCH(LOB_ALGO_QLAMBDA, 8); else LOB_QL_LAUNCH(LOB_ALGO_QLAMBDA, 0); }
+                        else { if (e->P.V == 8) LOB_QL_LAUNCH(LOB_ALGO_SARSA, 8); else LOB_QL_LAUNCH(LOB_ALGO_SARSA, 0); }
+#undef LOB_QL_LAUNCH
+                    } else if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL((learn_q_fast_kernel<LOB_ALGO_QLAMBDA, LOB_FAST_NB>), dim3(gf), dim3(LOB_FAST_BLOCK), fast_lds_bytes(e->P.cwords4, LOB_FAST_NB, false), st, e->P, e->S, rnd, lpar, ver);
                     else hipLaunchKernelGGL((learn_q_fast_kernel<LOB_ALGO_SARSA, LOB_FAST_NB>), dim3(gf), dim3(LOB_FAST_BLOCK), fast_lds_bytes(e->P.cwords4, LOB_FAST_NB, false), st, e->P, e->S, rnd, lpar, ver);
                 }
                 {

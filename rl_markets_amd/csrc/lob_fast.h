@@ -588,4 +588,181 @@ __global__ void __launch_bounds__(LOB_FAST_BLOCK) learn_q_fast_kernel(DevParams 
     }
 }
 
+
+// ---- Q(to_state, .) + TD error, one LANE per book ------------------------------------------------------------------
+// The wave-per-book kernel above spends most of its instructions on work that is the same in all 64 lanes (headers,
+// memo checks, ballots, the ordered continuation, argmax, the TD error); only the tile hashing itself is spread over
+// the lanes.  With a lane per book every instruction does 64 books' worth: a lane walks its book's 64 group-1/2
+// tilings (hash sum from the LDS table, nine tile indices, nine coarse-map bits from the LDS image), looks the coarse
+// hits up in the exact map, and appends the tiles on marked weights to the book's hit list in the order Agent::getQ
+// adds them (per action: group-1 tilings ascending with w1 | the same again with w2 | group-2 tilings ascending with
+// w2 -- the list holds [all group-1 hits, w1][the same, w2][all group-2 hits], which is that order for every action).
+// Q is then the memoised group-0 sum + the listed additions, exactly as act_light_kernel replays them.
+// The exact-map look-ups are the only global loads inside the walk: they are issued for LOB_QL_CHUNK tilings at a
+// time, unconditionally (a tile that is not a coarse hit reads word 0: one broadcast line) and consumed one stage
+// later, so their latency hides behind the next stage's hashing -- a CU runs one 4-wave block (the LDS image).
+#define LOB_QL_BLOCK 256
+#define LOB_QL_ROW 25   /* u64 per lane in LDS: its hit list (LOB_HL_REC) + 1 pad */
+#define LOB_QL_CHUNK 4  /* tilings per pipeline stage */
+static_assert(32 % (2 * LOB_QL_CHUNK) == 0, "two stages per loop iteration");
+__host__ __device__ inline size_t qlane_lds_bytes(int cwords4) { return (size_t)(2048 + 32 + cwords4 * 4) * 4 + (size_t)LOB_QL_BLOCK * LOB_QL_ROW * 8; }
+
+struct QlStage {
+    i32 idx[LOB_QL_CHUNK][LOB_N_ACTIONS];
+    uint32_t xw[LOB_QL_CHUNK][LOB_N_ACTIONS];  // exact-map word of the tile (word 0 if it is not a coarse hit)
+    uint32_t maybe[LOB_QL_CHUNK];
+};
+// tilings j0 .. j0 + LOB_QL_CHUNK - 1 of group G (1: state variables 3..V-1, 2: all V): tile indices, coarse bits,
+// exact-map loads issued
+// VT: the number of state variables when it is the default 8 (every loop bound static: the table reads of a tiling
+// leave together), 0: any (P.V; reads beyond it are made and discarded rather than branched around).
+template <int G, int VT>
+__device__ __forceinline__ void ql_issue(const DevParams& P, const DevState& S, const uint32_t* rnd, const uint32_t* terms, const uint32_t* coarse,
+                                         const int* q, int j0, QlStage& st) {
+    const uint32_t M = (uint32_t)P.M;
+    const int V = VT ? VT : P.V;
+    const int nf = G == 1 ? V - 3 : V;
+    const int cs = P.cshift;
+    constexpr int NI = VT ? (G == 1 ? VT - 3 : VT) : (G == 1 ? LOB_MAX_VARS - 3 : LOB_MAX_VARS);
+#pragma unroll
+    for (int u = 0; u < LOB_QL_CHUNK; u++) {
+        const int j = j0 + u;
+        uint32_t t[NI];
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+            const int qi = G == 1 ? q[i + 3] : q[i];
+            const int base = j * (1 + 2 * i);
+            t[i] = rnd[(base + ((qi - base) & ~31) + 449 * i) & 2047];  // tile_coord without the wrap-around case (such books are not here)
+        }
+        uint32_t sum = rnd[(j + 449 * nf) & 2047];
+#pragma unroll
+        for (int i = 0; i < NI; i++) sum = mod_add(sum, (VT || i < nf) ? t[i] : 0u, M);
+        uint32_t mb = 0;
+#pragma unroll
+        for (int a = 0; a < LOB_N_ACTIONS; a++) {
+            const i32 x = tile_index(sum, terms[a], M);
+            st.idx[u][a] = x;
+            mb |= ((coarse[(uint32_t)x >> (cs + 5)] >> (((uint32_t)x >> cs) & 31)) & 1u) << a;
+        }
+        st.maybe[u] = mb;
+#pragma unroll
+        for (int a = 0; a < LOB_N_ACTIONS; a++) st.xw[u][a] = S.theta_nzx[((mb >> a) & 1u) ? (uint32_t)st.idx[u][a] >> 5 : 0u];
+    }
+}
+// the tiles of a stage that fall on marked weights join the lane's list (`row[1 + n]`, n counts on beyond the capacity)
+template <int G>
+__device__ __forceinline__ void ql_consume(const QlStage& st, u64* row, int& n) {
+#pragma unroll
+    for (int u = 0; u < LOB_QL_CHUNK; u++) {
+        uint32_t hit = 0;
+#pragma unroll
+        for (int a = 0; a < LOB_N_ACTIONS; a++) hit |= ((st.xw[u][a] >> ((uint32_t)st.idx[u][a] & 31)) & (st.maybe[u] >> a) & 1u) << a;
+        if (hit) {
+#pragma unroll
+            for (int a = 0; a < LOB_N_ACTIONS; a++) {
+                if ((hit >> a) & 1u) {
+                    if (n < LOB_HL_CAP) row[1 + n] = (u64)(uint32_t)st.idx[u][a] | ((u64)a << 32) | (G == 2 ? 1ull << 36 : 0ull);
+                    n++;
+                }
+            }
+        }
+    }
+}
+template <int G, int VT>
+__device__ __forceinline__ void ql_group(const DevParams& P, const DevState& S, const uint32_t* rnd, const uint32_t* act_terms, const uint32_t* coarse,
+                                         const int* q, u64* row, int& n) {
+    const uint32_t* terms = act_terms + G * LOB_N_ACTIONS;
+    QlStage A, B;
+    ql_issue<G, VT>(P, S, rnd, terms, coarse, q, 0, A);
+#pragma unroll 1
+    for (int j0 = LOB_QL_CHUNK; j0 < 32; j0 += 2 * LOB_QL_CHUNK) {
+        ql_issue<G, VT>(P, S, rnd, terms, coarse, q, j0, B);
+        ql_consume<G>(A, row, n);
+        if (j0 + LOB_QL_CHUNK < 32) ql_issue<G, VT>(P, S, rnd, terms, coarse, q, j0 + LOB_QL_CHUNK, A);
+        ql_consume<G>(B, row, n);
+    }
+}
+
+template <int ALGO, int VT>
+__global__ void __launch_bounds__(LOB_QL_BLOCK) learn_q_lane_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g, int lpar, u64 ver) {
+    static_assert(ALGO == LOB_ALGO_SARSA || ALGO == LOB_ALGO_QLAMBDA, "one weight vector");
+    extern __shared__ __align__(16) unsigned char fast_lds_raw[];
+    uint32_t* rnd = reinterpret_cast<uint32_t*>(fast_lds_raw);
+    uint32_t* act_terms = rnd + 2048;
+    uint32_t* coarse = act_terms + 32;
+    u64* row = reinterpret_cast<u64*>(coarse + (size_t)P.cwords4 * 4) + (size_t)threadIdx.x * LOB_QL_ROW;
+    for (int i = threadIdx.x; i < 512; i += LOB_QL_BLOCK) reinterpret_cast<uint4*>(rnd)[i] = reinterpret_cast<const uint4*>(rnd_g)[i];
+    if (threadIdx.x < 27) act_terms[threadIdx.x] = rnd_g[2048 + threadIdx.x];
+    for (int i = threadIdx.x; i < P.cwords4; i += LOB_QL_BLOCK) reinterpret_cast<uint4*>(coarse)[i] = reinterpret_cast<const uint4*>(S.theta_nzc)[i];
+    __syncthreads();
+#pragma unroll 1
+    for (int b = blockIdx.x * LOB_QL_BLOCK + threadIdx.x; b < S.B; b += gridDim.x * LOB_QL_BLOCK) {
+        const LHdr h = S.hdr[b];
+        LHdr* hp = S.hdr + b;
+        u64* recp = S.hl_rec + (size_t)b * LOB_HL_REC;
+        if (!h.stepped) { recp[0] = LOB_HL_NONE; continue; }
+        const int mslot = S.mk_slot[b];
+        int q[LOB_MAX_VARS];
+        {
+            const float4* vp = reinterpret_cast<const float4*>(S.vars + (size_t)b * 48 + h.slot_cur * 16);
+            const float4 v0 = vp[0], v1 = vp[1], v2 = vp[2], v3 = vp[3];
+            const f32 v[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+#pragma unroll
+            for (int i = 0; i < LOB_MAX_VARS; i++) q[i] = tile_quant(v[i]);
+        }
+        // a quantised variable within 1024 of INT_MIN (in practice: a NaN state variable) takes tile_coord's
+        // wrap-around branch: left to the general kernel
+        bool plain = true;
+#pragma unroll
+        for (int i = 0; i < LOB_MAX_VARS; i++) plain = plain && (i >= P.V || q[i] >= (int)0x80000400);
+        const int ms = mslot >= 0 ? mslot : 0;
+        const int4 mid = *reinterpret_cast<const int4*>(S.mk_ident + (size_t)ms * 4);
+        const f64* recm = S.mk_rec + (size_t)ms * LOB_MK_REC;  // [0]: under theta_t
+        const u64 rver = reinterpret_cast<const u64*>(recm)[LOB_N_ACTIONS];
+        int n = 0;
+        bool ok = plain && mslot >= 0 && rver == ver && mid.x == q[0] && mid.y == q[1] && mid.z == q[2];
+        if (ok) {
+            ql_group<1, VT>(P, S, rnd, act_terms, coarse, q, row, n);
+            // the group-1 additions once more, with w2 (quirk Q3)
+            const int n1 = n;
+            for (int i = 0; i < n1; i++) {
+                if (n < LOB_HL_CAP) row[1 + n] = row[1 + i] | (1ull << 36);
+                n++;
+            }
+            if (n <= LOB_HL_CAP) ql_group<2, VT>(P, S, rnd, act_terms, coarse, q, row, n);
+            ok = n <= LOB_HL_CAP;
+        }
+        if (!ok) {  // no (valid) memo record, or a list longer than a record: the general kernel takes the book
+            const int pos = atomicAdd(&S.slow_n[lpar * 2 + 1], 1);
+            S.slow_list[(size_t)S.B + pos] = b;
+            recp[0] = LOB_HL_NONE;
+            continue;
+        }
+        f64 qs[LOB_N_ACTIONS];
+#pragma unroll
+        for (int a = 0; a < LOB_N_ACTIONS; a++) qs[a] = recm[a];
+        const f64 w1 = P.w1, w2 = P.w2;
+        for (int i0 = 0; i0 < n; i0 += 4) {
+            u64 ent[4];
+            f64 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) ent[u] = i0 + u < n ? row[1 + i0 + u] : 0ull;
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = i0 + u < n ? S.theta[(uint32_t)ent[u]] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (v[u] == 0.0) continue;  // (+0.0 added to a sum that is never -0.0)
+                const int a = (int)(ent[u] >> 32) & 15;
+                const f64 x = ((ent[u] >> 36) & 1ull ? w2 : w1) * v[u];
+#pragma unroll
+                for (int c = 0; c < LOB_N_ACTIONS; c++) qs[c] = a == c ? qs[c] + x : qs[c];
+            }
+        }
+        Rng g{P.seed, P.book_id_offset + (u64)b, h.rng_ctr};
+        learn_delta_single<ALGO>(P, hp, h, qs, h.td, g, 0);
+        recp[0] = (u64)n;
+        for (int i = 0; i < n; i++) recp[1 + i] = row[1 + i];
+    }
+}
+
 #endif

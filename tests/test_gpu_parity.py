@@ -625,6 +625,50 @@ def test_hit_list_carry_on_off_identical(monkeypatch, algo, mem):
     np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-9, atol=1e-12)
 
 
+@pytest.mark.parametrize("algo", [abi.ALGO_SARSA, abi.ALGO_QLAMBDA])
+@pytest.mark.parametrize("mem,n_vars", [(1 << 12, 8), (1 << 18, 8), (1 << 22, 8), (1 << 20, 13), (1 << 20, 4)])
+def test_q_lane_kernel_on_off_identical(monkeypatch, algo, mem, n_vars):
+    """learn_q_lane_kernel (a lane per book: it walks the book's 64 group-1/2 tilings itself) against
+    learn_q_fast_kernel (a wave per book, tilings spread over the lanes): same tile indices, same hit lists, same
+    ordered sums -- actions, TD errors and books bit for bit, theta up to its atomics' ordering.  With 13 and with
+    4 state variables (group 1 then hashes 10 / 1 of them), and with tables small enough for long lists."""
+    B = 160
+    out = []
+    for lanes in ("0", "1"):
+        monkeypatch.setenv("LOB_Q_LANES", lanes)
+        p = engine.default_params()
+        p.depth, p.max_trades, p.algo, p.theta_mode, p.memory_size, p.epsilon = 5, 2, algo, abi.THETA_SHARED, mem, 0.3
+        if n_vars != 8:
+            # the first three stay pos / a_dist / b_dist (the group-0 triple); 13: every variable, 4: one market variable
+            order = list(p.vars[:3]) + [v for v in range(13) if v not in list(p.vars[:3])]
+            p.n_vars = n_vars
+            for i in range(13):
+                p.vars[i] = order[i] if i < n_vars else 0
+        g = engine.default_gen_params()
+        g.n_events = 500
+        rec = engine.gen_stream_host(g, 5, 2, 0, B)
+        eng = engine.Engine(p, B)
+        eng.load_events(rec)
+        eng.reset()
+        trail = []
+        for n in (1, 1, 2, 5, 1, 9, 14, 3, 25):
+            eng.td_step(n)
+            trail.append((eng.last_actions().copy(), eng.last_td().copy(), bytes(eng.get_books())))
+        th = eng.theta()
+        th[::7] += 1e-3
+        eng.set_theta(th)
+        for n in (1, 6, 11):
+            eng.td_step(n)
+            trail.append((eng.last_actions().copy(), eng.last_td().copy(), bytes(eng.get_books())))
+        out.append((trail, eng.theta()))
+        eng.close()
+    for k, ((a0, t0, b0), (a1, t1, b1)) in enumerate(zip(out[0][0], out[1][0])):
+        np.testing.assert_array_equal(a0, a1, err_msg="actions, record %d" % k)
+        assert b0 == b1, "books differ at record %d" % k
+        np.testing.assert_allclose(t0, t1, rtol=1e-9, atol=1e-12, err_msg="td, record %d" % k)
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-9, atol=1e-12)
+
+
 # ---- long streams: the market track as a ring, refilled while the episode runs ------------------------
 @pytest.mark.parametrize("ring,refill", [(256, 8), (512, 40)])
 def test_long_streams_use_a_track_ring(monkeypatch, ring, refill):
