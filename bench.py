@@ -59,8 +59,8 @@ def algorithmic_bytes(kernel, depth, trades, n_vars, n_live, events_per_step):
 
 
 # timer name (lob_kernel_time_ms) -> kernel function(s) launched under it, as rocprofv3 names them
-TIMER_KERNELS = {"act_kernel": ("act_fast_kernel", "act_kernel"), "trace_kernel": ("trace_fast_kernel",),
-                 "learn_kernel": ("learn_q_fast_kernel", "learn_kernel"), "act_rest_kernel": (), "learn_rest_kernel": ()}
+TIMER_KERNELS = {"act_kernel": ("act_light_kernel", "act_fast_kernel", "act_kernel"), "trace_kernel": ("trace_fast_kernel",),
+                 "learn_kernel": ("learn_q_lane_kernel", "learn_q_fast_kernel", "learn_kernel"), "act_rest_kernel": (), "learn_rest_kernel": ()}
 
 
 def traffic_of(traffic_file, timer):
@@ -342,7 +342,7 @@ def main():
         print(result, flush=True)
 
 
-KERNELS = ("act_kernel", "act_rest_kernel", "env_kernel", "memo_kernel", "trace_kernel", "learn_kernel", "learn_rest_kernel",
+KERNELS = ("act_kernel", "act_rest_kernel", "env_kernel", "memo_kernel", "trace_light_kernel", "trace_kernel", "learn_kernel", "learn_rest_kernel",
            "update_kernel", "accumulate_kernel", "apply_kernel", "prepass_extend_kernel", "delta_begin_kernel", "delta_apply_kernel")
 
 if __name__ == "__main__":

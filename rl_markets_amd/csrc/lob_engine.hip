@@ -56,6 +56,7 @@ struct lob_engine {
     bool hits_ok = false;       // the previous call was a fast-path learner step and nothing has touched weights, maps or states since:
                                 // the hit lists its learn kernel left are those of the States the next step acts on (act_light_kernel)
     bool light = true;          // use them (LOB_NO_LIGHT=1: always the full act kernel, for A/B runs)
+ bool t_light = true;        // trace_light_kernel in front of the wave-per-book trace kernel (Q(lambda); LOB_NO_TLIGHT=1: off)
     int q_lanes = -1;           // learn_q_lane_kernel (a lane per book) instead of learn_q_fast_kernel (a wave per book): -1 by batch size,
                                 // 0 / 1 forced (LOB_Q_LANES)
     std::vector<void*> allocs;
@@ -258,6 +259,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     if (const char* g = getenv("LOB_ACC_LANES")) { int v = atoi(g); if (v == 8 || v == 16 || v == 32 || v == 64) e->acc_shift = v == 8 ? 3 : v == 16 ? 4 : v == 32 ? 5 : 6; }
     if (const char* g = getenv("LOB_NO_LIGHT")) e->light = !(g[0] == '1');
     if (const char* g = getenv("LOB_Q_LANES")) e->q_lanes = g[0] == '1' ? 1 : 0;
+    if (const char* g = getenv("LOB_NO_TLIGHT")) e->t_light = !(g[0] == '1');
     if (const char* g = getenv("LOB_RESET_LANES")) { int v = atoi(g); if (v == 16 || v == 32 || v == 64) e->reset_lanes = v; }
 
     // ---- DevParams ----
@@ -372,6 +374,11 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
         if (rc == LOB_OK) rc = dev_alloc(e, &S.mk_list, 2 * ms);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.mk_count, 2);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.mk_rec, 2 * ms * LOB_MK_REC);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.mk_tiles, P.memo ? ms * LOB_N_ACTIONS * 32 : 1);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.mk_tiles_ok, ms);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.mk_marked, ms);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.tr_list, B);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.tr_list_n, 2);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.mk_slot, B);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.mk_slot_last, B);
         if (rc == LOB_OK && hipMemsetAsync(S.mk_hash, 0xff, ms * 8, e->stream) != hipSuccess) rc = LOB_EHIP;
@@ -405,8 +412,9 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
             if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_lane_kernel<LOB_ALGO_QLAMBDA, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, ql_lds);
             if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_lane_kernel<LOB_ALGO_SARSA, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, ql_lds);
             if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_lane_kernel<LOB_ALGO_QLAMBDA, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, ql_lds);
-            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)trace_fast_kernel<LOB_ALGO_SARSA>, hipFuncAttributeMaxDynamicSharedMemorySize, tr_lds);
-            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)trace_fast_kernel<LOB_ALGO_QLAMBDA>, hipFuncAttributeMaxDynamicSharedMemorySize, tr_lds);
+            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)trace_fast_kernel<LOB_ALGO_SARSA, false>, hipFuncAttributeMaxDynamicSharedMemorySize, tr_lds);
+            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)trace_fast_kernel<LOB_ALGO_QLAMBDA, false>, hipFuncAttributeMaxDynamicSharedMemorySize, tr_lds);
+            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)trace_fast_kernel<LOB_ALGO_QLAMBDA, true>, hipFuncAttributeMaxDynamicSharedMemorySize, tr_lds);
             if (er != hipSuccess && rc == LOB_OK) { lob_set_error(std::string("hipFuncSetAttribute(dynamic LDS): ") + hipGetErrorString(er)); rc = LOB_EHIP; }
         }
     }
@@ -636,6 +644,8 @@ int lob_reset(lob_engine* e) {
     { int rc = finalize_episode(e); if (rc) return rc; }
     // the memo table starts empty every episode (reset_kernel voids every book's slot)
     HIPCHK(hipMemsetAsync(e->S.mk_hash, 0xff, (size_t)e->S.mk_slots * 8, e->stream));
+    HIPCHK(hipMemsetAsync(e->S.mk_tiles_ok, 0, (size_t)e->S.mk_slots * 4, e->stream));
+    HIPCHK(hipMemsetAsync(e->S.mk_marked, 0, (size_t)e->S.mk_slots * 4, e->stream));
     {
         TimedLaunch t(e, "reset_kernel", nullptr, true);
         const int rb = e->reset_lanes;
@@ -813,11 +823,19 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode) {
             }
             if (fast) launch_memo(e, par, mode == 0 ? 0 : 1);  // learner: S0 under theta_t for learn_kernel; backtester: for the next act
             if (mode == 0 && fast) {
+                const bool tl = e->P.algo == LOB_ALGO_QLAMBDA && e->t_light;
+                if (tl) {
+                    // a lane per book where the step leaves no older generation behind, the wave-per-book kernel for the rest
+                    TimedLaunch t(e, "trace_light_kernel", st);
+                    hipLaunchKernelGGL(trace_light_kernel, dim3((nb + LOB_LIGHT_BLOCK - 1) / LOB_LIGHT_BLOCK), dim3(LOB_LIGHT_BLOCK), 0, st, e->P, e->S, lpar);
+                }
                 {
                     TimedLaunch t(e, "trace_kernel", st);
                     const int gt = std::min((4 * LOB_TRACE_OCC / LOB_TRACE_WAVES) * e->n_cus, (nb + LOB_TRACE_WAVES - 1) / LOB_TRACE_WAVES);
-                    if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL(trace_fast_kernel<LOB_ALGO_QLAMBDA>, dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, e->P, e->S, rnd, par);
-                    else hipLaunchKernelGGL(trace_fast_kernel<LOB_ALGO_SARSA>, dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, e->P, e->S, rnd, par);
+                    if (tl) {
+                        hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_QLAMBDA, true>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, e->P, e->S, rnd, par, lpar);
+                    } else if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_QLAMBDA, false>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, e->P, e->S, rnd, par, lpar);
+                    else hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_SARSA, false>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, e->P, e->S, rnd, par, lpar);
                 }
                 {
                     TimedLaunch t(e, "learn_kernel", st);

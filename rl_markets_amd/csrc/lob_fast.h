@@ -268,6 +268,7 @@ __global__ void __launch_bounds__(LOB_FAST_BLOCK) act_fast_kernel(DevParams P, D
         S.mk_count[par] = 0;  // this step's env_kernel starts a new list of memo slots
         S.slow_n[(lpar ^ 1) * 2 + 0] = 0;  // the next step's work lists
         S.slow_n[(lpar ^ 1) * 2 + 1] = 0;
+        S.tr_list_n[lpar ^ 1] = 0;
     }
     const FastLds L = fast_stage(fast_lds_raw, P, S, rnd_g, NB, false);
     const int w = threadIdx.x >> 6;
@@ -354,6 +355,7 @@ __global__ void __launch_bounds__(LOB_LIGHT_BLOCK) act_light_kernel(DevParams P,
         S.mk_count[par] = 0;
         S.slow_n[(lpar ^ 1) * 2 + 0] = 0;
         S.slow_n[(lpar ^ 1) * 2 + 1] = 0;
+        S.tr_list_n[lpar ^ 1] = 0;
     }
     const int b = blockIdx.x * LOB_LIGHT_BLOCK + threadIdx.x;
     if (b >= S.B) return;
@@ -428,8 +430,9 @@ __global__ void __launch_bounds__(LOB_LIGHT_BLOCK) act_light_kernel(DevParams P,
 // (learn_q_fast_kernel).  Persistent 16-wave blocks, two per CU (75 KB of LDS each: the hash table and a
 // 4 KB tile map per wave).  A book's slot claims are resolved one book later, so that their CAS round
 // trips overlap the next book's work.
-template <int ALGO>
-__global__ void __launch_bounds__(LOB_TRACE_BLOCK, LOB_TRACE_OCC) trace_fast_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g, int par) {
+// LIST: only the books the lane-per-book kernel (trace_light_kernel, below) left on the list `tr_list`.
+template <int ALGO, bool LIST>
+__global__ void __launch_bounds__(LOB_TRACE_BLOCK, LOB_TRACE_OCC) trace_fast_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g, int par, int lpar) {
     extern __shared__ __align__(16) unsigned char fast_lds_raw[];
     // this step's update appends to nz_new[par]; the list the general act path reads is nz_new[par ^ 1]
     if (blockIdx.x == 0 && threadIdx.x < LOB_NZ_WORDS) {
@@ -449,11 +452,12 @@ __global__ void __launch_bounds__(LOB_TRACE_BLOCK, LOB_TRACE_OCC) trace_fast_ker
     CbPending prev;
     prev.active = false;
     int lane_ = threadIdx.x & 63;
+    const int n_todo = LIST ? S.tr_list_n[lpar] : S.B;
 #pragma unroll 1
-    for (int t = blockIdx.x * LOB_TRACE_WAVES + w; t < S.B; t += gridDim.x * LOB_TRACE_WAVES) {
+    for (int t = blockIdx.x * LOB_TRACE_WAVES + w; t < n_todo; t += gridDim.x * LOB_TRACE_WAVES) {
         asm volatile("" : "+v"(lane_));
         const int lane = lane_;
-        const int b = __builtin_amdgcn_readfirstlane(t);
+        const int b = __builtin_amdgcn_readfirstlane(LIST ? S.tr_list[t] : t);
         const LHdr h = S.hdr[b];
         const int lslot = P.memo ? S.mk_slot_last[b] : -1;  // memo slot of last_state's group-0 triple (checked below)
         f64 qs_last[LOB_N_ACTIONS];
@@ -487,6 +491,89 @@ __global__ void __launch_bounds__(LOB_TRACE_BLOCK, LOB_TRACE_OCC) trace_fast_ker
     }
     cb_claim_finish(S, prev);
 }
+// Agent::UpdateTraces with one LANE per book, for the books whose step leaves no older generation behind -- Watkins's
+// cut after an exploratory action (QLearn::UpdateTraces, agent.cpp:272-280: traces.decay(0.0)), or no traces yet --
+// and whose last_state has a memo slot with its 288 group-0 tiles on record and known to be distinct: the new
+// generation is then the chosen action's 32 tiles, all alive, copied from the slot's record (memo_kernel wrote them),
+// and nothing is looked up in any set.  At an exploration rate of 0.8 that is 7 books in 10; the others go on the list
+// of the wave-per-book kernel.  Same draws, same stores as learn_traces for these books.
+__global__ void __launch_bounds__(LOB_LIGHT_BLOCK) trace_light_kernel(DevParams P, DevState S, int lpar) {
+    // Slot claims of the combined update: thousands of books hold the very same generation, and compare-and-swaps on one
+    // address queue up behind each other.  The block elects one claimant per distinct generation first (LDS).
+    __shared__ u64 claimed[512];
+    for (int i = threadIdx.x; i < 512; i += LOB_LIGHT_BLOCK) claimed[i] = LOB_CB_EMPTY;
+    __syncthreads();
+    const int b = blockIdx.x * LOB_LIGHT_BLOCK + threadIdx.x;
+    if (b >= S.B) return;
+    const LHdr h = S.hdr[b];
+    if (!h.stepped) return;
+    LHdr* hp = S.hdr + b;
+    const int lslot = S.mk_slot_last[b];
+    f64 qs_last[LOB_N_ACTIONS];
+#pragma unroll
+    for (int a = 0; a < LOB_N_ACTIONS; a++) qs_last[a] = S.qs_last[(size_t)b * LOB_N_ACTIONS + a];
+    const int last = h.slot_cur ^ 1;
+    const bool zero_last = (h.zero_mask >> last) & 1;
+    const float4 vl = *reinterpret_cast<const float4*>(S.vars + (size_t)b * 48 + last * 16);
+    const int q0 = tile_quant(vl.x), q1 = tile_quant(vl.y), q2 = tile_quant(vl.z);
+    const int ls = lslot >= 0 ? lslot : 0;
+    const int4 lid = *reinterpret_cast<const int4*>(S.mk_ident + (size_t)ls * 4);
+    const int tiles_ok = S.mk_tiles_ok[ls];
+    Rng g{P.seed, P.book_id_offset + (u64)b, h.rng_ctr};
+    const int action = h.action;
+    const int amax = argmax_ties(qs_last, g);
+    int n_old = h.tr_n;
+    int kmax = P.trace_kmax;
+    if (action != amax) kmax = 1;
+    if (n_old > kmax - 1) n_old = kmax - 1;
+    const bool light = n_old == 0 && lslot >= 0 && !zero_last && lid.x == q0 && lid.y == q1 && lid.z == q2 && lid.w == 1 && tiles_ok != 0;
+    {   // (one atomic per wave: tens of thousands of lanes adding to one counter queue up behind each other)
+        const u64 mb = __ballot(!light);
+        if (mb) {
+            int base = 0;
+            const int leader = __builtin_ctzll(mb);
+            if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(&S.tr_list_n[lpar], __builtin_popcountll(mb));
+            base = __shfl(base, leader);
+            if (!light) {
+                S.tr_list[base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mb, 0u))] = b;
+                return;  // (nothing of the book has been touched)
+            }
+        }
+    }
+    const int G = P.trace_gens;
+    const int nh = (h.tr_head + 1) & (G - 1);
+    const int4* src = reinterpret_cast<const int4*>(S.mk_tiles + ((size_t)lslot * LOB_N_ACTIONS + action) * 32);
+    int4* dst = reinterpret_cast<int4*>(S.tr_idx + ((size_t)b * G + nh) * 32);
+    int4 tl[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) tl[i] = src[i];
+    // the generation's tiles are marked in the written-weights maps before the learn kernel looks (learn_traces): once
+    // per (triple, action), remembered in the slot
+    if (!((S.mk_marked[lslot] >> action) & 1u)) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) { nzx_mark(P, S, tl[i].x); nzx_mark(P, S, tl[i].y); nzx_mark(P, S, tl[i].z); nzx_mark(P, S, tl[i].w); }
+        atomicOr(&S.mk_marked[lslot], 1u << action);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) dst[i] = tl[i];
+    S.tr_alive[(size_t)b * G + nh] = 0xffffffffu;
+    hp->tr_head = nh;
+    hp->tr_n = 1;
+    hp->td = sel9(qs_last, action);  // Q(s, a), for the TD error
+    hp->rng_ctr = g.ctr;
+    if (P.combine) {
+        *reinterpret_cast<int4*>(S.tr_sig + ((size_t)b * G + nh) * 4) = make_int4(q0, q1, q2, action);
+        // (thousands of books hold this very generation: look before the compare-and-swap)
+        const u64 ch = cb_hash(q0, q1, q2, action, 0xffffffffu);
+        const u64 seen = atomicCAS((unsigned long long*)&claimed[(ch >> 40) & 511], (unsigned long long)LOB_CB_EMPTY, (unsigned long long)ch);
+        if (seen != ch && S.cb_key[(uint32_t)ch & (uint32_t)(S.cb_slots - 1)] != ch) {  // (not: another lane of the block claims it / it is claimed)
+            CbPending pend;
+            cb_claim_issue(S, pend, q0, q1, q2, action, 0xffffffffu, b * G + nh);
+            cb_claim_finish(S, pend);
+        }
+    }
+}
+
 __host__ __device__ inline size_t trace_lds_bytes() { return (size_t)(2048 + 32) * 4 + (size_t)LOB_TRACE_WAVES * 48 * 4 + (size_t)LOB_TRACE_WAVES * LOB_HSLOTS * 8; }
 
 // What a wave of the persistent kernels fetches of a book one loop iteration AHEAD (the loads of the next batch are

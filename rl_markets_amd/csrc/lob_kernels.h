@@ -1206,10 +1206,17 @@ __global__ void __launch_bounds__(256) memo_kernel(DevParams P, DevState S, cons
             sum = mod_add(sum, rnd_g[(j + 449 * 3) & 2047], M);
         }
         f64 t[5];
+        const bool fill = S.mk_tiles_ok[s] == 0;  // first time on a list: leave the tile indices for the trace kernel
 #pragma unroll
         for (int k = 0; k < 5; k++) {
             const int a = (hi ? 5 : 0) + k;
-            t[k] = a < LOB_N_ACTIONS ? S.theta[tile_index(sum, rnd_g[2048 + (a < LOB_N_ACTIONS ? a : 0)], M)] : 0.0;
+            const i32 tile = tile_index(sum, rnd_g[2048 + (a < LOB_N_ACTIONS ? a : 0)], M);
+            t[k] = a < LOB_N_ACTIONS ? S.theta[tile] : 0.0;
+            if (fill && a < LOB_N_ACTIONS) S.mk_tiles[((size_t)s * LOB_N_ACTIONS + a) * 32 + j] = tile;
+        }
+        if (fill && lane == 0) {
+            __threadfence();  // (read by a LATER kernel only; the flag just must not precede the tiles of another wave's view: one wave per slot)
+            S.mk_tiles_ok[s] = 1;
         }
 #pragma unroll
         for (int k = 0; k < 5; k++) {

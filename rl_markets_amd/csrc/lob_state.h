@@ -255,6 +255,10 @@ struct DevState {
     i32* mk_list;        // [2 parities][mk_slots] slots in use this step
     i32* mk_count;       // [2]
     f64* mk_rec;         // [2: theta_t for learn, theta_{t+1} for the next act][mk_slots][LOB_MK_REC]: S0[9], theta version tag
+    i32* mk_tiles;       // [mk_slots][9][32] the triple's 288 group-0 tile indices (action, tiling), written by memo_kernel the first time
+                         //   the slot is on a step's list: the lane-per-book trace kernel copies a generation from here
+    i32* mk_tiles_ok;    // [mk_slots] 1 once mk_tiles[slot] is filled
+    uint32_t* mk_marked; // [mk_slots] bit a: the 32 tiles of (triple, action a) are marked in the written-weights maps
     i32* mk_slot;        // [B] slot of the book's latest state (-1: none)
     i32* mk_slot_last;   // [B] slot of the state before that (the learner's last_state in the next step)
     i32 mk_slots;        // power of two
@@ -263,6 +267,8 @@ struct DevState {
     // the fast kernels hand back to the general ones.
     uint32_t* theta_nzx; // [M / 32 + 1]
     uint32_t* theta_nzc; // [cwords4 * 4]
+    i32* tr_list;        // [B] books the lane-per-book trace kernel leaves to the wave-per-book one
+    i32* tr_list_n;      // [2 parities]
     i32* slow_list;      // [2 kinds: act, learn][B]
     i32* slow_n;         // [2 parities][2 kinds]
     // Hit-list carry-over learn_q(t) -> act(t+1) (lob_fast.h act_light_kernel): the Q evaluation of the TD target and the

@@ -669,6 +669,44 @@ def test_q_lane_kernel_on_off_identical(monkeypatch, algo, mem, n_vars):
     np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-9, atol=1e-12)
 
 
+@pytest.mark.parametrize("mem,eps", [(1 << 12, 0.8), (1 << 22, 0.8), (1 << 22, 0.1)])
+def test_trace_light_kernel_on_off_identical(monkeypatch, mem, eps):
+    """Q(lambda): trace_light_kernel (a lane per book) serves the books whose step leaves no older trace generation
+    behind -- the new generation copied from the memo slot's tile record -- and hands the others to the wave-per-book
+    kernel; LOB_NO_TLIGHT=1 sends every book there.  Actions, TD errors, books and trace lists bit for bit; theta up
+    to its atomics' ordering.  A 4 096-weight table makes colliding tiles the rule (no slot is ever "known distinct")."""
+    B = 160
+    out = []
+    for off in ("1", "0"):
+        monkeypatch.setenv("LOB_NO_TLIGHT", off)
+        p, g, rec, eng, orc = make(depth=5, n_events=600, B=B, algo=abi.ALGO_QLAMBDA, theta_mode=abi.THETA_SHARED, mem=mem, epsilon=eps)
+        orc.close()
+        eng.reset()
+        trail = []
+        rng = np.random.default_rng(5)
+        for phase in range(2):
+            for n in (1, 1, 2, 5, 1, 9, 14, 3):
+                eng.td_step(n)
+                tr = [tuple(sorted(zip(*[x.tolist() for x in eng.traces(b)]))) for b in (0, 7, B - 1)]
+                trail.append((eng.last_actions().copy(), eng.last_td().copy(), bytes(eng.get_books()), tr))
+            eng.step(rng.integers(0, 9, size=B).astype(np.int32))
+            th = eng.theta()
+            th[::5] += 1e-3
+            eng.set_theta(th)
+        eng.reset()
+        for n in (1, 4, 10):
+            eng.td_step(n)
+            trail.append((eng.last_actions().copy(), eng.last_td().copy(), bytes(eng.get_books()), None))
+        out.append((trail, eng.theta()))
+        eng.close()
+    for k, ((a0, t0, b0, r0), (a1, t1, b1, r1)) in enumerate(zip(out[0][0], out[1][0])):
+        np.testing.assert_array_equal(a0, a1, err_msg="actions, record %d" % k)
+        assert b0 == b1, "books differ at record %d" % k
+        assert r0 == r1, "trace lists differ at record %d" % k
+        np.testing.assert_allclose(t0, t1, rtol=1e-9, atol=1e-12, err_msg="td, record %d" % k)
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-9, atol=1e-12)
+
+
 # ---- long streams: the market track as a ring, refilled while the episode runs ------------------------
 @pytest.mark.parametrize("ring,refill", [(256, 8), (512, 40)])
 def test_long_streams_use_a_track_ring(monkeypatch, ring, refill):
