@@ -377,6 +377,8 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
         if (rc == LOB_OK) rc = dev_alloc(e, &S.mk_tiles, P.memo ? ms * LOB_N_ACTIONS * 32 : 1);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.mk_tiles_ok, ms);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.mk_marked, ms);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.mk_marklist, ms);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.mk_markcount, 1);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.tr_list, B);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.tr_list_n, 2);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.mk_slot, B);
@@ -408,13 +410,16 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
             if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_fast_kernel<LOB_ALGO_SARSA, LOB_FAST_NB>, hipFuncAttributeMaxDynamicSharedMemorySize, q_lds);
             if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_fast_kernel<LOB_ALGO_QLAMBDA, LOB_FAST_NB>, hipFuncAttributeMaxDynamicSharedMemorySize, q_lds);
             const int ql_lds = (int)qlane_lds_bytes(P.cwords4);
-            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_lane_kernel<LOB_ALGO_SARSA, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, ql_lds);
-            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_lane_kernel<LOB_ALGO_QLAMBDA, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, ql_lds);
-            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_lane_kernel<LOB_ALGO_SARSA, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, ql_lds);
-            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_lane_kernel<LOB_ALGO_QLAMBDA, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, ql_lds);
-            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)trace_fast_kernel<LOB_ALGO_SARSA, false>, hipFuncAttributeMaxDynamicSharedMemorySize, tr_lds);
-            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)trace_fast_kernel<LOB_ALGO_QLAMBDA, false>, hipFuncAttributeMaxDynamicSharedMemorySize, tr_lds);
-            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)trace_fast_kernel<LOB_ALGO_QLAMBDA, true>, hipFuncAttributeMaxDynamicSharedMemorySize, tr_lds);
+            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_lane_kernel<LOB_ALGO_SARSA, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ql_lds);
+            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_lane_kernel<LOB_ALGO_QLAMBDA, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ql_lds);
+            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_lane_kernel<LOB_ALGO_SARSA, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ql_lds);
+            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_lane_kernel<LOB_ALGO_QLAMBDA, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ql_lds);
+            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_lane_kernel<LOB_ALGO_QLAMBDA, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ql_lds);
+            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_lane_kernel<LOB_ALGO_QLAMBDA, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ql_lds);
+            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)trace_fast_kernel<LOB_ALGO_SARSA, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, tr_lds);
+            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)trace_fast_kernel<LOB_ALGO_QLAMBDA, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, tr_lds);
+            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)trace_fast_kernel<LOB_ALGO_QLAMBDA, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, tr_lds);
+            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)trace_fast_kernel<LOB_ALGO_QLAMBDA, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, tr_lds);
             if (er != hipSuccess && rc == LOB_OK) { lob_set_error(std::string("hipFuncSetAttribute(dynamic LDS): ") + hipGetErrorString(er)); rc = LOB_EHIP; }
         }
     }
@@ -824,29 +829,34 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode) {
             if (fast) launch_memo(e, par, mode == 0 ? 0 : 1);  // learner: S0 under theta_t for learn_kernel; backtester: for the next act
             if (mode == 0 && fast) {
                 const bool tl = e->P.algo == LOB_ALGO_QLAMBDA && e->t_light;
-                if (tl) {
+                // Q(s', .) + TD error: a lane per book once the batch gives every CU a full block of them, else a wave per book
+                const bool lanes = e->q_lanes >= 0 ? e->q_lanes == 1 : nb >= LOB_QL_BLOCK * e->n_cus / 2;
+                // ... and then the lane kernel also takes the trace step of the books it can (those left go on a list for the
+                // wave-per-book trace kernel, which runs AFTER it)
+                static const bool no_fuse = getenv("LOB_NO_FUSE") && getenv("LOB_NO_FUSE")[0] == '1';  // (A/B switch)
+                const bool fuse = tl && lanes && !no_fuse;
+                const int gt = std::min((4 * LOB_TRACE_OCC / LOB_TRACE_WAVES) * e->n_cus, (nb + LOB_TRACE_WAVES - 1) / LOB_TRACE_WAVES);
+                const int sid = e->step_id;
+                if (tl && !fuse) {
                     // a lane per book where the step leaves no older generation behind, the wave-per-book kernel for the rest
                     TimedLaunch t(e, "trace_light_kernel", st);
                     hipLaunchKernelGGL(trace_light_kernel, dim3((nb + LOB_LIGHT_BLOCK - 1) / LOB_LIGHT_BLOCK), dim3(LOB_LIGHT_BLOCK), 0, st, e->P, e->S, lpar);
                 }
-                {
+                if (!fuse) {
                     TimedLaunch t(e, "trace_kernel", st);
-                    const int gt = std::min((4 * LOB_TRACE_OCC / LOB_TRACE_WAVES) * e->n_cus, (nb + LOB_TRACE_WAVES - 1) / LOB_TRACE_WAVES);
-                    if (tl) {
-                        hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_QLAMBDA, true>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, e->P, e->S, rnd, par, lpar);
-                    } else if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_QLAMBDA, false>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, e->P, e->S, rnd, par, lpar);
-                    else hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_SARSA, false>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, e->P, e->S, rnd, par, lpar);
+                    if (tl) hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_QLAMBDA, 1>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, e->P, e->S, rnd, par, lpar, sid);
+                    else if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_QLAMBDA, 0>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, e->P, e->S, rnd, par, lpar, sid);
+                    else hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_SARSA, 0>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, e->P, e->S, rnd, par, lpar, sid);
                 }
                 {
                     TimedLaunch t(e, "learn_kernel", st);
-                    // a lane per book once the batch gives every CU a full block of them; else a wave per book
-                    const bool lanes = e->q_lanes >= 0 ? e->q_lanes == 1 : nb >= LOB_QL_BLOCK * e->n_cus / 2;
                     if (lanes) {
                         const int gq = std::min(e->n_cus, (nb + LOB_QL_BLOCK - 1) / LOB_QL_BLOCK);
                         const size_t lds = qlane_lds_bytes(e->P.cwords4);
-#define LOB_QL_LAUNCH(A, VT) hipLaunchKernelGGL((learn_q_lane_kernel<A, VT>), dim3(gq), dim3(LOB_QL_BLOCK), lds, st, e->P, e->S, rnd, lpar, ver)
-                        if (e->P.algo == LOB_ALGO_QLAMBDA) { if (e->P.V == 8) LOB_QL_LAUNCH(LOB_ALGO_QLAMBDA, 8); else LOB_QL_LAUNCH(LOB_ALGO_QLAMBDA, 0); }
-                        else { if (e->P.V == 8) LOB_QL_LAUNCH(LOB_ALGO_SARSA, 8); else LOB_QL_LAUNCH(LOB_ALGO_SARSA, 0); }
+#define LOB_QL_LAUNCH(A, VT, TR) hipLaunchKernelGGL((learn_q_lane_kernel<A, VT, TR>), dim3(gq), dim3(LOB_QL_BLOCK), lds, st, e->P, e->S, rnd, lpar, ver, sid)
+                        if (fuse) { if (e->P.V == 8) LOB_QL_LAUNCH(LOB_ALGO_QLAMBDA, 8, true); else LOB_QL_LAUNCH(LOB_ALGO_QLAMBDA, 0, true); }
+                        else if (e->P.algo == LOB_ALGO_QLAMBDA) { if (e->P.V == 8) LOB_QL_LAUNCH(LOB_ALGO_QLAMBDA, 8, false); else LOB_QL_LAUNCH(LOB_ALGO_QLAMBDA, 0, false); }
+                        else { if (e->P.V == 8) LOB_QL_LAUNCH(LOB_ALGO_SARSA, 8, false); else LOB_QL_LAUNCH(LOB_ALGO_SARSA, 0, false); }
 #undef LOB_QL_LAUNCH
                     } else if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL((learn_q_fast_kernel<LOB_ALGO_QLAMBDA, LOB_FAST_NB>), dim3(gf), dim3(LOB_FAST_BLOCK), fast_lds_bytes(e->P.cwords4, LOB_FAST_NB, false), st, e->P, e->S, rnd, lpar, ver);
                     else hipLaunchKernelGGL((learn_q_fast_kernel<LOB_ALGO_SARSA, LOB_FAST_NB>), dim3(gf), dim3(LOB_FAST_BLOCK), fast_lds_bytes(e->P.cwords4, LOB_FAST_NB, false), st, e->P, e->S, rnd, lpar, ver);
@@ -855,6 +865,10 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode) {
                     TimedLaunch t(e, "learn_rest_kernel", st);
                     if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL(learn_q_rest_kernel<LOB_ALGO_QLAMBDA>, dim3(gl), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, learn_list, learn_n);
                     else hipLaunchKernelGGL(learn_q_rest_kernel<LOB_ALGO_SARSA>, dim3(gl), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, learn_list, learn_n);
+                }
+                if (fuse) {
+                    TimedLaunch t(e, "trace_kernel", st);
+                    hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_QLAMBDA, 2>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, e->P, e->S, rnd, par, lpar, sid);
                 }
             } else if (mode == 0) {
                 TimedLaunch t(e, "learn_kernel", st);

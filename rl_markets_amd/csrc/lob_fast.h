@@ -338,8 +338,35 @@ __global__ void __launch_bounds__(LOB_FAST_BLOCK) act_fast_kernel(DevParams P, D
                 hp->stepped = 1;
                 hp->rng_ctr = g.ctr;
             }
+            // (as act_light_kernel: the chosen action's 32 group-0 tiles are marked before the learn kernel looks)
+            if (mode == 0 && S.mk_tiles_ok[mslot[k]] && !((S.mk_marked[mslot[k]] >> action) & 1u)) {
+                if (lane < 32) nzx_mark(P, S, S.mk_tiles[((size_t)mslot[k] * LOB_N_ACTIONS + action) * 32 + lane]);
+                if (lane == 0) atomicOr(&S.mk_marked[mslot[k]], 1u << action);
+            }
         }
         pf.mark(5);  // policy + stores
+    }
+}
+
+// One lane marks the 32 group-0 tiles of (memo slot, action) in the written-weights maps (nzx_mark): all tile
+// loads, then all map words, in flight together -- a lane alone would otherwise walk 32 dependent round trips.
+__device__ __forceinline__ void mark_generation(const DevParams& P, const DevState& S, int slot, int action) {
+    const int4* src = reinterpret_cast<const int4*>(S.mk_tiles + ((size_t)slot * LOB_N_ACTIONS + action) * 32);
+    int4 t[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) t[i] = src[i];
+    uint32_t w[32];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        w[4 * i + 0] = S.theta_nzx[(uint32_t)t[i].x >> 5]; w[4 * i + 1] = S.theta_nzx[(uint32_t)t[i].y >> 5];
+        w[4 * i + 2] = S.theta_nzx[(uint32_t)t[i].z >> 5]; w[4 * i + 3] = S.theta_nzx[(uint32_t)t[i].w >> 5];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const i32 f[4] = {t[i].x, t[i].y, t[i].z, t[i].w};
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (!((w[4 * i + k] >> ((uint32_t)f[k] & 31)) & 1u)) nzx_mark(P, S, f[k]);
     }
 }
 
@@ -375,8 +402,13 @@ __global__ void __launch_bounds__(LOB_LIGHT_BLOCK) act_light_kernel(DevParams P,
     const int n = l0.x == LOB_HL_NONE ? -1 : (int)l0.x;
     bool ok = !dirty && !((h.zero_mask >> (cur ^ 1)) & 1) && mslot >= 0 && n >= 0;
     f64 q[LOB_N_ACTIONS];
+    uint32_t marked = 0x1ffu;
     if (ok) {
+        // (the memo record and the slot's mark bits leave together)
         const MemoRec rec = *reinterpret_cast<const MemoRec*>(S.mk_rec + ((size_t)S.mk_slots + mslot) * LOB_MK_REC);  // [1]: after the last update
+        const int tiles_ok = S.mk_tiles_ok[mslot];
+        const uint32_t mk = S.mk_marked[mslot];
+        marked = tiles_ok ? mk : 0x1ffu;
         ok = rec.ver == ver;
 #pragma unroll
         for (int a = 0; a < LOB_N_ACTIONS; a++) q[a] = rec.s0[a];
@@ -421,6 +453,15 @@ __global__ void __launch_bounds__(LOB_LIGHT_BLOCK) act_light_kernel(DevParams P,
     hp->action = action;
     hp->stepped = 1;
     hp->rng_ctr = g.ctr;
+    // The tiles the trace generation of (this state, this action) will write are marked in the written-weights maps NOW,
+    // before this step's learn kernel looks at the maps (see learn_traces): once per (triple, action), remembered in the slot.
+    // (by memo_kernel, a lane per tile: a lane here would hold its whole wave up over a few round trips)
+    if (!((marked >> action) & 1u)) {
+        const int pos = atomicAdd(&S.mk_markcount[0], 1);
+        if (pos < S.mk_slots) S.mk_marklist[pos] = mslot * 16 + action;
+        else mark_generation(P, S, mslot, action);
+        atomicOr(&S.mk_marked[mslot], 1u << action);
+    }
     const u64 act = __ballot(1);
     if ((int)(threadIdx.x & 63) == __builtin_ctzll(act)) atomicAdd((unsigned long long*)&S.counters[5], (unsigned long long)__builtin_popcountll(act));
 }
@@ -430,9 +471,14 @@ __global__ void __launch_bounds__(LOB_LIGHT_BLOCK) act_light_kernel(DevParams P,
 // (learn_q_fast_kernel).  Persistent 16-wave blocks, two per CU (75 KB of LDS each: the hash table and a
 // 4 KB tile map per wave).  A book's slot claims are resolved one book later, so that their CAS round
 // trips overlap the next book's work.
-// LIST: only the books the lane-per-book kernel (trace_light_kernel, below) left on the list `tr_list`.
-template <int ALGO, bool LIST>
-__global__ void __launch_bounds__(LOB_TRACE_BLOCK, LOB_TRACE_OCC) trace_fast_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g, int par, int lpar) {
+// LIST 1: only the books the lane-per-book kernel (trace_light_kernel, below) left on the list `tr_list`.
+// LIST 2: the same list left by learn_q_lane_kernel<.., TR = true>, which has ALREADY run for this step: the entries
+// carry argmax Q(s, .) (its draws are made), Q(s, a) and the RNG counter are the learn kernel's business, marks are late.
+#define LOB_TRL_BOOK(x) ((x) & 0x7ffffff)
+#define LOB_TRL_AMAX(x) ((int)((uint32_t)(x) >> 27))
+template <int ALGO, int LIST>
+__global__ void __launch_bounds__(LOB_TRACE_BLOCK, LOB_TRACE_OCC) trace_fast_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g, int par, int lpar,
+                                                                                    int sid) {
     extern __shared__ __align__(16) unsigned char fast_lds_raw[];
     // this step's update appends to nz_new[par]; the list the general act path reads is nz_new[par ^ 1]
     if (blockIdx.x == 0 && threadIdx.x < LOB_NZ_WORDS) {
@@ -457,7 +503,8 @@ __global__ void __launch_bounds__(LOB_TRACE_BLOCK, LOB_TRACE_OCC) trace_fast_ker
     for (int t = blockIdx.x * LOB_TRACE_WAVES + w; t < n_todo; t += gridDim.x * LOB_TRACE_WAVES) {
         asm volatile("" : "+v"(lane_));
         const int lane = lane_;
-        const int b = __builtin_amdgcn_readfirstlane(LIST ? S.tr_list[t] : t);
+        const int ent = __builtin_amdgcn_readfirstlane(LIST ? S.tr_list[t] : t);
+        const int b = LIST == 2 ? LOB_TRL_BOOK(ent) : ent;
         const LHdr h = S.hdr[b];
         const int lslot = P.memo ? S.mk_slot_last[b] : -1;  // memo slot of last_state's group-0 triple (checked below)
         f64 qs_last[LOB_N_ACTIONS];
@@ -478,9 +525,10 @@ __global__ void __launch_bounds__(LOB_TRACE_BLOCK, LOB_TRACE_OCC) trace_fast_ker
         Rng g{P.seed, P.book_id_offset + (u64)b, h.rng_ctr};
         CbPending pend;
         bool dup = false;
-        learn_traces<ALGO>(P, S, b, h, rnd, act_terms, tab, false, vars + last * 16, zero_last, qs_last, g, lane, pend, pf, lmatch ? lid.w : 0, &dup);
+        learn_traces<ALGO>(P, S, b, h, rnd, act_terms, tab, false, vars + last * 16, zero_last, qs_last, g, lane, pend, pf, lmatch ? lid.w : 0, &dup,
+                           LIST == 2 ? LOB_TRL_AMAX(ent) : -1, LIST == 2 ? sid : -1);
         if (lmatch && lid.w == 0 && lane == 0) S.mk_ident[(size_t)lslot * 4 + 3] = dup ? 2 : 1;  // (every wave that gets here writes the same value)
-        if (lane == 0) {
+        if (LIST != 2 && lane == 0) {
             LHdr* hp = S.hdr + b;
             hp->td = sel9(qs_last, h.action);  // Q(s, a), for the TD error
             hp->rng_ctr = g.ctr;
@@ -770,10 +818,17 @@ __device__ __forceinline__ void ql_group(const DevParams& P, const DevState& S, 
     }
 }
 
-template <int ALGO, int VT>
-__global__ void __launch_bounds__(LOB_QL_BLOCK) learn_q_lane_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g, int lpar, u64 ver) {
+// TR (Q(lambda)): the kernel also runs Agent::UpdateTraces for its books, BEFORE the Q evaluation as the reference does
+// (its argmax draws come first): the light case of trace_light_kernel right here, the others through the list
+// `tr_list` to trace_fast_kernel<.., 2>, which runs after this kernel (the entry carries argmax Q(s, .); Q(s, a) and
+// the RNG counter are settled here).  The look-ups of the trace part are issued at the top and consumed after the
+// tile walk, whose arithmetic hides them.
+template <int ALGO, int VT, bool TR>
+__global__ void __launch_bounds__(LOB_QL_BLOCK) learn_q_lane_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g, int lpar, u64 ver, int sid) {
     static_assert(ALGO == LOB_ALGO_SARSA || ALGO == LOB_ALGO_QLAMBDA, "one weight vector");
+    static_assert(!TR || ALGO == LOB_ALGO_QLAMBDA, "the fused trace step is Watkins's");
     extern __shared__ __align__(16) unsigned char fast_lds_raw[];
+    __shared__ u64 claimed[512];  // (as trace_light_kernel)
     uint32_t* rnd = reinterpret_cast<uint32_t*>(fast_lds_raw);
     uint32_t* act_terms = rnd + 2048;
     uint32_t* coarse = act_terms + 32;
@@ -781,18 +836,58 @@ __global__ void __launch_bounds__(LOB_QL_BLOCK) learn_q_lane_kernel(DevParams P,
     for (int i = threadIdx.x; i < 512; i += LOB_QL_BLOCK) reinterpret_cast<uint4*>(rnd)[i] = reinterpret_cast<const uint4*>(rnd_g)[i];
     if (threadIdx.x < 27) act_terms[threadIdx.x] = rnd_g[2048 + threadIdx.x];
     for (int i = threadIdx.x; i < P.cwords4; i += LOB_QL_BLOCK) reinterpret_cast<uint4*>(coarse)[i] = reinterpret_cast<const uint4*>(S.theta_nzc)[i];
+    if (TR) for (int i = threadIdx.x; i < 512; i += LOB_QL_BLOCK) claimed[i] = LOB_CB_EMPTY;
     __syncthreads();
 #pragma unroll 1
     for (int b = blockIdx.x * LOB_QL_BLOCK + threadIdx.x; b < S.B; b += gridDim.x * LOB_QL_BLOCK) {
+        // everything whose address does not depend on the header leaves with it (both State rows: which is which comes with the header)
         const LHdr h = S.hdr[b];
+        const int mslot = S.mk_slot[b];
+        const int lslot_ = TR ? S.mk_slot_last[b] : -1;
+        float4 vr[2][4];
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) vr[r][i] = reinterpret_cast<const float4*>(S.vars + (size_t)b * 48 + r * 16)[i];
+        f64 qs_last[LOB_N_ACTIONS];
+#pragma unroll
+        for (int a = 0; a < LOB_N_ACTIONS; a++) qs_last[a] = TR ? S.qs_last[(size_t)b * LOB_N_ACTIONS + a] : 0.0;
         LHdr* hp = S.hdr + b;
         u64* recp = S.hl_rec + (size_t)b * LOB_HL_REC;
         if (!h.stepped) { recp[0] = LOB_HL_NONE; continue; }
-        const int mslot = S.mk_slot[b];
+        Rng g{P.seed, P.book_id_offset + (u64)b, h.rng_ctr};
+        // ---- UpdateTraces, first half: the decisions (QLearn::UpdateTraces, agent.cpp:272-280) ----
+        f64 q_sa = h.td;
+        int amax = 0, lslot = -1, tq0 = 0, tq1 = 0, tq2 = 0;
+        bool tlight = false;
+        uint32_t tmarked = 0;
+        int4 tl[8];  // the new generation's tiles (light case), fetched before the tile walk, stored after it
+        if (TR) {
+            lslot = lslot_;
+            const int last = h.slot_cur ^ 1;
+            const bool zero_last = (h.zero_mask >> last) & 1;
+            const float4 vl = last ? vr[1][0] : vr[0][0];
+            tq0 = tile_quant(vl.x); tq1 = tile_quant(vl.y); tq2 = tile_quant(vl.z);
+            const int ls = lslot >= 0 ? lslot : 0;
+            const int4 lid = *reinterpret_cast<const int4*>(S.mk_ident + (size_t)ls * 4);
+            const int tiles_ok = S.mk_tiles_ok[ls];
+            tmarked = S.mk_marked[ls];
+            amax = argmax_ties(qs_last, g);
+            int n_old = h.tr_n, kmax = P.trace_kmax;
+            if (h.action != amax) kmax = 1;
+            if (n_old > kmax - 1) n_old = kmax - 1;
+            tlight = n_old == 0 && lslot >= 0 && !zero_last && lid.x == tq0 && lid.y == tq1 && lid.z == tq2 && lid.w == 1 && tiles_ok != 0;
+            q_sa = sel9(qs_last, h.action);
+            if (tlight) {
+                const int4* src = reinterpret_cast<const int4*>(S.mk_tiles + ((size_t)lslot * LOB_N_ACTIONS + h.action) * 32);
+#pragma unroll
+                for (int i = 0; i < 8; i++) tl[i] = src[i];
+            }
+        }
         int q[LOB_MAX_VARS];
         {
-            const float4* vp = reinterpret_cast<const float4*>(S.vars + (size_t)b * 48 + h.slot_cur * 16);
-            const float4 v0 = vp[0], v1 = vp[1], v2 = vp[2], v3 = vp[3];
+            const bool c1 = h.slot_cur != 0;
+            const float4 v0 = c1 ? vr[1][0] : vr[0][0], v1 = c1 ? vr[1][1] : vr[0][1], v2 = c1 ? vr[1][2] : vr[0][2], v3 = c1 ? vr[1][3] : vr[0][3];
             const f32 v[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
 #pragma unroll
             for (int i = 0; i < LOB_MAX_VARS; i++) q[i] = tile_quant(v[i]);
@@ -819,10 +914,50 @@ __global__ void __launch_bounds__(LOB_QL_BLOCK) learn_q_lane_kernel(DevParams P,
             if (n <= LOB_HL_CAP) ql_group<2, VT>(P, S, rnd, act_terms, coarse, q, row, n);
             ok = n <= LOB_HL_CAP;
         }
+        // ---- UpdateTraces, second half ----
+        CbPending pend;
+        pend.active = false;
+        if (TR) {
+            const u64 mb = __ballot(!tlight);  // (one atomic per wave for the list)
+            if (mb) {
+                int base = 0;
+                const int leader = __builtin_ctzll(mb);
+                if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(&S.tr_list_n[lpar], __builtin_popcountll(mb));
+                base = __shfl(base, leader);
+                if (!tlight) S.tr_list[base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mb, 0u))] = b | (amax << 27);
+            }
+            if (tlight) {  // the new generation = the chosen action's 32 tiles, all alive, from the memo slot's record
+                const int action = h.action;
+                const int G = P.trace_gens;
+                const int nh = (h.tr_head + 1) & (G - 1);
+                int4* dst = reinterpret_cast<int4*>(S.tr_idx + ((size_t)b * G + nh) * 32);
+                if (!((tmarked >> action) & 1u)) {  // (the act kernel marks them; if it could not, the marks are late)
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        nzx_mark_late(P, S, tl[i].x, sid); nzx_mark_late(P, S, tl[i].y, sid); nzx_mark_late(P, S, tl[i].z, sid); nzx_mark_late(P, S, tl[i].w, sid);
+                    }
+                    atomicOr(&S.mk_marked[lslot], 1u << action);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; i++) dst[i] = tl[i];
+                S.tr_alive[(size_t)b * G + nh] = 0xffffffffu;
+                hp->tr_head = nh;
+                hp->tr_n = 1;
+                if (P.combine) {
+                    *reinterpret_cast<int4*>(S.tr_sig + ((size_t)b * G + nh) * 4) = make_int4(tq0, tq1, tq2, action);
+                    const u64 ch = cb_hash(tq0, tq1, tq2, action, 0xffffffffu);
+                    const u64 seen = atomicCAS((unsigned long long*)&claimed[(ch >> 40) & 511], (unsigned long long)LOB_CB_EMPTY, (unsigned long long)ch);
+                    if (seen != ch && S.cb_key[(uint32_t)ch & (uint32_t)(S.cb_slots - 1)] != ch)
+                        cb_claim_issue(S, pend, tq0, tq1, tq2, action, 0xffffffffu, b * G + nh);  // (its answer is looked at last)
+                }
+            }
+        }
         if (!ok) {  // no (valid) memo record, or a list longer than a record: the general kernel takes the book
+            if (TR) { hp->td = q_sa; hp->rng_ctr = g.ctr; }  // (what it expects of the trace step)
             const int pos = atomicAdd(&S.slow_n[lpar * 2 + 1], 1);
             S.slow_list[(size_t)S.B + pos] = b;
             recp[0] = LOB_HL_NONE;
+            cb_claim_finish(S, pend);
             continue;
         }
         f64 qs[LOB_N_ACTIONS];
@@ -845,10 +980,10 @@ __global__ void __launch_bounds__(LOB_QL_BLOCK) learn_q_lane_kernel(DevParams P,
                 for (int c = 0; c < LOB_N_ACTIONS; c++) qs[c] = a == c ? qs[c] + x : qs[c];
             }
         }
-        Rng g{P.seed, P.book_id_offset + (u64)b, h.rng_ctr};
-        learn_delta_single<ALGO>(P, hp, h, qs, h.td, g, 0);
+        learn_delta_single<ALGO>(P, hp, h, qs, q_sa, g, 0);
         recp[0] = (u64)n;
         for (int i = 0; i < n; i++) recp[1 + i] = row[1 + i];
+        cb_claim_finish(S, pend);
     }
 }
 

@@ -521,6 +521,7 @@ __device__ inline u64 vd_tag(uint32_t epoch, int slot) { return (u64)epoch | ((u
 // mode 1: Backtester::_step prologue (no swap, greedy action on the current state)
 // ALGO is a compile-time parameter: the double-Q path needs a second weight vector and more
 // registers; keeping it out of the SARSA / Q(lambda) instantiations keeps them small.
+__device__ inline bool nzx_mark(const DevParams& P, const DevState& S, i32 f);
 template <int ALGO>
 __device__ __forceinline__ void act_book(const DevParams& P, const DevState& S, LearnLds& L, int w, int lane, int b, int mode, int par) {
     const LHdr h = S.hdr[b];  // one scalar 64-byte load
@@ -573,6 +574,19 @@ __device__ __forceinline__ void act_book(const DevParams& P, const DevState& S, 
         hp->action = action;
         hp->stepped = 1;
         hp->rng_ctr = g.ctr;
+    }
+    // fast path (this kernel then serves the books handed back by its act kernels): the chosen action's 32 group-0
+    // tiles are marked in the written-weights maps before the learn kernel looks, as those kernels do
+    if (P.memo && mode == 0 && !zero) {
+        const int ms = S.mk_slot[b];
+        if (ms >= 0 && S.mk_tiles_ok[ms] && !((S.mk_marked[ms] >> action) & 1u)) {
+            const int4 id = *reinterpret_cast<const int4*>(S.mk_ident + (size_t)ms * 4);
+            const f32* v = L.vars[w][src];
+            if (id.x == tile_quant(v[0]) && id.y == tile_quant(v[1]) && id.z == tile_quant(v[2])) {
+                if (lane < 32) nzx_mark(P, S, S.mk_tiles[((size_t)ms * LOB_N_ACTIONS + action) * 32 + lane]);
+                if (lane == 0) atomicOr(&S.mk_marked[ms], 1u << action);
+            }
+        }
     }
 }
 
@@ -659,7 +673,7 @@ __device__ inline unsigned trace_step(uint32_t x) { return ((x >> 9) ^ (x << 3) 
 template <int ALGO>
 __device__ __forceinline__ void learn_traces(const DevParams& P, const DevState& S, int b, const LHdr& h, const uint32_t* rnd, const uint32_t* act_terms,
                                     u64* tab, bool init_tab, const f32* vars_from, bool zero_last, const f64* qs_last, Rng& g, int lane,
-                                    CbPending& pend, Prof& pf, int dup_flag = 0, bool* dup_out = nullptr) {
+                                    CbPending& pend, Prof& pf, int dup_flag = 0, bool* dup_out = nullptr, int amax_given = -1, int late_sid = -1) {
     LHdr* hp = S.hdr + b;
     const int action = h.action;
     // ---- group-0 tiles of last_state for all nine actions: lane -> (a = half + 2k, j) ----
@@ -680,7 +694,8 @@ __device__ __forceinline__ void learn_traces(const DevParams& P, const DevState&
     const int head = h.tr_head;
     int kmax = P.trace_kmax;
     if (ALGO == LOB_ALGO_QLAMBDA || ALGO == LOB_ALGO_DOUBLE_Q) {
-        const int amax = argmax_ties(qs_last, g);  // QLearn / DoubleQLearn::UpdateTraces (agent.cpp:272-280, 319-327)
+        // QLearn / DoubleQLearn::UpdateTraces (agent.cpp:272-280, 319-327); `amax_given`: the learn kernel ran first and made the draws
+        const int amax = amax_given >= 0 ? amax_given : argmax_ties(qs_last, g);
         if (action != amax) kmax = 1;              // traces.decay(0.0)
     }
     if (n_old > kmax - 1) n_old = kmax - 1;        // generations whose eligibility fell below tolerance
@@ -812,7 +827,12 @@ __device__ __forceinline__ void learn_traces(const DevParams& P, const DevState&
         // fast path: the tiles this generation will write are marked in the written-weights maps NOW, before the
         // learn kernel evaluates Q(s', .) -- the set of group-1/2 tiles of s' that fall on a marked weight is then
         // the same for that evaluation and for the next step's action selection (hit lists, lob_state.h)
-        if (P.memo && half == 0 && !dead) nzx_mark(P, S, N);
+        // (`late_sid`: this kernel runs AFTER the learn kernel of step late_sid -- the act kernel has marked the tiles, and a
+        // bit that still flips here voids the hit lists)
+        if (P.memo && half == 0 && !dead) {
+            if (late_sid >= 0) nzx_mark_late(P, S, N, late_sid);
+            else nzx_mark(P, S, N);
+        }
         if (lane == 0) {
             tr_alive[nh] = (uint32_t)m;
             hp->tr_head = nh;
@@ -1234,6 +1254,18 @@ __global__ void __launch_bounds__(256) memo_kernel(DevParams P, DevState S, cons
         if (lane == LOB_N_ACTIONS) reinterpret_cast<u64*>(rec)[LOB_N_ACTIONS] = ver;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local");
         __builtin_amdgcn_wave_barrier();
+    }
+    // the (triple, action) pairs this step's act_light_kernel met for the first time: their 32 tiles are marked in the
+    // written-weights maps here, a lane per tile, before the learn kernel looks (see learn_traces)
+    if (which == 0) {
+        int nm = S.mk_markcount[0];
+        if (nm > S.mk_slots) nm = S.mk_slots;
+        for (int i = wave; i < nm; i += n_waves) {
+            const int e = S.mk_marklist[i];
+            if (lane < 32) nzx_mark(P, S, S.mk_tiles[((size_t)(e >> 4) * LOB_N_ACTIONS + (e & 15)) * 32 + lane]);
+        }
+    } else if (blockIdx.x == 0 && threadIdx.x == 0) {
+        S.mk_markcount[0] = 0;
     }
 }
 

@@ -259,6 +259,8 @@ struct DevState {
                          //   the slot is on a step's list: the lane-per-book trace kernel copies a generation from here
     i32* mk_tiles_ok;    // [mk_slots] 1 once mk_tiles[slot] is filled
     uint32_t* mk_marked; // [mk_slots] bit a: the 32 tiles of (triple, action a) are marked in the written-weights maps
+    i32* mk_marklist;    // [mk_slots] (slot * 16 + action) pairs whose tiles act_light_kernel wants marked: memo_kernel (which 0) does it,
+    i32* mk_markcount;   // [1]          a wave per pair, before the learn kernel looks; reset by memo_kernel (which 1)
     i32* mk_slot;        // [B] slot of the book's latest state (-1: none)
     i32* mk_slot_last;   // [B] slot of the state before that (the learner's last_state in the next step)
     i32 mk_slots;        // power of two

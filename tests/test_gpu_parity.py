@@ -669,16 +669,20 @@ def test_q_lane_kernel_on_off_identical(monkeypatch, algo, mem, n_vars):
     np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-9, atol=1e-12)
 
 
+@pytest.mark.parametrize("lanes", ["0", "1"])
 @pytest.mark.parametrize("mem,eps", [(1 << 12, 0.8), (1 << 22, 0.8), (1 << 22, 0.1)])
-def test_trace_light_kernel_on_off_identical(monkeypatch, mem, eps):
+def test_trace_light_kernel_on_off_identical(monkeypatch, mem, eps, lanes):
     """Q(lambda): trace_light_kernel (a lane per book) serves the books whose step leaves no older trace generation
     behind -- the new generation copied from the memo slot's tile record -- and hands the others to the wave-per-book
     kernel; LOB_NO_TLIGHT=1 sends every book there.  Actions, TD errors, books and trace lists bit for bit; theta up
-    to its atomics' ordering.  A 4 096-weight table makes colliding tiles the rule (no slot is ever "known distinct")."""
+    to its atomics' ordering.  A 4 096-weight table makes colliding tiles the rule (no slot is ever "known distinct").
+    `lanes` 1: with the lane-per-book learn kernel the light trace step is part of THAT kernel (learn_q_lane_kernel<.., TR>)
+    and the wave-per-book trace kernel runs after it on the books it left (trace_fast_kernel<.., 2>)."""
     B = 160
     out = []
     for off in ("1", "0"):
         monkeypatch.setenv("LOB_NO_TLIGHT", off)
+        monkeypatch.setenv("LOB_Q_LANES", "0" if off == "1" else lanes)
         p, g, rec, eng, orc = make(depth=5, n_events=600, B=B, algo=abi.ALGO_QLAMBDA, theta_mode=abi.THETA_SHARED, mem=mem, epsilon=eps)
         orc.close()
         eng.reset()
