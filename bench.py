@@ -39,7 +39,7 @@ def algorithmic_bytes(kernel, depth, trades, n_vars, n_live, events_per_step):
     rec = 4 * ((2 + 4 * depth + 2 * trades + 3) // 4 * 4)
     hdr = 64                          # learner header, one 64-byte record per book
     if kernel == "trace_kernel":      # UpdateTraces: header + state slots + Q(last,.) in; trace index list r/w, new generation + masks, header out
-        return hdr + 192 + 9 * 8 + n_live * 4 + 32 * 4 + 26 * 4 + 32
+        return hdr + 192 + 9 * 8 + n_live * 4 + 32 * 4 + 26 * 4 + 32   # (all books: the step's trace work, whichever kernels share it)
     if kernel == "act_kernel":        # header + 3 state slots in, 9*96 weights (f64), Q(last,.) + header out
         return hdr + 192 + 9 * 96 * 8 + 9 * 8 + 32
     if kernel == "learn_kernel":      # Q(s', .) + TD error: header + slots in, 9*96 weights, header out (the traces are trace_kernel's)
@@ -60,6 +60,7 @@ def algorithmic_bytes(kernel, depth, trades, n_vars, n_live, events_per_step):
 
 # timer name (lob_kernel_time_ms) -> kernel function(s) launched under it, as rocprofv3 names them
 TIMER_KERNELS = {"act_kernel": ("act_light_kernel", "act_fast_kernel", "act_kernel"), "trace_kernel": ("trace_fast_kernel",),
+                 "trace_light_kernel": ("trace_light_kernel",),
                  "learn_kernel": ("learn_q_lane_kernel", "learn_q_fast_kernel", "learn_kernel"), "act_rest_kernel": (), "learn_rest_kernel": ()}
 
 
@@ -260,10 +261,18 @@ def main():
         roofline = None
         if ktimes:
             per_kernel = {}
+            # Agent::UpdateTraces of a step is shared by up to three kernels (the light case inside the lane-per-book learn
+            # kernel or in trace_light_kernel, the rest in the wave-per-book trace kernel): the step's trace bytes are set
+            # against the time of the kernels that do nothing else, the learn kernel keeps its own yardstick
+            trace_ms = sum(ktimes[k]["avg_ms"] for k in ("trace_kernel", "trace_light_kernel") if k in ktimes)
             for k, v in ktimes.items():
                 if k.startswith("delta"):
                     continue
                 per_book = algorithmic_bytes(k, args.depth, 2, p.n_vars, n_live, eps)
+                if k == "trace_kernel" and trace_ms > 0:
+                    per_book *= v["avg_ms"] / trace_ms
+                elif k == "trace_light_kernel" and trace_ms > 0:
+                    per_book = algorithmic_bytes("trace_kernel", args.depth, 2, p.n_vars, n_live, eps) * v["avg_ms"] / trace_ms
                 live_books = steps_done / world / args.steps   # books one launch covers
                 ach = per_book * live_books / (v["avg_ms"] * 1e-3) / 1e9
                 tr = traffic_of(traffic_file, k)
@@ -278,7 +287,14 @@ def main():
                 "traffic": traffic_of(traffic_file, "reset_kernel")}
             dom = max((k for k in ktimes if not k.startswith("delta")), key=lambda k: ktimes[k]["avg_ms"])
             d = per_kernel[dom]
+            # the whole step against the same roof: SURVEY.md 8(d)'s bytes per env-step (event read + book state + scalars +
+            # Q-value gathers + n_live traces' worth of index / eligibility / theta read-modify-write) x env-steps per second
+            step_bytes = eps * (2 * args.depth * 8 + 2 * 8) + eps * 2 * args.depth * 8 + 256 + 9 * 3 * 32 * 8 + n_live * (4 + 4 + 4 + 8 + 8)
             roofline = {"bound": "hbm", "kernel": dom, "achieved": d["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "whole_step": {"algorithmic_bytes_per_env_step": round(step_bytes, 1),
+                                       "achieved_GBps": round(step_bytes * steps_done / elapsed / 1e9, 1),
+                                       "frac": round(step_bytes * steps_done / elapsed / 1e9 / HBM_PEAK_GBS, 5),
+                                       "note": "SURVEY.md 8(d) yardstick (the reference algorithm's bytes); the memo / hit-list kernels move far fewer: a per-kernel frac above 1 means the yardstick's traffic was avoided, not that the roof was beaten"},
                         "frac": d["frac"], "traffic": d["traffic"],
                         "traffic_source": traffic_file.get("_source", "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command; static file, not measured in this run)") if d["traffic"] else None,
                         "algorithmic_bytes_per_book": d["algorithmic_bytes_per_book"],
