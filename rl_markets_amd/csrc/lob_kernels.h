@@ -278,6 +278,9 @@ __global__ void __launch_bounds__(LOB_ENV_BLOCK) env_kernel(const DevParams* __r
             i64 ev0 = e.events;
             bool ok = perform_action<TM>(c, e, action, t0, cur);
             d_events = e.events - ev0;
+            bool claim = false;
+            u64 claim_k = 0;
+            int claim_stamp = 0, claim_slot_prev = -1, claim_q0 = 0, claim_q1 = 0, claim_q2 = 0;
             if (ok) {
                 const int cur = h.slot_cur;
                 f32* v = S.vars + ((size_t)b * 3 + cur) * 16;
@@ -289,10 +292,15 @@ __global__ void __launch_bounds__(LOB_ENV_BLOCK) env_kernel(const DevParams* __r
                     vf[i] = v[i];
                     if (i < 3) qg[i] = tile_quant(v[i]);
                 }
-                // group-0 memo: the new state's triple gets (or finds) its slot and goes on this step's list
+                // group-0 memo: the new state's triple gets (or finds) its slot and goes on this step's list -- at the very end
+                // (below): its home slot's hash and stamp are requested here, the answer is looked at after everything else
                 if (P.memo) {
-                    S.mk_slot_last[b] = S.mk_slot[b];
-                    S.mk_slot[b] = mk_claim(S, qg[0], qg[1], qg[2], step_id, par);
+                    const uint32_t s0 = (uint32_t)mk_hash3(qg[0], qg[1], qg[2]) & (uint32_t)(S.mk_slots - 1);
+                    claim_k = S.mk_hash[s0];
+                    claim_stamp = S.mk_stamp[s0];
+                    claim_slot_prev = S.mk_slot[b];
+                    claim_q0 = qg[0]; claim_q1 = qg[1]; claim_q2 = qg[2];
+                    claim = true;
                 }
                 h.zero_mask &= ~(1 << cur);
                 S.verdict[(size_t)b * LOB_VD_STRIDE + 67] = 0;  // a State changed: saved verdicts are void until learn saves new ones
@@ -302,11 +310,15 @@ __global__ void __launch_bounds__(LOB_ENV_BLOCK) env_kernel(const DevParams* __r
             } else {
                 h.stepped = 0;
             }
-            c.mark(28);  // state variables, memo claim
+            c.mark(28);  // state variables
             h.done = e.done;
             h.time_ms = e.time_ms;
             env_store(S, b, e);
-            c.mark(29);  // agent scalars out
+            if (claim) {
+                S.mk_slot_last[b] = claim_slot_prev;
+                S.mk_slot[b] = mk_claim(S, claim_q0, claim_q1, claim_q2, step_id, par, claim_k, claim_stamp);
+            }
+            c.mark(29);  // agent scalars out, memo claim
         } else {
             h.stepped = 0;
         }
@@ -427,8 +439,11 @@ __global__ void __launch_bounds__(LOB_ENVC_BLOCK) env_compact_kernel(const DevPa
                 if (i < 3) qg[i] = tile_quant(v[i]);
             }
             if (P.memo) {
+                const uint32_t s0 = (uint32_t)mk_hash3(qg[0], qg[1], qg[2]) & (uint32_t)(S.mk_slots - 1);
+                const u64 pk = S.mk_hash[s0];
+                const int ps = S.mk_stamp[s0];
                 S.mk_slot_last[b] = S.mk_slot[b];
-                S.mk_slot[b] = mk_claim(S, qg[0], qg[1], qg[2], step_id, par);
+                S.mk_slot[b] = mk_claim(S, qg[0], qg[1], qg[2], step_id, par, pk, ps);
             }
             h.zero_mask &= ~(1 << cur);
             S.verdict[(size_t)b * LOB_VD_STRIDE + 67] = 0;

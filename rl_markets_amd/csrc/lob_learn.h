@@ -376,12 +376,16 @@ __device__ inline u64 mk_hash3(int q0, int q1, int q2) {
 // this step's list (once per slot and step).  The 64-bit hash picks and marks the slot; the identity
 // is written by the claim winner only and compared in full by the readers in LATER kernels (no
 // cross-wave publication inside this one).  -1: table crowded, the book takes the general path.
-__device__ inline int mk_claim(const DevState& S, int q0, int q1, int q2, int step_id, int par) {
+// `pre_k` / `pre_stamp`: mk_hash / mk_stamp of the triple's home slot, fetched by the caller ahead of time (together, and with
+// other work in between: the claim is the last thing a book's step does, and looked up on the spot it is two dependent round
+// trips at the tail of every wave).
+__device__ inline int mk_claim(const DevState& S, int q0, int q1, int q2, int step_id, int par, u64 pre_k, int pre_stamp) {
     const u64 h = mk_hash3(q0, q1, q2);
     const uint32_t mask = (uint32_t)(S.mk_slots - 1);
     uint32_t s = (uint32_t)h & mask;
+    if (pre_k == h && pre_stamp == step_id) return (int)s;  // claimed, and on this step's list already: the usual case
     for (int probe = 0; probe < LOB_MK_PROBES; probe++) {
-        u64 k = S.mk_hash[s];
+        u64 k = probe == 0 ? pre_k : S.mk_hash[s];
         if (k == LOB_MK_EMPTY) {
             k = atomicCAS((unsigned long long*)&S.mk_hash[s], (unsigned long long)LOB_MK_EMPTY, (unsigned long long)h);
             if (k == LOB_MK_EMPTY) {
