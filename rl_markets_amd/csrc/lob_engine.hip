@@ -57,6 +57,7 @@ struct lob_engine {
                                 // the hit lists its learn kernel left are those of the States the next step acts on (act_light_kernel)
     bool light = true;          // use them (LOB_NO_LIGHT=1: always the full act kernel, for A/B runs)
  bool t_light = true;        // trace_light_kernel in front of the wave-per-book trace kernel (Q(lambda); LOB_NO_TLIGHT=1: off)
+    bool q_pair = true;         // ... two lanes per book (learn_q_pair_kernel; LOB_Q_PAIR=0: one)
     int q_lanes = -1;           // learn_q_lane_kernel (a lane per book) instead of learn_q_fast_kernel (a wave per book): -1 by batch size,
                                 // 0 / 1 forced (LOB_Q_LANES)
     std::vector<void*> allocs;
@@ -260,6 +261,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     if (const char* g = getenv("LOB_NO_LIGHT")) e->light = !(g[0] == '1');
     if (const char* g = getenv("LOB_Q_LANES")) e->q_lanes = g[0] == '1' ? 1 : 0;
     if (const char* g = getenv("LOB_NO_TLIGHT")) e->t_light = !(g[0] == '1');
+    if (const char* g = getenv("LOB_Q_PAIR")) e->q_pair = !(g[0] == '0');
     if (const char* g = getenv("LOB_RESET_LANES")) { int v = atoi(g); if (v == 16 || v == 32 || v == 64) e->reset_lanes = v; }
 
     // ---- DevParams ----
@@ -416,6 +418,13 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
             if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_lane_kernel<LOB_ALGO_QLAMBDA, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ql_lds);
             if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_lane_kernel<LOB_ALGO_QLAMBDA, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ql_lds);
             if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_lane_kernel<LOB_ALGO_QLAMBDA, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ql_lds);
+            const int qp_lds = (int)qpair_lds_bytes(P.cwords4);
+            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_pair_kernel<LOB_ALGO_SARSA, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, qp_lds);
+            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_pair_kernel<LOB_ALGO_QLAMBDA, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, qp_lds);
+            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_pair_kernel<LOB_ALGO_SARSA, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, qp_lds);
+            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_pair_kernel<LOB_ALGO_QLAMBDA, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, qp_lds);
+            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_pair_kernel<LOB_ALGO_QLAMBDA, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, qp_lds);
+            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_pair_kernel<LOB_ALGO_QLAMBDA, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, qp_lds);
             if (er == hipSuccess) er = hipFuncSetAttribute((const void*)trace_fast_kernel<LOB_ALGO_SARSA, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, tr_lds);
             if (er == hipSuccess) er = hipFuncSetAttribute((const void*)trace_fast_kernel<LOB_ALGO_QLAMBDA, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, tr_lds);
             if (er == hipSuccess) er = hipFuncSetAttribute((const void*)trace_fast_kernel<LOB_ALGO_QLAMBDA, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, tr_lds);
@@ -852,8 +861,13 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode) {
                     TimedLaunch t(e, "learn_kernel", st);
                     if (lanes) {
                         const int gq = std::min(e->n_cus, (nb + LOB_QL_BLOCK - 1) / LOB_QL_BLOCK);
-                        const size_t lds = qlane_lds_bytes(e->P.cwords4);
-#define LOB_QL_LAUNCH(A, VT, TR) hipLaunchKernelGGL((learn_q_lane_kernel<A, VT, TR>), dim3(gq), dim3(LOB_QL_BLOCK), lds, st, e->P, e->S, rnd, lpar, ver, sid)
+                        const bool pair = e->q_pair && e->P.M < (1ll << 27);  // (its LDS rows hold tile indices in 27 bits)
+                        const size_t lds = pair ? qpair_lds_bytes(e->P.cwords4) : qlane_lds_bytes(e->P.cwords4);
+#define LOB_QL_LAUNCH(A, VT, TR)                                                                                                                            \
+    do {                                                                                                                                                    \
+        if (pair) hipLaunchKernelGGL((learn_q_pair_kernel<A, VT, TR>), dim3(gq), dim3(LOB_QP_BLOCK), lds, st, e->P, e->S, rnd, lpar, ver, sid);             \
+        else hipLaunchKernelGGL((learn_q_lane_kernel<A, VT, TR>), dim3(gq), dim3(LOB_QL_BLOCK), lds, st, e->P, e->S, rnd, lpar, ver, sid);                  \
+    } while (0)
                         if (fuse) { if (e->P.V == 8) LOB_QL_LAUNCH(LOB_ALGO_QLAMBDA, 8, true); else LOB_QL_LAUNCH(LOB_ALGO_QLAMBDA, 0, true); }
                         else if (e->P.algo == LOB_ALGO_QLAMBDA) { if (e->P.V == 8) LOB_QL_LAUNCH(LOB_ALGO_QLAMBDA, 8, false); else LOB_QL_LAUNCH(LOB_ALGO_QLAMBDA, 0, false); }
                         else { if (e->P.V == 8) LOB_QL_LAUNCH(LOB_ALGO_SARSA, 8, false); else LOB_QL_LAUNCH(LOB_ALGO_SARSA, 0, false); }

@@ -738,29 +738,32 @@ __global__ void __launch_bounds__(LOB_FAST_BLOCK) learn_q_fast_kernel(DevParams 
 // later, so their latency hides behind the next stage's hashing -- a CU runs one 4-wave block (the LDS image).
 #define LOB_QL_BLOCK 256
 #define LOB_QL_ROW 25   /* u64 per lane in LDS: its hit list (LOB_HL_REC) + 1 pad */
+#ifndef LOB_QL_CHUNK
 #define LOB_QL_CHUNK 4  /* tilings per pipeline stage */
+#endif
 static_assert(32 % (2 * LOB_QL_CHUNK) == 0, "two stages per loop iteration");
 __host__ __device__ inline size_t qlane_lds_bytes(int cwords4) { return (size_t)(2048 + 32 + cwords4 * 4) * 4 + (size_t)LOB_QL_BLOCK * LOB_QL_ROW * 8; }
 
+template <int CH>
 struct QlStage {
-    i32 idx[LOB_QL_CHUNK][LOB_N_ACTIONS];
-    uint32_t xw[LOB_QL_CHUNK][LOB_N_ACTIONS];  // exact-map word of the tile (word 0 if it is not a coarse hit)
-    uint32_t maybe[LOB_QL_CHUNK];
+    i32 idx[CH][LOB_N_ACTIONS];
+    uint32_t xw[CH][LOB_N_ACTIONS];  // exact-map word of the tile (word 0 if it is not a coarse hit)
+    uint32_t maybe[CH];
 };
 // tilings j0 .. j0 + LOB_QL_CHUNK - 1 of group G (1: state variables 3..V-1, 2: all V): tile indices, coarse bits,
 // exact-map loads issued
 // VT: the number of state variables when it is the default 8 (every loop bound static: the table reads of a tiling
 // leave together), 0: any (P.V; reads beyond it are made and discarded rather than branched around).
-template <int G, int VT>
+template <int G, int VT, int CH>
 __device__ __forceinline__ void ql_issue(const DevParams& P, const DevState& S, const uint32_t* rnd, const uint32_t* terms, const uint32_t* coarse,
-                                         const int* q, int j0, QlStage& st) {
+                                         const int* q, int j0, QlStage<CH>& st) {
     const uint32_t M = (uint32_t)P.M;
     const int V = VT ? VT : P.V;
     const int nf = G == 1 ? V - 3 : V;
     const int cs = P.cshift;
     constexpr int NI = VT ? (G == 1 ? VT - 3 : VT) : (G == 1 ? LOB_MAX_VARS - 3 : LOB_MAX_VARS);
 #pragma unroll
-    for (int u = 0; u < LOB_QL_CHUNK; u++) {
+    for (int u = 0; u < CH; u++) {
         const int j = j0 + u;
         uint32_t t[NI];
 #pragma unroll
@@ -785,10 +788,15 @@ __device__ __forceinline__ void ql_issue(const DevParams& P, const DevState& S, 
     }
 }
 // the tiles of a stage that fall on marked weights join the lane's list (`row[1 + n]`, n counts on beyond the capacity)
-template <int G>
-__device__ __forceinline__ void ql_consume(const QlStage& st, u64* row, int& n) {
+// `row`: u64 entries as in the record (tile index | action << 32 | w2 << 36), or -- learn_q_pair_kernel, tables below 2^27
+// weights -- packed in 32 bits (tile index | action << 27 | w2 << 31)
+__device__ __forceinline__ void ql_put(u64* row, int i, i32 tile, int a, bool g2) { row[i] = (u64)(uint32_t)tile | ((u64)a << 32) | (g2 ? 1ull << 36 : 0ull); }
+__device__ __forceinline__ void ql_put(uint32_t* row, int i, i32 tile, int a, bool g2) { row[i] = (uint32_t)tile | ((uint32_t)a << 27) | (g2 ? 1u << 31 : 0u); }
+__device__ __forceinline__ u64 ql_unpack(uint32_t e) { return (u64)(e & 0x7ffffffu) | ((u64)((e >> 27) & 15u) << 32) | ((u64)(e >> 31) << 36); }
+template <int G, int CH, int CAP, class E>
+__device__ __forceinline__ void ql_consume(const QlStage<CH>& st, E* row, int& n) {
 #pragma unroll
-    for (int u = 0; u < LOB_QL_CHUNK; u++) {
+    for (int u = 0; u < CH; u++) {
         uint32_t hit = 0;
 #pragma unroll
         for (int a = 0; a < LOB_N_ACTIONS; a++) hit |= ((st.xw[u][a] >> ((uint32_t)st.idx[u][a] & 31)) & (st.maybe[u] >> a) & 1u) << a;
@@ -796,25 +804,26 @@ __device__ __forceinline__ void ql_consume(const QlStage& st, u64* row, int& n) 
 #pragma unroll
             for (int a = 0; a < LOB_N_ACTIONS; a++) {
                 if ((hit >> a) & 1u) {
-                    if (n < LOB_HL_CAP) row[1 + n] = (u64)(uint32_t)st.idx[u][a] | ((u64)a << 32) | (G == 2 ? 1ull << 36 : 0ull);
+                    if (n < CAP) ql_put(row, 1 + n, st.idx[u][a], a, G == 2);
                     n++;
                 }
             }
         }
     }
 }
-template <int G, int VT>
+template <int G, int VT, int CH = LOB_QL_CHUNK, int CAP = LOB_HL_CAP, class E = u64>
 __device__ __forceinline__ void ql_group(const DevParams& P, const DevState& S, const uint32_t* rnd, const uint32_t* act_terms, const uint32_t* coarse,
-                                         const int* q, u64* row, int& n) {
+                                         const int* q, E* row, int& n) {
+    static_assert(32 % (2 * CH) == 0, "two stages per loop iteration");
     const uint32_t* terms = act_terms + G * LOB_N_ACTIONS;
-    QlStage A, B;
-    ql_issue<G, VT>(P, S, rnd, terms, coarse, q, 0, A);
+    QlStage<CH> A, B;
+    ql_issue<G, VT, CH>(P, S, rnd, terms, coarse, q, 0, A);
 #pragma unroll 1
-    for (int j0 = LOB_QL_CHUNK; j0 < 32; j0 += 2 * LOB_QL_CHUNK) {
-        ql_issue<G, VT>(P, S, rnd, terms, coarse, q, j0, B);
-        ql_consume<G>(A, row, n);
-        if (j0 + LOB_QL_CHUNK < 32) ql_issue<G, VT>(P, S, rnd, terms, coarse, q, j0 + LOB_QL_CHUNK, A);
-        ql_consume<G>(B, row, n);
+    for (int j0 = CH; j0 < 32; j0 += 2 * CH) {
+        ql_issue<G, VT, CH>(P, S, rnd, terms, coarse, q, j0, B);
+        ql_consume<G, CH, CAP, E>(A, row, n);
+        if (j0 + CH < 32) ql_issue<G, VT, CH>(P, S, rnd, terms, coarse, q, j0 + CH, A);
+        ql_consume<G, CH, CAP, E>(B, row, n);
     }
 }
 
@@ -984,6 +993,235 @@ __global__ void __launch_bounds__(LOB_QL_BLOCK) learn_q_lane_kernel(DevParams P,
         recp[0] = (u64)n;
         for (int i = 0; i < n; i++) recp[1 + i] = row[1 + i];
         cb_claim_finish(S, pend);
+    }
+}
+
+
+// ---- the same with TWO lanes per book --------------------------------------------------------------------------------
+// learn_q_lane_kernel runs one wave per SIMD (65 536 books are 1 024 waves) and waits half of the time: on the LDS table
+// reads, on the exact-map words, on the dependent look-ups before and after the walk.  Here a 256-book block is 8 waves:
+// waves 0-3 walk the books' group-1 tilings (and run the trace step), waves 4-7 the same books' group-2 tilings, then --
+// after one block barrier -- finish: Q = (S0 + the group-1 additions, summed by the group-1 lane) + the group-2
+// additions, argmax, TD error, the hit list.  Two waves per SIMD, the same instructions in total.
+#define LOB_QP_BOOKS 256
+#define LOB_QP_BLOCK (2 * LOB_QP_BOOKS)
+#define LOB_QP_CAP1 22  /* entries of the group-1 half (both passes: 11 tiles on marked weights) */
+#define LOB_QP_CAP2 14  /* entries of the group-2 half */
+#define LOB_QP_ROW1 23  /* u32 per lane in LDS (entries packed in 32 bits: tables below 2^27 weights) */
+#define LOB_QP_ROW2 15
+#define LOB_QP_XCH 12   /* f64 per book handed from the group-1 lane to the group-2 lane: S0 + group-1 additions (9), entries (-1: none), Q(s, a), RNG counter */
+__host__ __device__ inline size_t qpair_lds_bytes(int cwords4) {
+    return (size_t)(2048 + 32 + cwords4 * 4) * 4 + (size_t)LOB_QP_BOOKS * (LOB_QP_ROW1 + LOB_QP_ROW2 + 2) * 4 + (size_t)LOB_QP_BOOKS * LOB_QP_XCH * 8;
+}
+template <int ALGO, int VT, bool TR>
+__global__ void __launch_bounds__(LOB_QP_BLOCK) learn_q_pair_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g, int lpar, u64 ver, int sid) {
+    static_assert(ALGO == LOB_ALGO_SARSA || ALGO == LOB_ALGO_QLAMBDA, "one weight vector");
+    static_assert(!TR || ALGO == LOB_ALGO_QLAMBDA, "the fused trace step is Watkins's");
+    extern __shared__ __align__(16) unsigned char fast_lds_raw[];
+    __shared__ u64 claimed[512];  // (as trace_light_kernel)
+    uint32_t* rnd = reinterpret_cast<uint32_t*>(fast_lds_raw);
+    uint32_t* act_terms = rnd + 2048;
+    uint32_t* coarse = act_terms + 32;
+    uint32_t* rows1 = coarse + (size_t)P.cwords4 * 4;                        // [books][LOB_QP_ROW1]
+    uint32_t* rows2 = rows1 + (size_t)LOB_QP_BOOKS * LOB_QP_ROW1;           // [books][LOB_QP_ROW2]
+    f64* xch = reinterpret_cast<f64*>(rows2 + (size_t)LOB_QP_BOOKS * LOB_QP_ROW2 + ((LOB_QP_BOOKS * (LOB_QP_ROW1 + LOB_QP_ROW2)) & 1) + 0);
+    for (int i = threadIdx.x; i < 512; i += LOB_QP_BLOCK) reinterpret_cast<uint4*>(rnd)[i] = reinterpret_cast<const uint4*>(rnd_g)[i];
+    if (threadIdx.x < 27) act_terms[threadIdx.x] = rnd_g[2048 + threadIdx.x];
+    for (int i = threadIdx.x; i < P.cwords4; i += LOB_QP_BLOCK) reinterpret_cast<uint4*>(coarse)[i] = reinterpret_cast<const uint4*>(S.theta_nzc)[i];
+    if (TR) for (int i = threadIdx.x; i < 512; i += LOB_QP_BLOCK) claimed[i] = LOB_CB_EMPTY;
+    __syncthreads();
+    const bool second = threadIdx.x >= LOB_QP_BOOKS;  // wave-uniform: the group-2 half
+    const int lb = threadIdx.x - (second ? LOB_QP_BOOKS : 0);
+    uint32_t* row = second ? rows2 + (size_t)lb * LOB_QP_ROW2 : rows1 + (size_t)lb * LOB_QP_ROW1;  // this lane's entries: row[1 + i]
+    f64* xc = xch + (size_t)lb * LOB_QP_XCH;
+    const f64 w1 = P.w1, w2 = P.w2;
+#pragma unroll 1
+    for (int base = blockIdx.x * LOB_QP_BOOKS; base < S.B; base += gridDim.x * LOB_QP_BOOKS) {
+        const int b = base + lb;
+        const bool real = b < S.B;
+        const int bb = real ? b : 0;
+        // everything whose address does not depend on the header leaves with it (both State rows: which is which comes with the header)
+        const LHdr h = S.hdr[bb];
+        const int mslot = S.mk_slot[bb];
+        float4 vr[2][4];
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) vr[r][i] = reinterpret_cast<const float4*>(S.vars + (size_t)bb * 48 + r * 16)[i];
+        LHdr* hp = S.hdr + bb;
+        u64* recp = S.hl_rec + (size_t)bb * LOB_HL_REC;
+        const bool stepped = real && h.stepped != 0;
+        int q[LOB_MAX_VARS];
+        {
+            const bool c1 = h.slot_cur != 0;
+            const float4 v0 = c1 ? vr[1][0] : vr[0][0], v1 = c1 ? vr[1][1] : vr[0][1], v2 = c1 ? vr[1][2] : vr[0][2], v3 = c1 ? vr[1][3] : vr[0][3];
+            const f32 v[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+#pragma unroll
+            for (int i = 0; i < LOB_MAX_VARS; i++) q[i] = tile_quant(v[i]);
+        }
+        bool plain = true;  // (see learn_q_lane_kernel)
+#pragma unroll
+        for (int i = 0; i < LOB_MAX_VARS; i++) plain = plain && (i >= P.V || q[i] >= (int)0x80000400);
+        const int ms = mslot >= 0 ? mslot : 0;
+        const int4 mid = *reinterpret_cast<const int4*>(S.mk_ident + (size_t)ms * 4);
+        const f64* recm = S.mk_rec + (size_t)ms * LOB_MK_REC;  // [0]: under theta_t
+        const u64 rver = reinterpret_cast<const u64*>(recm)[LOB_N_ACTIONS];
+        // both lanes of a book come to the same verdict
+        const bool walk = stepped && plain && mslot >= 0 && rver == ver && mid.x == q[0] && mid.y == q[1] && mid.z == q[2];
+        int n = 0;
+        CbPending pend;
+        pend.active = false;
+        f64 v2[LOB_QP_CAP2];  // (group-2 lane) the weights of its entries
+        if (!second) {
+            // ---- group-1 lane: the trace step's decisions, the group-1 walk, S0 + its additions, the trace step's stores ----
+            Rng g{P.seed, P.book_id_offset + (u64)bb, h.rng_ctr};
+            f64 q_sa = h.td;
+            int amax = 0, lslot = -1, tq0 = 0, tq1 = 0, tq2 = 0;
+            bool tlight = false;
+            uint32_t tmarked = 0;
+            if (TR && stepped) {
+                f64 qs_last[LOB_N_ACTIONS];
+#pragma unroll
+                for (int a = 0; a < LOB_N_ACTIONS; a++) qs_last[a] = S.qs_last[(size_t)bb * LOB_N_ACTIONS + a];
+                lslot = S.mk_slot_last[bb];
+                const int last = h.slot_cur ^ 1;
+                const bool zero_last = (h.zero_mask >> last) & 1;
+                const float4 vl = last ? vr[1][0] : vr[0][0];
+                tq0 = tile_quant(vl.x); tq1 = tile_quant(vl.y); tq2 = tile_quant(vl.z);
+                const int ls = lslot >= 0 ? lslot : 0;
+                const int4 lid = *reinterpret_cast<const int4*>(S.mk_ident + (size_t)ls * 4);
+                const int tiles_ok = S.mk_tiles_ok[ls];
+                tmarked = S.mk_marked[ls];
+                amax = argmax_ties(qs_last, g);
+                int n_old = h.tr_n, kmax = P.trace_kmax;
+                if (h.action != amax) kmax = 1;
+                if (n_old > kmax - 1) n_old = kmax - 1;
+                tlight = n_old == 0 && lslot >= 0 && !zero_last && lid.x == tq0 && lid.y == tq1 && lid.z == tq2 && lid.w == 1 && tiles_ok != 0;
+                q_sa = sel9(qs_last, h.action);
+            }
+            if (walk) {
+                ql_group<1, VT, 2, LOB_QP_CAP1, uint32_t>(P, S, rnd, act_terms, coarse, q, row, n);
+                const int n1 = n;  // the group-1 additions once more, with w2 (quirk Q3)
+                for (int i = 0; i < n1; i++) {
+                    if (n < LOB_QP_CAP1) row[1 + n] = row[1 + i] | (1u << 31);
+                    n++;
+                }
+            }
+            // S0 + the group-1 additions, in their order
+            f64 qs[LOB_N_ACTIONS];
+#pragma unroll
+            for (int a = 0; a < LOB_N_ACTIONS; a++) qs[a] = walk ? recm[a] : 0.0;
+            if (walk && n <= LOB_QP_CAP1) {
+                for (int i0 = 0; i0 < n; i0 += 4) {
+                    u64 ent[4];
+                    f64 v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) ent[u] = i0 + u < n ? ql_unpack(row[1 + i0 + u]) : 0ull;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) v[u] = i0 + u < n ? S.theta[(uint32_t)ent[u]] : 0.0;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        if (v[u] == 0.0) continue;  // (+0.0 added to a sum that is never -0.0)
+                        const int a = (int)(ent[u] >> 32) & 15;
+                        const f64 x = ((ent[u] >> 36) & 1ull ? w2 : w1) * v[u];
+#pragma unroll
+                        for (int c = 0; c < LOB_N_ACTIONS; c++) qs[c] = a == c ? qs[c] + x : qs[c];
+                    }
+                }
+                for (int i = 0; i < n && i < LOB_HL_CAP; i++) recp[1 + i] = ql_unpack(row[1 + i]);  // its part of the book's hit list
+            }
+#pragma unroll
+            for (int a = 0; a < LOB_N_ACTIONS; a++) xc[a] = qs[a];
+            reinterpret_cast<int*>(xc + LOB_N_ACTIONS)[0] = (walk && n <= LOB_QP_CAP1) ? n : -1;
+            // ---- UpdateTraces, second half (see learn_q_lane_kernel) ----
+            if (TR) {
+                const bool listed = stepped && !tlight;
+                const u64 mb = __ballot(listed);  // (one atomic per wave for the list)
+                if (mb) {
+                    int lbase = 0;
+                    const int leader = __builtin_ctzll(mb);
+                    if ((int)(threadIdx.x & 63) == leader) lbase = atomicAdd(&S.tr_list_n[lpar], __builtin_popcountll(mb));
+                    lbase = __shfl(lbase, leader);
+                    if (listed) S.tr_list[lbase + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mb, 0u))] = b | (amax << 27);
+                }
+                if (stepped && tlight) {  // the new generation = the chosen action's 32 tiles, all alive, from the memo slot's record
+                    const int action = h.action;
+                    const int G = P.trace_gens;
+                    const int nh = (h.tr_head + 1) & (G - 1);
+                    const int4* src = reinterpret_cast<const int4*>(S.mk_tiles + ((size_t)lslot * LOB_N_ACTIONS + action) * 32);
+                    int4* dst = reinterpret_cast<int4*>(S.tr_idx + ((size_t)b * G + nh) * 32);
+                    int4 tl[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) tl[i] = src[i];
+                    if (!((tmarked >> action) & 1u)) {  // (the act kernel marks them; if it could not, the marks are late)
+#pragma unroll
+                        for (int i = 0; i < 8; i++) {
+                            nzx_mark_late(P, S, tl[i].x, sid); nzx_mark_late(P, S, tl[i].y, sid); nzx_mark_late(P, S, tl[i].z, sid); nzx_mark_late(P, S, tl[i].w, sid);
+                        }
+                        atomicOr(&S.mk_marked[lslot], 1u << action);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; i++) dst[i] = tl[i];
+                    S.tr_alive[(size_t)b * G + nh] = 0xffffffffu;
+                    hp->tr_head = nh;
+                    hp->tr_n = 1;
+                    if (P.combine) {
+                        *reinterpret_cast<int4*>(S.tr_sig + ((size_t)b * G + nh) * 4) = make_int4(tq0, tq1, tq2, action);
+                        const u64 ch = cb_hash(tq0, tq1, tq2, action, 0xffffffffu);
+                        const u64 seen = atomicCAS((unsigned long long*)&claimed[(ch >> 40) & 511], (unsigned long long)LOB_CB_EMPTY, (unsigned long long)ch);
+                        if (seen != ch && S.cb_key[(uint32_t)ch & (uint32_t)(S.cb_slots - 1)] != ch)
+                            cb_claim_issue(S, pend, tq0, tq1, tq2, action, 0xffffffffu, b * G + nh);
+                    }
+                }
+                // Q(s, a) and the RNG counter after the trace step's draws: for the general kernel if the book is handed back
+                if (stepped) { hp->td = q_sa; hp->rng_ctr = g.ctr; }
+            }
+            // ... and for the group-2 lane
+            xc[LOB_N_ACTIONS + 1] = q_sa;
+            reinterpret_cast<u64*>(xc)[LOB_N_ACTIONS + 2] = g.ctr;
+        } else {
+            // ---- group-2 lane: the group-2 walk (its weights can be fetched before the other half is in) ----
+            if (walk) ql_group<2, VT, 2, LOB_QP_CAP2, uint32_t>(P, S, rnd, act_terms, coarse, q, row, n);
+#pragma unroll
+            for (int i = 0; i < LOB_QP_CAP2; i++) v2[i] = (walk && i < n) ? S.theta[row[1 + i] & 0x7ffffffu] : 0.0;
+        }
+        __syncthreads();
+        if (!second) {
+            cb_claim_finish(S, pend);
+        } else {
+            // ---- group-2 lane: Q, argmax, the TD error, the rest of the hit list ----
+            const int n1 = reinterpret_cast<const int*>(xc + LOB_N_ACTIONS)[0];
+            if (stepped) {
+                if (!(walk && n1 >= 0 && n <= LOB_QP_CAP2 && n1 + n <= LOB_HL_CAP)) {
+                    // no (valid) memo record, or a half-list longer than its row: the general kernel takes the book
+                    const int pos = atomicAdd(&S.slow_n[lpar * 2 + 1], 1);
+                    S.slow_list[(size_t)S.B + pos] = b;
+                    recp[0] = LOB_HL_NONE;
+                } else {
+                    f64 qs[LOB_N_ACTIONS];
+#pragma unroll
+                    for (int a = 0; a < LOB_N_ACTIONS; a++) qs[a] = xc[a];
+#pragma unroll
+                    for (int i = 0; i < LOB_QP_CAP2; i++) {
+                        if (i < n && v2[i] != 0.0) {
+                            const int a = (int)(row[1 + i] >> 27) & 15;
+                            const f64 x = w2 * v2[i];
+#pragma unroll
+                            for (int c = 0; c < LOB_N_ACTIONS; c++) qs[c] = a == c ? qs[c] + x : qs[c];
+                        }
+                    }
+                    // Q(s, a) / the RNG counter after the trace step, as the group-1 lane left them
+                    const f64 q_sa = xc[LOB_N_ACTIONS + 1];
+                    Rng g{P.seed, P.book_id_offset + (u64)b, reinterpret_cast<const u64*>(xc)[LOB_N_ACTIONS + 2]};
+                    learn_delta_single<ALGO>(P, hp, h, qs, q_sa, g, 0);
+                    recp[0] = (u64)(n1 + n);
+                    for (int i = 0; i < n; i++) recp[1 + n1 + i] = ql_unpack(row[1 + i]);
+                }
+            } else if (real) {
+                recp[0] = LOB_HL_NONE;
+            }
+        }
+        __syncthreads();  // (the rows and the hand-over area are reused by the block's next batch of books)
     }
 }
 

@@ -625,15 +625,18 @@ def test_hit_list_carry_on_off_identical(monkeypatch, algo, mem):
     np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-9, atol=1e-12)
 
 
+@pytest.mark.parametrize("pair", ["0", "1"])
 @pytest.mark.parametrize("algo", [abi.ALGO_SARSA, abi.ALGO_QLAMBDA])
 @pytest.mark.parametrize("mem,n_vars", [(1 << 12, 8), (1 << 18, 8), (1 << 22, 8), (1 << 20, 13), (1 << 20, 4)])
-def test_q_lane_kernel_on_off_identical(monkeypatch, algo, mem, n_vars):
+def test_q_lane_kernel_on_off_identical(monkeypatch, algo, mem, n_vars, pair):
     """learn_q_lane_kernel (a lane per book: it walks the book's 64 group-1/2 tilings itself) against
     learn_q_fast_kernel (a wave per book, tilings spread over the lanes): same tile indices, same hit lists, same
     ordered sums -- actions, TD errors and books bit for bit, theta up to its atomics' ordering.  With 13 and with
-    4 state variables (group 1 then hashes 10 / 1 of them), and with tables small enough for long lists."""
+    4 state variables (group 1 then hashes 10 / 1 of them), and with tables small enough for long lists.
+    `pair` 1: learn_q_pair_kernel, two lanes per book (one walks the group-1 tilings, the other the group-2 ones)."""
     B = 160
     out = []
+    monkeypatch.setenv("LOB_Q_PAIR", pair)
     for lanes in ("0", "1"):
         monkeypatch.setenv("LOB_Q_LANES", lanes)
         p = engine.default_params()
