@@ -61,7 +61,7 @@ def algorithmic_bytes(kernel, depth, trades, n_vars, n_live, events_per_step):
 # timer name (lob_kernel_time_ms) -> kernel function(s) launched under it, as rocprofv3 names them
 TIMER_KERNELS = {"act_kernel": ("act_light_kernel", "act_fast_kernel", "act_kernel"), "trace_kernel": ("trace_fast_kernel",),
                  "trace_light_kernel": ("trace_light_kernel",),
-                 "learn_kernel": ("learn_q_lane_kernel", "learn_q_fast_kernel", "learn_kernel"), "act_rest_kernel": (), "learn_rest_kernel": ()}
+                 "learn_kernel": ("learn_q_pair_kernel", "learn_q_lane_kernel", "learn_q_fast_kernel", "learn_kernel"), "act_rest_kernel": (), "learn_rest_kernel": ()}
 
 
 def traffic_of(traffic_file, timer):
