@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LOB_ABI_VERSION 2
+#define LOB_ABI_VERSION 3
 
 #define LOB_N_ACTIONS 9   /* reference Intraday::DoAction table, src/environment/intraday.cpp:181-219 */
 #define LOB_N_TILINGS 32  /* config/example.yaml:18 (compile-time in the kernels) */
@@ -82,7 +82,9 @@ enum { LOB_QUOTE_TARGET = 0, LOB_QUOTE_BOOK = 1 };
  * weight vector theta_b (`which` = 1 in lob_theta_get/set for shared theta, book + n_books for
  * private), actions from (Qa+Qb)/2, a coin flip per step from the agent's own
  * std::mt19937_64 (seeded with seed + global book id) choosing which vector is updated. */
-enum { LOB_ALGO_SARSA = 0, LOB_ALGO_QLAMBDA = 1, LOB_ALGO_DOUBLE_Q = 2 };
+/* SARSA / QLearn / DoubleQLearn (src/rl/agent.cpp:268-353); RLearn / OnlineRLearn (average-reward: src/rl/agent.cpp:357-412,
+ * selected by learning.algorithm r_learn / online_r_learn, src/main.cpp:179-183; they run the general kernels). */
+enum { LOB_ALGO_SARSA = 0, LOB_ALGO_QLAMBDA = 1, LOB_ALGO_DOUBLE_Q = 2, LOB_ALGO_R_LEARN = 3, LOB_ALGO_ONLINE_R_LEARN = 4 };
 
 /* Weight sharing: one theta shared by all books of the engine (the batched
  * analogue of the reference's Hogwild threads, src/main.cpp:196-206), or one
@@ -147,6 +149,7 @@ typedef struct lob_params {
     int32_t policy;             /* LOB_POLICY_* */
     int32_t _pad_policy;
     double tau;                 /* Boltzmann temperature (schedule host-side, lob_set_tau) */
+    double beta;                /* learning.beta: step size of the average reward rho (R-learning agents) */
 } lob_params;
 
 /* Synthetic event-stream generator. */

@@ -949,6 +949,8 @@ struct oracle_learner {
     std::vector<int> done;  // 0 live, 1 terminal, 2 out of data
     std::vector<oracle_step_rec> recs;
     double alpha, epsilon, tau;
+    std::vector<double> rho;  // RLearn / OnlineRLearn::rho (include/rl/agent.h:131,145): one per agent (1 shared, B private)
+    double& rh(int b) { return rho[P.theta_mode == LOB_THETA_PRIVATE ? b : 0]; }
     int64_t n_steps_done = 0, n_updates = 0;
 
     double* th(int b) { return theta[P.theta_mode == LOB_THETA_PRIVATE ? b : 0].data(); }
@@ -1075,6 +1077,7 @@ oracle_learner* oracle_create(const lob_params* p, int32_t n_books, const uint32
     o->alpha = p->alpha;
     o->epsilon = p->epsilon;
     o->tau = p->tau;
+    o->rho.assign(nt, 0.0);
     return o;
 }
 void oracle_destroy(oracle_learner* o) { delete o; }
@@ -1105,6 +1108,9 @@ int oracle_td_step(oracle_learner* o, int32_t n_steps) {
     for (int s = 0; s < n_steps; s++) {
         std::vector<double> upd(o->B, 0.0);
         std::vector<char> has(o->B, 0);  // 1: update theta, 2: update theta_b
+        // R-learning (agent.cpp:357-412): what the rho update after updateQ still needs of the step
+        const bool r_learn = o->P.algo == LOB_ALGO_R_LEARN || o->P.algo == LOB_ALGO_ONLINE_R_LEARN;
+        std::vector<double> rl_q(o->B, 0.0), rl_t(o->B, 0.0), rl_r(o->B, 0.0);
         for (int b = 0; b < o->B; b++) {
             if (o->done[b]) continue;
             Env& e = *o->env[b];
@@ -1139,6 +1145,23 @@ int oracle_td_step(oracle_learner* o, int32_t n_steps) {
                     delta = reward + F_term + o->P.gamma * o->getQ(b, o->feats[b], o->argmaxQ(b, o->feats[b], true)) - Qb;
                     target = 2;
                 }
+            } else if (o->P.algo == LOB_ALGO_R_LEARN) {
+                int amax = o->argmaxQ(b, o->last_feats[b]);  // RLearn::UpdateTraces, agent.cpp:363-371
+                if (a != amax) o->traces[b].decay(0.0f);
+                else o->traces[b].decay(rate);
+                o->traces[b].update(o->last_feats[b], a, 9, 32);
+                double Q = o->getQ(b, o->last_feats[b], a);  // RLearn::UpdateWeights, agent.cpp:373-380
+                double mQ = o->getQ(b, o->feats[b], o->argmaxQ(b, o->feats[b]));
+                delta = reward - o->rh(b) + mQ - Q;
+                rl_q[b] = Q; rl_t[b] = mQ; rl_r[b] = reward;
+            } else if (o->P.algo == LOB_ALGO_ONLINE_R_LEARN) {
+                o->traces[b].decay(rate);  // Agent::UpdateTraces, agent.cpp:111-115
+                o->traces[b].update(o->last_feats[b], a, 9, 32);
+                double Q = o->getQ(b, o->last_feats[b], a);  // OnlineRLearn::UpdateWeights, agent.cpp:398-405
+                int a2 = o->action(b, o->feats[b]);
+                double gQ = o->getQ(b, o->feats[b], a2);
+                delta = reward - o->rh(b) + gQ - Q;
+                rl_q[b] = Q; rl_t[b] = gQ; rl_r[b] = reward;
             } else if (o->P.algo == LOB_ALGO_QLAMBDA) {
                 int amax = o->argmaxQ(b, o->last_feats[b]);  // QLearn::UpdateTraces, agent.cpp:272-280
                 if (a != amax) o->traces[b].decay(0.0f);
@@ -1170,6 +1193,20 @@ int oracle_td_step(oracle_learner* o, int32_t n_steps) {
             double* t = has[b] == 2 ? o->thb(b) : o->th(b);
             for (int f : o->traces[b].nonzero) t[f] += scaled * o->traces[b].get(f);
             o->n_updates++;
+        }
+        // R-learning: nQ = Q + update; if (nQ - maxQ(from_state) < 1e-7) rho += beta * (reward - rho + target - nQ)
+        // (agent.cpp:382-385, 407-410) -- maxQ under the weights AFTER updateQ, its argmax draws last in the book's
+        // stream; every book reads rho_t, the increments are summed (the batch semantic of theta)
+        if (r_learn) {
+            std::vector<double> inc(o->rho.size(), 0.0);
+            for (int b = 0; b < o->B; b++) {
+                if (!has[b]) continue;
+                const double nQ = rl_q[b] + upd[b];
+                const double mq_from = o->getQ(b, o->last_feats[b], o->argmaxQ(b, o->last_feats[b]));
+                o->recs[b].rng_ctr = o->rng_ctr[b];
+                if (nQ - mq_from < 1e-7) inc[o->P.theta_mode == LOB_THETA_PRIVATE ? b : 0] += o->P.beta * (rl_r[b] - o->rh(b) + rl_t[b] - nQ);
+            }
+            for (size_t i = 0; i < inc.size(); i++) o->rho[i] += inc[i];
         }
     }
     return 0;
@@ -1217,6 +1254,11 @@ int oracle_handle_terminal(oracle_learner* o) {
 void oracle_set_alpha(oracle_learner* o, double a) { o->alpha = a; }
 void oracle_set_epsilon(oracle_learner* o, double e) { o->epsilon = e; }
 void oracle_set_tau(oracle_learner* o, double t) { o->tau = t; }
+int oracle_get_rho(oracle_learner* o, double* out, int32_t n) {
+    if ((size_t)n > o->rho.size()) return -1;
+    for (int i = 0; i < n; i++) out[i] = o->rho[i];
+    return 0;
+}
 void oracle_get_rec(oracle_learner* o, int32_t book, oracle_step_rec* out) { *out = o->recs[book]; }
 double* oracle_theta(oracle_learner* o, int32_t which) { return o->theta[which].data(); }
 double* oracle_theta_b(oracle_learner* o, int32_t which) { return o->theta_b.empty() ? nullptr : o->theta_b[which].data(); }

@@ -57,6 +57,8 @@ int oracle_handle_terminal(oracle_learner* o);
 void oracle_set_alpha(oracle_learner* o, double a);
 void oracle_set_epsilon(oracle_learner* o, double e);
 void oracle_set_tau(oracle_learner* o, double t);
+/* rho of the R-learning agents: out[n], n = 1 (shared theta) or n_books (private) */
+int oracle_get_rho(oracle_learner* o, double* out, int32_t n);
 /* last step's record for `book` */
 void oracle_get_rec(oracle_learner* o, int32_t book, oracle_step_rec* out);
 double* oracle_theta(oracle_learner* o, int32_t which);

@@ -280,6 +280,7 @@ static std::string make_yaml(const Args& a, const std::string& path) {
     f << "    group_weights: [" << a.get("w0", "0.65") << ", " << a.get("w1", "0.25") << ", " << a.get("w2", "0.10") << "]\n";
     f << "    gamma: " << a.get("gamma", "0.975") << "\n    lambda: " << a.get("lambda", "0.85") << "\n";
     f << "    omega: 1.0\n    alpha_start: " << a.get("alpha", "0.001") << "\n    alpha_floor: " << a.get("alpha", "0.001") << "\n";
+    f << "    beta: " << a.get("beta", "0.005") << "\n";  // RLearn / OnlineRLearn (src/rl/agent.cpp:357-412)
     f << "policy:\n    type: epsilon_greedy\n    eps_init: 0.8\n    eps_floor: 0.0001\n    eps_T: 800\n";
     f << "    spread_lookback: " << a.geti("lb_spread", 45) << "\n";
     f << "reward:\n    measure: " << a.get("reward", "pnl_damped") << "\n";
@@ -616,6 +617,8 @@ int main(int argc, char** argv) {
         if (algo == "sarsa") rc = run_dropin<rl::SARSA>(a, c, genv, a.get("out", tmp + ".traj"));
         else if (algo == "q_learn") rc = run_dropin<rl::QLearn>(a, c, genv, a.get("out", tmp + ".traj"));
         else if (algo == "double_q_learn") rc = run_dropin<rl::DoubleQLearn>(a, c, genv, a.get("out", tmp + ".traj"));
+        else if (algo == "r_learn") rc = run_dropin<rl::RLearn>(a, c, genv, a.get("out", tmp + ".traj"));
+        else if (algo == "online_r_learn") rc = run_dropin<rl::OnlineRLearn>(a, c, genv, a.get("out", tmp + ".traj"));
         if (!a.geti("keep", 0) && a.kv.count("stream")) { remove(md.c_str()); remove(tas.c_str()); }
         remove(yaml.c_str());
         return rc;
@@ -629,11 +632,15 @@ int main(int argc, char** argv) {
         if (algo == "sarsa") rc = run_episode<rl::SARSA>(a, c, env, a.get("out", tmp + ".traj"));
         else if (algo == "q_learn") rc = run_episode<rl::QLearn>(a, c, env, a.get("out", tmp + ".traj"));
         else if (algo == "double_q_learn") rc = run_episode<rl::DoubleQLearn>(a, c, env, a.get("out", tmp + ".traj"));
+        else if (algo == "r_learn") rc = run_episode<rl::RLearn>(a, c, env, a.get("out", tmp + ".traj"));
+        else if (algo == "online_r_learn") rc = run_episode<rl::OnlineRLearn>(a, c, env, a.get("out", tmp + ".traj"));
         else { fprintf(stderr, "unknown algo\n"); rc = 2; }
     } else if (mode == "learner") {
         if (algo == "sarsa") rc = run_learner<rl::SARSA>(a, c, env);
         else if (algo == "q_learn") rc = run_learner<rl::QLearn>(a, c, env);
         else if (algo == "double_q_learn") rc = run_learner<rl::DoubleQLearn>(a, c, env);
+        else if (algo == "r_learn") rc = run_learner<rl::RLearn>(a, c, env);
+        else if (algo == "online_r_learn") rc = run_learner<rl::OnlineRLearn>(a, c, env);
         else { fprintf(stderr, "unknown algo\n"); rc = 2; }
     } else {
         fprintf(stderr, "unknown mode %s\n", mode.c_str());

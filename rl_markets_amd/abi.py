@@ -28,7 +28,7 @@ REWARD_NAMES = {"none": 0, "pnl": 1, "pnl_damped": 2, "spread": 3, "normed": 4, 
                 "mm_exp": 7, "mm_div": 8}
 TP_MIDPRICE, TP_MICROPRICE = 0, 1
 QUOTE_TARGET, QUOTE_BOOK = 0, 1
-ALGO_SARSA, ALGO_QLAMBDA, ALGO_DOUBLE_Q = 0, 1, 2
+ALGO_SARSA, ALGO_QLAMBDA, ALGO_DOUBLE_Q, ALGO_R_LEARN, ALGO_ONLINE_R_LEARN = 0, 1, 2, 3, 4
 THETA_SHARED, THETA_PRIVATE = 0, 1
 POLICY_EPS_GREEDY, POLICY_BOLTZMANN = 0, 1
 
@@ -63,7 +63,7 @@ class Params(_Strict):
         ("group_weights", C.c_double * 3), ("gamma", C.c_double), ("lambda_", C.c_double),
         ("alpha", C.c_double), ("epsilon", C.c_double),
         ("algo", C.c_int32), ("theta_mode", C.c_int32), ("seed", C.c_uint64), ("book_id_offset", C.c_uint64),
-        ("policy", C.c_int32), ("_pad_policy", C.c_int32), ("tau", C.c_double),
+        ("policy", C.c_int32), ("_pad_policy", C.c_int32), ("tau", C.c_double), ("beta", C.c_double),
     ]
 
 

@@ -200,7 +200,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     if (p->n_vars < 4 || p->n_vars > LOB_MAX_VARS) { lob_set_error("lob_create: n_vars must be in [4,13]"); return LOB_EINVAL; }
     if (p->memory_size < 1 || p->memory_size >= (1LL << 31)) { lob_set_error("lob_create: memory_size out of range"); return LOB_EINVAL; }
     if (p->market.n_bands < 1 || p->market.n_bands > LOB_MAX_BANDS) { lob_set_error("lob_create: bad tick table"); return LOB_EINVAL; }
-    if (p->algo < LOB_ALGO_SARSA || p->algo > LOB_ALGO_DOUBLE_Q) { lob_set_error("lob_create: unknown algorithm"); return LOB_EINVAL; }
+    if (p->algo < LOB_ALGO_SARSA || p->algo > LOB_ALGO_ONLINE_R_LEARN) { lob_set_error("lob_create: unknown algorithm"); return LOB_EINVAL; }
     if (p->policy != LOB_POLICY_EPS_GREEDY && p->policy != LOB_POLICY_BOLTZMANN) { lob_set_error("lob_create: unknown policy"); return LOB_EINVAL; }
     if (p->policy == LOB_POLICY_BOLTZMANN && !(p->tau > 0.0)) { lob_set_error("lob_create: Boltzmann temperature must be positive"); return LOB_EINVAL; }
     const int lbs[] = {p->lb_mpm, p->lb_vlt, p->lb_svl, p->lb_vwap, p->lb_rsi, p->lb_spread, p->lb_pnl, p->lb_target};
@@ -282,7 +282,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     P.M = p->memory_size;
     P.w0 = p->group_weights[0]; P.w1 = p->group_weights[1]; P.w2 = p->group_weights[2];
     P.gamma = p->gamma; P.alpha = p->alpha; P.epsilon = p->epsilon;
-    P.policy = p->policy; P.tau = p->tau;
+    P.policy = p->policy; P.tau = p->tau; P.beta = p->beta;
     P.trace_rate = trace_rate;
     for (int k = 0; k <= LOB_TRACE_GENS; k++) P.trace_pow[k] = trace_pow[k];
     P.trace_kmax = trace_kmax;
@@ -292,7 +292,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     { const char* nc = getenv("LOB_NO_COMBINE"); P.combine = !P.theta_private && !(nc && nc[0] == '1'); }
     {   // group-0 memo: shared theta, one weight vector, one book group
         const char* nc = getenv("LOB_NO_MEMO");
-        P.memo = !P.theta_private && p->algo != LOB_ALGO_DOUBLE_Q && e->n_groups == 1 && !(nc && nc[0] == '1');
+        P.memo = !P.theta_private && (p->algo == LOB_ALGO_SARSA || p->algo == LOB_ALGO_QLAMBDA) && e->n_groups == 1 && !(nc && nc[0] == '1');
         // the memo path never reads the carry-over filter, and its hot counter serialises first writes
         if (P.memo) P.carry_verdicts = 0;
     }
@@ -353,6 +353,13 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
         if (rc == LOB_OK) rc = dev_alloc(e, &S.qs_last_b, B * LOB_N_ACTIONS);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.mt_state, B * LOB_MT_N);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.mt_idx, B);
+    }
+    {
+        const bool rl = p->algo == LOB_ALGO_R_LEARN || p->algo == LOB_ALGO_ONLINE_R_LEARN;
+        const size_t nr = rl ? (P.theta_private ? B : 1) : 1;
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.rho, nr);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.rho_inc, nr);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.rl_t, rl ? B : 1);
     }
     if (rc == LOB_OK) rc = dev_alloc(e, &S.tr_sig, B * (size_t)P.trace_gens * 4);
     {
@@ -887,7 +894,7 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode) {
             } else if (mode == 0) {
                 TimedLaunch t(e, "learn_kernel", st);
                 if (e->P.algo == LOB_ALGO_DOUBLE_Q) hipLaunchKernelGGL((learn_kernel<LOB_ALGO_DOUBLE_Q, false>), dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, b0, nb, par, (const i32*)nullptr, (const i32*)nullptr);
-                else if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL((learn_kernel<LOB_ALGO_QLAMBDA, false>), dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, b0, nb, par, (const i32*)nullptr, (const i32*)nullptr);
+                else if (e->P.algo == LOB_ALGO_QLAMBDA || e->P.algo == LOB_ALGO_R_LEARN) hipLaunchKernelGGL((learn_kernel<LOB_ALGO_QLAMBDA, false>), dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, b0, nb, par, (const i32*)nullptr, (const i32*)nullptr);
                 else hipLaunchKernelGGL((learn_kernel<LOB_ALGO_SARSA, false>), dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, b0, nb, par, (const i32*)nullptr, (const i32*)nullptr);
             }
         }
@@ -910,6 +917,13 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode) {
         } else if (mode == 0) {
             TimedLaunch t(e, "update_kernel");
             hipLaunchKernelGGL(update_kernel, dim3(grid_waves(e->B)), dim3(LOB_BLOCK), 0, e->stream, e->P, e->S, par, e->step_id);
+        }
+        if (mode == 0 && (e->P.algo == LOB_ALGO_R_LEARN || e->P.algo == LOB_ALGO_ONLINE_R_LEARN)) {
+            // R-learning: the average reward rho, after updateQ (rho_kernel, lob_kernels.h)
+            TimedLaunch t(e, "rho_kernel");
+            const int nr = e->P.theta_private ? e->B : 1;
+            hipLaunchKernelGGL(rho_kernel, dim3(grid_waves(e->B)), dim3(LOB_BLOCK), 0, e->stream, e->P, e->S, rnd);
+            hipLaunchKernelGGL(rho_fold_kernel, dim3((nr + 255) / 256), dim3(256), 0, e->stream, e->S, nr);
         }
         if (mode == 0) {
             e->theta_ver++;                          // theta_{t+1}
@@ -1216,6 +1230,15 @@ extern "C" int lob_debug_light(lob_engine* e, int64_t out[2]) {
     HIPCHK(hipStreamSynchronize(e->stream));
     out[0] = c[5];
     out[1] = d;
+    return LOB_OK;
+}
+
+// Diagnostics (not part of include/lob_engine.h): rho of the R-learning agents (`n` = 1 shared, n_books private).
+extern "C" int lob_debug_rho(lob_engine* e, double* out, int32_t n) {
+    if (!e || !out || n < 1 || !e->S.rho) return LOB_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemcpyAsync(out, e->S.rho, (size_t)n * 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
     return LOB_OK;
 }
 

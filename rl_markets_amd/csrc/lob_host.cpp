@@ -160,6 +160,7 @@ void lob_default_params(lob_params* p) {
     p->book_id_offset = 0;
     p->policy = LOB_POLICY_EPS_GREEDY;
     p->tau = 1.0;
+    p->beta = 0.005;
 }
 
 void lob_default_gen_params(lob_gen_params* g) {

@@ -876,16 +876,24 @@ __device__ __forceinline__ void learn_traces(const DevParams& P, const DevState&
 // UpdateWeights of SARSA / QLearn (agent.cpp:282-311) once Q(to_state, .) is known: the TD error and
 // the header stores.
 template <int ALGO>
-__device__ __forceinline__ void learn_delta_single(const DevParams& P, LHdr* hp, const LHdr& h, const f64* qs_to, f64 q_sa, Rng& g, int lane) {
+__device__ __forceinline__ void learn_delta_single(const DevParams& P, LHdr* hp, const LHdr& h, const f64* qs_to, f64 q_sa, Rng& g, int lane,
+                                                   const f64* rho = nullptr, f64* rl_t = nullptr) {
     static_assert(ALGO != LOB_ALGO_DOUBLE_Q, "two weight vectors: see learn_book");
     const f64 F_term = P.gamma * 0.0 - 0.0;  // potentials are identically 0 (base.cpp:239-242)
-    f64 delta;
+    f64 tq;  // the bootstrap value: maxQ(to_state) (QLearn, RLearn) / Q(to_state, this->action(to_state)) (SARSA -- quirk Q9 --, OnlineRLearn)
     if (ALGO == LOB_ALGO_QLAMBDA) {
-        const int am2 = argmax_ties(qs_to, g);  // maxQ(to_state)
-        delta = h.reward + F_term + P.gamma * sel9(qs_to, am2) - q_sa;
+        const int am2 = argmax_ties(qs_to, g);
+        tq = sel9(qs_to, am2);
     } else {
-        const int a2 = policy_sample(P, qs_to, false, g);  // this->action(to_state), quirk Q9
-        delta = h.reward + F_term + P.gamma * sel9(qs_to, a2) - q_sa;
+        const int a2 = policy_sample(P, qs_to, false, g);
+        tq = sel9(qs_to, a2);
+    }
+    f64 delta;
+    if (rho) {  // RLearn / OnlineRLearn::UpdateWeights (agent.cpp:373-380, 398-405): delta = reward - rho + target - Q
+        delta = h.reward - *rho + tq - q_sa;
+        if (lane == 0) *rl_t = tq;
+    } else {
+        delta = h.reward + F_term + P.gamma * tq - q_sa;
     }
     if (lane == 0) {
         hp->td = delta;
@@ -964,7 +972,9 @@ __device__ __forceinline__ void learn_book(const DevParams& P, const DevState& S
             hp->rng_ctr = g.ctr;
         }
     } else {
-        learn_delta_single<ALGO == LOB_ALGO_DOUBLE_Q ? LOB_ALGO_SARSA : ALGO>(P, hp, h, qs_to, sel9(qs_last, action), g, lane);
+        const bool r_learn = P.algo == LOB_ALGO_R_LEARN || P.algo == LOB_ALGO_ONLINE_R_LEARN;  // (run as the Q(lambda) / SARSA instantiation)
+        learn_delta_single<ALGO == LOB_ALGO_DOUBLE_Q ? LOB_ALGO_SARSA : ALGO>(P, hp, h, qs_to, sel9(qs_last, action), g, lane,
+                                                                              r_learn ? S.rho + (P.theta_private ? b : 0) : nullptr, S.rl_t + b);
     }
     pf.mark(17);  // argmax / delta / header stores
     cb_claim_finish(S, pend);  // the CAS was issued before Q(s', .): its answer has long arrived
@@ -1082,6 +1092,44 @@ __global__ void __launch_bounds__(LOB_BLOCK) update_kernel(DevParams P, DevState
             }
         }
     }
+}
+
+// RLearn / OnlineRLearn::UpdateWeights after updateQ (agent.cpp:382-385, 407-410):
+//     nQ = Q + update;  if (nQ - maxQ(from_state) < 1e-7) rho += beta * (reward - rho + target - nQ)
+// with maxQ(from_state) under the weights the update has just written (one more Q evaluation of last_state; its argmax
+// draws are the last of the book's step).  Every book reads rho_t; the increments are summed (rho_inc) and folded in by
+// rho_fold_kernel -- the batch semantic of theta.  One wave per book, as learn_kernel.
+__global__ void __launch_bounds__(LOB_BLOCK) rho_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g) {
+    __shared__ LearnLds L;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    learn_stage_table(rnd_g, L);
+    const int b = __builtin_amdgcn_readfirstlane(blockIdx.x * LOB_WAVES_PER_BLOCK + w);
+    if (b >= S.B) return;
+    const LHdr h = S.hdr[b];
+    if (!h.stepped) return;
+    learn_stage_vars(S.vars + (size_t)b * 48, &L.vars[w][0][0], lane);
+    const int last = h.slot_cur ^ 1;
+    const bool zero_last = (h.zero_mask >> last) & 1;
+    const f64* theta = S.theta + (P.theta_private ? (size_t)b * (size_t)P.M : 0);
+    const uint32_t* nz = S.theta_nz + (P.theta_private ? (size_t)b * LOB_NZ_NWORDS(P.M) : 0);
+    f64 qs[LOB_N_ACTIONS];
+    q_values(P, theta, nz, L.vars[w][last], zero_last, L.rnd, L.act_terms, L.vals[w], lane, qs);
+    Rng g{P.seed, P.book_id_offset + (u64)b, h.rng_ctr};
+    const int am = argmax_ties(qs, g);
+    const f64 mq_from = sel9(qs, am);
+    const int ri = P.theta_private ? b : 0;
+    const f64 rho = S.rho[ri];
+    const f64 nQ = S.qs_last[(size_t)b * LOB_N_ACTIONS + h.action] + h.upd;
+    if (lane == 0) {
+        S.hdr[b].rng_ctr = g.ctr;
+        if (nQ - mq_from < 1e-7) __hip_atomic_fetch_add(&S.rho_inc[ri], P.beta * (h.reward - rho + S.rl_t[b] - nQ), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__global__ void rho_fold_kernel(DevState S, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    S.rho[i] += S.rho_inc[i];
+    S.rho_inc[i] = 0.0;
 }
 
 // ---- combined update (shared theta) --------------------------------------------------------------

@@ -281,6 +281,12 @@ struct DevState {
     u64* hl_rec;         // [B][LOB_HL_REC]: [0] = number of entries, or ~0: no list (not evaluated by the fast learn kernel, or more
                          //   than LOB_HL_CAP); [1 + i] = entry i
     i32* hl_dirty;       // [1] step id of the last update that set a map bit AFTER learn_q had looked (voids every list)
+    // R-learning agents (RLearn / OnlineRLearn, src/rl/agent.cpp:357-412): the average reward rho of each agent -- one per weight
+    // vector: [1] shared, [B] private --, the sum of a step's increments (folded in by rho_fold_kernel: every book reads rho_t),
+    // and per book the bootstrap value the TD error used (maxQ(to_state) / Q(to_state, a')), which the rho update needs again
+    f64* rho;
+    f64* rho_inc;
+    f64* rl_t;        // [B]
     f64* theta_sync;  // [M] (multi-GPU) or null
     f64* delta;       // [M] scratch for the all-reduce or null
     i64* counters;    // [8] device counters
@@ -312,6 +318,7 @@ struct DevParams {
     f64 gamma, alpha, epsilon;
     i32 policy;                       // LOB_POLICY_*
     f64 tau;                          // Boltzmann temperature
+    f64 beta;                         // R-learning: step size of rho
     f32 trace_rate;                   // (float)(gamma*lambda)
     f32 trace_pow[LOB_TRACE_GENS + 1];  // eligibility by age, iterated float products
     i32 trace_kmax;                   // first age whose eligibility < tolerance

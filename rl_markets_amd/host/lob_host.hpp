@@ -197,7 +197,10 @@ public:
         if (algo == "sarsa") p.algo = LOB_ALGO_SARSA;
         else if (algo == "q_learn") p.algo = LOB_ALGO_QLAMBDA;
         else if (algo == "double_q_learn") p.algo = LOB_ALGO_DOUBLE_Q;
-        else throw std::invalid_argument("Unknown learning algorithm: " + algo + " (supported: sarsa, q_learn, double_q_learn; R-learning is out of scope, SURVEY.md §2 row 14)");
+        else if (algo == "r_learn") p.algo = LOB_ALGO_R_LEARN;                // src/main.cpp:179-183
+        else if (algo == "online_r_learn") p.algo = LOB_ALGO_ONLINE_R_LEARN;
+        else throw std::invalid_argument("Unknown learning algorithm: " + algo + " (supported: sarsa, q_learn, double_q_learn, r_learn, online_r_learn)");
+        if (p.algo == LOB_ALGO_R_LEARN || p.algo == LOB_ALGO_ONLINE_R_LEARN) p.beta = num("learning.beta");  // (required, as c["learning"]["beta"].as<double>())
         p.seed = (uint64_t)integer("debug.random_seed", 1994);
         return p;
     }

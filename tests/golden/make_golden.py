@@ -52,6 +52,9 @@ TRAJ_CASES = [
     ("sarsa_boltzmann_b23", "sarsa", 500, 23, {"policy": "boltzmann", "tau": "25.0"}, {"policy": abi.POLICY_BOLTZMANN, "tau": 25.0}),
     ("sarsa_mm_exp_b20", "sarsa", 500, 20, {"reward": "mm_exp", "pos_weight": "0.05", "eps": "0.5"},
      {"reward_measure": abi.REWARD_MM_EXP, "pos_weight": 0.05, "epsilon": 0.5}),
+    # average-reward agents: rl::RLearn / rl::OnlineRLearn (src/rl/agent.cpp:357-412), rho updated after updateQ
+    ("rlearn_b24", "r_learn", 500, 24, {"beta": "0.02", "eps": "0.4"}, {"beta": 0.02, "epsilon": 0.4}),
+    ("online_rlearn_b25", "online_r_learn", 500, 25, {"beta": "0.01"}, {"beta": 0.01}),
     # a NaN state variable: vwap over a window without trades is 0/0, ulb() passes the NaN on, the
     # tile coder turns it into INT_MIN coordinates (x86 conversion) -- inside group 0, i.e. in the traces
     ("qlearn_vwap_nan_b19", "q_learn", 420, 19,

@@ -65,6 +65,7 @@ def load():
     lib.oracle_set_alpha.argtypes = [vp, C.c_double]
     lib.oracle_set_epsilon.argtypes = [vp, C.c_double]
     lib.oracle_set_tau.argtypes = [vp, C.c_double]
+    lib.oracle_get_rho.argtypes = [vp, vp, C.c_int32]
     lib.oracle_get_rec.argtypes = [vp, C.c_int32, P(StepRec)]
     lib.oracle_theta.restype = P(C.c_double)
     lib.oracle_theta.argtypes = [vp, C.c_int32]

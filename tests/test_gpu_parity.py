@@ -33,7 +33,7 @@ def make(depth=5, trades=2, n_events=500, B=4, algo=abi.ALGO_SARSA, theta_mode=a
 
 def test_no_cpu_fallback_symbols():
     lib = abi.load()
-    assert lib.lob_abi_version() == 2
+    assert lib.lob_abi_version() == 3
 
 
 def test_features_match_oracle():
@@ -712,6 +712,44 @@ def test_trace_light_kernel_on_off_identical(monkeypatch, mem, eps, lanes):
         assert r0 == r1, "trace lists differ at record %d" % k
         np.testing.assert_allclose(t0, t1, rtol=1e-9, atol=1e-12, err_msg="td, record %d" % k)
     np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("algo", [abi.ALGO_R_LEARN, abi.ALGO_ONLINE_R_LEARN])
+@pytest.mark.parametrize("theta_mode", [abi.THETA_PRIVATE, abi.THETA_SHARED])
+def test_r_learning_against_oracle(algo, theta_mode):
+    """rl::RLearn / rl::OnlineRLearn (src/rl/agent.cpp:357-412): TD error without discount against the average reward
+    rho, and rho's own update after updateQ -- conditional on maxQ(from_state) under the NEW weights (rho_kernel).  The
+    oracle reproduces two reference trajectories of these agents (tests/golden/traj_rlearn_b24, traj_online_rlearn_b25);
+    here the engine follows the oracle step by step: private weights bit for bit (rho included), shared weights up to
+    the order of the atomic additions."""
+    import ctypes
+    B = 24
+    p, g, rec, eng, orc = make(depth=5, n_events=500, B=B, algo=algo, theta_mode=theta_mode, mem=1 << 16, epsilon=0.4, beta=0.02)
+    eng.reset()
+    orc.reset()
+    n_rho = B if theta_mode == abi.THETA_PRIVATE else 1
+    eng.lib.lob_debug_rho.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]
+    exact = theta_mode == abi.THETA_PRIVATE
+    for step in range(150):
+        eng.td_step(1)
+        orc.td_step(1)
+        compare_learner_step(eng, orc, tag="r-learning step %d" % step, exact=exact, rtol=1e-9)
+        if step % 10 == 9:
+            er, orr = np.zeros(n_rho), np.zeros(n_rho)
+            assert eng.lib.lob_debug_rho(eng.h, ol.ptr(er), n_rho) == 0
+            assert orc.lib.oracle_get_rho(orc.h, ol.ptr(orr), n_rho) == 0
+            assert np.any(orr != 0.0) or step < 20, "rho never moved: the test exercises nothing"
+            if exact:
+                np.testing.assert_array_equal(er, orr, err_msg="rho, step %d" % step)
+            else:
+                np.testing.assert_allclose(er, orr, rtol=1e-9, atol=1e-12, err_msg="rho, step %d" % step)
+    for b in range(n_rho if exact else 1):
+        if exact:
+            np.testing.assert_array_equal(eng.theta(b), orc.theta(b))
+        else:
+            np.testing.assert_allclose(eng.theta(b), orc.theta(b), rtol=1e-9, atol=1e-12)
+    eng.close()
+    orc.close()
 
 
 # ---- long streams: the market track as a ring, refilled while the episode runs ------------------------

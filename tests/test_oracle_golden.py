@@ -81,7 +81,7 @@ def test_tick_maths_match_reference(ticker):
 def _params_for(over, algo, book):
     p = engine.default_params()
     p.memory_size = 1 << 20
-    p.algo = abi.ALGO_SARSA if algo == "sarsa" else abi.ALGO_QLAMBDA
+    p.algo = {"sarsa": abi.ALGO_SARSA, "q_learn": abi.ALGO_QLAMBDA, "r_learn": abi.ALGO_R_LEARN, "online_r_learn": abi.ALGO_ONLINE_R_LEARN}[algo]
     p.book_id_offset = book
     for k, v in over.items():
         if k.startswith("_"):
