@@ -82,9 +82,11 @@ enum { LOB_QUOTE_TARGET = 0, LOB_QUOTE_BOOK = 1 };
  * weight vector theta_b (`which` = 1 in lob_theta_get/set for shared theta, book + n_books for
  * private), actions from (Qa+Qb)/2, a coin flip per step from the agent's own
  * std::mt19937_64 (seeded with seed + global book id) choosing which vector is updated. */
-/* SARSA / QLearn / DoubleQLearn (src/rl/agent.cpp:268-353); RLearn / OnlineRLearn (average-reward: src/rl/agent.cpp:357-412,
- * selected by learning.algorithm r_learn / online_r_learn, src/main.cpp:179-183; they run the general kernels). */
-enum { LOB_ALGO_SARSA = 0, LOB_ALGO_QLAMBDA = 1, LOB_ALGO_DOUBLE_Q = 2, LOB_ALGO_R_LEARN = 3, LOB_ALGO_ONLINE_R_LEARN = 4 };
+/* SARSA / QLearn / DoubleQLearn (src/rl/agent.cpp:268-353); RLearn / OnlineRLearn / DoubleRLearn (average-reward:
+ * src/rl/agent.cpp:357-467, selected by learning.algorithm r_learn / online_r_learn / double_r_learn, src/main.cpp:179-186;
+ * they run the general kernels). */
+enum { LOB_ALGO_SARSA = 0, LOB_ALGO_QLAMBDA = 1, LOB_ALGO_DOUBLE_Q = 2, LOB_ALGO_R_LEARN = 3, LOB_ALGO_ONLINE_R_LEARN = 4,
+       LOB_ALGO_DOUBLE_R_LEARN = 5 };
 
 /* Weight sharing: one theta shared by all books of the engine (the batched
  * analogue of the reference's Hogwild threads, src/main.cpp:196-206), or one

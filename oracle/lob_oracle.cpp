@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <cfloat>
 #include <deque>
 #include <map>
 #include <memory>
@@ -1020,7 +1021,7 @@ struct oracle_learner {
     }
     int action(int b, const std::vector<std::vector<int>>& f, bool greedy = false) {  // Agent::action, agent.cpp:67-74
         double qs[9];
-        if (P.algo == LOB_ALGO_DOUBLE_Q)  // DoubleAgent::action, agent.cpp:196-204
+        if (P.algo == LOB_ALGO_DOUBLE_Q || P.algo == LOB_ALGO_DOUBLE_R_LEARN)  // DoubleAgent::action, agent.cpp:196-204
             for (int a = 0; a < 9; a++) qs[a] = (getQ(b, f, a) + getQ(b, f, a, true)) / 2.0f;
         else
             for (int a = 0; a < 9; a++) qs[a] = getQ(b, f, a);
@@ -1058,7 +1059,7 @@ oracle_learner* oracle_create(const lob_params* p, int32_t n_books, const uint32
         o->env.emplace_back(new Env(*p, records + (size_t)b * n_events * W, n_events));
     int nt = p->theta_mode == LOB_THETA_PRIVATE ? n_books : 1;
     o->theta.assign(nt, std::vector<double>((size_t)o->M, 0.0));
-    if (p->algo == LOB_ALGO_DOUBLE_Q) {
+    if (p->algo == LOB_ALGO_DOUBLE_Q || p->algo == LOB_ALGO_DOUBLE_R_LEARN) {
         o->theta_b.assign(nt, std::vector<double>((size_t)o->M, 0.0));
         for (int b = 0; b < n_books; b++) {
             // gen(c["debug"]["random_seed"].as<unsigned>()), one agent per book: seed + global book id
@@ -1109,7 +1110,7 @@ int oracle_td_step(oracle_learner* o, int32_t n_steps) {
         std::vector<double> upd(o->B, 0.0);
         std::vector<char> has(o->B, 0);  // 1: update theta, 2: update theta_b
         // R-learning (agent.cpp:357-412): what the rho update after updateQ still needs of the step
-        const bool r_learn = o->P.algo == LOB_ALGO_R_LEARN || o->P.algo == LOB_ALGO_ONLINE_R_LEARN;
+        const bool r_learn = o->P.algo == LOB_ALGO_R_LEARN || o->P.algo == LOB_ALGO_ONLINE_R_LEARN || o->P.algo == LOB_ALGO_DOUBLE_R_LEARN;
         std::vector<double> rl_q(o->B, 0.0), rl_t(o->B, 0.0), rl_r(o->B, 0.0);
         for (int b = 0; b < o->B; b++) {
             if (o->done[b]) continue;
@@ -1131,7 +1132,23 @@ int oracle_td_step(oracle_learner* o, int32_t n_steps) {
             // HandleTransition: UpdateTraces, UpdateWeights (agent.cpp:86-115)
             double delta;
             int target = 1;
-            if (o->P.algo == LOB_ALGO_DOUBLE_Q) {
+            if (o->P.algo == LOB_ALGO_DOUBLE_R_LEARN) {
+                int amax = o->argmaxQ(b, o->last_feats[b]);  // DoubleRLearn::UpdateTraces, agent.cpp:422-430
+                if (a != amax) o->traces[b].decay(0.0f);
+                else o->traces[b].decay(rate);
+                o->traces[b].update(o->last_feats[b], a, 9, 32);
+                double Q, mQ;
+                if (o->agent_unif[b](o->agent_gen[b]) > 0.5) {  // UPDATE(A), agent.cpp:436-443
+                    Q = o->getQ(b, o->last_feats[b], a);
+                    mQ = o->getQ(b, o->feats[b], o->argmaxQ(b, o->feats[b]), true);
+                } else {  // UPDATE(B)
+                    Q = o->getQ(b, o->last_feats[b], a, true);
+                    mQ = o->getQ(b, o->feats[b], o->argmaxQ(b, o->feats[b], true));
+                    target = 2;
+                }
+                delta = reward - o->rh(b) + mQ - Q;
+                rl_q[b] = Q; rl_r[b] = reward;
+            } else if (o->P.algo == LOB_ALGO_DOUBLE_Q) {
                 int amax = o->argmaxQ(b, o->last_feats[b]);  // DoubleQLearn::UpdateTraces, agent.cpp:319-327
                 if (a != amax) o->traces[b].decay(0.0f);
                 else o->traces[b].decay(rate);
@@ -1202,6 +1219,16 @@ int oracle_td_step(oracle_learner* o, int32_t n_steps) {
             for (int b = 0; b < o->B; b++) {
                 if (!has[b]) continue;
                 const double nQ = rl_q[b] + upd[b];
+                if (o->P.algo == LOB_ALGO_DOUBLE_R_LEARN) {
+                    // agent.cpp:453-464: mQ = max_i (getQ + getQb) / 2.0 of from_state (first maximum), and THAT mQ in the increment
+                    double mQ = -DBL_MAX;
+                    for (int i = 0; i < 9; i++) {
+                        double val = (o->getQ(b, o->last_feats[b], i) + o->getQ(b, o->last_feats[b], i, true)) / 2.0;
+                        if (val > mQ) mQ = val;
+                    }
+                    if (nQ - mQ < 1e-7) inc[o->P.theta_mode == LOB_THETA_PRIVATE ? b : 0] += o->P.beta * (rl_r[b] - o->rh(b) + mQ - nQ);
+                    continue;
+                }
                 const double mq_from = o->getQ(b, o->last_feats[b], o->argmaxQ(b, o->last_feats[b]));
                 o->recs[b].rng_ctr = o->rng_ctr[b];
                 if (nQ - mq_from < 1e-7) inc[o->P.theta_mode == LOB_THETA_PRIVATE ? b : 0] += o->P.beta * (rl_r[b] - o->rh(b) + rl_t[b] - nQ);

@@ -619,6 +619,7 @@ int main(int argc, char** argv) {
         else if (algo == "double_q_learn") rc = run_dropin<rl::DoubleQLearn>(a, c, genv, a.get("out", tmp + ".traj"));
         else if (algo == "r_learn") rc = run_dropin<rl::RLearn>(a, c, genv, a.get("out", tmp + ".traj"));
         else if (algo == "online_r_learn") rc = run_dropin<rl::OnlineRLearn>(a, c, genv, a.get("out", tmp + ".traj"));
+        else if (algo == "double_r_learn") rc = run_dropin<rl::DoubleRLearn>(a, c, genv, a.get("out", tmp + ".traj"));
         if (!a.geti("keep", 0) && a.kv.count("stream")) { remove(md.c_str()); remove(tas.c_str()); }
         remove(yaml.c_str());
         return rc;
@@ -634,6 +635,7 @@ int main(int argc, char** argv) {
         else if (algo == "double_q_learn") rc = run_episode<rl::DoubleQLearn>(a, c, env, a.get("out", tmp + ".traj"));
         else if (algo == "r_learn") rc = run_episode<rl::RLearn>(a, c, env, a.get("out", tmp + ".traj"));
         else if (algo == "online_r_learn") rc = run_episode<rl::OnlineRLearn>(a, c, env, a.get("out", tmp + ".traj"));
+        else if (algo == "double_r_learn") rc = run_episode<rl::DoubleRLearn>(a, c, env, a.get("out", tmp + ".traj"));
         else { fprintf(stderr, "unknown algo\n"); rc = 2; }
     } else if (mode == "learner") {
         if (algo == "sarsa") rc = run_learner<rl::SARSA>(a, c, env);
@@ -641,6 +643,7 @@ int main(int argc, char** argv) {
         else if (algo == "double_q_learn") rc = run_learner<rl::DoubleQLearn>(a, c, env);
         else if (algo == "r_learn") rc = run_learner<rl::RLearn>(a, c, env);
         else if (algo == "online_r_learn") rc = run_learner<rl::OnlineRLearn>(a, c, env);
+        else if (algo == "double_r_learn") rc = run_learner<rl::DoubleRLearn>(a, c, env);
         else { fprintf(stderr, "unknown algo\n"); rc = 2; }
     } else {
         fprintf(stderr, "unknown mode %s\n", mode.c_str());

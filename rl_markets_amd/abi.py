@@ -28,7 +28,7 @@ REWARD_NAMES = {"none": 0, "pnl": 1, "pnl_damped": 2, "spread": 3, "normed": 4, 
                 "mm_exp": 7, "mm_div": 8}
 TP_MIDPRICE, TP_MICROPRICE = 0, 1
 QUOTE_TARGET, QUOTE_BOOK = 0, 1
-ALGO_SARSA, ALGO_QLAMBDA, ALGO_DOUBLE_Q, ALGO_R_LEARN, ALGO_ONLINE_R_LEARN = 0, 1, 2, 3, 4
+ALGO_SARSA, ALGO_QLAMBDA, ALGO_DOUBLE_Q, ALGO_R_LEARN, ALGO_ONLINE_R_LEARN, ALGO_DOUBLE_R_LEARN = 0, 1, 2, 3, 4, 5
 THETA_SHARED, THETA_PRIVATE = 0, 1
 POLICY_EPS_GREEDY, POLICY_BOLTZMANN = 0, 1
 

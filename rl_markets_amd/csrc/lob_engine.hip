@@ -200,7 +200,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     if (p->n_vars < 4 || p->n_vars > LOB_MAX_VARS) { lob_set_error("lob_create: n_vars must be in [4,13]"); return LOB_EINVAL; }
     if (p->memory_size < 1 || p->memory_size >= (1LL << 31)) { lob_set_error("lob_create: memory_size out of range"); return LOB_EINVAL; }
     if (p->market.n_bands < 1 || p->market.n_bands > LOB_MAX_BANDS) { lob_set_error("lob_create: bad tick table"); return LOB_EINVAL; }
-    if (p->algo < LOB_ALGO_SARSA || p->algo > LOB_ALGO_ONLINE_R_LEARN) { lob_set_error("lob_create: unknown algorithm"); return LOB_EINVAL; }
+    if (p->algo < LOB_ALGO_SARSA || p->algo > LOB_ALGO_DOUBLE_R_LEARN) { lob_set_error("lob_create: unknown algorithm"); return LOB_EINVAL; }
     if (p->policy != LOB_POLICY_EPS_GREEDY && p->policy != LOB_POLICY_BOLTZMANN) { lob_set_error("lob_create: unknown policy"); return LOB_EINVAL; }
     if (p->policy == LOB_POLICY_BOLTZMANN && !(p->tau > 0.0)) { lob_set_error("lob_create: Boltzmann temperature must be positive"); return LOB_EINVAL; }
     const int lbs[] = {p->lb_mpm, p->lb_vlt, p->lb_svl, p->lb_vwap, p->lb_rsi, p->lb_spread, p->lb_pnl, p->lb_target};
@@ -287,12 +287,16 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     for (int k = 0; k <= LOB_TRACE_GENS; k++) P.trace_pow[k] = trace_pow[k];
     P.trace_kmax = trace_kmax;
     P.trace_gens = P.trace_kmax <= 32 ? 32 : LOB_TRACE_GENS;
-    P.algo = p->algo; P.theta_private = p->theta_mode == LOB_THETA_PRIVATE;
+    // the average-reward agents are their base algorithm + r_learn (RLearn: Q(lambda), OnlineRLearn: SARSA, DoubleRLearn: double Q)
+    P.r_learn = p->algo >= LOB_ALGO_R_LEARN;
+    P.algo = p->algo == LOB_ALGO_R_LEARN ? LOB_ALGO_QLAMBDA : p->algo == LOB_ALGO_ONLINE_R_LEARN ? LOB_ALGO_SARSA
+             : p->algo == LOB_ALGO_DOUBLE_R_LEARN ? LOB_ALGO_DOUBLE_Q : p->algo;
+    P.theta_private = p->theta_mode == LOB_THETA_PRIVATE;
     { const char* nc = getenv("LOB_NO_CARRY"); P.carry_verdicts = !P.theta_private && !(nc && nc[0] == '1'); }
     { const char* nc = getenv("LOB_NO_COMBINE"); P.combine = !P.theta_private && !(nc && nc[0] == '1'); }
     {   // group-0 memo: shared theta, one weight vector, one book group
         const char* nc = getenv("LOB_NO_MEMO");
-        P.memo = !P.theta_private && (p->algo == LOB_ALGO_SARSA || p->algo == LOB_ALGO_QLAMBDA) && e->n_groups == 1 && !(nc && nc[0] == '1');
+        P.memo = !P.theta_private && P.algo != LOB_ALGO_DOUBLE_Q && !P.r_learn && e->n_groups == 1 && !(nc && nc[0] == '1');
         // the memo path never reads the carry-over filter, and its hot counter serialises first writes
         if (P.memo) P.carry_verdicts = 0;
     }
@@ -347,7 +351,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     if (rc == LOB_OK) rc = dev_alloc(e, &S.tr_alive, B * (size_t)P.trace_gens);
     if (rc == LOB_OK) rc = dev_alloc(e, &S.theta, (size_t)P.M * (P.theta_private ? B : 1));
     if (rc == LOB_OK) rc = dev_alloc(e, &S.theta_nz, LOB_NZ_NWORDS(P.M) * (P.theta_private ? B : 1));
-    if (p->algo == LOB_ALGO_DOUBLE_Q) {
+    if (P.algo == LOB_ALGO_DOUBLE_Q) {
         if (rc == LOB_OK) rc = dev_alloc(e, &S.theta_b, (size_t)P.M * (P.theta_private ? B : 1));
         if (rc == LOB_OK) rc = dev_alloc(e, &S.theta_b_nz, LOB_NZ_NWORDS(P.M) * (P.theta_private ? B : 1));
         if (rc == LOB_OK) rc = dev_alloc(e, &S.qs_last_b, B * LOB_N_ACTIONS);
@@ -355,7 +359,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
         if (rc == LOB_OK) rc = dev_alloc(e, &S.mt_idx, B);
     }
     {
-        const bool rl = p->algo == LOB_ALGO_R_LEARN || p->algo == LOB_ALGO_ONLINE_R_LEARN;
+        const bool rl = P.r_learn != 0;
         const size_t nr = rl ? (P.theta_private ? B : 1) : 1;
         if (rc == LOB_OK) rc = dev_alloc(e, &S.rho, nr);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.rho_inc, nr);
@@ -441,7 +445,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     }
     if (rc == LOB_OK) rc = dev_alloc(e, &S.verdict, B * LOB_VD_STRIDE);
     if (rc == LOB_OK) rc = dev_alloc(e, &S.nz_new, 4 * LOB_NZ_WORDS);
-    if (rc == LOB_OK) rc = dev_alloc(e, &S.verdict_b, p->algo == LOB_ALGO_DOUBLE_Q ? B * 64 : 1);
+    if (rc == LOB_OK) rc = dev_alloc(e, &S.verdict_b, P.algo == LOB_ALGO_DOUBLE_Q ? B * 64 : 1);
     if (rc == LOB_OK) rc = dev_alloc(e, &S.nz_epoch, 1);
     if (rc == LOB_OK) rc = dev_alloc(e, &S.counters, 8);
     if (rc == LOB_OK) rc = dev_alloc(e, &S.error_flag, 1);
@@ -479,7 +483,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
         HIPCHK_E(hipMemcpyAsync(e->rnd_dev, rnd, sizeof rnd, hipMemcpyHostToDevice, e->stream));
         HIPCHK_E(hipStreamSynchronize(e->stream));
     }
-    if (p->algo == LOB_ALGO_DOUBLE_Q) {
+    if (P.algo == LOB_ALGO_DOUBLE_Q) {
         hipLaunchKernelGGL(mt_init_kernel, dim3(grid_lanes(e->B)), dim3(256), 0, e->stream, e->P, e->S);
         HIPCHK_E(hipGetLastError());
         HIPCHK_E(hipStreamSynchronize(e->stream));
@@ -894,7 +898,7 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode) {
             } else if (mode == 0) {
                 TimedLaunch t(e, "learn_kernel", st);
                 if (e->P.algo == LOB_ALGO_DOUBLE_Q) hipLaunchKernelGGL((learn_kernel<LOB_ALGO_DOUBLE_Q, false>), dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, b0, nb, par, (const i32*)nullptr, (const i32*)nullptr);
-                else if (e->P.algo == LOB_ALGO_QLAMBDA || e->P.algo == LOB_ALGO_R_LEARN) hipLaunchKernelGGL((learn_kernel<LOB_ALGO_QLAMBDA, false>), dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, b0, nb, par, (const i32*)nullptr, (const i32*)nullptr);
+                else if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL((learn_kernel<LOB_ALGO_QLAMBDA, false>), dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, b0, nb, par, (const i32*)nullptr, (const i32*)nullptr);
                 else hipLaunchKernelGGL((learn_kernel<LOB_ALGO_SARSA, false>), dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, b0, nb, par, (const i32*)nullptr, (const i32*)nullptr);
             }
         }
@@ -918,7 +922,7 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode) {
             TimedLaunch t(e, "update_kernel");
             hipLaunchKernelGGL(update_kernel, dim3(grid_waves(e->B)), dim3(LOB_BLOCK), 0, e->stream, e->P, e->S, par, e->step_id);
         }
-        if (mode == 0 && (e->P.algo == LOB_ALGO_R_LEARN || e->P.algo == LOB_ALGO_ONLINE_R_LEARN)) {
+        if (mode == 0 && e->P.r_learn) {
             // R-learning: the average reward rho, after updateQ (rho_kernel, lob_kernels.h)
             TimedLaunch t(e, "rho_kernel");
             const int nr = e->P.theta_private ? e->B : 1;

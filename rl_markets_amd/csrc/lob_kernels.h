@@ -954,15 +954,19 @@ __device__ __forceinline__ void learn_book(const DevParams& P, const DevState& S
         if (mi >= LOB_MT_N) { mt64_twist_wave(mt, reinterpret_cast<u64*>(L.vals[w]), lane); mi = 0; }
         const f64 coin = mt64_canonical(mt64_temper(mt[mi]));
         if (lane == 0) S.mt_idx[b] = mi + 1;
+        // (DoubleRLearn::UpdateWeights, agent.cpp:432-451: the same two branches with delta = reward - rho + mQ - Q)
+        const f64 rho = P.r_learn ? S.rho[P.theta_private ? b : 0] : 0.0;
         if (coin > 0.5) {  // UPDATE(A)
             const int am = argmax_ties(qs_to, g);
-            delta = reward + F_term + P.gamma * sel9(qb_to, am) - sel9(qs_last, action);
+            delta = P.r_learn ? reward - rho + sel9(qb_to, am) - sel9(qs_last, action)
+                              : reward + F_term + P.gamma * sel9(qb_to, am) - sel9(qs_last, action);
         } else {           // UPDATE(B)
             f64 qb_last[LOB_N_ACTIONS];
 #pragma unroll
             for (int a = 0; a < LOB_N_ACTIONS; a++) qb_last[a] = S.qs_last_b[(size_t)b * LOB_N_ACTIONS + a];
             const int am = argmax_ties(qb_to, g);
-            delta = reward + F_term + P.gamma * sel9(qs_to, am) - sel9(qb_last, action);
+            delta = P.r_learn ? reward - rho + sel9(qs_to, am) - sel9(qb_last, action)
+                              : reward + F_term + P.gamma * sel9(qs_to, am) - sel9(qb_last, action);
             target = 2;
         }
         if (lane == 0 && target == 2) hp->stepped = 2;  // update_kernel scatters into theta_b
@@ -972,7 +976,7 @@ __device__ __forceinline__ void learn_book(const DevParams& P, const DevState& S
             hp->rng_ctr = g.ctr;
         }
     } else {
-        const bool r_learn = P.algo == LOB_ALGO_R_LEARN || P.algo == LOB_ALGO_ONLINE_R_LEARN;  // (run as the Q(lambda) / SARSA instantiation)
+        const bool r_learn = P.r_learn != 0;  // RLearn / OnlineRLearn: the Q(lambda) / SARSA instantiation with the average-reward TD error
         learn_delta_single<ALGO == LOB_ALGO_DOUBLE_Q ? LOB_ALGO_SARSA : ALGO>(P, hp, h, qs_to, sel9(qs_last, action), g, lane,
                                                                               r_learn ? S.rho + (P.theta_private ? b : 0) : nullptr, S.rl_t + b);
     }
@@ -1114,11 +1118,29 @@ __global__ void __launch_bounds__(LOB_BLOCK) rho_kernel(DevParams P, DevState S,
     const uint32_t* nz = S.theta_nz + (P.theta_private ? (size_t)b * LOB_NZ_NWORDS(P.M) : 0);
     f64 qs[LOB_N_ACTIONS];
     q_values(P, theta, nz, L.vars[w][last], zero_last, L.rnd, L.act_terms, L.vals[w], lane, qs);
+    const int ri = P.theta_private ? b : 0;
+    const f64 rho = S.rho[ri];
+    if (P.algo == LOB_ALGO_DOUBLE_Q) {
+        // DoubleRLearn (agent.cpp:453-464): mQ = max over the actions of (getQ + getQb) / 2.0 of from_state (first maximum: no
+        // draws), Q = the vector's that was updated, and the increment uses THIS mQ, not the bootstrap value
+        f64 qb[LOB_N_ACTIONS];
+        q_values(P, S.theta_b + (P.theta_private ? (size_t)b * (size_t)P.M : 0), S.theta_b_nz + (P.theta_private ? (size_t)b * LOB_NZ_NWORDS(P.M) : 0),
+                 L.vars[w][last], zero_last, L.rnd, L.act_terms, L.vals[w], lane, qb);
+        f64 mQ = -1.7976931348623157e308;
+#pragma unroll
+        for (int a = 0; a < LOB_N_ACTIONS; a++) {
+            const f64 val = (qs[a] + qb[a]) / 2.0;
+            if (val > mQ) mQ = val;
+        }
+        const f64 Q = (h.stepped == 2 ? S.qs_last_b : S.qs_last)[(size_t)b * LOB_N_ACTIONS + h.action];
+        const f64 nQ = Q + h.upd;
+        if (lane == 0 && nQ - mQ < 1e-7)
+            __hip_atomic_fetch_add(&S.rho_inc[ri], P.beta * (h.reward - rho + mQ - nQ), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
     Rng g{P.seed, P.book_id_offset + (u64)b, h.rng_ctr};
     const int am = argmax_ties(qs, g);
     const f64 mq_from = sel9(qs, am);
-    const int ri = P.theta_private ? b : 0;
-    const f64 rho = S.rho[ri];
     const f64 nQ = S.qs_last[(size_t)b * LOB_N_ACTIONS + h.action] + h.upd;
     if (lane == 0) {
         S.hdr[b].rng_ctr = g.ctr;

@@ -319,6 +319,8 @@ struct DevParams {
     i32 policy;                       // LOB_POLICY_*
     f64 tau;                          // Boltzmann temperature
     f64 beta;                         // R-learning: step size of rho
+    i32 r_learn;                      // 1: the agent is the average-reward variant of `algo` (RLearn of Q(lambda), OnlineRLearn of
+                                      //   SARSA, DoubleRLearn of double Q): `algo` here is always one of the three base algorithms
     f32 trace_rate;                   // (float)(gamma*lambda)
     f32 trace_pow[LOB_TRACE_GENS + 1];  // eligibility by age, iterated float products
     i32 trace_kmax;                   // first age whose eligibility < tolerance

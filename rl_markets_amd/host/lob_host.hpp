@@ -199,8 +199,9 @@ public:
         else if (algo == "double_q_learn") p.algo = LOB_ALGO_DOUBLE_Q;
         else if (algo == "r_learn") p.algo = LOB_ALGO_R_LEARN;                // src/main.cpp:179-183
         else if (algo == "online_r_learn") p.algo = LOB_ALGO_ONLINE_R_LEARN;
-        else throw std::invalid_argument("Unknown learning algorithm: " + algo + " (supported: sarsa, q_learn, double_q_learn, r_learn, online_r_learn)");
-        if (p.algo == LOB_ALGO_R_LEARN || p.algo == LOB_ALGO_ONLINE_R_LEARN) p.beta = num("learning.beta");  // (required, as c["learning"]["beta"].as<double>())
+        else if (algo == "double_r_learn") p.algo = LOB_ALGO_DOUBLE_R_LEARN;
+        else throw std::invalid_argument("Unknown learning algorithm: " + algo);  // as src/main.cpp:187-188
+        if (p.algo >= LOB_ALGO_R_LEARN) p.beta = num("learning.beta");  // (required, as c["learning"]["beta"].as<double>())
         p.seed = (uint64_t)integer("debug.random_seed", 1994);
         return p;
     }

@@ -174,12 +174,16 @@ def main():
                                 theta_val=theta[1], steps=info["steps"], end=info["end"], rng_ctr=info["rng_ctr"])
             print(name, info)
         # ---- DoubleQLearn (config/example.yaml's default algorithm): theta_b + the agent's own mt19937_64 coin ----
-        for name, n_events, book in (("double_q_b4", 520, 4), ("double_q_b17", 400, 17)):
+        # ... and rl::DoubleRLearn, the same two vectors with the average-reward TD error (agent.cpp:416-467)
+        for name, n_events, book, ralgo, rextra in (("double_q_b4", 520, 4, "double_q_learn", {}), ("double_q_b17", 400, 17, "double_q_learn", {}),
+                                                    ("double_r_b26", 450, 26, "double_r_learn", {"beta": "0.02"})):
+            if "--only" in sys.argv and name not in sys.argv:
+                continue
             g.n_events = n_events
             rec = engine.gen_stream_host(g, 5, 2, book, 1)
             tb = os.path.join(td, "theta_b.bin")
-            traj, info, theta = ol.run_ref_episode(rec[0], algo="double_q_learn", mem=1 << 20, rng_stream=book,
-                                                   extra={"agent_seed": 1994 + book, "theta_b_out": tb})
+            traj, info, theta = ol.run_ref_episode(rec[0], algo=ralgo, mem=1 << 20, rng_stream=book,
+                                                   extra=dict({"agent_seed": 1994 + book, "theta_b_out": tb}, **rextra))
             raw = np.fromfile(tb, dtype=np.uint8)
             nn = int(np.frombuffer(raw[:8].tobytes(), dtype=np.int64)[0])
             pairs = np.frombuffer(raw[8:8 + 16 * nn].tobytes(), dtype=[("i", np.int64), ("v", np.float64)])

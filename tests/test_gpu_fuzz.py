@@ -46,7 +46,7 @@ def random_case(seed):
     p.lambda_ = float(r.uniform(0.0, min(0.95, 0.93 / p.gamma)))
     p.alpha = float(r.choice([0.0, 1e-4, 1e-2, 0.3]))
     p.epsilon = float(r.choice([0.0, 0.1, 0.8, 1.0]))
-    p.algo = int(r.integers(0, 5))  # SARSA, Q(lambda), double Q, R-learning, on-line R-learning
+    p.algo = int(r.integers(0, 6))  # SARSA, Q(lambda), double Q, and their average-reward variants (R-learning)
     p.theta_mode = int(r.integers(0, 2))
     p.seed = int(r.integers(0, 1 << 40))
     p.book_id_offset = int(r.choice([0, 7, 1 << 20]))

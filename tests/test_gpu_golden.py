@@ -157,7 +157,7 @@ from tests.test_oracle_golden import DOUBLE_Q_CASES, _check_sparse  # noqa: E402
 def test_engine_double_q_vs_reference(case):
     """rl::DoubleQLearn: both weight vectors, (Qa+Qb)/2 action values, and the update coin drawn
     from a device-side std::mt19937_64 that must reproduce libstdc++'s stream."""
-    name, n_events, book = case
+    name, n_events, book = case[:3]
     fx = np.load(os.path.join(GOLD, "traj_%s.npz" % name))
     traj = fx["traj"]
     g = engine.default_gen_params()
@@ -165,6 +165,8 @@ def test_engine_double_q_vs_reference(case):
     rec = engine.gen_stream_host(g, 5, 2, book, 1)
     p = _params_for({}, "sarsa", book)
     p.algo = abi.ALGO_DOUBLE_Q
+    if len(case) > 3:  # rl::DoubleRLearn
+        p.algo, p.beta = case[3], case[4]
     eng = engine.Engine(p, 1)
     eng.load_events(rec)
     eng.reset()

@@ -714,10 +714,10 @@ def test_trace_light_kernel_on_off_identical(monkeypatch, mem, eps, lanes):
     np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-9, atol=1e-12)
 
 
-@pytest.mark.parametrize("algo", [abi.ALGO_R_LEARN, abi.ALGO_ONLINE_R_LEARN])
+@pytest.mark.parametrize("algo", [abi.ALGO_R_LEARN, abi.ALGO_ONLINE_R_LEARN, abi.ALGO_DOUBLE_R_LEARN])
 @pytest.mark.parametrize("theta_mode", [abi.THETA_PRIVATE, abi.THETA_SHARED])
 def test_r_learning_against_oracle(algo, theta_mode):
-    """rl::RLearn / rl::OnlineRLearn (src/rl/agent.cpp:357-412): TD error without discount against the average reward
+    """rl::RLearn / rl::OnlineRLearn / rl::DoubleRLearn (src/rl/agent.cpp:357-467): TD error without discount against the average reward
     rho, and rho's own update after updateQ -- conditional on maxQ(from_state) under the NEW weights (rho_kernel).  The
     oracle reproduces two reference trajectories of these agents (tests/golden/traj_rlearn_b24, traj_online_rlearn_b25);
     here the engine follows the oracle step by step: private weights bit for bit (rho included), shared weights up to

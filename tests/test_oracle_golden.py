@@ -204,7 +204,8 @@ def test_oracle_multi_episode(case):
     np.testing.assert_array_equal(th[nz], fx["theta_val"])
 
 
-DOUBLE_Q_CASES = [("double_q_b4", 520, 4), ("double_q_b17", 400, 17)]
+# name, events, book (+ for rl::DoubleRLearn: the algorithm and beta)
+DOUBLE_Q_CASES = [("double_q_b4", 520, 4), ("double_q_b17", 400, 17), ("double_r_b26", 450, 26, abi.ALGO_DOUBLE_R_LEARN, 0.02)]
 
 
 def _check_sparse(th, idx, val):
@@ -215,13 +216,15 @@ def _check_sparse(th, idx, val):
 
 @pytest.mark.parametrize("case", DOUBLE_Q_CASES, ids=[c[0] for c in DOUBLE_Q_CASES])
 def test_oracle_double_q_matches_reference(case):
-    name, n_events, book = case
+    name, n_events, book = case[:3]
     fx = np.load(os.path.join(GOLD, "traj_%s.npz" % name))
     g = engine.default_gen_params()
     g.n_events = n_events
     rec = engine.gen_stream_host(g, 5, 2, book, 1)
     p = _params_for({}, "sarsa", book)
     p.algo = abi.ALGO_DOUBLE_Q
+    if len(case) > 3:
+        p.algo, p.beta = case[3], case[4]
     o = ol.Oracle(p, rec)
     o.reset()
     compare_traj(lambda: o.td_step(1), lambda: o.rec(0), fx["traj"], name)
