@@ -3,7 +3,7 @@
 // n episodes on synthetic streams, evaluate greedily, print the per-episode
 // rows of the reference's training_log (serial.cpp:81-88) for book 0.
 //
-//   lob_run -c config/engine.yaml [-n books] [-e episodes] [-a sarsa|q_learn|double_q_learn] [--events N] [--depth D]
+//   lob_run -c config/engine.yaml [-n books] [-e episodes] [-a sarsa|q_learn|double_q_learn|r_learn|online_r_learn|double_r_learn] [--events N] [--depth D]
 //           [--theta out.bin] [--profit-log profit_log.csv]
 //           [--gpus N [--sync-every K]]   one process per GPU (forked here), -n books EACH, book ids rank * n ..,
 //            delta-theta all-reduced over RCCL/xGMI every K steps (include/lob_comm.h): the stand-in for the

@@ -49,8 +49,13 @@ def test_lob_run_errors_like_the_reference():
     exe = os.path.join(ROOT, "rl_markets_amd", "host", "lob_run")
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 2 and "Unhandled Exception" in out.stderr
-    out = subprocess.run([exe, "-c", os.path.join(ROOT, "config", "engine.yaml"), "-a", "r_learn"], capture_output=True, text=True)
-    assert out.returncode == 2 and "Unknown learning algorithm" in out.stderr
+    out = subprocess.run([exe, "-c", os.path.join(ROOT, "config", "engine.yaml"), "-a", "td_zero"], capture_output=True, text=True)
+    assert out.returncode == 2 and "Unknown learning algorithm" in out.stderr  # src/main.cpp:187-188
+    # every algorithm main.cpp knows runs (the average-reward agents read learning.beta from the config)
+    for algo in ("q_learn", "double_q_learn", "r_learn", "online_r_learn", "double_r_learn"):
+        out = subprocess.run([exe, "-c", os.path.join(ROOT, "config", "engine.yaml"), "-a", algo, "-n", "1", "-e", "1", "--events", "300"],
+                             capture_output=True, text=True)
+        assert out.returncode == 0, (algo, out.stderr)
 
 
 def test_lob_run_backtest_profit_log(tmp_path):
