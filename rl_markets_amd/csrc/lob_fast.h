@@ -1,5 +1,15 @@
-// The fast learner path (shared theta, SARSA / Q(lambda)): persistent 16-wave blocks, one per CU.
+// The fast learner path (shared theta, SARSA / Q(lambda)).  Kernels of one step, in launch order:
+//     act_light_kernel        action selection from the hit list the previous step's learn kernel left (a lane per book);
+//                             act_fast_kernel, the full evaluation (a wave per book), when there is no valid list
+//     [env_kernel, memo_kernel: lob_kernels.h]
+//     learn_q_pair_kernel     Q(s', .), TD error, hit list -- two lanes per book -- and, Q(lambda), the trace step of the books
+//                             whose step leaves no older generation; learn_q_lane_kernel (one lane per book) for tables of
+//                             2^27 weights and more, learn_q_fast_kernel (a wave per book) for batches below 32 768 books
+//     trace_fast_kernel       the remaining trace steps, a wave per book (all of them for SARSA(lambda));
+//                             trace_light_kernel: the light trace step as its own kernel when the learn kernel is the wave one
+//     [accumulate_kernel, apply_kernel, memo_kernel: lob_kernels.h]
 //
+// The wave-per-book Q evaluation (act_fast_kernel, learn_q_fast_kernel): persistent 16-wave blocks, one per CU.
 // What bounds the per-book Q evaluation after the group-0 memo (lob_learn.h) is the 576 group-1/2
 // "was this weight ever written" look-ups: divergent 4-byte gathers from the L2-resident map run
 // at ~280 G lane-loads/s on the whole chip (tools/ubench/gather2: 37.7 M of them per launch =
