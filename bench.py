@@ -358,7 +358,7 @@ def main():
         print(result, flush=True)
 
 
-KERNELS = ("act_kernel", "act_rest_kernel", "env_kernel", "memo_kernel", "trace_light_kernel", "trace_kernel", "learn_kernel", "learn_rest_kernel",
+KERNELS = ("act_kernel", "act_rest_kernel", "env_kernel", "env_rest_kernel", "memo_kernel", "trace_light_kernel", "trace_kernel", "learn_kernel", "learn_rest_kernel",
            "update_kernel", "accumulate_kernel", "apply_kernel", "prepass_extend_kernel", "delta_begin_kernel", "delta_apply_kernel")
 
 if __name__ == "__main__":

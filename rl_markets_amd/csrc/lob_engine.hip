@@ -56,6 +56,8 @@ struct lob_engine {
     bool hits_ok = false;       // the previous call was a fast-path learner step and nothing has touched weights, maps or states since:
                                 // the hit lists its learn kernel left are those of the States the next step acts on (act_light_kernel)
     bool light = true;          // use them (LOB_NO_LIGHT=1: always the full act kernel, for A/B runs)
+    bool force_fuse_act = false;
+    bool fuse_act = true;       // ... inside the env kernel (env_kernel<.., 1>; LOB_NO_FUSE_ACT=1: act_light_kernel as a launch of its own)
  bool t_light = true;        // trace_light_kernel in front of the wave-per-book trace kernel (Q(lambda); LOB_NO_TLIGHT=1: off)
     bool q_pair = true;         // ... two lanes per book (learn_q_pair_kernel; LOB_Q_PAIR=0: one)
     int q_lanes = -1;           // learn_q_lane_kernel (a lane per book) instead of learn_q_fast_kernel (a wave per book): -1 by batch size,
@@ -259,6 +261,8 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     if (const char* g = getenv("LOB_TRACK_REFILL")) { int v = atoi(g); if (v >= 1) e->track_refill = v; }
     if (const char* g = getenv("LOB_ACC_LANES")) { int v = atoi(g); if (v == 8 || v == 16 || v == 32 || v == 64) e->acc_shift = v == 8 ? 3 : v == 16 ? 4 : v == 32 ? 5 : 6; }
     if (const char* g = getenv("LOB_NO_LIGHT")) e->light = !(g[0] == '1');
+    if (const char* g = getenv("LOB_NO_FUSE_ACT")) e->fuse_act = !(g[0] == '1');
+    if (const char* g = getenv("LOB_FUSE_ACT")) e->force_fuse_act = g[0] == '1';  // (also for small batches: the tests)
     if (const char* g = getenv("LOB_Q_LANES")) e->q_lanes = g[0] == '1' ? 1 : 0;
     if (const char* g = getenv("LOB_NO_TLIGHT")) e->t_light = !(g[0] == '1');
     if (const char* g = getenv("LOB_Q_PAIR")) e->q_pair = !(g[0] == '0');
@@ -657,9 +661,31 @@ static void maybe_refill_track(lob_engine* e) {
 }
 // S0 of every group-0 triple on this step's list (lob_kernels.h memo_kernel): `which` 0 = for learn_kernel
 // (theta_t), 1 = for the next act_kernel (after the update)
-static void launch_memo(lob_engine* e, int par, int which) {
+static void launch_memo(lob_engine* e, int par, int which, int reset_lpar = -1) {
     TimedLaunch t(e, "memo_kernel");
-    hipLaunchKernelGGL(memo_kernel, dim3(256), dim3(256), 0, e->stream, e->P, e->S, (const uint32_t*)e->rnd_dev, par, which, (u64)e->theta_ver);
+    hipLaunchKernelGGL(memo_kernel, dim3(256), dim3(256), 0, e->stream, e->P, e->S, (const uint32_t*)e->rnd_dev, par, which, (u64)e->theta_ver, reset_lpar);
+}
+// The learner step's action selection inside the env kernel (env_kernel<64, TM, 1>), the general act kernel for the books it
+// leaves on the work list, and their steps (env_kernel<64, TM, 2>).
+static void launch_env_fused(lob_engine* e, hipStream_t st, int par, int lpar, u64 ver, const i32* act_list, const i32* act_n, int gl) {
+    const DevParams* Pd = (const DevParams*)e->P_dev;
+    const bool t2 = e->P.T <= 2;
+    const int nb = e->B, sid = e->step_id;
+    const EnvFuse F1{nullptr, nullptr, lpar, sid - 1, ver}, F2{act_list, act_n, lpar, sid - 1, ver};
+    {
+        TimedLaunch t(e, "env_kernel", st);
+        if (t2) hipLaunchKernelGGL((env_kernel<64, 2, 1>), dim3((nb + 63) / 64), dim3(64), 0, st, Pd, e->S, (const i32*)nullptr, 1, 0, nb, sid, par, F1);
+        else hipLaunchKernelGGL((env_kernel<64, LOB_MAX_TRADES, 1>), dim3((nb + 63) / 64), dim3(64), 0, st, Pd, e->S, (const i32*)nullptr, 1, 0, nb, sid, par, F1);
+    }
+    {
+        TimedLaunch t(e, "act_rest_kernel", st);
+        hipLaunchKernelGGL((act_kernel<LOB_ALGO_SARSA, true>), dim3(gl), dim3(LOB_BLOCK), 0, st, e->P, e->S, (const uint32_t*)e->rnd_dev, 0, 0, e->B, par, act_list, act_n);
+    }
+    {
+        TimedLaunch t(e, "env_rest_kernel", st);
+        if (t2) hipLaunchKernelGGL((env_kernel<64, 2, 2>), dim3((nb + 63) / 64), dim3(64), 0, st, Pd, e->S, (const i32*)nullptr, 1, 0, nb, sid, par, F2);
+        else hipLaunchKernelGGL((env_kernel<64, LOB_MAX_TRADES, 2>), dim3((nb + 63) / 64), dim3(64), 0, st, Pd, e->S, (const i32*)nullptr, 1, 0, nb, sid, par, F2);
+    }
 }
 
 int lob_reset(lob_engine* e) {
@@ -824,7 +850,11 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode) {
             // stagger: group 1 starts acting when group 0 has finished acting, so that the
             // latency-bound env kernel of one group runs beside a gather kernel of the other
             if (G > 1 && g == 1) HIPCHK(hipStreamWaitEvent(st, e->ev_stagger, 0));
-            if (fast) {
+            // (big batches, env_kernel<64>: the action selection rides in the env kernel)
+            const bool fused_act = fast && mode == 0 && e->hits_ok && e->light && e->fuse_act && e->env_lanes == 0 && (e->B > 16384 || e->force_fuse_act);
+            if (fused_act) {
+                launch_env_fused(e, st, par, lpar, ver, act_list, act_n, gl);
+            } else if (fast) {
                 {
                     TimedLaunch t(e, "act_kernel", st);
                     if (mode == 0 && e->hits_ok && e->light)
@@ -842,7 +872,7 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode) {
                 else hipLaunchKernelGGL((act_kernel<LOB_ALGO_SARSA, false>), dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, mode, b0, nb, par, (const i32*)nullptr, (const i32*)nullptr);
             }
             if (G > 1 && g == 0) HIPCHK(hipEventRecord(e->ev_stagger, st));
-            {
+            if (!fused_act) {
                 TimedLaunch t(e, "env_kernel", st);
                 launch_env(e, st, (const i32*)nullptr, mode == 0 ? 1 : 0, b0, nb, par);
             }
@@ -931,7 +961,7 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode) {
         }
         if (mode == 0) {
             e->theta_ver++;                          // theta_{t+1}
-            if (e->P.memo) launch_memo(e, par, 1);   // the same triples again, for the next act_kernel
+            if (e->P.memo) launch_memo(e, par, 1, lpar);   // the same triples again, for the next action selection (+ its list resets)
         }
         e->hits_ok = mode == 0 && fast;              // learn_q_fast_kernel has left the hit lists of the States the next step acts on
         maybe_refill_track(e);

@@ -1,6 +1,7 @@
 // The fast learner path (shared theta, SARSA / Q(lambda)).  Kernels of one step, in launch order:
-//     act_light_kernel        action selection from the hit list the previous step's learn kernel left (a lane per book);
-//                             act_fast_kernel, the full evaluation (a wave per book), when there is no valid list
+//     act_light_book          action selection from the hit list the previous step's learn kernel left (a lane per book), inside
+//                             env_kernel<.., 1> (lob_kernels.h) or as act_light_kernel; act_fast_kernel, the full evaluation
+//                             (a wave per book), when there is no valid list
 //     [env_kernel, memo_kernel: lob_kernels.h]
 //     learn_q_pair_kernel     Q(s', .), TD error, hit list -- two lanes per book -- and, Q(lambda), the trace step of the books
 //                             whose step leaves no older generation; learn_q_lane_kernel (one lane per book) for tables of
@@ -386,28 +387,20 @@ __device__ __forceinline__ void mark_generation(const DevParams& P, const DevSta
 // not of this weight version, or -- never in the steady state -- every book after an update set a map bit that the trace
 // kernel had not (`hl_dirty`), goes to the general kernel through the work list, like act_fast_kernel's hand-backs.
 #define LOB_LIGHT_BLOCK 256
-__global__ void __launch_bounds__(LOB_LIGHT_BLOCK) act_light_kernel(DevParams P, DevState S, int par, int lpar, u64 ver, int sid_prev) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        S.cb_count[0] = 0;    // (as act_fast_kernel)
-        S.mk_count[par] = 0;
-        S.slow_n[(lpar ^ 1) * 2 + 0] = 0;
-        S.slow_n[(lpar ^ 1) * 2 + 1] = 0;
-        S.tr_list_n[lpar ^ 1] = 0;
-    }
-    const int b = blockIdx.x * LOB_LIGHT_BLOCK + threadIdx.x;
-    if (b >= S.B) return;
-    const bool dirty = S.hl_dirty[0] == sid_prev;
-    const LHdr h = S.hdr[b];
+// One book's part of it (one lane): false if the book does not step now -- done, terminal, or handed to the general kernel
+// through the act work list (then its header is left alone) --, else the action (header and Q(s, .) stored).
+__device__ inline bool act_light_book(const DevParams& P, const DevState& S, int b, const LHdr& h, int lpar, u64 ver, bool dirty, int& action) {
     LHdr* hp = S.hdr + b;
     // the first 64 bytes of the book's list -- the count and seven entries, the usual case in full -- with the header
     const ulonglong2* lp = reinterpret_cast<const ulonglong2*>(S.hl_rec + (size_t)b * LOB_HL_REC);
     const ulonglong2 l0 = lp[0], l1 = lp[1], l2 = lp[2], l3 = lp[3];
     const int mslot = S.mk_slot[b];
     const int cur = h.slot_cur ^ 1;  // swap(state, last_state)
-    if (h.done) { hp->stepped = 0; return; }
+    action = 0;
+    if (h.done) { hp->stepped = 0; return false; }
     if (!is_open(P, h.time_ms)) {  // environment.isTerminal()
         hp->slot_cur = cur; hp->done = 1; hp->stepped = 0; S.done[b] = 1;
-        return;
+        return false;
     }
     const int n = l0.x == LOB_HL_NONE ? -1 : (int)l0.x;
     bool ok = !dirty && !((h.zero_mask >> (cur ^ 1)) & 1) && mslot >= 0 && n >= 0;
@@ -426,7 +419,7 @@ __global__ void __launch_bounds__(LOB_LIGHT_BLOCK) act_light_kernel(DevParams P,
     if (!ok) {
         const int pos = atomicAdd(&S.slow_n[lpar * 2 + 0], 1);
         S.slow_list[pos] = b;
-        return;
+        return false;
     }
     const f64 w1 = P.w1, w2 = P.w2;
 #define LOB_LIGHT_ADD(ENT, V)                                                              \
@@ -458,7 +451,7 @@ __global__ void __launch_bounds__(LOB_LIGHT_BLOCK) act_light_kernel(DevParams P,
 #pragma unroll
     for (int a = 0; a < LOB_N_ACTIONS; a++) S.qs_last[(size_t)b * LOB_N_ACTIONS + a] = q[a];
     Rng g{P.seed, P.book_id_offset + (u64)b, h.rng_ctr};
-    const int action = policy_sample(P, q, false, g);
+    action = policy_sample(P, q, false, g);
     hp->slot_cur = cur;
     hp->action = action;
     hp->stepped = 1;
@@ -474,6 +467,21 @@ __global__ void __launch_bounds__(LOB_LIGHT_BLOCK) act_light_kernel(DevParams P,
     }
     const u64 act = __ballot(1);
     if ((int)(threadIdx.x & 63) == __builtin_ctzll(act)) atomicAdd((unsigned long long*)&S.counters[5], (unsigned long long)__builtin_popcountll(act));
+    return true;
+}
+__global__ void __launch_bounds__(LOB_LIGHT_BLOCK) act_light_kernel(DevParams P, DevState S, int par, int lpar, u64 ver, int sid_prev) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        S.cb_count[0] = 0;    // (as act_fast_kernel)
+        S.mk_count[par] = 0;
+        S.slow_n[(lpar ^ 1) * 2 + 0] = 0;
+        S.slow_n[(lpar ^ 1) * 2 + 1] = 0;
+        S.tr_list_n[lpar ^ 1] = 0;
+    }
+    const int b = blockIdx.x * LOB_LIGHT_BLOCK + threadIdx.x;
+    if (b >= S.B) return;
+    const LHdr h = S.hdr[b];
+    int action;
+    act_light_book(P, S, b, h, lpar, ver, S.hl_dirty[0] == sid_prev, action);
 }
 
 // Agent::UpdateTraces for every book that stepped (learn_traces), the first half of learn_book; leaves

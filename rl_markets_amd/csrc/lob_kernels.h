@@ -242,22 +242,40 @@ __global__ void __launch_bounds__(256) get_state_kernel(const DevParams* __restr
 // books; at 65 536 books the same choice is slower (0.31 vs 0.19 ms).
 // TM = compile-time bound of the trade slots per record (lob_params.max_trades <= TM): the merged trade
 // list of a pass lives in registers, and the engine's default of 2 slots should not carry arrays of 8.
-template <int LOB_ENV_BLOCK, int TM>
+// MODE 0: the books b0 .. b0 + nb - 1, their actions chosen by an act kernel (or given by the host).
+// MODE 1: the same, the action chosen HERE from the book's hit list (act_light_book, lob_fast.h): the look-ups of the
+//         action selection and of the step's first loads share their round trips, and the step is one launch shorter.  A
+//         book without a valid list goes on the act work list and is skipped; after the general act kernel has served the
+//         list, MODE 2 takes its books' steps.
+// MODE 2: the books of the work list `list` (`*list_n` entries).
+struct EnvFuse {  // MODE 1 / 2
+    const i32* list;
+    const i32* list_n;
+    int lpar, sid_prev;
+    u64 ver;
+};
+__device__ inline bool act_light_book(const DevParams& P, const DevState& S, int b, const LHdr& h, int lpar, u64 ver, bool dirty, int& action);
+template <int LOB_ENV_BLOCK, int TM, int MODE = 0>
 __global__ void __launch_bounds__(LOB_ENV_BLOCK) env_kernel(const DevParams* __restrict__ Pp, DevState S, const i32* host_actions, int count_updates, int b0, int nb,
-                                                            int step_id, int par) {
+                                                            int step_id, int par, EnvFuse F = EnvFuse()) {
     const DevParams& P = *Pp;  // parameters read through the scalar cache, never copied to scratch
+    if (MODE == 2 && (int)(blockIdx.x * blockDim.x) >= *F.list_n) return;  // (the usual case: nothing on the list)
     __shared__ TickLds tick_lds;
     stage_ticks(P, tick_lds);
     __shared__ EnvSlot lds_env[LOB_ENV_BLOCK];
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int b = b0 + t;
+    const int n_here = MODE == 2 ? *F.list_n : nb;
+    const int b = MODE == 2 ? (t < n_here ? F.list[t] : 0) : b0 + t;
     i64 d_steps = 0, d_events = 0;
-    if (t < nb) {
+    if (t < n_here) {
         const int k0 = S.k[b], rc0 = S.rec_cur[b];  // in flight together with the header
         LHdr& h = S.hdr[b];
         bool go;
         int action;
-        if (host_actions) {
+        if (MODE == 1) {
+            const LHdr h0 = h;
+            go = act_light_book(P, S, b, h0, F.lpar, F.ver, S.hl_dirty[0] == F.sid_prev, action);
+        } else if (host_actions) {
             go = S.done[b] != 2;
             action = host_actions[b];
             h.action = action;
@@ -319,7 +337,7 @@ __global__ void __launch_bounds__(LOB_ENV_BLOCK) env_kernel(const DevParams* __r
                 S.mk_slot[b] = mk_claim(S, claim_q0, claim_q1, claim_q2, step_id, par, claim_k, claim_stamp);
             }
             c.mark(29);  // agent scalars out, memo claim
-        } else {
+        } else if (MODE != 1) {  // (MODE 1: act_light_book has set the header of a book that does not step, or left it to the work list)
             h.stepped = 0;
         }
     }
@@ -1290,7 +1308,17 @@ __global__ void __launch_bounds__(256) apply_kernel(DevParams P, DevState S, int
 // through LDS and nine lanes add them up sequentially, exactly as q_values does.  `which` 0: under
 // theta_t, read by learn_kernel; 1: after the update, read by the next act_kernel.  A few hundred
 // triples per step: the hash table is read from global memory (8 KB, cache-resident), no staging.
-__global__ void __launch_bounds__(256) memo_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g, int par, int which, u64 ver) {
+// `reset_lpar` >= 0 (the step's last launch, which 1): also what an act kernel does before anything else -- empty the lists this
+// step has consumed -- so that the next step may start with env_kernel<.., 1>, whose blocks append to them from the first
+// instruction on.
+__global__ void __launch_bounds__(256) memo_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g, int par, int which, u64 ver, int reset_lpar) {
+    if (reset_lpar >= 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+        S.cb_count[0] = 0;                     // (apply_kernel has consumed it)
+        S.mk_count[par ^ 1] = 0;               // the next step's list of memo slots
+        S.slow_n[reset_lpar * 2 + 0] = 0;      // this step's work lists: the step after the next fills them again
+        S.slow_n[reset_lpar * 2 + 1] = 0;
+        S.tr_list_n[reset_lpar] = 0;
+    }
     __shared__ f64 vals[4][LOB_N_ACTIONS * LOB_QSTRIDE];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31;
     const bool hi = lane >= 32;
