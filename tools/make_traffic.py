@@ -7,16 +7,25 @@ import csv, json, os, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = os.path.join(root, "profiles", tag + "_pmc.csv")
-rows = {}
+# several instantiations of one kernel template may run (env_kernel<64;2;1> takes the step, <64;2;2> the -- usually empty --
+# work list, <64;2;0> the first step): the entry of the base name is the instantiation that moves the most bytes in total
+inst = {}
 with open(src) as fh:
     for r in csv.DictReader(l for l in fh if not l.startswith("#")):
-        k = r["kernel"].split("<")[0]
-        rows.setdefault(k, {})[r["counter"]] = float(r["avg_per_launch"])
+        d = inst.setdefault(r["kernel"], {"_launches": int(r["launches"])})
+        d[r["counter"]] = float(r["avg_per_launch"])
+rows = {}
+for name, c in inst.items():
+    k = name.split("<")[0]
+    total = (c.get("FETCH_SIZE", 0.0) + c.get("WRITE_SIZE", 0.0)) * c["_launches"]
+    if k not in rows or total > rows[k][0]:
+        rows[k] = (total, name, c)
+rows = {k: dict(v[2], _instantiation=v[1]) for k, v in rows.items()}
 out = {}
 for k, c in sorted(rows.items()):
     if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
         continue
-    e = {"hbm_bytes_per_launch": (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0, "fetch_kib": c["FETCH_SIZE"],
+    e = {"hbm_bytes_per_launch": (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0, "instantiation": c["_instantiation"], "fetch_kib": c["FETCH_SIZE"],
          "write_kib": c["WRITE_SIZE"], "source": "profiles/%s_pmc.csv" % tag}
     for n in ("TCC_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum"):
         if n in c:
