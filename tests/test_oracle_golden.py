@@ -100,7 +100,8 @@ def compare_traj(step_fn, rec_fn, traj, tag, skip_book=("cursor",)):
         got = rec_fn()
         want = traj[i]
         for name in ("action", "reward", "td", "rng_ctr"):
-            assert got[name] == want[name], "%s step %d: %s %r != %r" % (tag, i, name, got[name], want[name])
+            same = got[name] == want[name] or (got[name] != got[name] and want[name] != want[name])   # NaN on both sides
+            assert same, "%s step %d: %s %r != %r" % (tag, i, name, got[name], want[name])
         np.testing.assert_array_equal(got["vars"], want["vars"], err_msg="%s step %d vars" % (tag, i))
         for name in got["book"].dtype.names:
             if name in skip_book:

@@ -1,0 +1,133 @@
+"""Randomised differential run of the oracle against the UNMODIFIED reference (oracle/_ref/ref_harness
+= /root/reference/src compiled in place): every key the reference's yaml exposes for the hot path is drawn
+at random -- agent (all six of src/main.cpp:168-188), reward measure, state-variable set and order,
+look-backs, target-price / quoting mode, position bounds, order size, weights, learning constants,
+policy, table size, trade slots, stream statistics -- and the two trajectories must agree bit for bit,
+step by step, weights included.  The committed fixtures pin ≈ 25 hand-picked configurations; this pins
+the space between them.  Runs where the reference checkout was present at build time (the build
+container); LOB_REF_SWEEP=n widens it."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+from rl_markets_amd import abi, engine
+from tests import oracle_lib as ol
+from tests.test_oracle_golden import compare_traj
+
+pytestmark = pytest.mark.skipif(not ol.have_ref(), reason="oracle/_ref/ref_harness not built (needs the reference checkout)")
+
+VAR_OF = {v: k for k, v in abi.VAR_NAMES.items()}
+REWARD_OF = {v: k for k, v in abi.REWARD_NAMES.items()}
+ALGOS = [("sarsa", abi.ALGO_SARSA), ("q_learn", abi.ALGO_QLAMBDA), ("double_q_learn", abi.ALGO_DOUBLE_Q),
+         ("r_learn", abi.ALGO_R_LEARN), ("online_r_learn", abi.ALGO_ONLINE_R_LEARN), ("double_r_learn", abi.ALGO_DOUBLE_R_LEARN)]
+
+
+def f32(x):
+    return float(np.float32(x))
+
+
+def random_case(seed):
+    """-> (engine/oracle parameters, generator parameters, harness arguments)."""
+    r = np.random.default_rng(seed)
+    p = engine.default_params()
+    x = {}
+    p.max_trades = int(r.choice([1, 2, 4]))
+    nv = int(r.integers(4, abi.LOB_MAX_VARS + 1))
+    order = [int(v) for v in r.permutation(abi.LOB_MAX_VARS)[:nv]]
+    p.n_vars = nv
+    for i in range(abi.LOB_MAX_VARS):
+        p.vars[i] = order[i] if i < nv else 0
+    x["vars"] = ", ".join('"%s"' % VAR_OF[v] for v in order)
+    p.order_size = x["order_size"] = int(r.choice([1, 10, 25, 100]))
+    p.reward_measure = int(r.choice(sorted(REWARD_OF)[1:]))     # pnl ... mm_div (mm_exp included)
+    x["reward"] = REWARD_OF[p.reward_measure]
+    bound = int(r.choice([1, 3, 10, 50])) * p.order_size
+    p.pos_lb, p.pos_ub = -bound, int(r.choice([bound, 2 * bound]))
+    x["pos_lb"], x["pos_ub"] = p.pos_lb, p.pos_ub
+    # read as float by the reference (base.cpp:14-60): hand over decimal strings of float values
+    p.damping_factor = f32(r.uniform(0.0, 1.0))
+    p.pos_weight = f32(r.uniform(0.0, 0.2 if p.reward_measure == abi.REWARD_MM_EXP else 2.0))
+    p.pnl_weight = f32(r.uniform(0.0, 2.0))
+    x["damping"], x["pos_weight"], x["pnl_weight"] = repr(p.damping_factor), repr(p.pos_weight), repr(p.pnl_weight)
+    for name in ("lb_mpm", "lb_vlt", "lb_svl", "lb_vwap", "lb_rsi", "lb_spread", "lb_pnl", "lb_target"):
+        v = int(r.choice([1, 2, 7, 15, 45, 60, 100]))
+        setattr(p, name, v)
+        x[name] = v
+    # market.target_price.type: "midprice" builds MicroPrice (quirk Q5), anything else MidPrice; "book" quotes off the book
+    tp = str(r.choice(["midprice", "microprice", "book"]))
+    x["tp"] = tp
+    p.target_price = abi.TP_MICROPRICE if tp == "midprice" else abi.TP_MIDPRICE
+    p.quote_mode = abi.QUOTE_BOOK if tp == "book" else abi.QUOTE_TARGET
+    p.memory_size = x["mem"] = int(r.choice([4099, 1 << 14, 100003, 1 << 20, 3000017]))
+    w = r.uniform(0.05, 1.0, size=3)
+    for i in range(3):
+        p.group_weights[i] = float(w[i] / w.sum())
+        x["w%d" % i] = repr(p.group_weights[i])
+    p.gamma = float(r.uniform(0.8, 1.0))
+    p.lambda_ = float(r.uniform(0.0, min(0.95, 0.93 / p.gamma)))
+    p.alpha = float(r.choice([0.0, 1e-4, 1e-2, 0.3]))
+    p.beta = float(r.choice([0.0, 0.005, 0.05]))
+    x["gamma"], x["lambda"], x["alpha"], x["beta"] = repr(p.gamma), repr(p.lambda_), repr(p.alpha), repr(p.beta)
+    if r.integers(0, 4) == 0:
+        p.policy, p.tau = abi.POLICY_BOLTZMANN, float(r.choice([0.5, 5.0, 50.0]))
+        x["policy"], x["tau"] = "boltzmann", repr(p.tau)
+    else:
+        p.epsilon = float(r.choice([0.0, 0.1, 0.8, 1.0]))
+    name, p.algo = ALGOS[int(r.integers(0, 6))]
+    p.seed = int(r.integers(0, 1 << 40))
+    p.book_id_offset = int(r.choice([0, 7, 1 << 20]))
+    x["agent_seed"] = p.seed + p.book_id_offset     # DoubleQLearn's own mt19937_64 (agent.cpp:286-290), one agent per book
+    g = engine.default_gen_params()
+    g.seed = int(r.integers(0, 1 << 40))
+    g.n_events = int(r.choice([150, 260, 400]))
+    g.move_prob_q16 = int(r.uniform(0.05, 1.0) * 65536)
+    g.spread2_prob_q16 = int(r.uniform(0.0, 0.9) * 65536)
+    g.trade_prob_q16 = int(r.uniform(0.0, 1.0) * 65536)
+    g.trade2_prob_q16 = int(r.uniform(0.0, 1.0) * 65536) if p.max_trades > 1 else 0
+    g.touch_prob_q16 = int(r.uniform(0.3, 1.0) * 65536)
+    g.vol_min, g.vol_max = 1, int(r.choice([50, 5000]))
+    g.trade_min, g.trade_max = 1, int(r.choice([20, 3000]))
+    return p, g, name, x
+
+
+def sparse(path):
+    raw = np.fromfile(path, dtype=np.uint8)
+    n = int(np.frombuffer(raw[:8].tobytes(), dtype=np.int64)[0])
+    pairs = np.frombuffer(raw[8:8 + 16 * n].tobytes(), dtype=[("i", np.int64), ("v", np.float64)])
+    return pairs["i"], pairs["v"]
+
+
+def check_sparse(th, idx, val, tag):
+    nz = np.nonzero(th)[0]
+    np.testing.assert_array_equal(nz, idx, err_msg=tag)
+    np.testing.assert_array_equal(th[nz], val, err_msg=tag)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("LOB_REF_SWEEP", "200"))))
+def test_random_configuration_against_the_reference(seed):
+    p, g, algo, x = random_case(31000 + seed)
+    rec = engine.gen_stream_host(g, 5, p.max_trades, p.book_id_offset, 1)   # the reference's depth file has 5 levels
+    with tempfile.TemporaryDirectory() as td:
+        tb = os.path.join(td, "theta_b.bin")
+        if "double" in algo:
+            x["theta_b_out"] = tb
+        traj, info, theta = ol.run_ref_episode(rec[0], trades=p.max_trades, algo=algo, mem=p.memory_size, seed=p.seed,
+                                               rng_stream=p.book_id_offset, eps=p.epsilon, extra=x)
+        theta_b = sparse(tb) if "double" in algo else None
+    tag = "seed %d (%s, %s)" % (seed, algo, x["reward"])
+    o = ol.Oracle(p, rec)
+    o.reset()
+    r0 = o.rec(0)
+    for n in r0["book"].dtype.names:
+        if n != "cursor":
+            assert np.array_equal(r0["book"][n], traj[0]["book"][n]), "%s reset book.%s" % (tag, n)
+    np.testing.assert_array_equal(r0["vars"], traj[0]["vars"], err_msg=tag)
+    compare_traj(lambda: o.td_step(1), lambda: o.rec(0), traj, tag)
+    o.td_step(1)    # the reference ended on out-of-data / the close
+    assert o.counters()[0] == int(info["steps"]), tag
+    check_sparse(o.theta(0), theta[0], theta[1], tag)
+    if theta_b is not None:
+        check_sparse(o.theta_b(0), theta_b[0], theta_b[1], tag + " theta_b")
+    o.close()
