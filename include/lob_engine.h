@@ -235,6 +235,9 @@ int lob_tick_size(const lob_market* m, double price, double* tick);
  * Layout in memory: records[book][event] (each book's events contiguous).
  */
 #define LOB_EVT_FLAG_SAME_TIME 1u /* more depth rows with this timestamp follow (quirk Q14) */
+#define LOB_EVT_FLAG_TAS_DRY 2u   /* no event may START at this row: the time-and-sales stream has run dry (Streamer::LoadUntil
+                                   * fails, src/data/streamer.cpp:61-85, so Intraday::NextState returns false before it
+                                   * touches the books); set by lob_convert_csv from the last trade rows of the file */
 
 int32_t lob_record_words(int32_t depth, int32_t max_trades);
 void lob_default_gen_params(lob_gen_params* g);

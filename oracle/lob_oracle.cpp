@@ -716,6 +716,8 @@ struct Env {
     // Intraday::NextState — intraday.cpp:225-272
     bool NextState() {
         if (cursor >= n_events) { exhausted = true; return false; }
+        // time_and_sales.LoadUntil fails (streamer.cpp:61-85): the converter marked the rows from which on it does
+        if (row(cursor)[LOB_REC_FLAGS] & LOB_EVT_FLAG_TAS_DRY) { exhausted = true; return false; }
         // trades carried by the record about to be applied (= LoadUntil(next depth time))
         // time_and_sales.LoadUntil(next depth row's time): every trade up to that row which
         // has not been handed over yet (rows carry the trades of their own interval)
@@ -813,6 +815,9 @@ struct Env {
         while (!(f_ask_tx.full() && f_bid_tx.full() && f_vwap_numer.full() && f_vwap_denom.full() &&
                  f_volatility.full() && f_midprice.full() && tp_mp.full() && spread_window.full()))
             if (!NextState()) return false;
+        // the second time_and_sales.SkipUntil(market time), intraday.cpp:130: when the last of these NextStates went
+        // through more than one depth row (an invalid state in between), the trades up to the last of them are dropped
+        trades_from = cursor;
         place_orders(1, 1);
         return true;
     }

@@ -26,6 +26,7 @@ VAR_NAMES = {"pos": VAR_POS, "spd": VAR_SPD, "mpm": VAR_MPM, "imb": VAR_IMB, "sv
  REWARD_MM_EXP, REWARD_MM_DIV) = range(9)
 REWARD_NAMES = {"none": 0, "pnl": 1, "pnl_damped": 2, "spread": 3, "normed": 4, "lovol": 5, "mm_linear": 6,
                 "mm_exp": 7, "mm_div": 8}
+EVT_FLAG_SAME_TIME, EVT_FLAG_TAS_DRY = 1, 2   # record word [1]
 TP_MIDPRICE, TP_MICROPRICE = 0, 1
 QUOTE_TARGET, QUOTE_BOOK = 0, 1
 ALGO_SARSA, ALGO_QLAMBDA, ALGO_DOUBLE_Q, ALGO_R_LEARN, ALGO_ONLINE_R_LEARN, ALGO_DOUBLE_R_LEARN = 0, 1, 2, 3, 4, 5

@@ -1248,6 +1248,13 @@ __device__ inline void prepass_run(const EnvCtx& c, PrepState& st, BookMeta& M, 
     acc_load(S.f_vwap_numer, b, w_vn); acc_load(S.f_vwap_denom, b, w_vd);
     while (!M.complete && k < k_stop) {
         const int first = m.cursor;
+        if (first < c.S.n_events && (c.row(first)[LOB_REC_FLAGS] & LOB_EVT_FLAG_TAS_DRY)) {
+            // the time-and-sales stream has run dry (Streamer::LoadUntil fails, streamer.cpp:61-85): NextState returns
+            // false before it touches the books -- out of data with nothing of this event applied (ex_first < 0)
+            M.ex_first = -1; M.ex_cur = m.rec_cur; M.ex_last = m.rec_last; M.ex_time = m.time_ms; M.ex_records = 0;
+            M.complete = 1;
+            break;
+        }
         f64 tp[TM];
         i64 tv[TM];
         load_trades<TM>(c, prev_first + 1, first, tp, tv);
@@ -1346,6 +1353,9 @@ __device__ inline void prepass_run(const EnvCtx& c, PrepState& st, BookMeta& M, 
                 w_tp.cnt == S.tp_mp.w && w_spr.cnt == S.spread_window.w)
                 M.k_warm = k + 1;  // Intraday::Initialise stops pulling events here (intraday.cpp:119-128)
         }
+        // ... and calls time_and_sales.SkipUntil(market time) once more (intraday.cpp:130): if this event went through
+        // more than one depth row, the trades up to the last of them are dropped, not handed to the next event
+        if (k + 1 == M.k_warm) prev_first = m.rec_cur;
         k++;
     }
     rm_store(S.f_midprice, b, w_mid); rm_store(S.f_volatility, b, w_vol); rm_store(S.spread_window, b, w_spr);

@@ -266,6 +266,11 @@ void split_csv(const std::string& line, std::vector<std::string>& cols) {  // ut
         pos = next + 1;
     }
 }
+void split_csv_append(const std::string& line, std::vector<std::string>& cols) {  // CSV::next: parseRow onto the caller's vector
+    std::vector<std::string> one;
+    split_csv(line, one);
+    cols.insert(cols.end(), one.begin(), one.end());
+}
 bool parse_time(const std::string& s, long& out) {  // utilities/time.h:28-39 "HH:MM:SS.mmm"
     if (s.size() < 12) return false;
     out = atol(s.substr(0, 2).c_str()) * 3600000L + atol(s.substr(3, 2).c_str()) * 60000L +
@@ -279,7 +284,7 @@ struct Snap {
 };
 struct Trade { long time; float price; long size; };
 
-int emit_records(const std::vector<Snap>& snaps, const std::vector<Trade>& trades, int D, int T, uint32_t** out, int32_t* n) {
+int emit_records(const std::vector<Snap>& snaps, const std::vector<Trade>& trades, int D, int T, uint32_t** out, int32_t* n, long t_dry = LONG_MAX) {
     const int W = lob_rec_words(D, T);
     const size_t N = snaps.size();
     if (N < 2) { lob_set_error("convert: fewer than 2 usable depth rows"); return LOB_EDATA; }
@@ -292,7 +297,7 @@ int emit_records(const std::vector<Snap>& snaps, const std::vector<Trade>& trade
         const Snap& s = snaps[r];
         if (r > 0 && s.time < snaps[r - 1].time) { free(rec); lob_set_error("convert: depth rows go backwards in time"); return LOB_EDATA; }
         w[LOB_REC_TIME] = (uint32_t)(int32_t)s.time;
-        w[LOB_REC_FLAGS] = (r + 1 < N && snaps[r + 1].time == s.time) ? LOB_EVT_FLAG_SAME_TIME : 0;
+        w[LOB_REC_FLAGS] = ((r + 1 < N && snaps[r + 1].time == s.time) ? LOB_EVT_FLAG_SAME_TIME : 0) | (s.time >= t_dry ? LOB_EVT_FLAG_TAS_DRY : 0);
         // levels best -> worst (the reference sorts them itself, book.cpp:86)
         std::vector<std::pair<float, int32_t>> a, b;
         for (int l = 0; l < D; l++) { a.push_back({s.ap[l], s.av[l]}); b.push_back({s.bp[l], s.bv[l]}); }
@@ -346,13 +351,19 @@ int lob_convert_csv(const char* md_path, const char* tas_path, int32_t T, uint32
     std::string line;
     std::vector<std::string> c;
     std::vector<Snap> snaps;
-    int date0 = 0, skipped_md = 0, skipped_tas = 0;
+    int date0 = 0;
+    bool cut_md = false, cut_tas = false;
     std::getline(md, line);  // header
+    // MarketDepth::_LoadRow (basic.cpp:31-43) keeps APPENDING the columns of the lines it reads to its row until the
+    // row has exactly 22 of them (utilities/csv.cpp:31-53 never clears the vector): a line with fewer columns is glued
+    // to the next one, and once the count has passed 22 no row is ever complete again -- the reference's day ends
+    // there.  Same reader, same outcome: the rows after such a line are not part of the stream.
+    c.clear();
     while (std::getline(md, line)) {
         if (!line.empty() && line.back() == '\r') line.pop_back();
-        if (line.empty()) continue;
-        split_csv(line, c);
-        if (c.size() != 22) { skipped_md++; continue; }  // MarketDepth::_LoadRow skips rows that do not have 22 columns (basic.cpp:31-43)
+        split_csv_append(line, c);
+        if (c.size() < 22) continue;
+        if (c.size() > 22) { cut_md = true; break; }
         Snap s;
         int date = atoi(c[0].c_str());
         if (!date0) date0 = date;
@@ -372,26 +383,49 @@ int lob_convert_csv(const char* md_path, const char* tas_path, int32_t T, uint32
             s.bv[i] = (int32_t)bv;
         }
         if (ok) snaps.push_back(s);
+        c.clear();   // _ParseRow clears the row whether it keeps the record or not
     }
     std::vector<Trade> trades;
+    std::vector<long> tas_times;   // the time of every complete row, kept or not: the streamer groups rows by it
     std::getline(ts, line);
+    c.clear();
     while (std::getline(ts, line)) {
         if (!line.empty() && line.back() == '\r') line.pop_back();
-        if (line.empty()) continue;
-        split_csv(line, c);
-        if (c.size() != 4) { skipped_tas++; continue; }  // TimeAndSales::_LoadRow (basic.cpp:138-150)
+        split_csv_append(line, c);   // TimeAndSales::_LoadRow (basic.cpp:138-150): as above, with 4 columns
+        if (c.size() < 4) continue;
+        if (c.size() > 4) { cut_tas = true; break; }
         Trade t;
         if (!parse_time(c[1], t.time)) { lob_set_error("lob_convert_csv: bad time"); return LOB_EDATA; }
         t.price = strtof(c[2].c_str(), nullptr);
         t.size = atol(c[3].c_str());
         if (t.size > INT32_MAX) { lob_set_error("lob_convert_csv: trade size outside int32 (records carry 32-bit volumes)"); return LOB_EDATA; }
         if (t.price > 0.0f && t.size > 0) trades.push_back(t);  // basic.cpp:156-157
+        tas_times.push_back(t.time);
+        c.clear();
     }
+    // The time-and-sales streamer runs dry before its file does: Streamer::LoadUntil(t) (streamer.cpp:61-85) merges
+    // the row groups (runs of rows, each row no later than the group's first: TimeAndSales::_LoadNext, basic.cpp:164-181)
+    // that are due at t into one record and then needs the NEXT group loaded behind it -- and _LoadNext reports failure
+    // when the group it loads ends the file.  So a NextState aimed at a depth row at or after the time of the last
+    // group but one fails before it touches the books (Intraday::NextState, intraday.cpp:225-232) and the reference's
+    // episode is over.  Those rows are flagged LOB_EVT_FLAG_TAS_DRY: no event starts at them (they are still there
+    // for an event that began earlier and runs through invalid states).  No trade rows at all: no event ever starts.
+    std::vector<long> group_first;
+    for (size_t i = 0; i < tas_times.size();) {
+        const long target = tas_times[i];
+        group_first.push_back(target);
+        for (i++; i < tas_times.size() && tas_times[i] <= target; i++) {}
+    }
+    const long t_dry = group_first.size() >= 2 ? group_first[group_first.size() - 2] : group_first.size() == 1 ? group_first[0] : LONG_MIN;
+    size_t n_dry = 0;
+    for (const Snap& sn : snaps) n_dry += sn.time >= t_dry;
     // Trades are consumed in FILE order, as TimeAndSales::_LoadNext does (basic.cpp:164-181): no sort.
-    int rc = emit_records(snaps, trades, 5, T, out, n);
-    if (rc == LOB_OK && (skipped_md || skipped_tas)) {
-        char buf[160];
-        snprintf(buf, sizeof buf, "lob_convert_csv: skipped %d depth row(s) without 22 columns and %d trade row(s) without 4 (as the reference does)", skipped_md, skipped_tas);
+    int rc = emit_records(snaps, trades, 5, T, out, n, t_dry);
+    if (rc == LOB_OK && (cut_md || cut_tas || n_dry)) {
+        char buf[400];
+        snprintf(buf, sizeof buf, "lob_convert_csv: %s%s%zu depth row(s) at the end flagged LOB_EVT_FLAG_TAS_DRY: the time-and-sales stream "
+                 "runs dry before them (the reference's day ends at the same row)", cut_md ? "depth file cut at a row without 22 columns; " : "",
+                 cut_tas ? "time-and-sales file cut at a row without 4 columns; " : "", n_dry);
         lob_set_error(buf);  // informational: the call succeeded, lob_last_error() carries the note
     }
     return rc;

@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(RB) reset_kernel(const DevParams* __restrict__
         const int k = M.k_warm;
         const Track t1 = c.track(k - 1);
         e.k = k;
-        e.pf = t1.rec_first;
+        e.pf = t1.rec_last;   // Initialise's closing SkipUntil(market time), intraday.cpp:130 (== rec_first unless the event ran through invalid rows)
         e.rec_cur = t1.rec_last;
         e.mid = t1.mid;
         e.time_ms = t1.time_ms;
@@ -188,6 +188,7 @@ __global__ void __launch_bounds__(256, 1) finalize_kernel(const DevParams* __res
         PrepState st;
         BookMeta M;
         prepass_begin(c, st, M);
+        M.k_warm = S.meta[b].k_warm;   // where Initialise's warm-up ended (its closing SkipUntil drops trades there)
         prepass_run<TM>(c, st, M, k, false);
     }
 }

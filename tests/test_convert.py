@@ -43,6 +43,56 @@ def test_csv_drops_bad_rows_and_reports_errors(tmp_path):
     assert ei.value.code == abi.LOB_EDATA
 
 
+def test_csv_short_row_ends_the_day_and_dry_trades_are_flagged(tmp_path):
+    """The reference's readers glue lines until a row has its 22 (4) columns (utilities/csv.cpp:31-53 appends,
+    basic.cpp:31-43 / 138-150 wait for the exact count), so a line with a column missing is the last thing they ever
+    deliver; and Streamer::LoadUntil needs two row groups later than a depth row to serve it (streamer.cpp:61-85)."""
+    g = engine.default_gen_params()
+    g.n_events = 60
+    rec = engine.gen_stream_host(g, 5, 2, 3, 1)
+    md, tas = str(tmp_path / "md.csv"), str(tmp_path / "tas.csv")
+    write_reference_csvs(rec[0], 5, 2, md, tas)
+    full = engine.convert_csv(md, tas, 2)
+    assert full.shape[1] == 60 and not (full[0, :, 1] & abi.EVT_FLAG_TAS_DRY).any()   # two sentinel groups: never dry
+    lib = abi.load()
+    # (1) depth line 41 (row 40) loses its last three columns: rows 0..39 remain
+    lines = open(md).read().splitlines()
+    keep = lines[:]
+    keep[41] = ",".join(keep[41].split(",")[:19])
+    open(md, "w").write("\n".join(keep) + "\n")
+    cut = engine.convert_csv(md, tas, 2)
+    assert cut.shape[1] == 40 and b"depth file cut" in lib.lob_last_error()
+    np.testing.assert_array_equal(cut[0, :, 2:], full[0, :40, 2:])
+    open(md, "w").write("\n".join(lines) + "\n")
+    # (2) without the sentinel groups the stream is dry from the last trade group but one on
+    tl = open(tas).read().splitlines()
+    assert tl[-1].endswith(",1.0,1") and tl[-2].endswith(",1.0,1")
+    open(tas, "w").write("\n".join(tl[:-2]) + "\n")
+    times = [l.split(",")[1] for l in tl[1:-2]]
+    groups = sorted(set(times))
+    dry = engine.convert_csv(md, tas, 2)
+    flagged = (dry[0, :, 1] & abi.EVT_FLAG_TAS_DRY) != 0
+    from tests.csv_io import ms_to_str
+    want = np.array([ms_to_str(int(t)) >= groups[-2] for t in dry[0, :, 0].astype(np.int32)])
+    np.testing.assert_array_equal(flagged, want)
+    assert flagged.any() and not flagged.all() and b"LOB_EVT_FLAG_TAS_DRY" in lib.lob_last_error()
+    # (3) a trade line with a column missing: the trade stream ends before it
+    bad = tl[:]
+    k = len(bad) // 2
+    bad[k] = ",".join(bad[k].split(",")[:3])
+    open(tas, "w").write("\n".join(bad) + "\n")
+    groups3 = sorted(set(l.split(",")[1] for l in bad[1:k]))
+    dry3 = engine.convert_csv(md, tas, 2)
+    flagged3 = (dry3[0, :, 1] & abi.EVT_FLAG_TAS_DRY) != 0
+    want3 = np.array([ms_to_str(int(t)) >= groups3[-2] for t in dry3[0, :, 0].astype(np.int32)])
+    np.testing.assert_array_equal(flagged3, want3)
+    assert b"time-and-sales file cut" in lib.lob_last_error()
+    # (4) no trades at all: no event can start anywhere
+    open(tas, "w").write(tl[0] + "\n")
+    none = engine.convert_csv(md, tas, 2)
+    assert ((none[0, :, 1] & abi.EVT_FLAG_TAS_DRY) != 0).all()
+
+
 def test_lobster_round_trip(tmp_path):
     g = engine.default_gen_params()
     g.n_events = 200

@@ -131,3 +131,33 @@ def test_random_configuration_against_the_reference(seed):
     if theta_b is not None:
         check_sparse(o.theta_b(0), theta_b[0], theta_b[1], tag + " theta_b")
     o.close()
+
+
+@pytest.mark.parametrize("seed", range(max(1, int(os.environ.get("LOB_REF_SWEEP", "200")) // 4)))
+def test_random_multi_episode_against_the_reference(seed):
+    """Runner::RunEpisode x 2..3 on one agent (serial.cpp:18-34,79): Initialise over the window sums the last
+    episode left behind (quirk Q7), the state swap before the first action (Q19), ClearInventory, HandleTerminal,
+    episodes cut short by a step cap or run to the end of the data -- on random configurations."""
+    from tests.test_oracle_golden import replay_multi
+    r = np.random.default_rng(77000 + seed)
+    p, g, algo, x = random_case(52000 + seed)
+    g.n_events = int(r.choice([120, 200, 260]))
+    x["episodes"] = int(r.integers(2, 4))
+    if r.integers(0, 2):
+        x["steps"] = int(r.choice([5, 30, 90]))
+    rec = engine.gen_stream_host(g, 5, p.max_trades, p.book_id_offset, 1)
+    with tempfile.TemporaryDirectory() as td:
+        tb = os.path.join(td, "theta_b.bin")
+        if "double" in algo:
+            x["theta_b_out"] = tb
+        traj, info, theta = ol.run_ref_episode(rec[0], trades=p.max_trades, algo=algo, mem=p.memory_size, seed=p.seed,
+                                               rng_stream=p.book_id_offset, eps=p.epsilon, extra=x)
+        theta_b = sparse(tb) if "double" in algo else None
+    tag = "multi seed %d (%s, %s, %d episodes)" % (seed, algo, x["reward"], x["episodes"])
+    o = ol.Oracle(p, rec)
+    replay_multi({"traj": traj, "ends": np.array(info["ends"])}, o.reset, lambda: o.td_step(1), o.clear_inventory,
+                 lambda: ol.load().oracle_handle_terminal(o.h), lambda: o.rec(0), tag)
+    check_sparse(o.theta(0), theta[0], theta[1], tag)
+    if theta_b is not None:
+        check_sparse(o.theta_b(0), theta_b[0], theta_b[1], tag + " theta_b")
+    o.close()
