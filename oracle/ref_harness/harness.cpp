@@ -295,7 +295,7 @@ static std::string make_yaml(const Args& a, const std::string& path) {
     f << "    latency:\n        type: fixed\n        floor: 0.0\n";
     f << "    pos_ub: " << a.geti("pos_ub", 50) << "\n    pos_lb: " << a.geti("pos_lb", -50) << "\n";
     f << "    order_size: " << a.geti("order_size", 10) << "\n";
-    f << "logging:\n    log_learning: true\n    log_backtest: false\n    max_size: 1000000\n";
+    f << "logging:\n    log_learning: true\n    log_backtest: " << (a.geti("backtest", 0) ? "true" : "false") << "\n    max_size: 1000000\n";
     f << "output_dir: /tmp/\n";
     f.close();
     return path;
@@ -413,6 +413,28 @@ static int run_episode(const Args& a, Config& c, ProbeEnv& env, const std::strin
     }
     if (a.kv.count("theta_b_out")) {
         dump_theta_b(agent, a.get("theta_b_out"));
+    }
+    if (a.geti("backtest", 0)) {
+        // the testing phase of src/main.cpp:216-226: GoGreedy, re-open the data, the reference's own Backtester
+        // (Runner::RunEpisode + Backtester::_step, serial.cpp:18-34,124-137) with log_backtest on; the rows
+        // Intraday::LogProfit hands to its "profit_log" logger go to --profit_out (12 doubles per row)
+        agent.GoGreedy();
+        env.LoadData(a.get("ticker", "HSBA.L"), a.get("md"), a.get("tas"));
+        experiment::serial::Backtester bt(c, env);
+        bool ok = bt.RunEpisode(&agent);
+        auto lg = spdlog::get("profit_log");
+        if (!lg) { fprintf(stderr, "no profit_log logger\n"); return 4; }
+        FILE* f = fopen(a.get("profit_out").c_str(), "wb");
+        if (!f) { perror("profit_out"); return 2; }
+        int64_t n = 0;
+        for (auto& row : lg->rows) if (row.size() == 12) n++;   // (the header line has no numeric argument)
+        fwrite(&n, 8, 1, f);
+        for (auto& row : lg->rows) if (row.size() == 12) fwrite(row.data(), 8, 12, f);
+        lob_book_dump d;
+        env.fill(d);
+        fwrite(&d, sizeof d, 1, f);   // the state Runner::RunEpisode leaves behind (after ClearInventory)
+        fclose(f);
+        printf("{\"backtest_ok\": %d, \"backtest_rows\": %lld}\n", ok ? 1 : 0, (long long)n);
     }
     if (a.kv.count("traces_out")) {
         FILE* f = fopen(a.get("traces_out").c_str(), "wb");

@@ -1,6 +1,6 @@
 // TEST INFRASTRUCTURE ONLY (oracle/_ref build).  Not part of the product.
 //
-// No-op stand-in for spdlog so the unmodified reference translation units
+// Stand-in for spdlog (nothing is written) so the unmodified reference translation units
 // compile without the (absent, un-pinned) third-party logger.  spdlog is used
 // by the reference for CSV logging only; it carries no
 // hot-path arithmetic.
@@ -12,6 +12,8 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <type_traits>
+#include <vector>
 
 namespace spdlog {
 
@@ -22,10 +24,28 @@ public:
     const char* what() const noexcept override { return m_.c_str(); }
 };
 
+// Records are not formatted or written anywhere; the numeric arguments of each call are kept so that the harness
+// can read back what the reference logged (profit_log rows of Intraday::LogProfit, intraday.cpp:438-451).
 class logger {
+    static void put(std::vector<double>&) {}
+    template <typename T, typename... R>
+    static typename std::enable_if<std::is_arithmetic<T>::value>::type put(std::vector<double>& row, const T& v, const R&... rest) {
+        row.push_back((double)v);
+        put(row, rest...);
+    }
+    template <typename T, typename... R>
+    static typename std::enable_if<!std::is_arithmetic<T>::value>::type put(std::vector<double>& row, const T&, const R&... rest) {
+        put(row, rest...);
+    }
 public:
     unsigned long n_records = 0;
-    template <typename... A> void info(const A&...) { n_records++; }
+    std::vector<std::vector<double>> rows;
+    template <typename... A> void info(const A&... a) {
+        n_records++;
+        std::vector<double> row;
+        put(row, a...);
+        rows.push_back(row);
+    }
 };
 
 inline std::map<std::string, std::shared_ptr<logger>>& registry() {

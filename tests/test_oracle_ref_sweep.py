@@ -161,3 +161,56 @@ def test_random_multi_episode_against_the_reference(seed):
     if theta_b is not None:
         check_sparse(o.theta_b(0), theta_b[0], theta_b[1], tag + " theta_b")
     o.close()
+
+
+@pytest.mark.parametrize("seed", range(max(1, int(os.environ.get("LOB_REF_SWEEP", "200")) // 4)))
+def test_random_backtest_against_the_reference(seed):
+    """The testing phase of src/main.cpp:216-226 on random configurations: one training episode, GoGreedy, then the
+    reference's own experiment::serial::Backtester (Runner::RunEpisode + Backtester::_step, serial.cpp:18-34,124-137)
+    with log_backtest on.  Every row Intraday::LogProfit hands to the profit_log logger (intraday.cpp:438-451:
+    time, action, position, midprice, spread, quotes, levels, PnL, buy-and-hold move) against the oracle's
+    lob_eval_step, and the state the episode leaves behind after ClearInventory."""
+    p, g, algo, x = random_case(64000 + seed)
+    x["backtest"] = 1
+    x["clear_inventory"] = 1
+    rec = engine.gen_stream_host(g, 5, p.max_trades, p.book_id_offset, 1)
+    with tempfile.TemporaryDirectory() as td:
+        x["profit_out"] = os.path.join(td, "profit.bin")
+        traj, info, theta = ol.run_ref_episode(rec[0], trades=p.max_trades, algo=algo, mem=p.memory_size, seed=p.seed,
+                                               rng_stream=p.book_id_offset, eps=p.epsilon, extra=x)
+        raw = open(x["profit_out"], "rb").read()
+    n = int(np.frombuffer(raw[:8], dtype=np.int64)[0])
+    rows = np.frombuffer(raw[8:8 + 96 * n], dtype=np.float64).reshape(n, 12)
+    left = np.frombuffer(raw[8 + 96 * n:], dtype=ol.BOOK_DTYPE)[0]
+    tag = "backtest seed %d (%s, %s)" % (seed, algo, x["reward"])
+    o = ol.Oracle(p, rec)
+    o.reset()
+    o.td_step(len(traj) + 2)                  # the training episode (checked step by step by the tests above)
+    assert o.counters()[0] == int(info["steps"]), tag
+    o.clear_inventory()
+    check_sparse(o.theta(0), theta[0], theta[1], tag)
+    o.reset()                                 # Backtester's Runner::RunEpisode: Initialise ...
+    bandh = 0.0
+    for i in range(n):
+        o.eval_step(1)
+        r = o.rec(0)
+        b = r["book"]
+        want = rows[i]
+        got = (b["time_ms"], r["action"], b["position"], (b["ask_px"][0] + b["bid_px"][0]) / 2.0, b["ask_px"][0] - b["bid_px"][0],
+               b["ask_quote"], b["bid_quote"], b["ask_level"], b["bid_level"], b["pnl_step"])
+        for k, name in enumerate(("time", "action", "position", "midprice", "spread", "quoted_ask", "quoted_bid", "ask_level",
+                                  "bid_level", "pnl_step")):
+            assert float(got[k]) == want[1 + k], "%s row %d: %s %r != %r" % (tag, i, name, got[k], want[1 + k])
+        # bandh_step is the step's summed mid-price move; the dump carries its running total
+        step_move = b["episode_bandh"] - bandh
+        bandh = b["episode_bandh"]
+        assert abs(step_move - want[11]) <= 1e-9 * max(1.0, abs(bandh)), "%s row %d: bandh_step" % (tag, i)
+    before = o.counters()[0]
+    o.eval_step(1)                            # ... until _step finds the episode over
+    assert o.counters()[0] == before, "%s: the reference logged %d rows" % (tag, n)
+    o.clear_inventory()
+    got = o.rec(0)["book"]
+    for name in got.dtype.names:
+        if name not in ("cursor", "n_traces", "terminal"):
+            assert np.array_equal(got[name], left[name]), "%s after the backtest: book.%s %r != %r" % (tag, name, got[name], left[name])
+    o.close()
