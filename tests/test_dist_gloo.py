@@ -129,8 +129,11 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
 
 def test_spawn_ranks_stops_everyone_when_one_rank_fails(tmp_path, capfd):
     from rl_markets_amd import launch
+    # rank 1 fails once every rank has said hello (marker files: interpreter start-up times differ under load)
     code = "import os,sys,time\nr=int(os.environ['RANK'])\nprint('hello from', r, os.environ['WORLD_SIZE'], flush=True)\n" \
-           "sys.exit(3) if r == 1 else time.sleep(60)"
+           "d=%r\nopen(os.path.join(d,'up%%d'%%r),'w').close()\n" \
+           "t=time.time()\nwhile r == 1 and len(os.listdir(d)) < 3 and time.time() - t < 60: time.sleep(0.05)\n" \
+           "sys.exit(3) if r == 1 else time.sleep(60)" % str(tmp_path)
     rc = launch.spawn_ranks([sys.executable, "-c", code], 3, timeout=120)
     out = capfd.readouterr()
     assert rc == 3
