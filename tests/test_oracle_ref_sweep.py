@@ -6,6 +6,7 @@ policy, table size, trade slots, stream statistics -- and the two trajectories m
 step by step, weights included.  The committed fixtures pin ≈ 25 hand-picked configurations; this pins
 the space between them.  Runs where the reference checkout was present at build time (the build
 container); LOB_REF_SWEEP=n widens it."""
+import ctypes as C
 import os
 import tempfile
 
@@ -22,6 +23,9 @@ VAR_OF = {v: k for k, v in abi.VAR_NAMES.items()}
 REWARD_OF = {v: k for k, v in abi.REWARD_NAMES.items()}
 ALGOS = [("sarsa", abi.ALGO_SARSA), ("q_learn", abi.ALGO_QLAMBDA), ("double_q_learn", abi.ALGO_DOUBLE_Q),
          ("r_learn", abi.ALGO_R_LEARN), ("online_r_learn", abi.ALGO_ONLINE_R_LEARN), ("double_r_learn", abi.ALGO_DOUBLE_R_LEARN)]
+
+
+TICKERS = ["HSBA.L", "NXT.L", "CRDI.MI", "AIR.PA", "NOKIA.HE", "RYA.I", "OMV.VI", "NESN.VX", "MAERSK.CO", "PHIA.AS"]
 
 
 def f32(x):
@@ -89,7 +93,38 @@ def random_case(seed):
     g.touch_prob_q16 = int(r.uniform(0.3, 1.0) * 65536)
     g.vol_min, g.vol_max = 1, int(r.choice([50, 5000]))
     g.trade_min, g.trade_max = 1, int(r.choice([20, 3000]))
+    # venue (market::Market::make_market, src/market/market.cpp:39-59: session times, tick bands) and where the stream
+    # sits in its session: mid-session, starting before the open (Initialise's `while not IsOpen` loop), or running
+    # into the close (isTerminal ends the episode, base.cpp:180-184)
+    ticker = str(r.choice(TICKERS))
+    assert abi.load().lob_market_preset(ticker.encode(), C.byref(p.market)) == 0
+    x["ticker"] = ticker
+    g.dt_ms = int(r.choice([100, 500, 2000]))
+    where = int(r.integers(0, 4))
+    trading_from, trading_to = p.market.open_ms + 30 * 60000, p.market.close_ms - 30 * 60000   # Market::IsOpen, market.cpp:67-70
+    if where == 1:
+        g.t0_ms = int(trading_from - int(r.integers(0, 40)) * g.dt_ms)
+    elif where == 2:
+        g.t0_ms = int(trading_to - int(r.integers(30, 220)) * g.dt_ms)   # short of the look-back windows now and then: Initialise fails
+    else:
+        g.t0_ms = int(p.market.open_ms + 30 * 60000 + 500)
     return p, g, name, x
+
+
+def ref_or_failed_init(p, rec, tag, **kw):
+    """run_ref_episode, or None when the reference's Initialise fails (the data ends before the look-back windows
+    are full) -- after checking that the oracle never takes a step on that stream either."""
+    try:
+        return ol.run_ref_episode(rec[0], **kw)
+    except RuntimeError as e:
+        if "Initialise failed" not in str(e):
+            raise
+    o = ol.Oracle(p, rec)
+    o.reset()
+    o.td_step(3)
+    assert o.counters()[0] == 0, tag + ": the reference's Initialise fails on this stream"
+    o.close()
+    return None
 
 
 def sparse(path):
@@ -113,10 +148,13 @@ def test_random_configuration_against_the_reference(seed):
         tb = os.path.join(td, "theta_b.bin")
         if "double" in algo:
             x["theta_b_out"] = tb
-        traj, info, theta = ol.run_ref_episode(rec[0], trades=p.max_trades, algo=algo, mem=p.memory_size, seed=p.seed,
-                                               rng_stream=p.book_id_offset, eps=p.epsilon, extra=x)
+        out = ref_or_failed_init(p, rec, "seed %d" % seed, trades=p.max_trades, algo=algo, mem=p.memory_size, seed=p.seed,
+                                 rng_stream=p.book_id_offset, eps=p.epsilon, extra=x)
+        if out is None:
+            return
+        traj, info, theta = out
         theta_b = sparse(tb) if "double" in algo else None
-    tag = "seed %d (%s, %s)" % (seed, algo, x["reward"])
+    tag = "seed %d (%s, %s, %s)" % (seed, algo, x["reward"], x["ticker"])
     o = ol.Oracle(p, rec)
     o.reset()
     r0 = o.rec(0)
@@ -150,8 +188,11 @@ def test_random_multi_episode_against_the_reference(seed):
         tb = os.path.join(td, "theta_b.bin")
         if "double" in algo:
             x["theta_b_out"] = tb
-        traj, info, theta = ol.run_ref_episode(rec[0], trades=p.max_trades, algo=algo, mem=p.memory_size, seed=p.seed,
-                                               rng_stream=p.book_id_offset, eps=p.epsilon, extra=x)
+        out = ref_or_failed_init(p, rec, "multi seed %d" % seed, trades=p.max_trades, algo=algo, mem=p.memory_size, seed=p.seed,
+                                 rng_stream=p.book_id_offset, eps=p.epsilon, extra=x)
+        if out is None:
+            return
+        traj, info, theta = out
         theta_b = sparse(tb) if "double" in algo else None
     tag = "multi seed %d (%s, %s, %d episodes)" % (seed, algo, x["reward"], x["episodes"])
     o = ol.Oracle(p, rec)
@@ -176,8 +217,11 @@ def test_random_backtest_against_the_reference(seed):
     rec = engine.gen_stream_host(g, 5, p.max_trades, p.book_id_offset, 1)
     with tempfile.TemporaryDirectory() as td:
         x["profit_out"] = os.path.join(td, "profit.bin")
-        traj, info, theta = ol.run_ref_episode(rec[0], trades=p.max_trades, algo=algo, mem=p.memory_size, seed=p.seed,
-                                               rng_stream=p.book_id_offset, eps=p.epsilon, extra=x)
+        out = ref_or_failed_init(p, rec, "backtest seed %d" % seed, trades=p.max_trades, algo=algo, mem=p.memory_size, seed=p.seed,
+                                 rng_stream=p.book_id_offset, eps=p.epsilon, extra=x)
+        if out is None:
+            return
+        traj, info, theta = out
         raw = open(x["profit_out"], "rb").read()
     n = int(np.frombuffer(raw[:8], dtype=np.int64)[0])
     rows = np.frombuffer(raw[8:8 + 96 * n], dtype=np.float64).reshape(n, 12)
