@@ -4,7 +4,7 @@ reference (oracle/_ref/ref_harness = /root/reference sources compiled in
 place by oracle/Makefile).  Runs only in the build container (the reference
 checkout is not present on the GPU box); the fixtures it writes are committed.
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py [--only NAME ...]
 """
 import ctypes as C
 import os
@@ -104,8 +104,11 @@ def run(cmd):
     return res.stdout
 
 
-def main():
+def main(out_dir=None):
+    """Writes the fixtures next to this file, or into `out_dir` (tests/test_oracle_golden.py regenerates them
+    there and compares with the committed ones)."""
     assert ol.have_ref(), "build oracle/_ref first: make -C oracle ref"
+    OUT = out_dir or HERE
     rng = np.random.default_rng(20260925)
     with tempfile.TemporaryDirectory() as td:
         # ---- hash table ----
@@ -139,7 +142,7 @@ def main():
         for mem in (20000000, 4099):
             run([HARNESS, "tiles", "--mem", str(mem), "--nvars", "8", "--in", vin, "--out", vout])
             tiles_n[mem] = np.fromfile(vout, dtype=np.int32).reshape(vn.shape[0], 9, 96)
-        np.savez_compressed(os.path.join(HERE, "kat_nonfinite.npz"), vars=vn, **{"tiles_%d" % m: t for m, t in tiles_n.items()})
+        np.savez_compressed(os.path.join(OUT, "kat_nonfinite.npz"), vars=vn, **{"tiles_%d" % m: t for m, t in tiles_n.items()})
         if "--only-nonfinite" in sys.argv:
             return
 
@@ -158,7 +161,7 @@ def main():
             out = np.fromfile(pout, dtype=[("ticks", np.int32), ("pad", np.int32), ("back", np.float64), ("tick", np.float64)])
             ticks[ticker] = (prices, out["ticks"].copy(), out["back"].copy(), out["tick"].copy())
 
-        np.savez_compressed(os.path.join(HERE, "kat_reference.npz"), rndseq=rnd, tiles_vars=v,
+        np.savez_compressed(os.path.join(OUT, "kat_reference.npz"), rndseq=rnd, tiles_vars=v,
                             **{"tiles_%d" % m: t for m, t in tiles.items()}, tiles5_vars=v5, tiles5=tiles5,
                             **{"ticks_%s_%s" % (k, n): a for k, (pr, tk, bk, ts) in ticks.items()
                                for n, a in (("price", pr), ("ticks", tk), ("back", bk), ("tick", ts))})
@@ -170,7 +173,7 @@ def main():
                 continue
             rec = engine.gen_stream_host(gen_for(n_events, _over), 5, 2, book, 1)
             traj, info, theta = ol.run_ref_episode(rec[0], algo=algo, mem=1 << 20, rng_stream=book, extra=extra)
-            np.savez_compressed(os.path.join(HERE, "traj_%s.npz" % name), traj=traj, theta_idx=theta[0],
+            np.savez_compressed(os.path.join(OUT, "traj_%s.npz" % name), traj=traj, theta_idx=theta[0],
                                 theta_val=theta[1], steps=info["steps"], end=info["end"], rng_ctr=info["rng_ctr"])
             print(name, info)
         # ---- DoubleQLearn (config/example.yaml's default algorithm): theta_b + the agent's own mt19937_64 coin ----
@@ -187,7 +190,7 @@ def main():
             raw = np.fromfile(tb, dtype=np.uint8)
             nn = int(np.frombuffer(raw[:8].tobytes(), dtype=np.int64)[0])
             pairs = np.frombuffer(raw[8:8 + 16 * nn].tobytes(), dtype=[("i", np.int64), ("v", np.float64)])
-            np.savez_compressed(os.path.join(HERE, "traj_%s.npz" % name), traj=traj, theta_idx=theta[0], theta_val=theta[1],
+            np.savez_compressed(os.path.join(OUT, "traj_%s.npz" % name), traj=traj, theta_idx=theta[0], theta_val=theta[1],
                                 theta_b_idx=pairs["i"].copy(), theta_b_val=pairs["v"].copy(), steps=info["steps"],
                                 end=info["end"], rng_ctr=info["rng_ctr"])
             print(name, info, "theta_b nonzeros", nn)
@@ -196,7 +199,7 @@ def main():
             g.n_events = n_events
             rec = engine.gen_stream_host(g, 5, 2, book, 1)
             traj, info, theta = ol.run_ref_episode(rec[0], algo=algo, mem=1 << 20, rng_stream=book, extra=extra)
-            np.savez_compressed(os.path.join(HERE, "multi_%s.npz" % name), traj=traj, theta_idx=theta[0],
+            np.savez_compressed(os.path.join(OUT, "multi_%s.npz" % name), traj=traj, theta_idx=theta[0],
                                 theta_val=theta[1], steps=info["steps"], ends=np.array(info["ends"]), rng_ctr=info["rng_ctr"])
             print(name, info)
         # ---- recorded-data path: the reference reading CSV files that contain same-timestamp
@@ -208,7 +211,7 @@ def main():
             rec[r, 0] = rec[r - 1, 0]
         for r in (180, 260):                     # crossed book: asks below bids -> IsValidState false
             rec[r, 2:7], rec[r, 12:17] = rec[r, 12:17][::-1].copy(), rec[r, 2:7][::-1].copy()
-        md, tas = os.path.join(HERE, "q14_md.csv"), os.path.join(HERE, "q14_tas.csv")
+        md, tas = os.path.join(OUT, "q14_md.csv"), os.path.join(OUT, "q14_tas.csv")
         write_reference_csvs(rec, 5, 2, md, tas)
         out = os.path.join(td, "q14.traj")
         th = os.path.join(td, "q14.theta")
@@ -220,10 +223,10 @@ def main():
         raw = np.fromfile(th, dtype=np.uint8)
         nn = int(np.frombuffer(raw[:8].tobytes(), dtype=np.int64)[0])
         pairs = np.frombuffer(raw[8:8 + 16 * nn].tobytes(), dtype=[("i", np.int64), ("v", np.float64)])
-        np.savez_compressed(os.path.join(HERE, "csv_q14.npz"), traj=traj, theta_idx=pairs["i"].copy(), theta_val=pairs["v"].copy(),
+        np.savez_compressed(os.path.join(OUT, "csv_q14.npz"), traj=traj, theta_idx=pairs["i"].copy(), theta_val=pairs["v"].copy(),
                             steps=info["steps"], end=info["end"])
         print("csv_q14", info)
-    print("golden fixtures written to", HERE)
+    print("golden fixtures written to", OUT)
 
 
 if __name__ == "__main__":

@@ -246,3 +246,29 @@ def test_reference_build_passes_the_references_own_unit_tests():
     last = out.stdout.strip().splitlines()[-1]
     assert out.returncode == 0 and last.startswith("mini-catch: 17 test cases") and last.endswith(" 0 failed"), out.stdout[-2000:]
     assert int(last.split(",")[1].split()[0]) >= 281   # every REQUIRE* of the four files was reached
+
+
+@pytest.mark.skipif(not ol.have_ref(), reason="oracle/_ref/ref_harness not built (needs the reference checkout)")
+def test_committed_fixtures_are_what_the_reference_build_produces(tmp_path, capsys):
+    """tests/golden/*.npz and the two q14 CSVs, regenerated from the unmodified reference by the committed script,
+    are byte-for-byte (array-for-array) the committed files: no fixture has drifted from its generator."""
+    from tests.golden import make_golden
+    import sys
+    argv, sys.argv = sys.argv, ["make_golden.py"]
+    try:
+        make_golden.main(str(tmp_path))
+    finally:
+        sys.argv = argv
+    capsys.readouterr()
+    made = sorted(os.listdir(tmp_path))
+    committed = sorted(f for f in os.listdir(GOLD) if f.endswith(".npz") or f.endswith(".csv"))
+    assert made == committed
+    for f in made:
+        if f.endswith(".csv"):
+            assert open(os.path.join(tmp_path, f)).read() == open(os.path.join(GOLD, f)).read(), f
+            continue
+        a, b = np.load(os.path.join(tmp_path, f)), np.load(os.path.join(GOLD, f))
+        assert sorted(a.files) == sorted(b.files), f
+        for k in a.files:
+            assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape, "%s[%s]" % (f, k)
+            assert a[k].tobytes() == b[k].tobytes(), "%s[%s] differs from the committed fixture" % (f, k)
