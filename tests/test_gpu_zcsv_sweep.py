@@ -66,3 +66,65 @@ def test_engine_on_crafted_csv_days():
         failed_init += out[0] == 0
     # the sample really contains what it is for
     assert steps > 500 and dry_days >= 3 and failed_init >= 1
+
+
+@pytest.mark.parametrize("fuse", [0, 1])
+@pytest.mark.parametrize("ticker,where,algo,theta_mode", [
+    ("HSBA.L", "closes", abi.ALGO_QLAMBDA, abi.THETA_SHARED),
+    ("CRDI.MI", "closes", abi.ALGO_SARSA, abi.THETA_PRIVATE),
+    ("NOKIA.HE", "opens", abi.ALGO_QLAMBDA, abi.THETA_SHARED),
+    ("AIR.PA", "opens", abi.ALGO_DOUBLE_Q, abi.THETA_PRIVATE),
+])
+def test_trading_window_edges(monkeypatch, ticker, where, algo, theta_mode, fuse):
+    """Market::IsOpen (market.cpp:67-70: open + 30 min < t < close − 30 min) at both ends, on several venues' session
+    times and tick tables: a stream that starts before the window (Initialise's `while not IsOpen` loop eats the early
+    rows) and one that runs past it (isTerminal ends the step loop and the episode: terminal = 1, the reference's
+    normal end of a day), two episodes each, against the oracle (pinned on the same cases against the reference by
+    tests/test_oracle_ref_sweep.py).  `fuse`: action selection inside the env kernel, whose terminal check is its own."""
+    if fuse:
+        monkeypatch.setenv("LOB_FUSE_ACT", "1")
+    B = 12
+    p = engine.default_params()
+    p.memory_size = 1 << 20
+    p.algo, p.theta_mode = algo, theta_mode
+    p.book_id_offset = 300
+    assert abi.load().lob_market_preset(ticker.encode(), p.market) == 0
+    g = engine.default_gen_params()
+    g.n_events = 420
+    lo, hi = p.market.open_ms + 30 * 60000, p.market.close_ms - 30 * 60000
+    g.t0_ms = int(lo - 25 * g.dt_ms) if where == "opens" else int(hi - 160 * g.dt_ms)
+    rec = engine.gen_stream_host(g, 5, 2, p.book_id_offset, B)
+    eng = engine.Engine(p, B)
+    eng.load_events(rec)
+    orc = ol.Oracle(p, rec)
+    exact = theta_mode == abi.THETA_PRIVATE
+    from tests.parity import compare_env
+    for episode in range(2):
+        eng.reset()
+        orc.reset()
+        compare_env(eng, orc, "%s %s episode %d reset" % (ticker, where, episode))
+        assert (dumps_to_np(eng.get_books())["time_ms"] > lo).all()      # Initialise ends inside the trading window
+        for step in range(g.n_events + 2):
+            eng.td_step(1)
+            orc.td_step(1)
+            compare_learner_step(eng, orc, "%s %s episode %d step %d" % (ticker, where, episode, step), exact=exact, rtol=1e-9)
+            if (eng.get_terminal() != 0).all():
+                break
+        want = 1 if where == "closes" else 2
+        assert (eng.get_terminal() == want).all(), eng.get_terminal()
+        assert eng.counters()[0] == orc.counters()[0]
+        eng.clear_inventory()
+        orc.clear_inventory()
+        compare_env(eng, orc, "%s %s episode %d after ClearInventory" % (ticker, where, episode))
+        eng.handle_terminal()
+        orc.handle_terminal()
+    for which in range(B if exact else 1):
+        if exact:
+            np.testing.assert_array_equal(eng.theta(which), orc.theta(which))
+        else:
+            np.testing.assert_allclose(eng.theta(which), orc.theta(which), rtol=1e-9, atol=1e-12)
+    if algo == abi.ALGO_DOUBLE_Q:       # theta_b of book b: which = b + n_books (private weights)
+        for b in range(B):
+            np.testing.assert_array_equal(eng.theta(b + B), orc.theta_b(b))
+    eng.close()
+    orc.close()
