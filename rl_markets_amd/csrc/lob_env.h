@@ -543,8 +543,10 @@ __device__ inline void market_order(const EnvCtx& c, EnvR& e, i64 size, i64& out
     i64 abs_size = size < 0 ? -size : size;
     // cumulative total_volume_ (quirk Q1) of the side being walked
     i64 tv;
-    if (e.done == 2) {  // after an abandoned event the totals are those of the last complete event
-        tv = e.k > 0 ? (side == 0 ? c.track(e.k - 1).a_tv : c.track(e.k - 1).b_tv) : 0;
+    if (e.done == 2) {
+        // out of data: the totals where the pre-pass stopped -- the last complete event's plus the rows an abandoned
+        // event still applied before the stream ran dry (it went through same-timestamp rows / invalid states)
+        tv = side == 0 ? c.S.prep[c.b].a_tv : c.S.prep[c.b].b_tv;
     } else {
         tv = side == 0 ? c.track(e.k - 1).a_tv : c.track(e.k - 1).b_tv;
     }

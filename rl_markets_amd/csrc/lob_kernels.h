@@ -1509,6 +1509,9 @@ __global__ void dump_kernel(const DevParams* __restrict__ Pp, DevState S, int fi
         d.ask_total_volume = t.a_tv; d.bid_total_volume = t.b_tv;
         d.spread_mean = t.spread_mean; d.target_price = t.tp_val;
     }
+    if (e.done == 2) {  // out of data: where the pre-pass stopped (incl. the rows an abandoned event still applied)
+        d.ask_total_volume = S.prep[b].a_tv; d.bid_total_volume = S.prep[b].b_tv;
+    }
     {   // last_total_volume_ = total before the last ApplyChanges row (book.cpp:71)
         // the last applied row is the current snapshot, except after an abandoned
         // (out-of-data) event that only stashed: then it is the stashed one
