@@ -128,3 +128,44 @@ def test_trading_window_edges(monkeypatch, ticker, where, algo, theta_mode, fuse
             np.testing.assert_array_equal(eng.theta(b + B), orc.theta_b(b))
     eng.close()
     orc.close()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_configuration_venues_and_sessions(seed):
+    """tests/test_gpu_fuzz.py's random configurations with two more dimensions drawn: the venue (session times, tick
+    bands: ten of market.cpp's) and where the stream sits in the trading window (inside it, starting before it, running
+    past its end) -- the dimensions tests/test_oracle_ref_sweep.py draws against the reference."""
+    from tests.test_gpu_fuzz import random_case
+    from tests.test_oracle_ref_sweep import TICKERS
+    p, g, B = random_case(7000 + seed)
+    r = np.random.default_rng(9000 + seed)
+    ticker = str(r.choice(TICKERS))
+    assert abi.load().lob_market_preset(ticker.encode(), p.market) == 0
+    g.dt_ms = int(r.choice([100, 500, 2000]))
+    lo, hi = p.market.open_ms + 30 * 60000, p.market.close_ms - 30 * 60000
+    where = int(r.integers(0, 3))
+    g.t0_ms = int(lo + 30 * 60000) if where == 0 else int(lo - int(r.integers(0, 40)) * g.dt_ms) if where == 1 else \
+        int(hi - int(r.integers(30, 220)) * g.dt_ms)
+    rec = engine.gen_stream_host(g, p.depth, p.max_trades, p.book_id_offset, B)
+    eng = engine.Engine(p, B)
+    eng.load_events(rec)
+    orc = ol.Oracle(p, rec)
+    exact = p.theta_mode == abi.THETA_PRIVATE or B == 1
+    tag = "seed %d %s where %d" % (seed, ticker, where)
+    for episode in range(2):
+        eng.reset()
+        orc.reset()
+        for step in range(70):
+            eng.td_step(1)
+            orc.td_step(1)
+            compare_learner_step(eng, orc, "%s episode %d step %d" % (tag, episode, step), exact=exact, rtol=1e-9)
+        eng.clear_inventory(); orc.clear_inventory()
+        eng.handle_terminal(); orc.handle_terminal()
+    for which in range(B if p.theta_mode == abi.THETA_PRIVATE else 1):
+        a, b = eng.theta(which), orc.theta(which)
+        if exact:
+            np.testing.assert_array_equal(a, b)
+        else:
+            np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-12)
+    eng.close()
+    orc.close()
