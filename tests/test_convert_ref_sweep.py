@@ -7,6 +7,7 @@ a time-and-sales file that runs dry before the depth file does, several trades a
 trades stamped exactly on a depth row, zero-size / zero-price trades, trade rows out of time order (the
 reference consumes them in FILE order).  tests/golden/csv_q14.npz pins one hand-made day; this pins the
 space around it.  Runs where oracle/_ref exists (the build container); LOB_REF_SWEEP=n widens it."""
+import ctypes as C
 import json
 import os
 import subprocess
@@ -44,7 +45,9 @@ def craft_csvs(seed, md_path, tas_path):
     # a row with a missing column ends the reference's day (its reader glues lines until it has 22 columns): mostly late
     # in the file, sometimes before the look-back windows have filled (Initialise fails)
     lo_bad = 5 if r.integers(0, 5) == 0 else (2 * n) // 3
-    short = set(int(i) for i in r.choice(np.arange(lo_bad, n), size=int(r.integers(0, 3)), replace=False))
+    # (not the last line: 21 columns + the empty read at the end of a newline-terminated file make a 22-column row whose
+    #  last field is "" -- the reference dies of an uncaught std::invalid_argument from stol when it gets there)
+    short = set(int(i) for i in r.choice(np.arange(lo_bad, n - 1), size=int(r.integers(0, 3)), replace=False))
     short = set(i for i in short if i - 1 not in short)   # two short lines in a row could add up to one 22-column row of garbage
     zeroed = set(int(i) for i in r.choice(np.arange(5, n), size=int(r.integers(0, 4)), replace=False))
     date = 20200102
@@ -147,4 +150,57 @@ def test_random_csv_day_against_the_reference(seed):
     nz = np.nonzero(thv)[0]
     np.testing.assert_array_equal(nz, pairs["i"], err_msg=tag)
     np.testing.assert_array_equal(thv[nz], pairs["v"], err_msg=tag)
+    o.close()
+
+
+@pytest.mark.parametrize("seed", range(max(1, int(os.environ.get("LOB_REF_SWEEP", "200")) // 8)))
+def test_random_configuration_on_csv_days_multi_episode(seed):
+    """The two sweeps crossed: a random configuration (tests/test_oracle_ref_sweep.py: agent, reward, variables,
+    look-backs up to 100 events, bounds, policy, venue ...) run for 2-3 episodes over one crafted CSV day -- what the
+    window sums carry from a day that ended at a short line, at a dry trade file or at the last row into the next
+    Initialise (quirk Q7 x Q21 / Q22), step caps, ClearInventory and HandleTerminal in between."""
+    from tests.test_oracle_golden import replay_multi
+    from tests.test_oracle_ref_sweep import random_case, sparse, check_sparse
+    with tempfile.TemporaryDirectory() as td:
+        md, tas = os.path.join(td, "md.csv"), os.path.join(td, "tas.csv")
+        r = craft_csvs(123000 + seed, md, tas)
+        p, _g, algo, x = random_case(124000 + seed)
+        x.pop("ticker")                      # the crafted prices sit on HSBA.L's grid and in its session
+        assert abi.load().lob_market_preset(b"HSBA.L", C.byref(p.market)) == 0
+        x["episodes"] = int(r.integers(2, 4))
+        if r.integers(0, 2):
+            x["steps"] = int(r.choice([5, 30, 90]))
+        out, th, tb = os.path.join(td, "t.traj"), os.path.join(td, "theta.bin"), os.path.join(td, "theta_b.bin")
+        cmd = [ol.REF_HARNESS, "episode", "--md", md, "--tas", tas, "--algo", algo, "--mem", str(p.memory_size), "--seed", str(p.seed),
+               "--rng_stream", str(p.book_id_offset), "--eps", repr(p.epsilon), "--out", out, "--theta_out", th, "--tmp", os.path.join(td, "h")]
+        if "double" in algo:
+            cmd += ["--theta_b_out", tb]
+        for k, v in x.items():
+            cmd += ["--" + k, str(v)]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        tag = "csv multi seed %d (%s, %s, %d episodes)" % (seed, algo, x["reward"], x["episodes"])
+        p.max_trades = T_SLOTS
+        if res.returncode == 3 and "Initialise failed" in res.stderr:
+            try:
+                rec = engine.convert_csv(md, tas, T_SLOTS)
+            except engine.LobError:
+                return
+            o = ol.Oracle(p, rec)
+            o.reset()
+            o.td_step(3)
+            assert o.counters()[0] == 0, tag + ": the reference's Initialise fails on this pair"
+            o.close()
+            return
+        assert res.returncode == 0, res.stderr
+        info = json.loads(res.stdout.strip().splitlines()[-1])
+        traj = np.fromfile(out, dtype=ol.STEP_DTYPE)
+        theta = sparse(th)
+        theta_b = sparse(tb) if "double" in algo else None
+        rec = engine.convert_csv(md, tas, T_SLOTS)
+    o = ol.Oracle(p, rec)
+    replay_multi({"traj": traj, "ends": np.array(info["ends"])}, o.reset, lambda: o.td_step(1), o.clear_inventory,
+                 lambda: ol.load().oracle_handle_terminal(o.h), lambda: o.rec(0), tag)
+    check_sparse(o.theta(0), theta[0], theta[1], tag)
+    if theta_b is not None:
+        check_sparse(o.theta_b(0), theta_b[0], theta_b[1], tag + " theta_b")
     o.close()
