@@ -48,7 +48,7 @@ def random_case(seed):
     p.reward_measure = int(r.choice(sorted(REWARD_OF)[1:]))     # pnl ... mm_div (mm_exp included)
     x["reward"] = REWARD_OF[p.reward_measure]
     bound = int(r.choice([1, 3, 10, 50])) * p.order_size
-    p.pos_lb, p.pos_ub = -bound, int(r.choice([bound, 2 * bound]))
+    p.pos_lb, p.pos_ub = -int(r.choice([bound, bound, 2 * bound, max(1, bound // 2)])), int(r.choice([bound, 2 * bound]))
     x["pos_lb"], x["pos_ub"] = p.pos_lb, p.pos_ub
     # read as float by the reference (base.cpp:14-60): hand over decimal strings of float values
     p.damping_factor = f32(r.uniform(0.0, 1.0))
@@ -56,8 +56,10 @@ def random_case(seed):
     p.pnl_weight = f32(r.uniform(0.0, 2.0))
     x["damping"], x["pos_weight"], x["pnl_weight"] = repr(p.damping_factor), repr(p.pos_weight), repr(p.pnl_weight)
     for name in ("lb_mpm", "lb_vlt", "lb_svl", "lb_vwap", "lb_rsi", "lb_spread", "lb_pnl", "lb_target"):
-        v = int(r.choice([1, 2, 7, 15, 45, 60, 100]))
-        setattr(p, name, v)
+        # example.yaml's rsi / vwap / pnl look-backs are 0: the reference takes max(., 1) (base.cpp:35-50) -- of all but
+        # the target price's, where a window of 0 leaves no price to quote at (it throws; lob_create refuses it)
+        v = int(r.choice([1, 2, 7, 15, 45, 60, 100] if name == "lb_target" else [0, 1, 2, 7, 15, 45, 60, 100]))
+        setattr(p, name, max(1, v))
         x[name] = v
     # market.target_price.type: "midprice" builds MicroPrice (quirk Q5), anything else MidPrice; "book" quotes off the book
     tp = str(r.choice(["midprice", "microprice", "book"]))
@@ -148,6 +150,15 @@ def test_random_configuration_against_the_reference(seed):
         tb = os.path.join(td, "theta_b.bin")
         if "double" in algo:
             x["theta_b_out"] = tb
+        # one case in four starts from a dense weight vector (Agent::theta read from a file the way the harness's
+        # --theta_in does): every term of getQ's 96-term sums is live from the first step on
+        th0 = None
+        rt = np.random.default_rng(41000 + seed)
+        if rt.integers(0, 4) == 0 and p.memory_size <= (1 << 20):
+            th0 = rt.normal(0.0, float(rt.choice([1e-6, 1e-2, 10.0])), size=p.memory_size)
+            th0[rt.integers(0, p.memory_size, size=p.memory_size // 8)] = 0.0
+            x["theta_in"] = os.path.join(td, "theta_in.bin")
+            th0.tofile(x["theta_in"])
         out = ref_or_failed_init(p, rec, "seed %d" % seed, trades=p.max_trades, algo=algo, mem=p.memory_size, seed=p.seed,
                                  rng_stream=p.book_id_offset, eps=p.epsilon, extra=x)
         if out is None:
@@ -156,6 +167,8 @@ def test_random_configuration_against_the_reference(seed):
         theta_b = sparse(tb) if "double" in algo else None
     tag = "seed %d (%s, %s, %s)" % (seed, algo, x["reward"], x["ticker"])
     o = ol.Oracle(p, rec)
+    if th0 is not None:
+        o.theta(0)[:] = th0
     o.reset()
     r0 = o.rec(0)
     for n in r0["book"].dtype.names:
