@@ -1,4 +1,7 @@
-"""The HIP engine on crafted CSV days (tests/test_convert_ref_sweep.py: same-timestamp rows, crossed books, rows the
+"""Three sweeps the engine runs last (file name sorts after the other GPU files): crafted CSV days, the edges of the
+trading window, random configurations over venues and session placement.
+
+The HIP engine on crafted CSV days (tests/test_convert_ref_sweep.py: same-timestamp rows, crossed books, rows the
 reference's readers drop or never get past, a time-and-sales file that runs dry first), step by step against the
 oracle -- which the CPU suite pins on the same files against the unmodified reference.  Covers the two places where the
 record stream carries the reference's streamer semantics into the kernels: LOB_EVT_FLAG_TAS_DRY (no event starts at a
