@@ -271,3 +271,39 @@ def test_random_backtest_against_the_reference(seed):
         if name not in ("cursor", "n_traces", "terminal"):
             assert np.array_equal(got[name], left[name]), "%s after the backtest: book.%s %r != %r" % (tag, name, got[name], left[name])
     o.close()
+
+
+@pytest.mark.parametrize("seed", range(max(1, int(os.environ.get("LOB_REF_SWEEP", "200")) // 8)))
+def test_random_configuration_through_the_references_own_learner(seed):
+    """The trajectories above come from a loop in the harness that mirrors Learner::_step statement by statement so that
+    it can record every step.  Here the reference's OWN experiment::serial::Learner::RunEpisode (serial.cpp:72-93) drives
+    its environment and agent; only the end can be observed -- the step count and the weights -- and it must be what the
+    oracle ends with."""
+    import json
+    import subprocess
+    p, g, algo, x = random_case(85000 + seed)
+    if p.policy == abi.POLICY_BOLTZMANN:      # the harness's learner mode builds the epsilon-greedy replay policy only
+        p.policy = abi.POLICY_EPS_GREEDY
+        x.pop("policy"), x.pop("tau")
+    rec = engine.gen_stream_host(g, 5, p.max_trades, p.book_id_offset, 1)
+    with tempfile.TemporaryDirectory() as td:
+        sp, th = os.path.join(td, "s.bin"), os.path.join(td, "theta.bin")
+        np.ascontiguousarray(rec[0], dtype=np.uint32).tofile(sp)
+        cmd = [ol.REF_HARNESS, "learner", "--stream", sp, "--events", str(rec.shape[1]), "--book", "0", "--depth", "5", "--trades",
+               str(p.max_trades), "--algo", algo, "--mem", str(p.memory_size), "--seed", str(p.seed), "--rng_stream", str(p.book_id_offset),
+               "--eps", repr(p.epsilon), "--theta_out", th, "--tmp", os.path.join(td, "h")]
+        for k, v in x.items():
+            cmd += ["--" + k, str(v)]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        assert res.returncode == 0, res.stderr
+        info = json.loads(res.stdout.strip().splitlines()[-1])
+        theta = sparse(th) if os.path.exists(th) else None
+    tag = "learner seed %d (%s, %s, %s)" % (seed, algo, x["reward"], x["ticker"])
+    o = ol.Oracle(p, rec)
+    o.reset()
+    o.td_step(rec.shape[1] + 2)
+    o.clear_inventory()
+    o.handle_terminal()
+    assert o.rec(0)["book"]["total_ticks"] == info["steps_per_episode"], tag
+    check_sparse(o.theta(0), theta[0], theta[1], tag)
+    o.close()
