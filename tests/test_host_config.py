@@ -22,9 +22,10 @@ int main(int argc, char** argv) {
         lob::Config c(argv[1]);
         for (int i = 2; i + 1 < argc; i += 2) c.set(argv[i], argv[i + 1]);
         lob_params p = c.to_params("HSBA.L");
-        std::printf("%d %d %.17g %.17g %.17g %.17g %.17g %d %.17g %d %d %lld %d %d\n", (int)p.algo, (int)p.policy, p.beta, p.epsilon,
+        std::printf("%d %d %.17g %.17g %.17g %.17g %.17g %d %.17g %d %d %lld %d %d %d %d %d %d %d\n", (int)p.algo, (int)p.policy, p.beta, p.epsilon,
                     p.tau, p.gamma, p.alpha, (int)p.target_price, (double)p.group_weights[2], (int)p.n_tilings, (int)p.n_actions,
-                    (long long)p.memory_size, (int)p.quote_mode, (int)p.market.n_bands);
+                    (long long)p.memory_size, (int)p.quote_mode, (int)p.market.n_bands, (int)p.lb_rsi, (int)p.lb_vwap,
+                    (int)p.lb_pnl, (int)p.lb_spread, (int)p.lb_target);
     } catch (const std::exception& e) {
         std::fprintf(stderr, "EXC %s\n", e.what());
         return 3;
@@ -57,7 +58,8 @@ def fields(out):
     f = out.stdout.split()
     return dict(algo=int(f[0]), policy=int(f[1]), beta=float(f[2]), epsilon=float(f[3]), tau=float(f[4]), gamma=float(f[5]),
                 alpha=float(f[6]), target_price=int(f[7]), gw2=float(f[8]), n_tilings=int(f[9]), n_actions=int(f[10]),
-                memory_size=int(f[11]), quote_mode=int(f[12]), n_bands=int(f[13]))
+                memory_size=int(f[11]), quote_mode=int(f[12]), n_bands=int(f[13]), lb_rsi=int(f[14]), lb_vwap=int(f[15]),
+                lb_pnl=int(f[16]), lb_spread=int(f[17]), lb_target=int(f[18]))
 
 
 def test_engine_yaml_is_the_reference_example(probe):
@@ -108,3 +110,13 @@ def test_target_price_quirk_and_quote_mode(probe):
     assert fields(probe(**{"market__target_price__type": "microprice"}))["target_price"] == abi.TP_MIDPRICE
     f = fields(probe(**{"market__target_price__type": "book"}))
     assert f["quote_mode"] == abi.QUOTE_BOOK
+
+
+def test_lookbacks_are_clamped_like_base_cpp(probe):
+    """Every window is max(lookback, 1) (base.cpp:35-50: example.yaml's rsi / vwap / pnl look-backs are 0) except the
+    target price's (base.cpp:102), which goes through as written -- lob_create refuses 0 where the reference has no price
+    to quote at."""
+    f = fields(probe())
+    assert (f["lb_rsi"], f["lb_vwap"], f["lb_pnl"], f["lb_spread"], f["lb_target"]) == (1, 1, 1, 45, 1)
+    f = fields(probe(**{"policy__spread_lookback": 0, "market__target_price__lookback": 0, "state__lookback__rsi": 14}))
+    assert (f["lb_spread"], f["lb_target"], f["lb_rsi"]) == (1, 0, 14)
