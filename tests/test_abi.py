@@ -132,6 +132,21 @@ def test_no_gpu_means_no_engine():
         engine.Engine(p, 4)
 
 
+@pytest.mark.skipif(has_gpu(), reason="only meaningful on a box without a GPU")
+def test_no_gpu_drivers_fail_loudly():
+    """The C++ driver and the bench on a box without a GPU: an error that says so and a non-zero exit, not a CPU run."""
+    import subprocess
+    import sys
+    exe = os.path.join(ROOT, "rl_markets_amd", "host", "lob_run")
+    out = subprocess.run([exe, "-c", os.path.join(ROOT, "config", "engine.yaml"), "-a", "q_learn", "-n", "1", "-e", "1", "--events", "300"],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 2 and "no usable HIP device" in out.stderr and out.stdout.strip() == ""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--books", "64", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode != 0 and "no usable HIP device" in (out.stderr + out.stdout)
+    assert '"metric"' not in out.stdout        # no result line without a GPU
+
+
 def test_product_does_not_reference_the_oracle():
     """Nothing under rl_markets_amd/ may include, import, link or execute anything under oracle/ or tests/."""
     pat = re.compile(r"#\s*include[^\n]*oracle|liblob_oracle|oracle_lib|ref_harness|from\s+tests|import\s+tests|oracle/")
