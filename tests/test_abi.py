@@ -155,3 +155,13 @@ def test_product_does_not_reference_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not pat.search(txt), "%s reaches into the oracle" % f
+
+
+def test_traffic_table_is_what_the_committed_counter_passes_give(tmp_path):
+    """profiles/pmc_traffic.json (bench.py's roofline.traffic) regenerated from the committed rocprofv3 counter summary."""
+    import json
+    import subprocess
+    import sys
+    out = str(tmp_path / "traffic.json")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_traffic.py"), "r02", out], stdout=subprocess.DEVNULL)
+    assert json.load(open(out)) == json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))

@@ -34,7 +34,8 @@ for k, c in sorted(rows.items()):
         e["fetch_over_miss64"] = round(c["FETCH_SIZE"] * 1024.0 / (c["TCC_MISS_sum"] * 64.0), 3)
     out[k] = e
 out["_source"] = "profiles/%s_pmc.csv: rocprofv3 --pmc passes of the bench command (one counter group per pass), averages per launch; a static file, not measured in the bench run itself" % tag
-json.dump(out, open(os.path.join(root, "profiles", "pmc_traffic.json"), "w"), indent=1)
+dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(root, "profiles", "pmc_traffic.json")
+json.dump(out, open(dst, "w"), indent=1)
 for k, e in out.items():
     if k.startswith("_"):
         continue
