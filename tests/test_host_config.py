@@ -120,3 +120,35 @@ def test_lookbacks_are_clamped_like_base_cpp(probe):
     assert (f["lb_rsi"], f["lb_vwap"], f["lb_pnl"], f["lb_spread"], f["lb_target"]) == (1, 1, 1, 45, 1)
     f = fields(probe(**{"policy__spread_lookback": 0, "market__target_price__lookback": 0, "state__lookback__rsi": 14}))
     assert (f["lb_spread"], f["lb_target"], f["lb_rsi"]) == (1, 0, 14)
+
+
+REF_YAML = "/root/reference/config/example.yaml"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_YAML), reason="needs the reference checkout")
+def test_the_references_own_example_yaml_reads_the_same(tmp_path):
+    """lob::Config on the reference's config/example.yaml, unedited: the same lob_params, byte for byte, as on
+    config/engine.yaml (which documents the keys) -- a user's existing config file works as it is."""
+    src = tmp_path / "cmp.cpp"
+    src.write_text(r'''
+#include <cstdio>
+#include <cstring>
+#include "lob_host.hpp"
+int main(int, char** argv) {
+    lob::Config a(argv[1]), b(argv[2]);
+    lob_params pa = a.to_params("HSBA.L"), pb = b.to_params("HSBA.L"), pd;
+    lob_default_params(&pd);
+    std::printf("%d %d\n", std::memcmp(&pa, &pb, sizeof pa), std::memcmp(&pa, &pd, sizeof pa));
+    return 0;
+}
+''')
+    exe = str(tmp_path / "cmp")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "rl_markets_amd", "host"), "-o", exe, str(src),
+                           "-L" + CSRC, "-llob_comm", "-llob_engine", "-Wl,-rpath," + CSRC, "-L/opt/rocm/lib",
+                           "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link," + CSRC + ":/opt/rocm/lib"])
+    same_as_engine_yaml, same_as_defaults = subprocess.check_output([exe, REF_YAML, YAML]).split()
+    assert int(same_as_engine_yaml) == 0
+    # lob_default_params is example.yaml except for its algorithm (double_q_learn there, SARSA in the struct's defaults)
+    p = abi.Params()
+    abi.load().lob_default_params(p)
+    assert p.algo == abi.ALGO_SARSA
