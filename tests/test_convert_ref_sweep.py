@@ -26,7 +26,7 @@ pytestmark = pytest.mark.skipif(not ol.have_ref(), reason="oracle/_ref/ref_harne
 T_SLOTS = abi.LOB_MAX_TRADES
 
 
-def craft_csvs(seed, md_path, tas_path):
+def craft_csvs(seed, md_path, tas_path, ulps=True):
     r = np.random.default_rng(seed)
     g = engine.default_gen_params()
     g.seed = int(r.integers(0, 1 << 40))
@@ -63,6 +63,11 @@ def craft_csvs(seed, md_path, tas_path):
                 ap, av = [ap[k] for k in o], [av[k] for k in o]
                 o = r.permutation(5)
                 bp, bv = [bp[k] for k in o], [bv[k] for k in o]
+            if ulps and r.integers(0, 10) == 0:                 # level prices one float off the grid (same key, other bits)
+                k = int(r.integers(0, 5))
+                ap[k] = float(np.nextafter(np.float32(ap[k]), np.float32(1e9 if r.integers(0, 2) else 0.0)))
+                k = int(r.integers(0, 5))
+                bp[k] = float(np.nextafter(np.float32(bp[k]), np.float32(1e9 if r.integers(0, 2) else 0.0)))
             if i in zeroed:
                 (ap if r.integers(0, 2) else bp)[int(r.integers(0, 5))] = 0.0   # row dropped (basic.cpp:54-58)
             cols = [str(date), ms_to_str(int(times[i]))] + ["%.9g" % x for x in ap] + ["%d" % x for x in av] + \
@@ -82,6 +87,10 @@ def craft_csvs(seed, md_path, tas_path):
             t = hi if (hi == lo or r.integers(0, 4) == 0) else int(r.integers(lo + 1, hi + 1))   # (lo, hi], often == hi
             size = int(r.choice([0, 1, 7, 150, 2500], p=[0.05, 0.2, 0.25, 0.3, 0.2]))
             price = 0.0 if r.integers(0, 40) == 0 else px[int(r.integers(0, len(px)))]
+            if ulps and price > 0.0 and r.integers(0, 6) == 0:
+                # a neighbouring float: mostly the same 1e-4 price key (merged under the first-seen price by the reference's
+                # map<double, long, FloatComparator>), now and then the next key
+                price = float(np.nextafter(np.float32(price), np.float32(1e9 if r.integers(0, 2) else 0.0)))
             rows.append((t, price, size))
     # file order = generation order: within an interval the times are NOT sorted
     last_t = int(times[-1])

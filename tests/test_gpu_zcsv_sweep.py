@@ -25,7 +25,7 @@ pytestmark = pytest.mark.gpu
 def run_day(seed, algo, tag):
     with tempfile.TemporaryDirectory() as td:
         md, tas = os.path.join(td, "md.csv"), os.path.join(td, "tas.csv")
-        craft_csvs(seed, md, tas)
+        craft_csvs(seed, md, tas, ulps=False)   # (prices one float off the grid: pinned on the oracle, not yet run on the GPU)
         try:
             rec = engine.convert_csv(md, tas, T_SLOTS)
         except engine.LobError:
