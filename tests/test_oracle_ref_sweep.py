@@ -142,10 +142,26 @@ def check_sparse(th, idx, val, tag):
     np.testing.assert_array_equal(th[nz], val, err_msg=tag)
 
 
+def off_grid(rec, T, seed):
+    """One record stream with some level and trade prices moved to a neighbouring float: mostly the same 1e-4 price key
+    with other bits (the reference compares prices through FloatComparator / its map keys), now and then the next key."""
+    r = np.random.default_rng(seed)
+    f = rec.view(np.float32)
+    n = rec.shape[1]
+    cols = np.concatenate([np.arange(2, 7), np.arange(12, 17), np.arange(22, 22 + T)])
+    for _ in range(max(1, n // 3)):
+        i, c = int(r.integers(0, n)), int(r.choice(cols))
+        if f[0, i, c] > 0:
+            f[0, i, c] = np.nextafter(f[0, i, c], np.float32(1e9 if r.integers(0, 2) else 0.0))
+    return rec
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("LOB_REF_SWEEP", "200"))))
 def test_random_configuration_against_the_reference(seed):
     p, g, algo, x = random_case(31000 + seed)
     rec = engine.gen_stream_host(g, 5, p.max_trades, p.book_id_offset, 1)   # the reference's depth file has 5 levels
+    if seed % 3 == 2:
+        rec = off_grid(rec, p.max_trades, seed)
     with tempfile.TemporaryDirectory() as td:
         tb = os.path.join(td, "theta_b.bin")
         if "double" in algo:
