@@ -21,6 +21,13 @@
 
 #include "../rl_markets_amd/csrc/lob_stream.h"  // record layout + lob_rng only (inputs, RNG)
 
+// Debug statistics for kernel design (tools/env_pass_stats.py): what an event pass (NextState) did to the agent's two
+// orders.  Bits of g_pass; counted per pass and OR-ed per step in the env loop below.  Not part of any comparison.
+enum { PS_TOUCH = 1, PS_FILL = 2, PS_EXECUTED = 4, PS_CANCEL = 8, PS_LEVEL_GONE = 16, PS_NO_LAST = 32, PS_VOL_BEHIND = 64,
+       PS_ADVERSE = 128, PS_ERASED = 256 };
+static unsigned g_pass = 0;
+static long long g_pass_stats[16] = {0};
+
 namespace {
 
 // ---------------------------------------------------------------------------
@@ -179,16 +186,17 @@ template <class C> struct Book {
         // book.cpp:102-141
         double p = it->first;
         Order& o = *it->second;
-        if (o.isExecuted()) return open_orders.erase(it);
+        if (o.isExecuted()) { g_pass |= PS_ERASED; return open_orders.erase(it); }
         long lv = last_volume(p);
-        if (lv == 0) { ++it; return it; }
+        if (lv == 0) { g_pass |= PS_NO_LAST; ++it; return it; }
         long v = volume(p);
-        if (v == 0) { o.clearQueues(); ++it; return it; }
+        if (v == 0) { g_pass |= PS_LEVEL_GONE; o.clearQueues(); ++it; return it; }
         long vol_diff = lv - v;
         if (vol_diff >= 0) {
             long cancelled = vol_diff - transaction_volume;
-            if (cancelled > 0) o.doCancellation(cancelled);
+            if (cancelled > 0) { g_pass |= PS_CANCEL; o.doCancellation(cancelled); }
         } else {
+            g_pass |= PS_VOL_BEHIND;
             o.addVolumeBehind(vol_diff);  // quirk Q2: negative
         }
         ++it;
@@ -228,10 +236,12 @@ struct AskBook : Book<Less> {
                 long rem0 = o_it->second->remaining();
                 vol = o_it->second->doTransaction(vol);
                 long exec = rem0 - o_it->second->remaining();
+                g_pass |= PS_TOUCH | (exec ? PS_FILL : 0);
                 volume -= exec;
                 proxy += (o_it->first - reference_price) * exec;
                 value += o_it->first * exec;
                 if (o_it->second->isExecuted()) {
+                    g_pass |= PS_EXECUTED;
                     o_it = open_orders.erase(o_it);
                     n_transacted_++;
                 }
@@ -275,11 +285,13 @@ struct BidBook : Book<Greater> {
                 long rem0 = o_it->second->remaining();
                 vol = o_it->second->doTransaction(vol);
                 long exec = rem0 - o_it->second->remaining();
+                g_pass |= PS_TOUCH | (exec ? PS_FILL : 0);
                 volume += exec;
                 proxy += (reference_price - o_it->first) * exec;
                 value -= o_it->first * exec;
                 bool erased = false;
                 if (o_it->second->isExecuted()) {
+                    g_pass |= PS_EXECUTED;
                     open_orders.erase(o_it);
                     n_transacted_++;
                     erased = true;
@@ -721,6 +733,7 @@ struct Env {
         // trades carried by the record about to be applied (= LoadUntil(next depth time))
         // time_and_sales.LoadUntil(next depth row's time): every trade up to that row which
         // has not been handed over yet (rows carry the trades of their own interval)
+        g_pass = 0;
         TradeMap tx;
         for (int rr = trades_from; rr <= cursor; rr++) {
             const uint32_t* r = row(rr);
@@ -735,6 +748,7 @@ struct Env {
         Fill au = ask.ApplyTransactions(tx, mp), bu = bid.ApplyTransactions(tx, mp);
         if (!UpdateBookProfiles(tx)) return false;
         Fill adv = HandleAdverseSelection(ask, bid);
+        if (std::get<0>(adv) != 0) g_pass |= PS_ADVERSE;
         pnl_step += std::get<1>(au) + std::get<1>(bu) + std::get<1>(adv);
         lo_vol_step += (int)(std::get<0>(bu) - std::get<0>(au) + labs(std::get<0>(adv)));
         ep_pnl += std::get<2>(au) + std::get<2>(bu) + std::get<2>(adv);
@@ -833,9 +847,16 @@ struct Env {
         double agg_r = getReward();
         double agg_pnl = pnl_step;
         double agg_mpm = 0.0;
+        unsigned step_or = 0;
+        int n_pass = 0;
         do {
             pnl_step = 0.0;
             if (!NextState()) return false;
+            g_pass_stats[0]++;                                   // passes
+            for (int b = 0; b < 9; b++) g_pass_stats[1 + b] += (g_pass >> b) & 1;
+            if (!(g_pass & ~(unsigned)PS_VOL_BEHIND)) g_pass_stats[10]++;   // quiet pass: nothing but more volume behind
+            step_or |= g_pass;
+            n_pass++;
             double mpm = midprice_move(ask, bid);
             pnl_step += position * mpm;
             momentum_pnl_step += position * mpm;
@@ -843,6 +864,10 @@ struct Env {
             agg_pnl += pnl_step;
             agg_mpm += mpm;
         } while (!isTerminal() && fabs(agg_mpm) < 1e-5);
+        g_pass_stats[11]++;                                      // steps
+        if (!(step_or & ~(unsigned)PS_VOL_BEHIND)) g_pass_stats[12]++;      // steps all of whose passes were quiet
+        if (!(step_or & (PS_FILL | PS_EXECUTED | PS_ADVERSE | PS_ERASED | PS_LEVEL_GONE))) g_pass_stats[13]++;  // no fill / structural change
+        g_pass_stats[14] += n_pass > 1;
         pnl_step = agg_pnl;
         pnl_ups.push(std::max(0.0, pnl_step));
         pnl_downs.push(fabs(std::min(0.0, pnl_step)));
@@ -1087,6 +1112,9 @@ oracle_learner* oracle_create(const lob_params* p, int32_t n_books, const uint32
     return o;
 }
 void oracle_destroy(oracle_learner* o) { delete o; }
+void oracle_debug_pass_stats(long long* out16, int reset) {
+    for (int i = 0; i < 16; i++) { out16[i] = g_pass_stats[i]; if (reset) g_pass_stats[i] = 0; }
+}
 
 int oracle_reset(oracle_learner* o) {
     for (int b = 0; b < o->B; b++) {

@@ -65,6 +65,8 @@ double* oracle_theta(oracle_learner* o, int32_t which);
 double* oracle_theta_b(oracle_learner* o, int32_t which);
 int32_t oracle_get_traces(oracle_learner* o, int32_t book, int32_t* idx, float* e, int32_t cap);
 void oracle_get_counters(oracle_learner* o, int64_t out[4]);
+/* debug statistics of the env loop (tools/env_pass_stats.py); process-wide, not thread-safe */
+void oracle_debug_pass_stats(long long* out16, int reset);
 
 /* ---- unit-level entry points (known-answer tests) ------------------------ */
 void oracle_tiles(int64_t memory_size, const float* vars, int32_t n_vars, int32_t n, int32_t* out /*[n][9][96]*/);
