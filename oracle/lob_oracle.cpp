@@ -17,6 +17,7 @@
 #include <stdexcept>
 #include <tuple>
 #include <unordered_map>
+#include <thread>
 #include <vector>
 
 #include "../rl_markets_amd/csrc/lob_stream.h"  // record layout + lob_rng only (inputs, RNG)
@@ -25,8 +26,8 @@
 // orders.  Bits of g_pass; counted per pass and OR-ed per step in the env loop below.  Not part of any comparison.
 enum { PS_TOUCH = 1, PS_FILL = 2, PS_EXECUTED = 4, PS_CANCEL = 8, PS_LEVEL_GONE = 16, PS_NO_LAST = 32, PS_VOL_BEHIND = 64,
        PS_ADVERSE = 128, PS_ERASED = 256 };
-static unsigned g_pass = 0;
-static long long g_pass_stats[16] = {0};
+static thread_local unsigned g_pass = 0;
+static thread_local long long g_pass_stats[16] = {0};  // (of the calling thread: meaningful with ORACLE_THREADS unset)
 
 namespace {
 
@@ -1145,7 +1146,11 @@ int oracle_td_step(oracle_learner* o, int32_t n_steps) {
         // R-learning (agent.cpp:357-412): what the rho update after updateQ still needs of the step
         const bool r_learn = o->P.algo == LOB_ALGO_R_LEARN || o->P.algo == LOB_ALGO_ONLINE_R_LEARN || o->P.algo == LOB_ALGO_DOUBLE_R_LEARN;
         std::vector<double> rl_q(o->B, 0.0), rl_t(o->B, 0.0), rl_r(o->B, 0.0);
-        for (int b = 0; b < o->B; b++) {
+        // read phase: the books are independent (every one reads theta_t / rho_t, draws from its own counter-based
+        // stream, writes its own traces and record), so a test may spread them over host threads (ORACLE_THREADS=n;
+        // the write phase below stays serial, in book order)
+        auto read_phase = [&](int b_lo, int b_hi, int64_t* n_done) {
+        for (int b = b_lo; b < b_hi; b++) {
             if (o->done[b]) continue;
             Env& e = *o->env[b];
             // swap(state, last_state)
@@ -1233,8 +1238,22 @@ int oracle_td_step(oracle_learner* o, int32_t n_steps) {
             }
             upd[b] = o->alpha * delta;
             has[b] = (char)target;
-            o->n_steps_done++;
+            ++*n_done;
             o->record(b, a, reward, delta);
+        }
+        };
+        {
+            static const int n_thr_env = getenv("ORACLE_THREADS") ? atoi(getenv("ORACLE_THREADS")) : 1;
+            const int n_thr = std::max(1, std::min(n_thr_env, o->B / 64));
+            std::vector<int64_t> done_cnt(n_thr, 0);
+            if (n_thr == 1) read_phase(0, o->B, &done_cnt[0]);
+            else {
+                std::vector<std::thread> pool;
+                for (int t = 0; t < n_thr; t++)
+                    pool.emplace_back(read_phase, (int)((int64_t)o->B * t / n_thr), (int)((int64_t)o->B * (t + 1) / n_thr), &done_cnt[t]);
+                for (auto& th : pool) th.join();
+            }
+            for (int64_t c : done_cnt) o->n_steps_done += c;
         }
         // write phase: updateQ (agent.cpp:137-142) for every book, book order
         for (int b = 0; b < o->B; b++) {
@@ -1249,6 +1268,7 @@ int oracle_td_step(oracle_learner* o, int32_t n_steps) {
         // stream; every book reads rho_t, the increments are summed (the batch semantic of theta)
         if (r_learn) {
             std::vector<double> inc(o->rho.size(), 0.0);
+            std::vector<int> cnt(o->rho.size(), 0);  // rho moves by the MEAN of the step's increments
             for (int b = 0; b < o->B; b++) {
                 if (!has[b]) continue;
                 const double nQ = rl_q[b] + upd[b];
@@ -1259,14 +1279,14 @@ int oracle_td_step(oracle_learner* o, int32_t n_steps) {
                         double val = (o->getQ(b, o->last_feats[b], i) + o->getQ(b, o->last_feats[b], i, true)) / 2.0;
                         if (val > mQ) mQ = val;
                     }
-                    if (nQ - mQ < 1e-7) inc[o->P.theta_mode == LOB_THETA_PRIVATE ? b : 0] += o->P.beta * (rl_r[b] - o->rh(b) + mQ - nQ);
+                    if (nQ - mQ < 1e-7) { inc[o->P.theta_mode == LOB_THETA_PRIVATE ? b : 0] += o->P.beta * (rl_r[b] - o->rh(b) + mQ - nQ); cnt[o->P.theta_mode == LOB_THETA_PRIVATE ? b : 0]++; }
                     continue;
                 }
                 const double mq_from = o->getQ(b, o->last_feats[b], o->argmaxQ(b, o->last_feats[b]));
                 o->recs[b].rng_ctr = o->rng_ctr[b];
-                if (nQ - mq_from < 1e-7) inc[o->P.theta_mode == LOB_THETA_PRIVATE ? b : 0] += o->P.beta * (rl_r[b] - o->rh(b) + rl_t[b] - nQ);
+                if (nQ - mq_from < 1e-7) { inc[o->P.theta_mode == LOB_THETA_PRIVATE ? b : 0] += o->P.beta * (rl_r[b] - o->rh(b) + rl_t[b] - nQ); cnt[o->P.theta_mode == LOB_THETA_PRIVATE ? b : 0]++; }
             }
-            for (size_t i = 0; i < inc.size(); i++) o->rho[i] += inc[i];
+            for (size_t i = 0; i < inc.size(); i++) if (cnt[i] > 0) o->rho[i] += inc[i] / (double)cnt[i];
         }
     }
     return 0;

@@ -5,6 +5,7 @@
 #include <rccl/rccl.h>
 #include <stdio.h>
 #include <string.h>
+#include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -84,23 +85,27 @@ int lob_comm_create_file(const char* path, int32_t rank, int32_t world, int32_t 
     if (rank == 0) {
         int rc = lob_comm_get_id(id);
         if (rc) return rc;
+        // the token is written to a fresh file of our own (O_EXCL | O_NOFOLLOW: never through a link somebody left at a
+        // predictable name in a shared directory) and published by rename; callers put `path` in a private directory
+        // (launch.py, lob_run: mkdtemp) or at least give it a per-run nonce
         const std::string tmp = std::string(path) + ".tmp";
-        FILE* f = fopen(tmp.c_str(), "wb");
-        if (!f || fwrite(id, 1, sizeof id, f) != sizeof id) {
-            if (f) fclose(f);
+        unlink(tmp.c_str());
+        const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+        if (fd < 0 || write(fd, id, sizeof id) != (ssize_t)sizeof id) {
+            if (fd >= 0) { close(fd); unlink(tmp.c_str()); }
             lob_set_error(std::string("lob_comm_create_file: cannot write ") + tmp);
             return LOB_EINVAL;
         }
-        fclose(f);
+        close(fd);
         if (rename(tmp.c_str(), path) != 0) { lob_set_error(std::string("lob_comm_create_file: cannot publish ") + path); return LOB_EINVAL; }
     } else {
         const auto t0 = std::chrono::steady_clock::now();
         while (true) {
             struct stat st;
             if (stat(path, &st) == 0 && st.st_size == (off_t)sizeof id) {
-                FILE* f = fopen(path, "rb");
-                const bool ok = f && fread(id, 1, sizeof id, f) == sizeof id;
-                if (f) fclose(f);
+                const int fd = open(path, O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+                const bool ok = fd >= 0 && read(fd, id, sizeof id) == (ssize_t)sizeof id;
+                if (fd >= 0) close(fd);
                 if (ok) break;
             }
             if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > (double)timeout_s) {

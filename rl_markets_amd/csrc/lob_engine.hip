@@ -59,6 +59,7 @@ struct lob_engine {
     bool force_fuse_act = false;
     bool fuse_act = true;       // ... inside the env kernel (env_kernel<.., 1>; LOB_NO_FUSE_ACT=1: act_light_kernel as a launch of its own)
  bool t_light = true;        // trace_light_kernel in front of the wave-per-book trace kernel (Q(lambda); LOB_NO_TLIGHT=1: off)
+    bool no_fuse = false;       // LOB_NO_FUSE=1: the light trace step as a kernel of its own, not inside the lane learner kernel (A/B switch)
     bool q_pair = true;         // ... two lanes per book (learn_q_pair_kernel; LOB_Q_PAIR=0: one)
     int q_lanes = -1;           // learn_q_lane_kernel (a lane per book) instead of learn_q_fast_kernel (a wave per book): -1 by batch size,
                                 // 0 / 1 forced (LOB_Q_LANES)
@@ -266,6 +267,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     if (const char* g = getenv("LOB_Q_LANES")) e->q_lanes = g[0] == '1' ? 1 : 0;
     if (const char* g = getenv("LOB_NO_TLIGHT")) e->t_light = !(g[0] == '1');
     if (const char* g = getenv("LOB_Q_PAIR")) e->q_pair = !(g[0] == '0');
+    if (const char* g = getenv("LOB_NO_FUSE")) e->no_fuse = g[0] == '1';
     if (const char* g = getenv("LOB_RESET_LANES")) { int v = atoi(g); if (v == 16 || v == 32 || v == 64) e->reset_lanes = v; }
 
     // ---- DevParams ----
@@ -367,6 +369,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
         const size_t nr = rl ? (P.theta_private ? B : 1) : 1;
         if (rc == LOB_OK) rc = dev_alloc(e, &S.rho, nr);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.rho_inc, nr);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.rho_cnt, nr);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.rl_t, rl ? B : 1);
     }
     if (rc == LOB_OK) rc = dev_alloc(e, &S.tr_sig, B * (size_t)P.trace_gens * 4);
@@ -587,7 +590,10 @@ int lob_load_events(lob_engine* e, const uint32_t* host_records, int32_t n_event
     if (rc != LOB_OK) return rc;
     rc = set_records(e, n_events, (size_t)e->B * n_events);
     if (rc != LOB_OK) return rc;
-    return upload_records(e, host_records, (size_t)e->B * n_events);
+    e->have_events = false;  // (a failed upload leaves no stream behind)
+    rc = upload_records(e, host_records, (size_t)e->B * n_events);
+    e->have_events = rc == LOB_OK;
+    return rc;
 }
 
 int lob_load_events_shared(lob_engine* e, const uint32_t* host_records, int64_t n_total, const int64_t* phase, int32_t n_events) {
@@ -605,12 +611,15 @@ int lob_load_events_shared(lob_engine* e, const uint32_t* host_records, int64_t 
     if (rc != LOB_OK) return rc;
     rc = set_records(e, n_events, (size_t)n_total);
     if (rc != LOB_OK) return rc;
+    // until the phases are in place the buffer (n_total rows) must not pass for a per-book stream (B * n_events rows)
+    e->have_events = false;
     hipError_t err = hipMalloc((void**)&e->phase_dev, (size_t)e->B * sizeof(i64));
-    if (err != hipSuccess) { lob_set_error("hipMalloc(phase) failed"); return LOB_ENOMEM; }
+    if (err != hipSuccess) { e->phase_dev = nullptr; lob_set_error("hipMalloc(phase) failed"); return LOB_ENOMEM; }
     rc = upload_records(e, host_records, (size_t)n_total);
     if (rc != LOB_OK) return rc;
     HIPCHK(hipMemcpyAsync(e->phase_dev, phase, (size_t)e->B * sizeof(i64), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    e->have_events = true;
     e->S.rec_phase = e->phase_dev;
     return LOB_OK;
 }
@@ -697,6 +706,11 @@ int lob_reset(lob_engine* e) {
     HIPCHK(hipMemsetAsync(e->S.mk_hash, 0xff, (size_t)e->S.mk_slots * 8, e->stream));
     HIPCHK(hipMemsetAsync(e->S.mk_tiles_ok, 0, (size_t)e->S.mk_slots * 4, e->stream));
     HIPCHK(hipMemsetAsync(e->S.mk_marked, 0, (size_t)e->S.mk_slots * 4, e->stream));
+    // ... and so do its lists: a lob_theta_set / lob_delta_apply between this reset and the first step runs
+    // memo_kernel over the `last_par` list, which must not hold the slots of the episode before (their hashes
+    // are gone: re-stamping mk_tiles_ok for a stale triple would hand a later claimant of the slot the wrong tiles)
+    HIPCHK(hipMemsetAsync(e->S.mk_count, 0, 2 * sizeof(i32), e->stream));
+    HIPCHK(hipMemsetAsync(e->S.mk_markcount, 0, sizeof(i32), e->stream));
     {
         TimedLaunch t(e, "reset_kernel", nullptr, true);
         const int rb = e->reset_lanes;
@@ -883,8 +897,7 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode) {
                 const bool lanes = e->q_lanes >= 0 ? e->q_lanes == 1 : nb >= LOB_QL_BLOCK * e->n_cus / 2;
                 // ... and then the lane kernel also takes the trace step of the books it can (those left go on a list for the
                 // wave-per-book trace kernel, which runs AFTER it)
-                static const bool no_fuse = getenv("LOB_NO_FUSE") && getenv("LOB_NO_FUSE")[0] == '1';  // (A/B switch)
-                const bool fuse = tl && lanes && !no_fuse;
+                const bool fuse = tl && lanes && !e->no_fuse;
                 const int gt = std::min((4 * LOB_TRACE_OCC / LOB_TRACE_WAVES) * e->n_cus, (nb + LOB_TRACE_WAVES - 1) / LOB_TRACE_WAVES);
                 const int sid = e->step_id;
                 if (tl && !fuse) {
@@ -1149,6 +1162,8 @@ int lob_get_counters(lob_engine* e, int64_t out[4]) {
 // Double Q carries two weight vectors: sync / delta buffers hold [theta | theta_b] back to back and
 // one all-reduce of 2M doubles exchanges both.
 static int delta_vectors(const lob_engine* e) { return e->P.algo == LOB_ALGO_DOUBLE_Q ? 2 : 1; }
+// R-learning: the shared average reward rho travels behind the weights as [rho - rho_sync, 1.0] (rho_delta_*_kernel)
+static int delta_extra(const lob_engine* e) { return e->P.r_learn ? 2 : 0; }
 
 int lob_delta_init(lob_engine* e) {
     if (!e) return LOB_EINVAL;
@@ -1157,12 +1172,13 @@ int lob_delta_init(lob_engine* e) {
     const size_t M = (size_t)e->P.M;
     const int nv = delta_vectors(e);
     if (!e->S.theta_sync) {
-        int rc = dev_alloc(e, &e->S.theta_sync, M * nv);
-        if (rc == LOB_OK) rc = dev_alloc(e, &e->S.delta, M * nv);
+        int rc = dev_alloc(e, &e->S.theta_sync, M * nv + delta_extra(e));
+        if (rc == LOB_OK) rc = dev_alloc(e, &e->S.delta, M * nv + delta_extra(e));
         if (rc != LOB_OK) return rc;
     }
     HIPCHK(hipMemcpyAsync(e->S.theta_sync, e->S.theta, M * 8, hipMemcpyDeviceToDevice, e->stream));
     if (nv == 2) HIPCHK(hipMemcpyAsync(e->S.theta_sync + M, e->S.theta_b, M * 8, hipMemcpyDeviceToDevice, e->stream));
+    if (delta_extra(e)) HIPCHK(hipMemcpyAsync(e->S.theta_sync + M * nv, e->S.rho, 8, hipMemcpyDeviceToDevice, e->stream));
     return LOB_OK;
 }
 int lob_delta_begin_async(lob_engine* e, double** dev_delta, int64_t* count) {
@@ -1176,9 +1192,11 @@ int lob_delta_begin_async(lob_engine* e, double** dev_delta, int64_t* count) {
         hipLaunchKernelGGL(delta_begin_kernel, dim3(2048), dim3(256), 0, e->stream, (const f64*)(v ? e->S.theta_b : e->S.theta),
                            (const f64*)(e->S.theta_sync + v * M), e->S.delta + v * M, e->P.M);
     }
+    if (delta_extra(e))
+        hipLaunchKernelGGL(rho_delta_begin_kernel, dim3(1), dim3(1), 0, e->stream, (const f64*)e->S.rho, (const f64*)(e->S.theta_sync + M * nv), e->S.delta + M * nv);
     HIPCHK(hipGetLastError());
     *dev_delta = e->S.delta;
-    *count = (int64_t)(M * nv);
+    *count = (int64_t)(M * nv + delta_extra(e));
     return LOB_OK;
 }
 int lob_delta_begin(lob_engine* e, double** dev_delta, int64_t* count) {
@@ -1201,6 +1219,8 @@ int lob_delta_apply(lob_engine* e) {
                            (const f64*)(e->S.delta + v * M), v ? e->S.theta_b_nz : e->S.theta_nz, e->S.nz_epoch, e->P.M,
                            (v == 0 && e->P.memo) ? e->S.theta_nzx : (uint32_t*)nullptr, e->S.theta_nzc, e->P.cshift);
     }
+    if (delta_extra(e))
+        hipLaunchKernelGGL(rho_delta_apply_kernel, dim3(1), dim3(1), 0, e->stream, e->S.rho, e->S.theta_sync + M * nv, (const f64*)(e->S.delta + M * nv));
     if (e->P.memo) launch_memo(e, e->last_par, 1);  // the current triples under the exchanged weights
     HIPCHK(hipGetLastError());
     return LOB_OK;

@@ -1153,8 +1153,10 @@ __global__ void __launch_bounds__(LOB_BLOCK) rho_kernel(DevParams P, DevState S,
         }
         const f64 Q = (h.stepped == 2 ? S.qs_last_b : S.qs_last)[(size_t)b * LOB_N_ACTIONS + h.action];
         const f64 nQ = Q + h.upd;
-        if (lane == 0 && nQ - mQ < 1e-7)
+        if (lane == 0 && nQ - mQ < 1e-7) {
             __hip_atomic_fetch_add(&S.rho_inc[ri], P.beta * (h.reward - rho + mQ - nQ), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            atomicAdd(&S.rho_cnt[ri], 1);
+        }
         return;
     }
     Rng g{P.seed, P.book_id_offset + (u64)b, h.rng_ctr};
@@ -1163,14 +1165,34 @@ __global__ void __launch_bounds__(LOB_BLOCK) rho_kernel(DevParams P, DevState S,
     const f64 nQ = S.qs_last[(size_t)b * LOB_N_ACTIONS + h.action] + h.upd;
     if (lane == 0) {
         S.hdr[b].rng_ctr = g.ctr;
-        if (nQ - mq_from < 1e-7) __hip_atomic_fetch_add(&S.rho_inc[ri], P.beta * (h.reward - rho + S.rl_t[b] - nQ), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (nQ - mq_from < 1e-7) {
+            __hip_atomic_fetch_add(&S.rho_inc[ri], P.beta * (h.reward - rho + S.rl_t[b] - nQ), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            atomicAdd(&S.rho_cnt[ri], 1);
+        }
     }
 }
+// rho_{t+1} = rho_t + the MEAN of the step's increments: the reference's shared Agent applies them one after the other
+// (each relative to the rho the one before left: a contraction), which a sum of n increments all relative to rho_t is
+// not -- beta * n > 2 diverges.  One contributor (one book, or private weights): the increment itself, bit for bit.
 __global__ void rho_fold_kernel(DevState S, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    S.rho[i] += S.rho_inc[i];
+    const int c = S.rho_cnt[i];
+    if (c > 0) S.rho[i] += S.rho_inc[i] / (f64)c;
     S.rho_inc[i] = 0.0;
+    S.rho_cnt[i] = 0;
+}
+// Multi-GPU exchange of the shared rho (two extra slots behind the weights' delta: [rho - rho_sync, 1.0]; the all-reduce
+// sums both, so the second is the number of ranks and rho <- rho_sync + mean of the ranks' changes)
+__global__ void rho_delta_begin_kernel(const f64* rho, const f64* sync_slot, f64* delta_slots) {
+    delta_slots[0] = rho[0] - sync_slot[0];
+    delta_slots[1] = 1.0;
+}
+__global__ void rho_delta_apply_kernel(f64* rho, f64* sync_slot, const f64* delta_slots) {
+    const f64 n = delta_slots[1];
+    const f64 r = sync_slot[0] + (n > 0.0 ? delta_slots[0] / n : 0.0);
+    rho[0] = r;
+    sync_slot[0] = r;
 }
 
 // ---- combined update (shared theta) --------------------------------------------------------------

@@ -286,6 +286,7 @@ struct DevState {
     // and per book the bootstrap value the TD error used (maxQ(to_state) / Q(to_state, a')), which the rho update needs again
     f64* rho;
     f64* rho_inc;
+    i32* rho_cnt;     // books that contributed to rho_inc this step
     f64* rl_t;        // [B]
     f64* theta_sync;  // [M] (multi-GPU) or null
     f64* delta;       // [M] scratch for the all-reduce or null

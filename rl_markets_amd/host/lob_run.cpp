@@ -10,6 +10,7 @@
 //            reference's N training threads on one shared Agent (src/main.cpp:196-206)
 //           [--md depth.csv --tas trades.csv | --lobster orderbook.csv message.csv LEVELS]   (a recorded day, replayed
 //            by every book from evenly spread starting records; default: synthetic streams)
+#include <signal.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
@@ -26,12 +27,19 @@ int main(int argc, char** argv) {
     int gpus = 1;
     for (int i = 1; i + 1 < argc; i++)
         if (!strcmp(argv[i], "--gpus")) gpus = atoi(argv[i + 1]);
+    // rendezvous token of the RCCL communicator: a file in a private (0700) directory of this run
+    char rdir[] = "/tmp/lob_run_XXXXXX";
+    if (!mkdtemp(rdir)) { perror("mkdtemp"); return 2; }
     char rdzv[128];
-    snprintf(rdzv, sizeof rdzv, "/tmp/lob_run_rdzv_%d", (int)getpid());
-    unlink(rdzv);
+    snprintf(rdzv, sizeof rdzv, "%s/rdzv", rdir);
     // LOB_FORCE_DIST=1: the whole exchange path with a one-rank communicator (a 1-GPU box can run it)
     const char* fd = getenv("LOB_FORCE_DIST");
-    if (gpus <= 1) return run(argc, argv, 0, 1, (fd && fd[0] == '1') ? rdzv : "");
+    if (gpus <= 1) {
+        const int rc1 = run(argc, argv, 0, 1, (fd && fd[0] == '1') ? rdzv : "");
+        unlink(rdzv);
+        rmdir(rdir);
+        return rc1;
+    }
     // one process per GPU, forked before anything touches the HIP runtime
     std::vector<pid_t> kids;
     for (int r = 0; r < gpus; r++) {
@@ -40,14 +48,27 @@ int main(int argc, char** argv) {
         if (pid == 0) _exit(run(argc, argv, r, gpus, rdzv));
         kids.push_back(pid);
     }
+    // wait for whichever rank ends first: when one fails (no device, no data, an exception) the others would sit in
+    // ncclCommInitRank or the next all-reduce for ever -- stop exactly the processes forked above
     int rc = 0;
-    for (pid_t k : kids) {
+    size_t left = kids.size();
+    while (left > 0) {
         int st = 0;
-        waitpid(k, &st, 0);
+        const pid_t k = waitpid(-1, &st, 0);
+        if (k < 0) break;
+        bool ours = false;
+        for (pid_t& q : kids) if (q == k) { q = -1; ours = true; }
+        if (!ours) continue;
+        left--;
         const int code = WIFEXITED(st) ? WEXITSTATUS(st) : 2;
-        if (code && !rc) rc = code;
+        if (code && !rc) {
+            rc = code;
+            fprintf(stderr, "[lob_run] a rank exited with %d: stopping the other ranks\n", code);
+            for (pid_t q : kids) if (q > 0) kill(q, SIGTERM);
+        }
     }
     unlink(rdzv);
+    rmdir(rdir);
     return rc;
 }
 

@@ -8,6 +8,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# the oracle's read phase spreads the books of a big batch over the host's cores (oracle/lob_oracle.cpp oracle_td_step;
+# results do not depend on the thread count) -- read once, when liblob_oracle.so runs its first step
+os.environ.setdefault("ORACLE_THREADS", str(max(1, min(32, (os.cpu_count() or 1)))))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
 

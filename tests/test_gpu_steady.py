@@ -1,0 +1,179 @@
+"""The kernels bench.py TIMES, against the oracle, in the states a long run actually reaches.
+
+tests/test_gpu_parity.py follows the headline configuration for a dozen steps from a reset; the
+instantiations the bench spends its time in (env_kernel<64, 2, 1> with the fused action selection,
+learn_q_pair_kernel / learn_q_lane_kernel, trace_fast_kernel<., 2>, the memo pair, the hit lists)
+only reach their steady state later: long hit lists, several live trace generations, written-weights
+maps filling up, lists voided by a weight exchange, a second episode.  Here they are compared with
+the oracle step by step through exactly that (reference: Learner::_step / Runner::RunEpisode,
+src/experiment/serial.cpp:18-34,53-70).  The oracle's read phase runs on the host's cores
+(ORACLE_THREADS, tests/conftest.py); the engine is the thing checked."""
+import os
+
+import numpy as np
+import pytest
+
+from rl_markets_amd import abi, engine
+from tests import oracle_lib as ol
+from tests.parity import compare_learner_step
+from tests.test_gpu_fuzz import random_case
+
+pytestmark = pytest.mark.gpu
+
+
+def light_books(eng):
+    """Books whose action came from the hit-list replay so far (lob_debug_light, a diagnostic export)."""
+    import ctypes
+    out = (ctypes.c_int64 * 2)()
+    eng.lib.lob_debug_light.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)]
+    assert eng.lib.lob_debug_light(eng.h, out) == 0
+    return int(out[0])
+
+
+def make(B, algo, n_events, mem=20000000, depth=10, **over):
+    p = engine.default_params()
+    p.depth, p.max_trades = depth, 2
+    p.algo, p.theta_mode, p.memory_size = algo, abi.THETA_SHARED, mem
+    for k, v in over.items():
+        setattr(p, k, v)
+    g = engine.default_gen_params()
+    g.n_events = n_events
+    rec = engine.gen_stream_host(g, depth, 2, 0, B)
+    eng = engine.Engine(p, B)
+    eng.load_events(rec)
+    orc = ol.Oracle(p, rec)
+    return p, eng, orc
+
+
+@pytest.mark.parametrize("algo", [abi.ALGO_QLAMBDA, abi.ALGO_SARSA], ids=["qlambda", "sarsa"])
+def test_steady_state_at_the_dispatch_threshold_across_an_exchange(algo, tmp_path):
+    """32 768 books (the smallest batch that takes the lane-per-book learner kernels and the fused
+    env kernel by itself -- no switches), D = 10, M = 20 M, one shared weight vector, 70 steps against
+    the oracle; after step 64 a one-rank lob_theta_allreduce (RCCL in place on the engine's buffer:
+    theta must not change, but every hit list is voided and every memo record re-stamped, so step 65 runs
+    act_fast_kernel and the wave-per-book trace kernel and steps 66+ are back on the light path); then
+    ClearInventory / HandleTerminal / Initialise and 4 steps of a second episode."""
+    from rl_markets_amd.comm import RcclComm
+    from rl_markets_amd.parallel import EngineBackend
+    B = 32768
+    p, eng, orc = make(B, algo, n_events=330)
+    comm = RcclComm(str(tmp_path / "rdzv"), 0, 1, 0)
+    eng.delta_init()
+    eng.reset()
+    orc.reset()
+    light0 = light_books(eng)
+    for step in range(70):
+        eng.td_step(1)
+        orc.td_step(1)
+        # every step around the start and the exchange, every 4th in between (a comparison moves 40 MB of dumps)
+        if step < 4 or step % 4 == 3 or 60 <= step:
+            compare_learner_step(eng, orc, "steady %d step %d" % (algo, step), exact=False, rtol=1e-9)
+        if step == 63:
+            before = eng.theta()
+            comm.sync_weights(EngineBackend(eng))
+            eng.sync()
+            np.testing.assert_array_equal(eng.theta(), before)
+    # the light path really was the one running: from step 3 on every live book's action comes from its hit list
+    # (minus the step after the exchange)
+    assert light_books(eng) - light0 > 60 * B * 0.9
+    th, oth = eng.theta(), orc.theta()
+    assert np.array_equal(th != 0, oth != 0) and np.count_nonzero(th) > 50000
+    np.testing.assert_allclose(th, oth, rtol=1e-9, atol=1e-12)
+    eng.clear_inventory(); orc.clear_inventory()
+    eng.handle_terminal(); orc.handle_terminal()
+    eng.reset(); orc.reset()
+    for step in range(4):
+        eng.td_step(1)
+        orc.td_step(1)
+        compare_learner_step(eng, orc, "steady %d episode 2 step %d" % (algo, step), exact=False, rtol=1e-9)
+    np.testing.assert_allclose(eng.theta(), orc.theta(), rtol=1e-9, atol=1e-12)
+    comm.close()
+    eng.close()
+    orc.close()
+
+
+@pytest.mark.parametrize("algo", [abi.ALGO_QLAMBDA, abi.ALGO_SARSA], ids=["qlambda", "sarsa"])
+def test_lane_learner_kernel_for_large_tables(algo):
+    """learn_q_lane_kernel (one lane per book) is what tables of 2^27 weights and more take -- the pair kernel's
+    LDS rows hold tile indices in 27 bits.  M = 2^27 + 1, 32 768 books, against the oracle."""
+    B = 32768
+    p, eng, orc = make(B, algo, n_events=160, mem=(1 << 27) + 1)
+    eng.reset()
+    orc.reset()
+    for step in range(10):
+        eng.td_step(1)
+        orc.td_step(1)
+        if step < 3 or step >= 7:
+            compare_learner_step(eng, orc, "lane %d step %d" % (algo, step), exact=False, rtol=1e-9)
+    np.testing.assert_allclose(eng.theta(), orc.theta(), rtol=1e-9, atol=1e-12)
+    eng.close()
+    orc.close()
+
+
+def test_reset_then_weight_load_then_steps(monkeypatch):
+    """lob_reset -> lob_theta_set -> lob_td_step: the weight load re-evaluates the memo records of the slots on the
+    current list, which after a reset must be EMPTY -- slots of the episode before would be re-stamped as holding
+    valid tiles for triples whose hashes the reset has wiped.  Engine against the oracle through that
+    sequence, small table so that slots are reused by different triples."""
+    B = 300
+    p, eng, orc = make(B, abi.ALGO_QLAMBDA, n_events=260, mem=1 << 12, depth=5, epsilon=0.5)
+    eng.reset(); orc.reset()
+    for step in range(30):
+        eng.td_step(1); orc.td_step(1)
+    compare_learner_step(eng, orc, "episode 1", exact=False, rtol=1e-9)
+    eng.clear_inventory(); orc.clear_inventory()
+    eng.handle_terminal(); orc.handle_terminal()
+    eng.reset(); orc.reset()
+    th = orc.theta().copy()
+    rng = np.random.default_rng(5)
+    th[rng.integers(0, th.size, size=200)] += 1e-3
+    eng.set_theta(th)
+    orc.theta()[:] = th
+    for step in range(30):
+        eng.td_step(1); orc.td_step(1)
+        compare_learner_step(eng, orc, "after reset + load, step %d" % step, exact=False, rtol=1e-9)
+    np.testing.assert_allclose(eng.theta(), orc.theta(), rtol=1e-9, atol=1e-12)
+    eng.close()
+    orc.close()
+
+
+# ---- the randomised configuration sweep with the timed kernels forced on ------------------------------------
+VARIANTS = {
+    "lane": {"LOB_Q_LANES": "1", "LOB_Q_PAIR": "0", "LOB_FUSE_ACT": "1"},
+    "pair": {"LOB_Q_LANES": "1", "LOB_Q_PAIR": "1", "LOB_FUSE_ACT": "1"},
+    "pair_nofuse": {"LOB_Q_LANES": "1", "LOB_Q_PAIR": "1", "LOB_NO_FUSE": "1", "LOB_FUSE_ACT": "1"},
+}
+
+
+@pytest.mark.parametrize("variant", sorted(VARIANTS))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("LOB_FUZZ_SEEDS", "32")) // 2))
+def test_random_configuration_timed_kernels(monkeypatch, seed, variant):
+    """tests/test_gpu_fuzz.py's random configurations (depth, trade slots, state-variable sets, rewards, bounds,
+    look-backs, table sizes, learning constants, stream statistics), restricted to what the fast path serves
+    (shared theta, SARSA(lambda) / Q(lambda)) and with the kernels of the timed run forced on for batches that
+    would not select them by size: the lane-per-book learner kernels (one or two lanes per book, with and without
+    the fused trace step) and the action selection inside env_kernel.  Two episodes of 70 steps, every step
+    against the oracle."""
+    for k, v in VARIANTS[variant].items():
+        monkeypatch.setenv(k, v)
+    p, g, _ = random_case(9000 + seed)
+    r = np.random.default_rng(77 + seed)
+    p.theta_mode = abi.THETA_SHARED
+    p.algo = int(r.choice([abi.ALGO_SARSA, abi.ALGO_QLAMBDA]))
+    B = int(r.choice([3, 64, 130, 300]))
+    rec = engine.gen_stream_host(g, p.depth, p.max_trades, p.book_id_offset, B)
+    eng = engine.Engine(p, B)
+    eng.load_events(rec)
+    orc = ol.Oracle(p, rec)
+    for episode in range(2):
+        eng.reset()
+        orc.reset()
+        for step in range(70):
+            eng.td_step(1)
+            orc.td_step(1)
+            compare_learner_step(eng, orc, "%s seed %d episode %d step %d" % (variant, seed, episode, step), exact=False, rtol=1e-9)
+        eng.clear_inventory(); orc.clear_inventory()
+        eng.handle_terminal(); orc.handle_terminal()
+    np.testing.assert_allclose(eng.theta(), orc.theta(), rtol=1e-9, atol=1e-12)
+    eng.close()
+    orc.close()
