@@ -110,6 +110,7 @@ struct EnvCtx {
     __device__ const uint32_t* row(int i) const { return rows + (size_t)i * (size_t)P.Wd; }
     __device__ const Track& track(int k) const { return S.track[(size_t)b * (size_t)S.track_len + (size_t)(k & S.track_mask)]; }
     __device__ const TrackHead& track_head(int k) const { return *reinterpret_cast<const TrackHead*>(&track(k)); }
+    __device__ const TrackHead64& track_head64(int k) const { return *reinterpret_cast<const TrackHead64*>(&track(k)); }
     __device__ Track& track_w(int k) const { return S.track[(size_t)b * (size_t)S.track_len + (size_t)(k & S.track_mask)]; }
 };
 
@@ -1025,6 +1026,233 @@ __device__ inline bool perform_action(const EnvCtx& c, EnvR& e, int action, Trac
     return true;
 }
 
+// ---- the event pass again, for streams with at most two trade slots per record (TM == 2): "pass_fast" -----------
+// Same arithmetic, statement for statement, as next_state + step_event above -- AskBook / BidBook::ApplyTransactions,
+// Book::UpdateOrder, BookUtils::HandleAdverseSelection, RiskManager::Update / CheckOrders and the loop body of
+// Base::performAction (base.cpp:285-305) -- written for the latency of ONE pass, which is what bounds env_kernel (a
+// wave runs until its unluckiest book's midprice has moved, and each pass was ~20 000 clocks of dependent work):
+//  * the book's hot scalars (`EnvR h`, a register copy of the LDS slot) stay in registers across the loop;
+//  * the merged trade list and the touch after the event come with the track entry (TrackHead64, written by the
+//    pre-pass: they do not depend on the agent), so a pass reads nothing of the record stream but the level arrays
+//    of the rows it applies -- and those are requested ONE PASS AHEAD (an event's first row is the record after the
+//    previous event's last), like the track entry itself: a pass waits for no memory at all;
+//  * the order prices are fixed inside a step, so their 1e-4 keys are computed once (ka, kb);
+//  * the two sides are straight-line select form instead of nested divergent branches (only the pro-rata
+//    cancellation, with its two IEEE divisions, stays behind a branch).
+// Anything else (a step that starts without freshly placed orders, the end of the stream) takes the general pass.
+// the fields of EnvR an event pass can write (everything else of the register copy is dead after the loop)
+#define LOB_ENV_PASS_FIELDS(X) \
+    X(k) X(time_ms) X(rec_cur) X(rec_last) X(pf) X(mid) X(mid_prev) X(position) X(lo_vol_step) X(pnl_step) X(momentum_pnl_step) \
+    X(ep_pnl) X(events) X(a_ntr) X(a_on) X(a_oqh) X(a_oqt) X(a_oex) X(b_ntr) X(b_on) X(b_oqh) X(b_oqt) X(b_oex)
+struct FastKeys {
+    f64 ka, kb;  // key4 of the two order prices
+};
+// Order::doTransaction (order.cpp:84-107) under a predicate; returns the volume executed
+__device__ inline i64 tx_sel(bool act, i64 size, i64& qh, i64& ex, i64 volume) {
+    const i64 rem0 = size - ex > 0 ? size - ex : 0;
+    const i64 rv = volume - qh;
+    const bool pos = rv > 0;
+    const bool full = pos && rem0 <= rv;
+    const i64 n_ex = full ? size : (pos ? ex + rv : ex);
+    const i64 n_qh = pos ? 0 : qh - volume;
+    const i64 rem1 = size - n_ex > 0 ? size - n_ex : 0;
+    qh = act ? n_qh : qh;
+    ex = act ? n_ex : ex;
+    return act ? rem0 - rem1 : 0;
+}
+// Book::UpdateOrder (book.cpp:102-141) of one side for one applied row: `lv` / `v` = last_volume / volume at the order's price
+__device__ inline void update_order_sel(i32& on, i64 size, i64& qh, i64& qt, i64 ex, f64 k, i64 lv, i64 v, f64 tk0, f64 tk1, i64 tv0, i64 tv1) {
+    const bool dead = on && ex >= size;
+    on = dead ? 0 : on;
+    const bool act = on && lv != 0;
+    const i64 diff = lv - v;
+    i64 trade_vol = 0;
+    if (tv0 > 0 && tk0 == k) trade_vol = tv0;
+    if (tv1 > 0 && tk1 == k) trade_vol = tv1;
+    const i64 cancelled = diff - trade_vol;
+    const bool gone = act && v == 0;
+    const bool can = act && v != 0 && diff >= 0 && cancelled > 0;
+    const bool behind = act && v != 0 && diff < 0;
+    i64 nh = qh, nt = qt;
+    if (can) {  // Order::doCancellation (order.cpp:51-82)
+        if (qt == 0) {
+            nh = qh - cancelled;
+        } else {
+            const f64 total = (f64)(qh + qt);
+            nh = cvt_long_x86((f64)qh - ceil((f64)(cancelled * qh) / total));
+            nt = cvt_long_x86((f64)qt - floor((f64)(cancelled * qt) / total));
+        }
+        if (nh < 0) { nt = (i64)((u64)nt + (u64)nh); nh = 0; }
+        if (nt < 0) nt = 0;
+    }
+    nt = behind ? qt + diff : nt;  // quirk Q2: addVolumeBehind(negative)
+    qh = gone ? 0 : nh;
+    qt = gone ? 0 : nt;
+}
+// volume resting at the two order keys in one row
+__device__ inline void row_volumes_k(const EnvCtx& c, bool a_on, bool b_on, f64 ka, f64 kb, const RowFull& L, i64& a_v, i64& b_v) {
+    const int D = c.P.D;
+    uint32_t va = 0, vb = 0;
+    bool fa = false, fb = false;
+#pragma unroll
+    for (int l = 0; l < LOB_MAX_DEPTH; l++) {
+        const f32 pa = l < D ? __uint_as_float(L.apx[l]) : 0.0f;
+        const f32 pb = l < D ? __uint_as_float(L.bpx[l]) : 0.0f;
+        const bool ha = pa != 0.0f && key4((f64)pa) == ka;  // price keys are unique per side (lob_validate_stream)
+        const bool hb = pb != 0.0f && key4((f64)pb) == kb;
+        va = ha ? L.avol[l] : va; fa = fa || ha;
+        vb = hb ? L.bvol[l] : vb; fb = fb || hb;
+    }
+    a_v = (a_on && fa) ? (i64)(i32)va : 0;
+    b_v = (b_on && fb) ? (i64)(i32)vb : 0;
+}
+// one pass: 0 = another event follows, 1 = the step is complete.  `L` = the level arrays of row t.rec_first.
+__device__ inline int pass_fast(const EnvCtx& c, EnvR& h, StepAgg& g, const TrackHead64& t, RowFull& L, const FastKeys& K) {
+    const DevParams& P = c.P;
+    h.pnl_step = 0.0;
+    const f64 tp0 = (f64)t.tr_px[0], tp1 = (f64)t.tr_px[1];
+    const i64 tv0 = (t.info & 3) > 0 ? t.tr_vol[0] : 0, tv1 = (t.info & 3) > 1 ? t.tr_vol[1] : 0;
+    const f64 tk0 = key4(tp0), tk1 = key4(tp1);
+    h.pf = t.rec_first;
+    c.mark(22);
+    const f64 mp = h.mid;
+    i64 au_vol = 0; f64 au_proxy = 0.0, au_value = 0.0;
+    i64 bu_vol = 0; f64 bu_proxy = 0.0, bu_value = 0.0;
+    // AskBook::ApplyTransactions: a trade at or above the reference price runs through the ask order priced at or below it
+#define LOB_FP_ASK(TP, TV)                                                                                  \
+    {                                                                                                       \
+        const bool act = (TV) > 0 && !((TP) < mp) && h.a_on && h.a_opx <= (TP);                             \
+        const i64 exec = tx_sel(act, h.a_osz, h.a_oqh, h.a_oex, (TV));                                      \
+        au_vol -= exec;                                                                                     \
+        const f64 pr = au_proxy + (h.a_opx - mp) * (f64)exec, va = au_value + h.a_opx * (f64)exec;          \
+        au_proxy = act ? pr : au_proxy;                                                                     \
+        au_value = act ? va : au_value;                                                                     \
+        const bool done = act && h.a_oex >= h.a_osz;                                                        \
+        h.a_on = done ? 0 : h.a_on;                                                                         \
+        h.a_ntr += done ? 1 : 0;                                                                            \
+    }
+    // BidBook::ApplyTransactions: at or below it, through the bid order priced at or above
+#define LOB_FP_BID(TP, TV)                                                                                  \
+    {                                                                                                       \
+        const bool act = (TV) > 0 && !((TP) > mp) && h.b_on && h.b_opx >= (TP);                             \
+        const i64 exec = tx_sel(act, h.b_osz, h.b_oqh, h.b_oex, (TV));                                      \
+        bu_vol += exec;                                                                                     \
+        const f64 pr = bu_proxy + (mp - h.b_opx) * (f64)exec, va = bu_value - h.b_opx * (f64)exec;          \
+        bu_proxy = act ? pr : bu_proxy;                                                                     \
+        bu_value = act ? va : bu_value;                                                                     \
+        const bool done = act && h.b_oex >= h.b_osz;                                                        \
+        h.b_on = done ? 0 : h.b_on;                                                                         \
+        h.b_ntr += done ? 1 : 0;                                                                            \
+    }
+    LOB_FP_ASK(tp0, tv0) LOB_FP_ASK(tp1, tv1)   // ascending prices
+    LOB_FP_BID(tp1, tv1) LOB_FP_BID(tp0, tv0)   // descending
+#undef LOB_FP_ASK
+#undef LOB_FP_BID
+    c.mark(23);
+    // UpdateBookProfiles: StashState, then ApplyChanges (-> UpdateOrder) for every applied row
+    const int last_rec = h.rec_cur;
+    const i64 a_lv = g.cv_a, b_lv = g.cv_b;
+    for (int r = t.rec_first; r <= t.rec_last; r++) {
+        if (r != t.rec_first) row_full_load(c, r, L);
+        i64 a_v, b_v;
+        row_volumes_k(c, h.a_on != 0, h.b_on != 0, K.ka, K.kb, L, a_v, b_v);
+        update_order_sel(h.a_on, h.a_osz, h.a_oqh, h.a_oqt, h.a_oex, K.ka, a_lv, a_v, tk0, tk1, tv0, tv1);
+        update_order_sel(h.b_on, h.b_osz, h.b_oqh, h.b_oqt, h.b_oex, K.kb, b_lv, b_v, tk0, tk1, tv0, tv1);
+        g.cv_a = a_v;
+        g.cv_b = b_v;
+    }
+    c.mark(24);
+    h.rec_last = last_rec;
+    h.rec_cur = t.rec_last;
+    h.mid_prev = h.mid;
+    h.mid = t.mid;
+    h.time_ms = t.time_ms;
+    h.events += (i64)(t.rec_last - t.rec_first + 1);
+    h.k++;
+    // BookUtils::HandleAdverseSelection (book.cpp:551-592) against the touch of the new snapshot
+    i64 ad_vol = 0; f64 ad_proxy = 0.0, ad_value = 0.0;
+    {
+        const f64 bap = (f64)t.bap, bbp = (f64)t.bbp, rp = h.mid_prev;
+        const bool ha = h.a_on && h.a_opx <= bbp;
+        {
+            const i64 rem = h.a_osz - h.a_oex > 0 ? h.a_osz - h.a_oex : 0;
+            const f64 pr = ad_proxy + (f64)rem * (h.a_opx - rp), va = ad_value + (f64)rem * h.a_opx;
+            ad_vol -= ha ? rem : 0;
+            ad_proxy = ha ? pr : ad_proxy;
+            ad_value = ha ? va : ad_value;
+            h.a_on = ha ? 0 : h.a_on;
+            h.a_ntr += ha ? 1 : 0;
+        }
+        const bool hb = h.b_on && h.b_opx >= bap;
+        {
+            const i64 rem = h.b_osz - h.b_oex > 0 ? h.b_osz - h.b_oex : 0;
+            const f64 pr = ad_proxy + (f64)rem * (rp - h.b_opx), va = ad_value - (f64)rem * h.b_opx;
+            ad_vol += hb ? rem : 0;
+            ad_proxy = hb ? pr : ad_proxy;
+            ad_value = hb ? va : ad_value;
+            h.b_on = hb ? 0 : h.b_on;
+            h.b_ntr += hb ? 1 : 0;
+        }
+    }
+    h.pnl_step += au_proxy + bu_proxy + ad_proxy;
+    h.lo_vol_step += (i32)(bu_vol - au_vol + (ad_vol < 0 ? -ad_vol : ad_vol));
+    h.ep_pnl += au_value + bu_value + ad_value;
+    h.position += bu_vol + au_vol + ad_vol;  // RiskManager::Update
+    check_orders(P, h);
+    c.mark(25);
+    // the rest of the loop body of Base::performAction
+    const f64 mpm = h.mid - h.mid_prev;
+    h.pnl_step += (f64)h.position * mpm;
+    h.momentum_pnl_step += (f64)h.position * mpm;
+    g.r += get_reward(c, h);
+    g.pnl += h.pnl_step;
+    g.mpm += mpm;
+    c.mark(26);
+    c.mark(31);
+    return (is_open(P, h.time_ms) && fabs(g.mpm) < 1e-5) ? 0 : 1;
+}
+// perform_action with the fast pass.  `first` = the level arrays of record e.rec_cur + 1 (the first row of the step's first
+// event), requested by the caller together with `cur`.
+__device__ inline bool perform_action_fast(const EnvCtx& c, EnvR& e, int action, TrackHead64 t, const RowFull& cur, RowFull L) {
+    StepAgg g;
+    step_prologue(c, e, action, g, cur);
+    EnvR h = e;  // registers from here to the end of the loop
+    const FastKeys K{key4(h.a_opx), key4(h.b_opx)};
+    const int last_row = c.S.n_events - 1;
+    int st;
+    do {
+        const TrackHead64 tn = c.track_head64(h.k + 1);
+        // the fast pass needs: the event inside the track, freshly placed orders behind it, its trade list whole, and the row
+        // it was handed (a step's first row is the record after the current snapshot -- anything else is reloaded)
+        const bool fast = h.k < g.n_track && g.cv_valid && (t.info & LOB_TRK_TRADES_OK);
+        if (fast) {
+            if (t.rec_first != h.rec_cur + 1) row_full_load(c, t.rec_first, L);
+            RowFull Ln;  // next pass's first row, in flight during this one
+            { const int rn = t.rec_last + 1; row_full_load(c, rn < last_row ? rn : last_row, Ln); }
+            st = pass_fast(c, h, g, t, L, K);
+            L = Ln;
+        } else {
+#define X(n) e.n = h.n;
+            LOB_ENV_PASS_FIELDS(X)
+#undef X
+            TrackHead t32;
+            t32.rec_first = t.rec_first; t32.rec_last = t.rec_last; t32.time_ms = t.time_ms; t32.tick_ap0 = t.tick_ap0;
+            t32.tick_bp0 = t.tick_bp0; t32.info = t.info; t32.mid = t.mid;
+            st = step_event<2>(c, e, g, t32);
+            h = e;
+            if (st == 0) row_full_load(c, h.rec_cur + 1 < last_row ? h.rec_cur + 1 : last_row, L);
+        }
+        t = tn;
+    } while (st == 0);
+#define X(n) e.n = h.n;
+    LOB_ENV_PASS_FIELDS(X)
+#undef X
+    e.done = h.done;  // (the general pass sets it when the stream runs dry)
+    if (st == 2) return false;
+    step_epilogue(c, e, g);
+    return true;
+}
+
 // Intraday::getVariable (intraday.cpp:316-409): market variables come from the
 // track entry of the last completed event, agent variables are computed here.
 // `t` = state_track(c, e), fetched ONCE by the caller (by value: six 16-byte loads in flight) rather
@@ -1321,7 +1549,16 @@ __device__ inline void prepass_run(const EnvCtx& c, PrepState& st, BookMeta& M, 
         if (write_track) {
             Track t;
             t.rec_first = first; t.rec_last = m.rec_cur; t.time_ms = m.time_ms;
-            t.tick_ap0 = tick_ap0; t.tick_bp0 = tick_bp0; t._pad = 0;
+            t.tick_ap0 = tick_ap0; t.tick_bp0 = tick_bp0;
+            {   // the event's merged trade list (entries are packed at the front, ascending key) and the touch it leaves behind
+                int ntr = 0;
+#pragma unroll
+                for (int i = 0; i < TM; i++) ntr += (i < P.T && tv[i] > 0) ? 1 : 0;
+                t.info = (ntr < 2 ? ntr : 2) | (ntr <= 2 ? LOB_TRK_TRADES_OK : 0);
+                t.tr_px[0] = (f32)tp[0]; t.tr_vol[0] = tv[0];
+                t.tr_px[1] = TM > 1 ? (f32)tp[TM > 1 ? 1 : 0] : 0.0f; t.tr_vol[1] = TM > 1 ? tv[TM > 1 ? 1 : 0] : 0;
+                t.bap = (f32)m.ap0; t.bbp = (f32)m.bp0;
+            }
             t.mid = mid; t.tp_val = m.tp_val; t.spread_mean = w_spr.mean;
             t.a_tv = m.a_tv; t.b_tv = m.b_tv;
             // Intraday::getVariable (intraday.cpp:316-409), the stream-only variables

@@ -36,6 +36,11 @@ __device__ inline void stage_ticks(const DevParams& P, TickLds& t) {
 }
 
 #define LOB_TRACK_MARGIN 4
+// the lean event pass of env_kernel for streams with at most two trade slots per record (lob_env.h pass_fast);
+// -DLOB_FAST_PASS=0 builds the general pass everywhere (A/B runs, tools/exp_variants.sh)
+#ifndef LOB_FAST_PASS
+#define LOB_FAST_PASS 1
+#endif
 #include "lob_env.h"
 #include "lob_learn.h"
 
@@ -287,15 +292,25 @@ __global__ void __launch_bounds__(LOB_ENV_BLOCK) env_kernel(const DevParams* __r
         if (go) {
             EnvCtx c(P, S, b, &tick_lds);
             c.prof_start(S.prof, threadIdx.x & 63);
-            // the first event's track entry and the current snapshot are requested before the bulk of the state
-            const TrackHead t0 = c.track_head(k0);
+            // the first event's track entry, the current snapshot and (fast pass) the first row the step will apply are
+            // requested before the bulk of the state
+            const TrackHead64 t0 = c.track_head64(k0);
             RowFull cur;
             row_full_load(c, rc0, cur);
+            RowFull first;
+            if (LOB_FAST_PASS && TM == 2) row_full_load(c, rc0 + 1 < S.n_events - 1 ? rc0 + 1 : S.n_events - 1, first);
             EnvR& e = lds_env[threadIdx.x].e;
             env_load(S, b, e);
             c.mark(20);  // agent scalars in
             i64 ev0 = e.events;
-            bool ok = perform_action<TM>(c, e, action, t0, cur);
+            bool ok;
+            if (LOB_FAST_PASS && TM == 2) ok = perform_action_fast(c, e, action, t0, cur, first);
+            else {
+                TrackHead t32;
+                t32.rec_first = t0.rec_first; t32.rec_last = t0.rec_last; t32.time_ms = t0.time_ms; t32.tick_ap0 = t0.tick_ap0;
+                t32.tick_bp0 = t0.tick_bp0; t32.info = t0.info; t32.mid = t0.mid;
+                ok = perform_action<TM>(c, e, action, t32, cur);
+            }
             d_events = e.events - ev0;
             bool claim = false;
             u64 claim_k = 0;

@@ -71,28 +71,45 @@ typedef float f32;
     X(i32, b_ntr) X(i32, b_on) X(f64, b_opx) X(i64, b_osz) X(i64, b_oqh) X(i64, b_oqt) X(i64, b_oex) X(i64, b_oiq) X(i32, b_otk)
 
 // One entry per NextState event of a book: the agent-independent outcome of
-// Intraday::NextState (intraday.cpp:225-272) when started at record rec_first.
+// Intraday::NextState (intraday.cpp:225-272) when started at record rec_first.  128 bytes; the first 64
+// (TrackHead64) are all an event pass of env_kernel reads: which rows the event applies, time, touch, midprice
+// and -- since they do not depend on the agent either -- the event's merged trade list (TimeAndSales::LoadUntil,
+// at most two price levels: streams with more trade slots per record keep reading the records' own slots) and
+// the best prices of the snapshot the event leaves behind (adverse selection); the rest feeds the quotes and the
+// state extraction after the step.
 struct __attribute__((aligned(16))) Track {
     i32 rec_first;  // record whose trade slots this event consumes (cursor at NextState entry)
     i32 rec_last;   // last depth record applied (the new current snapshot); rows rec_first..rec_last were applied
     i32 time_ms;
     i32 tick_ap0;   // ToTicks(best ask), ToTicks(best bid) of the new snapshot
     i32 tick_bp0;
-    i32 _pad;
+    i32 info;       // bits 0-1: entries of the merged trade list held below; bit 2 (LOB_TRK_TRADES_OK): that is the whole list
     f64 mid;          // midprice of the new snapshot
+    f32 tr_px[2];     // merged trades of the event, ascending price key (the order of the reference's std::map)
+    f32 bap, bbp;     // best ask / bid price of the new snapshot
+    i64 tr_vol[2];
     f64 tp_val;       // TargetPrice::get() after the update
     f64 spread_mean;  // spread_window.mean()
     i64 a_tv, b_tv;   // cumulative total_volume_ (quirk Q1)
     f32 mv[8];        // spd, mpm, imb, svl, vol, rsi, vwap (Intraday::getVariable), [7] unused
 };
-// The first 32 bytes of a Track entry: all an event pass reads of it (the rest feeds the state extraction
-// after the step).
+#define LOB_TRK_TRADES_OK 4
+// The first 32 bytes of a Track entry: what the general event pass (next_state) reads of it.
 struct __attribute__((aligned(16))) TrackHead {
     i32 rec_first, rec_last, time_ms, tick_ap0;
-    i32 tick_bp0, _pad;
+    i32 tick_bp0, info;
     f64 mid;
 };
-static_assert(sizeof(TrackHead) == 32 && sizeof(Track) == 96, "TrackHead is a prefix of Track");
+// The first 64: the fast pass (pass_fast, lob_env.h).
+struct __attribute__((aligned(16))) TrackHead64 {
+    i32 rec_first, rec_last, time_ms, tick_ap0;
+    i32 tick_bp0, info;
+    f64 mid;
+    f32 tr_px[2];
+    f32 bap, bbp;
+    i64 tr_vol[2];
+};
+static_assert(sizeof(TrackHead) == 32 && sizeof(TrackHead64) == 64 && sizeof(Track) == 128, "TrackHead / TrackHead64 are prefixes of Track");
 #define LOB_MV_SPD 0
 #define LOB_MV_MPM 1
 #define LOB_MV_IMB 2

@@ -40,6 +40,32 @@ static void run(const char* tag, const int* n, int* out) {
     }
 }
 
+// ... and of the size of its kernel-argument segment (the engine's kernels take DevParams / DevState by value: 1-2.5 KB)
+template <int N> struct Big { int w[N / 4]; };
+template <int N>
+__global__ void __launch_bounds__(256) probe_arg(Big<N> a, const int* __restrict__ n, int* out) {
+    if ((int)(blockIdx.x * blockDim.x) >= *n) return;
+    out[blockIdx.x * 256 + threadIdx.x] = a.w[threadIdx.x % (N / 4)];
+}
+template <int N>
+static void run_arg(const int* n, int* out) {
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    Big<N> big{};
+    for (int grid : {1, 512}) {
+        const int reps = 200;
+        float best = 1e9;
+        for (int t = 0; t < 5; t++) {
+            hipEventRecord(a);
+            for (int i = 0; i < reps; i++) hipLaunchKernelGGL((probe_arg<N>), dim3(grid), dim3(256), 0, 0, big, n, out);
+            hipEventRecord(b); hipEventSynchronize(b);
+            float ms; hipEventElapsedTime(&ms, a, b);
+            if (ms < best) best = ms;
+        }
+        printf("kernarg %5d B               grid %5d : %.2f us per launch\n", N, grid, best * 1000.0f / reps);
+    }
+}
+
 int main() {
     int *n, *out;
     hipMalloc(&n, 4); hipMemset(n, 0, 4);
@@ -49,5 +75,9 @@ int main() {
     run<16000, 4>("lds 62.5 KB, few regs", n, out);
     run<0, 200>("lds 0 KB, ~200 vgprs", n, out);
     run<4096, 200>("lds 16 KB, ~200 vgprs", n, out);
+    run_arg<64>(n, out);
+    run_arg<1024>(n, out);
+    run_arg<2560>(n, out);
+    run_arg<4000>(n, out);
     return 0;
 }
