@@ -92,14 +92,24 @@ struct EnvCtx {
     const uint32_t* rows;  // this book's first record: its own stream, or its window of the replayed one
     const TickLds* tk;     // the venue's tick table (LDS)
 #ifdef LOB_PROF
-    // phase clocks of the lane-per-book kernels (tools/exp_prof.py): the first lane of a wave stamps for the wave
+    // phase clocks of the lane-per-book kernels (tools/exp_prof.py): the first lane of a wave stamps for the wave.  The phases are
+    // summed in registers and written once, at the end (a read-modify-write of the counters per stamp put a memory round trip
+    // into every phase it was meant to measure).
     mutable long long pt_ = 0;
+    mutable long long acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     mutable i64* prow_ = nullptr;
-    __device__ void prof_start(i64* prof, int lane) const { prow_ = (prof && lane == 0) ? prof + (size_t)b * LOB_PROF_N : nullptr; pt_ = clock64(); }
-    __device__ void mark(int i) const { const long long n = clock64(); if (prow_) prow_[i] += n - pt_; pt_ = n; }
+    __device__ void prof_start(i64* prof, int lane, long long t0 = 0) const { prow_ = (prof && lane == 0) ? prof + (size_t)b * LOB_PROF_N : nullptr; pt_ = t0 ? t0 : clock64(); }
+    __device__ void mark(int i) const { const long long n = clock64(); acc_[i - 20] += n - pt_; pt_ = n; }
+    __device__ void flush() const {
+        if (prow_) {
+#pragma unroll
+            for (int i = 0; i < 12; i++) prow_[20 + i] += acc_[i];
+        }
+    }
 #else
-    __device__ void prof_start(i64*, int) const {}
+    __device__ void prof_start(i64*, int, long long = 0) const {}
     __device__ void mark(int) const {}
+    __device__ void flush() const {}
 #endif
     __device__ EnvCtx(const DevParams& p, const DevState& s, int book, const TickLds* t) : P(p), S(s), b(book), tk(t) {
         const size_t first = s.rec_phase ? (size_t)s.rec_phase[book] : (size_t)book * (size_t)s.n_events;
@@ -1114,7 +1124,6 @@ __device__ inline int pass_fast(const EnvCtx& c, EnvR& h, StepAgg& g, const Trac
     const i64 tv0 = (t.info & 3) > 0 ? t.tr_vol[0] : 0, tv1 = (t.info & 3) > 1 ? t.tr_vol[1] : 0;
     const f64 tk0 = key4(tp0), tk1 = key4(tp1);
     h.pf = t.rec_first;
-    c.mark(22);
     const f64 mp = h.mid;
     i64 au_vol = 0; f64 au_proxy = 0.0, au_value = 0.0;
     i64 bu_vol = 0; f64 bu_proxy = 0.0, bu_value = 0.0;
@@ -1148,7 +1157,6 @@ __device__ inline int pass_fast(const EnvCtx& c, EnvR& h, StepAgg& g, const Trac
     LOB_FP_BID(tp1, tv1) LOB_FP_BID(tp0, tv0)   // descending
 #undef LOB_FP_ASK
 #undef LOB_FP_BID
-    c.mark(23);
     // UpdateBookProfiles: StashState, then ApplyChanges (-> UpdateOrder) for every applied row
     const int last_rec = h.rec_cur;
     const i64 a_lv = g.cv_a, b_lv = g.cv_b;
@@ -1161,7 +1169,6 @@ __device__ inline int pass_fast(const EnvCtx& c, EnvR& h, StepAgg& g, const Trac
         g.cv_a = a_v;
         g.cv_b = b_v;
     }
-    c.mark(24);
     h.rec_last = last_rec;
     h.rec_cur = t.rec_last;
     h.mid_prev = h.mid;
@@ -1199,7 +1206,6 @@ __device__ inline int pass_fast(const EnvCtx& c, EnvR& h, StepAgg& g, const Trac
     h.ep_pnl += au_value + bu_value + ad_value;
     h.position += bu_vol + au_vol + ad_vol;  // RiskManager::Update
     check_orders(P, h);
-    c.mark(25);
     // the rest of the loop body of Base::performAction
     const f64 mpm = h.mid - h.mid_prev;
     h.pnl_step += (f64)h.position * mpm;
@@ -1207,8 +1213,6 @@ __device__ inline int pass_fast(const EnvCtx& c, EnvR& h, StepAgg& g, const Trac
     g.r += get_reward(c, h);
     g.pnl += h.pnl_step;
     g.mpm += mpm;
-    c.mark(26);
-    c.mark(31);
     return (is_open(P, h.time_ms) && fabs(g.mpm) < 1e-5) ? 0 : 1;
 }
 // perform_action with the fast pass.  `first` = the level arrays of record e.rec_cur + 1 (the first row of the step's first
@@ -1218,6 +1222,7 @@ __device__ inline bool perform_action_fast(const EnvCtx& c, EnvR& e, int action,
     step_prologue(c, e, action, g, cur);
     EnvR h = e;  // registers from here to the end of the loop
     const FastKeys K{key4(h.a_opx), key4(h.b_opx)};
+    c.mark(22);  // hot copy
     const int last_row = c.S.n_events - 1;
     int st;
     do {
@@ -1229,8 +1234,10 @@ __device__ inline bool perform_action_fast(const EnvCtx& c, EnvR& e, int action,
             if (t.rec_first != h.rec_cur + 1) row_full_load(c, t.rec_first, L);
             RowFull Ln;  // next pass's first row, in flight during this one
             { const int rn = t.rec_last + 1; row_full_load(c, rn < last_row ? rn : last_row, Ln); }
+            c.mark(23);  // loop top: next entry / next row requested
             st = pass_fast(c, h, g, t, L, K);
             L = Ln;
+            c.mark(24);  // the pass itself
         } else {
 #define X(n) e.n = h.n;
             LOB_ENV_PASS_FIELDS(X)
@@ -1244,10 +1251,12 @@ __device__ inline bool perform_action_fast(const EnvCtx& c, EnvR& e, int action,
         }
         t = tn;
     } while (st == 0);
+    c.mark(25);  // waiting for the wave's slowest lane
 #define X(n) e.n = h.n;
     LOB_ENV_PASS_FIELDS(X)
 #undef X
     e.done = h.done;  // (the general pass sets it when the stream runs dry)
+    c.mark(26);  // hot copy back
     if (st == 2) return false;
     step_epilogue(c, e, g);
     return true;

@@ -273,6 +273,11 @@ __global__ void __launch_bounds__(LOB_ENV_BLOCK) env_kernel(const DevParams* __r
     const int n_here = MODE == 2 ? *F.list_n : nb;
     const int b = MODE == 2 ? (t < n_here ? F.list[t] : 0) : b0 + t;
     i64 d_steps = 0, d_events = 0;
+#ifdef LOB_PROF
+    const long long t_entry = clock64();
+#else
+    const long long t_entry = 0;
+#endif
     if (t < n_here) {
         const int k0 = S.k[b], rc0 = S.rec_cur[b];  // in flight together with the header
         LHdr& h = S.hdr[b];
@@ -291,7 +296,8 @@ __global__ void __launch_bounds__(LOB_ENV_BLOCK) env_kernel(const DevParams* __r
         }
         if (go) {
             EnvCtx c(P, S, b, &tick_lds);
-            c.prof_start(S.prof, threadIdx.x & 63);
+            c.prof_start(S.prof, threadIdx.x & 63, t_entry);
+            c.mark(30);  // action selection
             // the first event's track entry, the current snapshot and (fast pass) the first row the step will apply are
             // requested before the bulk of the state
             const TrackHead64 t0 = c.track_head64(k0);
@@ -353,6 +359,7 @@ __global__ void __launch_bounds__(LOB_ENV_BLOCK) env_kernel(const DevParams* __r
                 S.mk_slot[b] = mk_claim(S, claim_q0, claim_q1, claim_q2, step_id, par, claim_k, claim_stamp);
             }
             c.mark(29);  // agent scalars out, memo claim
+            c.flush();
         } else if (MODE != 1) {  // (MODE 1: act_light_book has set the header of a book that does not step, or left it to the work list)
             h.stepped = 0;
         }
