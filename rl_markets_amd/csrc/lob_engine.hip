@@ -14,6 +14,7 @@
 #include "lob_internal.h"
 #include "lob_fast.h"
 #include "lob_kernels.h"
+#include "lob_envstep.h"
 
 #define HIPCHK(expr)                                                                         \
     do {                                                                                     \
@@ -59,6 +60,7 @@ struct lob_engine {
     bool force_fuse_act = false;
     bool fuse_act = true;       // ... inside the env kernel (env_kernel<.., 1>; LOB_NO_FUSE_ACT=1: act_light_kernel as a launch of its own)
  bool t_light = true;        // trace_light_kernel in front of the wave-per-book trace kernel (Q(lambda); LOB_NO_TLIGHT=1: off)
+    bool env_step = true;       // env_step_kernel for the fused action selection + step (LOB_ENV_STEP=0: env_kernel<64, 2, 1>; A/B switch)
     bool no_fuse = false;       // LOB_NO_FUSE=1: the light trace step as a kernel of its own, not inside the lane learner kernel (A/B switch)
     bool q_pair = true;         // ... two lanes per book (learn_q_pair_kernel; LOB_Q_PAIR=0: one)
     int q_lanes = -1;           // learn_q_lane_kernel (a lane per book) instead of learn_q_fast_kernel (a wave per book): -1 by batch size,
@@ -268,6 +270,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     if (const char* g = getenv("LOB_NO_TLIGHT")) e->t_light = !(g[0] == '1');
     if (const char* g = getenv("LOB_Q_PAIR")) e->q_pair = !(g[0] == '0');
     if (const char* g = getenv("LOB_NO_FUSE")) e->no_fuse = g[0] == '1';
+    if (const char* g = getenv("LOB_ENV_STEP")) e->env_step = !(g[0] == '0');
     if (const char* g = getenv("LOB_RESET_LANES")) { int v = atoi(g); if (v == 16 || v == 32 || v == 64) e->reset_lanes = v; }
 
     // ---- DevParams ----
@@ -543,7 +546,7 @@ static int set_records(lob_engine* e, int32_t n_events, size_t n_rows) {
     if (e->records_dev) { hipFree(e->records_dev); e->records_dev = nullptr; }
     if (e->phase_dev) { hipFree(e->phase_dev); e->phase_dev = nullptr; }
     if (e->track_dev) { hipFree(e->track_dev); e->track_dev = nullptr; }
-    size_t bytes = n_rows * e->P.Wd * 4;
+    size_t bytes = n_rows * e->P.Wd * 4 + 256;  // (tail pad: drec_levels reads whole 16-byte quads past a short level array)
     hipError_t err = hipMalloc((void**)&e->records_dev, bytes);
     if (err != hipSuccess) { e->records_dev = nullptr; lob_set_error("hipMalloc(records) failed"); return LOB_ENOMEM; }
     // market track: resident (one entry per event) up to track_ring events per book, a ring of that many beyond
@@ -683,7 +686,9 @@ static void launch_env_fused(lob_engine* e, hipStream_t st, int par, int lpar, u
     const EnvFuse F1{nullptr, nullptr, lpar, sid - 1, ver}, F2{act_list, act_n, lpar, sid - 1, ver};
     {
         TimedLaunch t(e, "env_kernel", st);
-        if (t2) hipLaunchKernelGGL((env_kernel<64, 2, 1>), dim3((nb + 63) / 64), dim3(64), 0, st, Pd, e->S, (const i32*)nullptr, 1, 0, nb, sid, par, F1);
+        // (two trade slots per record: the same step with its memory round trips regrouped, lob_envstep.h; LOB_ENV_STEP=0: env_kernel<64, 2, 1>)
+        if (t2 && e->env_step) hipLaunchKernelGGL(env_step_kernel, dim3((nb + 63) / 64), dim3(64), 0, st, Pd, e->S, sid, par, F1);
+        else if (t2) hipLaunchKernelGGL((env_kernel<64, 2, 1>), dim3((nb + 63) / 64), dim3(64), 0, st, Pd, e->S, (const i32*)nullptr, 1, 0, nb, sid, par, F1);
         else hipLaunchKernelGGL((env_kernel<64, LOB_MAX_TRADES, 1>), dim3((nb + 63) / 64), dim3(64), 0, st, Pd, e->S, (const i32*)nullptr, 1, 0, nb, sid, par, F1);
     }
     {

@@ -64,17 +64,22 @@ LOB_HD void drec_from_abi(const uint32_t* src, int D, int T, uint32_t* dst) {
     }
 }
 #if defined(__HIPCC__)
-// One level array (16-byte aligned, D <= LOB_MAX_DEPTH words used) in ceil(D / 4) loads; entries >= D come back 0.
+// One level array (16-byte aligned, D <= LOB_MAX_DEPTH words used); entries >= D come back 0.  All (LOB_MAX_DEPTH + 3) / 4
+// 16-byte loads are issued unconditionally -- a load under a branch on D splits the batch of loads it belongs to (the
+// compiler waits for everything in flight at the join), and these kernels are chains of memory round trips.  For D <= 8 the
+// last quad lies in the next array of the record, after the last array in the trade slots / the next record: read and
+// masked out (the stream buffer is allocated with a tail pad, lob_engine.hip set_records).
 __device__ inline void drec_levels(const uint32_t* arr, int D, uint32_t* out) {
     const uint4* a4 = reinterpret_cast<const uint4*>(arr);
+    uint4 v[(LOB_MAX_DEPTH + 3) / 4];
+#pragma unroll
+    for (int q = 0; q < (LOB_MAX_DEPTH + 3) / 4; q++) v[q] = a4[q];
 #pragma unroll
     for (int q = 0; q < (LOB_MAX_DEPTH + 3) / 4; q++) {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (q * 4 < D) v = a4[q];  // wave-uniform
-        if (q * 4 + 0 < LOB_MAX_DEPTH) out[q * 4 + 0] = v.x;
-        if (q * 4 + 1 < LOB_MAX_DEPTH) out[q * 4 + 1] = v.y;
-        if (q * 4 + 2 < LOB_MAX_DEPTH) out[q * 4 + 2] = v.z;
-        if (q * 4 + 3 < LOB_MAX_DEPTH) out[q * 4 + 3] = v.w;
+        if (q * 4 + 0 < LOB_MAX_DEPTH) out[q * 4 + 0] = q * 4 + 0 < D ? v[q].x : 0u;
+        if (q * 4 + 1 < LOB_MAX_DEPTH) out[q * 4 + 1] = q * 4 + 1 < D ? v[q].y : 0u;
+        if (q * 4 + 2 < LOB_MAX_DEPTH) out[q * 4 + 2] = q * 4 + 2 < D ? v[q].z : 0u;
+        if (q * 4 + 3 < LOB_MAX_DEPTH) out[q * 4 + 3] = q * 4 + 3 < D ? v[q].w : 0u;
     }
 }
 #endif
@@ -91,6 +96,11 @@ struct EnvCtx {
     int b;
     const uint32_t* rows;  // this book's first record: its own stream, or its window of the replayed one
     const TickLds* tk;     // the venue's tick table (LDS)
+    // what the caller has fetched already, in the same round trip as the rest of the step's inputs (env_step_kernel): the
+    // track entry of event k - 1 at the start of the step (target price, spread mean, cumulative volumes: the quotes, the market
+    // order's guard) and BookMeta's n_track / complete.  Null / -1: looked up where needed.
+    const Track* pre_prev = nullptr;
+    int pre_n_track = -1, pre_complete = 0;
 #ifdef LOB_PROF
     // phase clocks of the lane-per-book kernels (tools/exp_prof.py): the first lane of a wave stamps for the wave.  The phases are
     // summed in registers and written once, at the end (a read-modify-write of the counters per stamp put a memory round trip
@@ -452,10 +462,10 @@ __device__ inline void row_full_load(const EnvCtx& c, int rec, RowFull& R) {
     drec_levels(r + drec_ask_vol(D, c.P.T), D, R.avol);
     drec_levels(r + drec_bid_px(D, c.P.T), D, R.bpx);
     drec_levels(r + drec_bid_vol(D, c.P.T), D, R.bvol);
-    if (rec < 0) {  // no snapshot: every price reads as "undefined" (0), like rec_price / book_volume
+    // no snapshot: every price reads as "undefined" (0), like rec_price / book_volume
+    const uint32_t keep = rec < 0 ? 0u : ~0u;
 #pragma unroll
-        for (int l = 0; l < LOB_MAX_DEPTH; l++) R.apx[l] = R.avol[l] = R.bpx[l] = R.bvol[l] = 0u;
-    }
+    for (int l = 0; l < LOB_MAX_DEPTH; l++) { R.apx[l] &= keep; R.avol[l] &= keep; R.bpx[l] &= keep; R.bvol[l] &= keep; }
 }
 __device__ inline void row_volumes(const EnvCtx& c, const EnvR& e, const RowFull& L, i64& a_v, i64& b_v) {
     const int D = c.P.D;
@@ -525,7 +535,7 @@ __device__ inline void place_orders(const EnvCtx& c, EnvR& e, int al, int bl, co
         ta = lobh::to_ticks_t((*c.tk), ap0) + al;
         tb = lobh::to_ticks_t((*c.tk), bp0) - bl;
     } else {
-        const Track& t = c.track(e.k - 1);
+        const Track& t = c.pre_prev ? *c.pre_prev : c.track(e.k - 1);
         f64 tp = t.tp_val;
         f64 half = t.spread_mean / 2.0;
         f64 half_spd = 0.0 > half ? 0.0 : half;  // std::max(0.0, x)
@@ -559,7 +569,7 @@ __device__ inline void market_order(const EnvCtx& c, EnvR& e, i64 size, i64& out
         // event still applied before the stream ran dry (it went through same-timestamp rows / invalid states)
         tv = side == 0 ? c.S.prep[c.b].a_tv : c.S.prep[c.b].b_tv;
     } else {
-        tv = side == 0 ? c.track(e.k - 1).a_tv : c.track(e.k - 1).b_tv;
+        tv = c.pre_prev ? (side == 0 ? c.pre_prev->a_tv : c.pre_prev->b_tv) : (side == 0 ? c.track(e.k - 1).a_tv : c.track(e.k - 1).b_tv);
     }
     if (abs_size > tv) return;
     i64 executed = 0;
@@ -664,7 +674,8 @@ __device__ inline f32 expf_glibc(f32 x) {
 }
 
 // Base::getReward (base.cpp:166-237)
-__device__ inline f64 get_reward(const EnvCtx& c, const EnvR& e) {
+// `spread_mean`: spread_window.mean() as of the last completed event (track entry e.k - 1), when the caller holds it
+__device__ inline f64 get_reward(const EnvCtx& c, const EnvR& e, const f64* spread_mean = nullptr) {
     const DevParams& P = c.P;
     f64 r = 0.0;
     i64 ap = e.position < 0 ? -e.position : e.position;
@@ -677,7 +688,7 @@ __device__ inline f64 get_reward(const EnvCtx& c, const EnvR& e) {
             r = e.pnl_step - (f64)P.damping_factor * m;
             break;
         }
-        case LOB_REWARD_SPREAD: r = e.pnl_step / c.track(e.k - 1).spread_mean; break;
+        case LOB_REWARD_SPREAD: r = e.pnl_step / (spread_mean ? *spread_mean : c.track(e.k - 1).spread_mean); break;
         case LOB_REWARD_LOVOL: r = (f64)e.lo_vol_step; break;
         case LOB_REWARD_MM_LINEAR: {
             f32 pen = -P.pos_weight * (f32)abs_pos;  // float product in the reference
@@ -962,7 +973,10 @@ __device__ inline bool next_state(const EnvCtx& c, EnvR& e, const TrackHead& t, 
 // up to the first NextState: DoAction, CheckOrders, UpdateStats, the reward of the action itself
 __device__ inline void step_prologue(const EnvCtx& c, EnvR& e, int action, StepAgg& g, const RowFull& cur) {
     const DevParams& P = c.P;
-    {
+    if (c.pre_n_track >= 0) {
+        g.n_track = c.pre_n_track;
+        g.complete = c.pre_complete;
+    } else {
         const BookMeta& M = c.S.meta[c.b];
         g.n_track = M.n_track;
         g.complete = M.complete;
@@ -1010,6 +1024,15 @@ __device__ inline void step_epilogue(const EnvCtx& c, EnvR& e, const StepAgg& g)
         rm_apply(c.S.pnl_ups, c.S.B, c.b, wu, 0.0 > e.pnl_step ? 0.0 : e.pnl_step);
         rm_apply(c.S.pnl_downs, c.S.B, c.b, wd, fabs(0.0 < e.pnl_step ? 0.0 : e.pnl_step));
     }
+    e.ep_reward += g.r;
+    e.ep_bandh += g.mpm;
+    c.mark(27);  // PnL windows
+}
+// the same with the two windows' registers already loaded and prepared (rm_load + rm_prep) by the caller
+__device__ inline void step_epilogue_pre(const EnvCtx& c, EnvR& e, const StepAgg& g, RMReg& wu, RMReg& wd) {
+    e.pnl_step = g.pnl;
+    rm_apply(c.S.pnl_ups, c.S.B, c.b, wu, 0.0 > e.pnl_step ? 0.0 : e.pnl_step);
+    rm_apply(c.S.pnl_downs, c.S.B, c.b, wd, fabs(0.0 < e.pnl_step ? 0.0 : e.pnl_step));
     e.ep_reward += g.r;
     e.ep_bandh += g.mpm;
     c.mark(27);  // PnL windows
@@ -1117,7 +1140,8 @@ __device__ inline void row_volumes_k(const EnvCtx& c, bool a_on, bool b_on, f64 
     b_v = (b_on && fb) ? (i64)(i32)vb : 0;
 }
 // one pass: 0 = another event follows, 1 = the step is complete.  `L` = the level arrays of row t.rec_first.
-__device__ inline int pass_fast(const EnvCtx& c, EnvR& h, StepAgg& g, const TrackHead64& t, RowFull& L, const FastKeys& K) {
+template <class TH>  // TrackHead64, or the whole Track entry
+__device__ inline int pass_fast(const EnvCtx& c, EnvR& h, StepAgg& g, const TH& t, RowFull& L, const FastKeys& K, const f64* spread_mean = nullptr) {
     const DevParams& P = c.P;
     h.pnl_step = 0.0;
     const f64 tp0 = (f64)t.tr_px[0], tp1 = (f64)t.tr_px[1];
@@ -1210,23 +1234,25 @@ __device__ inline int pass_fast(const EnvCtx& c, EnvR& h, StepAgg& g, const Trac
     const f64 mpm = h.mid - h.mid_prev;
     h.pnl_step += (f64)h.position * mpm;
     h.momentum_pnl_step += (f64)h.position * mpm;
-    g.r += get_reward(c, h);
+    g.r += get_reward(c, h, spread_mean);
     g.pnl += h.pnl_step;
     g.mpm += mpm;
     return (is_open(P, h.time_ms) && fabs(g.mpm) < 1e-5) ? 0 : 1;
 }
-// perform_action with the fast pass.  `first` = the level arrays of record e.rec_cur + 1 (the first row of the step's first
-// event), requested by the caller together with `cur`.
-__device__ inline bool perform_action_fast(const EnvCtx& c, EnvR& e, int action, TrackHead64 t, const RowFull& cur, RowFull L) {
-    StepAgg g;
-    step_prologue(c, e, action, g, cur);
+// The event loop of a step with the fast pass.  `t` = the track entry of event e.k, `L` = the level arrays of record
+// e.rec_cur + 1 (the first row the step applies), both requested by the caller ahead of time; every pass requests the next
+// entry and the next row before it starts on its own.  TE = TrackHead64, or Track when the caller wants the last completed
+// event's whole entry back in `t` (the state extraction reads its second half).  Returns the last pass's status (1: step
+// complete, 2: out of data).
+template <class TE>
+__device__ inline int event_loop_fast(const EnvCtx& c, EnvR& e, StepAgg& g, TE& t, RowFull L) {
     EnvR h = e;  // registers from here to the end of the loop
     const FastKeys K{key4(h.a_opx), key4(h.b_opx)};
     c.mark(22);  // hot copy
     const int last_row = c.S.n_events - 1;
     int st;
-    do {
-        const TrackHead64 tn = c.track_head64(h.k + 1);
+    while (true) {
+        const TE tn = *reinterpret_cast<const TE*>(&c.track(h.k + 1));
         // the fast pass needs: the event inside the track, freshly placed orders behind it, its trade list whole, and the row
         // it was handed (a step's first row is the record after the current snapshot -- anything else is reloaded)
         const bool fast = h.k < g.n_track && g.cv_valid && (t.info & LOB_TRK_TRADES_OK);
@@ -1235,7 +1261,7 @@ __device__ inline bool perform_action_fast(const EnvCtx& c, EnvR& e, int action,
             RowFull Ln;  // next pass's first row, in flight during this one
             { const int rn = t.rec_last + 1; row_full_load(c, rn < last_row ? rn : last_row, Ln); }
             c.mark(23);  // loop top: next entry / next row requested
-            st = pass_fast(c, h, g, t, L, K);
+            st = pass_fast(c, h, g, t, L, K, sizeof(TE) == sizeof(Track) ? &reinterpret_cast<const Track*>(&t)->spread_mean : nullptr);
             L = Ln;
             c.mark(24);  // the pass itself
         } else {
@@ -1249,19 +1275,25 @@ __device__ inline bool perform_action_fast(const EnvCtx& c, EnvR& e, int action,
             h = e;
             if (st == 0) row_full_load(c, h.rec_cur + 1 < last_row ? h.rec_cur + 1 : last_row, L);
         }
+        if (st != 0) break;
         t = tn;
-    } while (st == 0);
+    }
     c.mark(25);  // waiting for the wave's slowest lane
 #define X(n) e.n = h.n;
     LOB_ENV_PASS_FIELDS(X)
 #undef X
     e.done = h.done;  // (the general pass sets it when the stream runs dry)
     c.mark(26);  // hot copy back
-    if (st == 2) return false;
+    return st;
+}
+// perform_action with the fast pass.  `first` = the level arrays of record e.rec_cur + 1, requested by the caller together with `cur`.
+__device__ inline bool perform_action_fast(const EnvCtx& c, EnvR& e, int action, TrackHead64 t, const RowFull& cur, const RowFull& first) {
+    StepAgg g;
+    step_prologue(c, e, action, g, cur);
+    if (event_loop_fast(c, e, g, t, first) == 2) return false;
     step_epilogue(c, e, g);
     return true;
 }
-
 // Intraday::getVariable (intraday.cpp:316-409): market variables come from the
 // track entry of the last completed event, agent variables are computed here.
 // `t` = state_track(c, e), fetched ONCE by the caller (by value: six 16-byte loads in flight) rather

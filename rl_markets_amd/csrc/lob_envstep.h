@@ -1,0 +1,239 @@
+// env_step_kernel: the learner step's action selection + performAction of every book, a lane per book -- the same work as
+// env_kernel<64, 2, 1> (lob_kernels.h: act_light_book + perform_action_fast), re-ordered around what actually bounds it.
+//
+// Measured (tools/exp_prof.py, tools/ubench/rowload): with one wave per SIMD and 65 536 lanes asking at once, a dependent
+// memory round trip costs ~6 600 clocks (2.7 us) whatever its size, and env_kernel<64, 2, 1> was a chain of ~40 of them --
+// header -> hit list -> memo record -> weights -> (more list entries -> more weights) -> agent scalars -> track entry of the
+// quotes -> BookMeta -> [per pass: row] -> window state -> window slots -> track entry of the state -> memo slot -> ... --
+// 173 000 of its 256 000 clocks outside the event loop.  Nothing in that chain is a real dependency beyond two levels:
+//   round 1 (needs the book id only):   header, k, rec_cur, memo slot, the WHOLE hit list (192 B), all agent scalars,
+//                                       the PnL windows' registers, BookMeta, the tick table;
+//   round 2 (needs round 1's indices):  memo record + mark bits, every listed weight, the track entries of events k - 1
+//                                       (quotes) and k (first pass), the current snapshot's rows and the first row the
+//                                       step applies, the two window slots that fall out;
+//   event loop:                         entry k + 1 and its first row requested one pass ahead (event_loop_fast);
+//   round 3 (needs the new state):      the memo slot's hash / stamp.
+// The arithmetic is act_light_book's and perform_action_fast's, call for call.  Books the hit-list replay cannot serve go
+// on the act work list exactly as before (general act kernel + env_kernel<64, 2, 2>).
+#ifndef LOB_ENVSTEP_H
+#define LOB_ENVSTEP_H
+
+#include "lob_fast.h"
+
+__device__ inline Track track_load(const Track* p) {
+    // eight 16-byte loads, in flight together
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 w[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) w[i] = q[i];
+    Track t;
+    uint4* d = reinterpret_cast<uint4*>(&t);
+#pragma unroll
+    for (int i = 0; i < 8; i++) d[i] = w[i];
+    return t;
+}
+
+__global__ void __launch_bounds__(64) env_step_kernel(const DevParams* __restrict__ Pp, DevState S, int step_id, int par, EnvFuse F) {
+    const DevParams& P = *Pp;
+    __shared__ TickLds tick_lds;
+    __shared__ EnvSlot lds_env[64];
+#ifdef LOB_PROF
+    const long long t_entry = clock64();
+#else
+    const long long t_entry = 0;
+#endif
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    const bool valid = t < S.B;
+    const int b = valid ? t : S.B - 1;  // (lanes past the batch fetch the last book's inputs and do nothing with them)
+    const int B = S.B;
+
+    // ---- round 1: everything addressed by the book id ------------------------------------------------------------------
+    f64 tk_lb = 0.0, tk_tick = 0.0, tk_pp = 0.0;
+    i64 tk_cum = 0;
+    i32 tk_pt = 0;
+    if (threadIdx.x < LOB_MAX_BANDS) {
+        const int i = threadIdx.x;
+        tk_lb = P.band_lb[i]; tk_tick = P.band_tick[i]; tk_cum = P.band_cum[i]; tk_pp = P.band_pp[i]; tk_pt = P.band_pt[i];
+    }
+    EnvCtx c(P, S, b, &tick_lds);  // (a replayed stream: the book's phase is a round-1 load too)
+    LHdr* hp = S.hdr + b;
+    const LHdr h0 = *hp;
+    const int k0 = S.k[b], rc0 = S.rec_cur[b];
+    const int mslot = S.mk_slot[b];
+    const bool dirty = S.hl_dirty[0] == F.sid_prev;
+    ulonglong2 hl[LOB_HL_REC / 2];
+    {
+        const ulonglong2* lp = reinterpret_cast<const ulonglong2*>(S.hl_rec + (size_t)b * LOB_HL_REC);
+#pragma unroll
+        for (int i = 0; i < LOB_HL_REC / 2; i++) hl[i] = lp[i];
+    }
+    EnvR er;
+    env_load(S, b, er);
+    RMReg wu, wd;
+    rm_load(S.pnl_ups, b, wu);
+    rm_load(S.pnl_downs, b, wd);
+    const int m_n_track = S.meta[b].n_track, m_complete = S.meta[b].complete;
+
+    // (tick table and the book's scalars to LDS)
+    if (threadIdx.x < LOB_MAX_BANDS) {
+        const int i = threadIdx.x;
+        tick_lds.lb[i] = tk_lb; tick_lds.tick[i] = tk_tick; tick_lds.cum[i] = tk_cum; tick_lds.pp[i] = tk_pp; tick_lds.pt[i] = tk_pt;
+    }
+    if (threadIdx.x == 0) tick_lds.n = P.n_bands;
+    EnvR& e = lds_env[threadIdx.x].e;
+    e = er;
+    __syncthreads();
+
+    // ---- who steps, and from which list (act_light_book) ----------------------------------------------------------------
+    const int cur_slot = h0.slot_cur ^ 1;  // swap(state, last_state)
+    const bool alive = valid && !h0.done;
+    const bool open = is_open(P, h0.time_ms);
+    const int n_list = hl[0].x == LOB_HL_NONE ? -1 : (int)hl[0].x;
+    bool ok = alive && open && !dirty && !((h0.zero_mask >> (cur_slot ^ 1)) & 1) && mslot >= 0 && n_list >= 0;
+
+    // ---- round 2: everything addressed by what round 1 brought ----------------------------------------------------------
+    const int ms = mslot >= 0 ? mslot : 0;
+    const MemoRec rec = *reinterpret_cast<const MemoRec*>(S.mk_rec + ((size_t)S.mk_slots + ms) * LOB_MK_REC);  // [1]: after the last update
+    const int tiles_ok = S.mk_tiles_ok[ms];
+    const uint32_t mk_bits = S.mk_marked[ms];
+    // entry i of the list = word 1 + i of the record
+#define LOB_HL_ENT(i) (((1 + (i)) & 1) ? hl[(1 + (i)) >> 1].y : hl[(1 + (i)) >> 1].x)
+    f64 wv[LOB_HL_CAP];
+#pragma unroll
+    for (int i = 0; i < LOB_HL_CAP; i++) {
+        wv[i] = 0.0;
+        if (ok && i < n_list) wv[i] = S.theta[(uint32_t)LOB_HL_ENT(i)];
+    }
+    const int kk = k0 > 0 ? k0 : 1;  // (a live book has consumed its warm-up: k0 >= 1)
+    const Track tprev = track_load(&c.track(kk - 1));
+    Track tcur = track_load(&c.track(k0));
+    RowFull cur, first;
+    row_full_load(c, rc0, cur);
+    {
+        const int last_row = S.n_events - 1;
+        row_full_load(c, rc0 + 1 < last_row ? rc0 + 1 : last_row, first);
+    }
+    rm_prep(S.pnl_ups, B, b, wu);
+    rm_prep(S.pnl_downs, B, b, wd);
+
+    // ---- the action (act_light_book, from here on) ------------------------------------------------------------------------
+    int action = 0;
+    bool go = false;
+    if (valid) {
+        if (h0.done) {
+            hp->stepped = 0;
+        } else if (!open) {  // environment.isTerminal()
+            hp->slot_cur = cur_slot; hp->done = 1; hp->stepped = 0; S.done[b] = 1;
+        } else {
+            ok = ok && rec.ver == F.ver;
+            if (!ok) {
+                const int pos = atomicAdd(&S.slow_n[F.lpar * 2 + 0], 1);
+                S.slow_list[pos] = b;
+            } else {
+                f64 q[LOB_N_ACTIONS];
+#pragma unroll
+                for (int a = 0; a < LOB_N_ACTIONS; a++) q[a] = rec.s0[a];
+                const f64 w1 = P.w1, w2 = P.w2;
+#pragma unroll
+                for (int i = 0; i < LOB_HL_CAP; i++) {
+                    const u64 ent = LOB_HL_ENT(i);
+                    const f64 v = wv[i];
+                    if (i < n_list && v != 0.0) {  // (+0.0 added to a sum that is never -0.0)
+                        const int a_ = (int)(ent >> 32) & 15;
+                        const f64 x_ = ((ent >> 36) & 1ull ? w2 : w1) * v;
+#pragma unroll
+                        for (int a = 0; a < LOB_N_ACTIONS; a++) q[a] = a_ == a ? q[a] + x_ : q[a];
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < LOB_N_ACTIONS; a++) S.qs_last[(size_t)b * LOB_N_ACTIONS + a] = q[a];
+                Rng g{P.seed, P.book_id_offset + (u64)b, h0.rng_ctr};
+                action = policy_sample(P, q, false, g);
+                hp->slot_cur = cur_slot;
+                hp->action = action;
+                hp->stepped = 1;
+                hp->rng_ctr = g.ctr;
+                // the tiles of (this state, this action)'s trace generation are marked in the written-weights maps before
+                // this step's learn kernel looks (by memo_kernel, a lane per tile), once per (triple, action)
+                const uint32_t marked = tiles_ok ? mk_bits : 0x1ffu;
+                if (!((marked >> action) & 1u)) {
+                    const int pos = atomicAdd(&S.mk_markcount[0], 1);
+                    if (pos < S.mk_slots) S.mk_marklist[pos] = mslot * 16 + action;
+                    else mark_generation(P, S, mslot, action);
+                    atomicOr(&S.mk_marked[mslot], 1u << action);
+                }
+                const u64 act = __ballot(1);
+                if ((int)(threadIdx.x & 63) == __builtin_ctzll(act)) atomicAdd((unsigned long long*)&S.counters[5], (unsigned long long)__builtin_popcountll(act));
+                go = true;
+            }
+        }
+    }
+#undef LOB_HL_ENT
+
+    // ---- performAction -----------------------------------------------------------------------------------------------------
+    i64 d_steps = 0, d_events = 0;
+    if (go) {
+        c.pre_prev = &tprev;
+        c.pre_n_track = m_n_track;
+        c.pre_complete = m_complete;
+        c.prof_start(S.prof, threadIdx.x & 63, t_entry);
+        c.mark(30);  // rounds 1 and 2, action selection
+        const i64 ev0 = e.events;
+        StepAgg g;
+        step_prologue(c, e, action, g, cur);
+        const int st = event_loop_fast(c, e, g, tcur, first);
+        bool claim = false;
+        u64 claim_k = 0;
+        int claim_stamp = 0, claim_slot_prev = -1, claim_q0 = 0, claim_q1 = 0, claim_q2 = 0;
+        d_events = e.events - ev0;
+        if (st != 2) {
+            step_epilogue_pre(c, e, g, wu, wd);
+            const int cs = cur_slot;
+            f32* v = S.vars + ((size_t)b * 3 + cs) * 16;
+            f32* vf = S.vars + ((size_t)b * 3 + 2) * 16;
+            int qg[3] = {0, 0, 0};
+            for (int i = 0; i < P.V; i++) {
+                v[i] = (f32)get_variable(c, e, P.vars[i], tcur);  // tcur = the entry of the last completed event (state_track)
+                vf[i] = v[i];
+                if (i < 3) qg[i] = tile_quant(v[i]);
+            }
+            if (P.memo) {
+                const uint32_t s0 = (uint32_t)mk_hash3(qg[0], qg[1], qg[2]) & (uint32_t)(S.mk_slots - 1);
+                claim_k = S.mk_hash[s0];
+                claim_stamp = S.mk_stamp[s0];
+                claim_slot_prev = mslot;
+                claim_q0 = qg[0]; claim_q1 = qg[1]; claim_q2 = qg[2];
+                claim = true;
+            }
+            hp->zero_mask = h0.zero_mask & ~(1 << cs);
+            S.verdict[(size_t)b * LOB_VD_STRIDE + 67] = 0;  // a State changed: saved verdicts are void until learn saves new ones
+            hp->reward = get_reward(c, e, &tcur.spread_mean);
+            hp->stepped = 1;
+            d_steps = 1;
+        } else {
+            hp->stepped = 0;
+        }
+        c.mark(28);  // state variables
+        hp->done = e.done;
+        hp->time_ms = e.time_ms;
+        env_store(S, b, e);
+        if (claim) {
+            S.mk_slot_last[b] = claim_slot_prev;
+            S.mk_slot[b] = mk_claim(S, claim_q0, claim_q1, claim_q2, step_id, par, claim_k, claim_stamp);
+        }
+        c.mark(29);  // agent scalars out, memo claim
+        c.flush();
+    }
+    // one atomic per wave for the counters
+    for (int off = 32; off > 0; off >>= 1) {
+        d_steps += __shfl_down(d_steps, off);
+        d_events += __shfl_down(d_events, off);
+    }
+    if ((threadIdx.x & 63) == 0 && (d_steps | d_events)) {
+        atomicAdd((u64*)&S.counters[0], (u64)d_steps);
+        atomicAdd((u64*)&S.counters[1], (u64)d_events);
+        atomicAdd((u64*)&S.counters[3], (u64)d_steps);  // every stepped book gets one TD update
+    }
+}
+
+#endif
