@@ -1252,17 +1252,23 @@ __device__ inline int event_loop_fast(const EnvCtx& c, EnvR& e, StepAgg& g, TE& 
     const int last_row = c.S.n_events - 1;
     int st;
     while (true) {
-        const TE tn = *reinterpret_cast<const TE*>(&c.track(h.k + 1));
+        // the next event's entry and first row are requested a pass ahead -- unless the entry says the step ends with this
+        // event (LOB_TRK_STEP_END: a hint from the pre-pass; when it is wrong the loop fetches what it needs on the spot)
+        const bool more = !(t.info & LOB_TRK_STEP_END);
+        TE tn;
+        if (more) tn = *reinterpret_cast<const TE*>(&c.track(h.k + 1));
         // the fast pass needs: the event inside the track, freshly placed orders behind it, its trade list whole, and the row
         // it was handed (a step's first row is the record after the current snapshot -- anything else is reloaded)
         const bool fast = h.k < g.n_track && g.cv_valid && (t.info & LOB_TRK_TRADES_OK);
+        bool have_next_row = false;
         if (fast) {
             if (t.rec_first != h.rec_cur + 1) row_full_load(c, t.rec_first, L);
             RowFull Ln;  // next pass's first row, in flight during this one
-            { const int rn = t.rec_last + 1; row_full_load(c, rn < last_row ? rn : last_row, Ln); }
+            if (more) { const int rn = t.rec_last + 1; row_full_load(c, rn < last_row ? rn : last_row, Ln); }
             c.mark(23);  // loop top: next entry / next row requested
             st = pass_fast(c, h, g, t, L, K, sizeof(TE) == sizeof(Track) ? &reinterpret_cast<const Track*>(&t)->spread_mean : nullptr);
-            L = Ln;
+            if (more) L = Ln;
+            have_next_row = more;
             c.mark(24);  // the pass itself
         } else {
 #define X(n) e.n = h.n;
@@ -1273,9 +1279,10 @@ __device__ inline int event_loop_fast(const EnvCtx& c, EnvR& e, StepAgg& g, TE& 
             t32.tick_bp0 = t.tick_bp0; t32.info = t.info; t32.mid = t.mid;
             st = step_event<2>(c, e, g, t32);
             h = e;
-            if (st == 0) row_full_load(c, h.rec_cur + 1 < last_row ? h.rec_cur + 1 : last_row, L);
         }
         if (st != 0) break;
+        if (!more) tn = *reinterpret_cast<const TE*>(&c.track(h.k));  // (h.k is the next event by now)
+        if (!have_next_row) row_full_load(c, h.rec_cur + 1 < last_row ? h.rec_cur + 1 : last_row, L);
         t = tn;
     }
     c.mark(25);  // waiting for the wave's slowest lane
@@ -1494,6 +1501,7 @@ __device__ inline void prepass_begin(const EnvCtx& c, PrepState& st, BookMeta& M
     st.ewma_up = m.ewma_up; st.ewma_down = m.ewma_down; st.tp_val = m.tp_val;
     st.records = m.records;
     st.k = 0;
+    st.step_mpm = 0.0;
     st.prev_first = m.rec_cur;  // Initialise: time_and_sales.SkipUntil(market time) drops everything up to here
 }
 
@@ -1511,6 +1519,7 @@ __device__ inline void prepass_run(const EnvCtx& c, PrepState& st, BookMeta& M, 
     m.records = st.records;
     int k = st.k;
     int prev_first = st.prev_first;
+    f64 step_mpm = st.step_mpm;
     // the ten windows of intraday.cpp:253-269: state in registers for the whole run
     RMReg w_mid, w_vol, w_spr, w_tp, w_atx, w_btx;
     AccReg w_vn, w_vd;
@@ -1596,6 +1605,14 @@ __device__ inline void prepass_run(const EnvCtx& c, PrepState& st, BookMeta& M, 
 #pragma unroll
                 for (int i = 0; i < TM; i++) ntr += (i < P.T && tv[i] > 0) ? 1 : 0;
                 t.info = (ntr < 2 ? ntr : 2) | (ntr <= 2 ? LOB_TRK_TRADES_OK : 0);
+                // Where the steps of an episode end (base.cpp:285-305: a step consumes events until the midprice has moved or
+                // the market has closed) does not depend on the agent: every step starts where the one before stopped, the
+                // first one after the warm-up.  Kept as a HINT only -- the event loop prefetches the next entry / row unless
+                // the hint says the step ends here, and decides the end itself.
+                if (M.k_warm >= 0 && k >= M.k_warm) {
+                    step_mpm += mpm;
+                    if (!(is_open(P, m.time_ms) && fabs(step_mpm) < 1e-5)) { t.info |= LOB_TRK_STEP_END; step_mpm = 0.0; }
+                }
                 t.tr_px[0] = (f32)tp[0]; t.tr_vol[0] = tv[0];
                 t.tr_px[1] = TM > 1 ? (f32)tp[TM > 1 ? 1 : 0] : 0.0f; t.tr_vol[1] = TM > 1 ? tv[TM > 1 ? 1 : 0] : 0;
                 t.bap = (f32)m.ap0; t.bbp = (f32)m.bp0;
@@ -1648,6 +1665,7 @@ __device__ inline void prepass_run(const EnvCtx& c, PrepState& st, BookMeta& M, 
     st.records = m.records;
     st.k = k;
     st.prev_first = prev_first;
+    st.step_mpm = step_mpm;
     S.ewma_up[b] = m.ewma_up; S.ewma_down[b] = m.ewma_down; S.tp_val[b] = m.tp_val;
     if (write_track) {
         M.n_track = k;

@@ -61,12 +61,11 @@ __global__ void __launch_bounds__(64) env_step_kernel(const DevParams* __restric
     const int k0 = S.k[b], rc0 = S.rec_cur[b];
     const int mslot = S.mk_slot[b];
     const bool dirty = S.hl_dirty[0] == F.sid_prev;
+    // the hit list: its first 128 bytes (the count and 15 entries: all of it but for a book in a thousand) now, the rest below
     ulonglong2 hl[LOB_HL_REC / 2];
-    {
-        const ulonglong2* lp = reinterpret_cast<const ulonglong2*>(S.hl_rec + (size_t)b * LOB_HL_REC);
+    const ulonglong2* hl_p = reinterpret_cast<const ulonglong2*>(S.hl_rec + (size_t)b * LOB_HL_REC);
 #pragma unroll
-        for (int i = 0; i < LOB_HL_REC / 2; i++) hl[i] = lp[i];
-    }
+    for (int i = 0; i < LOB_HL_REC / 2; i++) hl[i] = i < 8 ? hl_p[i] : make_ulonglong2(0ull, 0ull);
     EnvR er;
     env_load(S, b, er);
     RMReg wu, wd;
@@ -90,6 +89,10 @@ __global__ void __launch_bounds__(64) env_step_kernel(const DevParams* __restric
     const bool open = is_open(P, h0.time_ms);
     const int n_list = hl[0].x == LOB_HL_NONE ? -1 : (int)hl[0].x;
     bool ok = alive && open && !dirty && !((h0.zero_mask >> (cur_slot ^ 1)) & 1) && mslot >= 0 && n_list >= 0;
+    if (ok && n_list > 15) {  // (a round trip of its own, for the waves that hold such a book)
+#pragma unroll
+        for (int i = 8; i < LOB_HL_REC / 2; i++) hl[i] = hl_p[i];
+    }
 
     // ---- round 2: everything addressed by what round 1 brought ----------------------------------------------------------
     const int ms = mslot >= 0 ? mslot : 0;
