@@ -179,6 +179,8 @@ def main():
         from rl_markets_amd.comm import MAX, SUM, RcclComm
         rdzv = launch.rendezvous_path() if world > 1 else os.path.join(tempfile.gettempdir(), "lob_rdzv_single_%d" % os.getpid())
         comm = RcclComm(rdzv, rank, world, local_rank)
+        from rl_markets_amd.comm import pin_host_thread
+        pinned_cpus = pin_host_thread(local_rank)   # this rank's launches / event reads stay on its GPU's socket
 
     p = engine.default_params()
     p.depth, p.max_trades = args.depth, 2
@@ -219,6 +221,8 @@ def main():
 
     learner.run(args.warmup)
     barrier()
+    if comm is not None:
+        comm.exchange_stats()   # (drop the warm-up's)
     c0 = eng.counters()
     if not args.no_kernel_timing:
         # HIP events around the kernels of every n-th step of the timed region (5-8 sampled steps): timing every
@@ -243,7 +247,11 @@ def main():
     books = eng.get_books(0, min(args.books, 4096))
     n_live = float(sum(b.n_traces for b in books)) / len(books)
 
+    exchange = None
     if comm is not None:
+        exchange = comm.exchange_stats()                  # HIP events on the engine stream around the exchange's phases (this rank)
+        exchange["pinned_host_cpus"] = pinned_cpus
+        exchange["ms_per_exchange"] = round(exchange["pack_ms"] + exchange["collectives_ms"] + exchange["apply_ms"], 4)
         elapsed = comm.reduce([elapsed], MAX)[0]          # the slowest rank's clock
         steps_done, events_done = (int(v) for v in comm.reduce([steps_done, events_done], SUM))
 
@@ -336,7 +344,8 @@ def main():
                 "events_per_step": round(eps, 4), "live_traces_per_book": round(n_live, 1),
                 "env_steps": steps_done, "reset_ms_per_episode": round(reset_ms, 2), "steps_per_episode": round(steps_per_episode, 1),
                 "sync_every": SYNC_EVERY if comm is not None else None,
-                "parallelism": ("%d book shard(s), one process per GPU, dense RCCL all-reduce of delta-theta every %d steps" % (world, SYNC_EVERY))
+                "exchange": exchange,
+                "parallelism": ("%d book shard(s), one process per GPU, every %d steps the ranks' written-weights maps all-gathered and the packed delta-theta of their union all-reduced over RCCL" % (world, SYNC_EVERY))
                                if comm is not None else "1 shard",
             },
             "roofline": roofline,

@@ -54,12 +54,25 @@ int lob_comm_allreduce_f64(lob_comm* c, double* dev_buf, int64_t count, void* hi
  * doubles and receives the reduction over ranks.  Synchronises. */
 int lob_comm_reduce_host_f64(lob_comm* c, double* vals, int32_t n, int32_t op);
 int lob_comm_barrier(lob_comm* c);
+/* All-gather of `count` uint32 words per rank into dev_recv[world][count] on `hip_stream` (the ranks' written-weights maps). */
+int lob_comm_allgather_u32(lob_comm* c, const uint32_t* dev_send, uint32_t* dev_recv, int64_t count, void* hip_stream);
+/* Bind the calling thread to the host cores next to GPU `device` (sysfs local_cpulist of its PCIe function); *n_cpus = how
+ * many, 0 when the topology cannot be read (nothing changed). */
+int lob_comm_pin_host_thread(int32_t device, int32_t* n_cpus);
 
-/* The periodic weight exchange of one engine: lob_delta_begin_async ->
- * all-reduce(SUM) in place on the engine's stream -> lob_delta_apply.
- * lob_delta_init must have been called once (after create / theta_set).
- * Asynchronous: returns as soon as the work is enqueued. */
+/* The periodic weight exchange of one engine, on the engine's stream.  lob_delta_init must have been called once (after
+ * create / theta_set).
+ *   shared theta on the fast path (SARSA / Q(lambda)): SPARSE -- all-gather of the ranks' written-weights maps (2.5 MB each at
+ *     memory_size 20 M), union -> compact layout, all-reduce(SUM) of the packed deltas (a few hundred thousand doubles),
+ *     scatter (lob_delta_sparse_*); one host synchronisation (the element count).  LOB_DENSE_EXCHANGE=1 forces the dense path;
+ *   otherwise DENSE: lob_delta_begin_async -> all-reduce(SUM) of memory_size doubles in place -> lob_delta_apply, fully
+ *     asynchronous.
+ * Same result either way: theta = theta_sync + sum over ranks of (theta - theta_sync). */
 int lob_theta_allreduce(lob_engine* e, lob_comm* c);
+/* What the exchanges since the last call cost, from HIP events on the engine's stream (synchronises):
+ * out = [exchanges, pack / delta ms, collectives ms, apply ms, bytes through the collectives, sparse exchanges, ranks as
+ * ncclCommCount reports them]. */
+int lob_comm_exchange_stats(lob_comm* c, double out[7]);
 
 #ifdef __cplusplus
 }

@@ -314,6 +314,13 @@ int lob_get_books(lob_engine* e, int32_t first, int32_t n, lob_book_dump* out);
 /* `n_steps` x Learner::_step (src/experiment/serial.cpp:53-70) for every live
  * book: action(s) -> performAction -> newState -> HandleTransition. */
 int lob_td_step(lob_engine* e, int32_t n_steps);
+/* One such step in two halves: lob_td_step_begin = swap, isTerminal, action, performAction, newState of every book;
+ * lob_td_step_end = HandleTransition (traces, TD errors, update).  Between them no cached action-selection data is live, so
+ * that is where a multi-GPU weight exchange goes (include/lob_comm.h lob_theta_allreduce): Q(from_state, .) of the step is
+ * what it was when the action was chosen, Q(to_state, .) sees the exchanged weights.  Nothing else may come in between
+ * (LOB_ESTATE); begin + end without an exchange = lob_td_step(e, 1), bit for bit. */
+int lob_td_step_begin(lob_engine* e);
+int lob_td_step_end(lob_engine* e);
 /* Backtester::_step (serial.cpp:124-137): greedy action, no learning. */
 int lob_eval_step(lob_engine* e, int32_t n_steps);
 /* Agent::HandleTerminal (src/rl/agent.cpp:103-109): traces.decay(0). The
@@ -360,12 +367,26 @@ int lob_get_counters(lob_engine* e, int64_t out[4]);
  *                     lob_delta_begin_async only enqueues it)
  *   (caller: all-reduce SUM dev_delta over ranks)
  *   lob_delta_apply : theta = theta_sync + dev_delta ; theta_sync = theta
- * `count` = memory_size, or 2 x memory_size for LOB_ALGO_DOUBLE_Q (theta then theta_b).
+ * `count` = memory_size, or 2 x memory_size for LOB_ALGO_DOUBLE_Q (theta then theta_b); the average-reward agents
+ * append two slots [rho - rho_sync, 1.0] (the sum's second slot = the number of ranks: rho moves by the mean change).
  */
 int lob_delta_init(lob_engine* e);
 int lob_delta_begin(lob_engine* e, double** dev_delta, int64_t* count);
 int lob_delta_begin_async(lob_engine* e, double** dev_delta, int64_t* count);
 int lob_delta_apply(lob_engine* e);
+/* The same exchange without the dense vector (shared theta on the fast path, i.e. SARSA / Q(lambda); dense otherwise).  The
+ * engine's exact written-weights map (one bit per weight) enumerates every weight a step of this rank has touched:
+ *   lob_delta_sparse_maps  : the rank's map and a [world][words] buffer to ALL-GATHER the ranks' maps into (uint32 words)
+ *   lob_delta_sparse_pack  : union of the gathered maps -> one compact vector layout common to all ranks;
+ *                            dev_buf[p] = theta[f] - theta_sync[f] for the p-th weight f of the union.  Returns the element
+ *                            count (identical on all ranks) after ONE stream synchronisation: the collective needs it.
+ *   (caller: all-reduce SUM dev_buf[0 .. count) over ranks)
+ *   lob_delta_sparse_apply : theta[f] = theta_sync[f] + dev_buf[p] ; theta_sync[f] = theta[f]
+ * A few hundred thousand doubles instead of memory_size = 20 M of them. */
+int lob_delta_sparse_supported(lob_engine* e);
+int lob_delta_sparse_maps(lob_engine* e, int32_t world, uint32_t** dev_own, uint32_t** dev_gather, int64_t* words);
+int lob_delta_sparse_pack(lob_engine* e, int32_t world, double** dev_buf, int64_t* count);
+int lob_delta_sparse_apply(lob_engine* e);
 
 /* Synchronise the engine's stream / expose it (hipStream_t as void*). */
 int lob_sync(lob_engine* e);

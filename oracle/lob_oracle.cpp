@@ -991,6 +991,46 @@ struct oracle_learner {
     uint64_t raw(int b) { return lob_rng(P.seed, P.book_id_offset + (uint64_t)b, rng_ctr[b]++); }
     int rnd(int b) { return (int)(raw(b) >> 33); }  // interposed libc rand()
 
+    // a step run in two halves: the weights of its first half, the per-book hand-over, the step's accumulators
+    std::vector<std::vector<double>> theta_from, theta_b_from;
+    bool have_from = false;
+    std::vector<int> pend_a;
+    std::vector<double> pend_reward;
+    std::vector<char> pend_live;
+    std::vector<double> st_upd, st_rl_q, st_rl_t, st_rl_r;
+    std::vector<char> st_has;
+    double getQ_from(int b, const std::vector<std::vector<int>>& f, int action, bool use_b = false) {
+        if (!have_from) return getQ(b, f, action, use_b);
+        const int i = P.theta_mode == LOB_THETA_PRIVATE ? b : 0;
+        return getQ_t((use_b ? theta_b_from : theta_from)[i].data(), f, action);
+    }
+    int argmaxQ_from(int b, const std::vector<std::vector<int>>& f, bool use_b = false) {
+        if (!have_from) return argmaxQ(b, f, use_b);
+        int index = 0, n_ties = 1;
+        double cur = getQ_from(b, f, 0, use_b);
+        for (int a = 1; a < 9; a++) {
+            double val = getQ_from(b, f, a, use_b);
+            if (val >= cur) {
+                if (val > cur) { cur = val; index = a; }
+                else {
+                    n_ties++;
+                    if (0 == rnd(b) % n_ties) { cur = val; index = a; }
+                }
+            }
+        }
+        return index;
+    }
+    double getQ_t(const double* t, const std::vector<std::vector<int>>& f, int action) {
+        const std::vector<int>& ft = f[action];
+        double Q = 0.0;
+        double w = P.group_weights[0];
+        for (int i = 0; i < 32; i++) Q += w * t[ft[i]];
+        w = P.group_weights[1];
+        for (int i = 32; i < 64; i++) Q += w * t[ft[i]];
+        w = P.group_weights[2];
+        for (int i = 32; i < 96; i++) Q += w * t[ft[i]];
+        return Q;
+    }
     double getQ(int b, const std::vector<std::vector<int>>& f, int action, bool use_b = false) {  // agent.cpp:117-135 / getQb :206-227 (quirk Q3)
         const double* t = use_b ? thb(b) : th(b);
         const std::vector<int>& ft = f[action];
@@ -1106,6 +1146,7 @@ oracle_learner* oracle_create(const lob_params* p, int32_t n_books, const uint32
     o->rng_ctr.assign(n_books, 0);
     o->done.assign(n_books, 0);
     o->recs.resize(n_books);
+    o->pend_a.assign(n_books, 0); o->pend_reward.assign(n_books, 0.0); o->pend_live.assign(n_books, 0);
     o->alpha = p->alpha;
     o->epsilon = p->epsilon;
     o->tau = p->tau;
@@ -1138,91 +1179,105 @@ int oracle_reset(oracle_learner* o) {
     return 0;
 }
 
-int oracle_td_step(oracle_learner* o, int32_t n_steps) {
+static int oracle_td_step_impl(oracle_learner* o, int32_t n_steps, int half) {
     const float rate = (float)(o->P.gamma * o->P.lambda);
     for (int s = 0; s < n_steps; s++) {
-        std::vector<double> upd(o->B, 0.0);
-        std::vector<char> has(o->B, 0);  // 1: update theta, 2: update theta_b
+        std::vector<double>& upd = o->st_upd;
+        std::vector<char>& has = o->st_has;  // 1: update theta, 2: update theta_b
+        if (half != 2) { upd.assign(o->B, 0.0); has.assign(o->B, 0); }
         // R-learning (agent.cpp:357-412): what the rho update after updateQ still needs of the step
         const bool r_learn = o->P.algo == LOB_ALGO_R_LEARN || o->P.algo == LOB_ALGO_ONLINE_R_LEARN || o->P.algo == LOB_ALGO_DOUBLE_R_LEARN;
-        std::vector<double> rl_q(o->B, 0.0), rl_t(o->B, 0.0), rl_r(o->B, 0.0);
+        std::vector<double>&rl_q = o->st_rl_q, &rl_t = o->st_rl_t, &rl_r = o->st_rl_r;
+        if (half != 2) { rl_q.assign(o->B, 0.0); rl_t.assign(o->B, 0.0); rl_r.assign(o->B, 0.0); }
         // read phase: the books are independent (every one reads theta_t / rho_t, draws from its own counter-based
         // stream, writes its own traces and record), so a test may spread them over host threads (ORACLE_THREADS=n;
         // the write phase below stays serial, in book order)
-        auto read_phase = [&](int b_lo, int b_hi, int64_t* n_done) {
-        for (int b = b_lo; b < b_hi; b++) {
-            if (o->done[b]) continue;
+        // first half of a book's step: swap, isTerminal, action, performAction, newState; false: the book does not learn this step
+        auto phase1 = [&](int b) -> bool {
+            o->pend_live[b] = 0;
+            if (o->done[b]) return false;
             Env& e = *o->env[b];
             // swap(state, last_state)
             o->vars[b].swap(o->last_vars[b]);
             o->feats[b].swap(o->last_feats[b]);
-            if (e.isTerminal()) { o->done[b] = 1; continue; }
+            if (e.isTerminal()) { o->done[b] = 1; return false; }
             int a = o->action(b, o->last_feats[b]);
             if (!e.performAction(a)) {
                 o->done[b] = 2;
                 o->recs[b].rng_ctr = o->rng_ctr[b];
                 e.fill(o->recs[b].book);
                 o->recs[b].book.n_traces = (int)o->traces[b].nonzero.size();
-                continue;
+                return false;
             }
             o->new_state(b);
-            double reward = e.getReward();
+            o->pend_a[b] = a;
+            o->pend_reward[b] = e.getReward();
+            o->pend_live[b] = 1;
+            return true;
+        };
+        // second half: HandleTransition.  Q(from_state, .) is what it was when the action was chosen (getQ_from: the weights
+        // of the first half, when a weight exchange has come in between -- oracle_td_step_begin / _end).
+        auto phase2 = [&](int b, int64_t* n_done) {
+            Env& e = *o->env[b];
+            (void)e;
+            const int a = o->pend_a[b];
+            const double reward = o->pend_reward[b];
             // HandleTransition: UpdateTraces, UpdateWeights (agent.cpp:86-115)
             double delta;
             int target = 1;
             if (o->P.algo == LOB_ALGO_DOUBLE_R_LEARN) {
-                int amax = o->argmaxQ(b, o->last_feats[b]);  // DoubleRLearn::UpdateTraces, agent.cpp:422-430
+                int amax = o->argmaxQ_from(b, o->last_feats[b]);  // DoubleRLearn::UpdateTraces, agent.cpp:422-430
                 if (a != amax) o->traces[b].decay(0.0f);
                 else o->traces[b].decay(rate);
                 o->traces[b].update(o->last_feats[b], a, 9, 32);
                 double Q, mQ;
                 if (o->agent_unif[b](o->agent_gen[b]) > 0.5) {  // UPDATE(A), agent.cpp:436-443
-                    Q = o->getQ(b, o->last_feats[b], a);
+                    Q = o->getQ_from(b, o->last_feats[b], a);
                     mQ = o->getQ(b, o->feats[b], o->argmaxQ(b, o->feats[b]), true);
                 } else {  // UPDATE(B)
-                    Q = o->getQ(b, o->last_feats[b], a, true);
+                    Q = o->getQ_from(b, o->last_feats[b], a, true);
                     mQ = o->getQ(b, o->feats[b], o->argmaxQ(b, o->feats[b], true));
                     target = 2;
                 }
                 delta = reward - o->rh(b) + mQ - Q;
                 rl_q[b] = Q; rl_r[b] = reward;
             } else if (o->P.algo == LOB_ALGO_DOUBLE_Q) {
-                int amax = o->argmaxQ(b, o->last_feats[b]);  // DoubleQLearn::UpdateTraces, agent.cpp:319-327
+                int amax = o->argmaxQ_from(b, o->last_feats[b]);  // DoubleQLearn::UpdateTraces, agent.cpp:319-327
                 if (a != amax) o->traces[b].decay(0.0f);
                 else o->traces[b].decay(rate);
                 o->traces[b].update(o->last_feats[b], a, 9, 32);
                 double F_term = o->P.gamma * 0.0 - 0.0;
                 if (o->agent_unif[b](o->agent_gen[b]) > 0.5) {  // UPDATE(A), agent.cpp:334-342
-                    double Qa = o->getQ(b, o->last_feats[b], a);
+                    double Qa = o->getQ_from(b, o->last_feats[b], a);
                     delta = reward + F_term + o->P.gamma * o->getQ(b, o->feats[b], o->argmaxQ(b, o->feats[b]), true) - Qa;
                 } else {  // UPDATE(B)
-                    double Qb = o->getQ(b, o->last_feats[b], a, true);
+                    double Qb = o->getQ_from(b, o->last_feats[b], a, true);
                     delta = reward + F_term + o->P.gamma * o->getQ(b, o->feats[b], o->argmaxQ(b, o->feats[b], true)) - Qb;
                     target = 2;
                 }
             } else if (o->P.algo == LOB_ALGO_R_LEARN) {
-                int amax = o->argmaxQ(b, o->last_feats[b]);  // RLearn::UpdateTraces, agent.cpp:363-371
+                int amax = o->argmaxQ_from(b, o->last_feats[b]);  // RLearn::UpdateTraces, agent.cpp:363-371
                 if (a != amax) o->traces[b].decay(0.0f);
                 else o->traces[b].decay(rate);
                 o->traces[b].update(o->last_feats[b], a, 9, 32);
-                double Q = o->getQ(b, o->last_feats[b], a);  // RLearn::UpdateWeights, agent.cpp:373-380
+                double Q = o->getQ_from(b, o->last_feats[b], a);  // RLearn::UpdateWeights, agent.cpp:373-380
                 double mQ = o->getQ(b, o->feats[b], o->argmaxQ(b, o->feats[b]));
                 delta = reward - o->rh(b) + mQ - Q;
                 rl_q[b] = Q; rl_t[b] = mQ; rl_r[b] = reward;
             } else if (o->P.algo == LOB_ALGO_ONLINE_R_LEARN) {
                 o->traces[b].decay(rate);  // Agent::UpdateTraces, agent.cpp:111-115
                 o->traces[b].update(o->last_feats[b], a, 9, 32);
-                double Q = o->getQ(b, o->last_feats[b], a);  // OnlineRLearn::UpdateWeights, agent.cpp:398-405
+                double Q = o->getQ_from(b, o->last_feats[b], a);  // OnlineRLearn::UpdateWeights, agent.cpp:398-405
                 int a2 = o->action(b, o->feats[b]);
                 double gQ = o->getQ(b, o->feats[b], a2);
                 delta = reward - o->rh(b) + gQ - Q;
                 rl_q[b] = Q; rl_t[b] = gQ; rl_r[b] = reward;
             } else if (o->P.algo == LOB_ALGO_QLAMBDA) {
-                int amax = o->argmaxQ(b, o->last_feats[b]);  // QLearn::UpdateTraces, agent.cpp:272-280
+                int amax = o->argmaxQ_from(b, o->last_feats[b]);  // QLearn::UpdateTraces, agent.cpp:272-280
                 if (a != amax) o->traces[b].decay(0.0f);
                 else o->traces[b].decay(rate);
                 o->traces[b].update(o->last_feats[b], a, 9, 32);
-                double Q = o->getQ(b, o->last_feats[b], a);
+                double Q = o->getQ_from(b, o->last_feats[b], a);
                 double F_term = o->P.gamma * 0.0 - 0.0;
                 int am2 = o->argmaxQ(b, o->feats[b]);  // maxQ(to_state)
                 double mq = o->getQ(b, o->feats[b], am2);
@@ -1230,7 +1285,7 @@ int oracle_td_step(oracle_learner* o, int32_t n_steps) {
             } else {
                 o->traces[b].decay(rate);  // Agent::UpdateTraces, agent.cpp:111-115
                 o->traces[b].update(o->last_feats[b], a, 9, 32);
-                double Q1 = o->getQ(b, o->last_feats[b], a);
+                double Q1 = o->getQ_from(b, o->last_feats[b], a);
                 int a2 = o->action(b, o->feats[b]);
                 double Q2 = o->getQ(b, o->feats[b], a2);
                 double F = o->P.gamma * 0.0 - 0.0;
@@ -1240,7 +1295,13 @@ int oracle_td_step(oracle_learner* o, int32_t n_steps) {
             has[b] = (char)target;
             ++*n_done;
             o->record(b, a, reward, delta);
-        }
+        };
+        auto read_phase = [&](int b_lo, int b_hi, int64_t* n_done) {
+            for (int b = b_lo; b < b_hi; b++) {
+                if (half != 2) { if (!phase1(b)) continue; }
+                else if (!o->pend_live[b]) continue;
+                if (half != 1) phase2(b, n_done);
+            }
         };
         {
             static const int n_thr_env = getenv("ORACLE_THREADS") ? atoi(getenv("ORACLE_THREADS")) : 1;
@@ -1254,6 +1315,12 @@ int oracle_td_step(oracle_learner* o, int32_t n_steps) {
                 for (auto& th : pool) th.join();
             }
             for (int64_t c : done_cnt) o->n_steps_done += c;
+        }
+        if (half == 1) {  // the weights Q(from_state, .) was evaluated under
+            o->theta_from = o->theta;
+            o->theta_b_from = o->theta_b;
+            o->have_from = true;
+            continue;
         }
         // write phase: updateQ (agent.cpp:137-142) for every book, book order
         for (int b = 0; b < o->B; b++) {
@@ -1290,6 +1357,18 @@ int oracle_td_step(oracle_learner* o, int32_t n_steps) {
         }
     }
     return 0;
+}
+
+int oracle_td_step(oracle_learner* o, int32_t n_steps) { return oracle_td_step_impl(o, n_steps, 0); }
+// One step in two halves (lob_td_step_begin / lob_td_step_end): whatever changes the weights in between (a multi-GPU
+// exchange) is seen by the second half's evaluations of the NEW state only.
+int oracle_td_step_begin(oracle_learner* o) { return oracle_td_step_impl(o, 1, 1); }
+int oracle_td_step_end(oracle_learner* o) {
+    const int rc = oracle_td_step_impl(o, 1, 2);
+    o->have_from = false;
+    o->theta_from.clear(); o->theta_from.shrink_to_fit();
+    o->theta_b_from.clear(); o->theta_b_from.shrink_to_fit();
+    return rc;
 }
 
 int oracle_eval_step(oracle_learner* o, int32_t n_steps) {  // Backtester::_step, serial.cpp:124-137

@@ -50,6 +50,9 @@ oracle_learner* oracle_create(const lob_params* p, int32_t n_books, const uint32
 void oracle_destroy(oracle_learner* o);
 int oracle_reset(oracle_learner* o);                       /* Runner::RunEpisode prologue */
 int oracle_td_step(oracle_learner* o, int32_t n_steps);    /* n x Learner::_step */
+/* one step in two halves (lob_td_step_begin / _end): a change of the weights in between reaches only the new state's Q */
+int oracle_td_step_begin(oracle_learner* o);
+int oracle_td_step_end(oracle_learner* o);
 int oracle_eval_step(oracle_learner* o, int32_t n_steps);  /* n x Backtester::_step */
 int oracle_env_step(oracle_learner* o, const int32_t* actions); /* performAction only */
 int oracle_clear_inventory(oracle_learner* o);

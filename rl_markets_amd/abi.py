@@ -157,6 +157,8 @@ def load():
         "lob_get_book": (C.c_int, [vp, C.c_int32, P(BookDump)]),
         "lob_get_books": (C.c_int, [vp, C.c_int32, C.c_int32, vp]),
         "lob_td_step": (C.c_int, [vp, C.c_int32]),
+        "lob_td_step_begin": (C.c_int, [vp]),
+        "lob_td_step_end": (C.c_int, [vp]),
         "lob_eval_step": (C.c_int, [vp, C.c_int32]),
         "lob_handle_terminal": (C.c_int, [vp]),
         "lob_set_alpha": (C.c_int, [vp, C.c_double]),
@@ -178,6 +180,10 @@ def load():
         "lob_delta_begin": (C.c_int, [vp, P(vp), P(C.c_int64)]),
         "lob_delta_begin_async": (C.c_int, [vp, P(vp), P(C.c_int64)]),
         "lob_delta_apply": (C.c_int, [vp]),
+        "lob_delta_sparse_supported": (C.c_int, [vp]),
+        "lob_delta_sparse_maps": (C.c_int, [vp, C.c_int32, P(vp), P(vp), P(C.c_int64)]),
+        "lob_delta_sparse_pack": (C.c_int, [vp, C.c_int32, P(vp), P(C.c_int64)]),
+        "lob_delta_sparse_apply": (C.c_int, [vp]),
         "lob_sync": (C.c_int, [vp]),
         "lob_stream": (vp, [vp]),
         "lob_kernel_time_ms": (C.c_int, [vp, C.c_char_p, P(C.c_double), P(C.c_int64)]),

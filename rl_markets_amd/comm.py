@@ -35,6 +35,9 @@ def load():
         "lob_comm_reduce_host_f64": (C.c_int, [vp, vp, C.c_int32, C.c_int32]),
         "lob_comm_barrier": (C.c_int, [vp]),
         "lob_theta_allreduce": (C.c_int, [vp, vp]),
+        "lob_comm_allgather_u32": (C.c_int, [vp, vp, vp, C.c_int64, vp]),
+        "lob_comm_pin_host_thread": (C.c_int, [C.c_int32, P(C.c_int32)]),
+        "lob_comm_exchange_stats": (C.c_int, [vp, P(C.c_double)]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)
@@ -82,3 +85,18 @@ class RcclComm:
 
     def barrier(self):
         self._check(self.lib.lob_comm_barrier(self.h))
+
+    def exchange_stats(self):
+        """Cost of the exchanges since the last call (HIP events on the engine's stream)."""
+        out = (C.c_double * 7)()
+        self._check(self.lib.lob_comm_exchange_stats(self.h, out))
+        n = max(out[0], 1.0)
+        return {"exchanges": int(out[0]), "pack_ms": out[1] / n, "collectives_ms": out[2] / n, "apply_ms": out[3] / n,
+                "bytes_per_exchange": out[4] / n, "sparse": int(out[5]), "rccl_world": int(out[6])}
+
+
+def pin_host_thread(device):
+    """Bind this process's main thread to the cores next to GPU `device`; returns how many (0: left alone)."""
+    n = C.c_int32(0)
+    load().lob_comm_pin_host_thread(int(device), C.byref(n))
+    return n.value

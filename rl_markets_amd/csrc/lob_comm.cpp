@@ -6,19 +6,25 @@
 #include <stdio.h>
 #include <string.h>
 #include <fcntl.h>
+#include <sched.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
 #include <chrono>
 #include <string>
 #include <thread>
+#include <vector>
 
 #include "../../include/lob_comm.h"
 #include "lob_internal.h"
 
 static_assert(sizeof(ncclUniqueId) == LOB_COMM_ID_BYTES, "rendezvous token size");
 
+// the phases of one exchange, stamped on the engine's stream (read back by lob_comm_exchange_stats)
+struct ExchangeStamp { hipEvent_t ev[4]; int64_t bytes; int sparse; };
+
 struct lob_comm {
+    std::vector<ExchangeStamp> stamps;
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1, device = 0;
     hipStream_t stream = nullptr;  // for the small host-side reductions
@@ -120,6 +126,35 @@ int lob_comm_create_file(const char* path, int32_t rank, int32_t world, int32_t 
     return rc;
 }
 
+// Bind the calling thread to the cores next to GPU `device` (its PCIe function's local_cpulist in sysfs): launches, the
+// exchange's one synchronisation and the event reads then never cross a socket.  Best effort: LOB_OK with *n_cpus = 0 when the
+// topology cannot be read.
+int lob_comm_pin_host_thread(int32_t device, int32_t* n_cpus) {
+    if (n_cpus) *n_cpus = 0;
+    char bdf[64] = {0};
+    if (hipDeviceGetPCIBusId(bdf, sizeof bdf, device) != hipSuccess) return LOB_OK;
+    for (char* p = bdf; *p; p++) if (*p >= 'A' && *p <= 'F') *p = (char)(*p - 'A' + 'a');
+    const std::string path = std::string("/sys/bus/pci/devices/") + bdf + "/local_cpulist";
+    FILE* f = fopen(path.c_str(), "r");
+    if (!f) return LOB_OK;
+    char line[1024] = {0};
+    const bool got = fgets(line, sizeof line, f) != nullptr;
+    fclose(f);
+    if (!got) return LOB_OK;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    int n = 0;
+    for (char* tok = strtok(line, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+        int a = 0, b = 0;
+        const int k = sscanf(tok, "%d-%d", &a, &b);
+        if (k == 1) b = a;
+        if (k < 1) continue;
+        for (int i = a; i <= b && i < CPU_SETSIZE; i++) { CPU_SET(i, &set); n++; }
+    }
+    if (n > 0 && sched_setaffinity(0, sizeof set, &set) == 0 && n_cpus) *n_cpus = n;
+    return LOB_OK;
+}
+
 void lob_comm_destroy(lob_comm* c) {
     if (!c) return;
     hipSetDevice(c->device);
@@ -154,15 +189,77 @@ int lob_comm_barrier(lob_comm* c) {
     return lob_comm_reduce_host_f64(c, &z, 1, LOB_COMM_SUM);
 }
 
+int lob_comm_allgather_u32(lob_comm* c, const uint32_t* dev_send, uint32_t* dev_recv, int64_t count, void* hip_stream) {
+    if (!c || !dev_send || !dev_recv || count < 0) { lob_set_error("lob_comm_allgather_u32: bad argument"); return LOB_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    NCCLCHK(ncclAllGather(dev_send, dev_recv, (size_t)count, ncclUint32, c->comm, (hipStream_t)hip_stream));
+    return LOB_OK;
+}
+
+static hipEvent_t new_event() { hipEvent_t e; hipEventCreateWithFlags(&e, hipEventDisableSystemFence); return e; }
+
 int lob_theta_allreduce(lob_engine* e, lob_comm* c) {
     if (!e || !c) { lob_set_error("lob_theta_allreduce: bad argument"); return LOB_EINVAL; }
-    double* delta = nullptr;
-    int64_t count = 0;
-    int rc = lob_delta_begin_async(e, &delta, &count);  // delta = theta - theta_sync, on the engine stream
-    if (rc) return rc;
-    rc = lob_comm_allreduce_f64(c, delta, count, lob_stream(e));
-    if (rc) return rc;
-    return lob_delta_apply(e);                          // theta = theta_sync + sum(delta); theta_sync = theta
+    hipStream_t st = (hipStream_t)lob_stream(e);
+    static const bool dense_forced = getenv("LOB_DENSE_EXCHANGE") && getenv("LOB_DENSE_EXCHANGE")[0] == '1';
+    ExchangeStamp x;
+    for (auto& v : x.ev) v = new_event();
+    int rc;
+    hipEventRecord(x.ev[0], st);
+    if (!dense_forced && lob_delta_sparse_supported(e)) {
+        // maps all-gathered -> union -> packed deltas all-reduced -> scattered back (include/lob_engine.h)
+        uint32_t *own = nullptr, *gather = nullptr;
+        int64_t words = 0;
+        rc = lob_delta_sparse_maps(e, c->world, &own, &gather, &words);
+        if (rc) return rc;
+        rc = lob_comm_allgather_u32(c, own, gather, words, st);
+        if (rc) return rc;
+        double* buf = nullptr;
+        int64_t count = 0;
+        rc = lob_delta_sparse_pack(e, c->world, &buf, &count);
+        if (rc) return rc;
+        hipEventRecord(x.ev[1], st);
+        if (count > 0) rc = lob_comm_allreduce_f64(c, buf, count, st);
+        if (rc) return rc;
+        hipEventRecord(x.ev[2], st);
+        rc = lob_delta_sparse_apply(e);
+        x.bytes = count * 8 + words * 4 * c->world;
+        x.sparse = 1;
+    } else {
+        double* delta = nullptr;
+        int64_t count = 0;
+        rc = lob_delta_begin_async(e, &delta, &count);  // delta = theta - theta_sync, on the engine stream
+        if (rc) return rc;
+        hipEventRecord(x.ev[1], st);
+        rc = lob_comm_allreduce_f64(c, delta, count, st);
+        if (rc) return rc;
+        hipEventRecord(x.ev[2], st);
+        rc = lob_delta_apply(e);                          // theta = theta_sync + sum(delta); theta_sync = theta
+        x.bytes = count * 8;
+        x.sparse = 0;
+    }
+    hipEventRecord(x.ev[3], st);
+    c->stamps.push_back(x);
+    return rc;
+}
+
+int lob_comm_exchange_stats(lob_comm* c, double out[7]) {
+    if (!c || !out) return LOB_EINVAL;
+    HIPCHK(hipSetDevice(c->device));
+    for (int i = 0; i < 7; i++) out[i] = 0.0;
+    for (auto& x : c->stamps) {
+        hipEventSynchronize(x.ev[3]);
+        float a = 0, b = 0, d = 0;
+        hipEventElapsedTime(&a, x.ev[0], x.ev[1]);
+        hipEventElapsedTime(&b, x.ev[1], x.ev[2]);
+        hipEventElapsedTime(&d, x.ev[2], x.ev[3]);
+        out[0] += 1.0; out[1] += a; out[2] += b; out[3] += d; out[4] += (double)x.bytes; out[5] += x.sparse;
+        for (auto& v : x.ev) hipEventDestroy(v);
+    }
+    c->stamps.clear();
+    int n = 0;
+    if (ncclCommCount(c->comm, &n) == ncclSuccess) out[6] = n;  // ranks as RCCL sees them
+    return LOB_OK;
 }
 
 }  // extern "C"

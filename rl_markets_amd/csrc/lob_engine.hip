@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -54,6 +55,7 @@ struct lob_engine {
     bool chunked = false;       // the loaded stream is longer than the ring
     int steps_since_fill = 0;
     uint64_t theta_ver = 1;     // bumped whenever theta changes: memo records carry the version they were computed under
+    bool half_open = false;     // between lob_td_step_begin and lob_td_step_end
     bool hits_ok = false;       // the previous call was a fast-path learner step and nothing has touched weights, maps or states since:
                                 // the hit lists its learn kernel left are those of the States the next step acts on (act_light_kernel)
     bool light = true;          // use them (LOB_NO_LIGHT=1: always the full act kernel, for A/B runs)
@@ -66,6 +68,15 @@ struct lob_engine {
     int q_lanes = -1;           // learn_q_lane_kernel (a lane per book) instead of learn_q_fast_kernel (a wave per book): -1 by batch size,
                                 // 0 / 1 forced (LOB_Q_LANES)
     std::vector<void*> allocs;
+    // sparse weight exchange (lob_delta_sparse_*): the ranks' gathered maps, their union, per-block counts / offsets, the packed deltas
+    uint32_t* spx_gather = nullptr;
+    int spx_world = 0;
+    uint32_t* spx_union = nullptr;
+    i32* spx_block_cnt = nullptr;
+    i64* spx_block_off = nullptr;
+    i64* spx_total = nullptr;
+    f64* spx_buf = nullptr;
+    int64_t spx_cap = 0, spx_count = 0;
     uint32_t* rnd_dev = nullptr;
     uint32_t* records_dev = nullptr;
     i64* phase_dev = nullptr;  // replayed stream: first record of every book's window
@@ -519,6 +530,8 @@ void lob_destroy(lob_engine* e) {
     if (e->phase_dev) hipFree(e->phase_dev);
     if (e->track_dev) hipFree(e->track_dev);
     if (e->dump_dev) hipFree(e->dump_dev);
+    if (e->spx_gather) hipFree(e->spx_gather);
+    if (e->spx_buf) hipFree(e->spx_buf);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
 }
@@ -842,21 +855,26 @@ static int acc_lanes_shift(const lob_engine* e) {
     return 5;
 }
 
-static int run_steps(lob_engine* e, int32_t n_steps, int mode) {
+// `half`: 0 = whole steps; 1 = the first half of ONE learner step (action selection + performAction), 2 = its second half
+// (memo, traces, TD errors, update) -- lob_td_step_begin / lob_td_step_end: a weight exchange fits between the two, where
+// no hit list is live (the step's action has consumed the previous step's, the learn kernel builds the next under
+// whatever maps it then finds).
+static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
+    const bool first = half != 2, second = half != 1;
     HIPCHK(hipSetDevice(e->device));
     const int G = e->B >= 1024 ? e->n_groups : 1;  // small batches: one group (an empty group would be an empty launch)
     const uint32_t* rnd = (const uint32_t*)e->rnd_dev;
     for (int s = 0; s < n_steps; s++) {
         // double-buffered list of newly written weights (verdict carry-over, lob_state.h)
-        const int par = mode == 0 ? (e->td_parity ^= 1) : 0;
-        e->step_id++;
+        const int par = mode == 0 ? (first ? (e->td_parity ^= 1) : e->td_parity) : 0;
+        if (first) e->step_id++;
         const u64 ver = (u64)e->theta_ver;
         if (G > 1) {
             HIPCHK(hipEventRecord(e->ev_fork, e->stream));
             HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
         }
         const bool fast = e->P.memo != 0;  // (implies one group)
-        const int lpar = (e->list_par ^= 1);
+        const int lpar = first ? (e->list_par ^= 1) : e->list_par;
         e->last_par = par;
         for (int g = 0; g < G; g++) {
             hipStream_t st = g == 0 ? e->stream : e->stream2;
@@ -868,6 +886,7 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode) {
             const i32* act_n = e->S.slow_n + lpar * 2, *learn_n = e->S.slow_n + lpar * 2 + 1;
             // stagger: group 1 starts acting when group 0 has finished acting, so that the
             // latency-bound env kernel of one group runs beside a gather kernel of the other
+            if (first) {
             if (G > 1 && g == 1) HIPCHK(hipStreamWaitEvent(st, e->ev_stagger, 0));
             // (big batches, env_kernel<64>: the action selection rides in the env kernel)
             const bool fused_act = fast && mode == 0 && e->hits_ok && e->light && e->fuse_act && e->env_lanes == 0 && (e->B > 16384 || e->force_fuse_act);
@@ -895,6 +914,8 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode) {
                 TimedLaunch t(e, "env_kernel", st);
                 launch_env(e, st, (const i32*)nullptr, mode == 0 ? 1 : 0, b0, nb, par);
             }
+            }  // first half
+            if (!second) continue;
             if (fast) launch_memo(e, par, mode == 0 ? 0 : 1);  // learner: S0 under theta_t for learn_kernel; backtester: for the next act
             if (mode == 0 && fast) {
                 const bool tl = e->P.algo == LOB_ALGO_QLAMBDA && e->t_light;
@@ -954,6 +975,8 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode) {
             HIPCHK(hipEventRecord(e->ev_join, e->stream2));
             HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join, 0));
         }
+        if (!second) { e->half_open = true; continue; }
+        e->half_open = false;
         if (mode == 0 && e->P.combine) {
             {
                 TimedLaunch t(e, "accumulate_kernel");
@@ -992,12 +1015,27 @@ int lob_td_step(lob_engine* e, int32_t n_steps) {
     int rc = need_reset(e, "lob_td_step");
     if (rc) return rc;
     if (n_steps < 0) return LOB_EINVAL;
+    if (e->half_open) { lob_set_error("lob_td_step: a step is half done (lob_td_step_begin without lob_td_step_end)"); return LOB_ESTATE; }
     return run_steps(e, n_steps, 0);
+}
+int lob_td_step_begin(lob_engine* e) {
+    int rc = need_reset(e, "lob_td_step_begin");
+    if (rc) return rc;
+    if (e->half_open) { lob_set_error("lob_td_step_begin: the previous step has not been ended"); return LOB_ESTATE; }
+    if (e->B >= 1024 && e->n_groups > 1) { lob_set_error("lob_td_step_begin: not with two book groups (LOB_GROUPS=2)"); return LOB_ESTATE; }
+    return run_steps(e, 1, 0, 1);
+}
+int lob_td_step_end(lob_engine* e) {
+    int rc = need_reset(e, "lob_td_step_end");
+    if (rc) return rc;
+    if (!e->half_open) { lob_set_error("lob_td_step_end: no step begun"); return LOB_ESTATE; }
+    return run_steps(e, 1, 0, 2);
 }
 int lob_eval_step(lob_engine* e, int32_t n_steps) {
     int rc = need_reset(e, "lob_eval_step");
     if (rc) return rc;
     if (n_steps < 0) return LOB_EINVAL;
+    if (e->half_open) { lob_set_error("lob_eval_step: a learner step is half done"); return LOB_ESTATE; }
     return run_steps(e, n_steps, 1);
 }
 
@@ -1217,7 +1255,9 @@ int lob_delta_apply(lob_engine* e) {
     const size_t M = (size_t)e->P.M;
     const int nv = delta_vectors(e);
     e->theta_ver++;  // memo records computed under the pre-exchange weights are void
-    e->hits_ok = false;
+    // between lob_td_step_begin and lob_td_step_end no hit list is live and the step's own memo launches follow: nothing to void
+    const bool mid_step = e->half_open;
+    if (!mid_step) e->hits_ok = false;
     for (int v = 0; v < nv; v++) {
         TimedLaunch t(e, "delta_apply_kernel", nullptr, true);
         hipLaunchKernelGGL(delta_apply_kernel, dim3(2048), dim3(256), 0, e->stream, v ? e->S.theta_b : e->S.theta, e->S.theta_sync + v * M,
@@ -1226,7 +1266,82 @@ int lob_delta_apply(lob_engine* e) {
     }
     if (delta_extra(e))
         hipLaunchKernelGGL(rho_delta_apply_kernel, dim3(1), dim3(1), 0, e->stream, e->S.rho, e->S.theta_sync + M * nv, (const f64*)(e->S.delta + M * nv));
-    if (e->P.memo) launch_memo(e, e->last_par, 1);  // the current triples under the exchanged weights
+    if (e->P.memo && !mid_step) launch_memo(e, e->last_par, 1);  // the current triples under the exchanged weights
+    HIPCHK(hipGetLastError());
+    return LOB_OK;
+}
+
+// ---- sparse exchange (include/lob_engine.h) ------------------------------------------------------------------------------
+static int64_t spx_words(const lob_engine* e) { return (int64_t)((size_t)e->P.M / 32 + 1); }
+int lob_delta_sparse_supported(lob_engine* e) { return e && e->P.memo && e->S.theta_sync && e->S.theta_nzx ? 1 : 0; }
+int lob_delta_sparse_maps(lob_engine* e, int32_t world, uint32_t** dev_own, uint32_t** dev_gather, int64_t* words) {
+    if (!e || world < 1 || !dev_own || !dev_gather || !words) return LOB_EINVAL;
+    if (!lob_delta_sparse_supported(e)) { lob_set_error("lob_delta_sparse_*: needs the shared-theta fast path and lob_delta_init"); return LOB_ESTATE; }
+    HIPCHK(hipSetDevice(e->device));
+    const int64_t W = spx_words(e);
+    if (e->spx_world < world) {
+        if (e->spx_gather) { hipFree(e->spx_gather); e->spx_gather = nullptr; }
+        HIPCHK(hipMalloc((void**)&e->spx_gather, (size_t)world * W * 4));
+        e->spx_world = world;
+    }
+    if (!e->spx_union) {
+        const int nb = (int)((W + LOB_SPX_BLOCK - 1) / LOB_SPX_BLOCK);
+        int rc = dev_alloc(e, &e->spx_union, (size_t)W);
+        if (rc == LOB_OK) rc = dev_alloc(e, &e->spx_block_cnt, (size_t)nb);
+        if (rc == LOB_OK) rc = dev_alloc(e, &e->spx_block_off, (size_t)nb);
+        if (rc == LOB_OK) rc = dev_alloc(e, &e->spx_total, 1);
+        if (rc != LOB_OK) return rc;
+    }
+    *dev_own = e->S.theta_nzx;
+    *dev_gather = e->spx_gather;
+    *words = W;
+    return LOB_OK;
+}
+int lob_delta_sparse_pack(lob_engine* e, int32_t world, double** dev_buf, int64_t* count) {
+    if (!e || !dev_buf || !count || world < 1 || world > e->spx_world) return LOB_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    const int64_t W = spx_words(e);
+    const int nb = (int)((W + LOB_SPX_BLOCK - 1) / LOB_SPX_BLOCK);
+    {
+        TimedLaunch t(e, "delta_begin_kernel", nullptr, true);
+        hipLaunchKernelGGL(sparse_union_kernel, dim3(nb), dim3(LOB_SPX_BLOCK), 0, e->stream, (const uint32_t*)e->spx_gather, (int)world, (i64)W, e->spx_union, e->spx_block_cnt);
+        hipLaunchKernelGGL(sparse_scan_kernel, dim3(1), dim3(1024), 0, e->stream, (const i32*)e->spx_block_cnt, nb, e->spx_block_off, e->spx_total);
+    }
+    // the collective needs the element count on the host: the one synchronisation of an exchange
+    i64 total = 0;
+    HIPCHK(hipMemcpyAsync(&total, e->spx_total, sizeof total, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (total > e->spx_cap) {
+        if (e->spx_buf) { hipFree(e->spx_buf); e->spx_buf = nullptr; }
+        const int64_t cap = std::max<int64_t>(2 * total, 1 << 20);
+        HIPCHK(hipMalloc((void**)&e->spx_buf, (size_t)cap * 8));
+        e->spx_cap = cap;
+    }
+    e->spx_count = total;
+    {
+        TimedLaunch t(e, "delta_begin_kernel", nullptr, true);
+        hipLaunchKernelGGL(sparse_pack_kernel, dim3(nb), dim3(LOB_SPX_BLOCK), 0, e->stream, (const uint32_t*)e->spx_union, (i64)W, (const i64*)e->spx_block_off,
+                           (const f64*)e->S.theta, (const f64*)e->S.theta_sync, e->spx_buf);
+    }
+    HIPCHK(hipGetLastError());
+    *dev_buf = e->spx_buf;
+    *count = total;
+    return LOB_OK;
+}
+int lob_delta_sparse_apply(lob_engine* e) {
+    if (!e || !e->spx_union) return LOB_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    const int64_t W = spx_words(e);
+    const int nb = (int)((W + LOB_SPX_BLOCK - 1) / LOB_SPX_BLOCK);
+    e->theta_ver++;  // memo records computed under the pre-exchange weights are void
+    const bool mid_step = e->half_open;  // (see lob_delta_apply)
+    if (!mid_step) e->hits_ok = false;
+    if (e->spx_count > 0) {
+        TimedLaunch t(e, "delta_apply_kernel", nullptr, true);
+        hipLaunchKernelGGL(sparse_apply_kernel, dim3(nb), dim3(LOB_SPX_BLOCK), 0, e->stream, (const uint32_t*)e->spx_union, (i64)W, (const i64*)e->spx_block_off,
+                           e->S.theta, e->S.theta_sync, (const f64*)e->spx_buf, e->S.theta_nz, e->S.nz_epoch, e->S.theta_nzx, e->S.theta_nzc, e->P.cshift);
+    }
+    if (e->P.memo && !mid_step) launch_memo(e, e->last_par, 1);  // the current triples under the exchanged weights
     HIPCHK(hipGetLastError());
     return LOB_OK;
 }

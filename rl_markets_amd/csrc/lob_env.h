@@ -1254,7 +1254,11 @@ __device__ inline int event_loop_fast(const EnvCtx& c, EnvR& e, StepAgg& g, TE& 
     while (true) {
         // the next event's entry and first row are requested a pass ahead -- unless the entry says the step ends with this
         // event (LOB_TRK_STEP_END: a hint from the pre-pass; when it is wrong the loop fetches what it needs on the spot)
+#ifdef LOB_NO_STEP_HINT  /* (A/B: always prefetch) */
+        const bool more = true;
+#else
         const bool more = !(t.info & LOB_TRK_STEP_END);
+#endif
         TE tn;
         if (more) tn = *reinterpret_cast<const TE*>(&c.track(h.k + 1));
         // the fast pass needs: the event inside the track, freshly placed orders behind it, its trade list whole, and the row

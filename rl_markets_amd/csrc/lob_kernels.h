@@ -1498,6 +1498,105 @@ __global__ void delta_apply_kernel(f64* theta, f64* sync, const f64* __restrict_
         }
     }
 }
+// ---- sparse weight exchange (shared theta on the fast path) ---------------------------------------------------------------
+// The exact written-weights map theta_nzx (one bit per weight, 2.5 MB at M = 20 M) enumerates every weight a step of this
+// rank has touched or is about to: a few hundred thousand of 20 M.  The ranks all-gather their maps; the UNION, in index
+// order, defines one compact vector layout common to all ranks; each rank packs theta - theta_sync of those weights into
+// it, ONE all-reduce (f64, SUM) of |union| doubles replaces the dense one of M, and the result is scattered back.  Every
+// weight whose delta is non-zero on some rank has its bit set there, so the sum equals the dense exchange's term by term.
+#define LOB_SPX_BLOCK 256
+// union of the gathered maps + set bits per block
+__global__ void __launch_bounds__(LOB_SPX_BLOCK) sparse_union_kernel(const uint32_t* __restrict__ gathered, int world, i64 words, uint32_t* u_map, i32* block_cnt) {
+    __shared__ i32 red[LOB_SPX_BLOCK / 64];
+    const i64 w = (i64)blockIdx.x * LOB_SPX_BLOCK + threadIdx.x;
+    uint32_t u = 0;
+    if (w < words) {
+        for (int r = 0; r < world; r++) u |= gathered[(size_t)r * words + w];
+        u_map[w] = u;
+    }
+    i32 c = __builtin_popcount(u);
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        i32 t = 0;
+        for (int i = 0; i < LOB_SPX_BLOCK / 64; i++) t += red[i];
+        block_cnt[blockIdx.x] = t;
+    }
+}
+// exclusive scan of the block counts (one block; a few thousand entries) + the total
+__global__ void __launch_bounds__(1024) sparse_scan_kernel(const i32* __restrict__ block_cnt, int n_blocks, i64* block_off, i64* total) {
+    __shared__ i64 part[1024];
+    const int per = (n_blocks + 1023) / 1024;
+    const int lo = threadIdx.x * per, hi = lo + per < n_blocks ? lo + per : n_blocks;
+    i64 s = 0;
+    for (int i = lo; i < hi; i++) s += block_cnt[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        i64 run = 0;
+        for (int i = 0; i < 1024; i++) { const i64 v = part[i]; part[i] = run; run += v; }
+        *total = run;
+    }
+    __syncthreads();
+    i64 run = part[threadIdx.x];
+    for (int i = lo; i < hi; i++) { block_off[i] = run; run += block_cnt[i]; }
+}
+// position of a word's first set bit in the compact vector: block offset + exclusive prefix of the popcounts inside the block
+__device__ inline i64 sparse_word_base(uint32_t u, const i64* block_off, i32* lds) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const i32 c = __builtin_popcount(u);
+    i32 incl = c;
+    for (int off = 1; off < 64; off <<= 1) {
+        const i32 v = __shfl_up(incl, off);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) lds[wv] = incl;
+    __syncthreads();
+    i32 before = 0;
+    for (int i = 0; i < wv; i++) before += lds[i];
+    return block_off[blockIdx.x] + before + incl - c;
+}
+__global__ void __launch_bounds__(LOB_SPX_BLOCK) sparse_pack_kernel(const uint32_t* __restrict__ u_map, i64 words, const i64* __restrict__ block_off,
+                                                                    const f64* __restrict__ theta, const f64* __restrict__ sync, f64* buf) {
+    __shared__ i32 lds[LOB_SPX_BLOCK / 64];
+    const i64 w = (i64)blockIdx.x * LOB_SPX_BLOCK + threadIdx.x;
+    uint32_t u = w < words ? u_map[w] : 0u;
+    i64 p = sparse_word_base(u, block_off, lds);
+    while (u) {
+        const i64 f = (w << 5) + __builtin_ctz(u);
+        u &= u - 1;
+        buf[p++] = theta[f] - sync[f];
+    }
+}
+// theta = theta_sync + sum(delta), theta_sync = theta for the weights of the union; the maps take the union's bits (a set bit
+// only means "fetch the weight": a weight another rank marked but has not written yet reads as +0.0)
+__global__ void __launch_bounds__(LOB_SPX_BLOCK) sparse_apply_kernel(const uint32_t* __restrict__ u_map, i64 words, const i64* __restrict__ block_off,
+                                                                     f64* theta, f64* sync, const f64* __restrict__ buf, uint32_t* nz, i32* nz_epoch,
+                                                                     uint32_t* nzx, uint32_t* nzc, int cshift) {
+    __shared__ i32 lds[LOB_SPX_BLOCK / 64];
+    const i64 w = (i64)blockIdx.x * LOB_SPX_BLOCK + threadIdx.x;
+    if (w == 0) atomicAdd(nz_epoch, 1);  // verdicts saved before this exchange are stale
+    const uint32_t u0 = w < words ? u_map[w] : 0u;
+    uint32_t u = u0;
+    i64 p = sparse_word_base(u, block_off, lds);
+    uint32_t nzm = 0;
+    while (u) {
+        const i64 f = (w << 5) + __builtin_ctz(u);
+        u &= u - 1;
+        const f64 t = sync[f] + buf[p++];
+        theta[f] = t;
+        sync[f] = t;
+        nzm |= LOB_NZ_BIT(f);
+    }
+    if (u0) {
+        if (nzx[w] != u0) nzx[w] = nzx[w] | u0;  // (this thread owns the word; the rank's own bits are part of the union)
+        const i64 f0 = w << 5;  // the 32 weights of a word share their coarse bit (cshift >= 5) and their word of the 1-in-8 map
+        const uint32_t c = (uint32_t)(f0 >> cshift);
+        if (!(nzc[c >> 5] & (1u << (c & 31)))) atomicOr(&nzc[c >> 5], 1u << (c & 31));
+        if ((nz[LOB_NZ_WORD(f0)] & nzm) != nzm) atomicOr(&nz[LOB_NZ_WORD(f0)], nzm);
+    }
+}
 // the fast path's maps after lob_theta_set (both cleared by the caller first): bit = (theta != +0.0 bitwise)
 __global__ void rebuild_nzx_kernel(const f64* __restrict__ theta, uint32_t* nzx, uint32_t* nzc, int cshift, i64 M) {
     i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;

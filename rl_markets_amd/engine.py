@@ -165,6 +165,13 @@ class Engine:
     def td_step(self, n=1):
         self._check(self.lib.lob_td_step(self.h, n))
 
+    def td_step_begin(self):
+        """First half of one learner step (action selection + performAction); a weight exchange fits before td_step_end."""
+        self._check(self.lib.lob_td_step_begin(self.h))
+
+    def td_step_end(self):
+        self._check(self.lib.lob_td_step_end(self.h))
+
     def eval_step(self, n=1):
         self._check(self.lib.lob_eval_step(self.h, n))
 
@@ -252,6 +259,23 @@ class Engine:
 
     def delta_apply(self):
         self._check(self.lib.lob_delta_apply(self.h))
+
+    # sparse exchange (include/lob_engine.h lob_delta_sparse_*): device pointers as ints
+    def delta_sparse_supported(self):
+        return bool(self.lib.lob_delta_sparse_supported(self.h))
+
+    def delta_sparse_maps(self, world):
+        own, gather, words = C.c_void_p(), C.c_void_p(), C.c_int64()
+        self._check(self.lib.lob_delta_sparse_maps(self.h, int(world), C.byref(own), C.byref(gather), C.byref(words)))
+        return own.value, gather.value, words.value
+
+    def delta_sparse_pack(self, world):
+        p, n = C.c_void_p(), C.c_int64()
+        self._check(self.lib.lob_delta_sparse_pack(self.h, int(world), C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def delta_sparse_apply(self):
+        self._check(self.lib.lob_delta_sparse_apply(self.h))
 
     def sync(self):
         self._check(self.lib.lob_sync(self.h))

@@ -377,14 +377,23 @@ protected:
     bool _step(Agent*) override {
         int n = steps_per_call_;
         if (comm_ && since_sync_ + n > (unsigned long)sync_every_) n = (int)(sync_every_ - since_sync_);
-        check(lob_td_step(environment.handle(), n), "Learner::_step");
+        const bool sync_now = comm_ && since_sync_ + n >= (unsigned long)sync_every_;
+        if (!sync_now) {
+            check(lob_td_step(environment.handle(), n), "Learner::_step");
+        } else {
+            // the sync step carries the exchange between its two halves: no cached action-selection data is live there
+            // (include/lob_engine.h lob_td_step_begin)
+            if (n > 1) check(lob_td_step(environment.handle(), n - 1), "Learner::_step");
+            check(lob_td_step_begin(environment.handle()), "Learner::_step");
+            check(lob_theta_allreduce(environment.handle(), comm_), "Learner::_step (weight exchange)");
+            check(lob_td_step_end(environment.handle()), "Learner::_step");
+        }
         environment.invalidate();
         _step_counter += n;
         if (!comm_) return n_live() == 0;
         since_sync_ += n;
-        if (since_sync_ < (unsigned long)sync_every_) return false;
+        if (!sync_now) return false;
         since_sync_ = 0;
-        check(lob_theta_allreduce(environment.handle(), comm_), "Learner::_step (weight exchange)");
         // every rank keeps stepping (a no-op for finished books) until NO rank has a live book:
         // the exchange is a collective, all ranks must leave the episode at the same sync point
         double live = (double)n_live();

@@ -8,14 +8,14 @@ sets theta = theta_sync + sum(delta).  This is the batched analogue of the
 reference's unlocked shared-Agent threads (reference src/main.cpp:196-206) at
 sync granularity.
 
-``comm`` is what carries the exchange:
-  * rl_markets_amd.comm.RcclComm -- the product: one RCCL all-reduce over xGMI,
-    in place on the engine's delta buffer, on the engine's stream
-    (lob_theta_allreduce, include/lob_comm.h);
-  * TorchComm -- torch.distributed on a tensor view of the backend's delta
-    (the gloo CPU tests, where a CPU stand-in plays the engine).
-``backend`` is anything with td_step(n) and delta_init() (plus, for TorchComm,
-delta_tensor() / after_all_reduce() / delta_apply()).
+``comm`` is what carries the exchange: rl_markets_amd.comm.RcclComm -- RCCL over
+xGMI on the engine's own buffers and stream (lob_theta_allreduce,
+include/lob_comm.h: the ranks' written-weights maps all-gathered, the packed
+deltas of their union all-reduced; dense all-reduce of the whole vector where
+there is no such map) -- or anything else with sync_weights(backend) and
+barrier() (the CPU tests drive the same schedule over torch.distributed + gloo
+with a stand-in they keep under tests/).  ``backend`` is anything with
+td_step(n) and delta_init().
 """
 
 
@@ -25,24 +25,6 @@ def shard_books(total_books, world_size, rank):
     n = base + (1 if rank < extra else 0)
     first = rank * base + min(rank, extra)
     return first, n
-
-
-class TorchComm:
-    """Exchange through torch.distributed (any backend) on the backend's delta tensor."""
-
-    def __init__(self, dist):
-        self.dist = dist
-        self.world = dist.get_world_size()
-        self.rank = dist.get_rank()
-
-    def sync_weights(self, backend):
-        t = backend.delta_tensor()
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        backend.after_all_reduce()
-        backend.delta_apply()
-
-    def barrier(self):
-        self.dist.barrier()
 
 
 class ShardedLearner:
@@ -62,16 +44,31 @@ class ShardedLearner:
         self.n_syncs += 1
 
     def run(self, n_steps):
+        """n_steps steps of every book of this shard; every `sync_every`-th step carries the exchange INSIDE it, between
+        its first half (action selection + performAction) and its second (traces, TD errors, update): there no hit list is
+        live -- the step's action has consumed the previous step's lists, its learn kernel builds the next under the
+        exchanged weights and maps -- so the exchange voids nothing (lob_td_step_begin / lob_td_step_end)."""
         done = 0
+        split = self.comm is not None and hasattr(self.backend, "td_step_begin")
         while done < n_steps:
             chunk = n_steps - done
+            sync_now = False
             if self.comm is not None:
-                chunk = min(chunk, self.sync_every - self.steps % self.sync_every)
-            self.backend.td_step(chunk)
+                until = self.sync_every - self.steps % self.sync_every
+                chunk = min(chunk, until)
+                sync_now = chunk == until
+            if sync_now and split:
+                if chunk > 1:
+                    self.backend.td_step(chunk - 1)
+                self.backend.td_step_begin()
+                self.sync_weights()
+                self.backend.td_step_end()
+            else:
+                self.backend.td_step(chunk)
+                if sync_now:
+                    self.sync_weights()
             done += chunk
             self.steps += chunk
-            if self.comm is not None and self.steps % self.sync_every == 0:
-                self.sync_weights()
 
 
 class EngineBackend:
@@ -82,6 +79,12 @@ class EngineBackend:
 
     def td_step(self, n):
         self.eng.td_step(n)
+
+    def td_step_begin(self):
+        self.eng.td_step_begin()
+
+    def td_step_end(self):
+        self.eng.td_step_end()
 
     def delta_init(self):
         self.eng.delta_init()

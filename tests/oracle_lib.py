@@ -57,7 +57,7 @@ def load():
     lib.oracle_create.restype = vp
     lib.oracle_create.argtypes = [P(abi.Params), C.c_int32, vp, C.c_int32]
     lib.oracle_destroy.argtypes = [vp]
-    for n in ("oracle_reset", "oracle_clear_inventory", "oracle_handle_terminal"):
+    for n in ("oracle_reset", "oracle_clear_inventory", "oracle_handle_terminal", "oracle_td_step_begin", "oracle_td_step_end"):
         getattr(lib, n).argtypes = [vp]
     lib.oracle_td_step.argtypes = [vp, C.c_int32]
     lib.oracle_eval_step.argtypes = [vp, C.c_int32]
@@ -120,6 +120,12 @@ class Oracle:
 
     def td_step(self, n=1):
         self.lib.oracle_td_step(self.h, n)
+
+    def td_step_begin(self):
+        self.lib.oracle_td_step_begin(self.h)
+
+    def td_step_end(self):
+        self.lib.oracle_td_step_end(self.h)
 
     def eval_step(self, n=1):
         self.lib.oracle_eval_step(self.h, n)

@@ -32,12 +32,22 @@ class OracleBackend:
     def td_step(self, n):
         self.orc.td_step(n)
 
+    def td_step_begin(self):
+        self.orc.td_step_begin()
+
+    def td_step_end(self):
+        self.orc.td_step_end()
+
     def delta_init(self):
         self.sync = self.orc.theta(0).copy()
 
     def delta_tensor(self):
         self.delta = self.torch.from_numpy(self.orc.theta(0) - self.sync)
         return self.delta
+
+    def delta_mask(self):
+        # the engine's written-weights map marks every weight a step has touched: a superset of the non-zero deltas
+        return self.orc.theta(0) != 0.0
 
     def after_all_reduce(self):
         pass
@@ -70,14 +80,17 @@ def _worker(out_dir):
     import torch
     import torch.distributed as dist
     from rl_markets_amd import launch
-    from rl_markets_amd.parallel import ShardedLearner, TorchComm, shard_books
+    from rl_markets_amd.parallel import ShardedLearner, shard_books
+    from tests.torch_comm import SparseTorchComm, TorchComm
     rank, local_rank, world = launch.rank_env()
     assert local_rank == rank and "LOB_RDZV" in os.environ
     dist.init_process_group("gloo", init_method="file://" + launch.rendezvous_path() + ".gloo", rank=rank, world_size=world)
     first, n = shard_books(TOTAL_BOOKS, world, rank)
     o = _make(first, n)
-    sl = ShardedLearner(OracleBackend(o, torch), TorchComm(dist), sync_every=SYNC)
+    comm = (SparseTorchComm if os.environ.get("LOB_TEST_EXCHANGE") == "sparse" else TorchComm)(dist)
+    sl = ShardedLearner(OracleBackend(o, torch), comm, sync_every=SYNC)
     sl.run(STEPS)
+    np.save(os.path.join(out_dir, "bytes_%d.npy" % rank), np.array([comm.bytes]))
     np.save(os.path.join(out_dir, "theta_%d.npy" % rank), o.theta(0))
     np.save(os.path.join(out_dir, "steps_%d.npy" % rank), o.counters())
     dist.barrier()
@@ -95,14 +108,22 @@ def test_shard_books_partition():
                 assert f0 + n0 == f1
 
 
-def test_two_rank_gloo_matches_single_process(tmp_path):
+@pytest.mark.parametrize("exchange", ["dense", "sparse"])
+def test_two_rank_gloo_matches_single_process(tmp_path, exchange):
+    """Two ranks over gloo, each with its own book shard and weight replica, exchanging every SYNC steps -- densely, or the
+    product's way (maps gathered, packed union reduced: tests/torch_comm.py) -- against a single-process run of the same
+    two-shard schedule.  The sparse exchange must move a fraction of the dense one's bytes and give the very same weights."""
     from rl_markets_amd import launch
     world = 2
-    rc = launch.spawn_ranks([sys.executable, os.path.abspath(__file__), "worker", str(tmp_path)], world, timeout=600)
+    rc = launch.spawn_ranks([sys.executable, os.path.abspath(__file__), "worker", str(tmp_path)], world, timeout=600,
+                            env=dict(os.environ, LOB_TEST_EXCHANGE=exchange))
     assert rc == 0
+    moved = int(np.load(tmp_path / "bytes_0.npy")[0])
+    dense_bytes = (STEPS // SYNC) * (1 << 16) * 8
+    assert moved == dense_bytes if exchange == "dense" else 0 < moved < dense_bytes // 4
     t0 = np.load(tmp_path / "theta_0.npy")
     t1 = np.load(tmp_path / "theta_1.npy")
-    np.testing.assert_array_equal(t0, t1)  # replicas agree after the last sync... 
+    # (the exchange sits inside the sync step: right after it the replicas agree, then each adds that step's own update)
     # single-process emulation of the same schedule: two shards, private replicas, summed deltas
     from rl_markets_amd.parallel import shard_books
     shards = [_make(*shard_books(TOTAL_BOOKS, world, r)) for r in range(world)]
@@ -110,19 +131,22 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
     done = 0
     while done < STEPS:
         chunk = min(SYNC - done % SYNC, STEPS - done)
+        sync_now = (done + chunk) % SYNC == 0
         for o in shards:
-            o.td_step(chunk)
+            o.td_step(chunk - 1 if sync_now else chunk)
         done += chunk
-        if done % SYNC == 0:
+        if sync_now:   # the exchange sits inside the sync step, between its two halves (ShardedLearner.run)
+            for o in shards:
+                o.td_step_begin()
             total = sum(o.theta(0) - sync for o in shards)
             for o in shards:
                 o.theta(0)[:] = sync + total
             sync = shards[0].theta(0).copy()
-    if STEPS % SYNC == 0:
-        np.testing.assert_allclose(t0, shards[0].theta(0), rtol=1e-12, atol=0)
-    else:
-        # after the last sync the replicas drift apart again by their local updates
-        pass
+            for o in shards:
+                o.td_step_end()
+    np.testing.assert_allclose(t0, shards[0].theta(0), rtol=1e-12, atol=0)
+    np.testing.assert_allclose(t1, shards[1].theta(0), rtol=1e-12, atol=0)
+    assert np.count_nonzero(t0 != t1) < np.count_nonzero(t0) // 2   # they differ by one step of SARSA(lambda) updates only
     steps = sum(int(np.load(tmp_path / ("steps_%d.npy" % r))[0]) for r in range(world))
     assert steps == sum(int(o.counters()[0]) for o in shards)
 

@@ -100,6 +100,78 @@ def test_delta_exchange_two_shards_one_gpu(algo):
         e.close()
 
 
+def d2h_u32(ptr, n):
+    out = np.empty(n, np.uint32)
+    assert hip().hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), n * 4, 2) == 0
+    return out
+
+
+def host_sparse_allreduce(engs):
+    """What lob_theta_allreduce does on the sparse path, the two collectives formed on the host: all-gather of the ranks'
+    written-weights maps, union + pack on every rank, all-reduce (SUM) of the packed deltas, scatter."""
+    world = len(engs)
+    maps = [e.delta_sparse_maps(world) for e in engs]
+    own = [d2h_u32(o, w) for o, _, w in maps]
+    for (_, gather, words), e in zip(maps, engs):
+        for r in range(world):   # ncclAllGather: rank r's map lands in slot r on every rank
+            a = np.ascontiguousarray(own[r])
+            assert hip().hipMemcpy(C.c_void_p(gather + r * words * 4), a.ctypes.data_as(C.c_void_p), words * 4, 1) == 0
+    packed = [e.delta_sparse_pack(world) for e in engs]
+    counts = {n for _, n in packed}
+    assert len(counts) == 1, "every rank must arrive at the same compact layout"
+    n = counts.pop()
+    tot = sum(d2h(ptr, n) for ptr, _ in packed)
+    for (ptr, _), e in zip(packed, engs):
+        h2d(ptr, tot)
+        e.delta_sparse_apply()
+    return n
+
+
+@pytest.mark.parametrize("algo", [abi.ALGO_SARSA, abi.ALGO_QLAMBDA])
+def test_sparse_exchange_equals_dense(algo):
+    """The sparse exchange (written-weights maps gathered, union packed, a few thousand doubles reduced) against the dense
+    one (memory_size doubles) on two pairs of shards stepping the same books: the weights must agree bit for bit after
+    every exchange (two ranks: a sum of two terms has one order), keep agreeing while the shards go on learning from them
+    -- the maps the sparse path leaves mark a superset of the dense path's, which may not change a single Q value --, and
+    follow the oracle's two-shard schedule."""
+    M, steps, sync = 1 << 16, 64, 16
+    sparse, orcs = make_shards(algo, M=M)
+    dense, orcs2 = make_shards(algo, M=M)
+    for o in orcs2:
+        o.close()
+    assert all(e.delta_sparse_supported() for e in sparse)
+    osync = np.zeros(M)
+    for rnd, s0 in enumerate(range(0, steps, sync)):
+        mid = rnd % 2 == 1   # every other exchange sits INSIDE the sync step (lob_td_step_begin / _end), as ShardedLearner places it
+        for x in sparse + dense + orcs:
+            x.td_step(sync - 1 if mid else sync)
+            if mid:
+                x.td_step_begin()
+        n = host_sparse_allreduce(sparse)
+        host_allreduce(dense)
+        assert 0 < n < M // 2
+        ototal = sum(o.theta(0) - osync for o in orcs)
+        for o in orcs:
+            o.theta(0)[:] = osync + ototal
+        osync = orcs[0].theta(0).copy()
+        if not mid:
+            np.testing.assert_array_equal(sparse[0].theta(), sparse[1].theta())
+        for x in sparse + dense + orcs:
+            if mid:
+                x.td_step_end()
+        for es, ed, o in zip(sparse, dense, orcs):
+            np.testing.assert_array_equal(es.theta(), ed.theta(), err_msg="after the exchange at step %d" % (s0 + sync))
+            np.testing.assert_array_equal(es.last_actions(), ed.last_actions())
+            np.testing.assert_array_equal(es.last_actions(), o.recs()["action"])
+            np.testing.assert_allclose(es.last_td(), o.recs()["td"], rtol=1e-9, atol=1e-12)
+            np.testing.assert_allclose(es.theta(), o.theta(0), rtol=1e-9, atol=1e-15)
+    assert np.count_nonzero(sparse[0].theta()) > 100
+    for e in sparse + dense:
+        e.close()
+    for o in orcs:
+        o.close()
+
+
 def test_checkpoint_loaded_after_delta_init_is_not_scaled_by_world_size():
     """lob_theta_set after lob_delta_init (ShardedLearner's constructor ran, then a checkpoint is
     loaded on every rank): the loaded weights are the new common base.  Before the fix every rank

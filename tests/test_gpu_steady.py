@@ -49,9 +49,10 @@ def make(B, algo, n_events, mem=20000000, depth=10, **over):
 def test_steady_state_at_the_dispatch_threshold_across_an_exchange(algo, tmp_path):
     """32 768 books (the smallest batch that takes the lane-per-book learner kernels and the fused
     env kernel by itself -- no switches), D = 10, M = 20 M, one shared weight vector, 70 steps against
-    the oracle; after step 64 a one-rank lob_theta_allreduce (RCCL in place on the engine's buffer:
-    theta must not change, but every hit list is voided and every memo record re-stamped, so step 65 runs
-    act_fast_kernel and the wave-per-book trace kernel and steps 66+ are back on the light path); then
+    the oracle; a one-rank lob_theta_allreduce (RCCL on the engine's buffers: theta must not change) INSIDE step 32
+    (lob_td_step_begin / _end: where the product places it -- no hit list is live there, nothing is voided) and another
+    BETWEEN steps 64 and 65 (every hit list voided, every memo record re-stamped: step 65 runs act_fast_kernel and steps
+    66+ are back on the light path); then
     ClearInventory / HandleTerminal / Initialise and 4 steps of a second episode."""
     from rl_markets_amd.comm import RcclComm
     from rl_markets_amd.parallel import EngineBackend
@@ -63,10 +64,19 @@ def test_steady_state_at_the_dispatch_threshold_across_an_exchange(algo, tmp_pat
     orc.reset()
     light0 = light_books(eng)
     for step in range(70):
-        eng.td_step(1)
-        orc.td_step(1)
+        if step == 31:
+            # the exchange where ShardedLearner puts it: inside the step, between its two halves -- nothing is voided
+            eng.td_step_begin(); orc.td_step_begin()
+            before = eng.theta()
+            comm.sync_weights(EngineBackend(eng))
+            eng.sync()
+            np.testing.assert_array_equal(eng.theta(), before)
+            eng.td_step_end(); orc.td_step_end()
+        else:
+            eng.td_step(1)
+            orc.td_step(1)
         # every step around the start and the exchange, every 4th in between (a comparison moves 40 MB of dumps)
-        if step < 4 or step % 4 == 3 or 60 <= step:
+        if step < 4 or step % 4 == 3 or 60 <= step or 30 <= step <= 34:
             compare_learner_step(eng, orc, "steady %d step %d" % (algo, step), exact=False, rtol=1e-9)
         if step == 63:
             before = eng.theta()
