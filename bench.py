@@ -32,6 +32,8 @@ sys.path.insert(0, ROOT)
 
 SYNC_EVERY = 64
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+ISSUE_CLOCK_HZ = 2.4e9  # peak engine clock; the issue roof of a kernel = launch time x clock x CUs x 4 SIMDs x 1 instruction / clock
+N_SIMDS = 256 * 4
 
 # Algorithmic bytes per book per launch (DESIGN.md "Kernels and rooflines";
 # SURVEY.md §8d terms regrouped per kernel; n_live = live traces, measured).
@@ -59,15 +61,15 @@ def algorithmic_bytes(kernel, depth, trades, n_vars, n_live, events_per_step):
 
 
 # timer name (lob_kernel_time_ms) -> kernel function(s) launched under it, as rocprofv3 names them
-TIMER_KERNELS = {"act_kernel": ("act_light_kernel", "act_fast_kernel", "act_kernel"), "trace_kernel": ("trace_fast_kernel",),
+TIMER_KERNELS = {"act_kernel": ("act_light_kernel", "act_fast_kernel", "act_kernel"), "env_kernel": ("env_step_kernel", "env_kernel"), "trace_kernel": ("trace_fast_kernel",),
                  "trace_light_kernel": ("trace_light_kernel",),
                  "learn_kernel": ("learn_q_pair_kernel", "learn_q_lane_kernel", "learn_q_fast_kernel", "learn_kernel"), "act_rest_kernel": (), "learn_rest_kernel": ()}
 
 
-def traffic_of(traffic_file, timer):
-    """HBM bytes per launch of the kernel behind a timer, from profiles/pmc_traffic.json (None if absent)."""
+def traffic_of(traffic_file, timer, key="hbm_bytes_per_launch"):
+    """A per-launch counter figure of the kernel behind a timer, from profiles/pmc_traffic.json (None if absent)."""
     for fn in TIMER_KERNELS.get(timer, (timer,)):
-        v = traffic_file.get(fn, {}).get("hbm_bytes_per_launch") if isinstance(traffic_file.get(fn), dict) else None
+        v = traffic_file.get(fn, {}).get(key) if isinstance(traffic_file.get(fn), dict) else None
         if v:
             return v
     return None
@@ -284,32 +286,54 @@ def main():
                 live_books = steps_done / world / args.steps   # books one launch covers
                 ach = per_book * live_books / (v["avg_ms"] * 1e-3) / 1e9
                 tr = traffic_of(traffic_file, k)
+                insts = traffic_of(traffic_file, k, "insts_per_launch")
+                sec = v["avg_ms"] * 1e-3
                 per_kernel[k] = {"avg_ms": round(v["avg_ms"], 4), "launches": v["launches"],
-                                 "algorithmic_bytes_per_book": round(per_book, 1), "achieved_GBps": round(ach, 1),
-                                 "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": tr,
-                                 "counter_GBps": round(tr / (v["avg_ms"] * 1e-3) / 1e9, 1) if tr else None}
+                                 # what the counters say this kernel moved / issued per launch (profiles/, same command), over THIS run's time
+                                 "traffic": tr,
+                                 "hbm_frac_counter": round(tr / sec / 1e9 / HBM_PEAK_GBS, 5) if tr else None,
+                                 "insts_per_launch": insts,
+                                 "issue_frac": round(insts / (sec * ISSUE_CLOCK_HZ * N_SIMDS), 5) if insts else None,
+                                 # SURVEY.md 8(d)'s yardstick: the reference algorithm's bytes for this piece of the step
+                                 "algorithmic_bytes_per_book": round(per_book, 1), "yardstick_GBps": round(ach, 1),
+                                 "yardstick_frac": round(ach / HBM_PEAK_GBS, 5)}
             per_kernel["reset_kernel"] = {
                 "avg_ms": round(reset_ms, 3), "launches": 1, "note": "once per episode, outside `value`; see value_amortised",
                 "algorithmic_bytes_per_book": round(algorithmic_bytes("reset_kernel", args.depth, 2, p.n_vars, 0, g.n_events), 1),
-                "achieved_GBps": round(algorithmic_bytes("reset_kernel", args.depth, 2, p.n_vars, 0, g.n_events) * args.books / (reset_ms * 1e-3) / 1e9, 1) if reset_ms else None,
+                "yardstick_GBps": round(algorithmic_bytes("reset_kernel", args.depth, 2, p.n_vars, 0, g.n_events) * args.books / (reset_ms * 1e-3) / 1e9, 1) if reset_ms else None,
                 "traffic": traffic_of(traffic_file, "reset_kernel")}
             dom = max((k for k in ktimes if not k.startswith("delta")), key=lambda k: ktimes[k]["avg_ms"])
             d = per_kernel[dom]
             # the whole step against the same roof: SURVEY.md 8(d)'s bytes per env-step (event read + book state + scalars +
             # Q-value gathers + n_live traces' worth of index / eligibility / theta read-modify-write) x env-steps per second
             step_bytes = eps * (2 * args.depth * 8 + 2 * 8) + eps * 2 * args.depth * 8 + 256 + 9 * 3 * 32 * 8 + n_live * (4 + 4 + 4 + 8 + 8)
-            roofline = {"bound": "hbm", "kernel": dom, "achieved": d["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "whole_step": {"algorithmic_bytes_per_env_step": round(step_bytes, 1),
-                                       "achieved_GBps": round(step_bytes * steps_done / elapsed / 1e9, 1),
-                                       "frac": round(step_bytes * steps_done / elapsed / 1e9 / HBM_PEAK_GBS, 5),
-                                       "note": "SURVEY.md 8(d) yardstick (the reference algorithm's bytes); the memo / hit-list kernels move far fewer: a per-kernel frac above 1 means the yardstick's traffic was avoided, not that the roof was beaten"},
-                        "frac": d["frac"], "traffic": d["traffic"],
+            dsec = d["avg_ms"] * 1e-3
+            # `achieved` / `frac`: the dominant kernel's COUNTER bytes (FETCH_SIZE + WRITE_SIZE of the rocprofv3 --pmc passes kept
+            # under profiles/) over its HIP-event time in this run, against the HBM roof; the SURVEY yardstick under its own key.
+            # Without a counter file: the yardstick.
+            use_counter = d["traffic"] is not None
+            roofline = {"bound": "hbm", "kernel": dom,
+                        "achieved": round(d["traffic"] / dsec / 1e9, 1) if use_counter else d["yardstick_GBps"],
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": d["hbm_frac_counter"] if use_counter else d["yardstick_frac"],
+                        "frac_is": "counter bytes / launch time / peak" if use_counter else "SURVEY 8(d) yardstick bytes / launch time / peak",
+                        "traffic": d["traffic"],
                         "traffic_source": traffic_file.get("_source", "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command; static file, not measured in this run)") if d["traffic"] else None,
-                        "algorithmic_bytes_per_book": d["algorithmic_bytes_per_book"],
+                        "issue_frac": d["issue_frac"],
+                        "issue_note": "wave instructions of all kinds per launch (SQ_INSTS_*) / (launch time x 2.4 GHz x 1024 SIMDs x 1 instruction per clock): what these latency-chain kernels are nearest to is neither roof -- one wave per SIMD waiting on dependent memory round trips (DESIGN.md section 4)",
+                        "yardstick": {"algorithmic_bytes_per_book": d["algorithmic_bytes_per_book"], "GBps": d["yardstick_GBps"], "frac": d["yardstick_frac"]},
+                        "whole_step": {"algorithmic_bytes_per_env_step": round(step_bytes, 1),
+                                       "yardstick_GBps": round(step_bytes * steps_done / elapsed / 1e9, 1),
+                                       "yardstick_frac": round(step_bytes * steps_done / elapsed / 1e9 / HBM_PEAK_GBS, 5),
+                                       "counter_bytes_per_step": round(sum(v["traffic"] for v in per_kernel.values() if v.get("traffic") and v is not per_kernel.get("reset_kernel")), 1),
+                                       "note": "yardstick = SURVEY.md 8(d) (the reference algorithm's bytes per env-step); counter_bytes_per_step = sum over the step's kernels of FETCH_SIZE + WRITE_SIZE per launch: the memo / hit-list kernels move far fewer bytes than the yardstick assumes"},
                         "books_per_launch": round(steps_done / world / args.steps, 1),
                         "avg_launch_ms": d["avg_ms"],
                         "all_kernels_avg_ms": {k: round(v["avg_ms"], 4) for k, v in ktimes.items()},
                         "per_kernel": per_kernel}
+            ws = roofline["whole_step"]
+            if ws["counter_bytes_per_step"]:
+                ws["hbm_frac_counter"] = round(ws["counter_bytes_per_step"] / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5)
         cpu = None
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only (the contract); N > 1 runs report null
             try:

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LOB_ABI_VERSION 3
+#define LOB_ABI_VERSION 4
 
 #define LOB_N_ACTIONS 9   /* reference Intraday::DoAction table, src/environment/intraday.cpp:181-219 */
 #define LOB_N_TILINGS 32  /* config/example.yaml:18 (compile-time in the kernels) */
@@ -200,6 +200,12 @@ typedef struct lob_book_dump {
     int32_t terminal;          /* 1 = isTerminal(), 2 = stream exhausted */
     int32_t total_ticks;       /* TickStatistics::total_ticks */
     int32_t n_traces;          /* live eligibility traces */
+    /* TradeStatistics / TickStatistics of the episode (include/environment/statistics.h:19-50): what Base::ClearInventory
+     * (base.cpp:339-349) and Base::UpdateStats (base.cpp:412-442) count; ask/bid_transactions are ask/bid_n_transacted above,
+     * the reference never touches the placed / cancelled / "no ..." counters */
+    int32_t market_buys, market_sells;
+    int32_t ticks_with_ask, ticks_with_bid, ticks_with_both;
+    int32_t ticks_with_position, ticks_long, ticks_short;
 } lob_book_dump;
 
 typedef struct lob_engine lob_engine;

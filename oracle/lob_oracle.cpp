@@ -635,6 +635,7 @@ struct Env {
     double tp_val = -1.0;
     double ep_reward = 0, ep_pnl = 0, ep_bandh = 0;
     int total_ticks = 0, market_buys = 0, market_sells = 0;
+    int ticks_with_ask = 0, ticks_with_bid = 0, ticks_with_both = 0, ticks_with_position = 0, ticks_long = 0, ticks_short = 0;  // TickStatistics
     int64_t events_consumed = 0;
 
     Env(const lob_params& p, const uint32_t* r, int ne)
@@ -817,6 +818,7 @@ struct Env {
         bid.Reset();
         ep_reward = ep_pnl = ep_bandh = 0;  // ClearStats
         total_ticks = market_buys = market_sells = 0;
+        ticks_with_ask = ticks_with_bid = ticks_with_both = ticks_with_position = ticks_long = ticks_short = 0;
         spread_window.clear(); tp_mp.clear(); f_midprice.clear(); f_volatility.clear();
         f_vwap_numer.clear(); f_vwap_denom.clear(); pnl_ups.clear(); pnl_downs.clear();
         f_ask_tx.clear(); f_bid_tx.clear();
@@ -844,7 +846,17 @@ struct Env {
         momentum_pnl_step = 0.0;
         DoAction(action);
         CheckOrders();
-        total_ticks++;  // UpdateStats (tick counters other than total_ticks are not on the path)
+        total_ticks++;  // UpdateStats (base.cpp:412-442)
+        {
+            const bool has_ask = ask.order_count() > 0, has_bid = bid.order_count() > 0;
+            if (has_ask) ticks_with_ask++;
+            if (has_bid) ticks_with_bid++;
+            if (has_ask && has_bid) ticks_with_both++;
+            const long exposure = position;
+            if (exposure != 0) ticks_with_position++;
+            if (exposure > 0) ticks_long++;
+            else if (exposure < 0) ticks_short++;
+        }
         double agg_r = getReward();
         double agg_pnl = pnl_step;
         double agg_mpm = 0.0;
@@ -957,6 +969,9 @@ struct Env {
         d.cursor = cursor;
         d.terminal = exhausted ? 2 : (isTerminal() ? 1 : 0);
         d.total_ticks = total_ticks;
+        d.market_buys = market_buys; d.market_sells = market_sells;
+        d.ticks_with_ask = ticks_with_ask; d.ticks_with_bid = ticks_with_bid; d.ticks_with_both = ticks_with_both;
+        d.ticks_with_position = ticks_with_position; d.ticks_long = ticks_long; d.ticks_short = ticks_short;
     }
 };
 

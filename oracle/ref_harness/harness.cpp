@@ -82,6 +82,7 @@
 #include "../lob_oracle.h"                          // oracle_step_rec layout only
 #ifdef LOB_DROPIN
 #include "../../rl_markets_amd/host/ref_binding/gpu_intraday.h"  // the thing under test in `dropin` mode
+#include "../../rl_markets_amd/host/ref_binding/gpu_learner.h"   // ... and in `dropin_learner` mode
 #endif
 
 // ---------------------------------------------------------------------------
@@ -179,6 +180,9 @@ public:
         d.terminal = isTerminal() ? 1 : 0;
         d.total_ticks = tick_stats.total_ticks;
         d.n_traces = -1;
+        d.market_buys = trade_stats.market_buys; d.market_sells = trade_stats.market_sells;
+        d.ticks_with_ask = tick_stats.ticks_with_ask; d.ticks_with_bid = tick_stats.ticks_with_bid; d.ticks_with_both = tick_stats.ticks_with_both;
+        d.ticks_with_position = tick_stats.ticks_with_position; d.ticks_long = tick_stats.ticks_long; d.ticks_short = tick_stats.ticks_short;
     }
 };
 
@@ -545,6 +549,38 @@ static int run_dropin(const Args& a, Config& c, environment::GpuIntraday& env, c
            agent.steps, ok ? 1 : 0, (unsigned long long)g_ctr, sizeof(StepRec), env.getEpisodeReward(), env.getEpisodePnL());
     return 0;
 }
+// `dropin_learner`: the call sequence of src/main.cpp's train() (:47-70) -- runner.RunEpisode(agent) through a Runner& and an
+// rl::Agent*, then the episode getters of environment::Base -- over experiment::serial::GpuLearner / rl::GpuAgent /
+// environment::GpuIntraday with `books` books in one engine and the weights in HBM.
+static int run_dropin_learner(const Args& a, Config& c, environment::GpuIntraday& env) {
+    std::unique_ptr<rl::Agent> owner(new rl::GpuAgent(make_policy(a), c, env));
+    rl::Agent* agent = owner.get();
+    experiment::serial::GpuLearner gl(c, env, (int)a.geti("steps_per_call", 8));
+    experiment::serial::Runner& runner = gl;
+    environment::Base& base = env;
+    const int episodes = (int)a.geti("episodes", 1);
+    for (int ep = 0; ep < episodes; ep++) {
+        if (!runner.RunEpisode(agent)) { fprintf(stderr, "RunEpisode failed\n"); return 3; }
+        printf("{\"episode\": %d, \"reward\": %.17g, \"pnl\": %.17g, \"rho\": %.17g, \"nTr\": %d, \"order_ratio\": %.9g, \"steps\": %lu, \"descr\": %.17g}\n",
+               ep + 1, base.getEpisodeReward(), base.getEpisodePnL(), base.getMeanEpisodeReward(), base.getTotalTransactions(), (double)base.getOrderRatio(),
+               gl.step_counter(), agent->policy->descr());
+    }
+    if (a.kv.count("stats_out")) base.writeStats(a.get("stats_out"));
+    if (a.kv.count("theta_out")) {
+        const std::string path = a.get("theta_out");
+        agent->write_theta(path + ".raw");   // Agent::write_theta, unmodified (non-virtual): the host copy GpuLearner keeps current
+        const double* th = static_cast<rl::GpuAgent*>(agent)->theta_host();
+        const long M = env.params().memory_size;
+        FILE* f = fopen(path.c_str(), "wb");
+        int64_t n = 0;
+        for (long i = 0; i < M; i++) if (th[i] != 0.0) n++;
+        fwrite(&n, 8, 1, f);
+        for (long i = 0; i < M; i++)
+            if (th[i] != 0.0) { int64_t idx = i; fwrite(&idx, 8, 1, f); fwrite(&th[i], 8, 1, f); }
+        fclose(f);
+    }
+    return 0;
+}
 #endif
 
 int main(int argc, char** argv) {
@@ -631,6 +667,15 @@ int main(int argc, char** argv) {
     make_yaml(a, yaml);
     Config c(yaml);
 #ifdef LOB_DROPIN
+    if (mode == "dropin_learner") {
+        environment::GpuIntraday genv(c, 0, (int)a.geti("books", 1), true);
+        genv.set_rng(g_seed, g_stream);
+        genv.LoadData(a.get("ticker", "HSBA.L"), md, tas);
+        const int rc = run_dropin_learner(a, c, genv);
+        if (!a.geti("keep", 0) && a.kv.count("stream")) { remove(md.c_str()); remove(tas.c_str()); }
+        remove(yaml.c_str());
+        return rc;
+    }
     if (mode == "dropin") {
         environment::GpuIntraday genv(c);
         genv.LoadData(a.get("ticker", "HSBA.L"), md, tas);   // the call site of src/main.cpp:55 with the class swapped

@@ -97,6 +97,8 @@ class BookDump(C.Structure):
         ("spread_mean", C.c_double), ("target_price", C.c_double),
         ("time_ms", C.c_int64),
         ("cursor", C.c_int32), ("terminal", C.c_int32), ("total_ticks", C.c_int32), ("n_traces", C.c_int32),
+        ("market_buys", C.c_int32), ("market_sells", C.c_int32), ("ticks_with_ask", C.c_int32), ("ticks_with_bid", C.c_int32),
+        ("ticks_with_both", C.c_int32), ("ticks_with_position", C.c_int32), ("ticks_long", C.c_int32), ("ticks_short", C.c_int32),
     ]
 
 

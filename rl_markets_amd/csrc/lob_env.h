@@ -993,7 +993,12 @@ __device__ inline void step_prologue(const EnvCtx& c, EnvR& e, int action, StepA
     g.cv_b = e.b_oiq;
     check_orders(P, e);
     c.mark(21);  // DoAction: quotes, tick conversions, queue position
-    e.total_ticks++;  // UpdateStats
+    e.total_ticks++;  // UpdateStats (base.cpp:412-442): occupancy of the two quotes and of the inventory at decision time
+    {
+        const i64 ha = e.a_on ? 1 : 0, hb = e.b_on ? 1 : 0;
+        e.tick_ab += ha | (hb << 21) | ((ha & hb) << 42);
+        e.tick_pos += (i64)(e.position != 0) | ((i64)(e.position > 0) << 21) | ((i64)(e.position < 0) << 42);
+    }
     g.r = get_reward(c, e);
     g.pnl = e.pnl_step;
     g.mpm = 0.0;
@@ -1252,15 +1257,10 @@ __device__ inline int event_loop_fast(const EnvCtx& c, EnvR& e, StepAgg& g, TE& 
     const int last_row = c.S.n_events - 1;
     int st;
     while (true) {
-        // the next event's entry and first row are requested a pass ahead -- unless the entry says the step ends with this
-        // event (LOB_TRK_STEP_END: a hint from the pre-pass; when it is wrong the loop fetches what it needs on the spot)
-#ifdef LOB_NO_STEP_HINT  /* (A/B: always prefetch) */
-        const bool more = true;
-#else
-        const bool more = !(t.info & LOB_TRK_STEP_END);
-#endif
-        TE tn;
-        if (more) tn = *reinterpret_cast<const TE*>(&c.track(h.k + 1));
+        // the next event's entry and first row are requested a pass ahead (wasted on a step's last pass: skipping them there on a
+        // "step ends here" bit computed by the pre-pass measured SLOWER, 0.104 vs 0.098 ms -- the conditional requests split the
+        // batch of loads)
+        const TE tn = *reinterpret_cast<const TE*>(&c.track(h.k + 1));
         // the fast pass needs: the event inside the track, freshly placed orders behind it, its trade list whole, and the row
         // it was handed (a step's first row is the record after the current snapshot -- anything else is reloaded)
         const bool fast = h.k < g.n_track && g.cv_valid && (t.info & LOB_TRK_TRADES_OK);
@@ -1268,11 +1268,11 @@ __device__ inline int event_loop_fast(const EnvCtx& c, EnvR& e, StepAgg& g, TE& 
         if (fast) {
             if (t.rec_first != h.rec_cur + 1) row_full_load(c, t.rec_first, L);
             RowFull Ln;  // next pass's first row, in flight during this one
-            if (more) { const int rn = t.rec_last + 1; row_full_load(c, rn < last_row ? rn : last_row, Ln); }
+            { const int rn = t.rec_last + 1; row_full_load(c, rn < last_row ? rn : last_row, Ln); }
             c.mark(23);  // loop top: next entry / next row requested
             st = pass_fast(c, h, g, t, L, K, sizeof(TE) == sizeof(Track) ? &reinterpret_cast<const Track*>(&t)->spread_mean : nullptr);
-            if (more) L = Ln;
-            have_next_row = more;
+            L = Ln;
+            have_next_row = true;
             c.mark(24);  // the pass itself
         } else {
 #define X(n) e.n = h.n;
@@ -1285,7 +1285,6 @@ __device__ inline int event_loop_fast(const EnvCtx& c, EnvR& e, StepAgg& g, TE& 
             h = e;
         }
         if (st != 0) break;
-        if (!more) tn = *reinterpret_cast<const TE*>(&c.track(h.k));  // (h.k is the next event by now)
         if (!have_next_row) row_full_load(c, h.rec_cur + 1 < last_row ? h.rec_cur + 1 : last_row, L);
         t = tn;
     }
@@ -1505,7 +1504,6 @@ __device__ inline void prepass_begin(const EnvCtx& c, PrepState& st, BookMeta& M
     st.ewma_up = m.ewma_up; st.ewma_down = m.ewma_down; st.tp_val = m.tp_val;
     st.records = m.records;
     st.k = 0;
-    st.step_mpm = 0.0;
     st.prev_first = m.rec_cur;  // Initialise: time_and_sales.SkipUntil(market time) drops everything up to here
 }
 
@@ -1523,7 +1521,6 @@ __device__ inline void prepass_run(const EnvCtx& c, PrepState& st, BookMeta& M, 
     m.records = st.records;
     int k = st.k;
     int prev_first = st.prev_first;
-    f64 step_mpm = st.step_mpm;
     // the ten windows of intraday.cpp:253-269: state in registers for the whole run
     RMReg w_mid, w_vol, w_spr, w_tp, w_atx, w_btx;
     AccReg w_vn, w_vd;
@@ -1609,14 +1606,6 @@ __device__ inline void prepass_run(const EnvCtx& c, PrepState& st, BookMeta& M, 
 #pragma unroll
                 for (int i = 0; i < TM; i++) ntr += (i < P.T && tv[i] > 0) ? 1 : 0;
                 t.info = (ntr < 2 ? ntr : 2) | (ntr <= 2 ? LOB_TRK_TRADES_OK : 0);
-                // Where the steps of an episode end (base.cpp:285-305: a step consumes events until the midprice has moved or
-                // the market has closed) does not depend on the agent: every step starts where the one before stopped, the
-                // first one after the warm-up.  Kept as a HINT only -- the event loop prefetches the next entry / row unless
-                // the hint says the step ends here, and decides the end itself.
-                if (M.k_warm >= 0 && k >= M.k_warm) {
-                    step_mpm += mpm;
-                    if (!(is_open(P, m.time_ms) && fabs(step_mpm) < 1e-5)) { t.info |= LOB_TRK_STEP_END; step_mpm = 0.0; }
-                }
                 t.tr_px[0] = (f32)tp[0]; t.tr_vol[0] = tv[0];
                 t.tr_px[1] = TM > 1 ? (f32)tp[TM > 1 ? 1 : 0] : 0.0f; t.tr_vol[1] = TM > 1 ? tv[TM > 1 ? 1 : 0] : 0;
                 t.bap = (f32)m.ap0; t.bbp = (f32)m.bp0;
@@ -1669,7 +1658,6 @@ __device__ inline void prepass_run(const EnvCtx& c, PrepState& st, BookMeta& M, 
     st.records = m.records;
     st.k = k;
     st.prev_first = prev_first;
-    st.step_mpm = step_mpm;
     S.ewma_up[b] = m.ewma_up; S.ewma_down[b] = m.ewma_down; S.tp_val[b] = m.tp_val;
     if (write_track) {
         M.n_track = k;

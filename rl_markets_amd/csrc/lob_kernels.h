@@ -131,6 +131,7 @@ __global__ void __launch_bounds__(RB) reset_kernel(const DevParams* __restrict__
     e.a_ntr = 0; e.a_on = 0; e.b_ntr = 0; e.b_on = 0;
     e.ep_reward = e.ep_pnl = e.ep_bandh = 0.0;
     e.total_ticks = e.market_buys = e.market_sells = 0;
+    e.tick_ab = e.tick_pos = 0;
     if (M.init_ok) {
         const int k = M.k_warm;
         const Track t1 = c.track(k - 1);
@@ -1689,6 +1690,9 @@ __global__ void dump_kernel(const DevParams* __restrict__ Pp, DevState S, int fi
     d.cursor = (e.k > 0 ? c.track(e.k - 1).rec_last : M.rec_cur0) + 1 + (e.done == 2 ? (int)M.ex_records : 0);
     d.terminal = e.done == 2 ? 2 : (is_open(P, e.time_ms) ? 0 : 1);
     d.total_ticks = e.total_ticks;
+    d.market_buys = e.market_buys; d.market_sells = e.market_sells;
+    d.ticks_with_ask = (i32)(e.tick_ab & 0x1fffff); d.ticks_with_bid = (i32)((e.tick_ab >> 21) & 0x1fffff); d.ticks_with_both = (i32)((e.tick_ab >> 42) & 0x1fffff);
+    d.ticks_with_position = (i32)(e.tick_pos & 0x1fffff); d.ticks_long = (i32)((e.tick_pos >> 21) & 0x1fffff); d.ticks_short = (i32)((e.tick_pos >> 42) & 0x1fffff);
     int n_tr = 0;
     {
         const int ng = S.hdr[b].tr_n, head = S.hdr[b].tr_head;

@@ -65,6 +65,9 @@ typedef float f32;
     X(i32, total_ticks)                                                                                        \
     X(i32, market_buys)                                                                                        \
     X(i32, market_sells)                                                                                       \
+    /* TickStatistics (Base::UpdateStats, base.cpp:412-442), three 21-bit counters per word: with_ask | with_bid << 21 |         \
+     * with_both << 42, and with_position | long << 21 | short << 42 (an episode has < 2^21 steps) */                          \
+    X(i64, tick_ab) X(i64, tick_pos)                                                                                           \
     X(i64, events)    /* depth records consumed (incl. warm-up) */                                             \
     /* per side: n_transacted_ + the single live order (quirk Q13); otk = ToTicks(order price) */             \
     X(i32, a_ntr) X(i32, a_on) X(f64, a_opx) X(i64, a_osz) X(i64, a_oqh) X(i64, a_oqt) X(i64, a_oex) X(i64, a_oiq) X(i32, a_otk) \
@@ -83,8 +86,7 @@ struct __attribute__((aligned(16))) Track {
     i32 time_ms;
     i32 tick_ap0;   // ToTicks(best ask), ToTicks(best bid) of the new snapshot
     i32 tick_bp0;
-    i32 info;       // bits 0-1: entries of the merged trade list held below; bit 2 (LOB_TRK_TRADES_OK): that is the whole list;
-                    // bit 3 (LOB_TRK_STEP_END): see below
+    i32 info;       // bits 0-1: entries of the merged trade list held below; bit 2 (LOB_TRK_TRADES_OK): that is the whole list
     f64 mid;          // midprice of the new snapshot
     f32 tr_px[2];     // merged trades of the event, ascending price key (the order of the reference's std::map)
     f32 bap, bbp;     // best ask / bid price of the new snapshot
@@ -95,7 +97,6 @@ struct __attribute__((aligned(16))) Track {
     f32 mv[8];        // spd, mpm, imb, svl, vol, rsi, vwap (Intraday::getVariable), [7] unused
 };
 #define LOB_TRK_TRADES_OK 4
-#define LOB_TRK_STEP_END 8   /* hint: a step that started where the episode's steps chain from the warm-up ends with this event */
 // The first 32 bytes of a Track entry: what the general event pass (next_state) reads of it.
 struct __attribute__((aligned(16))) TrackHead {
     i32 rec_first, rec_last, time_ms, tick_ap0;
@@ -144,7 +145,6 @@ struct PrepState {
     i64 records;
     i32 k;            // events produced so far
     i32 prev_first;   // record up to which the trades have been handed over
-    f64 step_mpm;     // midprice move accumulated since the last step boundary (LOB_TRK_STEP_END hint)
 };
 
 // Per-book learner header (Runner / Agent / Traces scalars), one 64-byte

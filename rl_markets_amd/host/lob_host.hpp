@@ -281,6 +281,40 @@ public:
     double getEpisodeReward(int b = 0) { return book(b).episode_reward; }
     double getEpisodePnL(int b = 0) { return book(b).episode_pnl; }
     double getMeanEpisodeReward(int b = 0) { lob_book_dump d = book(b); return d.episode_reward / d.total_ticks; }
+    // Base::getTotalTransactions / getOrderRatio (base.cpp:463-473; "nTr" and the denominator of "Ppt" in src/main.cpp:234-236)
+    int getTotalTransactions(int b = 0) {
+        lob_book_dump d = book(b);
+        return d.ask_n_transacted + d.bid_n_transacted + d.market_buys + d.market_sells;
+    }
+    float getOrderRatio(int b = 0) {
+        lob_book_dump d = book(b);
+        return float(d.ask_n_transacted + d.bid_n_transacted) / (d.market_buys + d.market_sells);
+    }
+    // Base::writeStats (base.cpp:451-456): experiment, tick and trade statistics are each written to the SAME path, truncating
+    // it (statistics.cpp:12,36,70) -- what survives is TradeStatistics::write, eight lines (quirk Q17).  The reference never
+    // counts placed / cancelled orders: those four stay 0 there too.
+    void writeStats(const std::string& path, int b = 0) {
+        lob_book_dump d = book(b);
+        std::ofstream ofs(path, std::ofstream::out);
+        ofs << "asks_placed," << 0 << std::endl;
+        ofs << "bids_placed," << 0 << std::endl;
+        ofs << "asks_cancelled," << 0 << std::endl;
+        ofs << "bids_cancelled," << 0 << std::endl;
+        ofs << "ask_transactions," << d.ask_n_transacted << std::endl;
+        ofs << "bid_transactions," << d.bid_n_transacted << std::endl;
+        ofs << "market_sells," << d.market_sells << std::endl;
+        ofs << "market_buys," << d.market_buys << std::endl;
+    }
+    // TickStatistics::write's six occupancy figures (statistics.cpp:70-92), for callers that want what writeStats overwrites
+    std::string tickStatsText(int b = 0) {
+        lob_book_dump d = book(b);
+        std::ostringstream os;
+        const int tt = d.total_ticks;
+        os << "ask_occupancy," << 100 * float(d.ticks_with_ask) / tt << "%\n" << "bid_occupancy," << 100 * float(d.ticks_with_bid) / tt << "%\n"
+           << "both_occupancy," << 100 * float(d.ticks_with_both) / tt << "%\n" << "pos_occupancy," << 100 * float(d.ticks_with_position) / tt << "%\n"
+           << "short_occupancy," << 100 * float(d.ticks_short) / tt << "%\n" << "long_occupancy," << 100 * float(d.ticks_long) / tt << "%\n";
+        return os.str();
+    }
     std::string getEpisodeId() { return "synthetic"; }
 };
 

@@ -35,6 +35,7 @@
 #include <array>
 #include <cstring>
 #include <map>
+#include <new>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -51,7 +52,9 @@ class GpuIntraday : public Base {
     int device_;
     bool have_data_ = false;
     int init_date_ = 0;
-    lob_book_dump last_;  // the engine's view after the most recent call
+    lob_book_dump last_;  // the engine's view (of book 0) after the most recent call
+    int n_books_ = 1;
+    bool device_learning_ = false;
 
     static void check(int rc, const char* what) {
         if (rc != LOB_OK) throw std::runtime_error(std::string(what) + ": " + lob_last_error());
@@ -79,10 +82,21 @@ class GpuIntraday : public Base {
             ask_book_.StashState(); ask_book_.ApplyChanges(ap, av);
             bid_book_.StashState(); bid_book_.ApplyChanges(bp, bv);
         }
+        // Base::getReward()'s `spread` measure divides by spread_window.mean(): a one-slot window holding the engine's mean
+        // (RollingMean is not assignable -- a const member --: rebuilt in place, empty, then mean = 0 + (v - 0) / 1 = v exactly)
+        spread_window.~RollingMean<double>();
+        new (&spread_window) RollingMean<double>(1);
+        spread_window.push(last_.spread_mean);
         episode_stats.reward = last_.episode_reward;
         episode_stats.pnl = last_.episode_pnl;
         episode_stats.bandh = last_.episode_bandh;
         tick_stats.total_ticks = last_.total_ticks;
+        // TradeStatistics / TickStatistics (statistics.h:19-50): Base::getTotalTransactions / getOrderRatio / writeStats read these
+        trade_stats.ask_transactions = last_.ask_n_transacted; trade_stats.bid_transactions = last_.bid_n_transacted;
+        trade_stats.market_buys = last_.market_buys; trade_stats.market_sells = last_.market_sells;
+        tick_stats.ticks_with_ask = last_.ticks_with_ask; tick_stats.ticks_with_bid = last_.ticks_with_bid;
+        tick_stats.ticks_with_both = last_.ticks_with_both; tick_stats.ticks_with_position = last_.ticks_with_position;
+        tick_stats.ticks_long = last_.ticks_long; tick_stats.ticks_short = last_.ticks_short;
     }
 
     // Base::ClearInventory ran on the mirror (the reference's runner calls it through a Base&): same market
@@ -107,7 +121,10 @@ public:
     // The configuration reads of Base / Intraday (src/environment/base.cpp:14-115,
     // src/environment/intraday.cpp:37-82) folded into lob_params; Base(c) itself still runs (its own
     // books and windows stay empty).
-    explicit GpuIntraday(Config& c, int device = 0) : Base(c), device_(device) {
+    // `n_books` > 1 / `device_learning`: the batched use -- B books in one engine, the learner's weights, traces and TD
+    // updates in HBM (experiment::serial::GpuLearner + rl::GpuAgent, gpu_learner.h); the virtual interface then shows book 0.
+    explicit GpuIntraday(Config& c, int device = 0, int n_books = 1, bool device_learning = false)
+        : Base(c), device_(device), n_books_(n_books < 1 ? 1 : n_books), device_learning_(device_learning) {
         memset(&last_, 0, sizeof last_);
         lob_default_params(&params_);
         static const std::map<std::string, int> v2i = {
@@ -126,12 +143,15 @@ public:
         params_.pos_ub = c["market"]["pos_ub"].as<long>();
         static const std::map<std::string, int> r2i = {
             {"none", LOB_REWARD_NONE}, {"pnl", LOB_REWARD_PNL}, {"pnl_damped", LOB_REWARD_PNL_DAMPED},
-            {"lovol", LOB_REWARD_LOVOL}, {"mm_linear", LOB_REWARD_MM_LINEAR}, {"mm_exp", LOB_REWARD_MM_EXP}, {"mm_div", LOB_REWARD_MM_DIV}};
+            {"lovol", LOB_REWARD_LOVOL}, {"mm_linear", LOB_REWARD_MM_LINEAR}, {"mm_exp", LOB_REWARD_MM_EXP}, {"mm_div", LOB_REWARD_MM_DIV},
+            {"spread", LOB_REWARD_SPREAD}};  // (spread: Base's spread_window is given the engine's mean after every step, mirror())
         const std::string rm = c["reward"]["measure"].as<std::string>("pnl");
-        if (!r2i.count(rm))
+        if (!r2i.count(rm) && !device_learning_)
             throw std::runtime_error("GpuIntraday: reward measure " + rm + " reads Base's windows through the non-virtual getReward(); "
                                      "make Base::getReward virtual (INTEGRATION.md) or use the C ABI's lob_get_reward");
-        params_.reward_measure = r2i.at(rm);
+        if (r2i.count(rm)) params_.reward_measure = r2i.at(rm);
+        else if (rm == "normed") params_.reward_measure = LOB_REWARD_NORMED;  // (device learning: the engine's own getReward)
+        else throw std::runtime_error("Unknown reward measure: " + rm);
         params_.pos_weight = c["reward"]["pos_weight"].as<float>(0.0);
         params_.trd_weight = c["reward"]["trd_weight"].as<float>(0.0);
         params_.pnl_weight = c["reward"]["pnl_weight"].as<float>(1.0);
@@ -150,6 +170,38 @@ public:
         params_.lb_target = c["market"]["target_price"]["lookback"].as<int>(1);
         params_.memory_size = 1;  // the weights stay with the reference's rl::Agent on the host
         params_.theta_mode = LOB_THETA_PRIVATE;
+        if (device_learning_) {
+            // the reads of rl::Agent / the agents' constructors (src/rl/agent.cpp:21-64, src/main.cpp:140-188)
+            params_.memory_size = c["learning"]["memory_size"].as<long>();
+            params_.n_tilings = c["learning"]["n_tilings"].as<int>();
+            params_.n_actions = c["learning"]["n_actions"].as<int>();
+            params_.theta_mode = LOB_THETA_SHARED;
+            if (c["learning"]["group_weights"]) {
+                auto gw = c["learning"]["group_weights"].as<std::vector<double>>();
+                params_.group_weights[0] = gw.at(0);
+                params_.group_weights[1] = gw.at(1);
+                params_.group_weights[2] = gw.size() > 2 ? gw[2] : 1.0 - (gw[0] + gw[1]);
+            } else params_.group_weights[0] = params_.group_weights[1] = params_.group_weights[2] = 1.0 / 3;
+            params_.gamma = c["learning"]["gamma"].as<double>();
+            params_.lambda = c["learning"]["lambda"].as<double>();
+            params_.alpha = c["learning"]["alpha_start"].as<double>(0.2);
+            const std::string pt = c["policy"]["type"].as<std::string>("");
+            if (pt == "greedy") params_.epsilon = 0.0;
+            else if (pt == "epsilon_greedy") params_.epsilon = (double)c["policy"]["eps_init"].as<float>(0.0);
+            else if (pt == "random") params_.epsilon = 1.0;
+            else if (pt == "boltzmann") { params_.policy = LOB_POLICY_BOLTZMANN; params_.tau = (double)c["policy"]["tau_init"].as<float>(); }
+            else throw std::runtime_error("Please specify a valid policy!");
+            const std::string algo = c["learning"]["algorithm"].as<std::string>("sarsa");
+            if (algo == "sarsa") params_.algo = LOB_ALGO_SARSA;
+            else if (algo == "q_learn") params_.algo = LOB_ALGO_QLAMBDA;
+            else if (algo == "double_q_learn") params_.algo = LOB_ALGO_DOUBLE_Q;
+            else if (algo == "r_learn") params_.algo = LOB_ALGO_R_LEARN;
+            else if (algo == "online_r_learn") params_.algo = LOB_ALGO_ONLINE_R_LEARN;
+            else if (algo == "double_r_learn") params_.algo = LOB_ALGO_DOUBLE_R_LEARN;
+            else throw std::invalid_argument("Unknown learning algorithm: " + algo);
+            if (params_.algo >= LOB_ALGO_R_LEARN) params_.beta = c["learning"]["beta"].as<double>();
+            params_.seed = (uint64_t)c["debug"]["random_seed"].as<unsigned>(1994);
+        }
     }
     ~GpuIntraday() { lob_destroy(engine_); }
     GpuIntraday(const GpuIntraday&) = delete;
@@ -158,15 +210,33 @@ public:
     // Intraday::LoadData (intraday.cpp:141-150): the CSV pair -> event records -> HBM
     void LoadData(std::string ticker, std::string md_path, std::string tas_path) {
         check(lob_market_preset(ticker.c_str(), &params_.market), "Market::make_market");
-        if (engine_ == nullptr) check(lob_create(&params_, 1, device_, &engine_), "GpuIntraday");
+        if (engine_ == nullptr) check(lob_create(&params_, n_books_, device_, &engine_), "GpuIntraday");
         uint32_t* rec = nullptr;
         int32_t n = 0;
         check(lob_convert_csv(md_path.c_str(), tas_path.c_str(), params_.max_trades, &rec, &n), "LoadData");
-        const int rc = lob_load_events(engine_, rec, n);
+        int rc;
+        if (n_books_ == 1) rc = lob_load_events(engine_, rec, n);
+        else {  // every book replays the loaded day (one copy in HBM)
+            std::vector<int64_t> phase((size_t)n_books_, 0);
+            rc = lob_load_events_shared(engine_, rec, n, phase.data(), n);
+        }
         lob_free(rec);
         check(rc, "LoadData");
         have_data_ = true;
     }
+    // B synthetic streams generated in HBM (the bench's workload) instead of a CSV pair
+    void LoadSynthetic(std::string ticker, const lob_gen_params& g) {
+        check(lob_market_preset(ticker.c_str(), &params_.market), "Market::make_market");
+        if (engine_ == nullptr) check(lob_create(&params_, n_books_, device_, &engine_), "GpuIntraday");
+        check(lob_gen_events_device(engine_, &g), "LoadData");
+        have_data_ = true;
+    }
+    // the policy RNG streams of the books: draw k of book b = lob_rng(seed, first_stream + b, k) (include/lob_engine.h)
+    void set_rng(uint64_t seed, uint64_t first_stream) { params_.seed = seed; params_.book_id_offset = first_stream; }
+    int n_books() const { return n_books_; }
+    bool device_learning() const { return device_learning_; }
+    const lob_params& params() const { return params_; }
+    void refresh() { mirror(); }   // book 0's numbers into Base's members (GpuLearner calls it at the end of an episode)
 
     bool Initialise() override {  // Intraday::Initialise (intraday.cpp:103-138); false: ran out of data before the windows filled
         if (!have_data_) return false;

@@ -24,7 +24,7 @@ DROPIN = os.path.join(ROOT, "oracle", "_ref", "ref_dropin")
 
 # the fixtures whose reward Base::getReward() can compute from mirrored members, default state variables
 CASES = [c for c in TRAJ_CASES if c[0] in ("sarsa_b0", "qlearn_b3", "sarsa_mm_linear_b11", "sarsa_tight_bounds_b7", "sarsa_book_quotes_b9",
-                                          "qlearn_mm_div_b16", "sarsa_lovol_b18", "sarsa_mm_exp_b20", "sarsa_boltzmann_b23")]
+                                          "qlearn_mm_div_b16", "sarsa_lovol_b18", "sarsa_mm_exp_b20", "sarsa_boltzmann_b23", "sarsa_spread_b15")]
 
 
 @pytest.mark.skipif(not os.path.exists(DROPIN), reason="oracle/_ref/ref_dropin is built where the reference checkout is (make -C oracle dropin)")
@@ -67,13 +67,92 @@ def test_reference_learner_drives_the_gpu_environment(tmp_path, case):
 
 
 def test_binding_rejects_window_rewards(tmp_path):
-    """`spread` / `normed` read Base's rolling windows inside the NON-virtual Base::getReward(): the binding
-    refuses them instead of returning a reward computed on empty windows."""
+    """`normed` reads the mean AND deviation of Base's two PnL windows inside the NON-virtual Base::getReward(): the binding
+    refuses it instead of returning a reward computed on empty windows (`spread` needs one mean, which mirror() supplies:
+    the sarsa_spread_b15 case above)."""
     if not os.path.exists(DROPIN):
         pytest.skip("no ref_dropin")
     rec = engine.gen_stream_host(gen_for(200, {}), 5, 2, 0, 1)
     sp = str(tmp_path / "s.bin")
     rec[0].tofile(sp)
     res = subprocess.run([DROPIN, "dropin", "--stream", sp, "--events", "200", "--book", "0", "--algo", "sarsa", "--mem", "4096",
-                          "--reward", "spread", "--tmp", str(tmp_path / "h")], capture_output=True, text=True)
+                          "--reward", "normed", "--lb_pnl", "10", "--tmp", str(tmp_path / "h")], capture_output=True, text=True)
     assert res.returncode != 0 and "getReward" in res.stderr
+
+
+# ---- the learner half of the binding: experiment::serial::GpuLearner + rl::GpuAgent (gpu_learner.h) ------------------------
+def _sparse_theta(path):
+    raw = np.fromfile(path, dtype=np.uint8)
+    n = int(np.frombuffer(raw[:8].tobytes(), dtype=np.int64)[0])
+    return np.frombuffer(raw[8:8 + 16 * n].tobytes(), dtype=[("i", np.int64), ("v", np.float64)])
+
+
+def _run_learner(tmp_path, name, books, episodes=1, extra=()):
+    case = [c for c in TRAJ_CASES if c[0] == name][0]
+    _, algo, n_events, book, _extra, over = case
+    rec = engine.gen_stream_host(gen_for(n_events, over), 5, 2, book, 1)
+    sp, th, st = str(tmp_path / "s.bin"), str(tmp_path / "theta.bin"), str(tmp_path / "stats.csv")
+    rec[0].tofile(sp)
+    cmd = [DROPIN, "dropin_learner", "--stream", sp, "--events", str(n_events), "--book", "0", "--depth", "5", "--trades", "2",
+           "--algo", algo, "--mem", str(1 << 20), "--seed", "1994", "--rng_stream", str(book), "--eps", "0.8", "--books", str(books),
+           "--episodes", str(episodes), "--theta_out", th, "--stats_out", st, "--tmp", str(tmp_path / "h")] + list(extra)
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
+    eps = [json.loads(l) for l in res.stdout.strip().splitlines() if l.startswith("{")]
+    return case, rec, eps, _sparse_theta(th), open(st).read()
+
+
+@pytest.mark.skipif(not os.path.exists(DROPIN), reason="oracle/_ref/ref_dropin is built where the reference checkout is (make -C oracle dropin)")
+def test_train_call_sequence_over_the_gpu_learner_one_book(tmp_path):
+    """src/main.cpp's train() sequence -- runner.RunEpisode(agent) through a Runner& and an rl::Agent*, then Base's episode
+    getters -- over GpuLearner / GpuAgent / GpuIntraday with ONE book: the all-CPU reference's trajectory fixture must come
+    out -- the learned weights bit for bit (write_theta's host copy), episode reward / PnL, the step count, and the
+    statistics behind getTotalTransactions() / writeStats() (Q17: only the trade statistics survive in the file)."""
+    case, rec, eps, theta, stats = _run_learner(tmp_path, "qlearn_b3", books=1)
+    fx = np.load(os.path.join(GOLD, "traj_qlearn_b3.npz"))
+    last = fx["traj"][-1]["book"]
+    np.testing.assert_array_equal(theta["i"], fx["theta_idx"])
+    np.testing.assert_array_equal(theta["v"], fx["theta_val"])
+    e = eps[0]
+    assert e["reward"] == last["episode_reward"] and e["steps"] >= int(fx["steps"])
+    # the fixture's last record is the state BEFORE RunEpisode's closing ClearInventory: one more market order may follow
+    ntr = int(last["ask_n_transacted"] + last["bid_n_transacted"] + last["market_buys"] + last["market_sells"])
+    assert e["nTr"] in (ntr, ntr + 1)
+    want = ["asks_placed,0", "bids_placed,0", "asks_cancelled,0", "bids_cancelled,0", "ask_transactions,%d" % last["ask_n_transacted"],
+            "bid_transactions,%d" % last["bid_n_transacted"]]
+    assert stats.splitlines()[:6] == want and stats.splitlines()[6].startswith("market_sells,") and len(stats.splitlines()) == 8
+
+
+@pytest.mark.skipif(not os.path.exists(DROPIN), reason="oracle/_ref/ref_dropin is built where the reference checkout is (make -C oracle dropin)")
+@pytest.mark.parametrize("name", ["qlearn_b3", "sarsa_b0"])
+def test_train_call_sequence_over_the_gpu_learner_batched(tmp_path, name):
+    """The same call sequence with 96 books in the engine (every book replays the loaded day from its own policy stream),
+    two episodes: against the oracle running the same batch -- shared weights to 1e-9 (f64 atomic order), book 0's episode
+    totals as Base's getters report them."""
+    B = 96
+    case, rec, eps, theta, _ = _run_learner(tmp_path, name, books=B, episodes=2)
+    _, algo, n_events, book, _extra, over = case
+    from rl_markets_amd import abi
+    p = engine.default_params()
+    p.memory_size = 1 << 20
+    p.algo = {"sarsa": abi.ALGO_SARSA, "q_learn": abi.ALGO_QLAMBDA}[algo]
+    p.theta_mode = abi.THETA_SHARED
+    p.book_id_offset = book
+    for k, v in over.items():
+        setattr(p, k, v)
+    orc = ol.Oracle(p, np.repeat(rec, B, axis=0))
+    for ep in range(2):
+        orc.reset()
+        for _ in range(4000):
+            orc.td_step(8)
+            if orc.counters()[2] == 0:
+                break
+        want_book0 = orc.rec(0)["book"]
+        orc.clear_inventory()
+        orc.handle_terminal()
+        assert eps[ep]["reward"] == want_book0["episode_reward"], "episode %d" % ep
+    oth = orc.theta(0)
+    idx = np.flatnonzero(oth)
+    np.testing.assert_array_equal(theta["i"], idx)
+    np.testing.assert_allclose(theta["v"], oth[idx], rtol=1e-9, atol=1e-15)
+    orc.close()

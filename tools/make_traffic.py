@@ -30,6 +30,15 @@ for k, c in sorted(rows.items()):
     for n in ("TCC_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum"):
         if n in c:
             e[n.lower()] = c[n]
+    # instruction issue (bench.py's issue_frac): wave-level instructions of every kind per launch, waves, and the SQ's own clocks
+    insts = [c.get(n) for n in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM")]
+    if all(v is not None for v in insts):
+        e["insts_per_launch"] = sum(insts)
+        e["insts_valu"], e["insts_salu"] = c["SQ_INSTS_VALU"], c["SQ_INSTS_SALU"]
+    for n, key in (("SQ_WAVES", "waves"), ("SQ_WAVE_CYCLES", "wave_quad_cycles"), ("SQ_BUSY_CYCLES", "busy_cycles"), ("SQ_WAIT_ANY", "wait_any_quad_cycles"),
+                   ("SQ_ACTIVE_INST_VALU", "active_valu_quad_cycles")):
+        if n in c:
+            e[key] = c[n]
     if c.get("TCC_MISS_sum"):
         e["fetch_over_miss64"] = round(c["FETCH_SIZE"] * 1024.0 / (c["TCC_MISS_sum"] * 64.0), 3)
     out[k] = e
