@@ -387,6 +387,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
         if (rc == LOB_OK) rc = dev_alloc(e, &S.rl_t, rl ? B : 1);
     }
     if (rc == LOB_OK) rc = dev_alloc(e, &S.tr_sig, B * (size_t)P.trace_gens * 4);
+    if (rc == LOB_OK) rc = dev_alloc(e, &S.tr_cbslot, B * (size_t)P.trace_gens);
     {
         int slots = 1024;
         while ((size_t)slots < 4 * B && slots < (1 << 20)) slots <<= 1;

@@ -1253,24 +1253,21 @@ __global__ void __launch_bounds__(LOB_BLOCK) accumulate_kernel(DevParams P, DevS
         const int slot = (head - age + G) & (G - 1);
         uint32_t mask = 0;
         int4 sg = make_int4(0, 0, 0, 0);
+        int cs = -1;
         if (age < n) {
             mask = tr_alive[slot];
             sg = *reinterpret_cast<const int4*>(tr_sig + slot * 4);
+            cs = S.tr_cbslot[(size_t)bb * G + slot];  // where this step's claim of the generation ended (cb_claim_finish)
         }
         bool direct = false;
         if (mask) {
-            const u64 hsh = cb_hash(sg.x, sg.y, sg.z, sg.w, mask);
-            uint32_t s = (uint32_t)hsh & (uint32_t)(S.cb_slots - 1);
             bool found = false;
-            for (int probe = 0; probe < LOB_CB_PROBES; probe++) {
-                const u64 kk = S.cb_key[s];
-                if (kk == hsh) {
-                    const i32* id = S.cb_ident + (size_t)s * 8;
-                    found = id[0] == sg.x && id[1] == sg.y && id[2] == sg.z && id[3] == sg.w && (uint32_t)id[4] == mask;
-                    break;  // the first slot with this hash is the only one claim can have made
-                }
-                if (kk == LOB_CB_EMPTY) break;
-                s = (s + 1) & (uint32_t)(S.cb_slots - 1);
+            uint32_t s = 0;
+            if (cs >= 0) {
+                s = (uint32_t)cs;
+                const int4 id = *reinterpret_cast<const int4*>(S.cb_ident + (size_t)s * 8);
+                const uint32_t idm = (uint32_t)S.cb_ident[(size_t)s * 8 + 4];
+                found = id.x == sg.x && id.y == sg.y && id.z == sg.z && id.w == sg.w && idm == mask;
             }
             if (found) {
                 __hip_atomic_fetch_add(&S.cb_acc[(size_t)s * 2 + target], scaled * (f64)P.trace_pow[age], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

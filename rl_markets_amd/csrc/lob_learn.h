@@ -190,6 +190,9 @@ __device__ inline void cb_claim_issue(const DevState& S, CbPending& c, int q0, i
     c.s = (uint32_t)c.h & (uint32_t)(S.cb_slots - 1);
     c.old = atomicCAS((unsigned long long*)&S.cb_key[c.s], (unsigned long long)LOB_CB_EMPTY, (unsigned long long)c.h);
 }
+// ... and records, for the generation that asked (`src` = book * trace_gens + ring slot), which slot carries its hash:
+// accumulate_kernel goes straight there (it compares the identity in full: a slot taken by another identity with the same
+// 64-bit hash, or no slot at all, sends the generation down the direct path).
 __device__ inline void cb_claim_finish(const DevState& S, const CbPending& c) {
     if (!c.active) return;
     u64 old = c.old;
@@ -200,12 +203,14 @@ __device__ inline void cb_claim_finish(const DevState& S, const CbPending& c) {
             id[0] = c.q0; id[1] = c.q1; id[2] = c.q2; id[3] = c.code; id[4] = (i32)c.mask; id[5] = c.src;
             const int pos = atomicAdd(S.cb_count, 1);
             S.cb_list[pos] = (i32)s;  // pos < cb_slots: every slot is listed at most once
+            S.tr_cbslot[c.src] = (i32)s;
             return;
         }
-        if (old == c.h) return;
+        if (old == c.h) { S.tr_cbslot[c.src] = (i32)s; return; }
         s = (s + 1) & (uint32_t)(S.cb_slots - 1);
         old = atomicCAS((unsigned long long*)&S.cb_key[s], (unsigned long long)LOB_CB_EMPTY, (unsigned long long)c.h);
     }
+    S.tr_cbslot[c.src] = -1;  // table crowded
 }
 
 // (base + term) mod M with both operands already reduced: one add, one compare, one select.

@@ -247,6 +247,7 @@ struct DevState {
     // generation -- the live tiles one (group-0 state, action) left behind -- so their updates are
     // summed per distinct (generation identity, alive mask) first and applied to theta once.
     i32* tr_sig;         // [B][trace_gens][4]: q0, q1, q2 (= (int)floor(32 x) of the three group-0 variables), action | zero << 8
+    i32* tr_cbslot;      // [B][trace_gens] slot of cb_key the generation's claim of THIS step ended on (-1: none), cb_claim_finish
     u64* cb_key;         // [cb_slots] 64-bit hash of (signature, mask), ~0 = empty
     i32* cb_ident;       // [cb_slots][8]: q0, q1, q2, code, mask, representative (book * trace_gens + slot), -, -
     f64* cb_acc;         // [cb_slots][2]: summed update for theta / theta_b
