@@ -636,7 +636,7 @@ __global__ void __launch_bounds__(LOB_LIGHT_BLOCK) trace_light_kernel(DevParams 
             CbPending pend;
             cb_claim_issue(S, pend, q0, q1, q2, action, 0xffffffffu, b * G + nh);
             cb_claim_finish(S, pend);
-        }
+        } else S.tr_cbslot[(size_t)b * G + nh] = (i32)((uint32_t)ch & (uint32_t)(S.cb_slots - 1));
     }
 }
 
@@ -976,6 +976,7 @@ __global__ void __launch_bounds__(LOB_QL_BLOCK) learn_q_lane_kernel(DevParams P,
                     const u64 seen = atomicCAS((unsigned long long*)&claimed[(ch >> 40) & 511], (unsigned long long)LOB_CB_EMPTY, (unsigned long long)ch);
                     if (seen != ch && S.cb_key[(uint32_t)ch & (uint32_t)(S.cb_slots - 1)] != ch)
                         cb_claim_issue(S, pend, tq0, tq1, tq2, action, 0xffffffffu, b * G + nh);  // (its answer is looked at last)
+                    else S.tr_cbslot[(size_t)b * G + nh] = (i32)((uint32_t)ch & (uint32_t)(S.cb_slots - 1));  // (the hash's home slot: where accumulate_kernel looks first)
                 }
             }
         }
@@ -1189,6 +1190,7 @@ __global__ void __launch_bounds__(LOB_QP_BLOCK) learn_q_pair_kernel(DevParams P,
                         const u64 seen = atomicCAS((unsigned long long*)&claimed[(ch >> 40) & 511], (unsigned long long)LOB_CB_EMPTY, (unsigned long long)ch);
                         if (seen != ch && S.cb_key[(uint32_t)ch & (uint32_t)(S.cb_slots - 1)] != ch)
                             cb_claim_issue(S, pend, tq0, tq1, tq2, action, 0xffffffffu, b * G + nh);
+                        else S.tr_cbslot[(size_t)b * G + nh] = (i32)((uint32_t)ch & (uint32_t)(S.cb_slots - 1));
                     }
                 }
                 // Q(s, a) and the RNG counter after the trace step's draws: for the general kernel if the book is handed back

@@ -1263,11 +1263,25 @@ __global__ void __launch_bounds__(LOB_BLOCK) accumulate_kernel(DevParams P, DevS
         if (mask) {
             bool found = false;
             uint32_t s = 0;
-            if (cs >= 0) {
-                s = (uint32_t)cs;
+            if (cs >= 0) {  // the slot this step's claim ended on (or, for a claim another lane made, the hash's home slot)
+                s = (uint32_t)cs & (uint32_t)(S.cb_slots - 1);
                 const int4 id = *reinterpret_cast<const int4*>(S.cb_ident + (size_t)s * 8);
                 const uint32_t idm = (uint32_t)S.cb_ident[(size_t)s * 8 + 4];
-                found = id.x == sg.x && id.y == sg.y && id.z == sg.z && id.w == sg.w && idm == mask;
+                found = id.x == sg.x && id.y == sg.y && id.z == sg.z && id.w == sg.w && idm == mask && S.cb_key[s] != LOB_CB_EMPTY;
+            }
+            if (!found) {  // (a displaced slot: walk the probe sequence)
+                const u64 hsh = cb_hash(sg.x, sg.y, sg.z, sg.w, mask);
+                s = (uint32_t)hsh & (uint32_t)(S.cb_slots - 1);
+                for (int probe = 0; probe < LOB_CB_PROBES; probe++) {
+                    const u64 kk = S.cb_key[s];
+                    if (kk == hsh) {
+                        const i32* id = S.cb_ident + (size_t)s * 8;
+                        found = id[0] == sg.x && id[1] == sg.y && id[2] == sg.z && id[3] == sg.w && (uint32_t)id[4] == mask;
+                        break;  // the first slot with this hash is the only one claim can have made
+                    }
+                    if (kk == LOB_CB_EMPTY) break;
+                    s = (s + 1) & (uint32_t)(S.cb_slots - 1);
+                }
             }
             if (found) {
                 __hip_atomic_fetch_add(&S.cb_acc[(size_t)s * 2 + target], scaled * (f64)P.trace_pow[age], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
