@@ -62,6 +62,8 @@ struct lob_engine {
     bool force_fuse_act = false;
     bool fuse_act = true;       // ... inside the env kernel (env_kernel<.., 1>; LOB_NO_FUSE_ACT=1: act_light_kernel as a launch of its own)
  bool t_light = true;        // trace_light_kernel in front of the wave-per-book trace kernel (Q(lambda); LOB_NO_TLIGHT=1: off)
+    bool inline_general = true; // ... serving the books without a hit list itself (LOB_INLINE_GENERAL=0: through the work list, two more launches)
+    int steps_on_lists = 0;     // fused steps since the hit lists were last void
     bool env_step = true;       // env_step_kernel for the fused action selection + step (LOB_ENV_STEP=0: env_kernel<64, 2, 1>; A/B switch)
     bool no_fuse = false;       // LOB_NO_FUSE=1: the light trace step as a kernel of its own, not inside the lane learner kernel (A/B switch)
     bool q_pair = true;         // ... two lanes per book (learn_q_pair_kernel; LOB_Q_PAIR=0: one)
@@ -282,6 +284,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     if (const char* g = getenv("LOB_Q_PAIR")) e->q_pair = !(g[0] == '0');
     if (const char* g = getenv("LOB_NO_FUSE")) e->no_fuse = g[0] == '1';
     if (const char* g = getenv("LOB_ENV_STEP")) e->env_step = !(g[0] == '0');
+    if (const char* g = getenv("LOB_INLINE_GENERAL")) e->inline_general = !(g[0] == '0');
     if (const char* g = getenv("LOB_RESET_LANES")) { int v = atoi(g); if (v == 16 || v == 32 || v == 64) e->reset_lanes = v; }
 
     // ---- DevParams ----
@@ -698,13 +701,20 @@ static void launch_env_fused(lob_engine* e, hipStream_t st, int par, int lpar, u
     const bool t2 = e->P.T <= 2;
     const int nb = e->B, sid = e->step_id;
     const EnvFuse F1{nullptr, nullptr, lpar, sid - 1, ver}, F2{act_list, act_n, lpar, sid - 1, ver};
+    // Two trade slots per record: env_step_kernel (lob_envstep.h; LOB_ENV_STEP=0: env_kernel<64, 2, 1>).  It serves the books
+    // without a usable hit list itself (act_book in-kernel) -- except in the first step on lists after they were void, when a late
+    // map bit of the step before has voided them again and EVERY book takes the general path: that step goes through
+    // the work list to the general act kernel and env_kernel<64, 2, 2> as before (either version is correct for any step).
+    const bool inline_general = t2 && e->env_step && e->inline_general && e->steps_on_lists >= 1;
+    e->steps_on_lists++;
     {
         TimedLaunch t(e, "env_kernel", st);
-        // (two trade slots per record: the same step with its memory round trips regrouped, lob_envstep.h; LOB_ENV_STEP=0: env_kernel<64, 2, 1>)
-        if (t2 && e->env_step) hipLaunchKernelGGL(env_step_kernel, dim3((nb + 63) / 64), dim3(64), 0, st, Pd, e->S, sid, par, F1);
+        if (inline_general) hipLaunchKernelGGL(env_step_kernel<true>, dim3((nb + 63) / 64), dim3(64), 0, st, Pd, e->S, sid, par, F1, (const uint32_t*)e->rnd_dev);
+        else if (t2 && e->env_step) hipLaunchKernelGGL(env_step_kernel<false>, dim3((nb + 63) / 64), dim3(64), 0, st, Pd, e->S, sid, par, F1, (const uint32_t*)e->rnd_dev);
         else if (t2) hipLaunchKernelGGL((env_kernel<64, 2, 1>), dim3((nb + 63) / 64), dim3(64), 0, st, Pd, e->S, (const i32*)nullptr, 1, 0, nb, sid, par, F1);
         else hipLaunchKernelGGL((env_kernel<64, LOB_MAX_TRADES, 1>), dim3((nb + 63) / 64), dim3(64), 0, st, Pd, e->S, (const i32*)nullptr, 1, 0, nb, sid, par, F1);
     }
+    if (inline_general) return;
     {
         TimedLaunch t(e, "act_rest_kernel", st);
         hipLaunchKernelGGL((act_kernel<LOB_ALGO_SARSA, true>), dim3(gl), dim3(LOB_BLOCK), 0, st, e->P, e->S, (const uint32_t*)e->rnd_dev, 0, 0, e->B, par, act_list, act_n);
@@ -869,6 +879,7 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
         // double-buffered list of newly written weights (verdict carry-over, lob_state.h)
         const int par = mode == 0 ? (first ? (e->td_parity ^= 1) : e->td_parity) : 0;
         if (first) e->step_id++;
+        if (!e->hits_ok) e->steps_on_lists = 0;
         const u64 ver = (u64)e->theta_ver;
         if (G > 1) {
             HIPCHK(hipEventRecord(e->ev_fork, e->stream));

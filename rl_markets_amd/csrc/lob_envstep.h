@@ -33,10 +33,17 @@ __device__ inline Track track_load(const Track* p) {
     return t;
 }
 
-__global__ void __launch_bounds__(64) env_step_kernel(const DevParams* __restrict__ Pp, DevState S, int step_id, int par, EnvFuse F) {
+// INLINE_GENERAL: a book without a usable hit list (a list longer than a record, a State still at its constructor zeros, lists
+// voided by a late map bit) gets its action from the general evaluation right here -- act_book, the whole wave on one book at a
+// time -- instead of going through the work list to act_kernel + env_kernel<64, 2, 2>: two launches that find their list empty
+// in all but a handful of steps per episode no longer exist.  (false: the work-list version; the engine uses it for the one
+// step per episode in which EVERY book takes the general path.)
+template <bool INLINE_GENERAL>
+__global__ void __launch_bounds__(64) env_step_kernel(const DevParams* __restrict__ Pp, DevState S, int step_id, int par, EnvFuse F, const uint32_t* __restrict__ rnd_g) {
     const DevParams& P = *Pp;
     __shared__ TickLds tick_lds;
     __shared__ EnvSlot lds_env[64];
+    __shared__ LearnLds1 lds_learn;
 #ifdef LOB_PROF
     const long long t_entry = clock64();
 #else
@@ -130,8 +137,10 @@ __global__ void __launch_bounds__(64) env_step_kernel(const DevParams* __restric
         } else {
             ok = ok && rec.ver == F.ver;
             if (!ok) {
-                const int pos = atomicAdd(&S.slow_n[F.lpar * 2 + 0], 1);
-                S.slow_list[pos] = b;
+                if (!INLINE_GENERAL) {
+                    const int pos = atomicAdd(&S.slow_n[F.lpar * 2 + 0], 1);
+                    S.slow_list[pos] = b;
+                }
             } else {
                 f64 q[LOB_N_ACTIONS];
 #pragma unroll
@@ -172,6 +181,26 @@ __global__ void __launch_bounds__(64) env_step_kernel(const DevParams* __restric
         }
     }
 #undef LOB_HL_ENT
+    if (INLINE_GENERAL) {
+        // the books the replay could not serve: Agent::action in full (all 128 terms of every Q), one book at a time, the wave
+        // on it as in act_kernel (act_book: swap, terminal check, Q(last_state, .), policy, header, tile marks)
+        u64 todo = __ballot(valid && alive && open && !ok);
+        if (todo) {
+            const uint4* src = reinterpret_cast<const uint4*>(rnd_g);
+            uint4* dst = reinterpret_cast<uint4*>(lds_learn.rnd);
+            for (int i = threadIdx.x; i < 512; i += 64) dst[i] = src[i];
+            if (threadIdx.x < 27) lds_learn.act_terms[threadIdx.x] = rnd_g[2048 + threadIdx.x];
+            wave_lds_fence();
+            while (todo) {
+                const int src_lane = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const int b_src = __builtin_amdgcn_readlane(b, src_lane);
+                int act = -1;
+                act_book<LOB_ALGO_SARSA, LearnLds1>(P, S, lds_learn, 0, (int)threadIdx.x, b_src, 0, par, &act);
+                if ((int)threadIdx.x == src_lane && act >= 0) { action = act; go = true; }
+            }
+        }
+    }
 
     // ---- performAction -----------------------------------------------------------------------------------------------------
     i64 d_steps = 0, d_events = 0;

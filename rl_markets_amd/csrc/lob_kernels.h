@@ -535,6 +535,15 @@ struct LearnLds {
     uint32_t newf[2][LOB_NZ_FILTER];                      // act only: filters of the map bits first set by the previous update (theta, theta_b)
 };
 
+// The same for a block of ONE wave (env_step_kernel's in-kernel general action selection)
+struct LearnLds1 {
+    uint32_t rnd[2048];
+    uint32_t act_terms[32];
+    f64 vals[1][LOB_HSLOTS];
+    f32 vars[1][3][16];
+    uint32_t newf[2][LOB_NZ_FILTER];  // (unused on the memo path: no verdict carry-over there)
+};
+
 // Stage the hash table (8 KB, two 16-byte loads per thread), the 27 action terms and, for act, the
 // carry-over filters; ONE block barrier.
 __device__ inline void learn_stage_table(const uint32_t* __restrict__ rnd_g, LearnLds& L, const i32* __restrict__ nz_buf = nullptr) {
@@ -579,8 +588,11 @@ __device__ inline u64 vd_tag(uint32_t epoch, int slot) { return (u64)epoch | ((u
 // ALGO is a compile-time parameter: the double-Q path needs a second weight vector and more
 // registers; keeping it out of the SARSA / Q(lambda) instantiations keeps them small.
 __device__ inline bool nzx_mark(const DevParams& P, const DevState& S, i32 f);
-template <int ALGO>
-__device__ __forceinline__ void act_book(const DevParams& P, const DevState& S, LearnLds& L, int w, int lane, int b, int mode, int par) {
+// LDS = LearnLds, or the one-wave image env_step_kernel keeps for the books its hit-list replay cannot serve; `out_action`
+// (optional): the action chosen, or -1 if the book does not step.
+template <int ALGO, class LDS = LearnLds>
+__device__ __forceinline__ void act_book(const DevParams& P, const DevState& S, LDS& L, int w, int lane, int b, int mode, int par, int* out_action = nullptr) {
+    if (out_action) *out_action = -1;
     const LHdr h = S.hdr[b];  // one scalar 64-byte load
     const i32* nz_new = S.nz_new + (par ^ 1) * LOB_NZ_WORDS;  // written by the previous step's update
     const uint16_t* vd = S.verdict + (size_t)b * LOB_VD_STRIDE;
@@ -626,6 +638,7 @@ __device__ __forceinline__ void act_book(const DevParams& P, const DevState& S, 
     }
     Rng g{P.seed, P.book_id_offset + (u64)b, h.rng_ctr};
     const int action = policy_sample(P, qs, mode == 1, g);
+    if (out_action) *out_action = action;
     if (lane == 0) {
         hp->slot_cur = cur;
         hp->action = action;
