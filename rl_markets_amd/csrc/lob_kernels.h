@@ -1390,30 +1390,43 @@ __global__ void __launch_bounds__(256) memo_kernel(DevParams P, DevState S, cons
         S.tr_list_n[reset_lpar] = 0;
     }
     __shared__ f64 vals[4][LOB_N_ACTIONS * LOB_QSTRIDE];
+    __shared__ uint32_t rnd[2048 + 32];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31;
     const bool hi = lane >= 32;
     const int wave = blockIdx.x * 4 + w, n_waves = gridDim.x * 4;
     const uint32_t M = (uint32_t)P.M;
+    // The kernel is a short chain of dependent look-ups (count -> list entry -> identity -> hash table -> weights) run by a few
+    // hundred waves: the first list entry is requested with the count (wave i takes entry i first; the list is always
+    // allocated in full), and the hash table goes to LDS meanwhile -- two round trips fewer.
+    const int s_first = S.mk_list[(size_t)par * S.mk_slots + (wave < S.mk_slots ? wave : 0)];
     int count = S.mk_count[par];
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(rnd_g);
+        uint4* dst = reinterpret_cast<uint4*>(rnd);
+        const uint4 r0 = src[threadIdx.x], r1 = src[threadIdx.x + 256];
+        dst[threadIdx.x] = r0; dst[threadIdx.x + 256] = r1;
+        if (threadIdx.x < 27) rnd[2048 + threadIdx.x] = rnd_g[2048 + threadIdx.x];
+    }
+    __syncthreads();
     if (count > S.mk_slots) count = S.mk_slots;
     f64* v = vals[w];
     for (int i = wave; i < count; i += n_waves) {
-        const int s = S.mk_list[(size_t)par * S.mk_slots + i];
+        const int s = i == wave ? s_first : S.mk_list[(size_t)par * S.mk_slots + i];
         const int4 id = *reinterpret_cast<const int4*>(S.mk_ident + (size_t)s * 4);
         uint32_t sum = 0;
         {
             int base = j;
-            sum = mod_add(sum, rnd_g[(tile_coord(id.x, base) + 449 * 0) & 2047], M); base += 2 * j;
-            sum = mod_add(sum, rnd_g[(tile_coord(id.y, base) + 449 * 1) & 2047], M); base += 2 * j;
-            sum = mod_add(sum, rnd_g[(tile_coord(id.z, base) + 449 * 2) & 2047], M);
-            sum = mod_add(sum, rnd_g[(j + 449 * 3) & 2047], M);
+            sum = mod_add(sum, rnd[(tile_coord(id.x, base) + 449 * 0) & 2047], M); base += 2 * j;
+            sum = mod_add(sum, rnd[(tile_coord(id.y, base) + 449 * 1) & 2047], M); base += 2 * j;
+            sum = mod_add(sum, rnd[(tile_coord(id.z, base) + 449 * 2) & 2047], M);
+            sum = mod_add(sum, rnd[(j + 449 * 3) & 2047], M);
         }
         f64 t[5];
         const bool fill = S.mk_tiles_ok[s] == 0;  // first time on a list: leave the tile indices for the trace kernel
 #pragma unroll
         for (int k = 0; k < 5; k++) {
             const int a = (hi ? 5 : 0) + k;
-            const i32 tile = tile_index(sum, rnd_g[2048 + (a < LOB_N_ACTIONS ? a : 0)], M);
+            const i32 tile = tile_index(sum, rnd[2048 + (a < LOB_N_ACTIONS ? a : 0)], M);
             t[k] = a < LOB_N_ACTIONS ? S.theta[tile] : 0.0;
             if (fill && a < LOB_N_ACTIONS) S.mk_tiles[((size_t)s * LOB_N_ACTIONS + a) * 32 + j] = tile;
         }
