@@ -227,9 +227,9 @@ def main():
         comm.exchange_stats()   # (drop the warm-up's)
     c0 = eng.counters()
     if not args.no_kernel_timing:
-        # HIP events around the kernels of every n-th step of the timed region (5-8 sampled steps): timing every
-        # launch costs 9 % of a step (two event records per launch, eleven launches per step)
-        eng.kernel_timing(max(4, args.steps // 8))
+        # HIP events around the kernels of every n-th step of the timed region (2-8 sampled steps): timing every
+        # launch costs 9 % of a step (two event records per launch, eight launches per step)
+        eng.kernel_timing(max(8, args.steps // 8))
     t0 = time.perf_counter()
     learner.run(args.steps)
     barrier()
