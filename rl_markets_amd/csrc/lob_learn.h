@@ -12,6 +12,7 @@
 
 #include "lob_state.h"
 #include "lob_stream.h"
+#include "lob_exp_table.h"
 
 // Phase clocks of the wave-per-book kernels: -DLOB_PROF builds stamp clock64 at phase boundaries (lane 0
 // of every wave adds the elapsed clocks to its book's row); a regular build compiles them away.
@@ -116,13 +117,63 @@ __device__ inline int greedy_sample(const f64* qs, Rng& g) {
     }
     return argmax;
 }
+// std::exp(double) as the reference's libm computes it (glibc 2.35 x86-64, sysdeps/ieee754/dbl-64/e_exp.c, the FMA build its
+// ifunc selects): exp(x) = 2^(k/128) * (1 + tail + r + r^2 (C2 + r C3) + r^4 (C4 + r C5)), 128-entry table, every a*b+c fused
+// except inside the over/underflow special case.  Constants and table: lob_exp_table.h (the library's own __exp_data).
+// tools/check_exp.c compares this restatement with libm's exp over 4e8 inputs (ordinary Q / tau, +-750, any bit pattern, near 0):
+// 0 differences -- so a Boltzmann action, an index, is bit-exact by construction like every other action.
+__device__ inline f64 exp_glibc(f64 x) {
+    static const u64 T[256] = {LOB_EXP_TABLE_VALUES};
+    const u64 ux = (u64)__double_as_longlong(x);
+    uint32_t abstop = (uint32_t)(ux >> 52) & 0x7ffu;
+    if (abstop - 0x3c9u >= 0x408u - 0x3c9u) {  // top12(0x1p-54) = 0x3c9, top12(512.0) = 0x408
+        if (abstop - 0x3c9u >= 0x80000000u) return 1.0 + x;  // |x| < 2^-54
+        if (abstop >= 0x409u) {                 // top12(1024.0)
+            if (ux == 0xfff0000000000000ull) return 0.0;
+            if (abstop >= 0x7ffu) return 1.0 + x;
+            return (ux >> 63) ? 0.0 : __longlong_as_double(0x7ff0000000000000ll);  // __math_uflow / __math_oflow
+        }
+        abstop = 0;  // large |x|: the special case below
+    }
+    const f64 z = LOB_EXP_INVLN2N * x;
+    f64 kd = z + LOB_EXP_SHIFT;
+    const u64 ki = (u64)__double_as_longlong(kd);
+    kd -= LOB_EXP_SHIFT;
+    const f64 r = fma(kd, LOB_EXP_NEGLN2LON, fma(kd, LOB_EXP_NEGLN2HIN, x));
+    const u64 idx = 2 * (ki % 128), top = ki << (52 - 7);
+    const f64 tail = __longlong_as_double((long long)T[idx]);
+    u64 sbits = T[idx + 1] + top;
+    const f64 r2 = r * r;
+    const f64 p23 = fma(r, LOB_EXP_C3, LOB_EXP_C2), p45 = fma(r, LOB_EXP_C5, LOB_EXP_C4);
+    const f64 tmp = fma(r2 * r2, p45, fma(r2, p23, tail + r));
+    if (abstop == 0) {  // specialcase(): the result may over- or underflow
+        if ((ki & 0x80000000ull) == 0) {  // k > 0
+            sbits -= 1009ull << 52;
+            const f64 scale = __longlong_as_double((long long)sbits);
+            return 0x1p1009 * fma(scale, tmp, scale);
+        }
+        sbits += 1022ull << 52;  // k < 0: care in the subnormal range
+        const f64 scale = __longlong_as_double((long long)sbits);
+        f64 y = scale + scale * tmp;
+        if (y < 1.0) {
+            f64 lo = scale - y + scale * tmp;
+            const f64 hi = 1.0 + y;
+            lo = 1.0 - hi + y + lo;
+            y = (hi + lo) - 1.0;
+            if (y == 0.0) y = 0.0;
+        }
+        return 0x1p-1022 * y;
+    }
+    const f64 scale = __longlong_as_double((long long)sbits);
+    return fma(scale, tmp, scale);
+}
 // Boltzmann::Sample (policy.cpp:98-117): probabilities exp(Q / tau) / z, one uniform draw, first action whose
 // cumulative probability exceeds it.
 __device__ inline int boltzmann_sample(const f64* qs, f64 tau, Rng& g) {
     f64 p[LOB_N_ACTIONS], z = 0.0;
 #pragma unroll
     for (int a = 0; a < LOB_N_ACTIONS; a++) {
-        p[a] = exp(qs[a] / tau);
+        p[a] = exp_glibc(qs[a] / tau);
         z += p[a];
     }
     const f64 r = (f64)(g.raw() >> 11) * (1.0 / 9007199254740992.0);

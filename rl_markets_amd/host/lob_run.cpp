@@ -73,7 +73,7 @@ int main(int argc, char** argv) {
 }
 
 static int run(int argc, char** argv, int rank, int world, const std::string& rdzv) {
-    std::string cfg_path, algo, theta_out, profit_log, md, tas, lob_ob, lob_msg;
+    std::string cfg_path, algo, theta_out, profit_log, stats_out, md, tas, lob_ob, lob_msg;
     int lob_levels = 0;
     int books = 1, episodes = 1, events = 2112, depth = 5, sync_every = 64;
     for (int i = 1; i < argc; i++) {
@@ -87,6 +87,7 @@ static int run(int argc, char** argv, int rank, int world, const std::string& rd
         else if (a == "--depth") depth = atoi(next().c_str());
         else if (a == "--theta") theta_out = next();
         else if (a == "--profit-log") profit_log = next();
+        else if (a == "--stats-out") stats_out = next();   // env.writeStats(output_dir + "test_stats.csv"), src/main.cpp:242
         else if (a == "--md") md = next();
         else if (a == "--tas") tas = next();
         else if (a == "--lobster") { lob_ob = next(); lob_msg = next(); lob_levels = atoi(next().c_str()); }
@@ -146,6 +147,11 @@ static int run(int argc, char** argv, int rank, int world, const std::string& rd
             if (!bt.RunEpisode(&agent)) { fprintf(stderr, "[!] no data\n"); return 2; }
             bt.stop_logging();
             printf("backtest,%.10g,%.10g,%d\n", env.getEpisodeReward(0), env.getEpisodePnL(0), env.book(0).total_ticks);
+        }
+        if (!stats_out.empty() && rank == 0) {
+            // src/main.cpp:234-242: nTr / Ppt on the console, then writeStats (book 0; quirk Q17: the trade statistics survive)
+            printf("stats,%d,%.10g\n", env.getTotalTransactions(0), env.getEpisodePnL(0) / env.getTotalTransactions(0));
+            env.writeStats(stats_out, 0);
         }
     } catch (std::exception& e) {
         fprintf(stderr, "Unhandled Exception: %s\n", e.what());  // main.cpp:364-368

@@ -19,3 +19,20 @@ def test_fast_pass_equals_general_pass(tmp_path):
     out = subprocess.run([exe, os.environ.get("LOB_PASS_DIFF_CASES", "300000")], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout[-2000:]
     assert "pass_diff OK" in out.stdout
+
+
+def test_exp_restatement_equals_libm(tmp_path):
+    """rl::Boltzmann::Sample calls std::exp(double); the engine restates glibc 2.35's algorithm on the device (lob_learn.h
+    exp_glibc, table lob_exp_table.h).  tools/check_exp.c is the same arithmetic on the host against this libm's exp():
+    ordinary Q / tau, the over- and underflow ranges, arbitrary bit patterns, the neighbourhood of 0 -- no difference allowed."""
+    exe = str(tmp_path / "check_exp")
+    subprocess.check_call(["gcc", "-O2", "-fopenmp", "-mfma", "-ffp-contract=off", "-I" + os.path.join(ROOT, "rl_markets_amd", "csrc"),
+                           "-o", exe, os.path.join(ROOT, "tools", "check_exp.c"), "-lm"])
+    out = subprocess.run([exe, os.environ.get("LOB_EXP_CASES", "40000000")], capture_output=True, text=True)
+    assert out.returncode == 0 and "mismatches 0" in out.stdout, out.stdout[-1500:]
+    # the table in the header is the library's own (tools/gen_exp_table.py reads it back from libm.so.6)
+    gen = subprocess.run(["python3", os.path.join(ROOT, "tools", "gen_exp_table.py")], capture_output=True, text=True)
+    if gen.returncode == 0:   # (a libm without this __exp_data layout: nothing to compare)
+        hdr = open(os.path.join(ROOT, "rl_markets_amd", "csrc", "lob_exp_table.h")).read()
+        for line in gen.stdout.splitlines()[1:]:
+            assert line.strip().rstrip("\\").rstrip().rstrip(",") in hdr
