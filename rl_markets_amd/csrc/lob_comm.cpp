@@ -158,6 +158,7 @@ int lob_comm_pin_host_thread(int32_t device, int32_t* n_cpus) {
 void lob_comm_destroy(lob_comm* c) {
     if (!c) return;
     hipSetDevice(c->device);
+    for (auto& y : c->stamps) for (auto& v : y.ev) hipEventDestroy(v);
     if (c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); }
     if (c->scratch) hipFree(c->scratch);
     if (c->comm) ncclCommDestroy(c->comm);
@@ -198,12 +199,9 @@ int lob_comm_allgather_u32(lob_comm* c, const uint32_t* dev_send, uint32_t* dev_
 
 static hipEvent_t new_event() { hipEvent_t e; hipEventCreateWithFlags(&e, hipEventDisableSystemFence); return e; }
 
-int lob_theta_allreduce(lob_engine* e, lob_comm* c) {
-    if (!e || !c) { lob_set_error("lob_theta_allreduce: bad argument"); return LOB_EINVAL; }
+static int theta_allreduce_impl(lob_engine* e, lob_comm* c, ExchangeStamp& x) {
     hipStream_t st = (hipStream_t)lob_stream(e);
     static const bool dense_forced = getenv("LOB_DENSE_EXCHANGE") && getenv("LOB_DENSE_EXCHANGE")[0] == '1';
-    ExchangeStamp x;
-    for (auto& v : x.ev) v = new_event();
     int rc;
     hipEventRecord(x.ev[0], st);
     if (!dense_forced && lob_delta_sparse_supported(e)) {
@@ -239,6 +237,23 @@ int lob_theta_allreduce(lob_engine* e, lob_comm* c) {
         x.sparse = 0;
     }
     hipEventRecord(x.ev[3], st);
+    return rc;
+}
+
+int lob_theta_allreduce(lob_engine* e, lob_comm* c) {
+    if (!e || !c) { lob_set_error("lob_theta_allreduce: bad argument"); return LOB_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    ExchangeStamp x;
+    for (auto& v : x.ev) v = new_event();
+    const int rc = theta_allreduce_impl(e, c, x);
+    if (rc != LOB_OK || c->stamps.size() >= 4096) {  // a failed exchange, or nobody reads the statistics: no stamps kept
+        for (auto& v : x.ev) hipEventDestroy(v);
+        if (rc == LOB_OK && c->stamps.size() >= 4096) {
+            for (auto& y : c->stamps) for (auto& v : y.ev) hipEventDestroy(v);
+            c->stamps.clear();
+        }
+        return rc;
+    }
     c->stamps.push_back(x);
     return rc;
 }
