@@ -52,9 +52,10 @@ def algorithmic_bytes(kernel, depth, trades, n_vars, n_live, events_per_step):
         # the combined update: per live trace the same index + theta read-modify-write as update_kernel;
         # summing per distinct generation first only changes how many atomics reach theta
         return (hdr + n_live * (4 + 8 + 8) + 26 * 4) / 2.0
-    if kernel == "env_kernel":        # per event: track entry (96) + trade slots + the two snapshots' levels at the order
-        per_event = 96 + 2 * trades * 4 + 2 * 2 * depth * 8
-        return 2 * 232 + hdr + events_per_step * per_event + 2 * 96 + 3 * 4 * n_vars   # agent scalars r/w + quotes + vars out
+    if kernel == "env_kernel":        # per event: track entry (128: the merged trades ride in it) + the applied row's four level arrays
+        per_event = 128 + 2 * 2 * depth * 4
+        # agent scalars r/w (248 B) + header + events + the entries of the quotes / the state (2 x 128) + the current snapshot + vars out
+        return 2 * 248 + hdr + events_per_step * per_event + 2 * 128 + 2 * 2 * depth * 4 + 3 * 4 * n_vars
     if kernel == "reset_kernel":      # per event of the stream: the record in, the track entry out (events_per_step = events per book here)
         return events_per_step * (rec + 96) + 2 * 232
     return 0
@@ -63,7 +64,7 @@ def algorithmic_bytes(kernel, depth, trades, n_vars, n_live, events_per_step):
 # timer name (lob_kernel_time_ms) -> kernel function(s) launched under it, as rocprofv3 names them
 TIMER_KERNELS = {"act_kernel": ("act_light_kernel", "act_fast_kernel", "act_kernel"), "env_kernel": ("env_step_kernel", "env_kernel"), "trace_kernel": ("trace_fast_kernel",),
                  "trace_light_kernel": ("trace_light_kernel",),
-                 "learn_kernel": ("learn_q_pair_kernel", "learn_q_lane_kernel", "learn_q_fast_kernel", "learn_kernel"), "act_rest_kernel": (), "learn_rest_kernel": ()}
+                 "learn_kernel": ("learn_q_pair_kernel", "learn_q_lane_kernel", "learn_q_fast_kernel", "learn_kernel"), "act_rest_kernel": (), "learn_rest_kernel": ("learn_q_rest_kernel",)}
 
 
 def traffic_of(traffic_file, timer, key="hbm_bytes_per_launch"):
@@ -325,7 +326,8 @@ def main():
                         "whole_step": {"algorithmic_bytes_per_env_step": round(step_bytes, 1),
                                        "yardstick_GBps": round(step_bytes * steps_done / elapsed / 1e9, 1),
                                        "yardstick_frac": round(step_bytes * steps_done / elapsed / 1e9 / HBM_PEAK_GBS, 5),
-                                       "counter_bytes_per_step": round(sum(v["traffic"] for v in per_kernel.values() if v.get("traffic") and v is not per_kernel.get("reset_kernel")), 1),
+                                       "counter_bytes_per_step": round(sum(v["traffic"] * v["launches"] / max(per_kernel[dom]["launches"], 1) for k_, v in per_kernel.items()
+                                                                           if v.get("traffic") and k_ != "reset_kernel"), 1),
                                        "note": "yardstick = SURVEY.md 8(d) (the reference algorithm's bytes per env-step); counter_bytes_per_step = sum over the step's kernels of FETCH_SIZE + WRITE_SIZE per launch: the memo / hit-list kernels move far fewer bytes than the yardstick assumes"},
                         "books_per_launch": round(steps_done / world / args.steps, 1),
                         "avg_launch_ms": d["avg_ms"],
