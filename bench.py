@@ -369,6 +369,8 @@ def main():
                 "books_per_gpu": args.books, "depth": args.depth, "events_per_book": g.n_events,
                 "events_per_step": round(eps, 4), "live_traces_per_book": round(n_live, 1),
                 "env_steps": steps_done, "reset_ms_per_episode": round(reset_ms, 2), "steps_per_episode": round(steps_per_episode, 1),
+                "paths": dict(zip(("trace_lane_handed_back", "act_general", "memo_slots_registered", "ambiguous_indices", "registry_overflow", "memo_slots_in_step"),
+                                  (int(x) for x in eng.path_stats()[:6]))),
                 "sync_every": SYNC_EVERY if comm is not None else None,
                 "exchange": exchange,
                 "parallelism": ("%d book shard(s), one process per GPU, every %d steps the ranks' written-weights maps all-gathered and the packed delta-theta of their union all-reduced over RCCL" % (world, SYNC_EVERY))

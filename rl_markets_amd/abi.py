@@ -178,6 +178,7 @@ def load():
         "lob_get_learner_state": (C.c_int, [vp, vp]),
         "lob_get_traces": (C.c_int, [vp, C.c_int32, vp, vp, C.c_int32, P(C.c_int32)]),
         "lob_get_counters": (C.c_int, [vp, vp]),
+        "lob_get_path_stats": (C.c_int, [vp, vp]),
         "lob_delta_init": (C.c_int, [vp]),
         "lob_delta_begin": (C.c_int, [vp, P(vp), P(C.c_int64)]),
         "lob_delta_begin_async": (C.c_int, [vp, P(vp), P(C.c_int64)]),

@@ -322,6 +322,10 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
         P.memo = !P.theta_private && P.algo != LOB_ALGO_DOUBLE_Q && !P.r_learn && e->n_groups == 1 && !(nc && nc[0] == '1');
         // the memo path never reads the carry-over filter, and its hot counter serialises first writes
         if (P.memo) P.carry_verdicts = 0;
+        // SARSA(lambda): the trace step with a lane per generation (trace_sarsa_kernel, lob_fast.h) + the tile registry it needs
+        const char* sl = getenv("LOB_SARSA_LANES");
+        P.sarsa_lanes = P.memo && P.combine && P.algo == LOB_ALGO_SARSA && P.trace_gens == 32 && !(sl && sl[0] == '0');
+        P.epi_epoch = 0;
     }
     P.seed = p->seed; P.book_id_offset = p->book_id_offset;
 
@@ -392,15 +396,18 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     if (rc == LOB_OK) rc = dev_alloc(e, &S.tr_sig, B * (size_t)P.trace_gens * 4);
     if (rc == LOB_OK) rc = dev_alloc(e, &S.tr_cbslot, B * (size_t)P.trace_gens);
     {
-        int slots = 1024;
-        while ((size_t)slots < 4 * B && slots < (1 << 20)) slots <<= 1;
+        // (slots persist while in use: room for the generations of a few steps; LOB_CB_SLOTS overrides, for the tests)
+        int slots = 2048;
+        while ((size_t)slots < 8 * B && slots < (1 << 22)) slots <<= 1;
+        if (const char* g = getenv("LOB_CB_SLOTS")) { int v = atoi(g); if (v >= 64 && v <= (1 << 24) && (v & (v - 1)) == 0) slots = v; }
         S.cb_slots = slots;
         if (rc == LOB_OK) rc = dev_alloc(e, &S.cb_key, (size_t)slots);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.cb_ident, (size_t)slots * 8);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.cb_acc, (size_t)slots * 2);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.cb_touch, (size_t)slots);
-        if (rc == LOB_OK) rc = dev_alloc(e, &S.cb_list, (size_t)slots);
-        if (rc == LOB_OK) rc = dev_alloc(e, &S.cb_count, 1);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.cb_list, 2 * (size_t)slots);
+        S.cb_segs = std::min(2048, slots / 4);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.cb_count, 2 * (size_t)S.cb_segs);
         if (rc == LOB_OK && hipMemsetAsync(S.cb_key, 0xff, (size_t)slots * 8, e->stream) != hipSuccess) rc = LOB_EHIP;
     }
     {
@@ -424,6 +431,21 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
         if (rc == LOB_OK && hipMemsetAsync(S.mk_hash, 0xff, ms * 8, e->stream) != hipSuccess) rc = LOB_EHIP;
         if (rc == LOB_OK && hipMemsetAsync(S.mk_slot, 0xff, B * 4, e->stream) != hipSuccess) rc = LOB_EHIP;
         if (rc == LOB_OK && hipMemsetAsync(S.mk_slot_last, 0xff, B * 4, e->stream) != hipSuccess) rc = LOB_EHIP;
+        // tile registry of the SARSA lane path (lob_state.h)
+        const bool sl = P.sarsa_lanes != 0;
+        S.ow_slots = sl ? 1 << 25 : 1;  // 65 536 memo slots x 288 tiles at most: load <= 0.56
+        S.amb_cap = sl ? (int)std::min<long long>((long long)P.M, 1 << 18) : 1;
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.tr_mslot, sl ? B * (size_t)P.trace_gens : 1);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.ow_tab, (size_t)S.ow_slots);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.amb_bits, sl ? (size_t)P.M / 32 + 1 : 1);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.amb_new, 2 * (size_t)S.amb_cap);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.amb_new_n, 2);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.amb_flag, 1);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.mk_amb, sl ? ms * LOB_N_ACTIONS : 1);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.mk_all, sl ? ms : 1);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.mk_all_n, 1);
+        if (rc == LOB_OK && hipMemsetAsync(S.tr_mslot, 0xff, (sl ? B * (size_t)P.trace_gens : 1) * 4, e->stream) != hipSuccess) rc = LOB_EHIP;
+        if (rc == LOB_OK && hipMemsetAsync(S.ow_tab, 0xff, (size_t)S.ow_slots * 8, e->stream) != hipSuccess) rc = LOB_EHIP;
     }
     {
         // coarse written-weights map of the fast path: the finest granularity whose image fits 80 KB of LDS
@@ -462,6 +484,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
             if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_pair_kernel<LOB_ALGO_QLAMBDA, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, qp_lds);
             if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_pair_kernel<LOB_ALGO_QLAMBDA, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, qp_lds);
             if (er == hipSuccess) er = hipFuncSetAttribute((const void*)trace_fast_kernel<LOB_ALGO_SARSA, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, tr_lds);
+            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)trace_fast_kernel<LOB_ALGO_SARSA, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, tr_lds);
             if (er == hipSuccess) er = hipFuncSetAttribute((const void*)trace_fast_kernel<LOB_ALGO_QLAMBDA, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, tr_lds);
             if (er == hipSuccess) er = hipFuncSetAttribute((const void*)trace_fast_kernel<LOB_ALGO_QLAMBDA, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, tr_lds);
             if (er == hipSuccess) er = hipFuncSetAttribute((const void*)trace_fast_kernel<LOB_ALGO_QLAMBDA, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, tr_lds);
@@ -740,6 +763,18 @@ int lob_reset(lob_engine* e) {
     // are gone: re-stamping mk_tiles_ok for a stale triple would hand a later claimant of the slot the wrong tiles)
     HIPCHK(hipMemsetAsync(e->S.mk_count, 0, 2 * sizeof(i32), e->stream));
     HIPCHK(hipMemsetAsync(e->S.mk_markcount, 0, sizeof(i32), e->stream));
+    if (e->P.sarsa_lanes) {
+        // ... and the tile registry with it; the generations that still name a slot of the old table carry the old epoch
+        HIPCHK(hipMemsetAsync(e->S.ow_tab, 0xff, (size_t)e->S.ow_slots * 8, e->stream));
+        HIPCHK(hipMemsetAsync(e->S.amb_bits, 0, ((size_t)e->P.M / 32 + 1) * 4, e->stream));
+        HIPCHK(hipMemsetAsync(e->S.amb_new_n, 0, 2 * sizeof(i32), e->stream));
+        HIPCHK(hipMemsetAsync(e->S.amb_flag, 0, sizeof(i32), e->stream));
+        HIPCHK(hipMemsetAsync(e->S.mk_all_n, 0, sizeof(i32), e->stream));
+        HIPCHK(hipMemsetAsync(e->S.tr_cbslot, 0xff, (size_t)e->B * e->P.trace_gens * 4, e->stream));  // (slots of books that stopped stepping may be gone)
+        HIPCHK(hipMemsetAsync(e->S.counters + 7, 0, sizeof(i64), e->stream));
+        e->P.epi_epoch++;
+        { int rc = push_params(e); if (rc) return rc; }
+    }
     {
         TimedLaunch t(e, "reset_kernel", nullptr, true);
         const int rb = e->reset_lanes;
@@ -888,6 +923,7 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
         const bool fast = e->P.memo != 0;  // (implies one group)
         const int lpar = first ? (e->list_par ^= 1) : e->list_par;
         e->last_par = par;
+        if (mode == 0) e->S.cb_par = par;  // (DevState goes to the kernels by value: the launches below see it)
         for (int g = 0; g < G; g++) {
             hipStream_t st = g == 0 ? e->stream : e->stream2;
             const int b0 = (int)((long long)e->B * g / G), nb = (int)((long long)e->B * (g + 1) / G) - b0;
@@ -947,6 +983,11 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                     TimedLaunch t(e, "trace_kernel", st);
                     if (tl) hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_QLAMBDA, 1>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, e->P, e->S, rnd, par, lpar, sid);
                     else if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_QLAMBDA, 0>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, e->P, e->S, rnd, par, lpar, sid);
+                    else if (e->P.sarsa_lanes) {
+                        // a lane per generation; the wave-per-book kernel for the books it leaves on the list
+                        hipLaunchKernelGGL(trace_sarsa_kernel, dim3((nb + LOB_TS_BLOCK / 32 - 1) / (LOB_TS_BLOCK / 32)), dim3(LOB_TS_BLOCK), 0, st, e->P, e->S, lpar);
+                        hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_SARSA, 1>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, e->P, e->S, rnd, par, lpar, sid);
+                    }
                     else hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_SARSA, 0>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, e->P, e->S, rnd, par, lpar, sid);
                 }
                 {
@@ -998,8 +1039,8 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
             }
             {
                 TimedLaunch t(e, "apply_kernel");
-                const int blocks = std::min(2048, std::max(1, (e->S.cb_slots + 3) / 4));
-                hipLaunchKernelGGL(apply_kernel, dim3(blocks), dim3(256), 0, e->stream, e->P, e->S, par, e->step_id);
+                const int blocks = e->S.cb_segs;
+                hipLaunchKernelGGL(apply_kernel, dim3(blocks), dim3(256), 0, e->stream, e->P, e->S, rnd, par, e->step_id);
             }
         } else if (mode == 0) {
             TimedLaunch t(e, "update_kernel");
@@ -1211,6 +1252,23 @@ int lob_get_counters(lob_engine* e, int64_t out[4]) {
     i64 live = 0;
     for (int b = 0; b < e->B; b++) live += done[b] == 0;
     out[0] = c[0]; out[1] = c[1]; out[2] = live; out[3] = c[3];
+    return LOB_OK;
+}
+
+int lob_get_path_stats(lob_engine* e, int64_t out[8]) {
+    if (!e || !out) return LOB_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    i64 c[8];
+    i32 n_all = 0, flag = 0, mk_n[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(c, e->S.counters, sizeof c, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(mk_n, e->S.mk_count, sizeof mk_n, hipMemcpyDeviceToHost, e->stream));
+    if (e->P.sarsa_lanes) {
+        HIPCHK(hipMemcpyAsync(&n_all, e->S.mk_all_n, 4, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipMemcpyAsync(&flag, e->S.amb_flag, 4, hipMemcpyDeviceToHost, e->stream));
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (int i = 0; i < 8; i++) out[i] = 0;
+    out[0] = c[6]; out[1] = c[5]; out[2] = n_all; out[3] = c[7]; out[4] = flag; out[5] = mk_n[e->last_par & 1];
     return LOB_OK;
 }
 

@@ -670,7 +670,6 @@ __global__ void __launch_bounds__(LOB_BLOCK) act_kernel(DevParams P, DevState S,
     if (LIST && *list_n == 0) return;  // nothing handed back by the fast path: the usual case
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (!LIST && blockIdx.x == 0 && threadIdx.x == 0 && b0 == 0) {
-        S.cb_count[0] = 0;    // the previous step's apply_kernel has consumed the list
         S.mk_count[par] = 0;  // this step's env_kernel starts a new list of memo slots
     }
     learn_stage_table(rnd_g, L, S.nz_new + (par ^ 1) * LOB_NZ_WORDS);
@@ -743,7 +742,8 @@ __device__ inline unsigned trace_step(uint32_t x) { return ((x >> 9) ^ (x << 3) 
 template <int ALGO>
 __device__ __forceinline__ void learn_traces(const DevParams& P, const DevState& S, int b, const LHdr& h, const uint32_t* rnd, const uint32_t* act_terms,
                                     u64* tab, bool init_tab, const f32* vars_from, bool zero_last, const f64* qs_last, Rng& g, int lane,
-                                    CbPending& pend, Prof& pf, int dup_flag = 0, bool* dup_out = nullptr, int amax_given = -1, int late_sid = -1) {
+                                    CbPending& pend, Prof& pf, int dup_flag = 0, bool* dup_out = nullptr, int amax_given = -1, int late_sid = -1,
+                                    int mslot_tag = -1) {
     LHdr* hp = S.hdr + b;
     const int action = h.action;
     // ---- group-0 tiles of last_state for all nine actions: lane -> (a = half + 2k, j) ----
@@ -915,6 +915,7 @@ __device__ __forceinline__ void learn_traces(const DevParams& P, const DevState&
                           q2 = zero_last ? 0 : tile_quant(vars_from[2]);
                 const int code = action | (zero_last ? 256 : 0);
                 *reinterpret_cast<int4*>(tr_sig + nh * 4) = make_int4(q0, q1, q2, code);
+                if (P.sarsa_lanes) S.tr_mslot[(size_t)b * G + nh] = mslot_tag;  // (trace_sarsa_kernel: which memo slot holds the generation's tiles)
                 if ((uint32_t)m) cb_claim_issue(S, pend, q0, q1, q2, code, (uint32_t)m, b * G + nh);
             }
         }
@@ -1276,11 +1277,11 @@ __global__ void __launch_bounds__(LOB_BLOCK) accumulate_kernel(DevParams P, DevS
         if (mask) {
             bool found = false;
             uint32_t s = 0;
-            if (cs >= 0) {  // the slot this step's claim ended on (or, for a claim another lane made, the hash's home slot)
+            if (cs >= 0) {  // the slot the generation's claim ended on (or, for a claim another lane made, the hash's home slot)
                 s = (uint32_t)cs & (uint32_t)(S.cb_slots - 1);
                 const int4 id = *reinterpret_cast<const int4*>(S.cb_ident + (size_t)s * 8);
-                const uint32_t idm = (uint32_t)S.cb_ident[(size_t)s * 8 + 4];
-                found = id.x == sg.x && id.y == sg.y && id.z == sg.z && id.w == sg.w && idm == mask && S.cb_key[s] != LOB_CB_EMPTY;
+                const uint32_t idm = (uint32_t)S.cb_ident[(size_t)s * 8 + 4];  // (0 in a free slot; mask != 0 here)
+                found = id.x == sg.x && id.y == sg.y && id.z == sg.z && id.w == sg.w && idm == mask;
             }
             if (!found) {  // (a displaced slot: walk the probe sequence)
                 const u64 hsh = cb_hash(sg.x, sg.y, sg.z, sg.w, mask);
@@ -1290,7 +1291,7 @@ __global__ void __launch_bounds__(LOB_BLOCK) accumulate_kernel(DevParams P, DevS
                     if (kk == hsh) {
                         const i32* id = S.cb_ident + (size_t)s * 8;
                         found = id[0] == sg.x && id[1] == sg.y && id[2] == sg.z && id[3] == sg.w && (uint32_t)id[4] == mask;
-                        break;  // the first slot with this hash is the only one claim can have made
+                        if (found) break;  // (another identity with this hash: the claim may have walked on past it)
                     }
                     if (kk == LOB_CB_EMPTY) break;
                     s = (s + 1) & (uint32_t)(S.cb_slots - 1);
@@ -1332,20 +1333,54 @@ __global__ void __launch_bounds__(LOB_BLOCK) accumulate_kernel(DevParams P, DevS
     }
 }
 
-// apply_kernel: one wave per claimed slot: theta[tile] += summed update for the live tiles of the
-// representative generation, maintain the written-weights map and the carry-over filter, free the slot.
-__global__ void __launch_bounds__(256) apply_kernel(DevParams P, DevState S, int par, int sid) {
+// apply_kernel: one wave per occupied slot (the step's list, lob_learn.h).  Touched this step: theta[tile] += the summed update
+// for the live tiles of the slot's generation -- the 32 indices follow from its identity (quantised triple + action; all 0 for
+// a constructor-zero State: learn_traces) --, maintain the written-weights map and the carry-over filter, hand the slot on to
+// the next step's list.  Not touched: no stepped book holds the generation any more, free the slot.
+__global__ void __launch_bounds__(256) apply_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g, int par, int sid) {
+    __shared__ uint32_t rnd[2048 + 32];
+    __shared__ int n_surv;
+    // one block per segment of the table: its list, its survivors -- no counter shared between blocks
+    const int seg = par * S.cb_segs + blockIdx.x, seg_next = (par ^ 1) * S.cb_segs + blockIdx.x, cap = S.cb_slots / S.cb_segs;
+    const int count = S.cb_count[seg];
+    if (count == 0) return;  // (block-uniform)
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(rnd_g);
+        uint4* dst = reinterpret_cast<uint4*>(rnd);
+        const uint4 r0 = src[threadIdx.x], r1 = src[threadIdx.x + 256];
+        dst[threadIdx.x] = r0; dst[threadIdx.x + 256] = r1;
+        if (threadIdx.x < 27) rnd[2048 + threadIdx.x] = rnd_g[2048 + threadIdx.x];
+        if (threadIdx.x == 0) n_surv = 0;
+    }
     const int lane = threadIdx.x & 63, j = lane & 31;
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
-    const int count = S.cb_count[0];
+    const int wave = threadIdx.x >> 6, n_waves = 4;
+    const i32* list = S.cb_list + (size_t)seg * cap;
+    i32* list_next = S.cb_list + (size_t)seg_next * cap;
+    const uint32_t M = (uint32_t)P.M;
+    __syncthreads();
     for (int i = wave; i < count; i += n_waves) {
-        const int s = S.cb_list[i];
-        const i32* id = S.cb_ident + (size_t)s * 8;
-        const uint32_t mask = (uint32_t)id[4];
-        const int src = id[5];
+        const int s = list[i];
         const uint32_t touch = S.cb_touch[s];
+        const int4 id = *reinterpret_cast<const int4*>(S.cb_ident + (size_t)s * 8);
+        const uint32_t mask = (uint32_t)S.cb_ident[(size_t)s * 8 + 4];
         const f64 v0 = S.cb_acc[(size_t)s * 2], v1 = S.cb_acc[(size_t)s * 2 + 1];
-        const i32 f = S.tr_idx[(size_t)src * 32 + j];
+        if (touch == 0) {  // (wave-uniform)
+            if (lane == 0) {
+                S.cb_key[s] = LOB_CB_EMPTY;
+                S.cb_ident[(size_t)s * 8 + 4] = 0;
+            }
+            continue;
+        }
+        i32 f = 0;
+        if (!(id.w & 256)) {
+            uint32_t sum = 0;
+            int base = j;
+            sum = mod_add(sum, rnd[(tile_coord(id.x, base) + 449 * 0) & 2047], M); base += 2 * j;
+            sum = mod_add(sum, rnd[(tile_coord(id.y, base) + 449 * 1) & 2047], M); base += 2 * j;
+            sum = mod_add(sum, rnd[(tile_coord(id.z, base) + 449 * 2) & 2047], M);
+            sum = mod_add(sum, rnd[(j + 449 * 3) & 2047], M);
+            f = tile_index(sum, rnd[2048 + (id.w & 15)], M);
+        }
         // lanes 0-31 serve theta, lanes 32-63 theta_b (double Q)
         const int t = lane >> 5;
         if (((touch >> t) & 1u) && ((mask >> j) & 1u)) {
@@ -1364,12 +1399,57 @@ __global__ void __launch_bounds__(256) apply_kernel(DevParams P, DevState S, int
             }
         }
         if (lane == 0) {
-            S.cb_key[s] = LOB_CB_EMPTY;
             S.cb_acc[(size_t)s * 2] = 0.0;
             S.cb_acc[(size_t)s * 2 + 1] = 0.0;
             S.cb_touch[s] = 0;
+            list_next[atomicAdd(&n_surv, 1)] = s;
         }
     }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        S.cb_count[seg_next] = n_surv;  // (0 until now: the previous step's launch consumed that list; this step's claims are over)
+        S.cb_count[seg] = 0;
+    }
+}
+
+// Tile registry (lob_state.h ow_tab): enter tile (slot s of triple `id`, action a, tiling j) with weight index `tile`.  Returns 1 if the index
+// is (now) known to be ambiguous, 0 if not, -1 if the table had no room (the slot then stays unregistered: the lane path
+// leaves every book that meets it to the wave-per-book kernel).
+__device__ inline bool tile_same_cell(const int4& x, const int4& y, int j) {
+    int base = j;
+    bool same = ((tile_coord(x.x, base) ^ tile_coord(y.x, base)) & 2047) == 0; base += 2 * j;
+    same = same && ((tile_coord(x.y, base) ^ tile_coord(y.y, base)) & 2047) == 0; base += 2 * j;
+    return same && ((tile_coord(x.z, base) ^ tile_coord(y.z, base)) & 2047) == 0;
+}
+__device__ inline int tile_register(const DevState& S, const int4& id, int s, int a, int j, i32 tile, int par) {
+    const u64 want = ((u64)(uint32_t)tile << 32) | (u64)(uint32_t)(s * (LOB_N_ACTIONS * 32) + a * 32 + j);
+    const uint32_t mask = (uint32_t)(S.ow_slots - 1);
+    uint32_t h = ((uint32_t)tile * 2654435761u) & mask;
+    const uint32_t bit = 1u << ((uint32_t)tile & 31);
+    uint32_t* word = S.amb_bits + ((uint32_t)tile >> 5);
+    for (int probe = 0; probe < 64; probe++) {
+        const u64 old = atomicCAS((unsigned long long*)&S.ow_tab[h], ~0ull, (unsigned long long)want);
+        if (old == ~0ull) return (*word & bit) ? 1 : 0;  // first tile on this index (the bit is clear unless the table lost an entry)
+        if ((uint32_t)(old >> 32) == (uint32_t)tile) {
+            const uint32_t ref = (uint32_t)old;
+            const int s2 = (int)(ref / (LOB_N_ACTIONS * 32)), r2 = (int)(ref % (LOB_N_ACTIONS * 32));
+            bool same = (r2 >> 5) == a && (r2 & 31) == j;
+            if (same && s2 != s) same = tile_same_cell(id, *reinterpret_cast<const int4*>(S.mk_ident + (size_t)s2 * 4), j);
+            if (!same) {
+                const uint32_t was = atomicOr(word, bit);
+                if (!(was & bit)) {
+                    const int pos = atomicAdd(&S.amb_new_n[par], 1);
+                    atomicAdd((unsigned long long*)&S.counters[7], 1ull);
+                    if (pos < S.amb_cap) S.amb_new[(size_t)par * S.amb_cap + pos] = tile;
+                    else S.amb_flag[0] = 1;
+                }
+                return 1;
+            }
+            return (*word & bit) ? 1 : 0;
+        }
+        h = (h + 1) & mask;
+    }
+    return -1;
 }
 
 // Group-0 memo: S0(a) = the first 32 terms of Agent::getQ (agent.cpp:117-135), sum over the tilings of
@@ -1383,7 +1463,6 @@ __global__ void __launch_bounds__(256) apply_kernel(DevParams P, DevState S, int
 // instruction on.
 __global__ void __launch_bounds__(256) memo_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g, int par, int which, u64 ver, int reset_lpar) {
     if (reset_lpar >= 0 && blockIdx.x == 0 && threadIdx.x == 0) {
-        S.cb_count[0] = 0;                     // (apply_kernel has consumed it)
         S.mk_count[par ^ 1] = 0;               // the next step's list of memo slots
         S.slow_n[reset_lpar * 2 + 0] = 0;      // this step's work lists: the step after the next fills them again
         S.slow_n[reset_lpar * 2 + 1] = 0;
@@ -1423,14 +1502,42 @@ __global__ void __launch_bounds__(256) memo_kernel(DevParams P, DevState S, cons
         }
         f64 t[5];
         const bool fill = S.mk_tiles_ok[s] == 0;  // first time on a list: leave the tile indices for the trace kernel
+        // ... and (SARSA lane path, launches `which` 0 only: the launches which 1 read what these append) enter them in the
+        // tile registry
+        const bool reg = fill && which == 0 && P.sarsa_lanes != 0;
+        bool reg_fail = false;
+        uint32_t my_amb = 0;  // bit k: this lane's tile of action (hi ? 5 : 0) + k lies on an ambiguous index
 #pragma unroll
         for (int k = 0; k < 5; k++) {
             const int a = (hi ? 5 : 0) + k;
             const i32 tile = tile_index(sum, rnd[2048 + (a < LOB_N_ACTIONS ? a : 0)], M);
             t[k] = a < LOB_N_ACTIONS ? S.theta[tile] : 0.0;
             if (fill && a < LOB_N_ACTIONS) S.mk_tiles[((size_t)s * LOB_N_ACTIONS + a) * 32 + j] = tile;
+            if (reg && a < LOB_N_ACTIONS) {
+                const int r = tile_register(S, id, s, a, j, tile, par);
+                reg_fail |= r < 0;
+                if (r > 0) my_amb |= 1u << k;
+            }
         }
-        if (fill && lane == 0) {
+        if (reg) {
+            const bool failed = __ballot(reg_fail) != 0;
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const u64 mb = __ballot((my_amb >> k) & 1u);
+                if (lane == 0) {
+                    S.mk_amb[(size_t)s * LOB_N_ACTIONS + k] = (uint32_t)mb;
+                    if (k < 4) S.mk_amb[(size_t)s * LOB_N_ACTIONS + 5 + k] = (uint32_t)(mb >> 32);
+                }
+            }
+            if (lane == 0) {
+                __threadfence();
+                if (!failed) {
+                    const int pos = atomicAdd(S.mk_all_n, 1);
+                    S.mk_all[pos] = s;  // (pos < mk_slots: a slot registers once per episode)
+                }
+                S.mk_tiles_ok[s] = failed ? 1 : 3;
+            }
+        } else if (fill && lane == 0) {
             __threadfence();  // (read by a LATER kernel only; the flag just must not precede the tiles of another wave's view: one wave per slot)
             S.mk_tiles_ok[s] = 1;
         }
@@ -1462,6 +1569,32 @@ __global__ void __launch_bounds__(256) memo_kernel(DevParams P, DevState S, cons
         }
     } else if (blockIdx.x == 0 && threadIdx.x == 0) {
         S.mk_markcount[0] = 0;
+    }
+    // Tile registry: the indices this step's launch `which` 0 found ambiguous for the first time are marked in every
+    // registered slot that holds them (the slots registered since then know already: tile_register looks at the bitmap).
+    if (which == 1 && P.sarsa_lanes) {
+        int n_new = S.amb_new_n[par];
+        if (n_new > S.amb_cap) n_new = S.amb_cap;
+        if (blockIdx.x == 0 && threadIdx.x == 0) S.amb_new_n[par ^ 1] = 0;  // (consumed by the previous step's launch)
+        if (n_new > 0) {
+            const int n_all = S.mk_all_n[0];
+            const i32* nw = S.amb_new + (size_t)par * S.amb_cap;
+            for (int i = wave; i < n_all; i += n_waves) {
+                const int s = S.mk_all[i];
+                i32 tl[5];
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    const int a = (hi ? 5 : 0) + k;
+                    tl[k] = a < LOB_N_ACTIONS ? S.mk_tiles[((size_t)s * LOB_N_ACTIONS + a) * 32 + j] : -1;
+                }
+                for (int e = 0; e < n_new; e++) {
+                    const i32 f = nw[e];  // (wave-uniform)
+#pragma unroll
+                    for (int k = 0; k < 5; k++)
+                        if (tl[k] == f) atomicOr(&S.mk_amb[(size_t)s * LOB_N_ACTIONS + (hi ? 5 : 0) + k], 1u << j);
+                }
+            }
+        }
     }
 }
 

@@ -226,6 +226,13 @@ __device__ inline u64 cb_hash(int q0, int q1, int q2, int code, uint32_t mask) {
 }
 // One lane claims a slot for (signature, mask) unless somebody already has: the identity is written
 // by the winner only and read by later kernels only, so no cross-wave publication is needed here.
+// Slots PERSIST from step to step while some stepped book's generation adds to them.  The occupied slots are exactly those on
+// the step's lists (cb_list[cb_par], one per segment of the table): the survivors of the previous step, then this step's new claims; apply_kernel adds the
+// sums of the slots the step touched to theta (the tiles follow from the identity) and hands them on to the next step's list,
+// and frees the others.  A generation whose (identity, mask) did not change keeps the slot it has on record (tr_cbslot)
+// without asking again -- trace_sarsa_kernel; the wave-per-book kernels ask every step, and find the key there.  A freed slot
+// cuts the probe sequences that ran through it, so an identity may come to hold two slots: both are summed and applied,
+// which is the same update.
 // The claim is split in two so that the CAS round trip overlaps the Q(s', .) evaluation:
 // cb_claim_issue fires the first probe's CAS, cb_claim_finish (much later) looks at the answer,
 // writes the identity if it won, and only then walks on along the probe sequence if it has to.
@@ -252,8 +259,9 @@ __device__ inline void cb_claim_finish(const DevState& S, const CbPending& c) {
         if (old == LOB_CB_EMPTY) {
             i32* id = S.cb_ident + (size_t)s * 8;
             id[0] = c.q0; id[1] = c.q1; id[2] = c.q2; id[3] = c.code; id[4] = (i32)c.mask; id[5] = c.src;
-            const int pos = atomicAdd(S.cb_count, 1);
-            S.cb_list[pos] = (i32)s;  // pos < cb_slots: every slot is listed at most once
+            const int seg = S.cb_par * S.cb_segs + (int)(s & (uint32_t)(S.cb_segs - 1));
+            const int pos = atomicAdd(&S.cb_count[seg], 1);
+            S.cb_list[(size_t)seg * (S.cb_slots / S.cb_segs) + pos] = (i32)s;  // (an occupied slot is on its segment's list exactly once: it fits)
             S.tr_cbslot[c.src] = (i32)s;
             return;
         }

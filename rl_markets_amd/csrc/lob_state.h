@@ -248,13 +248,18 @@ struct DevState {
     // summed per distinct (generation identity, alive mask) first and applied to theta once.
     i32* tr_sig;         // [B][trace_gens][4]: q0, q1, q2 (= (int)floor(32 x) of the three group-0 variables), action | zero << 8
     i32* tr_cbslot;      // [B][trace_gens] slot of cb_key the generation's claim of THIS step ended on (-1: none), cb_claim_finish
+    i32* tr_mslot;       // [B][trace_gens] SARSA lane path (lob_fast.h trace_sarsa_kernel): memo slot of the generation's triple |
+                         //   (episode epoch & 0x7fff) << 16, or -1: not known / slot's tiles not registered (DevParams::sarsa_lanes)
     u64* cb_key;         // [cb_slots] 64-bit hash of (signature, mask), ~0 = empty
-    i32* cb_ident;       // [cb_slots][8]: q0, q1, q2, code, mask, representative (book * trace_gens + slot), -, -
+    i32* cb_ident;       // [cb_slots][8]: q0, q1, q2, code, mask (0: free slot), the generation that claimed it (book * trace_gens + slot), -, -
     f64* cb_acc;         // [cb_slots][2]: summed update for theta / theta_b
-    uint32_t* cb_touch;  // [cb_slots] bit 0: theta gets an update, bit 1: theta_b
-    i32* cb_list;        // [cb_slots] occupied slots, in claim order
-    i32* cb_count;       // [1]
+    uint32_t* cb_touch;  // [cb_slots] bit 0: theta gets an update this step, bit 1: theta_b
+    i32* cb_list;        // [2 parities][cb_segs][cb_slots / cb_segs] the occupied slots, slot s in segment s & (cb_segs - 1): survivors of
+                         //   the previous step (apply_kernel, one block per segment: no global counter), then this step's claims
+    i32* cb_count;       // [2][cb_segs]
     i32 cb_slots;        // power of two
+    i32 cb_segs;         // power of two <= cb_slots / 4: apply_kernel's grid
+    i32 cb_par;          // parity of the current learner step (set by the host before the step's launches)
     // Verdict carry-over: learn(t) saves, per book, which group-1/2 tiles of s' hit a written
     // weight (9 bits per tiling); act(t+1) evaluates the same state and reuses them instead of 576
     // bitmap look-ups, OR-ed with a small filter of the bits the update in between newly set.
@@ -278,10 +283,25 @@ struct DevState {
     f64* mk_rec;         // [2: theta_t for learn, theta_{t+1} for the next act][mk_slots][LOB_MK_REC]: S0[9], theta version tag
     i32* mk_tiles;       // [mk_slots][9][32] the triple's 288 group-0 tile indices (action, tiling), written by memo_kernel the first time
                          //   the slot is on a step's list: the lane-per-book trace kernel copies a generation from here
-    i32* mk_tiles_ok;    // [mk_slots] 1 once mk_tiles[slot] is filled
+    i32* mk_tiles_ok;    // [mk_slots] bit 0: mk_tiles[slot] is filled; bit 1: ... and every tile is in the registry (ow_tab)
     uint32_t* mk_marked; // [mk_slots] bit a: the 32 tiles of (triple, action a) are marked in the written-weights maps
     i32* mk_marklist;    // [mk_slots] (slot * 16 + action) pairs whose tiles act_light_kernel wants marked: memo_kernel (which 0) does it,
     i32* mk_markcount;   // [1]          a wave per pair, before the learn kernel looks; reset by memo_kernel (which 1)
+    // Tile registry of the SARSA lane path: which weight indices are shared by two DIFFERENT group-0 tiles of the episode's
+    // memo slots (a collision of the hash -- or of its 2048-entry table: coordinates 2048 apart, permuted terms).  Two tiles
+    // are the same tile when tiling, action and the three coordinates & 2047 agree; every other pair on one index is
+    // "ambiguous".  A generation loses a tile to a new state either because the two triples fall in the same tile of that tiling
+    // (pure arithmetic on the quantised coordinates) or through an ambiguous index -- and only the latter needs the indices.
+    u64* ow_tab;         // [ow_slots] index << 32 | first registrant (slot * 288 + action * 32 + tiling), ~0 = empty
+    i32 ow_slots;        // power of two
+    uint32_t* amb_bits;  // [M / 32 + 1] bit f: index f is ambiguous
+    i32* amb_new;        // [2 parities][amb_cap] indices that became ambiguous in this step's memo_kernel (which 0) ...
+    i32* amb_new_n;      // [2]   ... its launch which 1 marks them in mk_amb of every registered slot
+    i32 amb_cap;
+    i32* amb_flag;       // [1] sticky until the next reset: amb_new overflowed (the lane path is off)
+    uint32_t* mk_amb;    // [mk_slots][9] bit j: tile (slot, action, tiling j) lies on an ambiguous index
+    i32* mk_all;         // [mk_slots] registered slots, in registration order
+    i32* mk_all_n;       // [1]
     i32* mk_slot;        // [B] slot of the book's latest state (-1: none)
     i32* mk_slot_last;   // [B] slot of the state before that (the learner's last_state in the next step)
     i32 mk_slots;        // power of two
@@ -350,6 +370,8 @@ struct DevParams {
     i32 algo, theta_private;
     i32 combine;         // shared theta: sum the updates per distinct trace generation first (0 with LOB_NO_COMBINE=1)
     i32 carry_verdicts;  // 0 with LOB_NO_CARRY=1 in the environment (A/B switch for the verdict carry-over)
+    i32 sarsa_lanes;     // SARSA(lambda): trace step with a lane per generation (trace_sarsa_kernel) + the tile registry it needs
+    i32 epi_epoch;       // episodes begun (lob_reset): tags the memo slots the generations refer to (tr_mslot)
     i32 memo;            // group-0 memo + fast learner kernels on (shared theta, SARSA / Q(lambda), one book group; 0 with LOB_NO_MEMO=1)
     i32 cshift, cwords4; // coarse map: bit = weight index >> cshift; size in 16-byte units
     u64 seed, book_id_offset;

@@ -247,6 +247,12 @@ class Engine:
         self._check(self.lib.lob_get_counters(self.h, _ptr(c)))
         return c
 
+    def path_stats(self):
+        """lob_get_path_stats: which kernels served the books (diagnostics of the fast paths)."""
+        c = np.zeros(8, np.int64)
+        self._check(self.lib.lob_get_path_stats(self.h, _ptr(c)))
+        return c
+
     # ---- multi-GPU weight exchange ----
     def delta_init(self):
         self._check(self.lib.lob_delta_init(self.h))

@@ -426,6 +426,7 @@ def test_combined_update_table_overflow(monkeypatch, acc_lanes):
     generations in rounds of 8 / 16 / 32 / 64: the shape must not show."""
     if acc_lanes:
         monkeypatch.setenv("LOB_ACC_LANES", str(acc_lanes))
+    monkeypatch.setenv("LOB_CB_SLOTS", "2048")
     B = 300
     p, g, rec, eng, orc = make(depth=5, n_events=330, B=B, algo=abi.ALGO_SARSA, theta_mode=abi.THETA_SHARED, mem=1 << 16,
                                gamma=1.0, lambda_=0.92, epsilon=0.6)
@@ -704,6 +705,48 @@ def test_trace_light_kernel_on_off_identical(monkeypatch, mem, eps, lanes):
         for n in (1, 4, 10):
             eng.td_step(n)
             trail.append((eng.last_actions().copy(), eng.last_td().copy(), bytes(eng.get_books()), None))
+        out.append((trail, eng.theta()))
+        eng.close()
+    for k, ((a0, t0, b0, r0), (a1, t1, b1, r1)) in enumerate(zip(out[0][0], out[1][0])):
+        np.testing.assert_array_equal(a0, a1, err_msg="actions, record %d" % k)
+        assert b0 == b1, "books differ at record %d" % k
+        assert r0 == r1, "trace lists differ at record %d" % k
+        np.testing.assert_allclose(t0, t1, rtol=1e-9, atol=1e-12, err_msg="td, record %d" % k)
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("mem,eps", [(1 << 12, 0.8), (1 << 16, 0.3), (1 << 22, 0.8), (1 << 22, 0.1)])
+def test_sarsa_lane_kernel_on_off_identical(monkeypatch, mem, eps):
+    """SARSA(lambda): trace_sarsa_kernel (a lane per trace generation: which tiles a generation loses to the new state
+    is decided from the quantised coordinates, index coincidences through the tile registry) against the wave-per-book
+    kernel that compares the indices themselves (LOB_SARSA_LANES=0).  Actions, TD errors, books and the trace lists of
+    every book bit for bit; theta up to its atomics' ordering.  With 4 096 / 65 536 weights most indices are shared by
+    several different tiles (every generation takes the index-by-index path, many books go back to the wave kernel);
+    with 4 M few are.  Two episodes (the registry and the memo table start afresh, old generations carry the old
+    epoch), external steps and a lob_theta_set in between."""
+    B = 192
+    out = []
+    for on in ("0", "1"):
+        monkeypatch.setenv("LOB_SARSA_LANES", on)
+        p, g, rec, eng, orc = make(depth=5, n_events=600, B=B, algo=abi.ALGO_SARSA, theta_mode=abi.THETA_SHARED, mem=mem, epsilon=eps)
+        orc.close()
+        eng.reset()
+        trail = []
+        rng = np.random.default_rng(5)
+        for phase in range(2):
+            for n in (1, 1, 2, 5, 1, 9, 14, 3, 30):
+                eng.td_step(n)
+                tr = [tuple(sorted(zip(*[x.tolist() for x in eng.traces(b)]))) for b in range(0, B, 7)]
+                trail.append((eng.last_actions().copy(), eng.last_td().copy(), bytes(eng.get_books()), tr))
+            eng.step(rng.integers(0, 9, size=B).astype(np.int32))
+            th = eng.theta()
+            th[::5] += 1e-3
+            eng.set_theta(th)
+        eng.reset()  # (no HandleTerminal: the generations of the first episode are still there)
+        for n in (1, 4, 10, 40):
+            eng.td_step(n)
+            tr = [tuple(sorted(zip(*[x.tolist() for x in eng.traces(b)]))) for b in range(0, B, 7)]
+            trail.append((eng.last_actions().copy(), eng.last_td().copy(), bytes(eng.get_books()), tr))
         out.append((trail, eng.theta()))
         eng.close()
     for k, ((a0, t0, b0, r0), (a1, t1, b1, r1)) in enumerate(zip(out[0][0], out[1][0])):
