@@ -227,6 +227,7 @@ def main():
     if comm is not None:
         comm.exchange_stats()   # (drop the warm-up's)
     c0 = eng.counters()
+    ps0 = eng.path_stats()
     if not args.no_kernel_timing:
         # HIP events around the kernels of every n-th step of the timed region (2-8 sampled steps): timing every
         # launch costs 9 % of a step (two event records per launch, eight launches per step)
@@ -236,6 +237,7 @@ def main():
     barrier()
     t1 = time.perf_counter()
     c1 = eng.counters()
+    ps1 = eng.path_stats()
     elapsed = t1 - t0
     steps_done = int(c1[0] - c0[0])
     events_done = int(c1[1] - c0[1])
@@ -369,8 +371,10 @@ def main():
                 "books_per_gpu": args.books, "depth": args.depth, "events_per_book": g.n_events,
                 "events_per_step": round(eps, 4), "live_traces_per_book": round(n_live, 1),
                 "env_steps": steps_done, "reset_ms_per_episode": round(reset_ms, 2), "steps_per_episode": round(steps_per_episode, 1),
-                "paths": dict(zip(("trace_lane_handed_back", "act_general", "memo_slots_registered", "ambiguous_indices", "registry_overflow", "memo_slots_in_step"),
-                                  (int(x) for x in eng.path_stats()[:6]))),
+                # diagnostics of the fast paths (lob_get_path_stats), per timed step where cumulative
+                "paths": {"trace_lane_handed_back_per_step": round(float(ps1[0] - ps0[0]) / max(args.steps, 1), 1),
+                          "memo_slots_registered": int(ps1[2]), "ambiguous_indices": int(ps1[3]), "registry_overflow": int(ps1[4]),
+                          "memo_slots_in_step": int(ps1[5])},
                 "sync_every": SYNC_EVERY if comm is not None else None,
                 "exchange": exchange,
                 "parallelism": ("%d book shard(s), one process per GPU, every %d steps the ranks' written-weights maps all-gathered and the packed delta-theta of their union all-reduced over RCCL" % (world, SYNC_EVERY))

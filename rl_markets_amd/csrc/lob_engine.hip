@@ -42,6 +42,8 @@ struct lob_engine {
     hipStream_t stream = nullptr;   // main stream (all API calls)
     hipStream_t stream2 = nullptr;  // second book group of the step pipeline
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_stagger = nullptr;
+    hipEvent_t ev_reg_go = nullptr, ev_reg_done = nullptr;  // tile registry kernels on stream2 beside the learner kernels (lob_kernels.h registry_kernel)
+    bool reg_pending = false;
     int n_groups = 1;
     int env_lanes = 0;     // books per env_kernel wave: 0 = by batch size, or 16 / 32 / 64; 256 = env_compact_kernel (LOB_ENV_LANES, read by lob_create)
     int reset_lanes = 64;  // books per reset_kernel wave (LOB_RESET_LANES)
@@ -136,6 +138,14 @@ template <class T> int dev_alloc(lob_engine* e, T** p, size_t count) {
     return LOB_OK;
 }
 
+// The registry kernels of the previous learner step (stream2) must be done before anything else looks at what they write.
+static int registry_join(lob_engine* e) {
+    if (e->reg_pending) {
+        HIPCHK(hipStreamWaitEvent(e->stream, e->ev_reg_done, 0));
+        e->reg_pending = false;
+    }
+    return LOB_OK;
+}
 int push_params(lob_engine* e) {
     if (hipMemcpyAsync(e->P_dev, &e->P, sizeof(DevParams), hipMemcpyHostToDevice, e->stream) != hipSuccess) { lob_set_error("param upload failed"); return LOB_EHIP; }
     return LOB_OK;
@@ -266,6 +276,8 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     HIPCHK_E(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming | hipEventDisableSystemFence));
     HIPCHK_E(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming | hipEventDisableSystemFence));
     HIPCHK_E(hipEventCreateWithFlags(&e->ev_stagger, hipEventDisableTiming | hipEventDisableSystemFence));
+    HIPCHK_E(hipEventCreateWithFlags(&e->ev_reg_go, hipEventDisableTiming | hipEventDisableSystemFence));
+    HIPCHK_E(hipEventCreateWithFlags(&e->ev_reg_done, hipEventDisableTiming | hipEventDisableSystemFence));
     // Optional (LOB_GROUPS=2): two book groups pipelined on two streams so that the latency-bound env
     // kernel of one group runs beside a gather kernel of the other.  It paid 7 % before the market
     // track made the env kernel cheap; now one group is as fast and gives clean per-kernel timings.
@@ -323,8 +335,19 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
         // the memo path never reads the carry-over filter, and its hot counter serialises first writes
         if (P.memo) P.carry_verdicts = 0;
         // SARSA(lambda): the trace step with a lane per generation (trace_sarsa_kernel, lob_fast.h) + the tile registry it needs
+        // ... for every book of SARSA(lambda); for Q(lambda) where the lane-per-book learn kernel takes the light trace steps and
+        // lists the books that keep their traces (the same condition as in run_steps: big batches; LOB_TRACE_LANES=0 switches it off)
         const char* sl = getenv("LOB_SARSA_LANES");
-        P.sarsa_lanes = P.memo && P.combine && P.algo == LOB_ALGO_SARSA && P.trace_gens == 32 && !(sl && sl[0] == '0');
+        const char* tl = getenv("LOB_TRACE_LANES");
+        bool lanes_ok = P.memo && P.combine && P.trace_gens == 32 && !(sl && sl[0] == '0') && !(tl && tl[0] == '0');
+        if (lanes_ok && P.algo == LOB_ALGO_QLAMBDA) {
+            hipDeviceProp_t prop;
+            int n_cus = e->n_cus;
+            if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) n_cus = prop.multiProcessorCount;
+            const bool q_lanes = e->q_lanes >= 0 ? e->q_lanes == 1 : (long long)n_books >= (long long)LOB_QL_BLOCK * n_cus / 2;
+            lanes_ok = e->t_light && q_lanes && !e->no_fuse;
+        } else if (P.algo != LOB_ALGO_SARSA) lanes_ok = false;
+        P.sarsa_lanes = lanes_ok;
         P.epi_epoch = 0;
     }
     P.seed = p->seed; P.book_id_offset = p->book_id_offset;
@@ -426,6 +449,8 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
         if (rc == LOB_OK) rc = dev_alloc(e, &S.mk_markcount, 1);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.tr_list, B);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.tr_list_n, 2);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.tr_list2, B);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.tr_list2_n, 2);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.mk_slot, B);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.mk_slot_last, B);
         if (rc == LOB_OK && hipMemsetAsync(S.mk_hash, 0xff, ms * 8, e->stream) != hipSuccess) rc = LOB_EHIP;
@@ -550,6 +575,8 @@ void lob_destroy(lob_engine* e) {
     if (e->ev_fork) hipEventDestroy(e->ev_fork);
     if (e->ev_join) hipEventDestroy(e->ev_join);
     if (e->ev_stagger) hipEventDestroy(e->ev_stagger);
+    if (e->ev_reg_go) hipEventDestroy(e->ev_reg_go);
+    if (e->ev_reg_done) hipEventDestroy(e->ev_reg_done);
     if (e->stream2) hipStreamDestroy(e->stream2);
     for (auto ev : e->event_pool) hipEventDestroy(ev);
     for (void* p : e->allocs) hipFree(p);
@@ -754,6 +781,7 @@ int lob_reset(lob_engine* e) {
     if (!e->have_events) { lob_set_error("lob_reset: no event stream loaded"); return LOB_ESTATE; }
     HIPCHK(hipSetDevice(e->device));
     { int rc = finalize_episode(e); if (rc) return rc; }
+    { int rc = registry_join(e); if (rc) return rc; }
     // the memo table starts empty every episode (reset_kernel voids every book's slot)
     HIPCHK(hipMemsetAsync(e->S.mk_hash, 0xff, (size_t)e->S.mk_slots * 8, e->stream));
     HIPCHK(hipMemsetAsync(e->S.mk_tiles_ok, 0, (size_t)e->S.mk_slots * 4, e->stream));
@@ -965,6 +993,10 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
             }  // first half
             if (!second) continue;
             if (fast) launch_memo(e, par, mode == 0 ? 0 : 1);  // learner: S0 under theta_t for learn_kernel; backtester: for the next act
+            // (the previous learner step's registry kernels have had the update kernels of their own step, and this step's env and
+            // memo kernels, to finish beside: what they write is read from here on -- the dup flags by the light trace step, the
+            // rest by trace_lane_kernel)
+            if (mode == 0) { int rc = registry_join(e); if (rc) return rc; }
             if (mode == 0 && fast) {
                 const bool tl = e->P.algo == LOB_ALGO_QLAMBDA && e->t_light;
                 // Q(s', .) + TD error: a lane per book once the batch gives every CU a full block of them, else a wave per book
@@ -985,7 +1017,7 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                     else if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_QLAMBDA, 0>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, e->P, e->S, rnd, par, lpar, sid);
                     else if (e->P.sarsa_lanes) {
                         // a lane per generation; the wave-per-book kernel for the books it leaves on the list
-                        hipLaunchKernelGGL(trace_sarsa_kernel, dim3((nb + LOB_TS_BLOCK / 32 - 1) / (LOB_TS_BLOCK / 32)), dim3(LOB_TS_BLOCK), 0, st, e->P, e->S, lpar);
+                        hipLaunchKernelGGL(trace_lane_kernel<LOB_ALGO_SARSA>, dim3((nb + LOB_TS_BLOCK / 32 - 1) / (LOB_TS_BLOCK / 32)), dim3(LOB_TS_BLOCK), 0, st, e->P, e->S, lpar, sid);
                         hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_SARSA, 1>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, e->P, e->S, rnd, par, lpar, sid);
                     }
                     else hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_SARSA, 0>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, e->P, e->S, rnd, par, lpar, sid);
@@ -1013,8 +1045,22 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                     if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL(learn_q_rest_kernel<LOB_ALGO_QLAMBDA>, dim3(gl), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, learn_list, learn_n);
                     else hipLaunchKernelGGL(learn_q_rest_kernel<LOB_ALGO_SARSA>, dim3(gl), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, learn_list, learn_n);
                 }
+                if (e->P.sarsa_lanes) {
+                    // the step's new memo slots enter the tile registry on the second stream, beside the trace / update kernels that
+                    // follow (not beside the learn kernel: its one block per CU wants the CU's LDS to itself)
+                    HIPCHK(hipEventRecord(e->ev_reg_go, st));
+                    HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_reg_go, 0));
+                    hipLaunchKernelGGL(registry_kernel, dim3(64), dim3(256), 0, e->stream2, e->P, e->S, rnd, par);
+                    hipLaunchKernelGGL(registry_scan_kernel, dim3(256), dim3(256), 0, e->stream2, e->S, par);
+                    HIPCHK(hipEventRecord(e->ev_reg_done, e->stream2));
+                    e->reg_pending = true;
+                }
                 if (fuse) {
                     TimedLaunch t(e, "trace_kernel", st);
+                    // the listed books (their traces survive the step): a lane per generation, then the wave-per-book kernel for
+                    // those the lane kernel hands on
+                    if (e->P.sarsa_lanes)
+                        hipLaunchKernelGGL(trace_lane_kernel<LOB_ALGO_QLAMBDA>, dim3(std::min(4 * e->n_cus, (nb + LOB_TS_BLOCK / 32 - 1) / (LOB_TS_BLOCK / 32))), dim3(LOB_TS_BLOCK), 0, st, e->P, e->S, lpar, sid);
                     hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_QLAMBDA, 2>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, e->P, e->S, rnd, par, lpar, sid);
                 }
             } else if (mode == 0) {
@@ -1258,6 +1304,7 @@ int lob_get_counters(lob_engine* e, int64_t out[4]) {
 int lob_get_path_stats(lob_engine* e, int64_t out[8]) {
     if (!e || !out) return LOB_EINVAL;
     HIPCHK(hipSetDevice(e->device));
+    { int rc = registry_join(e); if (rc) return rc; }
     i64 c[8];
     i32 n_all = 0, flag = 0, mk_n[2] = {0, 0};
     HIPCHK(hipMemcpyAsync(c, e->S.counters, sizeof c, hipMemcpyDeviceToHost, e->stream));

@@ -279,6 +279,7 @@ __global__ void __launch_bounds__(LOB_FAST_BLOCK) act_fast_kernel(DevParams P, D
         S.slow_n[(lpar ^ 1) * 2 + 0] = 0;  // the next step's work lists
         S.slow_n[(lpar ^ 1) * 2 + 1] = 0;
         S.tr_list_n[lpar ^ 1] = 0;
+        S.tr_list2_n[lpar ^ 1] = 0;
     }
     const FastLds L = fast_stage(fast_lds_raw, P, S, rnd_g, NB, false);
     const int w = threadIdx.x >> 6;
@@ -474,6 +475,7 @@ __global__ void __launch_bounds__(LOB_LIGHT_BLOCK) act_light_kernel(DevParams P,
         S.slow_n[(lpar ^ 1) * 2 + 0] = 0;
         S.slow_n[(lpar ^ 1) * 2 + 1] = 0;
         S.tr_list_n[lpar ^ 1] = 0;
+        S.tr_list2_n[lpar ^ 1] = 0;
     }
     const int b = blockIdx.x * LOB_LIGHT_BLOCK + threadIdx.x;
     if (b >= S.B) return;
@@ -501,6 +503,10 @@ __global__ void __launch_bounds__(LOB_TRACE_BLOCK, LOB_TRACE_OCC) trace_fast_ker
         S.nz_new[par * LOB_NZ_WORDS + threadIdx.x] = 0;
         S.nz_new[(2 + par) * LOB_NZ_WORDS + threadIdx.x] = 0;
     }
+    // (with the lane-per-generation kernel on, this one serves what that kernel hands on: SARSA `tr_list`, Q(lambda) `tr_list2`)
+    const i32* list = (LIST == 2 && P.sarsa_lanes) ? S.tr_list2 : S.tr_list;
+    const int list_n = LIST ? ((LIST == 2 && P.sarsa_lanes) ? S.tr_list2_n[lpar] : S.tr_list_n[lpar]) : 0;
+    if (LIST && P.sarsa_lanes && list_n == 0) return;  // nothing handed on: the usual case
     uint32_t* rnd = reinterpret_cast<uint32_t*>(fast_lds_raw);
     uint32_t* act_terms = rnd + 2048;
     const int w = threadIdx.x >> 6;
@@ -514,12 +520,12 @@ __global__ void __launch_bounds__(LOB_TRACE_BLOCK, LOB_TRACE_OCC) trace_fast_ker
     CbPending prev;
     prev.active = false;
     int lane_ = threadIdx.x & 63;
-    const int n_todo = LIST ? S.tr_list_n[lpar] : S.B;
+    const int n_todo = LIST ? list_n : S.B;
 #pragma unroll 1
     for (int t = blockIdx.x * LOB_TRACE_WAVES + w; t < n_todo; t += gridDim.x * LOB_TRACE_WAVES) {
         asm volatile("" : "+v"(lane_));
         const int lane = lane_;
-        const int ent = __builtin_amdgcn_readfirstlane(LIST ? S.tr_list[t] : t);
+        const int ent = __builtin_amdgcn_readfirstlane(LIST ? list[t] : t);
         const int b = LIST == 2 ? LOB_TRL_BOOK(ent) : ent;
         const LHdr h = S.hdr[b];
         const int lslot = P.memo ? S.mk_slot_last[b] : -1;  // memo slot of last_state's group-0 triple (checked below)
@@ -542,7 +548,7 @@ __global__ void __launch_bounds__(LOB_TRACE_BLOCK, LOB_TRACE_OCC) trace_fast_ker
         CbPending pend;
         bool dup = false;
         int mtag = -1;
-        if (ALGO == LOB_ALGO_SARSA && P.sarsa_lanes && lmatch && S.mk_tiles_ok[lslot] == 3) mtag = lslot | ((P.epi_epoch & 0x7fff) << 16);
+        if (P.sarsa_lanes && lmatch && S.mk_tiles_ok[lslot] == 3) mtag = lslot | ((P.epi_epoch & 0x7fff) << 16);
         learn_traces<ALGO>(P, S, b, h, rnd, act_terms, tab, false, vars + last * 16, zero_last, qs_last, g, lane, pend, pf, lmatch ? lid.w : 0, &dup,
                            LIST == 2 ? LOB_TRL_AMAX(ent) : -1, LIST == 2 ? sid : -1, mtag);
         if (lmatch && lid.w == 0 && lane == 0) S.mk_ident[(size_t)lslot * 4 + 3] = dup ? 2 : 1;  // (every wave that gets here writes the same value)
@@ -640,149 +646,164 @@ __global__ void __launch_bounds__(LOB_LIGHT_BLOCK) trace_light_kernel(DevParams 
     }
 }
 
-// Agent::UpdateTraces of SARSA(lambda) (no Watkins cut: every book keeps its trace_kmax - 1 latest generations) with a LANE
-// per generation, 32 lanes per book.  What Traces::update (traces.cpp:40-50) does to an old generation -- clear, or re-set to 1
-// and so hand over to the new generation, every tile that is also one of last_state's 288 -- is decided without the tile
-// indices: tile j of generation (triple T, action a) is the tile of (T', a) in tiling j exactly when T and T' fall in the same
-// cell of that tiling (integer arithmetic on the six quantised coordinates), and any OTHER coincidence of indices goes through an
-// index the tile registry has marked ambiguous (lob_state.h ow_tab; mk_amb: per memo slot and action, which tilings) -- those few
-// are compared index by index from the slots' tile records.  The new generation is the chosen action's 32 tiles copied from the
-// slot's record, as in trace_light_kernel.  A book the path cannot serve exactly (no memo slot / unregistered tiles / a
-// constructor-zero or NaN state among its generations / duplicate tiles inside last_state / too many ambiguous pairs) goes on
-// `tr_list` untouched, for trace_fast_kernel<SARSA, 1>.  Same stores as learn_traces for the books it takes.
+// Agent::UpdateTraces with a LANE per trace generation, 32 lanes per book, for the books whose older generations survive the
+// step: every book of SARSA(lambda) (no Watkins cut: a book keeps its trace_kmax - 1 latest generations), the books of Watkins's
+// Q(lambda) whose action was the greedy one (ALGO Q(lambda): the entries learn_q_*_kernel<.., TR = true> left on `tr_list`,
+// which carry argmax Q(s, .); that kernel has run, so Q(s, a) and the RNG counter are its business and the marks are late).
+// What Traces::update (traces.cpp:40-50) does to an old generation -- clear, or re-set to 1 and so hand over to the new
+// generation, every tile that is also one of last_state's 288 -- is decided without the tile indices: tile j of generation
+// (triple T, action a) is the tile of (T', a) in tiling j exactly when T and T' fall in the same cell of that tiling (integer
+// arithmetic on the six quantised coordinates), and any OTHER coincidence of indices goes through an index the tile registry has
+// marked ambiguous (lob_state.h ow_tab; mk_amb: per memo slot and action, which tilings) -- those few are compared index by
+// index from the slots' tile records.  The new generation is the chosen action's 32 tiles copied from the slot's record, as in
+// trace_light_kernel.  A book the path cannot serve exactly (no memo slot / unregistered tiles / a constructor-zero or NaN
+// state among its generations / duplicate tiles inside last_state / too many ambiguous pairs) is handed on untouched to the
+// wave-per-book kernel: SARSA on `tr_list` (trace_fast_kernel<SARSA, 1>), Q(lambda) on `tr_list2` (trace_fast_kernel<.., 2>).
+// Same stores as learn_traces for the books it takes.
 #define LOB_TS_BLOCK 256
-__global__ void __launch_bounds__(LOB_TS_BLOCK) trace_sarsa_kernel(DevParams P, DevState S, int lpar) {
-    const int lane = threadIdx.x & 63, k = lane & 31, half = lane >> 5;
-    const int b = blockIdx.x * (LOB_TS_BLOCK / 32) + (threadIdx.x >> 5);
-    const bool in = b < S.B;
-    const int bb = in ? b : 0;
-    const LHdr h = S.hdr[bb];
-    const bool stepped = in && h.stepped != 0;
+template <int ALGO>
+__global__ void __launch_bounds__(LOB_TS_BLOCK, 5) trace_lane_kernel(DevParams P, DevState S, int lpar, int sid) {
+    constexpr bool QL = ALGO == LOB_ALGO_QLAMBDA;
+    const int lane = threadIdx.x & 63, k = lane & 31, half = lane >> 5, grp = threadIdx.x >> 5;
+    const int n_todo = QL ? S.tr_list_n[lpar] : S.B;
     const int G = P.trace_gens;  // 32
-    const int lslot = S.mk_slot_last[bb];
-    const int ls = lslot >= 0 ? lslot : 0;
-    const int last = h.slot_cur ^ 1;
-    const bool zero_last = (h.zero_mask >> last) & 1;
-    const float4 vl = *reinterpret_cast<const float4*>(S.vars + (size_t)bb * 48 + last * 16);
-    const int q0 = tile_quant(vl.x), q1 = tile_quant(vl.y), q2 = tile_quant(vl.z);
-    const int4 lid = *reinterpret_cast<const int4*>(S.mk_ident + (size_t)ls * 4);
-    const int action = h.action;
-    int n_old = h.tr_n;
-    if (n_old > P.trace_kmax - 1) n_old = P.trace_kmax - 1;
     const int tag_epoch = (P.epi_epoch & 0x7fff) << 16;
     const int lim = (int)0x80000400;  // (below: tile_coord's wrap-around branch -- a NaN variable)
-    bool ok = lslot >= 0 && !zero_last && lid.x == q0 && lid.y == q1 && lid.z == q2 && lid.w == 1 && S.mk_tiles_ok[ls] == 3 && S.amb_flag[0] == 0 &&
-              q0 >= lim && q1 >= lim && q2 >= lim;
-    // ---- this lane's generation (age k) ----
-    const int slot = (h.tr_head - k + G) & (G - 1);
-    const size_t gi = (size_t)bb * G + slot;
-    uint32_t m = 0;
-    int4 sg = make_int4(0, 0, 0, 0);
-    int tag = -1, cs = -1;
-    if (stepped && k < n_old) {
-        m = S.tr_alive[gi];
-        sg = *reinterpret_cast<const int4*>(S.tr_sig + gi * 4);
-        tag = S.tr_mslot[gi];
-        cs = S.tr_cbslot[gi];
-    }
-    // (the new generation's tile, ahead of its use: the chain of dependent look-ups is what this kernel's time is made of)
-    const i32 N = S.mk_tiles[((size_t)ls * LOB_N_ACTIONS + action) * 32 + k];
-    const uint32_t marked = S.mk_marked[ls];
-    const int so = tag & 0xffff;  // the generation's memo slot
-    uint32_t amb_old = 0;
-    if (m) {
-        const bool gen_ok = tag >= 0 && (tag & 0x7fff0000) == tag_epoch && !(sg.w & 256) && sg.x >= lim && sg.y >= lim && sg.z >= lim;
-        ok = ok && gen_ok;
-        if (gen_ok) amb_old = S.mk_amb[(size_t)so * LOB_N_ACTIONS + (sg.w & 15)];
-    }
-    // ambiguous tiles of last_state: lane a < 9 of the half holds the word of action a
-    const uint32_t amb_w = k < LOB_N_ACTIONS ? S.mk_amb[(size_t)ls * LOB_N_ACTIONS + k] : 0u;
-    int n_amb_new = __popc(amb_w);
+    const bool reg_ok = S.amb_flag[0] == 0;
+#pragma unroll 1
+    for (int t0 = blockIdx.x * (LOB_TS_BLOCK / 32); t0 < n_todo; t0 += gridDim.x * (LOB_TS_BLOCK / 32)) {
+        const int t = t0 + grp;
+        const bool in = t < n_todo;
+        const int ent = QL ? S.tr_list[in ? t : 0] : t;
+        const int b = QL ? LOB_TRL_BOOK(ent) : ent;
+        const int bb = in ? b : 0;
+        const LHdr h = S.hdr[bb];
+        const bool stepped = in && h.stepped != 0;
+        const int lslot = S.mk_slot_last[bb];
+        const int ls = lslot >= 0 ? lslot : 0;
+        const int last = h.slot_cur ^ 1;
+        const bool zero_last = (h.zero_mask >> last) & 1;
+        const float4 vl = *reinterpret_cast<const float4*>(S.vars + (size_t)bb * 48 + last * 16);
+        const int q0 = tile_quant(vl.x), q1 = tile_quant(vl.y), q2 = tile_quant(vl.z);
+        const int4 lid = *reinterpret_cast<const int4*>(S.mk_ident + (size_t)ls * 4);
+        const int action = h.action;
+        int n_old = h.tr_n;
+        if (n_old > P.trace_kmax - 1) n_old = P.trace_kmax - 1;
+        if (QL && action != LOB_TRL_AMAX(ent)) n_old = 0;  // Watkins's cut (QLearn::UpdateTraces, agent.cpp:272-280: traces.decay(0.0))
+        bool ok = lslot >= 0 && !zero_last && lid.x == q0 && lid.y == q1 && lid.z == q2 && lid.w == 1 && S.mk_tiles_ok[ls] == 3 && reg_ok &&
+                  q0 >= lim && q1 >= lim && q2 >= lim;
+        // ---- this lane's generation (age k) ----
+        const int slot = (h.tr_head - k + G) & (G - 1);
+        const size_t gi = (size_t)bb * G + slot;
+        uint32_t m = 0;
+        int4 sg = make_int4(0, 0, 0, 0);
+        int tag = -1, cs = -1;
+        if (stepped && k < n_old) {
+            m = S.tr_alive[gi];
+            sg = *reinterpret_cast<const int4*>(S.tr_sig + gi * 4);
+            tag = S.tr_mslot[gi];
+            cs = S.tr_cbslot[gi];
+        }
+        // (the new generation's tile, ahead of its use: the chain of dependent look-ups is what this kernel's time is made of)
+        const i32 N = S.mk_tiles[((size_t)ls * LOB_N_ACTIONS + action) * 32 + k];
+        const uint32_t marked = S.mk_marked[ls];
+        const int so = tag & 0xffff;  // the generation's memo slot
+        uint32_t amb_old = 0;
+        if (m) {
+            const bool gen_ok = tag >= 0 && (tag & 0x7fff0000) == tag_epoch && !(sg.w & 256) && sg.x >= lim && sg.y >= lim && sg.z >= lim;
+            ok = ok && gen_ok;
+            if (gen_ok) amb_old = S.mk_amb[(size_t)so * LOB_N_ACTIONS + (sg.w & 15)];
+        }
+        // ambiguous tiles of last_state: lane a < 9 of the half holds the word of action a
+        const uint32_t amb_w = k < LOB_N_ACTIONS ? S.mk_amb[(size_t)ls * LOB_N_ACTIONS + k] : 0u;
+        int n_amb_new = __popc(amb_w);
 #pragma unroll
-    for (int o = 1; o < 16; o <<= 1) n_amb_new += __shfl_xor(n_amb_new, o);  // (lanes 0-15 of the half: all nine words)
-    n_amb_new = __shfl(n_amb_new, half * 32);
-    // ---- same cell, tiling by tiling ----
-    uint32_t hit = 0;
-    if (m) {
-        const uint32_t d0 = (uint32_t)(q0 - sg.x) & 2047u, d1 = (uint32_t)(q1 - sg.y) & 2047u, d2 = (uint32_t)(q2 - sg.z) & 2047u;
-        // (a coordinate 32 .. 2015 away mod 2048 is in another cell of every tiling: the cell numbers differ by 1 .. 63 mod 64)
-        if (!(d0 - 32u <= 1983u || d1 - 32u <= 1983u || d2 - 32u <= 1983u)) {
+        for (int o = 1; o < 16; o <<= 1) n_amb_new += __shfl_xor(n_amb_new, o);  // (lanes 0-15 of the half: all nine words)
+        n_amb_new = __shfl(n_amb_new, half * 32);
+        // ---- same cell, tiling by tiling ----
+        uint32_t hit = 0;
+        if (m) {
+            const uint32_t d0 = (uint32_t)(q0 - sg.x) & 2047u, d1 = (uint32_t)(q1 - sg.y) & 2047u, d2 = (uint32_t)(q2 - sg.z) & 2047u;
+            // (a coordinate 32 .. 2015 away mod 2048 is in another cell of every tiling: the cell numbers differ by 1 .. 63 mod 64)
+            if (!(d0 - 32u <= 1983u || d1 - 32u <= 1983u || d2 - 32u <= 1983u)) {
 #pragma unroll 4
-            for (int j = 0; j < 32; j++) {
-                const int x = ((q0 - j) >> 5) ^ ((sg.x - j) >> 5), y = ((q1 - 3 * j) >> 5) ^ ((sg.y - 3 * j) >> 5), z = ((q2 - 5 * j) >> 5) ^ ((sg.z - 5 * j) >> 5);
-                if (((x | y | z) & 63) == 0) hit |= 1u << j;
-            }
-        }
-    }
-    const uint32_t cand = m & ~hit & amb_old;  // live tiles that may meet last_state's through an ambiguous index
-    const bool heavy = cand != 0 && n_amb_new != 0 && __popc(cand) * n_amb_new > 96;
-    {
-        const u64 bad = __ballot(stepped && (!ok || heavy));
-        const uint32_t mine = (uint32_t)(bad >> (half * 32));
-        if (mine) {
-            if (k == 0 && stepped) {
-                S.tr_list[atomicAdd(&S.tr_list_n[lpar], 1)] = b;
-                atomicAdd((unsigned long long*)&S.counters[6], 1ull);
-            }
-            return;  // (nothing of the book has been touched)
-        }
-    }
-    if (!stepped) return;
-    if (cand != 0 && n_amb_new != 0) {
-        const i32* to = S.mk_tiles + ((size_t)so * LOB_N_ACTIONS + (sg.w & 15)) * 32;
-        uint32_t c = cand;
-        while (c) {
-            const int j = __builtin_ctz(c);
-            c &= c - 1;
-            const i32 f = to[j];
-            for (int a = 0; a < LOB_N_ACTIONS; a++) {
-                uint32_t w = S.mk_amb[(size_t)ls * LOB_N_ACTIONS + a];
-                while (w) {
-                    const int j2 = __builtin_ctz(w);
-                    w &= w - 1;
-                    if (S.mk_tiles[((size_t)ls * LOB_N_ACTIONS + a) * 32 + j2] == f) hit |= 1u << j;
+                for (int j = 0; j < 32; j++) {
+                    const int x = ((q0 - j) >> 5) ^ ((sg.x - j) >> 5), y = ((q1 - 3 * j) >> 5) ^ ((sg.y - 3 * j) >> 5), z = ((q2 - 5 * j) >> 5) ^ ((sg.z - 5 * j) >> 5);
+                    if (((x | y | z) & 63) == 0) hit |= 1u << j;
                 }
             }
         }
-    }
-    // ---- old generations: new masks, slot claims of the combined update ----
-    if (m) {
-        const uint32_t m2 = m & ~hit;
-        if (m2 != m) S.tr_alive[gi] = m2;
-        if (m2 && (m2 != m || cs < 0)) {  // (an unchanged generation keeps the slot it has: the table persists, lob_learn.h)
-            const u64 ch = cb_hash(sg.x, sg.y, sg.z, sg.w, m2);
-            const uint32_t home = (uint32_t)ch & (uint32_t)(S.cb_slots - 1);
-            if (S.cb_key[home] == ch) S.tr_cbslot[gi] = (i32)home;  // (thousands of books hold this very generation: look before the compare-and-swap)
-            else {
-                CbPending pend;
-                cb_claim_issue(S, pend, sg.x, sg.y, sg.z, sg.w, m2, (int)gi);
-                cb_claim_finish(S, pend);
+        const uint32_t cand = m & ~hit & amb_old;  // live tiles that may meet last_state's through an ambiguous index
+        const bool heavy = cand != 0 && n_amb_new != 0 && __popc(cand) * n_amb_new > 96;
+        {
+            const u64 bad = __ballot(stepped && (!ok || heavy));
+            if ((uint32_t)(bad >> (half * 32))) {
+                if (k == 0 && stepped) {  // (nothing of the book has been touched)
+                    if (QL) S.tr_list2[atomicAdd(&S.tr_list2_n[lpar], 1)] = ent;
+                    else S.tr_list[atomicAdd(&S.tr_list_n[lpar], 1)] = b;
+                    atomicAdd((unsigned long long*)&S.counters[6], 1ull);
+                }
+                continue;
             }
         }
-    }
-    // ---- the new generation: the chosen action's 32 tiles, all alive ----
-    const int nh = (h.tr_head + 1) & (G - 1);
-    const size_t ni = (size_t)b * G + nh;
-    if (!((marked >> action) & 1u)) {  // marked in the written-weights maps before the learn kernel looks (learn_traces)
-        nzx_mark(P, S, N);
-        if (k == 0) atomicOr(&S.mk_marked[lslot], 1u << action);
-    }
-    S.tr_idx[ni * 32 + k] = N;
-    if (k == 31) {  // (n_old <= 31: this lane has no old generation)
-        LHdr* hp = S.hdr + b;
-        S.tr_alive[ni] = 0xffffffffu;
-        S.tr_mslot[ni] = lslot | tag_epoch;
-        *reinterpret_cast<int4*>(S.tr_sig + ni * 4) = make_int4(q0, q1, q2, action);
-        hp->tr_head = nh;
-        hp->tr_n = n_old + 1;
-        hp->td = S.qs_last[(size_t)b * LOB_N_ACTIONS + action];  // Q(s, a), for the TD error
-        const u64 ch = cb_hash(q0, q1, q2, action, 0xffffffffu);
-        const uint32_t home = (uint32_t)ch & (uint32_t)(S.cb_slots - 1);
-        if (S.cb_key[home] == ch) S.tr_cbslot[ni] = (i32)home;
-        else {
-            CbPending pend;
-            cb_claim_issue(S, pend, q0, q1, q2, action, 0xffffffffu, (int)ni);
-            cb_claim_finish(S, pend);
+        if (!stepped) continue;
+        if (cand != 0 && n_amb_new != 0) {
+            const i32* to = S.mk_tiles + ((size_t)so * LOB_N_ACTIONS + (sg.w & 15)) * 32;
+            uint32_t c = cand;
+            while (c) {
+                const int j = __builtin_ctz(c);
+                c &= c - 1;
+                const i32 f = to[j];
+                for (int a = 0; a < LOB_N_ACTIONS; a++) {
+                    uint32_t w = S.mk_amb[(size_t)ls * LOB_N_ACTIONS + a];
+                    while (w) {
+                        const int j2 = __builtin_ctz(w);
+                        w &= w - 1;
+                        if (S.mk_tiles[((size_t)ls * LOB_N_ACTIONS + a) * 32 + j2] == f) hit |= 1u << j;
+                    }
+                }
+            }
+        }
+        // ---- old generations: new masks, slot claims of the combined update ----
+        if (m) {
+            const uint32_t m2 = m & ~hit;
+            if (m2 != m) S.tr_alive[gi] = m2;
+            if (m2 && (m2 != m || cs < 0)) {  // (an unchanged generation keeps the slot it has: the table persists, lob_learn.h)
+                const u64 ch = cb_hash(sg.x, sg.y, sg.z, sg.w, m2);
+                const uint32_t home = (uint32_t)ch & (uint32_t)(S.cb_slots - 1);
+                if (S.cb_key[home] == ch) S.tr_cbslot[gi] = (i32)home;  // (thousands of books hold this very generation: look before the compare-and-swap)
+                else {
+                    CbPending pend;
+                    cb_claim_issue(S, pend, sg.x, sg.y, sg.z, sg.w, m2, (int)gi);
+                    cb_claim_finish(S, pend);
+                }
+            }
+        }
+        // ---- the new generation: the chosen action's 32 tiles, all alive ----
+        const int nh = (h.tr_head + 1) & (G - 1);
+        const size_t ni = (size_t)b * G + nh;
+        if (!((marked >> action) & 1u)) {  // marked in the written-weights maps before the learn kernel looks (learn_traces) -- or late
+            if (QL) nzx_mark_late(P, S, N, sid);
+            else nzx_mark(P, S, N);
+            if (k == 0) atomicOr(&S.mk_marked[lslot], 1u << action);
+        }
+        S.tr_idx[ni * 32 + k] = N;
+        if (k == 31) {  // (n_old <= 31: this lane has no old generation)
+            LHdr* hp = S.hdr + b;
+            S.tr_alive[ni] = 0xffffffffu;
+            S.tr_mslot[ni] = lslot | tag_epoch;
+            *reinterpret_cast<int4*>(S.tr_sig + ni * 4) = make_int4(q0, q1, q2, action);
+            hp->tr_head = nh;
+            hp->tr_n = n_old + 1;
+            if (!QL) hp->td = S.qs_last[(size_t)b * LOB_N_ACTIONS + action];  // Q(s, a), for the TD error
+            const u64 ch = cb_hash(q0, q1, q2, action, 0xffffffffu);
+            const uint32_t home = (uint32_t)ch & (uint32_t)(S.cb_slots - 1);
+            if (S.cb_key[home] == ch) S.tr_cbslot[ni] = (i32)home;
+            else {
+                CbPending pend;
+                cb_claim_issue(S, pend, q0, q1, q2, action, 0xffffffffu, (int)ni);
+                cb_claim_finish(S, pend);
+            }
         }
     }
 }
@@ -1035,6 +1056,7 @@ __global__ void __launch_bounds__(LOB_QL_BLOCK) learn_q_lane_kernel(DevParams P,
         int amax = 0, lslot = -1, tq0 = 0, tq1 = 0, tq2 = 0;
         bool tlight = false;
         uint32_t tmarked = 0;
+        int ttag = -1;  // tr_mslot of the generation the light step creates (trace_lane_kernel)
         int4 tl[8];  // the new generation's tiles (light case), fetched before the tile walk, stored after it
         if (TR) {
             lslot = lslot_;
@@ -1046,6 +1068,7 @@ __global__ void __launch_bounds__(LOB_QL_BLOCK) learn_q_lane_kernel(DevParams P,
             const int4 lid = *reinterpret_cast<const int4*>(S.mk_ident + (size_t)ls * 4);
             const int tiles_ok = S.mk_tiles_ok[ls];
             tmarked = S.mk_marked[ls];
+            if (tiles_ok == 3) ttag = ls | ((P.epi_epoch & 0x7fff) << 16);
             amax = argmax_ties(qs_last, g);
             int n_old = h.tr_n, kmax = P.trace_kmax;
             if (h.action != amax) kmax = 1;
@@ -1119,6 +1142,7 @@ __global__ void __launch_bounds__(LOB_QL_BLOCK) learn_q_lane_kernel(DevParams P,
                 hp->tr_n = 1;
                 if (P.combine) {
                     *reinterpret_cast<int4*>(S.tr_sig + ((size_t)b * G + nh) * 4) = make_int4(tq0, tq1, tq2, action);
+                    if (P.sarsa_lanes) S.tr_mslot[(size_t)b * G + nh] = ttag;
                     const u64 ch = cb_hash(tq0, tq1, tq2, action, 0xffffffffu);
                     const u64 seen = atomicCAS((unsigned long long*)&claimed[(ch >> 40) & 511], (unsigned long long)LOB_CB_EMPTY, (unsigned long long)ch);
                     if (seen != ch && S.cb_key[(uint32_t)ch & (uint32_t)(S.cb_slots - 1)] != ch)
@@ -1245,6 +1269,7 @@ __global__ void __launch_bounds__(LOB_QP_BLOCK) learn_q_pair_kernel(DevParams P,
             int amax = 0, lslot = -1, tq0 = 0, tq1 = 0, tq2 = 0;
             bool tlight = false;
             uint32_t tmarked = 0;
+            int ttag = -1;  // tr_mslot of the generation the light step creates (trace_lane_kernel)
             if (TR && stepped) {
                 f64 qs_last[LOB_N_ACTIONS];
 #pragma unroll
@@ -1258,6 +1283,7 @@ __global__ void __launch_bounds__(LOB_QP_BLOCK) learn_q_pair_kernel(DevParams P,
                 const int4 lid = *reinterpret_cast<const int4*>(S.mk_ident + (size_t)ls * 4);
                 const int tiles_ok = S.mk_tiles_ok[ls];
                 tmarked = S.mk_marked[ls];
+                if (tiles_ok == 3) ttag = ls | ((P.epi_epoch & 0x7fff) << 16);
                 amax = argmax_ties(qs_last, g);
                 int n_old = h.tr_n, kmax = P.trace_kmax;
                 if (h.action != amax) kmax = 1;
@@ -1333,6 +1359,7 @@ __global__ void __launch_bounds__(LOB_QP_BLOCK) learn_q_pair_kernel(DevParams P,
                     hp->tr_n = 1;
                     if (P.combine) {
                         *reinterpret_cast<int4*>(S.tr_sig + ((size_t)b * G + nh) * 4) = make_int4(tq0, tq1, tq2, action);
+                        if (P.sarsa_lanes) S.tr_mslot[(size_t)b * G + nh] = ttag;
                         const u64 ch = cb_hash(tq0, tq1, tq2, action, 0xffffffffu);
                         const u64 seen = atomicCAS((unsigned long long*)&claimed[(ch >> 40) & 511], (unsigned long long)LOB_CB_EMPTY, (unsigned long long)ch);
                         if (seen != ch && S.cb_key[(uint32_t)ch & (uint32_t)(S.cb_slots - 1)] != ch)

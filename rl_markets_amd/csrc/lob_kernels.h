@@ -1270,15 +1270,17 @@ __global__ void __launch_bounds__(LOB_BLOCK) accumulate_kernel(DevParams P, DevS
         int cs = -1;
         if (age < n) {
             mask = tr_alive[slot];
-            sg = *reinterpret_cast<const int4*>(tr_sig + slot * 4);
-            cs = S.tr_cbslot[(size_t)bb * G + slot];  // where this step's claim of the generation ended (cb_claim_finish)
+            cs = S.tr_cbslot[(size_t)bb * G + slot];  // where the generation's claim ended (cb_claim_finish)
         }
+        // LOB_CBS_VERIFIED: an earlier step has compared this slot's identity with the generation's, and neither has changed since
+        // (a claim rewrites tr_cbslot; the slot cannot have been freed: the generation added to it in every step in between)
+        const bool known = mask != 0 && cs >= 0 && (cs & LOB_CBS_VERIFIED);
+        if (mask != 0 && !known) sg = *reinterpret_cast<const int4*>(tr_sig + slot * 4);
         bool direct = false;
         if (mask) {
-            bool found = false;
-            uint32_t s = 0;
-            if (cs >= 0) {  // the slot the generation's claim ended on (or, for a claim another lane made, the hash's home slot)
-                s = (uint32_t)cs & (uint32_t)(S.cb_slots - 1);
+            bool found = known;
+            uint32_t s = (uint32_t)cs & (uint32_t)(S.cb_slots - 1);
+            if (!known && cs >= 0) {  // the slot the generation's claim ended on (or, for a claim another lane made, the hash's home slot)
                 const int4 id = *reinterpret_cast<const int4*>(S.cb_ident + (size_t)s * 8);
                 const uint32_t idm = (uint32_t)S.cb_ident[(size_t)s * 8 + 4];  // (0 in a free slot; mask != 0 here)
                 found = id.x == sg.x && id.y == sg.y && id.z == sg.z && id.w == sg.w && idm == mask;
@@ -1297,6 +1299,7 @@ __global__ void __launch_bounds__(LOB_BLOCK) accumulate_kernel(DevParams P, DevS
                     s = (s + 1) & (uint32_t)(S.cb_slots - 1);
                 }
             }
+            if (found && !known) S.tr_cbslot[(size_t)bb * G + slot] = (i32)(s | LOB_CBS_VERIFIED);
             if (found) {
                 __hip_atomic_fetch_add(&S.cb_acc[(size_t)s * 2 + target], scaled * (f64)P.trace_pow[age], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (!(S.cb_touch[s] & (1u << target))) atomicOr(&S.cb_touch[s], 1u << target);
@@ -1467,6 +1470,7 @@ __global__ void __launch_bounds__(256) memo_kernel(DevParams P, DevState S, cons
         S.slow_n[reset_lpar * 2 + 0] = 0;      // this step's work lists: the step after the next fills them again
         S.slow_n[reset_lpar * 2 + 1] = 0;
         S.tr_list_n[reset_lpar] = 0;
+        S.tr_list2_n[reset_lpar] = 0;
     }
     __shared__ f64 vals[4][LOB_N_ACTIONS * LOB_QSTRIDE];
     __shared__ uint32_t rnd[2048 + 32];
@@ -1501,45 +1505,17 @@ __global__ void __launch_bounds__(256) memo_kernel(DevParams P, DevState S, cons
             sum = mod_add(sum, rnd[(j + 449 * 3) & 2047], M);
         }
         f64 t[5];
-        const bool fill = S.mk_tiles_ok[s] == 0;  // first time on a list: leave the tile indices for the trace kernel
-        // ... and (SARSA lane path, launches `which` 0 only: the launches which 1 read what these append) enter them in the
-        // tile registry
-        const bool reg = fill && which == 0 && P.sarsa_lanes != 0;
-        bool reg_fail = false;
-        uint32_t my_amb = 0;  // bit k: this lane's tile of action (hi ? 5 : 0) + k lies on an ambiguous index
+        const bool fill = (S.mk_tiles_ok[s] & 1) == 0;  // first time on a list: leave the tile indices for the trace kernel
 #pragma unroll
         for (int k = 0; k < 5; k++) {
             const int a = (hi ? 5 : 0) + k;
             const i32 tile = tile_index(sum, rnd[2048 + (a < LOB_N_ACTIONS ? a : 0)], M);
             t[k] = a < LOB_N_ACTIONS ? S.theta[tile] : 0.0;
             if (fill && a < LOB_N_ACTIONS) S.mk_tiles[((size_t)s * LOB_N_ACTIONS + a) * 32 + j] = tile;
-            if (reg && a < LOB_N_ACTIONS) {
-                const int r = tile_register(S, id, s, a, j, tile, par);
-                reg_fail |= r < 0;
-                if (r > 0) my_amb |= 1u << k;
-            }
         }
-        if (reg) {
-            const bool failed = __ballot(reg_fail) != 0;
-#pragma unroll
-            for (int k = 0; k < 5; k++) {
-                const u64 mb = __ballot((my_amb >> k) & 1u);
-                if (lane == 0) {
-                    S.mk_amb[(size_t)s * LOB_N_ACTIONS + k] = (uint32_t)mb;
-                    if (k < 4) S.mk_amb[(size_t)s * LOB_N_ACTIONS + 5 + k] = (uint32_t)(mb >> 32);
-                }
-            }
-            if (lane == 0) {
-                __threadfence();
-                if (!failed) {
-                    const int pos = atomicAdd(S.mk_all_n, 1);
-                    S.mk_all[pos] = s;  // (pos < mk_slots: a slot registers once per episode)
-                }
-                S.mk_tiles_ok[s] = failed ? 1 : 3;
-            }
-        } else if (fill && lane == 0) {
+        if (fill && lane == 0) {
             __threadfence();  // (read by a LATER kernel only; the flag just must not precede the tiles of another wave's view: one wave per slot)
-            S.mk_tiles_ok[s] = 1;
+            atomicOr(&S.mk_tiles_ok[s], 1);  // (bit 1 belongs to registry_kernel, which may run beside this launch)
         }
 #pragma unroll
         for (int k = 0; k < 5; k++) {
@@ -1570,30 +1546,115 @@ __global__ void __launch_bounds__(256) memo_kernel(DevParams P, DevState S, cons
     } else if (blockIdx.x == 0 && threadIdx.x == 0) {
         S.mk_markcount[0] = 0;
     }
-    // Tile registry: the indices this step's launch `which` 0 found ambiguous for the first time are marked in every
-    // registered slot that holds them (the slots registered since then know already: tile_register looks at the bitmap).
-    if (which == 1 && P.sarsa_lanes) {
-        int n_new = S.amb_new_n[par];
-        if (n_new > S.amb_cap) n_new = S.amb_cap;
-        if (blockIdx.x == 0 && threadIdx.x == 0) S.amb_new_n[par ^ 1] = 0;  // (consumed by the previous step's launch)
-        if (n_new > 0) {
-            const int n_all = S.mk_all_n[0];
-            const i32* nw = S.amb_new + (size_t)par * S.amb_cap;
-            for (int i = wave; i < n_all; i += n_waves) {
-                const int s = S.mk_all[i];
-                i32 tl[5];
+}
+
+// Tile registry (lob_state.h ow_tab; trace_lane_kernel): the memo slots on this step's list whose tiles are not registered yet --
+// new triples, a few dozen per step -- enter their 288 tiles, learn which of them lie on an index another tile uses (mk_amb) and
+// whether two of their own coincide (mk_ident[3]).  One wave per slot.  Runs on the engine's SECOND stream beside the step's
+// learner kernels: nothing of what it writes is needed before the next step's trace kernel (a slot new in step t is nobody's
+// last_state before step t + 1; bits that appear early in mk_amb of older slots only widen the set of tile pairs the lane
+// kernel compares index by index, and equal indices are the ground truth).
+__global__ void __launch_bounds__(256) registry_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g, int par) {
+    __shared__ uint32_t rnd[2048 + 32];
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(rnd_g);
+        uint4* dst = reinterpret_cast<uint4*>(rnd);
+        const uint4 r0 = src[threadIdx.x], r1 = src[threadIdx.x + 256];
+        dst[threadIdx.x] = r0; dst[threadIdx.x + 256] = r1;
+        if (threadIdx.x < 27) rnd[2048 + threadIdx.x] = rnd_g[2048 + threadIdx.x];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, j = lane & 31;
+    const bool hi = lane >= 32;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+    const uint32_t M = (uint32_t)P.M;
+    int count = S.mk_count[par];
+    if (count > S.mk_slots) count = S.mk_slots;
+    for (int i = wave; i < count; i += n_waves) {
+        const int s = S.mk_list[(size_t)par * S.mk_slots + i];
+        if (S.mk_tiles_ok[s] & 2) continue;
+        const int4 id = *reinterpret_cast<const int4*>(S.mk_ident + (size_t)s * 4);
+        uint32_t sum = 0;
+        {
+            int base = j;
+            sum = mod_add(sum, rnd[(tile_coord(id.x, base) + 449 * 0) & 2047], M); base += 2 * j;
+            sum = mod_add(sum, rnd[(tile_coord(id.y, base) + 449 * 1) & 2047], M); base += 2 * j;
+            sum = mod_add(sum, rnd[(tile_coord(id.z, base) + 449 * 2) & 2047], M);
+            sum = mod_add(sum, rnd[(j + 449 * 3) & 2047], M);
+        }
+        bool reg_fail = false;
+        uint32_t my_amb = 0;  // bit k: this lane's tile of action (hi ? 5 : 0) + k lies on an ambiguous index
+        i32 tl[5];
 #pragma unroll
-                for (int k = 0; k < 5; k++) {
-                    const int a = (hi ? 5 : 0) + k;
-                    tl[k] = a < LOB_N_ACTIONS ? S.mk_tiles[((size_t)s * LOB_N_ACTIONS + a) * 32 + j] : -1;
-                }
-                for (int e = 0; e < n_new; e++) {
-                    const i32 f = nw[e];  // (wave-uniform)
-#pragma unroll
-                    for (int k = 0; k < 5; k++)
-                        if (tl[k] == f) atomicOr(&S.mk_amb[(size_t)s * LOB_N_ACTIONS + (hi ? 5 : 0) + k], 1u << j);
-                }
+        for (int k = 0; k < 5; k++) {
+            const int a = (hi ? 5 : 0) + k;
+            const i32 tile = tile_index(sum, rnd[2048 + (a < LOB_N_ACTIONS ? a : 0)], M);
+            tl[k] = a < LOB_N_ACTIONS ? tile : -1 - lane;  // (the idle fifth slot of lanes 32-63: equal to nothing)
+            if (a < LOB_N_ACTIONS) {
+                S.mk_tiles[((size_t)s * LOB_N_ACTIONS + a) * 32 + j] = tile;  // (memo_kernel writes the same values: registry_scan_kernel must find them)
+                const int r = tile_register(S, id, s, a, j, tile, par);
+                reg_fail |= r < 0;
+                if (r > 0) my_amb |= 1u << k;
             }
+        }
+        // do two of the triple's 288 tiles coincide?  (mk_ident[3]: the lane trace kernel takes only triples known to be free of
+        // that; the wave-per-book kernel would find out the first time it builds the set -- a step later, for every book that
+        // starts from this triple)
+        bool dupl = false;
+#pragma unroll
+        for (int k2 = 0; k2 < 5; k2++) {
+            for (int l = 0; l < 64; l++) {
+                const i32 t2 = __builtin_amdgcn_readlane(tl[k2], l);
+#pragma unroll
+                for (int k = 0; k < 5; k++) dupl |= tl[k] == t2 && !(k == k2 && l == lane);
+            }
+        }
+        const bool any_dup = __ballot(dupl) != 0;
+        const bool failed = __ballot(reg_fail) != 0;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const u64 mb = __ballot((my_amb >> k) & 1u);
+            if (lane == 0) {
+                S.mk_amb[(size_t)s * LOB_N_ACTIONS + k] = (uint32_t)mb;
+                if (k < 4) S.mk_amb[(size_t)s * LOB_N_ACTIONS + 5 + k] = (uint32_t)(mb >> 32);
+            }
+        }
+        if (lane == 0) {
+            S.mk_ident[(size_t)s * 4 + 3] = any_dup ? 2 : 1;
+            __threadfence();
+            if (!failed) {
+                const int pos = atomicAdd(S.mk_all_n, 1);
+                S.mk_all[pos] = s;  // (pos < mk_slots: a slot registers once per episode)
+                atomicOr(&S.mk_tiles_ok[s], 2);
+            }
+        }
+    }
+}
+// ... and the indices that launch found ambiguous for the first time are marked in every registered slot that holds them (the
+// slots registered since then know already: tile_register looks at the bitmap).  Same stream, right after it.
+__global__ void __launch_bounds__(256) registry_scan_kernel(DevState S, int par) {
+    int n_new = S.amb_new_n[par];
+    if (n_new > S.amb_cap) n_new = S.amb_cap;
+    if (blockIdx.x == 0 && threadIdx.x == 0) S.amb_new_n[par ^ 1] = 0;  // (consumed by the previous step's launch)
+    if (n_new == 0) return;
+    const int lane = threadIdx.x & 63, j = lane & 31;
+    const bool hi = lane >= 32;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+    const int n_all = S.mk_all_n[0];
+    const i32* nw = S.amb_new + (size_t)par * S.amb_cap;
+    for (int i = wave; i < n_all; i += n_waves) {
+        const int s = S.mk_all[i];
+        i32 tl[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int a = (hi ? 5 : 0) + k;
+            tl[k] = a < LOB_N_ACTIONS ? S.mk_tiles[((size_t)s * LOB_N_ACTIONS + a) * 32 + j] : -1;
+        }
+        for (int e = 0; e < n_new; e++) {
+            const i32 f = nw[e];  // (wave-uniform)
+#pragma unroll
+            for (int k = 0; k < 5; k++)
+                if (tl[k] == f) atomicOr(&S.mk_amb[(size_t)s * LOB_N_ACTIONS + (hi ? 5 : 0) + k], 1u << j);
         }
     }
 }

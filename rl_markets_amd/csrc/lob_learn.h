@@ -217,6 +217,7 @@ __device__ inline int argmax_ties(const f64* qs, Rng& g) {
 // ---- generation combining (lob_state.h) -------------------------------------
 #define LOB_CB_EMPTY (~0ull)
 #define LOB_CB_PROBES 64
+#define LOB_CBS_VERIFIED (1 << 30) /* tr_cbslot: accumulate_kernel has compared the slot's identity with the generation's (cb_slots <= 2^24) */
 __device__ inline u64 cb_hash(int q0, int q1, int q2, int code, uint32_t mask) {
     u64 h = lob_mix64((u64)(uint32_t)code ^ ((u64)mask << 32));
     h = lob_mix64(h + (u64)(uint32_t)q2);

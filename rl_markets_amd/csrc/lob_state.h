@@ -312,6 +312,8 @@ struct DevState {
     uint32_t* theta_nzc; // [cwords4 * 4]
     i32* tr_list;        // [B] books the lane-per-book trace kernel leaves to the wave-per-book one
     i32* tr_list_n;      // [2 parities]
+    i32* tr_list2;       // [B] Q(lambda): the entries of `tr_list` the lane-per-generation kernel (trace_lane_kernel) hands on to the wave-per-book one
+    i32* tr_list2_n;     // [2 parities]
     i32* slow_list;      // [2 kinds: act, learn][B]
     i32* slow_n;         // [2 parities][2 kinds]
     // Hit-list carry-over learn_q(t) -> act(t+1) (lob_fast.h act_light_kernel): the Q evaluation of the TD target and the
@@ -370,7 +372,7 @@ struct DevParams {
     i32 algo, theta_private;
     i32 combine;         // shared theta: sum the updates per distinct trace generation first (0 with LOB_NO_COMBINE=1)
     i32 carry_verdicts;  // 0 with LOB_NO_CARRY=1 in the environment (A/B switch for the verdict carry-over)
-    i32 sarsa_lanes;     // SARSA(lambda): trace step with a lane per generation (trace_sarsa_kernel) + the tile registry it needs
+    i32 sarsa_lanes;     // trace step with a lane per generation (trace_lane_kernel: SARSA(lambda), and the books of Q(lambda) that keep their traces) + the tile registry it needs
     i32 epi_epoch;       // episodes begun (lob_reset): tags the memo slots the generations refer to (tr_mslot)
     i32 memo;            // group-0 memo + fast learner kernels on (shared theta, SARSA / Q(lambda), one book group; 0 with LOB_NO_MEMO=1)
     i32 cshift, cwords4; // coarse map: bit = weight index >> cshift; size in 16-byte units

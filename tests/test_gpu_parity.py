@@ -715,11 +715,13 @@ def test_trace_light_kernel_on_off_identical(monkeypatch, mem, eps, lanes):
     np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-9, atol=1e-12)
 
 
+@pytest.mark.parametrize("algo", [abi.ALGO_SARSA, abi.ALGO_QLAMBDA])
 @pytest.mark.parametrize("mem,eps", [(1 << 12, 0.8), (1 << 16, 0.3), (1 << 22, 0.8), (1 << 22, 0.1)])
-def test_sarsa_lane_kernel_on_off_identical(monkeypatch, mem, eps):
-    """SARSA(lambda): trace_sarsa_kernel (a lane per trace generation: which tiles a generation loses to the new state
+def test_trace_lane_kernel_on_off_identical(monkeypatch, mem, eps, algo):
+    """SARSA(lambda), and the books of Q(lambda) whose traces survive the step (the lane-per-book learn kernel forced on
+    for this small batch: LOB_Q_LANES=1): trace_lane_kernel (a lane per trace generation: which tiles a generation loses to the new state
     is decided from the quantised coordinates, index coincidences through the tile registry) against the wave-per-book
-    kernel that compares the indices themselves (LOB_SARSA_LANES=0).  Actions, TD errors, books and the trace lists of
+    kernel that compares the indices themselves (LOB_TRACE_LANES=0).  Actions, TD errors, books and the trace lists of
     every book bit for bit; theta up to its atomics' ordering.  With 4 096 / 65 536 weights most indices are shared by
     several different tiles (every generation takes the index-by-index path, many books go back to the wave kernel);
     with 4 M few are.  Two episodes (the registry and the memo table start afresh, old generations carry the old
@@ -727,8 +729,9 @@ def test_sarsa_lane_kernel_on_off_identical(monkeypatch, mem, eps):
     B = 192
     out = []
     for on in ("0", "1"):
-        monkeypatch.setenv("LOB_SARSA_LANES", on)
-        p, g, rec, eng, orc = make(depth=5, n_events=600, B=B, algo=abi.ALGO_SARSA, theta_mode=abi.THETA_SHARED, mem=mem, epsilon=eps)
+        monkeypatch.setenv("LOB_TRACE_LANES", on)
+        monkeypatch.setenv("LOB_Q_LANES", "1")
+        p, g, rec, eng, orc = make(depth=5, n_events=600, B=B, algo=algo, theta_mode=abi.THETA_SHARED, mem=mem, epsilon=eps)
         orc.close()
         eng.reset()
         trail = []
