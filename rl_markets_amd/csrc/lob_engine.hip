@@ -460,6 +460,10 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
         const bool sl = P.sarsa_lanes != 0;
         S.ow_slots = sl ? 1 << 25 : 1;  // 65 536 memo slots x 288 tiles at most: load <= 0.56
         S.amb_cap = sl ? (int)std::min<long long>((long long)P.M, 1 << 18) : 1;
+        // (LOB_OW_SLOTS / LOB_AMB_CAP: tiny values for the tests -- a registry without room leaves slots unregistered, a full list
+        // of new ambiguous indices switches the lane kernel off until the next reset: every book then goes to the wave-per-book kernel)
+        if (sl) if (const char* g = getenv("LOB_OW_SLOTS")) { int v = atoi(g); if (v >= 64 && v <= (1 << 26) && (v & (v - 1)) == 0) S.ow_slots = v; }
+        if (sl) if (const char* g = getenv("LOB_AMB_CAP")) { int v = atoi(g); if (v >= 1 && v <= (1 << 18)) S.amb_cap = v; }
         if (rc == LOB_OK) rc = dev_alloc(e, &S.tr_mslot, sl ? B * (size_t)P.trace_gens : 1);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.ow_tab, (size_t)S.ow_slots);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.amb_bits, sl ? (size_t)P.M / 32 + 1 : 1);

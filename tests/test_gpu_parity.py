@@ -760,6 +760,37 @@ def test_trace_lane_kernel_on_off_identical(monkeypatch, mem, eps, algo):
     np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-9, atol=1e-12)
 
 
+@pytest.mark.parametrize("squeeze", ["LOB_OW_SLOTS=4096", "LOB_AMB_CAP=3", "LOB_CB_SLOTS=256"])
+@pytest.mark.parametrize("algo", [abi.ALGO_SARSA, abi.ALGO_QLAMBDA])
+def test_trace_lane_kernel_without_room(monkeypatch, algo, squeeze):
+    """The lane trace path when its tables have no room, against the oracle: a tile registry of 4 096 entries (a memo
+    slot brings 288: most slots stay unregistered and their books go to the wave-per-book kernel), a list of three new
+    ambiguous indices per step (it overflows in the first steps of each episode: the lane kernel is off until the next
+    reset), a combine table of 256 slots (most generations find none: the direct per-tile update; the slots that exist
+    persist from step to step)."""
+    k, v = squeeze.split("=")
+    monkeypatch.setenv(k, v)
+    monkeypatch.setenv("LOB_Q_LANES", "1")
+    B = 96
+    p, g, rec, eng, orc = make(depth=5, n_events=500, B=B, algo=algo, theta_mode=abi.THETA_SHARED, mem=1 << 15, epsilon=0.3)
+    for episode in range(2):
+        eng.reset()
+        orc.reset()
+        for step in range(60):
+            eng.td_step(1)
+            orc.td_step(1)
+            compare_learner_step(eng, orc, "%s episode %d step %d" % (squeeze, episode, step), exact=False, rtol=1e-9)
+        eng.handle_terminal(); orc.handle_terminal()
+    st = eng.path_stats()
+    if k == "LOB_AMB_CAP":
+        assert st[4] == 1, "the list of new ambiguous indices must have overflowed"
+    if k != "LOB_CB_SLOTS":
+        assert st[0] > 0, "books must have been handed on to the wave-per-book kernel"
+    np.testing.assert_allclose(eng.theta(), orc.theta(), rtol=1e-9, atol=1e-12)
+    eng.close()
+    orc.close()
+
+
 @pytest.mark.parametrize("algo", [abi.ALGO_R_LEARN, abi.ALGO_ONLINE_R_LEARN, abi.ALGO_DOUBLE_R_LEARN])
 @pytest.mark.parametrize("theta_mode", [abi.THETA_PRIVATE, abi.THETA_SHARED])
 def test_r_learning_against_oracle(algo, theta_mode):
