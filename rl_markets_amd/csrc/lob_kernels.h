@@ -1261,6 +1261,14 @@ __global__ void __launch_bounds__(LOB_BLOCK) accumulate_kernel(DevParams P, DevS
     const int bb = b < S.B ? b : 0;
     const uint32_t* tr_alive = S.tr_alive + (size_t)bb * G;
     const i32* tr_sig = S.tr_sig + (size_t)bb * G * 4;
+    // the sums are kept in S.cb_reps copies, one per XCD (apply_kernel adds them up): the additions to a popular generation's
+    // slot queue up behind each other at one address
+    int xcd = 0;
+    if (S.cb_reps > 1) {
+        unsigned x;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+        xcd = (int)(x & (unsigned)(S.cb_reps - 1));
+    }
     for (int base = 0; base < G; base += lpb) {
         const int age = base + sub;
         if (!__any(age < n)) break;
@@ -1301,7 +1309,7 @@ __global__ void __launch_bounds__(LOB_BLOCK) accumulate_kernel(DevParams P, DevS
             }
             if (found && !known) S.tr_cbslot[(size_t)bb * G + slot] = (i32)(s | LOB_CBS_VERIFIED);
             if (found) {
-                __hip_atomic_fetch_add(&S.cb_acc[(size_t)s * 2 + target], scaled * (f64)P.trace_pow[age], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(&S.cb_acc[((size_t)xcd * S.cb_slots + s) * 2 + target], scaled * (f64)P.trace_pow[age], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (!(S.cb_touch[s] & (1u << target))) atomicOr(&S.cb_touch[s], 1u << target);
             } else {
                 direct = true;
@@ -1366,7 +1374,19 @@ __global__ void __launch_bounds__(256) apply_kernel(DevParams P, DevState S, con
         const uint32_t touch = S.cb_touch[s];
         const int4 id = *reinterpret_cast<const int4*>(S.cb_ident + (size_t)s * 8);
         const uint32_t mask = (uint32_t)S.cb_ident[(size_t)s * 8 + 4];
-        const f64 v0 = S.cb_acc[(size_t)s * 2], v1 = S.cb_acc[(size_t)s * 2 + 1];
+        // (the copies of the sums, one per XCD: lane x fetches copy x, added up in the order of the copies)
+        f64 v0 = 0.0, v1 = 0.0;
+        {
+            f64 c0 = 0.0, c1 = 0.0;
+            if (lane < S.cb_reps) {
+                c0 = S.cb_acc[((size_t)lane * S.cb_slots + s) * 2];
+                c1 = S.cb_acc[((size_t)lane * S.cb_slots + s) * 2 + 1];
+            }
+            for (int x = 0; x < S.cb_reps; x++) {
+                v0 += readlane_f64(c0, x);
+                v1 += readlane_f64(c1, x);
+            }
+        }
         if (touch == 0) {  // (wave-uniform)
             if (lane == 0) {
                 S.cb_key[s] = LOB_CB_EMPTY;
@@ -1401,9 +1421,11 @@ __global__ void __launch_bounds__(256) apply_kernel(DevParams P, DevState S, con
                 }
             }
         }
+        if (lane < S.cb_reps) {
+            S.cb_acc[((size_t)lane * S.cb_slots + s) * 2] = 0.0;
+            S.cb_acc[((size_t)lane * S.cb_slots + s) * 2 + 1] = 0.0;
+        }
         if (lane == 0) {
-            S.cb_acc[(size_t)s * 2] = 0.0;
-            S.cb_acc[(size_t)s * 2 + 1] = 0.0;
             S.cb_touch[s] = 0;
             list_next[atomicAdd(&n_surv, 1)] = s;
         }

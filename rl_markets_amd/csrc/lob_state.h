@@ -258,6 +258,7 @@ struct DevState {
                          //   the previous step (apply_kernel, one block per segment: no global counter), then this step's claims
     i32* cb_count;       // [2][cb_segs]
     i32 cb_slots;        // power of two
+    i32 cb_reps;         // copies of cb_acc ([cb_reps][cb_slots][2]): 1, or 8 = one per XCD (accumulate_kernel)
     i32 cb_segs;         // power of two <= cb_slots / 4: apply_kernel's grid
     i32 cb_par;          // parity of the current learner step (set by the host before the step's launches)
     // Verdict carry-over: learn(t) saves, per book, which group-1/2 tiles of s' hit a written
