@@ -934,6 +934,7 @@ int lob_get_book(lob_engine* e, int32_t book, lob_book_dump* out) { return lob_g
 // alive; 8 lanes per book: 0.035 ms, 16: 0.030, 32: 0.029, 64: 0.036).  LOB_ACC_LANES=8|16|32|64 overrides.
 static int acc_lanes_shift(const lob_engine* e) {
     if (e->acc_shift >= 0) return e->acc_shift;
+    if (e->P.algo == LOB_ALGO_SARSA && e->S.cb_reps > 1) return 6;  // (with a copy of the sums per XCD: 64 lanes 0.096 ms, 32 lanes 0.101)
     return 5;
 }
 
