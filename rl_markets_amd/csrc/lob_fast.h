@@ -668,7 +668,7 @@ __global__ void __launch_bounds__(LOB_TS_BLOCK, 5) trace_lane_kernel(DevParams P
     const int n_todo = QL ? S.tr_list_n[lpar] : S.B;
     const int G = P.trace_gens;  // 32
     const int tag_epoch = (P.epi_epoch & 0x7fff) << 16;
-    const int lim = (int)0x80000400;  // (below: tile_coord's wrap-around branch -- a NaN variable)
+    const int lim = LOB_TILE_PLAIN_MIN;  // (below: tile_coord's wrap-around branch -- a NaN variable)
     const bool reg_ok = S.amb_flag[0] == 0;
 #pragma unroll 1
     for (int t0 = blockIdx.x * (LOB_TS_BLOCK / 32); t0 < n_todo; t0 += gridDim.x * (LOB_TS_BLOCK / 32)) {
@@ -720,19 +720,9 @@ __global__ void __launch_bounds__(LOB_TS_BLOCK, 5) trace_lane_kernel(DevParams P
 #pragma unroll
         for (int o = 1; o < 16; o <<= 1) n_amb_new += __shfl_xor(n_amb_new, o);  // (lanes 0-15 of the half: all nine words)
         n_amb_new = __shfl(n_amb_new, half * 32);
-        // ---- same cell, tiling by tiling ----
+        // ---- same cell, tiling by tiling (lob_tiles.h) ----
         uint32_t hit = 0;
-        if (m) {
-            const uint32_t d0 = (uint32_t)(q0 - sg.x) & 2047u, d1 = (uint32_t)(q1 - sg.y) & 2047u, d2 = (uint32_t)(q2 - sg.z) & 2047u;
-            // (a coordinate 32 .. 2015 away mod 2048 is in another cell of every tiling: the cell numbers differ by 1 .. 63 mod 64)
-            if (!(d0 - 32u <= 1983u || d1 - 32u <= 1983u || d2 - 32u <= 1983u)) {
-#pragma unroll 4
-                for (int j = 0; j < 32; j++) {
-                    const int x = ((q0 - j) >> 5) ^ ((sg.x - j) >> 5), y = ((q1 - 3 * j) >> 5) ^ ((sg.y - 3 * j) >> 5), z = ((q2 - 5 * j) >> 5) ^ ((sg.z - 5 * j) >> 5);
-                    if (((x | y | z) & 63) == 0) hit |= 1u << j;
-                }
-            }
-        }
+        if (m) hit = tile_same_cell_mask(q0, q1, q2, sg.x, sg.y, sg.z);
         const uint32_t cand = m & ~hit & amb_old;  // live tiles that may meet last_state's through an ambiguous index
         const bool heavy = cand != 0 && n_amb_new != 0 && __popc(cand) * n_amb_new > 96;
         {

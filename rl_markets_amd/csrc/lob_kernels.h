@@ -1440,12 +1440,6 @@ __global__ void __launch_bounds__(256) apply_kernel(DevParams P, DevState S, con
 // Tile registry (lob_state.h ow_tab): enter tile (slot s of triple `id`, action a, tiling j) with weight index `tile`.  Returns 1 if the index
 // is (now) known to be ambiguous, 0 if not, -1 if the table had no room (the slot then stays unregistered: the lane path
 // leaves every book that meets it to the wave-per-book kernel).
-__device__ inline bool tile_same_cell(const int4& x, const int4& y, int j) {
-    int base = j;
-    bool same = ((tile_coord(x.x, base) ^ tile_coord(y.x, base)) & 2047) == 0; base += 2 * j;
-    same = same && ((tile_coord(x.y, base) ^ tile_coord(y.y, base)) & 2047) == 0; base += 2 * j;
-    return same && ((tile_coord(x.z, base) ^ tile_coord(y.z, base)) & 2047) == 0;
-}
 __device__ inline int tile_register(const DevState& S, const int4& id, int s, int a, int j, i32 tile, int par) {
     const u64 want = ((u64)(uint32_t)tile << 32) | (u64)(uint32_t)(s * (LOB_N_ACTIONS * 32) + a * 32 + j);
     const uint32_t mask = (uint32_t)(S.ow_slots - 1);

@@ -37,50 +37,8 @@ struct Prof {
 #define LOB_QSTRIDE 33  // 32 tiles of one group + 1 pad double: lanes a=0..8 read column i without bank conflicts
 #define LOB_HSLOTS 512  // per-wave LDS hash map (64-bit slots: tile index | rank) of the 288 "current" tiles
 
-// The hash of tiles.cpp:152-168 is (sum of table terms) mod M.  The table is stored already reduced
-// mod M (lob_engine.hip), and the running sum is kept reduced: s, x < M < 2^31, so s + x fits 32 bits
-// and one conditional subtraction (min with the wrapped difference) restores s < M.  Same residue as
-// reducing the 64-bit sum once, no 64-bit arithmetic and no division on the device.
-__device__ inline uint32_t mod_add(uint32_t s, uint32_t x, uint32_t M) {
-    s += x;
-    const uint32_t d = s - M;  // wraps to >= 2^31 when s < M
-    return d < s ? d : s;
-}
+#include "lob_tiles.h"
 
-// (int) floor(x * num_tilings) with x86 `cvttsd2si` semantics (NaN / out of range -> INT_MIN), the
-// quantised coordinate of tiles.cpp:50-53.
-__device__ inline int tile_quant(f32 x) {
-    const f32 fq = floorf(x * 32.0f);
-    return (fq >= -2147483648.0f && fq < 2147483648.0f) ? (int)fq : (int)0x80000000;
-}
-
-// Coordinate of quantised value q in the tiling whose offset for this variable is `base`
-// (tiles.cpp:61-64):  q >= base: q - ((q - base) % 32);  else: q + 1 + ((base - q - 1) % 32) - 32.
-// Without overflow both branches are base + 32 floor((q - base) / 32) = base + ((q - base) & ~31)
-// (write base - q - 1 = 32 m + r in the second).  base <= 31 * 25, so the subtractions can only
-// overflow for q within 1024 of INT_MIN -- in practice q == INT_MIN, a NaN variable -- and there the
-// compiled reference wraps (two's complement) and takes a signed remainder: spelt out.
-__device__ inline int tile_coord(int q, int base) {
-    if (__builtin_expect(q < (int)0x80000400, 0)) {
-        if (q >= base) return (int)((uint32_t)q - (uint32_t)((int)((uint32_t)q - (uint32_t)base) % 32));
-        return (int)((uint32_t)q + 1u + (uint32_t)((int)((uint32_t)base - (uint32_t)q - 1u) % 32) - 32u);
-    }
-    return base + ((q - base) & ~31);
-}
-
-// Reduced sum of the table terms of tiling j that do not depend on the action: the nf float
-// coordinates and the tiling index (tiles.cpp:50-70).  `v` = the group's float sub-array
-// (State::populateFeatures passes &state_vars[0] or &state_vars[3]); `rndM` = the table mod M.
-// General form (any lane, any group): used where speed does not matter.
-__device__ inline uint32_t tile_base_m(uint32_t M, const f32* v, int nf, int j, const uint32_t* rndM) {
-    uint32_t sum = 0;
-    int base = j;  // j * (1 + 2 i), built up by adding 2 j per coordinate
-    for (int i = 0; i < nf; i++) {
-        sum = mod_add(sum, rndM[(tile_coord(tile_quant(v[i]), base) + 449 * i) & 2047], M);
-        base += 2 * j;
-    }
-    return mod_add(sum, rndM[(j + 449 * nf) & 2047], M);
-}
 // Wave form: `qv` holds, in lane i, the quantised variable i of the state (computed once per wave);
 // the coordinates [first, first + nf) are read back as wave-uniform scalars.
 template <int FIRST>
@@ -273,13 +231,6 @@ __device__ inline void cb_claim_finish(const DevState& S, const CbPending& c) {
     S.tr_cbslot[c.src] = -1;  // table crowded
 }
 
-// (base + term) mod M with both operands already reduced: one add, one compare, one select.
-// hash_UNH sums the table terms and reduces once (tiles.cpp:165-168); reducing the
-// action-independent partial sum and the action term separately gives the same residue.
-__device__ inline i32 tile_index(uint32_t base_m, uint32_t term_m, uint32_t M) {
-    const uint32_t s = base_m + term_m;  // < 2^32: M < 2^31
-    return (i32)(s >= M ? s - M : s);
-}
 
 // Q(s, a) for all 9 actions of one state, one wave.
 //   vars      : V floats of the state (LDS), ignored if `zero`

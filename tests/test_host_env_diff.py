@@ -36,3 +36,17 @@ def test_exp_restatement_equals_libm(tmp_path):
         hdr = open(os.path.join(ROOT, "rl_markets_amd", "csrc", "lob_exp_table.h")).read()
         for line in gen.stdout.splitlines()[1:]:
             assert line.strip().rstrip("\\").rstrip().rstrip(",") in hdr
+
+
+def test_same_cell_arithmetic_equals_tile_coord_and_implies_same_index(tmp_path):
+    """trace_lane_kernel decides which tiles an old trace generation loses to a new state from the quantised coordinates
+    alone (lob_tiles.h tile_same_cell_mask).  tests/host_env/cell_diff.cpp, compiled from the device header: the mask equals
+    the tiling-by-tiling comparison through tile_coord for random pairs of triples (near, 2 048 k apart, at both ends of the
+    plain range), and a same cell always means the same weight index under the real hash, for every action and table size;
+    the converse (an index shared by different cells) is what the tile registry exists for."""
+    exe = str(tmp_path / "cell_diff")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "tests", "host_env", "shim"),
+                           "-o", exe, os.path.join(ROOT, "tests", "host_env", "cell_diff.cpp")])
+    out = subprocess.run([exe, os.environ.get("LOB_CELL_DIFF_CASES", "200000")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-2000:]
+    assert "cell_diff OK" in out.stdout
