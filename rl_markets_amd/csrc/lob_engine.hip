@@ -44,6 +44,7 @@ struct lob_engine {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_stagger = nullptr;
     hipEvent_t ev_reg_go = nullptr, ev_reg_done = nullptr;  // tile registry kernels on stream2 beside the learner kernels (lob_kernels.h registry_kernel)
     bool reg_pending = false;
+    bool reg_fork_late = false;
     int n_groups = 1;
     int env_lanes = 0;     // books per env_kernel wave: 0 = by batch size, or 16 / 32 / 64; 256 = env_compact_kernel (LOB_ENV_LANES, read by lob_create)
     int reset_lanes = 64;  // books per reset_kernel wave (LOB_RESET_LANES)
@@ -144,6 +145,18 @@ static int registry_join(lob_engine* e) {
         HIPCHK(hipStreamWaitEvent(e->stream, e->ev_reg_done, 0));
         e->reg_pending = false;
     }
+    return LOB_OK;
+}
+// The step's new memo slots enter the tile registry on the second stream, beside kernels that follow on the main one (never
+// beside the learn kernel: its one block per CU wants the CU's LDS to itself).  LOB_REG_FORK=late: after the update instead of
+// after the learn kernels.
+static int registry_fork(lob_engine* e, hipStream_t st, const uint32_t* rnd, int par) {
+    HIPCHK(hipEventRecord(e->ev_reg_go, st));
+    HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_reg_go, 0));
+    hipLaunchKernelGGL(registry_kernel, dim3(64), dim3(256), 0, e->stream2, e->P, e->S, rnd, par);
+    hipLaunchKernelGGL(registry_scan_kernel, dim3(256), dim3(256), 0, e->stream2, e->S, par);
+    HIPCHK(hipEventRecord(e->ev_reg_done, e->stream2));
+    e->reg_pending = true;
     return LOB_OK;
 }
 int push_params(lob_engine* e) {
@@ -295,6 +308,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     if (const char* g = getenv("LOB_NO_TLIGHT")) e->t_light = !(g[0] == '1');
     if (const char* g = getenv("LOB_Q_PAIR")) e->q_pair = !(g[0] == '0');
     if (const char* g = getenv("LOB_NO_FUSE")) e->no_fuse = g[0] == '1';
+    if (const char* g = getenv("LOB_REG_FORK")) e->reg_fork_late = g[0] == 'l';
     if (const char* g = getenv("LOB_ENV_STEP")) e->env_step = !(g[0] == '0');
     if (const char* g = getenv("LOB_INLINE_GENERAL")) e->inline_general = !(g[0] == '0');
     if (const char* g = getenv("LOB_RESET_LANES")) { int v = atoi(g); if (v == 16 || v == 32 || v == 64) e->reset_lanes = v; }
@@ -1055,16 +1069,7 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                     if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL(learn_q_rest_kernel<LOB_ALGO_QLAMBDA>, dim3(gl), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, learn_list, learn_n);
                     else hipLaunchKernelGGL(learn_q_rest_kernel<LOB_ALGO_SARSA>, dim3(gl), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, learn_list, learn_n);
                 }
-                if (e->P.sarsa_lanes) {
-                    // the step's new memo slots enter the tile registry on the second stream, beside the trace / update kernels that
-                    // follow (not beside the learn kernel: its one block per CU wants the CU's LDS to itself)
-                    HIPCHK(hipEventRecord(e->ev_reg_go, st));
-                    HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_reg_go, 0));
-                    hipLaunchKernelGGL(registry_kernel, dim3(64), dim3(256), 0, e->stream2, e->P, e->S, rnd, par);
-                    hipLaunchKernelGGL(registry_scan_kernel, dim3(256), dim3(256), 0, e->stream2, e->S, par);
-                    HIPCHK(hipEventRecord(e->ev_reg_done, e->stream2));
-                    e->reg_pending = true;
-                }
+                if (e->P.sarsa_lanes && !e->reg_fork_late) { int rc = registry_fork(e, st, rnd, par); if (rc) return rc; }
                 if (fuse) {
                     TimedLaunch t(e, "trace_kernel", st);
                     // the listed books (their traces survive the step): a lane per generation, then the wave-per-book kernel for
@@ -1098,6 +1103,7 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                 const int blocks = e->S.cb_segs;
                 hipLaunchKernelGGL(apply_kernel, dim3(blocks), dim3(256), 0, e->stream, e->P, e->S, rnd, par, e->step_id);
             }
+            if (e->P.sarsa_lanes && e->reg_fork_late) { int rc = registry_fork(e, e->stream, rnd, par); if (rc) return rc; }
         } else if (mode == 0) {
             TimedLaunch t(e, "update_kernel");
             hipLaunchKernelGGL(update_kernel, dim3(grid_waves(e->B)), dim3(LOB_BLOCK), 0, e->stream, e->P, e->S, par, e->step_id);
