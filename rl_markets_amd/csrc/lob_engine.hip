@@ -443,7 +443,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
         // SARSA(lambda) adds 1.6 M terms per step to the slots' sums: a copy of the sums per XCD (0.147 -> 0.100 ms; apply_kernel
         // 0.023 -> 0.03); Q(lambda)'s few additions are a latency chain that the copies do not shorten
         S.cb_reps = (P.algo == LOB_ALGO_SARSA && P.memo) ? 8 : 1;
-        if (const char* g = getenv("LOB_ACC_REPS")) { int v = atoi(g); if (v == 1 || v == 2 || v == 4 || v == 8) S.cb_reps = v; }
+        if (const char* g = getenv("LOB_ACC_REPS")) { int v = atoi(g); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) S.cb_reps = v; }
         if (rc == LOB_OK) rc = dev_alloc(e, &S.cb_acc, (size_t)S.cb_reps * slots * 2);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.cb_touch, (size_t)slots);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.cb_list, 2 * (size_t)slots);

@@ -1268,6 +1268,8 @@ __global__ void __launch_bounds__(LOB_BLOCK) accumulate_kernel(DevParams P, DevS
         unsigned x;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
         xcd = (int)(x & (unsigned)(S.cb_reps - 1));
+        // (more than one copy per XCD -- LOB_ACC_REPS=16|32|64, an experiment: the waves of an XCD spread over cb_reps / 8 copies)
+        if (S.cb_reps > 8) xcd = (int)(x & 7u) * (S.cb_reps >> 3) + (wave & ((S.cb_reps >> 3) - 1));
     }
     for (int base = 0; base < G; base += lpb) {
         const int age = base + sub;
