@@ -364,7 +364,7 @@ int lob_get_traces(lob_engine* e, int32_t book, int32_t* idx, float* elig, int32
 int lob_get_counters(lob_engine* e, int64_t out[4]);
 /* Which kernels served the books (diagnostics of the fast paths, cumulative since lob_create unless noted):
  * [0] books the SARSA lane trace kernel (trace_sarsa_kernel) handed back to the wave-per-book kernel,
- * [1] books the fused action selection served through the general path, [2] memo slots registered this episode,
+ * [1] books whose action came from the hit-list replay (the light action selection), [2] memo slots registered this episode,
  * [3] weight indices found ambiguous this episode (tile registry), [4] 1 if the registry overflowed this episode,
  * [5] memo slots in use in the latest step, [6], [7] reserved (0). */
 int lob_get_path_stats(lob_engine* e, int64_t out[8]);
