@@ -67,8 +67,17 @@ TIMER_KERNELS = {"act_kernel": ("act_light_kernel", "act_fast_kernel", "act_kern
                  "learn_kernel": ("learn_q_pair_kernel", "learn_q_lane_kernel", "learn_q_fast_kernel", "learn_kernel"), "act_rest_kernel": (), "learn_rest_kernel": ("learn_q_rest_kernel",)}
 
 
+# ... and the timers that bracket two launches (the lane trace kernel and the wave-per-book kernel behind it): their figures add up
+TIMER_SUMS = {"trace_kernel": ("trace_lane_kernel", "trace_fast_kernel")}
+
+
 def traffic_of(traffic_file, timer, key="hbm_bytes_per_launch"):
     """A per-launch counter figure of the kernel behind a timer, from profiles/pmc_traffic.json (None if absent)."""
+    if timer in TIMER_SUMS:
+        vals = [traffic_file.get(fn, {}).get(key) for fn in TIMER_SUMS[timer] if isinstance(traffic_file.get(fn), dict)]
+        vals = [v for v in vals if v]
+        if len(vals) == len(TIMER_SUMS[timer]):
+            return sum(vals)
     for fn in TIMER_KERNELS.get(timer, (timer,)):
         v = traffic_file.get(fn, {}).get(key) if isinstance(traffic_file.get(fn), dict) else None
         if v:
