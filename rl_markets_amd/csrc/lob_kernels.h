@@ -1439,40 +1439,6 @@ __global__ void __launch_bounds__(256) apply_kernel(DevParams P, DevState S, con
     }
 }
 
-// Tile registry (lob_state.h ow_tab): enter tile (slot s of triple `id`, action a, tiling j) with weight index `tile`.  Returns 1 if the index
-// is (now) known to be ambiguous, 0 if not, -1 if the table had no room (the slot then stays unregistered: the lane path
-// leaves every book that meets it to the wave-per-book kernel).
-__device__ inline int tile_register(const DevState& S, const int4& id, int s, int a, int j, i32 tile, int par) {
-    const u64 want = ((u64)(uint32_t)tile << 32) | (u64)(uint32_t)(s * (LOB_N_ACTIONS * 32) + a * 32 + j);
-    const uint32_t mask = (uint32_t)(S.ow_slots - 1);
-    uint32_t h = ((uint32_t)tile * 2654435761u) & mask;
-    const uint32_t bit = 1u << ((uint32_t)tile & 31);
-    uint32_t* word = S.amb_bits + ((uint32_t)tile >> 5);
-    for (int probe = 0; probe < 64; probe++) {
-        const u64 old = atomicCAS((unsigned long long*)&S.ow_tab[h], ~0ull, (unsigned long long)want);
-        if (old == ~0ull) return (*word & bit) ? 1 : 0;  // first tile on this index (the bit is clear unless the table lost an entry)
-        if ((uint32_t)(old >> 32) == (uint32_t)tile) {
-            const uint32_t ref = (uint32_t)old;
-            const int s2 = (int)(ref / (LOB_N_ACTIONS * 32)), r2 = (int)(ref % (LOB_N_ACTIONS * 32));
-            bool same = (r2 >> 5) == a && (r2 & 31) == j;
-            if (same && s2 != s) same = tile_same_cell(id, *reinterpret_cast<const int4*>(S.mk_ident + (size_t)s2 * 4), j);
-            if (!same) {
-                const uint32_t was = atomicOr(word, bit);
-                if (!(was & bit)) {
-                    const int pos = atomicAdd(&S.amb_new_n[par], 1);
-                    atomicAdd((unsigned long long*)&S.counters[7], 1ull);
-                    if (pos < S.amb_cap) S.amb_new[(size_t)par * S.amb_cap + pos] = tile;
-                    else S.amb_flag[0] = 1;
-                }
-                return 1;
-            }
-            return (*word & bit) ? 1 : 0;
-        }
-        h = (h + 1) & mask;
-    }
-    return -1;
-}
-
 // Group-0 memo: S0(a) = the first 32 terms of Agent::getQ (agent.cpp:117-135), sum over the tilings of
 // w0 * theta[group-0 tile], in the reference's order, for every triple on this step's list.  One wave
 // per triple: lanes 0-31 (tiling j) fetch actions 0-4, lanes 32-63 actions 5-8; the products go

@@ -24,4 +24,9 @@ static inline long long __double_as_longlong(double d) { long long u; memcpy(&u,
 static inline double __longlong_as_double(long long u) { double d; memcpy(&d, &u, 8); return d; }
 static inline int atomicOr(int* p, int v) { int o = *p; *p |= v; return o; }
 static inline long long clock64() { return 0; }
+// (serial stand-ins: the host tests run one "lane" at a time)
+static inline unsigned long long atomicCAS(unsigned long long* p, unsigned long long c, unsigned long long v) { const unsigned long long o = *p; if (o == c) *p = v; return o; }
+static inline uint32_t atomicOr(uint32_t* p, uint32_t v) { const uint32_t o = *p; *p |= v; return o; }
+static inline int atomicAdd(int* p, int v) { const int o = *p; *p += v; return o; }
+static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { const unsigned long long o = *p; *p += v; return o; }
 #endif

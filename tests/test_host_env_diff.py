@@ -50,3 +50,18 @@ def test_same_cell_arithmetic_equals_tile_coord_and_implies_same_index(tmp_path)
     out = subprocess.run([exe, os.environ.get("LOB_CELL_DIFF_CASES", "200000")], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout[-2000:]
     assert "cell_diff OK" in out.stdout
+
+
+def test_tile_registry_flags_every_shared_index(tmp_path):
+    """The tile registry (lob_tiles.h tile_register -- the engine's own function --, registry_kernel's per-slot loop and
+    registry_scan_kernel restated serially in tests/host_env/registry_diff.cpp): whenever two registered tiles share a weight
+    index without being the same tile, both carry their bit in mk_amb -- after every step's registrations and scan, for random
+    batches of memo slots in random order (cells that coincide, twins 2 048 apart, three and more tiles on one index, tables
+    from 4 099 to 1 M weights) -- and no tile is flagged without reason.  That invariant is what allows trace_lane_kernel to
+    compare tile indices only where the bits are set."""
+    exe = str(tmp_path / "registry_diff")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "tests", "host_env", "shim"),
+                           "-o", exe, os.path.join(ROOT, "tests", "host_env", "registry_diff.cpp")])
+    out = subprocess.run([exe, os.environ.get("LOB_REGISTRY_DIFF_TRIALS", "40")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-2000:]
+    assert "registry_diff OK" in out.stdout
