@@ -323,8 +323,10 @@ int lob_td_step(lob_engine* e, int32_t n_steps);
 /* One such step in two halves: lob_td_step_begin = swap, isTerminal, action, performAction, newState of every book;
  * lob_td_step_end = HandleTransition (traces, TD errors, update).  Between them no cached action-selection data is live, so
  * that is where a multi-GPU weight exchange goes (include/lob_comm.h lob_theta_allreduce): Q(from_state, .) of the step is
- * what it was when the action was chosen, Q(to_state, .) sees the exchanged weights.  Nothing else may come in between
- * (LOB_ESTATE); begin + end without an exchange = lob_td_step(e, 1), bit for bit. */
+ * what it was when the action was chosen, Q(to_state, .) sees the exchanged weights.  Nothing else may come in between:
+ * lob_td_step, lob_td_step_begin, lob_eval_step, lob_step, lob_clear_inventory, lob_handle_terminal and lob_theta_set return
+ * LOB_ESTATE there; lob_reset abandons the half-done step with its episode.  begin + end without an exchange =
+ * lob_td_step(e, 1), bit for bit. */
 int lob_td_step_begin(lob_engine* e);
 int lob_td_step_end(lob_engine* e);
 /* Backtester::_step (serial.cpp:124-137): greedy action, no learning. */
@@ -366,7 +368,8 @@ int lob_get_counters(lob_engine* e, int64_t out[4]);
  * [0] books the SARSA lane trace kernel (trace_sarsa_kernel) handed back to the wave-per-book kernel,
  * [1] books whose action came from the hit-list replay (the light action selection), [2] memo slots registered this episode,
  * [3] weight indices found ambiguous this episode (tile registry), [4] 1 if the registry overflowed this episode,
- * [5] memo slots in use in the latest step, [6], [7] reserved (0). */
+ * [5] memo slots in use in the latest step, [6] books whose action the fused env kernel had to evaluate in full (no usable hit
+ * list: act_book in-kernel), [7] books the lane learn kernels handed back to the wave-per-book learn_q_rest_kernel. */
 int lob_get_path_stats(lob_engine* e, int64_t out[8]);
 
 /* ---- multi-GPU weight exchange ---------------------------

@@ -841,6 +841,7 @@ int lob_reset(lob_engine* e) {
     e->episode_open = true;
     e->steps_since_fill = 0;
     e->hits_ok = false;
+    e->half_open = false;  // (a step begun before the reset -- e.g. an exchange that failed between the halves -- is abandoned with the episode)
     return check_device_errors(e);
 }
 
@@ -849,10 +850,17 @@ static int need_reset(lob_engine* e, const char* who) {
     if (!e->was_reset) { lob_set_error(std::string(who) + ": call lob_reset first"); return LOB_ESTATE; }
     return LOB_OK;
 }
+// Between lob_td_step_begin and lob_td_step_end only the weight exchange may run (include/lob_engine.h): anything that moves
+// the books, the traces or the weights there would change what the second half consumes.
+static int not_mid_step(lob_engine* e, const char* who) {
+    if (e && e->half_open) { lob_set_error(std::string(who) + ": a learner step is half done (lob_td_step_begin without lob_td_step_end)"); return LOB_ESTATE; }
+    return LOB_OK;
+}
 
 int lob_step(lob_engine* e, const int32_t* host_actions) {
     int rc = need_reset(e, "lob_step");
     if (rc) return rc;
+    if ((rc = not_mid_step(e, "lob_step"))) return rc;
     if (!host_actions) { lob_set_error("lob_step: actions == NULL"); return LOB_EINVAL; }
     for (int b = 0; b < e->B; b++)
         if (host_actions[b] < 0 || host_actions[b] >= LOB_N_ACTIONS) { lob_set_error("lob_step: action out of range"); return LOB_EINVAL; }
@@ -916,6 +924,7 @@ int lob_get_terminal(lob_engine* e, uint8_t* host_out) {
 int lob_clear_inventory(lob_engine* e) {
     int rc = need_reset(e, "lob_clear_inventory");
     if (rc) return rc;
+    if ((rc = not_mid_step(e, "lob_clear_inventory"))) return rc;
     HIPCHK(hipSetDevice(e->device));
     hipLaunchKernelGGL(clear_inventory_kernel, dim3(grid_lanes(e->B)), dim3(256), 0, e->stream, (const DevParams*)e->P_dev, e->S);
     e->hits_ok = false;
@@ -1156,6 +1165,7 @@ int lob_eval_step(lob_engine* e, int32_t n_steps) {
 
 int lob_handle_terminal(lob_engine* e) {
     if (!e) return LOB_EINVAL;
+    { int rc = not_mid_step(e, "lob_handle_terminal"); if (rc) return rc; }
     HIPCHK(hipSetDevice(e->device));
     hipLaunchKernelGGL(clear_traces_kernel, dim3(grid_lanes(e->B)), dim3(256), 0, e->stream, e->S);
     HIPCHK(hipGetLastError());
@@ -1214,6 +1224,7 @@ int lob_theta_set(lob_engine* e, int32_t which, const double* host_in, int64_t c
     f64* th; uint32_t* nz;
     int rc = theta_slot(e, which, &th, &nz);
     if (rc) return rc;
+    if ((rc = not_mid_step(e, "lob_theta_set"))) return rc;
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipMemcpyAsync(th, host_in, (size_t)count * 8, hipMemcpyHostToDevice, e->stream));
     if (e->S.theta_sync) {
@@ -1332,6 +1343,7 @@ int lob_get_path_stats(lob_engine* e, int64_t out[8]) {
     HIPCHK(hipStreamSynchronize(e->stream));
     for (int i = 0; i < 8; i++) out[i] = 0;
     out[0] = c[6]; out[1] = c[5]; out[2] = n_all; out[3] = c[7]; out[4] = flag; out[5] = mk_n[e->last_par & 1];
+    out[6] = c[2]; out[7] = c[4];
     return LOB_OK;
 }
 
@@ -1522,6 +1534,26 @@ extern "C" int lob_debug_prof(lob_engine* e, int64_t out[LOB_PROF_N]) {
     for (int i = 0; i < LOB_PROF_N; i++) out[i] = 0;
     for (size_t b = 0; b < (size_t)e->B; b++)
         for (int i = 0; i < LOB_PROF_N; i++) out[i] += h[b * LOB_PROF_N + i];
+    return LOB_OK;
+}
+
+// Diagnostics (not part of include/lob_engine.h): the state the fast path's shortcuts depend on -- [0] weights the exact
+// written-weights map shows, [1] live books, [2] live books without a hit list, [3] sum of the live books' list lengths,
+// [4 + n] live books whose list has n entries (the last bin, n = 256: that many or more).  bench.py's sustained leg prints it.
+extern "C" int lob_debug_fastpath(lob_engine* e, int64_t* out, int32_t n_out) {
+    if (!e || !out || n_out < 4 + LOB_FP_BINS) return LOB_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    i64* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, (size_t)(4 + LOB_FP_BINS) * 8));
+    hipError_t err = hipMemsetAsync(d, 0, (size_t)(4 + LOB_FP_BINS) * 8, e->stream);
+    if (err == hipSuccess) {
+        hipLaunchKernelGGL(fastpath_stats_kernel, dim3(512), dim3(256), 0, e->stream, e->S, (i64)e->P.M, e->P.memo ? 1 : 0, d);
+        err = hipGetLastError();
+    }
+    if (err == hipSuccess) err = hipMemcpyAsync(out, d, (size_t)(4 + LOB_FP_BINS) * 8, hipMemcpyDeviceToHost, e->stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+    hipFree(d);
+    HIPCHK(err);
     return LOB_OK;
 }
 

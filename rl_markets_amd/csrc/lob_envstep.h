@@ -186,6 +186,7 @@ __global__ void __launch_bounds__(64) env_step_kernel(const DevParams* __restric
         // on it as in act_kernel (act_book: swap, terminal check, Q(last_state, .), policy, header, tile marks)
         u64 todo = __ballot(valid && alive && open && !ok);
         if (todo) {
+            if (threadIdx.x == 0) atomicAdd((u64*)&S.counters[2], (u64)__builtin_popcountll(todo));  // (lob_get_path_stats [6])
             const uint4* src = reinterpret_cast<const uint4*>(rnd_g);
             uint4* dst = reinterpret_cast<uint4*>(lds_learn.rnd);
             for (int i = threadIdx.x; i < 512; i += 64) dst[i] = src[i];

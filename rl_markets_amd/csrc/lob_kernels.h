@@ -1070,6 +1070,7 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_q_rest_kernel(DevParams P, De
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     learn_stage_table(rnd_g, L);
     const int n = *list_n;
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd((u64*)&S.counters[4], (u64)n);  // (lob_get_path_stats [7])
 #pragma unroll 1
     for (int i = __builtin_amdgcn_readfirstlane(blockIdx.x * LOB_WAVES_PER_BLOCK + w); i < n; i += gridDim.x * LOB_WAVES_PER_BLOCK)
         learn_q_book<ALGO>(P, S, L, w, lane, __builtin_amdgcn_readfirstlane(list[i]));
@@ -1918,6 +1919,39 @@ __global__ void dump_kernel(const DevParams* __restrict__ Pp, DevState S, int fi
     }
     d.n_traces = n_tr;
     out[t] = d;
+}
+
+// Diagnostics of the fast path (lob_debug_fastpath; not on the step): how many weights the exact written-weights map shows,
+// and the distribution of the live books' hit-list lengths.  out: [0] written weights, [1] live books, [2] live books without a
+// list, [3] sum of the lengths, [4 + n] books whose list has n entries (n = LOB_FP_BINS - 1: that many or more).
+#define LOB_FP_BINS 257
+__global__ void fastpath_stats_kernel(DevState S, i64 M, int have_lists, i64* out) {
+    __shared__ i32 hist[LOB_FP_BINS];
+    __shared__ i32 s_none, s_live;
+    __shared__ i64 s_sum, s_pop;
+    for (int i = threadIdx.x; i < LOB_FP_BINS; i += blockDim.x) hist[i] = 0;
+    if (threadIdx.x == 0) { s_none = 0; s_live = 0; s_sum = 0; s_pop = 0; }
+    __syncthreads();
+    const i64 words = M / 32 + 1;
+    i64 pop = 0;
+    if (S.theta_nzx)
+        for (i64 w = (i64)blockIdx.x * blockDim.x + threadIdx.x; w < words; w += (i64)gridDim.x * blockDim.x) pop += __popc(S.theta_nzx[w]);
+    if (pop) atomicAdd((u64*)&s_pop, (u64)pop);
+    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < S.B; b += gridDim.x * blockDim.x) {
+        if (S.hdr[b].done) continue;
+        atomicAdd(&s_live, 1);
+        if (!have_lists) continue;
+        const u64 n = S.hl_rec[(size_t)b * LOB_HL_REC];
+        if (n == ~0ull) { atomicAdd(&s_none, 1); continue; }
+        atomicAdd(&hist[n < LOB_FP_BINS - 1 ? (int)n : LOB_FP_BINS - 1], 1);
+        atomicAdd((u64*)&s_sum, n);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < LOB_FP_BINS; i += blockDim.x) if (hist[i]) atomicAdd((u64*)&out[4 + i], (u64)hist[i]);
+    if (threadIdx.x == 0) {
+        atomicAdd((u64*)&out[0], (u64)s_pop); atomicAdd((u64*)&out[1], (u64)s_live);
+        atomicAdd((u64*)&out[2], (u64)s_none); atomicAdd((u64*)&out[3], (u64)s_sum);
+    }
 }
 
 #endif

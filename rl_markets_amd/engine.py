@@ -253,6 +253,23 @@ class Engine:
         self._check(self.lib.lob_get_path_stats(self.h, _ptr(c)))
         return c
 
+    def fastpath_stats(self):
+        """lob_debug_fastpath (a diagnostic export, not in include/lob_engine.h): written weights and the live books' hit-list lengths."""
+        n = 4 + 257
+        c = np.zeros(n, np.int64)
+        fn = self.lib.lob_debug_fastpath
+        fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]
+        self._check(fn(self.h, _ptr(c), n))
+        hist = c[4:]
+        with_list = int(hist.sum())
+        cum = np.cumsum(hist)
+        def pct(q):
+            return int(np.searchsorted(cum, q * with_list)) if with_list else None
+        return {"written_weights": int(c[0]), "live_books": int(c[1]), "books_without_list": int(c[2]),
+                "list_len_mean": round(float(c[3]) / with_list, 2) if with_list else None,
+                "list_len_p50": pct(0.5), "list_len_p99": pct(0.99), "list_len_max": int(np.nonzero(hist)[0].max()) if with_list else None,
+                "hist": hist}
+
     # ---- multi-GPU weight exchange ----
     def delta_init(self):
         self._check(self.lib.lob_delta_init(self.h))
