@@ -69,6 +69,16 @@ LOB_HD void drec_from_abi(const uint32_t* src, int D, int T, uint32_t* dst) {
 // compiler waits for everything in flight at the join), and these kernels are chains of memory round trips.  For D <= 8 the
 // last quad lies in the next array of the record, after the last array in the trade slots / the next record: read and
 // masked out (the stream buffer is allocated with a tail pad, lob_engine.hip set_records).
+#define LOB_LEVEL_QUADS ((LOB_MAX_DEPTH + 3) / 4)
+__device__ inline void drec_unpack(const uint4* v, int D, uint32_t* out) {
+#pragma unroll
+    for (int q = 0; q < LOB_LEVEL_QUADS; q++) {
+        if (q * 4 + 0 < LOB_MAX_DEPTH) out[q * 4 + 0] = q * 4 + 0 < D ? v[q].x : 0u;
+        if (q * 4 + 1 < LOB_MAX_DEPTH) out[q * 4 + 1] = q * 4 + 1 < D ? v[q].y : 0u;
+        if (q * 4 + 2 < LOB_MAX_DEPTH) out[q * 4 + 2] = q * 4 + 2 < D ? v[q].z : 0u;
+        if (q * 4 + 3 < LOB_MAX_DEPTH) out[q * 4 + 3] = q * 4 + 3 < D ? v[q].w : 0u;
+    }
+}
 __device__ inline void drec_levels(const uint32_t* arr, int D, uint32_t* out) {
     const uint4* a4 = reinterpret_cast<const uint4*>(arr);
     uint4 v[(LOB_MAX_DEPTH + 3) / 4];
@@ -768,6 +778,41 @@ __device__ inline void update_order(const EnvCtx& c, EnvR& e, int side, i64 lv, 
 // yet, merged per 1e-4 price key.  Rows carry the trades of their own interval,
 // so an event whose predecessor swallowed several rows (same timestamp, invalid
 // states) merges the slots of rows lo..hi; normally lo == hi.
+// (merge_trade_slots: one record's trade slots -- `w4`: its (price, volume) pairs as loaded -- merged into the list tp / tv of n entries)
+template <int TM>
+__device__ inline void merge_trade_slots(const EnvCtx& c, const uint4* w4, int& n, f64* tp, i64* tv) {
+    const DevParams& P = c.P;
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        if (i >= P.T) continue;
+        const uint4 w = w4[i >> 1];
+        f32 p = __uint_as_float((i & 1) ? w.z : w.x);
+        i32 v = (i32)((i & 1) ? w.w : w.y);
+        if (!((p > 0.0f) && (v > 0))) continue;
+        const f64 pd = (f64)p, k = key4(pd);
+        // std::map<double,long,FloatComparator>::operator[] += : find the key or insert in order
+        int pos = 0;
+        bool found = false;
+#pragma unroll
+        for (int q = 0; q < TM; q++) {
+            if (q < n) {
+                const f64 kq = key4(tp[q]);
+                if (kq == k) { tv[q] += (i64)v; found = true; }
+                if (kq < k) pos = q + 1;
+            }
+        }
+        if (found) continue;
+        if (n >= P.T) { c.err(LOB_ERR_TRADE_OVERFLOW); continue; }
+#pragma unroll
+        for (int q = TM - 1; q > 0; q--) {
+            if (q > pos && q <= n) { tp[q] = tp[q - 1]; tv[q] = tv[q - 1]; }
+        }
+#pragma unroll
+        for (int q = 0; q < TM; q++)
+            if (q == pos) { tp[q] = pd; tv[q] = (i64)v; }
+        n++;
+    }
+}
 template <int TM>
 __device__ inline void load_trades(const EnvCtx& c, int lo, int hi, f64* tp, i64* tv) {
     const DevParams& P = c.P;
@@ -779,36 +824,7 @@ __device__ inline void load_trades(const EnvCtx& c, int lo, int hi, f64* tp, i64
         uint4 w4[(TM + 1) / 2];
 #pragma unroll
         for (int q = 0; q < (TM + 1) / 2; q++) w4[q] = 2 * q < P.T ? r4[q] : make_uint4(0, 0, 0, 0);  // wave-uniform; the pad reads as "no trade"
-#pragma unroll
-        for (int i = 0; i < TM; i++) {
-            if (i >= P.T) continue;
-            const uint4 w = w4[i >> 1];
-            f32 p = __uint_as_float((i & 1) ? w.z : w.x);
-            i32 v = (i32)((i & 1) ? w.w : w.y);
-            if (!((p > 0.0f) && (v > 0))) continue;
-            const f64 pd = (f64)p, k = key4(pd);
-            // std::map<double,long,FloatComparator>::operator[] += : find the key or insert in order
-            int pos = 0;
-            bool found = false;
-#pragma unroll
-            for (int q = 0; q < TM; q++) {
-                if (q < n) {
-                    const f64 kq = key4(tp[q]);
-                    if (kq == k) { tv[q] += (i64)v; found = true; }
-                    if (kq < k) pos = q + 1;
-                }
-            }
-            if (found) continue;
-            if (n >= P.T) { c.err(LOB_ERR_TRADE_OVERFLOW); continue; }
-#pragma unroll
-            for (int q = TM - 1; q > 0; q--) {
-                if (q > pos && q <= n) { tp[q] = tp[q - 1]; tv[q] = tv[q - 1]; }
-            }
-#pragma unroll
-            for (int q = 0; q < TM; q++)
-                if (q == pos) { tp[q] = pd; tv[q] = (i64)v; }
-            n++;
-        }
+        merge_trade_slots<TM>(c, w4, n, tp, tv);
     }
 }
 
@@ -1379,6 +1395,8 @@ __device__ inline f64 ulb(f64 val, f64 lb, f64 ub) {
 }
 
 // Book::ApplyChanges (book.cpp:64-99) without the order part.
+// (mk_apply_levels: the same on a row whose level arrays are in registers already)
+__device__ inline void mk_apply_levels(const EnvCtx& c, MarketR& m, int rec, i32 time_ms, const uint32_t* wpa, const uint32_t* wva, const uint32_t* wpb, const uint32_t* wvb);
 __device__ inline void mk_apply_row(const EnvCtx& c, MarketR& m, int rec) {
     const DevParams& P = c.P;
     const uint32_t* r = c.row(rec);
@@ -1388,6 +1406,10 @@ __device__ inline void mk_apply_row(const EnvCtx& c, MarketR& m, int rec) {
     drec_levels(r + drec_ask_vol(P.D, P.T), P.D, wva);
     drec_levels(r + drec_bid_px(P.D, P.T), P.D, wpb);
     drec_levels(r + drec_bid_vol(P.D, P.T), P.D, wvb);
+    mk_apply_levels(c, m, rec, (i32)r[LOB_REC_TIME], wpa, wva, wpb, wvb);
+}
+__device__ inline void mk_apply_levels(const EnvCtx& c, MarketR& m, int rec, i32 time_ms, const uint32_t* wpa, const uint32_t* wva, const uint32_t* wpb, const uint32_t* wvb) {
+    const DevParams& P = c.P;
     f32 pa[LOB_MAX_DEPTH], pb[LOB_MAX_DEPTH];
     i32 va[LOB_MAX_DEPTH], vb[LOB_MAX_DEPTH];
 #pragma unroll
@@ -1411,7 +1433,72 @@ __device__ inline void mk_apply_row(const EnvCtx& c, MarketR& m, int rec) {
     m.ap0 = (f64)pa[0];
     m.bp0 = (f64)pb[0];
     m.rec_cur = rec;
-    m.time_ms = (i32)r[LOB_REC_TIME];
+    m.time_ms = time_ms;
+}
+
+// One record of the stream in registers (the pre-pass keeps the row it is about to apply and the one after it there: every
+// book advances event by event, so the addresses are known an event ahead and no load is waited for where it is issued).
+template <int TM>
+struct PreRow {
+    uint4 hdr;                          // time, flags
+    uint4 lv[4][LOB_LEVEL_QUADS];       // ask px, ask vol, bid px, bid vol
+    uint4 tr[(TM + 1) / 2];             // (price, volume) pairs
+};
+template <int TM>
+__device__ inline void pre_row_issue(const EnvCtx& c, int rec, PreRow<TM>& R) {
+    const DevParams& P = c.P;
+    const int last = c.S.n_events - 1;
+    const uint4* r4 = reinterpret_cast<const uint4*>(c.row(rec < last ? rec : last));  // (past the stream: the last row again, never looked at)
+    const int d4 = drec_pad4(P.D) / 4;
+    R.hdr = r4[0];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int q = 0; q < LOB_LEVEL_QUADS; q++) R.lv[a][q] = r4[1 + a * d4 + q];
+#pragma unroll
+    for (int q = 0; q < (TM + 1) / 2; q++) R.tr[q] = 2 * q < P.T ? r4[1 + 4 * d4 + q] : make_uint4(0, 0, 0, 0);
+}
+__device__ inline i32 pre_row_time(const EnvCtx& c, int rec) {
+    const int last = c.S.n_events - 1;
+    return (i32)c.row(rec < last ? rec : last)[LOB_REC_TIME];
+}
+// Intraday::UpdateBookProfiles as mk_update_book_profiles, the first row it applies taken from registers (`R0` = row m.cursor,
+// `t1` = the time of the row after it); further rows of the event (same timestamp, invalid states) come from memory.
+template <int TM>
+__device__ inline bool mk_update_book_profiles_pre(const EnvCtx& c, MarketR& m, const PreRow<TM>& R0, i32 t1) {
+    { int t = m.rec_cur; m.rec_cur = m.rec_last; m.rec_last = t; }
+    { f64 t = m.ap0; m.ap0 = m.lap0; m.lap0 = t; }
+    { f64 t = m.bp0; m.bp0 = m.lbp0; m.lbp0 = t; }
+    bool regs = true;
+    while (true) {
+        if (m.cursor + 1 >= c.S.n_events) return false;
+        const int rec = m.cursor;
+        m.cursor++;
+        m.records++;
+        i32 next_time;
+        if (regs) {
+            uint32_t wpa[LOB_MAX_DEPTH], wpb[LOB_MAX_DEPTH], wva[LOB_MAX_DEPTH], wvb[LOB_MAX_DEPTH];
+            drec_unpack(R0.lv[0], c.P.D, wpa); drec_unpack(R0.lv[1], c.P.D, wva);
+            drec_unpack(R0.lv[2], c.P.D, wpb); drec_unpack(R0.lv[3], c.P.D, wvb);
+            mk_apply_levels(c, m, rec, (i32)R0.hdr.x, wpa, wva, wpb, wvb);
+            next_time = t1;
+            regs = false;
+        } else {
+            mk_apply_row(c, m, rec);
+            next_time = (i32)c.row(m.cursor)[LOB_REC_TIME];
+        }
+        if (next_time == m.time_ms) continue;  // !WillTimeChange()
+        // BookUtils::IsValidState (book.cpp:612-625)
+        const f64 mp = (m.ap0 + m.bp0) / 2.0;
+        const bool has_a = key4(m.lap0) != key4(0.0), has_b = key4(m.lbp0) != key4(0.0);
+        bool valid = true;
+        if (has_a && has_b) {
+            const f64 lm = (m.lap0 + m.lbp0) / 2.0;
+            valid = ((m.ap0 - m.bp0) >= 0.0) && (mp > 0.0) && (fabs(mp - lm) < mp);
+        }
+        if (valid) break;
+    }
+    return true;
 }
 
 // Intraday::UpdateBookProfiles (intraday.cpp:275-313), market part.  Returns
@@ -1527,9 +1614,24 @@ __device__ inline void prepass_run(const EnvCtx& c, PrepState& st, BookMeta& M, 
     rm_load(S.f_midprice, b, w_mid); rm_load(S.f_volatility, b, w_vol); rm_load(S.spread_window, b, w_spr);
     rm_load(S.tp_mp, b, w_tp); rm_load(S.f_ask_tx, b, w_atx); rm_load(S.f_bid_tx, b, w_btx);
     acc_load(S.f_vwap_numer, b, w_vn); acc_load(S.f_vwap_denom, b, w_vd);
+    // Software pipeline: every book of the wave goes through its stream event by event, so all addresses of an event are known
+    // one event ahead.  `R0` = the row the event applies first (row m.cursor), `t1` = the time of the row after it; the row of
+    // the NEXT event and the time behind it are requested at the top of this one, the ring slots that fall out of the windows at
+    // the next push right after this event's pushes.  An event that runs through more rows (same timestamp, invalid states)
+    // reads them where it needs them and the pipeline restarts.
+    PreRow<TM> R0, R1;
+    i32 t1 = 0, t2 = 0;
+    bool piped = false;
+    int band_px = 0, band_tk = 0;  // to_ticks_hint: the band of the last price / of the last tick count converted as a price
+    rm_prep(S.f_midprice, B, b, w_mid); rm_prep(S.f_volatility, B, b, w_vol); rm_prep(S.spread_window, B, b, w_spr);
+    rm_prep(S.tp_mp, B, b, w_tp); rm_prep(S.f_ask_tx, B, b, w_atx); rm_prep(S.f_bid_tx, B, b, w_btx);
+    acc_prep(S.f_vwap_numer, B, b, w_vn); acc_prep(S.f_vwap_denom, B, b, w_vd);
     while (!M.complete && k < k_stop) {
         const int first = m.cursor;
-        if (first < c.S.n_events && (c.row(first)[LOB_REC_FLAGS] & LOB_EVT_FLAG_TAS_DRY)) {
+        if (!piped) { pre_row_issue<TM>(c, first, R0); t1 = pre_row_time(c, first + 1); }
+        pre_row_issue<TM>(c, first + 1, R1);
+        t2 = pre_row_time(c, first + 2);
+        if (first < c.S.n_events && (R0.hdr.y & LOB_EVT_FLAG_TAS_DRY)) {
             // the time-and-sales stream has run dry (Streamer::LoadUntil fails, streamer.cpp:61-85): NextState returns
             // false before it touches the books -- out of data with nothing of this event applied (ex_first < 0)
             M.ex_first = -1; M.ex_cur = m.rec_cur; M.ex_last = m.rec_last; M.ex_time = m.time_ms; M.ex_records = 0;
@@ -1538,7 +1640,14 @@ __device__ inline void prepass_run(const EnvCtx& c, PrepState& st, BookMeta& M, 
         }
         f64 tp[TM];
         i64 tv[TM];
-        load_trades<TM>(c, prev_first + 1, first, tp, tv);
+        if (prev_first + 1 == first) {  // (the usual case: the trades of the event's own first row)
+#pragma unroll
+            for (int i = 0; i < TM; i++) { tp[i] = 0.0; tv[i] = 0; }
+            int ntr = 0;
+            merge_trade_slots<TM>(c, R0.tr, ntr, tp, tv);
+        } else {
+            load_trades<TM>(c, prev_first + 1, first, tp, tv);
+        }
         prev_first = first;
         const f64 mp = (m.ap0 + m.bp0) / 2.0;
         // observed transaction value / volume of Ask/BidBook::ApplyTransactions (book.cpp:394-400, 479-485)
@@ -1559,7 +1668,7 @@ __device__ inline void prepass_run(const EnvCtx& c, PrepState& st, BookMeta& M, 
             m.b_obsvol += tv[i];
         }
         const i64 rec0 = m.records;
-        if (!mk_update_book_profiles(c, m)) {
+        if (!mk_update_book_profiles_pre<TM>(c, m, R0, t1)) {
             M.ex_first = first; M.ex_cur = m.rec_cur; M.ex_last = m.rec_last; M.ex_time = m.time_ms;
             M.ex_records = m.records - rec0;
             M.complete = 1;
@@ -1567,13 +1676,10 @@ __device__ inline void prepass_run(const EnvCtx& c, PrepState& st, BookMeta& M, 
         }
         if (m.lap0 == 0.0 || m.lbp0 == 0.0) c.err(LOB_ERR_UNDEF_PRICE);
         const f64 mid = (m.ap0 + m.bp0) / 2.0, lmid = (m.lap0 + m.lbp0) / 2.0;
-        const int tick_ap0 = lobh::to_ticks_t((*c.tk), m.ap0), tick_bp0 = lobh::to_ticks_t((*c.tk), m.bp0);
-        const i64 mpt = (i64)lobh::to_ticks_t((*c.tk), mid);
+        const int tick_ap0 = lobh::to_ticks_hint((*c.tk), m.ap0, band_px), tick_bp0 = lobh::to_ticks_hint((*c.tk), m.bp0, band_px);
+        const i64 mpt = (i64)lobh::to_ticks_hint((*c.tk), mid, band_px);
         const f64 mpm = mid - lmid, sp = m.ap0 - m.bp0;
-        // ten window pushes (intraday.cpp:253-269), batched: the ring slots that fall out are fetched together
-        rm_prep(S.f_midprice, B, b, w_mid); rm_prep(S.f_volatility, B, b, w_vol); rm_prep(S.spread_window, B, b, w_spr);
-        rm_prep(S.tp_mp, B, b, w_tp); rm_prep(S.f_ask_tx, B, b, w_atx); rm_prep(S.f_bid_tx, B, b, w_btx);
-        acc_prep(S.f_vwap_numer, B, b, w_vn); acc_prep(S.f_vwap_denom, B, b, w_vd);
+        // ten window pushes (intraday.cpp:253-269): the ring slots that fall out were fetched an event ago
         rm_apply_reg(S.f_midprice, B, b, w_mid, (f64)mpt);
         rm_apply_reg(S.f_volatility, B, b, w_vol, (f64)mpt);
         acc_apply_reg(S.f_vwap_numer, B, b, w_vn, m.a_obsval + m.b_obsval);
@@ -1596,6 +1702,10 @@ __device__ inline void prepass_run(const EnvCtx& c, PrepState& st, BookMeta& M, 
         }
         rm_apply_reg(S.f_ask_tx, B, b, w_atx, (f64)m.a_obsvol);
         rm_apply_reg(S.f_bid_tx, B, b, w_btx, (f64)m.b_obsvol);
+        // ... and those of the next event's pushes leave now
+        rm_prep(S.f_midprice, B, b, w_mid); rm_prep(S.f_volatility, B, b, w_vol); rm_prep(S.spread_window, B, b, w_spr);
+        rm_prep(S.tp_mp, B, b, w_tp); rm_prep(S.f_ask_tx, B, b, w_atx); rm_prep(S.f_bid_tx, B, b, w_btx);
+        acc_prep(S.f_vwap_numer, B, b, w_vn); acc_prep(S.f_vwap_denom, B, b, w_vd);
 
         if (write_track) {
             Track t;
@@ -1618,8 +1728,9 @@ __device__ inline void prepass_run(const EnvCtx& c, PrepState& st, BookMeta& M, 
                 const f64 front = (f64)mpt;  // just pushed
                 i32 bi = w_mid.head - w_mid.cnt + 1;
                 if (bi < 0) bi += S.f_midprice.w;
-                const f64 back = S.f_midprice.ring[(size_t)bi * B + b];
-                t.mv[LOB_MV_MPM] = (f32)ulb((f64)(lobh::to_ticks_t((*c.tk), front) - lobh::to_ticks_t((*c.tk), back)), -10.0, 10.0);
+                // (a full window's oldest entry is the one the next push replaces: rm_prep has just asked for it)
+                const f64 back = w_mid.cnt == S.f_midprice.w ? w_mid.old : S.f_midprice.ring[(size_t)bi * B + b];
+                t.mv[LOB_MV_MPM] = (f32)ulb((f64)(lobh::to_ticks_hint((*c.tk), front, band_tk) - lobh::to_ticks_hint((*c.tk), back, band_tk)), -10.0, 10.0);
             }
             {
                 f64 v_a = (f64)m.a_tv, v_b = (f64)m.b_tv;
@@ -1647,6 +1758,8 @@ __device__ inline void prepass_run(const EnvCtx& c, PrepState& st, BookMeta& M, 
         // more than one depth row, the trades up to the last of them are dropped, not handed to the next event
         if (k + 1 == M.k_warm) prev_first = m.rec_cur;
         k++;
+        piped = m.cursor == first + 1;  // one row applied: what was requested at the top is what the next event starts with
+        if (piped) { R0 = R1; t1 = t2; }
     }
     rm_store(S.f_midprice, b, w_mid); rm_store(S.f_volatility, b, w_vol); rm_store(S.spread_window, b, w_spr);
     rm_store(S.tp_mp, b, w_tp); rm_store(S.f_ask_tx, b, w_atx); rm_store(S.f_bid_tx, b, w_btx);

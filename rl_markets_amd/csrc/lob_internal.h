@@ -85,6 +85,40 @@ template <class TT> LOB_HD int to_ticks_t(const TT& t, double price) {
     return ticks;
 }
 
+// to_ticks_t with the band search replaced by a check of `hint` (the band the caller's previous price fell in; prices of one
+// book stay in one band for hours) and the loop's first iteration written out: the same operations on the same operands.
+// i0 = h exactly when (h == 0 or lb[h] <= price) and (h is the last band or not lb[h + 1] <= price), the lower bounds being
+// strictly ascending (std::map keys); a NaN price fails the first test unless h == 0, where the search would also leave 0.
+template <class TT> LOB_HD int to_ticks_hint(const TT& t, double price, int& hint) {
+    int i0 = hint;
+    const bool ok = (i0 == 0 || t.lb[i0] <= price) && (i0 + 1 >= t.n || !(t.lb[i0 + 1] <= price));
+    if (!ok) {
+        i0 = 0;
+        for (int i = 1; i < t.n; i++)
+            if (t.lb[i] <= price) i0 = i;
+        hint = i0;
+    }
+    const double tk0 = t.tick[i0], lb0 = t.lb[i0];
+    const double half = tk0 / 2.0;
+    int ticks = t.pt[i0];
+    if (!(price + tk0 / 2.0 > lb0)) return ticks;
+    {
+        double ub;
+        if (i0 == t.n - 1 || price < t.lb[i0 + 1]) ub = price + half;
+        else ub = t.lb[i0 + 1];
+        ticks = (int)((double)ticks + (ub - lb0) / tk0);
+    }
+    for (int i = i0 + 1; i < t.n; i++) {  // (entered only by a price within half a tick of the next band)
+        const double lb = t.lb[i], tk = t.tick[i];
+        if (!(price + tk / 2.0 > lb)) break;
+        double ub;
+        if (i == t.n - 1 || price < t.lb[i + 1]) ub = price + half;
+        else ub = t.lb[i + 1];
+        ticks = (int)((double)ticks + (ub - lb) / tk);
+    }
+    return ticks;
+}
+
 template <class TT> LOB_HD double to_price_t(const TT& t, int ticks) {
     // same idea: bands whose upper tick count is <= ticks are full, start after them
     int i0 = 0;

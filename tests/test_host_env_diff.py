@@ -65,3 +65,15 @@ def test_tile_registry_flags_every_shared_index(tmp_path):
     out = subprocess.run([exe, os.environ.get("LOB_REGISTRY_DIFF_TRIALS", "40")], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout[-2000:]
     assert "registry_diff OK" in out.stdout
+
+
+def test_ticks_hint_equals_to_ticks(tmp_path):
+    """The pre-pass converts five prices per event with lobh::to_ticks_hint (band hint instead of the band search, the loop's first
+    iteration written out).  tests/host_env/ticks_diff.cpp: against lobh::to_ticks_t -- the restatement of Market::ToTicks pinned
+    on the reference's known answers -- on all 14 venue tables, band boundaries +- fractions of a tick, float32 prices, tick
+    counts used as prices, non-finite inputs, for every possible hint."""
+    exe = str(tmp_path / "ticks_diff")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-o", exe, os.path.join(ROOT, "tests", "host_env", "ticks_diff.cpp"),
+                           os.path.join(ROOT, "rl_markets_amd", "csrc", "lob_host.cpp")])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "ticks_diff OK" in out.stdout, out.stdout[-1500:]
