@@ -345,7 +345,20 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     { const char* nc = getenv("LOB_NO_COMBINE"); P.combine = !P.theta_private && !(nc && nc[0] == '1'); }
     {   // group-0 memo: shared theta, one weight vector, one book group
         const char* nc = getenv("LOB_NO_MEMO");
-        P.memo = !P.theta_private && P.algo != LOB_ALGO_DOUBLE_Q && !P.r_learn && e->n_groups == 1 && !(nc && nc[0] == '1');
+        P.memo = !P.theta_private && !P.r_learn && e->n_groups == 1 && !(nc && nc[0] == '1');
+        const bool dq = P.algo == LOB_ALGO_DOUBLE_Q;
+        if (dq && P.memo) {
+            // DoubleQLearn on the fast path: through the kernels that know two weight vectors -- env_step_kernel<., true> (two trade
+            // slots), learn_q_lane_kernel<LOB_ALGO_DOUBLE_Q> with the fused Watkins trace step (a lane per book: big batches, or
+            // LOB_Q_LANES=1), the lane trace kernel behind it.  Anything else: the general kernels, as before.
+            hipDeviceProp_t prop;
+            int n_cus = e->n_cus;
+            if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) n_cus = prop.multiProcessorCount;
+            const bool q_lanes = e->q_lanes >= 0 ? e->q_lanes == 1 : (long long)n_books >= (long long)LOB_QL_BLOCK * n_cus / 2;
+            const char* dqf = getenv("LOB_DQ_FAST");
+            P.memo = q_lanes && e->t_light && !e->no_fuse && e->light && e->fuse_act && e->env_step && e->env_lanes == 0 && P.T <= 2 && P.combine &&
+                     P.trace_gens == 32 && (n_books >= 1024 || e->force_fuse_act) && !(dqf && dqf[0] == '0');
+        }
         // the memo path never reads the carry-over filter, and its hot counter serialises first writes
         if (P.memo) P.carry_verdicts = 0;
         // SARSA(lambda): the trace step with a lane per generation (trace_sarsa_kernel, lob_fast.h) + the tile registry it needs
@@ -354,7 +367,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
         const char* sl = getenv("LOB_SARSA_LANES");
         const char* tl = getenv("LOB_TRACE_LANES");
         bool lanes_ok = P.memo && P.combine && P.trace_gens == 32 && !(sl && sl[0] == '0') && !(tl && tl[0] == '0');
-        if (lanes_ok && P.algo == LOB_ALGO_QLAMBDA) {
+        if (lanes_ok && (P.algo == LOB_ALGO_QLAMBDA || dq)) {
             hipDeviceProp_t prop;
             int n_cus = e->n_cus;
             if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) n_cus = prop.multiProcessorCount;
@@ -460,6 +473,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
         if (rc == LOB_OK) rc = dev_alloc(e, &S.mk_list, 2 * ms);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.mk_count, 2);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.mk_rec, 2 * ms * LOB_MK_REC);
+        if (P.memo && P.algo == LOB_ALGO_DOUBLE_Q && rc == LOB_OK) rc = dev_alloc(e, &S.mk_rec_b, 2 * ms * LOB_MK_REC);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.mk_tiles, P.memo ? ms * LOB_N_ACTIONS * 32 : 1);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.mk_tiles_ok, ms);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.mk_marked, ms);
@@ -523,6 +537,8 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
             if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_lane_kernel<LOB_ALGO_QLAMBDA, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ql_lds);
             if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_lane_kernel<LOB_ALGO_QLAMBDA, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ql_lds);
             if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_lane_kernel<LOB_ALGO_QLAMBDA, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ql_lds);
+            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_lane_kernel<LOB_ALGO_DOUBLE_Q, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ql_lds);
+            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_lane_kernel<LOB_ALGO_DOUBLE_Q, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ql_lds);
             const int qp_lds = (int)qpair_lds_bytes(P.cwords4);
             if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_pair_kernel<LOB_ALGO_SARSA, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, qp_lds);
             if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_pair_kernel<LOB_ALGO_QLAMBDA, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, qp_lds);
@@ -779,9 +795,12 @@ static void launch_env_fused(lob_engine* e, hipStream_t st, int par, int lpar, u
     // the work list to the general act kernel and env_kernel<64, 2, 2> as before (either version is correct for any step).
     const bool inline_general = t2 && e->env_step && e->inline_general && e->steps_on_lists >= 1;
     e->steps_on_lists++;
+    const bool dq = e->P.algo == LOB_ALGO_DOUBLE_Q;  // (then t2 && env_step: lob_create)
     {
         TimedLaunch t(e, "env_kernel", st);
-        if (inline_general) hipLaunchKernelGGL(env_step_kernel<true>, dim3((nb + 63) / 64), dim3(64), 0, st, Pd, e->S, sid, par, F1, (const uint32_t*)e->rnd_dev);
+        if (inline_general && dq) hipLaunchKernelGGL((env_step_kernel<true, true>), dim3((nb + 63) / 64), dim3(64), 0, st, Pd, e->S, sid, par, F1, (const uint32_t*)e->rnd_dev);
+        else if (dq) hipLaunchKernelGGL((env_step_kernel<false, true>), dim3((nb + 63) / 64), dim3(64), 0, st, Pd, e->S, sid, par, F1, (const uint32_t*)e->rnd_dev);
+        else if (inline_general) hipLaunchKernelGGL(env_step_kernel<true>, dim3((nb + 63) / 64), dim3(64), 0, st, Pd, e->S, sid, par, F1, (const uint32_t*)e->rnd_dev);
         else if (t2 && e->env_step) hipLaunchKernelGGL(env_step_kernel<false>, dim3((nb + 63) / 64), dim3(64), 0, st, Pd, e->S, sid, par, F1, (const uint32_t*)e->rnd_dev);
         else if (t2) hipLaunchKernelGGL((env_kernel<64, 2, 1>), dim3((nb + 63) / 64), dim3(64), 0, st, Pd, e->S, (const i32*)nullptr, 1, 0, nb, sid, par, F1);
         else hipLaunchKernelGGL((env_kernel<64, LOB_MAX_TRADES, 1>), dim3((nb + 63) / 64), dim3(64), 0, st, Pd, e->S, (const i32*)nullptr, 1, 0, nb, sid, par, F1);
@@ -789,7 +808,8 @@ static void launch_env_fused(lob_engine* e, hipStream_t st, int par, int lpar, u
     if (inline_general) return;
     {
         TimedLaunch t(e, "act_rest_kernel", st);
-        hipLaunchKernelGGL((act_kernel<LOB_ALGO_SARSA, true>), dim3(gl), dim3(LOB_BLOCK), 0, st, e->P, e->S, (const uint32_t*)e->rnd_dev, 0, 0, e->B, par, act_list, act_n);
+        if (dq) hipLaunchKernelGGL((act_kernel<LOB_ALGO_DOUBLE_Q, true>), dim3(gl), dim3(LOB_BLOCK), 0, st, e->P, e->S, (const uint32_t*)e->rnd_dev, 0, 0, e->B, par, act_list, act_n);
+        else hipLaunchKernelGGL((act_kernel<LOB_ALGO_SARSA, true>), dim3(gl), dim3(LOB_BLOCK), 0, st, e->P, e->S, (const uint32_t*)e->rnd_dev, 0, 0, e->B, par, act_list, act_n);
     }
     {
         TimedLaunch t(e, "env_rest_kernel", st);
@@ -981,6 +1001,7 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
             HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
         }
         const bool fast = e->P.memo != 0;  // (implies one group)
+        const bool dq = e->P.algo == LOB_ALGO_DOUBLE_Q;  // (fast && dq: every step without usable hit lists takes the general act kernel over the whole batch)
         const int lpar = first ? (e->list_par ^= 1) : e->list_par;
         e->last_par = par;
         if (mode == 0) e->S.cb_par = par;  // (DevState goes to the kernels by value: the launches below see it)
@@ -1001,7 +1022,7 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
             const bool fused_act = fast && mode == 0 && e->hits_ok && e->light && e->fuse_act && e->env_lanes == 0 && (e->B >= 1024 || e->force_fuse_act);
             if (fused_act) {
                 launch_env_fused(e, st, par, lpar, ver, act_list, act_n, gl);
-            } else if (fast) {
+            } else if (fast && !dq) {
                 {
                     TimedLaunch t(e, "act_kernel", st);
                     if (mode == 0 && e->hits_ok && e->light)
@@ -1031,7 +1052,7 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
             // rest by trace_lane_kernel)
             if (mode == 0) { int rc = registry_join(e); if (rc) return rc; }
             if (mode == 0 && fast) {
-                const bool tl = e->P.algo == LOB_ALGO_QLAMBDA && e->t_light;
+                const bool tl = (e->P.algo == LOB_ALGO_QLAMBDA || dq) && e->t_light;
                 // Q(s', .) + TD error: a lane per book once the batch gives every CU a full block of them, else a wave per book
                 const bool lanes = e->q_lanes >= 0 ? e->q_lanes == 1 : nb >= LOB_QL_BLOCK * e->n_cus / 2;
                 // ... and then the lane kernel also takes the trace step of the books it can (those left go on a list for the
@@ -1059,14 +1080,18 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                     TimedLaunch t(e, "learn_kernel", st);
                     if (lanes) {
                         const int gq = std::min(e->n_cus, (nb + LOB_QL_BLOCK - 1) / LOB_QL_BLOCK);
-                        const bool pair = e->q_pair && e->P.M < (1ll << 27);  // (its LDS rows hold tile indices in 27 bits)
+                        const bool pair = e->q_pair && e->P.M < (1ll << 27) && !dq;  // (its LDS rows hold tile indices in 27 bits; one weight vector)
                         const size_t lds = pair ? qpair_lds_bytes(e->P.cwords4) : qlane_lds_bytes(e->P.cwords4);
 #define LOB_QL_LAUNCH(A, VT, TR)                                                                                                                            \
     do {                                                                                                                                                    \
         if (pair) hipLaunchKernelGGL((learn_q_pair_kernel<A, VT, TR>), dim3(gq), dim3(LOB_QP_BLOCK), lds, st, e->P, e->S, rnd, lpar, ver, sid);             \
         else hipLaunchKernelGGL((learn_q_lane_kernel<A, VT, TR>), dim3(gq), dim3(LOB_QL_BLOCK), lds, st, e->P, e->S, rnd, lpar, ver, sid);                  \
     } while (0)
-                        if (fuse) { if (e->P.V == 8) LOB_QL_LAUNCH(LOB_ALGO_QLAMBDA, 8, true); else LOB_QL_LAUNCH(LOB_ALGO_QLAMBDA, 0, true); }
+                        if (dq) {  // (lob_create: only with the fused trace step)
+                            if (e->P.V == 8) hipLaunchKernelGGL((learn_q_lane_kernel<LOB_ALGO_DOUBLE_Q, 8, true>), dim3(gq), dim3(LOB_QL_BLOCK), lds, st, e->P, e->S, rnd, lpar, ver, sid);
+                            else hipLaunchKernelGGL((learn_q_lane_kernel<LOB_ALGO_DOUBLE_Q, 0, true>), dim3(gq), dim3(LOB_QL_BLOCK), lds, st, e->P, e->S, rnd, lpar, ver, sid);
+                        }
+                        else if (fuse) { if (e->P.V == 8) LOB_QL_LAUNCH(LOB_ALGO_QLAMBDA, 8, true); else LOB_QL_LAUNCH(LOB_ALGO_QLAMBDA, 0, true); }
                         else if (e->P.algo == LOB_ALGO_QLAMBDA) { if (e->P.V == 8) LOB_QL_LAUNCH(LOB_ALGO_QLAMBDA, 8, false); else LOB_QL_LAUNCH(LOB_ALGO_QLAMBDA, 0, false); }
                         else { if (e->P.V == 8) LOB_QL_LAUNCH(LOB_ALGO_SARSA, 8, false); else LOB_QL_LAUNCH(LOB_ALGO_SARSA, 0, false); }
 #undef LOB_QL_LAUNCH
@@ -1075,7 +1100,8 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                 }
                 {
                     TimedLaunch t(e, "learn_rest_kernel", st);
-                    if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL(learn_q_rest_kernel<LOB_ALGO_QLAMBDA>, dim3(gl), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, learn_list, learn_n);
+                    if (dq) hipLaunchKernelGGL(learn_q_rest_kernel<LOB_ALGO_DOUBLE_Q>, dim3(gl), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, learn_list, learn_n);
+                    else if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL(learn_q_rest_kernel<LOB_ALGO_QLAMBDA>, dim3(gl), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, learn_list, learn_n);
                     else hipLaunchKernelGGL(learn_q_rest_kernel<LOB_ALGO_SARSA>, dim3(gl), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, learn_list, learn_n);
                 }
                 if (e->P.sarsa_lanes && !e->reg_fork_late) { int rc = registry_fork(e, st, rnd, par); if (rc) return rc; }
@@ -1237,7 +1263,7 @@ int lob_theta_set(lob_engine* e, int32_t which, const double* host_in, int64_t c
     e->theta_ver++;  // memo records computed under the old weights are void
     e->hits_ok = false;
     hipLaunchKernelGGL(rebuild_nz_kernel, dim3(1024), dim3(256), 0, e->stream, (const f64*)th, nz, e->S.nz_epoch, e->P.M);
-    if (e->P.memo && th == e->S.theta) {
+    if (e->P.memo && (th == e->S.theta || th == e->S.theta_b)) {  // (double Q: one pair of maps for both vectors)
         // the maps keep the bits they have (monotone: the tiles of live trace generations stay marked, whatever the
         // loaded value of their weights -- a set bit only means "fetch the weight") and gain those of the loaded non-zeros
         hipLaunchKernelGGL(rebuild_nzx_kernel, dim3(2048), dim3(256), 0, e->stream, (const f64*)th, e->S.theta_nzx, e->S.theta_nzc, e->P.cshift, e->P.M);
@@ -1407,7 +1433,7 @@ int lob_delta_apply(lob_engine* e) {
         TimedLaunch t(e, "delta_apply_kernel", nullptr, true);
         hipLaunchKernelGGL(delta_apply_kernel, dim3(2048), dim3(256), 0, e->stream, v ? e->S.theta_b : e->S.theta, e->S.theta_sync + v * M,
                            (const f64*)(e->S.delta + v * M), v ? e->S.theta_b_nz : e->S.theta_nz, e->S.nz_epoch, e->P.M,
-                           (v == 0 && e->P.memo) ? e->S.theta_nzx : (uint32_t*)nullptr, e->S.theta_nzc, e->P.cshift);
+                           e->P.memo ? e->S.theta_nzx : (uint32_t*)nullptr, e->S.theta_nzc, e->P.cshift);
     }
     if (delta_extra(e))
         hipLaunchKernelGGL(rho_delta_apply_kernel, dim3(1), dim3(1), 0, e->stream, e->S.rho, e->S.theta_sync + M * nv, (const f64*)(e->S.delta + M * nv));
@@ -1418,7 +1444,7 @@ int lob_delta_apply(lob_engine* e) {
 
 // ---- sparse exchange (include/lob_engine.h) ------------------------------------------------------------------------------
 static int64_t spx_words(const lob_engine* e) { return (int64_t)((size_t)e->P.M / 32 + 1); }
-int lob_delta_sparse_supported(lob_engine* e) { return e && e->P.memo && e->S.theta_sync && e->S.theta_nzx ? 1 : 0; }
+int lob_delta_sparse_supported(lob_engine* e) { return e && e->P.memo && e->P.algo != LOB_ALGO_DOUBLE_Q && e->S.theta_sync && e->S.theta_nzx ? 1 : 0; }
 int lob_delta_sparse_maps(lob_engine* e, int32_t world, uint32_t** dev_own, uint32_t** dev_gather, int64_t* words) {
     if (!e || world < 1 || !dev_own || !dev_gather || !words) return LOB_EINVAL;
     if (!lob_delta_sparse_supported(e)) { lob_set_error("lob_delta_sparse_*: needs the shared-theta fast path and lob_delta_init"); return LOB_ESTATE; }

@@ -539,24 +539,25 @@ __device__ inline void place_orders(const EnvCtx& c, EnvR& e, int al, int bl, co
     e.ask_level = al;
     e.bid_level = bl;
     int ta, tb;
+    int band = 0, band_t = 0;  // (to_ticks_hint / to_price_hint: the six conversions of a re-quote fall in one band)
     if (P.quote_mode == LOB_QUOTE_BOOK) {
         const f64 ap0 = (f64)__uint_as_float(cur.apx[0]), bp0 = (f64)__uint_as_float(cur.bpx[0]);
         if (ap0 == 0.0 || bp0 == 0.0) c.err(LOB_ERR_UNDEF_PRICE);
-        ta = lobh::to_ticks_t((*c.tk), ap0) + al;
-        tb = lobh::to_ticks_t((*c.tk), bp0) - bl;
+        ta = lobh::to_ticks_hint((*c.tk), ap0, band) + al;
+        tb = lobh::to_ticks_hint((*c.tk), bp0, band) - bl;
     } else {
         const Track& t = c.pre_prev ? *c.pre_prev : c.track(e.k - 1);
         f64 tp = t.tp_val;
         f64 half = t.spread_mean / 2.0;
         f64 half_spd = 0.0 > half ? 0.0 : half;  // std::max(0.0, x)
-        ta = lobh::to_ticks_t((*c.tk), tp + (f64)al * half_spd);
-        tb = lobh::to_ticks_t((*c.tk), tp - (f64)bl * half_spd);
+        ta = lobh::to_ticks_hint((*c.tk), tp + (f64)al * half_spd, band);
+        tb = lobh::to_ticks_hint((*c.tk), tp - (f64)bl * half_spd, band);
     }
-    e.ask_quote = lobh::to_price_t((*c.tk), ta);
-    e.bid_quote = lobh::to_price_t((*c.tk), tb);
+    e.ask_quote = lobh::to_price_hint((*c.tk), ta, band_t);
+    e.bid_quote = lobh::to_price_hint((*c.tk), tb, band_t);
     // a_dist / b_dist need ToTicks(order price): computed once, here
-    place_one(c, e, 0, e.ask_quote, lobh::to_ticks_t((*c.tk), e.ask_quote), cur);
-    place_one(c, e, 1, e.bid_quote, lobh::to_ticks_t((*c.tk), e.bid_quote), cur);
+    place_one(c, e, 0, e.ask_quote, lobh::to_ticks_hint((*c.tk), e.ask_quote, band), cur);
+    place_one(c, e, 1, e.bid_quote, lobh::to_ticks_hint((*c.tk), e.bid_quote, band), cur);
 }
 __device__ inline void place_orders(const EnvCtx& c, EnvR& e, int al, int bl) {
     RowFull cur;

@@ -38,7 +38,10 @@ __device__ inline Track track_load(const Track* p) {
 // time -- instead of going through the work list to act_kernel + env_kernel<64, 2, 2>: two launches that find their list empty
 // in all but a handful of steps per episode no longer exist.  (false: the work-list version; the engine uses it for the one
 // step per episode in which EVERY book takes the general path.)
-template <bool INLINE_GENERAL>
+// DQ: DoubleQLearn on the fast path (DoubleAgent::action, agent.cpp:196-204): Q_a and Q_b continue from the memo's two records
+// with the same listed additions under theta / theta_b, the policy sees (Q_a + Q_b) / 2, both vectors' values are kept for the
+// learn kernel (qs_last, qs_last_b).
+template <bool INLINE_GENERAL, bool DQ = false>
 __global__ void __launch_bounds__(64) env_step_kernel(const DevParams* __restrict__ Pp, DevState S, int step_id, int par, EnvFuse F, const uint32_t* __restrict__ rnd_g) {
     const DevParams& P = *Pp;
     __shared__ TickLds tick_lds;
@@ -114,6 +117,18 @@ __global__ void __launch_bounds__(64) env_step_kernel(const DevParams* __restric
         wv[i] = 0.0;
         if (ok && i < n_list) wv[i] = S.theta[(uint32_t)LOB_HL_ENT(i)];
     }
+    f64 wvb[DQ ? LOB_HL_CAP : 1];
+    f64 s0b[DQ ? LOB_N_ACTIONS : 1];
+    if (DQ) {
+        const f64* recb = S.mk_rec_b + ((size_t)S.mk_slots + ms) * LOB_MK_REC;  // (written with `rec` by one memo_kernel launch: its version)
+#pragma unroll
+        for (int a = 0; a < LOB_N_ACTIONS; a++) s0b[DQ ? a : 0] = recb[a];
+#pragma unroll
+        for (int i = 0; i < LOB_HL_CAP; i++) {
+            wvb[DQ ? i : 0] = 0.0;
+            if (ok && i < n_list) wvb[DQ ? i : 0] = S.theta_b[(uint32_t)LOB_HL_ENT(i)];
+        }
+    }
     const int kk = k0 > 0 ? k0 : 1;  // (a live book has consumed its warm-up: k0 >= 1)
     const Track tprev = track_load(&c.track(kk - 1));
     Track tcur = track_load(&c.track(k0));
@@ -159,6 +174,27 @@ __global__ void __launch_bounds__(64) env_step_kernel(const DevParams* __restric
                 }
 #pragma unroll
                 for (int a = 0; a < LOB_N_ACTIONS; a++) S.qs_last[(size_t)b * LOB_N_ACTIONS + a] = q[a];
+                if (DQ) {
+                    f64 qb[LOB_N_ACTIONS];
+#pragma unroll
+                    for (int a = 0; a < LOB_N_ACTIONS; a++) qb[a] = s0b[DQ ? a : 0];
+#pragma unroll
+                    for (int i = 0; i < LOB_HL_CAP; i++) {
+                        const u64 ent = LOB_HL_ENT(i);
+                        const f64 v = wvb[DQ ? i : 0];
+                        if (i < n_list && v != 0.0) {
+                            const int a_ = (int)(ent >> 32) & 15;
+                            const f64 x_ = ((ent >> 36) & 1ull ? w2 : w1) * v;
+#pragma unroll
+                            for (int a = 0; a < LOB_N_ACTIONS; a++) qb[a] = a_ == a ? qb[a] + x_ : qb[a];
+                        }
+                    }
+#pragma unroll
+                    for (int a = 0; a < LOB_N_ACTIONS; a++) {
+                        S.qs_last_b[(size_t)b * LOB_N_ACTIONS + a] = qb[a];
+                        q[a] = (q[a] + qb[a]) / 2.0;  // qs[a] = (getQ + getQb) / 2.0f
+                    }
+                }
                 Rng g{P.seed, P.book_id_offset + (u64)b, h0.rng_ctr};
                 action = policy_sample(P, q, false, g);
                 hp->slot_cur = cur_slot;
@@ -197,7 +233,7 @@ __global__ void __launch_bounds__(64) env_step_kernel(const DevParams* __restric
                 todo &= todo - 1;
                 const int b_src = __builtin_amdgcn_readlane(b, src_lane);
                 int act = -1;
-                act_book<LOB_ALGO_SARSA, LearnLds1>(P, S, lds_learn, 0, (int)threadIdx.x, b_src, 0, par, &act);
+                act_book<DQ ? LOB_ALGO_DOUBLE_Q : LOB_ALGO_SARSA, LearnLds1>(P, S, lds_learn, 0, (int)threadIdx.x, b_src, 0, par, &act);
                 if ((int)threadIdx.x == src_lane && act >= 0) { action = act; go = true; }
             }
         }

@@ -1010,8 +1010,10 @@ __device__ __forceinline__ void ql_group(const DevParams& P, const DevState& S, 
 // tile walk, whose arithmetic hides them.
 template <int ALGO, int VT, bool TR>
 __global__ void __launch_bounds__(LOB_QL_BLOCK) learn_q_lane_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g, int lpar, u64 ver, int sid) {
-    static_assert(ALGO == LOB_ALGO_SARSA || ALGO == LOB_ALGO_QLAMBDA, "one weight vector");
-    static_assert(!TR || ALGO == LOB_ALGO_QLAMBDA, "the fused trace step is Watkins's");
+    // (LOB_ALGO_DOUBLE_Q: DoubleQLearn on the fast path -- both weight vectors share the triples, the tiles, the maps and the
+    // hit list; Q_a and Q_b continue from the memo's two records; its trace step is Watkins's, argmax over Q_a)
+    static_assert(!TR || ALGO == LOB_ALGO_QLAMBDA || ALGO == LOB_ALGO_DOUBLE_Q, "the fused trace step is Watkins's");
+    static_assert(ALGO != LOB_ALGO_DOUBLE_Q || TR, "double Q: with the fused trace step only");
     extern __shared__ __align__(16) unsigned char fast_lds_raw[];
     __shared__ u64 claimed[512];  // (as trace_light_kernel)
     uint32_t* rnd = reinterpret_cast<uint32_t*>(fast_lds_raw);
@@ -1169,7 +1171,33 @@ __global__ void __launch_bounds__(LOB_QL_BLOCK) learn_q_lane_kernel(DevParams P,
                 for (int c = 0; c < LOB_N_ACTIONS; c++) qs[c] = a == c ? qs[c] + x : qs[c];
             }
         }
-        learn_delta_single<ALGO>(P, hp, h, qs, q_sa, g, 0);
+        if (ALGO == LOB_ALGO_DOUBLE_Q) {
+            // Q_b(s', .) the same way: the memo's record under theta_b (written by the same memo_kernel launch: same version) + the
+            // same additions with theta_b's weights
+            const f64* recb = S.mk_rec_b + (size_t)ms * LOB_MK_REC;
+            f64 qb[LOB_N_ACTIONS];
+#pragma unroll
+            for (int a = 0; a < LOB_N_ACTIONS; a++) qb[a] = recb[a];
+            for (int i0 = 0; i0 < n; i0 += 4) {
+                u64 ent[4];
+                f64 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) ent[u] = i0 + u < n ? row[1 + i0 + u] : 0ull;
+#pragma unroll
+                for (int u = 0; u < 4; u++) v[u] = i0 + u < n ? S.theta_b[(uint32_t)ent[u]] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (v[u] == 0.0) continue;
+                    const int a = (int)(ent[u] >> 32) & 15;
+                    const f64 x = ((ent[u] >> 36) & 1ull ? w2 : w1) * v[u];
+#pragma unroll
+                    for (int c = 0; c < LOB_N_ACTIONS; c++) qb[c] = a == c ? qb[c] + x : qb[c];
+                }
+            }
+            learn_delta_double<false>(P, S, hp, h, b, qs, qb, q_sa, g, 0, nullptr);
+        } else {
+            learn_delta_single<ALGO == LOB_ALGO_DOUBLE_Q ? LOB_ALGO_SARSA : ALGO>(P, hp, h, qs, q_sa, g, 0);
+        }
         recp[0] = (u64)n;
         for (int i = 0; i < n; i++) recp[1 + i] = row[1 + i];
         cb_claim_finish(S, pend);

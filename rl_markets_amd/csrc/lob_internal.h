@@ -135,6 +135,30 @@ template <class TT> LOB_HD double to_price_t(const TT& t, int ticks) {
     return price;
 }
 
+// to_price_t with the band search replaced by a check of `hint` (see to_ticks_hint): i0 = h exactly when (h == 0 or
+// cum[h] <= ticks) and (h is the last band or not cum[h + 1] <= ticks), the cumulative tick counts being non-decreasing --
+// where two bands share a count the search keeps the LAST of them, so a hint is only accepted when the band after it starts
+// strictly above `ticks`.
+template <class TT> LOB_HD double to_price_hint(const TT& t, int ticks, int& hint) {
+    int i0 = hint;
+    const bool ok = (i0 == 0 || t.cum[i0] <= (int64_t)ticks) && (i0 + 1 >= t.n || !(t.cum[i0 + 1] <= (int64_t)ticks));
+    if (!ok) {
+        i0 = 0;
+        for (int i = 1; i < t.n; i++)
+            if (t.cum[i] <= (int64_t)ticks) i0 = i;
+        hint = i0;
+    }
+    double price = t.pp[i0];
+    for (int i = i0; i < t.n; i++) {
+        if (!((int64_t)ticks > t.cum[i])) break;
+        double ub;
+        if (i == t.n - 1 || (int64_t)ticks < t.cum[i + 1]) ub = (double)ticks;
+        else ub = (double)t.cum[i + 1];
+        price += (ub - (double)t.cum[i]) * t.tick[i];
+    }
+    return price;
+}
+
 inline double tick_size(const lob_market& m, double price) {
     TickTable t;
     build_tick_table(m, t);

@@ -1044,9 +1044,52 @@ __device__ __forceinline__ void learn_book(const DevParams& P, const DevState& S
 // The second half of learn_book alone, for the books the fast path's learn_q kernel hands back: its trace
 // kernel has already run UpdateTraces for them, left Q(s, a) in LHdr::td and the RNG counter after the
 // trace step's draws in LHdr::rng_ctr.
+// DoubleQLearn::UpdateWeights (agent.cpp:329-353) once Q(to_state, .) is known under both vectors: the coin of the agent's own
+// std::mt19937_64, the TD error against the other vector's value at this vector's argmax, the header stores.  `q_sa` = Q_a(from, a).
+// WAVE: one wave per book (the 312-word block is regenerated by the wave through `lds`); else one LANE per book (every lane its
+// own book: the block is regenerated in place, once per 312 steps).
+__device__ inline void mt64_twist_lane(u64* x) {
+    for (int i = 0; i < LOB_MT_M; i++) x[i] = mt64_mix(x[i], x[i + 1], x[i + LOB_MT_M]);
+    for (int i = LOB_MT_M; i < LOB_MT_N - 1; i++) x[i] = mt64_mix(x[i], x[i + 1], x[i - LOB_MT_M]);
+    x[LOB_MT_N - 1] = mt64_mix(x[LOB_MT_N - 1], x[0], x[LOB_MT_M - 1]);
+}
+template <bool WAVE>
+__device__ __forceinline__ void learn_delta_double(const DevParams& P, const DevState& S, LHdr* hp, const LHdr& h, int b, const f64* qs_to, const f64* qb_to,
+                                                   f64 q_sa, Rng& g, int lane, u64* lds) {
+    const f64 reward = h.reward;
+    const f64 F_term = P.gamma * 0.0 - 0.0;  // potentials are identically 0 (base.cpp:239-242)
+    const int action = h.action;
+    u64* mt = S.mt_state + (size_t)b * LOB_MT_N;
+    int mi = S.mt_idx[b];
+    if (mi >= LOB_MT_N) {
+        if (WAVE) mt64_twist_wave(mt, lds, lane);
+        else mt64_twist_lane(mt);
+        mi = 0;
+    }
+    const f64 coin = mt64_canonical(mt64_temper(mt[mi]));
+    if (lane == 0) S.mt_idx[b] = mi + 1;
+    f64 delta;
+    int target = 1;
+    if (coin > 0.5) {  // UPDATE(A)
+        const int am = argmax_ties(qs_to, g);
+        delta = reward + F_term + P.gamma * sel9(qb_to, am) - q_sa;
+    } else {           // UPDATE(B)
+        f64 qb_last[LOB_N_ACTIONS];
+#pragma unroll
+        for (int a = 0; a < LOB_N_ACTIONS; a++) qb_last[a] = S.qs_last_b[(size_t)b * LOB_N_ACTIONS + a];
+        const int am = argmax_ties(qb_to, g);
+        delta = reward + F_term + P.gamma * sel9(qs_to, am) - sel9(qb_last, action);
+        target = 2;
+    }
+    if (lane == 0) {
+        if (target == 2) hp->stepped = 2;  // the update scatters into theta_b
+        hp->td = delta;
+        hp->upd = P.alpha * delta;
+        hp->rng_ctr = g.ctr;
+    }
+}
 template <int ALGO>
 __device__ __forceinline__ void learn_q_book(const DevParams& P, const DevState& S, LearnLds& L, int w, int lane, int b) {
-    static_assert(ALGO != LOB_ALGO_DOUBLE_Q, "one weight vector");
     const LHdr h = S.hdr[b];
     if (!h.stepped) return;
     learn_stage_vars(S.vars + (size_t)b * 48, &L.vars[w][0][0], lane);
@@ -1060,7 +1103,15 @@ __device__ __forceinline__ void learn_q_book(const DevParams& P, const DevState&
     q_values(P, S.theta, S.theta_nz, L.vars[w][cur], false, L.rnd, L.act_terms, L.vals[w], lane, qs_to, 1, &my_vd);
     vd[lane] = (uint16_t)my_vd;
     if (lane == 0) *(u64*)(vd + 64) = vd_tag(ep, cur);
-    learn_delta_single<ALGO>(P, hp, h, qs_to, h.td, g, lane);
+    if (ALGO == LOB_ALGO_DOUBLE_Q) {
+        f64 qb_to[LOB_N_ACTIONS];
+        uint32_t my_vd_b = 0;
+        q_values(P, S.theta_b, S.theta_b_nz, L.vars[w][cur], false, L.rnd, L.act_terms, L.vals[w], lane, qb_to, 1, &my_vd_b);
+        S.verdict_b[(size_t)b * 64 + lane] = (uint16_t)my_vd_b;
+        learn_delta_double<true>(P, S, hp, h, b, qs_to, qb_to, h.td, g, lane, reinterpret_cast<u64*>(L.vals[w]));
+    } else {
+        learn_delta_single<ALGO == LOB_ALGO_DOUBLE_Q ? LOB_ALGO_SARSA : ALGO>(P, hp, h, qs_to, h.td, g, lane);
+    }
 }
 template <int ALGO>
 __global__ void __launch_bounds__(LOB_BLOCK) learn_q_rest_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g,
@@ -1136,7 +1187,7 @@ __global__ void __launch_bounds__(LOB_BLOCK) update_kernel(DevParams P, DevState
                 const f64 val = scaled * (f64)P.trace_pow[c0 + 2 * it + half];
                 __hip_atomic_fetch_add(&theta[f[it]], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 word[it] = nz[LOB_NZ_WORD(f[it])];
-                if (P.memo && h.stepped != 2) nzx_mark_late(P, S, f[it], sid);
+                if (P.memo) nzx_mark_late(P, S, f[it], sid);
             }
         }
 #pragma unroll
@@ -1332,7 +1383,7 @@ __global__ void __launch_bounds__(LOB_BLOCK) accumulate_kernel(DevParams P, DevS
             if (lane < 32 && ((m >> j) & 1u)) {
                 const i32 f = S.tr_idx[((size_t)d_b * G + sl) * 32 + j];
                 __hip_atomic_fetch_add(&theta[f], d_scaled * (f64)P.trace_pow[d_age], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (P.memo && !d_t) nzx_mark_late(P, S, f, sid);
+                if (P.memo) nzx_mark_late(P, S, f, sid);  // (one map for both weight vectors of double Q: written in either)
                 const uint32_t bit = LOB_NZ_BIT(f);
                 if (!(nz[LOB_NZ_WORD(f)] & bit)) {
                     const uint32_t old = atomicOr(&nz[LOB_NZ_WORD(f)], bit);
@@ -1413,7 +1464,7 @@ __global__ void __launch_bounds__(256) apply_kernel(DevParams P, DevState S, con
             f64* theta = t ? S.theta_b : S.theta;
             uint32_t* nz = t ? S.theta_b_nz : S.theta_nz;
             __hip_atomic_fetch_add(&theta[f], t ? v1 : v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (P.memo && !t) nzx_mark_late(P, S, f, sid);
+            if (P.memo) nzx_mark_late(P, S, f, sid);  // (one map for both weight vectors of double Q: written in either)
             const uint32_t bit = LOB_NZ_BIT(f);
             if (!(nz[LOB_NZ_WORD(f)] & bit)) {
                 const uint32_t old = atomicOr(&nz[LOB_NZ_WORD(f)], bit);
@@ -1489,13 +1540,15 @@ __global__ void __launch_bounds__(256) memo_kernel(DevParams P, DevState S, cons
             sum = mod_add(sum, rnd[(tile_coord(id.z, base) + 449 * 2) & 2047], M);
             sum = mod_add(sum, rnd[(j + 449 * 3) & 2047], M);
         }
-        f64 t[5];
+        f64 t[5], tb[5];
         const bool fill = (S.mk_tiles_ok[s] & 1) == 0;  // first time on a list: leave the tile indices for the trace kernel
+        const bool two = S.mk_rec_b != nullptr;         // double Q: the same 288 tiles under theta_b
 #pragma unroll
         for (int k = 0; k < 5; k++) {
             const int a = (hi ? 5 : 0) + k;
             const i32 tile = tile_index(sum, rnd[2048 + (a < LOB_N_ACTIONS ? a : 0)], M);
             t[k] = a < LOB_N_ACTIONS ? S.theta[tile] : 0.0;
+            tb[k] = (two && a < LOB_N_ACTIONS) ? S.theta_b[tile] : 0.0;
             if (fill && a < LOB_N_ACTIONS) S.mk_tiles[((size_t)s * LOB_N_ACTIONS + a) * 32 + j] = tile;
         }
         if (fill && lane == 0) {
@@ -1518,6 +1571,24 @@ __global__ void __launch_bounds__(256) memo_kernel(DevParams P, DevState S, cons
         if (lane == LOB_N_ACTIONS) reinterpret_cast<u64*>(rec)[LOB_N_ACTIONS] = ver;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local");
         __builtin_amdgcn_wave_barrier();
+        if (two) {  // (wave-uniform) DoubleAgent::getQb's first 32 terms, the same way
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const int a = (hi ? 5 : 0) + k;
+                if (a < LOB_N_ACTIONS) v[a * LOB_QSTRIDE + j] = P.w0 * tb[k];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local");
+            __builtin_amdgcn_wave_barrier();
+            f64 qb = 0.0;
+            if (lane < LOB_N_ACTIONS) {
+                for (int k = 0; k < 32; k++) qb += v[lane * LOB_QSTRIDE + k];
+            }
+            f64* recb = S.mk_rec_b + ((size_t)which * S.mk_slots + s) * LOB_MK_REC;
+            if (lane < LOB_N_ACTIONS) recb[lane] = qb;
+            if (lane == LOB_N_ACTIONS) reinterpret_cast<u64*>(recb)[LOB_N_ACTIONS] = ver;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local");
+            __builtin_amdgcn_wave_barrier();
+        }
     }
     // the (triple, action) pairs this step's act_light_kernel met for the first time: their 32 tiles are marked in the
     // written-weights maps here, a lane per tile, before the learn kernel looks (see learn_traces)

@@ -282,6 +282,7 @@ struct DevState {
     i32* mk_list;        // [2 parities][mk_slots] slots in use this step
     i32* mk_count;       // [2]
     f64* mk_rec;         // [2: theta_t for learn, theta_{t+1} for the next act][mk_slots][LOB_MK_REC]: S0[9], theta version tag
+    f64* mk_rec_b;       // the same under theta_b (double Q on the fast path: both vectors share the triples, the tiles and the maps), or null
     i32* mk_tiles;       // [mk_slots][9][32] the triple's 288 group-0 tile indices (action, tiling), written by memo_kernel the first time
                          //   the slot is on a step's list: the lane-per-book trace kernel copies a generation from here
     i32* mk_tiles_ok;    // [mk_slots] bit 0: mk_tiles[slot] is filled; bit 1: ... and every tile is in the registry (ow_tab)

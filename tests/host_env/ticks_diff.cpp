@@ -55,6 +55,22 @@ int main() {
             }
         }
         for (int r = 0; r < 20000; r++) check((double)(int)(rng() % 200000));  // tick counts converted as prices (Intraday::getVariable mpm)
+        // ToPrice: every band boundary +- a few ticks, random and negative tick counts, every hint
+        auto check_p = [&](int ticks) {
+            const double want = lobh::to_price_t(t, ticks);
+            for (int h = 0; h < t.n; h++) {
+                int hint = h;
+                const double got = lobh::to_price_hint(t, ticks, hint);
+                n++;
+                if (memcmp(&got, &want, 8) != 0 || hint < 0 || hint >= t.n) {
+                    if (bad++ < 10) printf("MISMATCH %s ticks %d hint %d: %.17g vs %.17g\n", tk, ticks, h, got, want);
+                }
+            }
+        };
+        for (int i = 0; i < t.n; i++)
+            for (int k = -4; k <= 4; k++) check_p((int)t.cum[i] + k);
+        for (int r = 0; r < 40000; r++) check_p((int)(rng() % 300000) - 1000);
+        check_p(0); check_p(-1); check_p(2147483647); check_p(-2147483647 - 1);
     }
     printf("ticks_diff: %d venues, %ld conversions, %ld mismatches\n", venues, n, bad);
     if (bad || venues < 5) return 1;
