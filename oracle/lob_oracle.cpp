@@ -1174,6 +1174,7 @@ void oracle_debug_pass_stats(long long* out16, int reset) {
 }
 
 int oracle_reset(oracle_learner* o) {
+    o->have_from = false;  // a step abandoned after its first half (no oracle_td_step_end) ends with its episode: lob_reset does the same
     for (int b = 0; b < o->B; b++) {
         bool ok = o->env[b]->Initialise();
         o->done[b] = ok ? 0 : 2;

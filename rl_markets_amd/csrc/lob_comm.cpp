@@ -29,6 +29,7 @@ struct lob_comm {
     int rank = 0, world = 1, device = 0;
     hipStream_t stream = nullptr;  // for the small host-side reductions
     double* scratch = nullptr;     // 64 doubles in HBM
+    int mode = -1;                 // the exchange all ranks agreed on at their first lob_theta_allreduce: 1 sparse, 0 dense (-1: not yet)
 };
 
 #define NCCLCHK(expr)                                                                         \
@@ -201,10 +202,19 @@ static hipEvent_t new_event() { hipEvent_t e; hipEventCreateWithFlags(&e, hipEve
 
 static int theta_allreduce_impl(lob_engine* e, lob_comm* c, ExchangeStamp& x) {
     hipStream_t st = (hipStream_t)lob_stream(e);
-    static const bool dense_forced = getenv("LOB_DENSE_EXCHANGE") && getenv("LOB_DENSE_EXCHANGE")[0] == '1';
     int rc;
+    if (c->mode < 0) {
+        // Which exchange: decided ONCE, by all ranks together -- sparse only if every rank can and wants to (a rank whose engine
+        // has no exact map, or whose environment says LOB_DENSE_EXCHANGE=1, would otherwise enter a different collective than
+        // its peers and all of them would wait for ever).  One tiny host-side all-reduce, at the first exchange.
+        const char* df = getenv("LOB_DENSE_EXCHANGE");
+        double dense_wanted = ((df && df[0] == '1') || !lob_delta_sparse_supported(e)) ? 1.0 : 0.0;
+        rc = lob_comm_reduce_host_f64(c, &dense_wanted, 1, LOB_COMM_MAX);
+        if (rc) return rc;
+        c->mode = dense_wanted > 0.0 ? 0 : 1;
+    }
     hipEventRecord(x.ev[0], st);
-    if (!dense_forced && lob_delta_sparse_supported(e)) {
+    if (c->mode == 1) {
         // maps all-gathered -> union -> packed deltas all-reduced -> scattered back (include/lob_engine.h)
         uint32_t *own = nullptr, *gather = nullptr;
         int64_t words = 0;

@@ -517,6 +517,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
         P.cwords4 = (int)((cwords + 3) / 4);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.theta_nzx, P.memo ? (size_t)P.M / 32 + 1 : 1);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.theta_nzc, (size_t)P.cwords4 * 4);
+        if (P.memo && rc == LOB_OK) rc = dev_alloc(e, &S.theta_nzd, 2 * ((size_t)P.M / 32 + 1));
         if (rc == LOB_OK) rc = dev_alloc(e, &S.slow_list, 2 * B);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.slow_n, 4);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.hl_rec, P.memo ? (size_t)LOB_HL_REC * B : 1);
@@ -564,6 +565,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     if (rc == LOB_OK) rc = dev_alloc(e, &S.prof, B * LOB_PROF_N);
 #endif
     if (rc == LOB_OK) rc = dev_alloc(e, &e->rnd_dev, 2048 + 64);
+    S.nzd_terms = e->rnd_dev ? e->rnd_dev + 2048 + LOB_N_ACTIONS : nullptr;  // term[1][.], term[2][.] (filled below)
     if (rc == LOB_OK) rc = dev_alloc(e, &e->actions_dev, B);
     if (rc == LOB_OK) rc = dev_alloc(e, &e->P_dev, 1);
     if (rc == LOB_OK) rc = push_params(e);
@@ -833,6 +835,18 @@ int lob_reset(lob_engine* e) {
     // are gone: re-stamping mk_tiles_ok for a stale triple would hand a later claimant of the slot the wrong tiles)
     HIPCHK(hipMemsetAsync(e->S.mk_count, 0, 2 * sizeof(i32), e->stream));
     HIPCHK(hipMemsetAsync(e->S.mk_markcount, 0, sizeof(i32), e->stream));
+    // ... and the step's work lists (nothing is pending across a reset; a step abandoned after its first half -- below -- has
+    // left its act list's count behind)
+    HIPCHK(hipMemsetAsync(e->S.slow_n, 0, 4 * sizeof(i32), e->stream));
+    HIPCHK(hipMemsetAsync(e->S.tr_list_n, 0, 2 * sizeof(i32), e->stream));
+    HIPCHK(hipMemsetAsync(e->S.tr_list2_n, 0, 2 * sizeof(i32), e->stream));
+    if (e->half_open) {
+        // a step abandoned between lob_td_step_begin and lob_td_step_end (a weight exchange that failed): its learner half never
+        // ran, so the double-buffered lists are where the step found them -- the survivors of the combine table wait in the
+        // abandoned step's parity, not the next one's.  The next step takes that parity again.
+        e->td_parity ^= 1;
+        e->list_par ^= 1;
+    }
     if (e->P.sarsa_lanes) {
         // ... and the tile registry with it; the generations that still name a slot of the old table carry the old epoch
         HIPCHK(hipMemsetAsync(e->S.ow_tab, 0xff, (size_t)e->S.ow_slots * 8, e->stream));
@@ -1079,8 +1093,8 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                 {
                     TimedLaunch t(e, "learn_kernel", st);
                     if (lanes) {
-                        const int gq = std::min(e->n_cus, (nb + LOB_QL_BLOCK - 1) / LOB_QL_BLOCK);
                         const bool pair = e->q_pair && e->P.M < (1ll << 27) && !dq;  // (its LDS rows hold tile indices in 27 bits; one weight vector)
+                        const int gq = pair ? std::min(LOB_QP_OCC * e->n_cus, (nb + LOB_QP_BOOKS - 1) / LOB_QP_BOOKS) : std::min(e->n_cus, (nb + LOB_QL_BLOCK - 1) / LOB_QL_BLOCK);
                         const size_t lds = pair ? qpair_lds_bytes(e->P.cwords4) : qlane_lds_bytes(e->P.cwords4);
 #define LOB_QL_LAUNCH(A, VT, TR)                                                                                                                            \
     do {                                                                                                                                                    \
@@ -1267,6 +1281,7 @@ int lob_theta_set(lob_engine* e, int32_t which, const double* host_in, int64_t c
         // the maps keep the bits they have (monotone: the tiles of live trace generations stay marked, whatever the
         // loaded value of their weights -- a set bit only means "fetch the weight") and gain those of the loaded non-zeros
         hipLaunchKernelGGL(rebuild_nzx_kernel, dim3(2048), dim3(256), 0, e->stream, (const f64*)th, e->S.theta_nzx, e->S.theta_nzc, e->P.cshift, e->P.M);
+        hipLaunchKernelGGL(rebuild_nzd_kernel, dim3(2048), dim3(256), 0, e->stream, (const uint32_t*)e->S.theta_nzx, e->S.theta_nzd, e->S.nzd_terms, e->P.M);
         launch_memo(e, e->last_par, 1);  // the current triples under the loaded weights: the next act stays on the fast path
     }
     HIPCHK(hipGetLastError());
@@ -1433,7 +1448,7 @@ int lob_delta_apply(lob_engine* e) {
         TimedLaunch t(e, "delta_apply_kernel", nullptr, true);
         hipLaunchKernelGGL(delta_apply_kernel, dim3(2048), dim3(256), 0, e->stream, v ? e->S.theta_b : e->S.theta, e->S.theta_sync + v * M,
                            (const f64*)(e->S.delta + v * M), v ? e->S.theta_b_nz : e->S.theta_nz, e->S.nz_epoch, e->P.M,
-                           e->P.memo ? e->S.theta_nzx : (uint32_t*)nullptr, e->S.theta_nzc, e->P.cshift);
+                           e->P.memo ? e->S.theta_nzx : (uint32_t*)nullptr, e->S.theta_nzc, e->P.cshift, e->S.theta_nzd, e->S.nzd_terms);
     }
     if (delta_extra(e))
         hipLaunchKernelGGL(rho_delta_apply_kernel, dim3(1), dim3(1), 0, e->stream, e->S.rho, e->S.theta_sync + M * nv, (const f64*)(e->S.delta + M * nv));
@@ -1463,13 +1478,22 @@ int lob_delta_sparse_maps(lob_engine* e, int32_t world, uint32_t** dev_own, uint
         if (rc == LOB_OK) rc = dev_alloc(e, &e->spx_total, 1);
         if (rc != LOB_OK) return rc;
     }
+    if (!e->spx_buf) {
+        // every buffer of the exchange exists before its first collective starts: a rank that failed to allocate between two
+        // collectives would leave the others waiting in the second.  The union has at most M entries.
+        HIPCHK(hipMalloc((void**)&e->spx_buf, (size_t)e->P.M * 8));
+        e->spx_cap = e->P.M;
+    }
     *dev_own = e->S.theta_nzx;
     *dev_gather = e->spx_gather;
     *words = W;
     return LOB_OK;
 }
 int lob_delta_sparse_pack(lob_engine* e, int32_t world, double** dev_buf, int64_t* count) {
-    if (!e || !dev_buf || !count || world < 1 || world > e->spx_world) return LOB_EINVAL;
+    if (!e || !dev_buf || !count || world < 1 || world > e->spx_world || !e->spx_buf) {
+        lob_set_error("lob_delta_sparse_pack: bad argument (call lob_delta_sparse_maps with this world size first)");
+        return LOB_EINVAL;
+    }
     HIPCHK(hipSetDevice(e->device));
     const int64_t W = spx_words(e);
     const int nb = (int)((W + LOB_SPX_BLOCK - 1) / LOB_SPX_BLOCK);
@@ -1482,12 +1506,7 @@ int lob_delta_sparse_pack(lob_engine* e, int32_t world, double** dev_buf, int64_
     i64 total = 0;
     HIPCHK(hipMemcpyAsync(&total, e->spx_total, sizeof total, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    if (total > e->spx_cap) {
-        if (e->spx_buf) { hipFree(e->spx_buf); e->spx_buf = nullptr; }
-        const int64_t cap = std::max<int64_t>(2 * total, 1 << 20);
-        HIPCHK(hipMalloc((void**)&e->spx_buf, (size_t)cap * 8));
-        e->spx_cap = cap;
-    }
+    if (total > e->spx_cap) { lob_set_error("lob_delta_sparse_pack: more union entries than weights"); return LOB_ESTATE; }  // (cannot happen: cap = M)
     e->spx_count = total;
     {
         TimedLaunch t(e, "delta_begin_kernel", nullptr, true);
@@ -1500,7 +1519,7 @@ int lob_delta_sparse_pack(lob_engine* e, int32_t world, double** dev_buf, int64_
     return LOB_OK;
 }
 int lob_delta_sparse_apply(lob_engine* e) {
-    if (!e || !e->spx_union) return LOB_EINVAL;
+    if (!e || !e->spx_union) { lob_set_error("lob_delta_sparse_apply: no packed exchange to apply"); return LOB_EINVAL; }
     HIPCHK(hipSetDevice(e->device));
     const int64_t W = spx_words(e);
     const int nb = (int)((W + LOB_SPX_BLOCK - 1) / LOB_SPX_BLOCK);
@@ -1510,7 +1529,8 @@ int lob_delta_sparse_apply(lob_engine* e) {
     if (e->spx_count > 0) {
         TimedLaunch t(e, "delta_apply_kernel", nullptr, true);
         hipLaunchKernelGGL(sparse_apply_kernel, dim3(nb), dim3(LOB_SPX_BLOCK), 0, e->stream, (const uint32_t*)e->spx_union, (i64)W, (const i64*)e->spx_block_off,
-                           e->S.theta, e->S.theta_sync, (const f64*)e->spx_buf, e->S.theta_nz, e->S.nz_epoch, e->S.theta_nzx, e->S.theta_nzc, e->P.cshift);
+                           e->S.theta, e->S.theta_sync, (const f64*)e->spx_buf, e->S.theta_nz, e->S.nz_epoch, e->S.theta_nzx, e->S.theta_nzc, e->P.cshift,
+                           e->S.theta_nzd, e->S.nzd_terms, (i64)e->P.M);
     }
     if (e->P.memo && !mid_step) launch_memo(e, e->last_par, 1);  // the current triples under the exchanged weights
     HIPCHK(hipGetLastError());

@@ -1003,6 +1003,93 @@ __device__ __forceinline__ void ql_group(const DevParams& P, const DevState& S, 
     }
 }
 
+// ---- the same walk over the map folded over the actions (lob_state.h theta_nzd) -----------------------------------------
+// One look-up per tiling instead of nine coarse-map reads: bit s of the group's theta_nzd map says whether ANY of the nine tiles
+// (s + term[a]) mod M of the tiling with hash sum s lies on a written weight.  The walk only hashes and tests that bit (the
+// words are requested a stage ahead); the few tilings that pass (7 % at 160 k written weights of 20 M) leave their sums in a
+// short per-lane list in LDS and are resolved afterwards, two at a time: nine exact-map words each, then the entries in
+// Agent::getQ's order (tilings ascending, actions ascending inside a tiling: what ql_consume produces).  No coarse image in
+// LDS: the block is small and several share a CU.
+#define LOB_QD_HCAP 12   /* tilings of one group that may pass per book (more: the general kernel takes the book) */
+template <int G, int VT, int CH>
+__device__ __forceinline__ void qd_issue(const DevParams& P, const DevState& S, const uint32_t* rnd, const int* q, int j0, uint32_t* sum_out, uint32_t* dw_out) {
+    const uint32_t M = (uint32_t)P.M;
+    const int V = VT ? VT : P.V;
+    const int nf = G == 1 ? V - 3 : V;
+    constexpr int NI = VT ? (G == 1 ? VT - 3 : VT) : (G == 1 ? LOB_MAX_VARS - 3 : LOB_MAX_VARS);
+#pragma unroll
+    for (int u = 0; u < CH; u++) {
+        const int j = j0 + u;
+        uint32_t t[NI];
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+            const int qi = G == 1 ? q[i + 3] : q[i];
+            const int base = j * (1 + 2 * i);
+            t[i] = rnd[(base + ((qi - base) & ~31) + 449 * i) & 2047];  // tile_coord without the wrap-around case (such books are not here)
+        }
+        uint32_t sum = rnd[(j + 449 * nf) & 2047];
+#pragma unroll
+        for (int i = 0; i < NI; i++) sum = mod_add(sum, (VT || i < nf) ? t[i] : 0u, M);
+        sum_out[u] = sum;
+        dw_out[u] = S.theta_nzd[(G == 2 ? (size_t)P.M / 32 + 1 : 0) + (sum >> 5)];
+    }
+}
+template <int G, int VT, int CAP, class E>
+__device__ __forceinline__ void ql_group_d(const DevParams& P, const DevState& S, const uint32_t* rnd, const uint32_t* act_terms, const int* q,
+                                           uint32_t* hits, E* row, int& n) {
+    constexpr int CH = 4;
+    const uint32_t* terms = act_terms + G * LOB_N_ACTIONS;
+    const uint32_t M = (uint32_t)P.M;
+    int nh = 0;
+    uint32_t sA[CH], dA[CH], sB[CH], dB[CH];
+#define LOB_QD_TAKE(SUM, DW)                                                        \
+    _Pragma("unroll") for (int u = 0; u < CH; u++) {                                \
+        if ((DW[u] >> (SUM[u] & 31)) & 1u) {                                        \
+            if (nh < LOB_QD_HCAP) hits[nh] = SUM[u];                                \
+            nh++;                                                                   \
+        }                                                                           \
+    }
+    qd_issue<G, VT, CH>(P, S, rnd, q, 0, sA, dA);
+#pragma unroll 1
+    for (int j0 = CH; j0 < 32; j0 += 2 * CH) {
+        qd_issue<G, VT, CH>(P, S, rnd, q, j0, sB, dB);
+        LOB_QD_TAKE(sA, dA)
+        if (j0 + CH < 32) qd_issue<G, VT, CH>(P, S, rnd, q, j0 + CH, sA, dA);
+        LOB_QD_TAKE(sB, dB)
+    }
+#undef LOB_QD_TAKE
+    if (nh > LOB_QD_HCAP) { n = CAP + 1; return; }  // (more tilings than the list holds: the general kernel)
+    // the tilings that passed, two per round: nine exact-map words each in flight together
+#pragma unroll 1
+    for (int k = 0; __any(k < nh); k += 2) {
+        const bool v0 = k < nh, v1 = k + 1 < nh;
+        const uint32_t s0 = v0 ? hits[k] : 0u, s1 = v1 ? hits[k + 1] : 0u;
+        i32 x0[LOB_N_ACTIONS], x1[LOB_N_ACTIONS];
+        uint32_t w0[LOB_N_ACTIONS], w1[LOB_N_ACTIONS];
+#pragma unroll
+        for (int a = 0; a < LOB_N_ACTIONS; a++) {
+            x0[a] = tile_index(s0, terms[a], M);
+            x1[a] = tile_index(s1, terms[a], M);
+            w0[a] = S.theta_nzx[v0 ? (uint32_t)x0[a] >> 5 : 0u];
+            w1[a] = S.theta_nzx[v1 ? (uint32_t)x1[a] >> 5 : 0u];
+        }
+#pragma unroll
+        for (int a = 0; a < LOB_N_ACTIONS; a++) {
+            if (v0 && ((w0[a] >> ((uint32_t)x0[a] & 31)) & 1u)) {
+                if (n < CAP) ql_put(row, 1 + n, x0[a], a, G == 2);
+                n++;
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < LOB_N_ACTIONS; a++) {
+            if (v1 && ((w1[a] >> ((uint32_t)x1[a] & 31)) & 1u)) {
+                if (n < CAP) ql_put(row, 1 + n, x1[a], a, G == 2);
+                n++;
+            }
+        }
+    }
+}
+
 // TR (Q(lambda)): the kernel also runs Agent::UpdateTraces for its books, BEFORE the Q evaluation as the reference does
 // (its argmax draws come first): the light case of trace_light_kernel right here, the others through the list
 // `tr_list` to trace_fast_kernel<.., 2>, which runs after this kernel (the entry carries argmax Q(s, .); Q(s, a) and
@@ -1211,15 +1298,19 @@ __global__ void __launch_bounds__(LOB_QL_BLOCK) learn_q_lane_kernel(DevParams P,
 // waves 0-3 walk the books' group-1 tilings (and run the trace step), waves 4-7 the same books' group-2 tilings, then --
 // after one block barrier -- finish: Q = (S0 + the group-1 additions, summed by the group-1 lane) + the group-2
 // additions, argmax, TD error, the hit list.  Two waves per SIMD, the same instructions in total.
-#define LOB_QP_BOOKS 256
+#ifndef LOB_QP_BOOKS
+#define LOB_QP_BOOKS 128   /* books per block: 4 waves, two blocks per CU (57 KB of LDS each: no coarse map image any more) */
+#endif
 #define LOB_QP_BLOCK (2 * LOB_QP_BOOKS)
+#define LOB_QP_OCC 2      /* blocks per CU the launch counts on */
 #define LOB_QP_CAP1 22  /* entries of the group-1 half (both passes: 11 tiles on marked weights) */
 #define LOB_QP_CAP2 14  /* entries of the group-2 half */
 #define LOB_QP_ROW1 23  /* u32 per lane in LDS (entries packed in 32 bits: tables below 2^27 weights) */
 #define LOB_QP_ROW2 15
 #define LOB_QP_XCH 12   /* f64 per book handed from the group-1 lane to the group-2 lane: S0 + group-1 additions (9), entries (-1: none), Q(s, a), RNG counter */
-__host__ __device__ inline size_t qpair_lds_bytes(int cwords4) {
-    return (size_t)(2048 + 32 + cwords4 * 4) * 4 + (size_t)LOB_QP_BOOKS * (LOB_QP_ROW1 + LOB_QP_ROW2 + 2) * 4 + (size_t)LOB_QP_BOOKS * LOB_QP_XCH * 8;
+__host__ __device__ inline size_t qpair_lds_bytes(int /*cwords4*/) {
+    return (size_t)(2048 + 32) * 4 + (size_t)LOB_QP_BOOKS * (LOB_QP_ROW1 + LOB_QP_ROW2 + 2) * 4 + (size_t)LOB_QP_BOOKS * LOB_QP_XCH * 8 +
+           (size_t)LOB_QP_BLOCK * LOB_QD_HCAP * 4;
 }
 template <int ALGO, int VT, bool TR>
 __global__ void __launch_bounds__(LOB_QP_BLOCK) learn_q_pair_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g, int lpar, u64 ver, int sid) {
@@ -1229,13 +1320,12 @@ __global__ void __launch_bounds__(LOB_QP_BLOCK) learn_q_pair_kernel(DevParams P,
     __shared__ u64 claimed[512];  // (as trace_light_kernel)
     uint32_t* rnd = reinterpret_cast<uint32_t*>(fast_lds_raw);
     uint32_t* act_terms = rnd + 2048;
-    uint32_t* coarse = act_terms + 32;
-    uint32_t* rows1 = coarse + (size_t)P.cwords4 * 4;                        // [books][LOB_QP_ROW1]
+    uint32_t* rows1 = act_terms + 32;                                        // [books][LOB_QP_ROW1]
     uint32_t* rows2 = rows1 + (size_t)LOB_QP_BOOKS * LOB_QP_ROW1;           // [books][LOB_QP_ROW2]
     f64* xch = reinterpret_cast<f64*>(rows2 + (size_t)LOB_QP_BOOKS * LOB_QP_ROW2 + ((LOB_QP_BOOKS * (LOB_QP_ROW1 + LOB_QP_ROW2)) & 1) + 0);
+    uint32_t* hits = reinterpret_cast<uint32_t*>(xch + (size_t)LOB_QP_BOOKS * LOB_QP_XCH) + (size_t)threadIdx.x * LOB_QD_HCAP;  // this lane's passed tilings (ql_group_d)
     for (int i = threadIdx.x; i < 512; i += LOB_QP_BLOCK) reinterpret_cast<uint4*>(rnd)[i] = reinterpret_cast<const uint4*>(rnd_g)[i];
     if (threadIdx.x < 27) act_terms[threadIdx.x] = rnd_g[2048 + threadIdx.x];
-    for (int i = threadIdx.x; i < P.cwords4; i += LOB_QP_BLOCK) reinterpret_cast<uint4*>(coarse)[i] = reinterpret_cast<const uint4*>(S.theta_nzc)[i];
     if (TR) for (int i = threadIdx.x; i < 512; i += LOB_QP_BLOCK) claimed[i] = LOB_CB_EMPTY;
     __syncthreads();
     const bool second = threadIdx.x >= LOB_QP_BOOKS;  // wave-uniform: the group-2 half
@@ -1310,7 +1400,7 @@ __global__ void __launch_bounds__(LOB_QP_BLOCK) learn_q_pair_kernel(DevParams P,
                 q_sa = sel9(qs_last, h.action);
             }
             if (walk) {
-                ql_group<1, VT, 2, LOB_QP_CAP1, uint32_t>(P, S, rnd, act_terms, coarse, q, row, n);
+                ql_group_d<1, VT, LOB_QP_CAP1, uint32_t>(P, S, rnd, act_terms, q, hits, row, n);
                 const int n1 = n;  // the group-1 additions once more, with w2 (quirk Q3)
                 for (int i = 0; i < n1; i++) {
                     if (n < LOB_QP_CAP1) row[1 + n] = row[1 + i] | (1u << 31);
@@ -1393,9 +1483,9 @@ __global__ void __launch_bounds__(LOB_QP_BLOCK) learn_q_pair_kernel(DevParams P,
             reinterpret_cast<u64*>(xc)[LOB_N_ACTIONS + 2] = g.ctr;
         } else {
             // ---- group-2 lane: the group-2 walk (its weights can be fetched before the other half is in) ----
-            if (walk) ql_group<2, VT, 2, LOB_QP_CAP2, uint32_t>(P, S, rnd, act_terms, coarse, q, row, n);
+            if (walk) ql_group_d<2, VT, LOB_QP_CAP2, uint32_t>(P, S, rnd, act_terms, q, hits, row, n);
 #pragma unroll
-            for (int i = 0; i < LOB_QP_CAP2; i++) v2[i] = (walk && i < n) ? S.theta[row[1 + i] & 0x7ffffffu] : 0.0;
+            for (int i = 0; i < LOB_QP_CAP2; i++) v2[i] = (walk && n <= LOB_QP_CAP2 && i < n) ? S.theta[row[1 + i] & 0x7ffffffu] : 0.0;  // (n beyond the row: entries not written)
         }
         __syncthreads();
         if (!second) {

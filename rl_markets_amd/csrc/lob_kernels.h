@@ -712,10 +712,24 @@ __device__ inline i32 sel5(const i32* f, int k) {
 
 // Weight f of the shared theta is (about to be) written for the first time: the exact map and its coarse image
 // (lob_fast.h); monotone bits.  True if this call set the exact bit.
+// (the map folded over the actions, lob_state.h theta_nzd: the 18 hash sums whose tilings contain weight f)
+__device__ inline void nzd_mark(uint32_t* nzd, const uint32_t* terms18, uint32_t M, uint32_t f) {
+    const size_t words = (size_t)M / 32 + 1;              // one map per tile group: [2][words]
+    // 18 independent read-modify-writes nobody waits for (the caller has just flipped the exact bit: once per weight)
+    uint32_t t[18];
+#pragma unroll
+    for (int i = 0; i < 18; i++) t[i] = terms18[i];       // < M
+#pragma unroll
+    for (int i = 0; i < 18; i++) {
+        const uint32_t s = f >= t[i] ? f - t[i] : f + (M - t[i]);  // (s + t) mod M == f
+        __hip_atomic_fetch_or(nzd + (i >= LOB_N_ACTIONS ? words : 0) + (s >> 5), 1u << (s & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
 __device__ inline bool nzx_mark(const DevParams& P, const DevState& S, i32 f) {
     const uint32_t xb = 1u << ((uint32_t)f & 31);
     if (S.theta_nzx[(uint32_t)f >> 5] & xb) return false;
     const uint32_t old = atomicOr(&S.theta_nzx[(uint32_t)f >> 5], xb);
+    if (!(old & xb) && S.theta_nzd) nzd_mark(S.theta_nzd, S.nzd_terms, (uint32_t)P.M, (uint32_t)f);
     const uint32_t c = (uint32_t)f >> P.cshift;
     const uint32_t cb = 1u << (c & 31);
     if (!(S.theta_nzc[c >> 5] & cb)) atomicOr(&S.theta_nzc[c >> 5], cb);
@@ -1765,7 +1779,7 @@ __global__ void delta_begin_kernel(const f64* __restrict__ theta, const f64* __r
     for (; i < M; i += stride) delta[i] = theta[i] - sync[i];
 }
 __global__ void delta_apply_kernel(f64* theta, f64* sync, const f64* __restrict__ delta, uint32_t* nz, i32* nz_epoch, i64 M,
-                                   uint32_t* nzx, uint32_t* nzc, int cshift) {
+                                   uint32_t* nzx, uint32_t* nzc, int cshift, uint32_t* nzd, const uint32_t* nzd_terms) {
     i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) atomicAdd(nz_epoch, 1);  // verdicts saved before this exchange are stale
     const i64 stride = (i64)gridDim.x * blockDim.x;
@@ -1779,7 +1793,10 @@ __global__ void delta_apply_kernel(f64* theta, f64* sync, const f64* __restrict_
             if (!(nz[LOB_NZ_WORD(i)] & bit)) atomicOr(&nz[LOB_NZ_WORD(i)], bit);
             if (nzx) {  // the fast path's maps (theta only)
                 const uint32_t xb = 1u << ((uint32_t)i & 31);
-                if (!(nzx[(uint32_t)i >> 5] & xb)) atomicOr(&nzx[(uint32_t)i >> 5], xb);
+                if (!(nzx[(uint32_t)i >> 5] & xb)) {
+                    const uint32_t old = atomicOr(&nzx[(uint32_t)i >> 5], xb);
+                    if (!(old & xb) && nzd) nzd_mark(nzd, nzd_terms, (uint32_t)M, (uint32_t)i);
+                }
                 const uint32_t c = (uint32_t)i >> cshift;
                 if (!(nzc[c >> 5] & (1u << (c & 31)))) atomicOr(&nzc[c >> 5], 1u << (c & 31));
             }
@@ -1861,7 +1878,7 @@ __global__ void __launch_bounds__(LOB_SPX_BLOCK) sparse_pack_kernel(const uint32
 // only means "fetch the weight": a weight another rank marked but has not written yet reads as +0.0)
 __global__ void __launch_bounds__(LOB_SPX_BLOCK) sparse_apply_kernel(const uint32_t* __restrict__ u_map, i64 words, const i64* __restrict__ block_off,
                                                                      f64* theta, f64* sync, const f64* __restrict__ buf, uint32_t* nz, i32* nz_epoch,
-                                                                     uint32_t* nzx, uint32_t* nzc, int cshift) {
+                                                                     uint32_t* nzx, uint32_t* nzc, int cshift, uint32_t* nzd, const uint32_t* nzd_terms, i64 M) {
     __shared__ i32 lds[LOB_SPX_BLOCK / 64];
     const i64 w = (i64)blockIdx.x * LOB_SPX_BLOCK + threadIdx.x;
     if (w == 0) atomicAdd(nz_epoch, 1);  // verdicts saved before this exchange are stale
@@ -1878,7 +1895,17 @@ __global__ void __launch_bounds__(LOB_SPX_BLOCK) sparse_apply_kernel(const uint3
         nzm |= LOB_NZ_BIT(f);
     }
     if (u0) {
-        if (nzx[w] != u0) nzx[w] = nzx[w] | u0;  // (this thread owns the word; the rank's own bits are part of the union)
+        const uint32_t have = nzx[w];
+        if (have != (have | u0)) {  // (this thread owns the word; the rank's own bits are part of the union)
+            nzx[w] = have | u0;
+            if (nzd) {
+                uint32_t fresh = u0 & ~have;  // weights only other ranks have written so far
+                while (fresh) {
+                    nzd_mark(nzd, nzd_terms, (uint32_t)M, (uint32_t)((w << 5) + __builtin_ctz(fresh)));
+                    fresh &= fresh - 1;
+                }
+            }
+        }
         const i64 f0 = w << 5;  // the 32 weights of a word share their coarse bit (cshift >= 5) and their word of the 1-in-8 map
         const uint32_t c = (uint32_t)(f0 >> cshift);
         if (!(nzc[c >> 5] & (1u << (c & 31)))) atomicOr(&nzc[c >> 5], 1u << (c & 31));
@@ -1895,6 +1922,32 @@ __global__ void rebuild_nzx_kernel(const f64* __restrict__ theta, uint32_t* nzx,
             const uint32_t c = (uint32_t)i >> cshift;
             atomicOr(&nzc[c >> 5], 1u << (c & 31));
         }
+    }
+}
+// ... and the map folded over the actions from the exact one (gather form: no atomics; monotone like the exact map)
+__global__ void rebuild_nzd_kernel(const uint32_t* __restrict__ nzx, uint32_t* nzd, const uint32_t* __restrict__ terms18, i64 M) {
+    const i64 words = M / 32 + 1;
+    uint32_t t[18];
+#pragma unroll
+    for (int i = 0; i < 18; i++) t[i] = terms18[i];
+    for (i64 w = (i64)blockIdx.x * blockDim.x + threadIdx.x; w < words; w += (i64)gridDim.x * blockDim.x) {
+        uint32_t out1 = 0, out2 = 0;
+        for (int k = 0; k < 32; k++) {
+            const i64 s = (w << 5) + k;
+            if (s >= M) break;
+            bool any1 = false, any2 = false;
+#pragma unroll
+            for (int i = 0; i < 18; i++) {
+                uint32_t f = (uint32_t)s + t[i];
+                if (f >= (uint32_t)M) f -= (uint32_t)M;   // (s, t < M < 2^31: no wrap of the 32-bit sum)
+                const bool hit = (nzx[f >> 5] >> (f & 31)) & 1u;
+                if (i < LOB_N_ACTIONS) any1 |= hit; else any2 |= hit;
+            }
+            out1 |= any1 ? 1u << k : 0u;
+            out2 |= any2 ? 1u << k : 0u;
+        }
+        if (out1 & ~nzd[w]) nzd[w] |= out1;   // (this thread owns the words)
+        if (out2 & ~nzd[words + w]) nzd[words + w] |= out2;
     }
 }
 // rebuild the bitmap after lob_theta_set: bit = (theta != +0.0 bitwise)

@@ -312,6 +312,12 @@ struct DevState {
     // the fast kernels hand back to the general ones.
     uint32_t* theta_nzx; // [M / 32 + 1]
     uint32_t* theta_nzc; // [cwords4 * 4]
+    // The exact map folded over the actions (learn_q_pair_kernel): the nine tiles of one tiling of group 1 / 2 are
+    // (s + term[g][a]) mod M for ONE hash sum s, so bit s of group g's map = OR over a of theta_nzx[(s + term[g][a]) mod M]
+    // answers "does any of this tiling's nine tiles lie on a written weight" with one look-up instead of nine (93 % of the
+    // tilings: none, at 160 k written weights of 20 M).  Set with the exact bit, wherever that is set (nzd_mark).
+    uint32_t* theta_nzd;      // [2: tile group 1, 2][M / 32 + 1]
+    const uint32_t* nzd_terms; // [18]: term[1][0..8], term[2][0..8] (the engine's hash table + 2048 + 9)
     i32* tr_list;        // [B] books the lane-per-book trace kernel leaves to the wave-per-book one
     i32* tr_list_n;      // [2 parities]
     i32* tr_list2;       // [B] Q(lambda): the entries of `tr_list` the lane-per-generation kernel (trace_lane_kernel) hands on to the wave-per-book one

@@ -406,6 +406,7 @@ class Learner : public Runner {
     lob_comm* comm_ = nullptr;  // multi-GPU: the shared Agent* of main.cpp:196-206 becomes a periodic all-reduce
     int sync_every_ = 64;
     unsigned long since_sync_ = 0;
+    bool split_ok_ = true;  // lob_td_step_begin / _end available (not with LOB_GROUPS=2)
 
 protected:
     bool _step(Agent*) override {
@@ -418,9 +419,18 @@ protected:
             // the sync step carries the exchange between its two halves: no cached action-selection data is live there
             // (include/lob_engine.h lob_td_step_begin)
             if (n > 1) check(lob_td_step(environment.handle(), n - 1), "Learner::_step");
-            check(lob_td_step_begin(environment.handle()), "Learner::_step");
-            check(lob_theta_allreduce(environment.handle(), comm_), "Learner::_step (weight exchange)");
-            check(lob_td_step_end(environment.handle()), "Learner::_step");
+            const int rc_begin = split_ok_ ? lob_td_step_begin(environment.handle()) : LOB_ESTATE;
+            if (rc_begin == LOB_ESTATE) {
+                // no half steps with this engine configuration (two book groups): the whole step, then the exchange -- correct
+                // too, the exchange then voids the cached action-selection data of one step
+                split_ok_ = false;
+                check(lob_td_step(environment.handle(), 1), "Learner::_step");
+                check(lob_theta_allreduce(environment.handle(), comm_), "Learner::_step (weight exchange)");
+            } else {
+                check(rc_begin, "Learner::_step");
+                check(lob_theta_allreduce(environment.handle(), comm_), "Learner::_step (weight exchange)");
+                check(lob_td_step_end(environment.handle()), "Learner::_step");
+            }
         }
         environment.invalidate();
         _step_counter += n;

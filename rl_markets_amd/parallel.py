@@ -36,6 +36,7 @@ class ShardedLearner:
         self.sync_every = int(sync_every)
         self.steps = 0
         self.n_syncs = 0
+        self._split_ok = True
         if self.comm is not None:
             backend.delta_init()
 
@@ -57,12 +58,22 @@ class ShardedLearner:
                 until = self.sync_every - self.steps % self.sync_every
                 chunk = min(chunk, until)
                 sync_now = chunk == until
-            if sync_now and split:
+            if sync_now and split and self._split_ok:
                 if chunk > 1:
                     self.backend.td_step(chunk - 1)
-                self.backend.td_step_begin()
-                self.sync_weights()
-                self.backend.td_step_end()
+                try:
+                    self.backend.td_step_begin()
+                except Exception as ex:
+                    if getattr(ex, "code", None) != -4:   # LOB_ESTATE: no half steps with this engine configuration (LOB_GROUPS=2)
+                        raise
+                    # ... then the whole step followed by the exchange, as before the split existed: correct too, the exchange
+                    # voids the cached action-selection data of one step
+                    self._split_ok = False
+                    self.backend.td_step(1)
+                    self.sync_weights()
+                else:
+                    self.sync_weights()
+                    self.backend.td_step_end()
             else:
                 self.backend.td_step(chunk)
                 if sync_now:

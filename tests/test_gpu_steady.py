@@ -127,6 +127,32 @@ def test_lane_learner_kernel_for_large_tables(algo):
     orc.close()
 
 
+def test_preloaded_theta_with_a_million_written_weights():
+    """The state a long training run is in, at scale: 32 768 books acting from a weight vector with 1.2 M non-zero entries
+    (6 % of the table: a hit list would need ~50 entries, so most books take the in-kernel full evaluation and the
+    wave-per-book learn kernel; the folded written-weights maps are half full).  20 steps against the oracle."""
+    B = 32768
+    p, eng, orc = make(B, abi.ALGO_QLAMBDA, n_events=200)
+    rng = np.random.default_rng(11)
+    th = np.zeros(p.memory_size)
+    idx = rng.choice(p.memory_size, size=1200000, replace=False)
+    th[idx] = rng.normal(0.0, 0.01, size=idx.size)
+    eng.reset(); orc.reset()
+    eng.set_theta(th)
+    orc.theta()[:] = th
+    for step in range(20):
+        eng.td_step(1); orc.td_step(1)
+        if step < 3 or step % 4 == 3:
+            compare_learner_step(eng, orc, "pre-loaded theta, step %d" % step, exact=False, rtol=1e-9)
+    st = eng.fastpath_stats()
+    assert st["written_weights"] >= 1200000
+    print("pre-loaded theta: %d written weights, %d of %d live books without a hit list, mean list %s" %
+          (st["written_weights"], st["books_without_list"], st["live_books"], st["list_len_mean"]))
+    np.testing.assert_allclose(eng.theta(), orc.theta(), rtol=1e-9, atol=1e-12)
+    eng.close()
+    orc.close()
+
+
 def test_reset_then_weight_load_then_steps(monkeypatch):
     """lob_reset -> lob_theta_set -> lob_td_step: the weight load re-evaluates the memo records of the slots on the
     current list, which after a reset must be EMPTY -- slots of the episode before would be re-stamped as holding
