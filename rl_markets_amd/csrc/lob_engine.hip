@@ -43,6 +43,12 @@ struct lob_engine {
     hipStream_t stream2 = nullptr;  // second book group of the step pipeline
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_stagger = nullptr;
     hipEvent_t ev_reg_go = nullptr, ev_reg_done = nullptr;  // tile registry kernels on stream2 beside the learner kernels (lob_kernels.h registry_kernel)
+    hipEvent_t ev_rest_go = nullptr, ev_rest_done = nullptr;  // learn_q_rest_kernel on stream2 beside the trace kernels
+    bool rest_side = true;      // (LOB_REST_SIDE=0: on the main stream, as before; A/B switch)
+    bool acc_block = true;      // SARSA(lambda): accumulate_block_kernel (LOB_ACC_BLOCK=0: accumulate_kernel; A/B switch)
+    i32* rest_hint = nullptr;   // host-mapped word learn_q_rest_kernel writes its list's length to
+    i32* rest_hint_dev = nullptr;
+    int rest_recent = 0;        // steps left to keep the launch on the second stream after the last non-empty list seen
     bool reg_pending = false;
     bool reg_fork_late = false;
     int n_groups = 1;
@@ -291,6 +297,14 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     HIPCHK_E(hipEventCreateWithFlags(&e->ev_stagger, hipEventDisableTiming | hipEventDisableSystemFence));
     HIPCHK_E(hipEventCreateWithFlags(&e->ev_reg_go, hipEventDisableTiming | hipEventDisableSystemFence));
     HIPCHK_E(hipEventCreateWithFlags(&e->ev_reg_done, hipEventDisableTiming | hipEventDisableSystemFence));
+    HIPCHK_E(hipEventCreateWithFlags(&e->ev_rest_go, hipEventDisableTiming | hipEventDisableSystemFence));
+    HIPCHK_E(hipEventCreateWithFlags(&e->ev_rest_done, hipEventDisableTiming | hipEventDisableSystemFence));
+    if (const char* g = getenv("LOB_REST_SIDE")) e->rest_side = !(g[0] == '0');
+    if (const char* g = getenv("LOB_ACC_BLOCK")) e->acc_block = !(g[0] == '0');
+    if (hipHostMalloc((void**)&e->rest_hint, sizeof(i32), hipHostMallocMapped) == hipSuccess) {
+        *e->rest_hint = 0;
+        if (hipHostGetDevicePointer((void**)&e->rest_hint_dev, e->rest_hint, 0) != hipSuccess) e->rest_hint_dev = nullptr;
+    } else e->rest_hint = nullptr;   // (no hint: the launch stays on the main stream)
     // Optional (LOB_GROUPS=2): two book groups pipelined on two streams so that the latency-bound env
     // kernel of one group runs beside a gather kernel of the other.  It paid 7 % before the market
     // track made the env kernel cheap; now one group is as fast and gives clean per-kernel timings.
@@ -617,6 +631,9 @@ void lob_destroy(lob_engine* e) {
     if (e->ev_stagger) hipEventDestroy(e->ev_stagger);
     if (e->ev_reg_go) hipEventDestroy(e->ev_reg_go);
     if (e->ev_reg_done) hipEventDestroy(e->ev_reg_done);
+    if (e->rest_hint) hipHostFree(e->rest_hint);
+    if (e->ev_rest_go) hipEventDestroy(e->ev_rest_go);
+    if (e->ev_rest_done) hipEventDestroy(e->ev_rest_done);
     if (e->stream2) hipStreamDestroy(e->stream2);
     for (auto ev : e->event_pool) hipEventDestroy(ev);
     for (void* p : e->allocs) hipFree(p);
@@ -795,7 +812,12 @@ static void launch_env_fused(lob_engine* e, hipStream_t st, int par, int lpar, u
     // without a usable hit list itself (act_book in-kernel) -- except in the first step on lists after they were void, when a late
     // map bit of the step before has voided them again and EVERY book takes the general path: that step goes through
     // the work list to the general act kernel and env_kernel<64, 2, 2> as before (either version is correct for any step).
-    const bool inline_general = t2 && e->env_step && e->inline_general && e->steps_on_lists >= 1;
+    // ... and while MOST books have no usable list (a dense weight vector -- learning.random_init, a loaded checkpoint: every tile
+    // lies on a written weight and no list fits a record): one wave per book in the general act kernel is far better than a
+    // 64-lane wave going through its books one at a time.  The learn kernels hand the same books back: their list's length,
+    // reported through the host-mapped word (a few steps late), tells.
+    const bool mostly_general = e->rest_hint && *(volatile i32*)e->rest_hint > e->B / 16;
+    const bool inline_general = t2 && e->env_step && e->inline_general && e->steps_on_lists >= 1 && !mostly_general;
     e->steps_on_lists++;
     const bool dq = e->P.algo == LOB_ALGO_DOUBLE_Q;  // (then t2 && env_step: lob_create)
     {
@@ -1015,6 +1037,7 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
             HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
         }
         const bool fast = e->P.memo != 0;  // (implies one group)
+        bool rest_pending = false;
         const bool dq = e->P.algo == LOB_ALGO_DOUBLE_Q;  // (fast && dq: every step without usable hit lists takes the general act kernel over the whole batch)
         const int lpar = first ? (e->list_par ^= 1) : e->list_par;
         e->last_par = par;
@@ -1113,10 +1136,29 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                     else hipLaunchKernelGGL((learn_q_fast_kernel<LOB_ALGO_SARSA, LOB_FAST_NB>), dim3(gf), dim3(LOB_FAST_BLOCK), fast_lds_bytes(e->P.cwords4, LOB_FAST_NB, false), st, e->P, e->S, rnd, lpar, ver);
                 }
                 {
-                    TimedLaunch t(e, "learn_rest_kernel", st);
-                    if (dq) hipLaunchKernelGGL(learn_q_rest_kernel<LOB_ALGO_DOUBLE_Q>, dim3(gl), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, learn_list, learn_n);
-                    else if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL(learn_q_rest_kernel<LOB_ALGO_QLAMBDA>, dim3(gl), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, learn_list, learn_n);
-                    else hipLaunchKernelGGL(learn_q_rest_kernel<LOB_ALGO_SARSA>, dim3(gl), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, learn_list, learn_n);
+                    // The books the lane kernels hand back (a list that is empty in most steps, a handful of books in the others).
+                    // When trace kernels follow on the main stream (the fused Q(lambda) / double Q flow), this launch runs beside
+                    // them on the second stream: nothing they do depends on it -- the update kernels wait for both.
+                    // (worth it only while books ARE handed back -- an empty launch is cheaper than the two cross-stream waits: the
+                    // kernel reports its list's length through a host-mapped word, read here a few steps late)
+                    if (e->rest_hint && *(volatile i32*)e->rest_hint > 0) e->rest_recent = 64;
+                    else if (e->rest_recent > 0) e->rest_recent--;
+                    const bool side = fuse && e->rest_side && e->rest_recent > 0;
+                    hipStream_t rs = side ? e->stream2 : st;
+                    if (side) {
+                        HIPCHK(hipEventRecord(e->ev_rest_go, st));
+                        HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_rest_go, 0));
+                    }
+                    {
+                        TimedLaunch t(e, "learn_rest_kernel", rs);
+                        if (dq) hipLaunchKernelGGL(learn_q_rest_kernel<LOB_ALGO_DOUBLE_Q>, dim3(gl), dim3(LOB_BLOCK), 0, rs, e->P, e->S, rnd, learn_list, learn_n, e->rest_hint_dev);
+                        else if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL(learn_q_rest_kernel<LOB_ALGO_QLAMBDA>, dim3(gl), dim3(LOB_BLOCK), 0, rs, e->P, e->S, rnd, learn_list, learn_n, e->rest_hint_dev);
+                        else hipLaunchKernelGGL(learn_q_rest_kernel<LOB_ALGO_SARSA>, dim3(gl), dim3(LOB_BLOCK), 0, rs, e->P, e->S, rnd, learn_list, learn_n, e->rest_hint_dev);
+                    }
+                    if (side) {
+                        HIPCHK(hipEventRecord(e->ev_rest_done, e->stream2));
+                        rest_pending = true;
+                    }
                 }
                 if (e->P.sarsa_lanes && !e->reg_fork_late) { int rc = registry_fork(e, st, rnd, par); if (rc) return rc; }
                 if (fuse) {
@@ -1140,12 +1182,18 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
         }
         if (!second) { e->half_open = true; continue; }
         e->half_open = false;
+        if (rest_pending) { HIPCHK(hipStreamWaitEvent(e->stream, e->ev_rest_done, 0)); rest_pending = false; }
         if (mode == 0 && e->P.combine) {
             {
                 TimedLaunch t(e, "accumulate_kernel");
-                const int sh = acc_lanes_shift(e);
-                const int waves = (e->B + (64 >> sh) - 1) / (64 >> sh);
-                hipLaunchKernelGGL(accumulate_kernel, dim3((waves + LOB_WAVES_PER_BLOCK - 1) / LOB_WAVES_PER_BLOCK), dim3(LOB_BLOCK), 0, e->stream, e->P, e->S, par, sh, e->step_id);
+                if (e->acc_block && e->P.algo == LOB_ALGO_SARSA && e->B >= 4 * LOB_ACB_BLOCK) {
+                    // SARSA(lambda): every book keeps all its generations -- sums per slot inside 1 024-book blocks first
+                    hipLaunchKernelGGL(accumulate_block_kernel, dim3((e->B + LOB_ACB_BLOCK - 1) / LOB_ACB_BLOCK, e->P.trace_kmax), dim3(LOB_ACB_BLOCK), 0, e->stream, e->P, e->S, par, e->step_id);
+                } else {
+                    const int sh = acc_lanes_shift(e);
+                    const int waves = (e->B + (64 >> sh) - 1) / (64 >> sh);
+                    hipLaunchKernelGGL(accumulate_kernel, dim3((waves + LOB_WAVES_PER_BLOCK - 1) / LOB_WAVES_PER_BLOCK), dim3(LOB_BLOCK), 0, e->stream, e->P, e->S, par, sh, e->step_id);
+                }
             }
             {
                 TimedLaunch t(e, "apply_kernel");

@@ -130,7 +130,16 @@ __global__ void __launch_bounds__(64) env_step_kernel(const DevParams* __restric
         }
     }
     const int kk = k0 > 0 ? k0 : 1;  // (a live book has consumed its warm-up: k0 >= 1)
-    const Track tprev = track_load(&c.track(kk - 1));
+    // (of the previous event's entry the quotes and the market order read tp_val, spread_mean, a_tv, b_tv: bytes 64-95)
+    Track tprev;
+    {
+        const uint4* q = reinterpret_cast<const uint4*>(&c.track(kk - 1));
+        const uint4 w4 = q[4], w5 = q[5];
+        uint4* d = reinterpret_cast<uint4*>(&tprev);
+#pragma unroll
+        for (int i = 0; i < 8; i++) d[i] = make_uint4(0, 0, 0, 0);
+        d[4] = w4; d[5] = w5;
+    }
     Track tcur = track_load(&c.track(k0));
     RowFull cur, first;
     row_full_load(c, rc0, cur);

@@ -1128,9 +1128,12 @@ __device__ __forceinline__ void learn_q_book(const DevParams& P, const DevState&
     }
 }
 template <int ALGO>
+// `hint` (host-mapped memory, or null): the list's length, for the host to see without a synchronisation -- a few steps late,
+// which is all it needs to decide whether this launch is worth a place beside the trace kernels on the second stream.
 __global__ void __launch_bounds__(LOB_BLOCK) learn_q_rest_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g,
-                                                                 const i32* __restrict__ list, const i32* __restrict__ list_n) {
+                                                                 const i32* __restrict__ list, const i32* __restrict__ list_n, i32* hint) {
     __shared__ LearnLds L;
+    if (hint && blockIdx.x == 0 && threadIdx.x == 0) *hint = *list_n;
     if (*list_n == 0) return;  // nothing handed back: the usual case
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     learn_stage_table(rnd_g, L);
@@ -1409,6 +1412,130 @@ __global__ void __launch_bounds__(LOB_BLOCK) accumulate_kernel(DevParams P, DevS
                 }
             }
         }
+    }
+}
+
+// accumulate_block_kernel: the same sums for SARSA(lambda), whose every book keeps ~25 live generations -- 1.6 M additions per step
+// landing on fewer than 10 k slots, bound by the rate of f64 atomics (11 G/s) however the addresses are spread.  A block takes
+// ONE age of 1 024 consecutive books (generations created in one step: the books that were in the same state then hold the very
+// same generation, and a popular one is held by a few per cent of all books), sums the updates per slot in an LDS table first
+// and sends one global addition per distinct slot: the heavy slots, which carry most of the additions, shrink by the number of
+// their holders among the block's books.  Slot look-up, verification and the direct path as in accumulate_kernel.
+#define LOB_ACB_BLOCK 1024
+#define LOB_ACB_TAB 2048
+__global__ void __launch_bounds__(LOB_ACB_BLOCK) accumulate_block_kernel(DevParams P, DevState S, int par, int sid) {
+    __shared__ i32 keys[LOB_ACB_TAB];
+    __shared__ f64 sums[LOB_ACB_TAB];
+    __shared__ i32 any_active;
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < LOB_ACB_TAB; i += LOB_ACB_BLOCK) { keys[i] = -1; sums[i] = 0.0; }
+    if (threadIdx.x == 0) any_active = 0;
+    __syncthreads();
+    const int b = blockIdx.x * LOB_ACB_BLOCK + threadIdx.x;
+    const int age = blockIdx.y;
+    int n = 0, head = 0;
+    f64 scaled = 0.0;
+    if (b < S.B) {
+        const LHdr& h = S.hdr[b];
+        if (h.stepped) { n = h.tr_n; head = h.tr_head; scaled = h.upd / (f64)LOB_N_TILINGS; }
+    }
+    const bool mine = age < n;
+    if (__any(mine) && lane == 0) any_active = 1;
+    __syncthreads();
+    if (!any_active) return;  // (block-uniform: no book of the block has a generation this old)
+    const int G = P.trace_gens;
+    const int bb = b < S.B ? b : 0;
+    const int slot = (head - age + G) & (G - 1);
+    uint32_t mask = 0;
+    int cs = -1;
+    if (mine) {
+        mask = S.tr_alive[(size_t)bb * G + slot];
+        cs = S.tr_cbslot[(size_t)bb * G + slot];
+    }
+    const bool known = mask != 0 && cs >= 0 && (cs & LOB_CBS_VERIFIED);
+    int4 sg = make_int4(0, 0, 0, 0);
+    if (mask != 0 && !known) sg = *reinterpret_cast<const int4*>(S.tr_sig + ((size_t)bb * G + slot) * 4);
+    bool direct = false, found = false;
+    uint32_t s = 0;
+    if (mask) {
+        found = known;
+        s = (uint32_t)cs & (uint32_t)(S.cb_slots - 1);
+        if (!known && cs >= 0) {
+            const int4 id = *reinterpret_cast<const int4*>(S.cb_ident + (size_t)s * 8);
+            const uint32_t idm = (uint32_t)S.cb_ident[(size_t)s * 8 + 4];
+            found = id.x == sg.x && id.y == sg.y && id.z == sg.z && id.w == sg.w && idm == mask;
+        }
+        if (!found) {
+            const u64 hsh = cb_hash(sg.x, sg.y, sg.z, sg.w, mask);
+            s = (uint32_t)hsh & (uint32_t)(S.cb_slots - 1);
+            for (int probe = 0; probe < LOB_CB_PROBES; probe++) {
+                const u64 kk = S.cb_key[s];
+                if (kk == hsh) {
+                    const i32* id = S.cb_ident + (size_t)s * 8;
+                    found = id[0] == sg.x && id[1] == sg.y && id[2] == sg.z && id[3] == sg.w && (uint32_t)id[4] == mask;
+                    if (found) break;
+                }
+                if (kk == LOB_CB_EMPTY) break;
+                s = (s + 1) & (uint32_t)(S.cb_slots - 1);
+            }
+        }
+        if (found && !known) S.tr_cbslot[(size_t)bb * G + slot] = (i32)(s | LOB_CBS_VERIFIED);
+        direct = !found;
+    }
+    // the block's sums per slot
+    bool spilled = false;
+    const f64 val = scaled * (f64)P.trace_pow[age];
+    if (found) {
+        uint32_t hh = (s * 2654435761u) >> 21;  // 11 bits
+        bool placed = false;
+        for (int probe = 0; probe < 16 && !placed; probe++) {
+            const i32 old = atomicCAS(&keys[hh], -1, (i32)s);
+            if (old == -1 || old == (i32)s) { unsafeAtomicAdd(&sums[hh], val); placed = true; }  // (LDS: ds_add_f64)
+            else hh = (hh + 1) & (LOB_ACB_TAB - 1);
+        }
+        spilled = !placed;
+    }
+    int xcd = 0;
+    if (S.cb_reps > 1) {
+        unsigned x;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+        xcd = (int)(x & (unsigned)(S.cb_reps - 1));
+        if (S.cb_reps > 8) xcd = (int)(x & 7u) * (S.cb_reps >> 3) + (int)(blockIdx.x & ((S.cb_reps >> 3) - 1));
+    }
+    if (spilled) {  // (a crowded block table: straight to the slot)
+        __hip_atomic_fetch_add(&S.cb_acc[((size_t)xcd * S.cb_slots + s) * 2], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!(S.cb_touch[s] & 1u)) atomicOr(&S.cb_touch[s], 1u);
+    }
+    u64 todo = __ballot(direct);
+    while (todo) {  // rare: a generation without a slot, applied tile by tile by the whole wave (as accumulate_kernel)
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int d_b = __shfl(bb, src), d_head = __shfl(head, src);
+        const uint32_t m = __shfl(mask, src);
+        const f64 d_val = readlane_f64(val, src);
+        const int sl = (d_head - age + G) & (G - 1);
+        const int j = lane & 31;
+        if (lane < 32 && ((m >> j) & 1u)) {
+            const i32 f = S.tr_idx[((size_t)d_b * G + sl) * 32 + j];
+            __hip_atomic_fetch_add(&S.theta[f], d_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (P.memo) nzx_mark_late(P, S, f, sid);
+            const uint32_t bit = LOB_NZ_BIT(f);
+            if (!(S.theta_nz[LOB_NZ_WORD(f)] & bit)) {
+                const uint32_t old = atomicOr(&S.theta_nz[LOB_NZ_WORD(f)], bit);
+                if (!(old & bit) && P.carry_verdicts) {
+                    i32* nz_new = S.nz_new + par * LOB_NZ_WORDS;
+                    atomicAdd(&nz_new[0], 1);
+                    atomicOr((uint32_t*)&nz_new[LOB_NZ_FILTER + (LOB_NZ_WORD(f) & (LOB_NZ_FILTER - 1))], bit);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < LOB_ACB_TAB; i += LOB_ACB_BLOCK) {
+        const i32 k = keys[i];
+        if (k < 0) continue;
+        __hip_atomic_fetch_add(&S.cb_acc[((size_t)xcd * S.cb_slots + (uint32_t)k) * 2], sums[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!(S.cb_touch[(uint32_t)k] & 1u)) atomicOr(&S.cb_touch[(uint32_t)k], 1u);
     }
 }
 
