@@ -565,6 +565,14 @@ static int run_dropin_learner(const Args& a, Config& c, environment::GpuIntraday
                ep + 1, base.getEpisodeReward(), base.getEpisodePnL(), base.getMeanEpisodeReward(), base.getTotalTransactions(), (double)base.getOrderRatio(),
                gl.step_counter(), agent->policy->descr());
     }
+    if (auto tl = spdlog::get("training_log")) {   // (--log_learning 1) what GpuLearner handed to the training_log logger: the numeric columns
+        for (auto& row : tl->rows) {
+            if (row.empty()) continue;                 // the header line
+            printf("{\"training_log\": [");
+            for (size_t i = 0; i < row.size(); i++) printf("%s%.17g", i ? ", " : "", row[i]);
+            printf("]}\n");
+        }
+    }
     if (a.kv.count("stats_out")) base.writeStats(a.get("stats_out"));
     if (a.kv.count("theta_out")) {
         const std::string path = a.get("theta_out");

@@ -469,7 +469,10 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
         if (rc == LOB_OK) rc = dev_alloc(e, &S.cb_ident, (size_t)slots * 8);
         // SARSA(lambda) adds 1.6 M terms per step to the slots' sums: a copy of the sums per XCD (0.147 -> 0.100 ms; apply_kernel
         // 0.023 -> 0.03); Q(lambda)'s few additions are a latency chain that the copies do not shorten
-        S.cb_reps = (P.algo == LOB_ALGO_SARSA && P.memo) ? 8 : 1;
+        // ... and so do Watkins's Q(lambda) / double Q once the policy is mostly greedy (epsilon decays over the episodes: no cut,
+        // 25 generations per book, and the greedy books crowd onto a few (triple, action) pairs: 0.44 ms per step with one copy at
+        // epsilon = 0.01).  One copy per XCD for every algorithm on the fast path; apply_kernel adds them up.
+        S.cb_reps = P.memo ? 8 : 1;
         if (const char* g = getenv("LOB_ACC_REPS")) { int v = atoi(g); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) S.cb_reps = v; }
         if (rc == LOB_OK) rc = dev_alloc(e, &S.cb_acc, (size_t)S.cb_reps * slots * 2);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.cb_touch, (size_t)slots);
@@ -1014,6 +1017,7 @@ int lob_get_book(lob_engine* e, int32_t book, lob_book_dump* out) { return lob_g
 static int acc_lanes_shift(const lob_engine* e) {
     if (e->acc_shift >= 0) return e->acc_shift;
     if (e->P.algo == LOB_ALGO_SARSA && e->S.cb_reps > 1) return 6;  // (with a copy of the sums per XCD: 64 lanes 0.096 ms, 32 lanes 0.101)
+    if (e->P.policy == LOB_POLICY_EPS_GREEDY && e->P.epsilon < 0.34) return 6;  // (mostly greedy: Q(lambda)'s books keep their generations like SARSA's)
     return 5;
 }
 
@@ -1186,8 +1190,10 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
         if (mode == 0 && e->P.combine) {
             {
                 TimedLaunch t(e, "accumulate_kernel");
-                if (e->acc_block && e->P.algo == LOB_ALGO_SARSA && e->B >= 4 * LOB_ACB_BLOCK) {
-                    // SARSA(lambda): every book keeps all its generations -- sums per slot inside 1 024-book blocks first
+                // SARSA(lambda): every book keeps all its generations -- sums per slot inside 1 024-book blocks first.  The same for
+                // Q(lambda) once most actions are greedy (P(greedy) = 1 - eps + eps / 9 > 0.7: more than three live generations per book)
+                const bool many_gens = e->P.algo == LOB_ALGO_SARSA || (e->P.algo == LOB_ALGO_QLAMBDA && e->P.policy == LOB_POLICY_EPS_GREEDY && e->P.epsilon < 0.34);
+                if (e->acc_block && e->P.memo && many_gens && e->B >= 4 * LOB_ACB_BLOCK) {
                     hipLaunchKernelGGL(accumulate_block_kernel, dim3((e->B + LOB_ACB_BLOCK - 1) / LOB_ACB_BLOCK, e->P.trace_kmax), dim3(LOB_ACB_BLOCK), 0, e->stream, e->P, e->S, par, e->step_id);
                 } else {
                     const int sh = acc_lanes_shift(e);

@@ -1620,7 +1620,19 @@ __device__ inline void prepass_run(const EnvCtx& c, PrepState& st, BookMeta& M, 
     // the NEXT event and the time behind it are requested at the top of this one, the ring slots that fall out of the windows at
     // the next push right after this event's pushes.  An event that runs through more rows (same timestamp, invalid states)
     // reads them where it needs them and the pipeline restarts.
+#ifndef LOB_PRE_TOUCH
+#define LOB_PRE_TOUCH 0
+#endif
+#if LOB_PRE_TOUCH
+    // (-DLOB_PRE_TOUCH=1, measured and not taken: holding the NEXT row in registers as well needs 128 registers for the two rows
+    // and spills 164 bytes per lane to scratch -- 16.4 ms; with the row two events ahead only TOUCHED (one word of each of its
+    // four 64-byte sectors, so that it is in L2 when its turn comes) and the row an event applies read at the top of that event
+    // nothing spills, but the L2 round trip of 64 lanes x 14 divergent 16-byte loads is exposed in every event: 19.8 ms)
+    PreRow<TM> R0;
+    uint32_t nt[4] = {0u, 0u, 0u, 0u};
+#else
     PreRow<TM> R0, R1;
+#endif
     i32 t1 = 0, t2 = 0;
     bool piped = false;
     int band_px = 0, band_tk = 0;  // to_ticks_hint: the band of the last price / of the last tick count converted as a price
@@ -1629,9 +1641,20 @@ __device__ inline void prepass_run(const EnvCtx& c, PrepState& st, BookMeta& M, 
     acc_prep(S.f_vwap_numer, B, b, w_vn); acc_prep(S.f_vwap_denom, B, b, w_vd);
     while (!M.complete && k < k_stop) {
         const int first = m.cursor;
+#if LOB_PRE_TOUCH
+        {
+            const int last = c.S.n_events - 1;
+            const uint32_t* r2 = c.row(first + 2 < last ? first + 2 : last);
+            const int wl = P.Wd - 1;
+            nt[0] = r2[0]; nt[1] = r2[16 < wl ? 16 : wl]; nt[2] = r2[32 < wl ? 32 : wl]; nt[3] = r2[wl];
+        }
+        pre_row_issue<TM>(c, first, R0);
+        if (!piped) t1 = pre_row_time(c, first + 1);
+#else
         if (!piped) { pre_row_issue<TM>(c, first, R0); t1 = pre_row_time(c, first + 1); }
         pre_row_issue<TM>(c, first + 1, R1);
         t2 = pre_row_time(c, first + 2);
+#endif
         if (first < c.S.n_events && (R0.hdr.y & LOB_EVT_FLAG_TAS_DRY)) {
             // the time-and-sales stream has run dry (Streamer::LoadUntil fails, streamer.cpp:61-85): NextState returns
             // false before it touches the books -- out of data with nothing of this event applied (ex_first < 0)
@@ -1760,7 +1783,13 @@ __device__ inline void prepass_run(const EnvCtx& c, PrepState& st, BookMeta& M, 
         if (k + 1 == M.k_warm) prev_first = m.rec_cur;
         k++;
         piped = m.cursor == first + 1;  // one row applied: what was requested at the top is what the next event starts with
+#if LOB_PRE_TOUCH
+        t2 = (i32)nt[0];
+        asm volatile("" ::"v"(nt[1]), "v"(nt[2]), "v"(nt[3]));  // (the touches are loads somebody waits for -- here, an event after they left)
+        if (piped) t1 = t2;
+#else
         if (piped) { R0 = R1; t1 = t2; }
+#endif
     }
     rm_store(S.f_midprice, b, w_mid); rm_store(S.f_volatility, b, w_vol); rm_store(S.spread_window, b, w_spr);
     rm_store(S.tp_mp, b, w_tp); rm_store(S.f_ask_tx, b, w_atx); rm_store(S.f_bid_tx, b, w_btx);

@@ -104,6 +104,14 @@ protected:
 public:
     GpuLearner(Config& c, environment::GpuIntraday& env, int steps_per_call = 8) : Runner(c, env), genv_(env), steps_per_call_(steps_per_call < 1 ? 1 : steps_per_call) {
         if (!env.device_learning()) throw std::invalid_argument("GpuLearner needs an environment::GpuIntraday built for device learning");
+        // Learner::Learner (src/experiment/serial.cpp:38-51): the per-episode training log, same logger name, same header
+        if (c["logging"] and c["logging"]["log_learning"].as<bool>()) {
+            try {
+                auto log = spdlog::rotating_logger_mt("training_log", c["output_dir"].as<std::string>() + "training_log.csv",
+                                                      c["logging"]["max_size"].as<size_t>(), 1);
+                log->info("episode,episode_id,reward,pnl,n_steps,epsilon");
+            } catch (spdlog::spdlog_ex& e) {}
+        }
     }
     unsigned long step_counter() const { return _step_counter; }
 
@@ -121,6 +129,11 @@ public:
         m->HandleTerminal(_episode_counter++);                          // the reference's schedules: alpha, and the policy's epsilon / tau
         push_schedules(m, ga);
         genv_.refresh();     // book 0's episode totals / statistics into Base's members (getEpisodeReward() ... getTotalTransactions())
+        // the row Learner::RunEpisode writes (serial.cpp:81-88), book 0's episode; no row without the logger (the reference
+        // dereferences a null pointer there when logging.log_learning is off)
+        if (auto log = spdlog::get("training_log"))
+            log->info("{},{},{},{},{},{}", _episode_counter, environment.getEpisodeId(), environment.getEpisodeReward(), environment.getEpisodePnL(),
+                      _step_counter, m->policy->descr());
         ga->pull_theta();    // write_theta() is not virtual: keep the host copy current
         return true;
     }

@@ -98,7 +98,14 @@ def _run_learner(tmp_path, name, books, episodes=1, extra=()):
            "--episodes", str(episodes), "--theta_out", th, "--stats_out", st, "--tmp", str(tmp_path / "h")] + list(extra)
     res = subprocess.run(cmd, capture_output=True, text=True)
     assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
-    eps = [json.loads(l) for l in res.stdout.strip().splitlines() if l.startswith("{")]
+    lines = [json.loads(l) for l in res.stdout.strip().splitlines() if l.startswith("{")]
+    eps = [d for d in lines if "episode" in d]
+    # the rows GpuLearner handed to the reference's "training_log" logger (Learner::RunEpisode, serial.cpp:81-88): episode, reward,
+    # pnl, n_steps, epsilon -- one per episode, the numbers Base's getters report
+    tlog = [d["training_log"] for d in lines if "training_log" in d]
+    assert len(tlog) == len(eps) == episodes
+    for e, row in zip(eps, tlog):
+        assert row == [e["episode"], e["reward"], e["pnl"], e["steps"], e["descr"]]
     return case, rec, eps, _sparse_theta(th), open(st).read()
 
 
