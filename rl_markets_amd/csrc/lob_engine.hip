@@ -46,6 +46,8 @@ struct lob_engine {
     hipEvent_t ev_rest_go = nullptr, ev_rest_done = nullptr;  // learn_q_rest_kernel on stream2 beside the trace kernels
     bool rest_side = true;      // (LOB_REST_SIDE=0: on the main stream, as before; A/B switch)
     bool acc_block = true;      // SARSA(lambda): accumulate_block_kernel (LOB_ACC_BLOCK=0: accumulate_kernel; A/B switch)
+    int env_step_lanes = 64;    // books per wave of env_step_kernel (LOB_ENV_STEP_LANES=32: two half-full waves per SIMD; experiment)
+    bool prepass_roles = false; // the pre-pass on two waves per 64 books (reset2_kernel / prepass_extend2_kernel; LOB_PREPASS_ROLES=1): measured slower, opt-in
     i32* rest_hint = nullptr;   // host-mapped word learn_q_rest_kernel writes its list's length to
     i32* rest_hint_dev = nullptr;
     int rest_recent = 0;        // steps left to keep the launch on the second stream after the last non-empty list seen
@@ -301,6 +303,8 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     HIPCHK_E(hipEventCreateWithFlags(&e->ev_rest_done, hipEventDisableTiming | hipEventDisableSystemFence));
     if (const char* g = getenv("LOB_REST_SIDE")) e->rest_side = !(g[0] == '0');
     if (const char* g = getenv("LOB_ACC_BLOCK")) e->acc_block = !(g[0] == '0');
+    if (const char* g = getenv("LOB_ENV_STEP_LANES")) { if (atoi(g) == 32) e->env_step_lanes = 32; }
+    if (const char* g = getenv("LOB_PREPASS_ROLES")) e->prepass_roles = g[0] == '1';
     if (hipHostMalloc((void**)&e->rest_hint, sizeof(i32), hipHostMallocMapped) == hipSuccess) {
         *e->rest_hint = 0;
         if (hipHostGetDevicePointer((void**)&e->rest_hint_dev, e->rest_hint, 0) != hipSuccess) e->rest_hint_dev = nullptr;
@@ -795,6 +799,11 @@ static void maybe_refill_track(lob_engine* e) {
     if (!e->chunked || ++e->steps_since_fill < e->track_refill) return;
     e->steps_since_fill = 0;
     TimedLaunch t(e, "prepass_extend_kernel", nullptr, true);
+    if (e->prepass_roles) {
+        if (e->P.T <= 2) hipLaunchKernelGGL(prepass_extend2_kernel<2>, dim3((e->B + 63) / 64), dim3(128), 0, e->stream, (const DevParams*)e->P_dev, e->S);
+        else hipLaunchKernelGGL(prepass_extend2_kernel<LOB_MAX_TRADES>, dim3((e->B + 63) / 64), dim3(128), 0, e->stream, (const DevParams*)e->P_dev, e->S);
+        return;
+    }
     if (e->P.T <= 2) hipLaunchKernelGGL(prepass_extend_kernel<2>, dim3((e->B + 63) / 64), dim3(64), 0, e->stream, (const DevParams*)e->P_dev, e->S);
     else hipLaunchKernelGGL(prepass_extend_kernel<LOB_MAX_TRADES>, dim3((e->B + 63) / 64), dim3(64), 0, e->stream, (const DevParams*)e->P_dev, e->S);
 }
@@ -820,13 +829,15 @@ static void launch_env_fused(lob_engine* e, hipStream_t st, int par, int lpar, u
     // 64-lane wave going through its books one at a time.  The learn kernels hand the same books back: their list's length,
     // reported through the host-mapped word (a few steps late), tells.
     const bool mostly_general = e->rest_hint && *(volatile i32*)e->rest_hint > e->B / 16;
-    const bool inline_general = t2 && e->env_step && e->inline_general && e->steps_on_lists >= 1 && !mostly_general;
+    const bool half_waves = e->env_step_lanes == 32 && t2 && e->env_step && e->P.algo != LOB_ALGO_DOUBLE_Q;  // (experiment: LOB_ENV_STEP_LANES=32)
+    const bool inline_general = t2 && e->env_step && e->inline_general && e->steps_on_lists >= 1 && !mostly_general && !half_waves;
     e->steps_on_lists++;
     const bool dq = e->P.algo == LOB_ALGO_DOUBLE_Q;  // (then t2 && env_step: lob_create)
     {
         TimedLaunch t(e, "env_kernel", st);
         if (inline_general && dq) hipLaunchKernelGGL((env_step_kernel<true, true>), dim3((nb + 63) / 64), dim3(64), 0, st, Pd, e->S, sid, par, F1, (const uint32_t*)e->rnd_dev);
         else if (dq) hipLaunchKernelGGL((env_step_kernel<false, true>), dim3((nb + 63) / 64), dim3(64), 0, st, Pd, e->S, sid, par, F1, (const uint32_t*)e->rnd_dev);
+        else if (half_waves) hipLaunchKernelGGL((env_step_kernel<false, false, 32>), dim3((nb + 31) / 32), dim3(64), 0, st, Pd, e->S, sid, par, F1, (const uint32_t*)e->rnd_dev);
         else if (inline_general) hipLaunchKernelGGL(env_step_kernel<true>, dim3((nb + 63) / 64), dim3(64), 0, st, Pd, e->S, sid, par, F1, (const uint32_t*)e->rnd_dev);
         else if (t2 && e->env_step) hipLaunchKernelGGL(env_step_kernel<false>, dim3((nb + 63) / 64), dim3(64), 0, st, Pd, e->S, sid, par, F1, (const uint32_t*)e->rnd_dev);
         else if (t2) hipLaunchKernelGGL((env_kernel<64, 2, 1>), dim3((nb + 63) / 64), dim3(64), 0, st, Pd, e->S, (const i32*)nullptr, 1, 0, nb, sid, par, F1);
@@ -890,7 +901,11 @@ int lob_reset(lob_engine* e) {
         const DevParams* Pd = (const DevParams*)e->P_dev;
         const bool t2 = e->P.T <= 2;
 #define LOB_RESET_LAUNCH(L, TM) hipLaunchKernelGGL((reset_kernel<L, TM>), dim3((e->B + L - 1) / L), dim3(L), 0, e->stream, Pd, e->S)
-        if (rb == 32) { if (t2) LOB_RESET_LAUNCH(32, 2); else LOB_RESET_LAUNCH(32, LOB_MAX_TRADES); }
+        if (e->prepass_roles && rb == 64) {  // the pre-pass on two waves per 64 books (LOB_PREPASS_ROLES=0: one)
+            if (t2) hipLaunchKernelGGL(reset2_kernel<2>, dim3((e->B + 63) / 64), dim3(128), 0, e->stream, Pd, e->S);
+            else hipLaunchKernelGGL(reset2_kernel<LOB_MAX_TRADES>, dim3((e->B + 63) / 64), dim3(128), 0, e->stream, Pd, e->S);
+        }
+        else if (rb == 32) { if (t2) LOB_RESET_LAUNCH(32, 2); else LOB_RESET_LAUNCH(32, LOB_MAX_TRADES); }
         else if (rb == 16) { if (t2) LOB_RESET_LAUNCH(16, 2); else LOB_RESET_LAUNCH(16, LOB_MAX_TRADES); }
         else { if (t2) LOB_RESET_LAUNCH(64, 2); else LOB_RESET_LAUNCH(64, LOB_MAX_TRADES); }
 #undef LOB_RESET_LAUNCH

@@ -1595,6 +1595,32 @@ __device__ inline void prepass_begin(const EnvCtx& c, PrepState& st, BookMeta& M
     st.prev_first = m.rec_cur;  // Initialise: time_and_sales.SkipUntil(market time) drops everything up to here
 }
 
+// (prepass_begin without the windows: the two-wave pre-pass's book role; the window role clears the windows itself)
+__device__ inline void prepass_begin_books(const EnvCtx& c, PrepState& st, BookMeta& M) {
+    const DevParams& P = c.P;
+    MarketR m;
+    m.cursor = 0; m.time_ms = 0; m.rec_cur = -1; m.rec_last = -1;
+    m.ap0 = m.bp0 = m.lap0 = m.lbp0 = 0.0;
+    m.a_tv = m.b_tv = 0;
+    m.a_obsval = m.b_obsval = 0.0; m.a_obsvol = m.b_obsvol = 0;
+    m.ewma_up = m.ewma_down = m.tp_val = 0.0;
+    m.records = 0;
+    M.n_track = 0; M.k_warm = -1; M.init_ok = 0; M.complete = 0; M._pad = 0;
+    M.ex_first = -1; M.ex_cur = -1; M.ex_last = -1; M.ex_time = 0; M.ex_records = 0;
+    bool ok = true;
+    while (ok && !is_open(P, m.time_ms)) ok = mk_update_book_profiles(c, m);
+    M.rec_cur0 = m.rec_cur; M.rec_last0 = m.rec_last; M.time0 = m.time_ms;
+    M.mid0 = (m.ap0 + m.bp0) / 2.0; M.mid_prev0 = (m.lap0 + m.lbp0) / 2.0;
+    if (!ok) { M.ex_cur = m.rec_cur; M.ex_last = m.rec_last; M.ex_time = m.time_ms; M.complete = 1; }
+    st.cursor = m.cursor; st.time_ms = m.time_ms; st.rec_cur = m.rec_cur; st.rec_last = m.rec_last;
+    st.ap0 = m.ap0; st.bp0 = m.bp0; st.lap0 = m.lap0; st.lbp0 = m.lbp0;
+    st.a_tv = m.a_tv; st.b_tv = m.b_tv;
+    st.ewma_up = st.ewma_down = st.tp_val = 0.0;
+    st.records = m.records;
+    st.k = 0;
+    st.prev_first = m.rec_cur;  // Initialise: time_and_sales.SkipUntil(market time) drops everything up to here
+}
+
 template <int TM>
 __device__ inline void prepass_run(const EnvCtx& c, PrepState& st, BookMeta& M, int k_stop, bool write_track) {
     const DevParams& P = c.P;
@@ -1806,6 +1832,266 @@ __device__ inline void prepass_run(const EnvCtx& c, PrepState& st, BookMeta& M, 
         M.n_track = k;
         M.init_ok = M.k_warm > 0 ? 1 : 0;
     }
+}
+
+
+// ---- the pre-pass on TWO waves per 64 books ----------------------------------------------------------------------------
+// prepass_run is one wave executing ~2 100 dependent instructions per event at ~9 clocks each, one wave per SIMD: the chip
+// issues an instruction every ninth clock.  Half of those instructions are the book (row, trades, validity, tick conversions),
+// half the ten windows and the state variables, and the second half needs nine numbers of the first.  So a block is two
+// waves over the same 64 books: wave 0 ("books") runs Intraday::UpdateBookProfiles and hands every event's numbers over
+// through LDS, wave 1 ("windows") is one event behind with the pushes and the variables; two such blocks share a SIMD
+// (registers: the larger of the two roles) and fill each other's stalls.  One block barrier per event.  The arithmetic is
+// prepass_run's, statement for statement; each role writes its own 64-byte half of the track entry.
+// Block barrier that orders LDS traffic only.  __syncthreads() also waits for every global load and store the wave has in flight
+// -- here the row touches, the ring slots requested for the NEXT event and the track stores, all of which are meant to stay in
+// flight across the hand-over.  (This compiler emits s_waitcnt lgkmcnt(0) + s_barrier for __syncthreads() in these kernels as
+// well; the explicit form states the requirement.)
+__device__ inline void lds_block_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+struct PreXch {  // what the book role hands the window role for one event (one buffer; struct-of-arrays: conflict-free)
+    i64 mpt[64], a_obsvol[64], b_obsvol[64], a_tv[64], b_tv[64];
+    f64 sp[64], mpm[64], tp_in[64], obsval[64];
+    i32 spd[64], live[64];
+    i32 go, _pad;
+};
+// The two roles are loops of their own (one loop body holding both kept both roles' state live: 340 registers spilled; as separate
+// loops their live ranges are disjoint); they run the same number of block barriers.
+// `on`: this lane takes part (block-uniform control flow: every lane runs the loop).
+template <int TM>
+__device__ inline void prepass_books_role(const DevParams* Pp, const DevState* Sp, int b, const uint32_t* rows, const TickLds* tk, PrepState* stp, BookMeta* Mp,
+                                                int k_stop, bool on, PreXch* xch, int lane) {
+    const DevParams& P = *Pp;
+    const DevState& S = *Sp;
+    const EnvCtx c(P, S, b, tk, rows);
+    PrepState& st = *stp;
+    BookMeta& M = *Mp;
+    MarketR m;
+    m.cursor = st.cursor; m.time_ms = st.time_ms; m.rec_cur = st.rec_cur; m.rec_last = st.rec_last;
+    m.ap0 = st.ap0; m.bp0 = st.bp0; m.lap0 = st.lap0; m.lbp0 = st.lbp0;
+    m.a_tv = st.a_tv; m.b_tv = st.b_tv;
+    m.a_obsval = m.b_obsval = 0.0; m.a_obsvol = m.b_obsvol = 0;
+    m.ewma_up = m.ewma_down = m.tp_val = 0.0;
+    m.records = st.records;
+    int k = st.k;
+    int prev_first = st.prev_first;
+    PreRow<TM> R0;
+    uint32_t nt[4] = {0u, 0u, 0u, 0u};
+    i32 t1 = 0;
+    bool piped = false;
+    int band_px = 0;
+    // every window is pushed once per event from a count of zero (prepass_begin): all are full after max(w) events -- where
+    // Intraday::Initialise stops pulling events (intraday.cpp:119-128).  The book role needs that event (the closing
+    // SkipUntil, below) and does not see the windows.
+    int w_max = S.f_midprice.w;
+    {
+        const int ws[] = {S.f_volatility.w, S.f_ask_tx.w, S.f_bid_tx.w, S.spread_window.w, S.tp_mp.w, S.f_vwap_numer.w, S.f_vwap_denom.w};
+        for (int w : ws) w_max = w > w_max ? w : w_max;
+    }
+#pragma unroll 1
+    for (int it = 0;; it++) {
+        PreXch& X = xch[it & 1];
+        int live = 0;
+        if (on && !M.complete && k < k_stop) {
+            do {  // (one event; `break` = the stream ends here, nothing produced)
+                const int first = m.cursor;
+                {   // the row two events ahead is touched (it is in L2 when its turn comes; its first word is the time the event
+                    // before it compares with); the other wave of the SIMD runs while this one waits for its own row
+                    const int last = c.S.n_events - 1;
+                    const uint32_t* r2 = c.row(first + 2 < last ? first + 2 : last);
+                    const int wl = P.Wd - 1;
+                    nt[0] = r2[0]; nt[1] = r2[16 < wl ? 16 : wl]; nt[2] = r2[32 < wl ? 32 : wl]; nt[3] = r2[wl];
+                }
+                pre_row_issue<TM>(c, first, R0);
+                if (!piped) t1 = pre_row_time(c, first + 1);
+                if (first < c.S.n_events && (R0.hdr.y & LOB_EVT_FLAG_TAS_DRY)) {
+                    M.ex_first = -1; M.ex_cur = m.rec_cur; M.ex_last = m.rec_last; M.ex_time = m.time_ms; M.ex_records = 0;
+                    M.complete = 1;
+                    break;
+                }
+                f64 tp[TM];
+                i64 tv[TM];
+                if (prev_first + 1 == first) {
+#pragma unroll
+                    for (int i = 0; i < TM; i++) { tp[i] = 0.0; tv[i] = 0; }
+                    int ntr = 0;
+                    merge_trade_slots<TM>(c, R0.tr, ntr, tp, tv);
+                } else {
+                    load_trades<TM>(c, prev_first + 1, first, tp, tv);
+                }
+                prev_first = first;
+                const f64 mp = (m.ap0 + m.bp0) / 2.0;
+                m.a_obsval = 0.0; m.a_obsvol = 0; m.b_obsval = 0.0; m.b_obsvol = 0;
+#pragma unroll
+                for (int i = 0; i < TM; i++) {
+                    if (i >= P.T || tv[i] <= 0) continue;
+                    if (tp[i] < mp) continue;
+                    m.a_obsval += tp[i] * (f64)tv[i];
+                    m.a_obsvol += tv[i];
+                }
+#pragma unroll
+                for (int ii = 0; ii < TM; ii++) {
+                    const int i = TM - 1 - ii;
+                    if (i >= P.T || tv[i] <= 0) continue;
+                    if (tp[i] > mp) continue;
+                    m.b_obsval += tp[i] * (f64)tv[i];
+                    m.b_obsvol += tv[i];
+                }
+                const i64 rec0 = m.records;
+                if (!mk_update_book_profiles_pre<TM>(c, m, R0, t1)) {
+                    M.ex_first = first; M.ex_cur = m.rec_cur; M.ex_last = m.rec_last; M.ex_time = m.time_ms;
+                    M.ex_records = m.records - rec0;
+                    M.complete = 1;
+                    break;
+                }
+                if (m.lap0 == 0.0 || m.lbp0 == 0.0) c.err(LOB_ERR_UNDEF_PRICE);
+                const f64 mid = (m.ap0 + m.bp0) / 2.0, lmid = (m.lap0 + m.lbp0) / 2.0;
+                const int tick_ap0 = lobh::to_ticks_hint((*c.tk), m.ap0, band_px), tick_bp0 = lobh::to_ticks_hint((*c.tk), m.bp0, band_px);
+                const i64 mpt = (i64)lobh::to_ticks_hint((*c.tk), mid, band_px);
+                const f64 mpm = mid - lmid, sp = m.ap0 - m.bp0;
+                f64 micro;
+                {   // measure::microprice (measures.h:40-55)
+                    f64 div = (f64)(m.a_tv + m.b_tv);
+                    f64 mpm_a = (f64)m.a_tv * m.bp0, mpm_b = m.ap0 * (f64)m.b_tv;
+                    micro = (mpm_a + mpm_b) / div;
+                }
+                X.mpt[lane] = mpt; X.a_obsvol[lane] = m.a_obsvol; X.b_obsvol[lane] = m.b_obsvol; X.a_tv[lane] = m.a_tv; X.b_tv[lane] = m.b_tv;
+                X.sp[lane] = sp; X.mpm[lane] = mpm; X.tp_in[lane] = P.target_price == LOB_TP_MICROPRICE ? micro : mid;
+                X.obsval[lane] = m.a_obsval + m.b_obsval;
+                X.spd[lane] = tick_ap0 - tick_bp0;
+                {   // the entry's first half: which rows, time, touch, midprice, the merged trade list
+                    TrackHead64 t;
+                    t.rec_first = first; t.rec_last = m.rec_cur; t.time_ms = m.time_ms;
+                    t.tick_ap0 = tick_ap0; t.tick_bp0 = tick_bp0;
+                    int ntr = 0;
+#pragma unroll
+                    for (int i = 0; i < TM; i++) ntr += (i < P.T && tv[i] > 0) ? 1 : 0;
+                    t.info = (ntr < 2 ? ntr : 2) | (ntr <= 2 ? LOB_TRK_TRADES_OK : 0);
+                    t.mid = mid;
+                    t.tr_px[0] = (f32)tp[0]; t.tr_vol[0] = tv[0];
+                    t.tr_px[1] = TM > 1 ? (f32)tp[TM > 1 ? 1 : 0] : 0.0f; t.tr_vol[1] = TM > 1 ? tv[TM > 1 ? 1 : 0] : 0;
+                    t.bap = (f32)m.ap0; t.bbp = (f32)m.bp0;
+                    *reinterpret_cast<TrackHead64*>(&c.track_w(k)) = t;
+                }
+                if (M.k_warm < 0 && k + 1 >= w_max) M.k_warm = k + 1;
+                if (k + 1 == M.k_warm) prev_first = m.rec_cur;  // Initialise's closing SkipUntil (intraday.cpp:130)
+                k++;
+                live = 1;
+                piped = m.cursor == first + 1;
+                asm volatile("" ::"v"(nt[1]), "v"(nt[2]), "v"(nt[3]));
+                if (piped) t1 = (i32)nt[0];
+            } while (false);
+        }
+        X.live[lane] = live;
+        const int more = __any(on && !M.complete && k < k_stop) ? 1 : 0;
+        if (lane == 0) X.go = more;
+        lds_block_barrier();
+        if (!more) break;
+    }
+    st.cursor = m.cursor; st.time_ms = m.time_ms; st.rec_cur = m.rec_cur; st.rec_last = m.rec_last;
+    st.ap0 = m.ap0; st.bp0 = m.bp0; st.lap0 = m.lap0; st.lbp0 = m.lbp0;
+    st.a_tv = m.a_tv; st.b_tv = m.b_tv;
+    st.records = m.records;
+    st.k = k;
+    st.prev_first = prev_first;
+    M.n_track = k;
+    M.init_ok = M.k_warm > 0 ? 1 : 0;
+}
+__device__ inline void prepass_windows_role(const DevParams* Pp, const DevState* Sp, int b, const TickLds* tk, PrepState* stp, bool on, PreXch* xch, int lane) {
+    const DevParams& P = *Pp;
+    const DevState& S = *Sp;
+    const int B = S.B;
+    PrepState& st = *stp;
+    f64 ewma_up = st.ewma_up, ewma_down = st.ewma_down, tp_val = st.tp_val;
+    int k = st.k;
+    int band_tk = 0;
+    Track* track_b = S.track + (size_t)b * (size_t)S.track_len;
+    RMReg w_mid, w_vol, w_spr, w_tp, w_atx, w_btx;
+    AccReg w_vn, w_vd;
+    if (on) {
+        rm_load(S.f_midprice, b, w_mid); rm_load(S.f_volatility, b, w_vol); rm_load(S.spread_window, b, w_spr);
+        rm_load(S.tp_mp, b, w_tp); rm_load(S.f_ask_tx, b, w_atx); rm_load(S.f_bid_tx, b, w_btx);
+        acc_load(S.f_vwap_numer, b, w_vn); acc_load(S.f_vwap_denom, b, w_vd);
+        rm_prep(S.f_midprice, B, b, w_mid); rm_prep(S.f_volatility, B, b, w_vol); rm_prep(S.spread_window, B, b, w_spr);
+        rm_prep(S.tp_mp, B, b, w_tp); rm_prep(S.f_ask_tx, B, b, w_atx); rm_prep(S.f_bid_tx, B, b, w_btx);
+        acc_prep(S.f_vwap_numer, B, b, w_vn); acc_prep(S.f_vwap_denom, B, b, w_vd);
+    }
+#pragma unroll 1
+    for (int it = 0;; it++) {
+        PreXch& X = xch[it & 1];
+        lds_block_barrier();
+        const int go = X.go;
+        if (on && X.live[lane]) {
+            const i64 mpt = X.mpt[lane], a_obsvol = X.a_obsvol[lane], b_obsvol = X.b_obsvol[lane], a_tv = X.a_tv[lane], b_tv = X.b_tv[lane];
+            const f64 sp = X.sp[lane], mpm = X.mpm[lane], tp_in = X.tp_in[lane], obsval = X.obsval[lane];
+            const int spd_ticks = X.spd[lane];
+            rm_apply_reg(S.f_midprice, B, b, w_mid, (f64)mpt);
+            rm_apply_reg(S.f_volatility, B, b, w_vol, (f64)mpt);
+            acc_apply_reg(S.f_vwap_numer, B, b, w_vn, obsval);
+            acc_apply_reg(S.f_vwap_denom, B, b, w_vd, (f64)(a_obsvol + b_obsvol));
+            rm_apply_reg(S.spread_window, B, b, w_spr, 0.0 > sp ? 0.0 : sp);
+            rm_apply_reg(S.tp_mp, B, b, w_tp, tp_in);  // TargetPrice::update (src/market/target_price.cpp:44-71)
+            tp_val = w_tp.mean;
+            {   // EWMA<double>::push (accumulators.cpp:157-163)
+                f64 up = 0.0 > mpm ? 0.0 : mpm;
+                f64 dn = fabs(0.0 < mpm ? 0.0 : mpm);
+                ewma_up = (P.ewma_alpha * up) + ((1 - P.ewma_alpha) * ewma_up);
+                ewma_down = (P.ewma_alpha * dn) + ((1 - P.ewma_alpha) * ewma_down);
+            }
+            rm_apply_reg(S.f_ask_tx, B, b, w_atx, (f64)a_obsvol);
+            rm_apply_reg(S.f_bid_tx, B, b, w_btx, (f64)b_obsvol);
+            rm_prep(S.f_midprice, B, b, w_mid); rm_prep(S.f_volatility, B, b, w_vol); rm_prep(S.spread_window, B, b, w_spr);
+            rm_prep(S.tp_mp, B, b, w_tp); rm_prep(S.f_ask_tx, B, b, w_atx); rm_prep(S.f_bid_tx, B, b, w_btx);
+            acc_prep(S.f_vwap_numer, B, b, w_vn); acc_prep(S.f_vwap_denom, B, b, w_vd);
+            {   // the entry's second half: target price, spread mean, cumulative volumes, the stream-only state variables
+                struct __attribute__((aligned(16))) Half { f64 tp_val, spread_mean; i64 a_tv, b_tv; f32 mv[8]; } h;
+                h.tp_val = tp_val; h.spread_mean = w_spr.mean; h.a_tv = a_tv; h.b_tv = b_tv;
+                h.mv[LOB_MV_SPD] = (f32)ulb((f64)spd_ticks, 0.0, 20.0);
+                {
+                    const f64 front = (f64)mpt;
+                    i32 bi = w_mid.head - w_mid.cnt + 1;
+                    if (bi < 0) bi += S.f_midprice.w;
+                    const f64 back = w_mid.cnt == S.f_midprice.w ? w_mid.old : S.f_midprice.ring[(size_t)bi * B + b];
+                    h.mv[LOB_MV_MPM] = (f32)ulb((f64)(lobh::to_ticks_hint((*tk), front, band_tk) - lobh::to_ticks_hint((*tk), back, band_tk)), -10.0, 10.0);
+                }
+                {
+                    f64 v_a = (f64)a_tv, v_b = (f64)b_tv;
+                    h.mv[LOB_MV_IMB] = (f32)((v_a + v_b) > 0 ? 5 * (v_b - v_a) / (v_b + v_a) : 0.0);
+                    f64 q_a = w_atx.sum, q_b = w_btx.sum;
+                    h.mv[LOB_MV_SVL] = (f32)((q_a + q_b) > 0 ? 5 * (q_b - q_a) / (q_a + q_b) : 0.0);
+                }
+                {
+                    f64 var = w_vol.s / (f64)(w_vol.cnt - 1);
+                    f64 sd = var > 0 ? sqrt(var) : 0.0;
+                    h.mv[LOB_MV_VOL] = (f32)ulb(5.0 * sd, 0.0, 10.0);
+                    f64 u = ewma_up, d = ewma_down;
+                    h.mv[LOB_MV_RSI] = (f32)((u + d) != 0.0 ? 5.0 * (u - d) / (u + d) : 0.0);
+                    f64 vw = w_vn.sum / w_vd.sum;
+                    h.mv[LOB_MV_VWAP] = (f32)ulb(vw / w_spr.mean, -10.0, 10.0);
+                    h.mv[7] = 0.0f;
+                }
+                static_assert(sizeof(Half) == 64, "the second half of a Track entry");
+                *reinterpret_cast<Half*>(reinterpret_cast<char*>(&track_b[(size_t)(k & S.track_mask)]) + 64) = h;
+            }
+            k++;
+        }
+        if (!go) break;
+    }
+    if (on) {
+        rm_store(S.f_midprice, b, w_mid); rm_store(S.f_volatility, b, w_vol); rm_store(S.spread_window, b, w_spr);
+        rm_store(S.tp_mp, b, w_tp); rm_store(S.f_ask_tx, b, w_atx); rm_store(S.f_bid_tx, b, w_btx);
+        acc_store(S.f_vwap_numer, b, w_vn); acc_store(S.f_vwap_denom, b, w_vd);
+        st.ewma_up = ewma_up; st.ewma_down = ewma_down; st.tp_val = tp_val;
+        S.ewma_up[b] = ewma_up; S.ewma_down[b] = ewma_down; S.tp_val[b] = tp_val;
+    }
+}
+template <int TM>
+__device__ inline void prepass_run2(const EnvCtx& c, PrepState& st, BookMeta& M, int k_stop, bool on, int role, PreXch* xch, int lane) {
+    if (role == 0) prepass_books_role<TM>(&c.P, &c.S, c.b, c.rows, c.tk, &st, &M, k_stop, on, xch, lane);
+    else prepass_windows_role(&c.P, &c.S, c.b, c.tk, &st, on, xch, lane);
 }
 
 #endif

@@ -41,19 +41,24 @@ __device__ inline Track track_load(const Track* p) {
 // DQ: DoubleQLearn on the fast path (DoubleAgent::action, agent.cpp:196-204): Q_a and Q_b continue from the memo's two records
 // with the same listed additions under theta / theta_b, the policy sees (Q_a + Q_b) / 2, both vectors' values are kept for the
 // learn kernel (qs_last, qs_last_b).
-template <bool INLINE_GENERAL, bool DQ = false>
-__global__ void __launch_bounds__(64) env_step_kernel(const DevParams* __restrict__ Pp, DevState S, int step_id, int par, EnvFuse F, const uint32_t* __restrict__ rnd_g) {
+// LANES: books per wave.  64; or 32 with the register budget of TWO waves per SIMD (an experiment, LOB_ENV_STEP_LANES=32: the
+// kernel is one dependent instruction stream per wave at one wave per SIMD -- two half-full waves per SIMD fill each other's
+// stalls if they fit; they only fit by spilling, see NOTES).
+template <int LANES> struct EnvStepOcc { static constexpr int waves = LANES == 64 ? 1 : 2; };
+template <bool INLINE_GENERAL, bool DQ = false, int LANES = 64>
+__global__ void __launch_bounds__(64, EnvStepOcc<LANES>::waves) env_step_kernel(const DevParams* __restrict__ Pp, DevState S, int step_id, int par, EnvFuse F, const uint32_t* __restrict__ rnd_g) {
+    static_assert(LANES == 64 || !INLINE_GENERAL, "the half-full variant leaves the books without a list to the work list");
     const DevParams& P = *Pp;
     __shared__ TickLds tick_lds;
-    __shared__ EnvSlot lds_env[64];
+    __shared__ EnvSlot lds_env[LANES];
     __shared__ LearnLds1 lds_learn;
 #ifdef LOB_PROF
     const long long t_entry = clock64();
 #else
     const long long t_entry = 0;
 #endif
-    const int t = blockIdx.x * 64 + threadIdx.x;
-    const bool valid = t < S.B;
+    const int t = blockIdx.x * LANES + (int)threadIdx.x;
+    const bool valid = (int)threadIdx.x < LANES && t < S.B;
     const int b = valid ? t : S.B - 1;  // (lanes past the batch fetch the last book's inputs and do nothing with them)
     const int B = S.B;
 
@@ -89,8 +94,8 @@ __global__ void __launch_bounds__(64) env_step_kernel(const DevParams* __restric
         tick_lds.lb[i] = tk_lb; tick_lds.tick[i] = tk_tick; tick_lds.cum[i] = tk_cum; tick_lds.pp[i] = tk_pp; tick_lds.pt[i] = tk_pt;
     }
     if (threadIdx.x == 0) tick_lds.n = P.n_bands;
-    EnvR& e = lds_env[threadIdx.x].e;
-    e = er;
+    EnvR& e = lds_env[threadIdx.x & (LANES - 1)].e;  // (the idle upper half of a 32-book wave writes the slots of lanes that do nothing with them)
+    if (LANES == 64 || threadIdx.x < LANES) e = er;
     __syncthreads();
 
     // ---- who steps, and from which list (act_light_book) ----------------------------------------------------------------

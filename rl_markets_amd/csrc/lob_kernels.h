@@ -175,6 +175,101 @@ __global__ void __launch_bounds__(RB) reset_kernel(const DevParams* __restrict__
     atomicAdd((u64*)&S.counters[1], (u64)(e.events - ev0));  // warm-up events count as consumed
 }
 
+// reset_kernel<64, TM> with the pre-pass on two waves per 64 books (lob_env.h prepass_run2): wave 0 of the block is the books'
+// row / trade / tick side and, after the loop, everything reset_kernel does with the result; wave 1 the windows' side.
+// OPT-IN (LOB_PREPASS_ROLES=1), bit-exact, measured SLOWER than the one-wave kernel: 20.6 ms against 16.4 -- the roles alone take
+// 14.2 and 9.2 ms and together almost their sum, although nothing they share (LDS, scalar unit, VALU) is near saturation by the
+// counters of the one-wave kernel; what doubles is the number of waves fetching instructions from a 54 KB kernel body.
+template <int TM>
+__global__ void __launch_bounds__(128, 2) reset2_kernel(const DevParams* __restrict__ Pp, DevState S) {
+    const DevParams& P = *Pp;
+    __shared__ TickLds tick_lds;
+    __shared__ PreXch xch[2];
+    __shared__ EnvSlot lds_env[64];
+    stage_ticks(P, tick_lds);
+    const int role = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 64 + lane;
+    const bool on = t < S.B;
+    const int b = on ? t : S.B - 1;
+    EnvCtx c(P, S, b, &tick_lds);
+    EnvR& e = lds_env[lane].e;
+    i64 ev0 = 0;
+    BookMeta M;
+    PrepState st;
+    memset(&st, 0, sizeof st);
+    memset(&M, 0, sizeof M);
+    if (role == 0) {
+        if (on) env_load(S, b, e);  // position, pnl_step, quote levels etc. persist across episodes
+        ev0 = e.events;
+        if (on) prepass_begin_books(c, st, M);
+        else M.complete = 1;
+    } else if (on) {
+        persist_io(S, b, true);  // sums as of this episode's start
+        // ClearWindows (base.cpp:145-163): deques emptied, running sums kept (quirk Q7)
+#define X(n) S.n.cnt[b] = 0;
+        LOB_ROLLING_MEANS(X)
+        LOB_ACCUMULATORS(X)
+#undef X
+        st.ewma_up = S.ewma_up[b]; st.ewma_down = S.ewma_down[b]; st.tp_val = S.tp_val[b];
+        st.k = 0;
+    }
+    prepass_run2<TM>(c, st, M, S.track_mask == 0x7fffffff ? 0x7fffffff : S.track_len - LOB_TRACK_MARGIN, on, role, xch, lane);
+    // the window role's last words (ewma, target price) belong in the resumable state the book role's lanes write
+    f64* hand = reinterpret_cast<f64*>(&xch[0]);
+    __syncthreads();
+    if (role == 1) { hand[lane] = st.ewma_up; hand[64 + lane] = st.ewma_down; hand[128 + lane] = st.tp_val; }
+    __syncthreads();   // (also: both halves of every track entry are written -- the same CU's L1 serves both waves)
+    if (role != 0 || !on) return;
+    st.ewma_up = hand[lane]; st.ewma_down = hand[64 + lane]; st.tp_val = hand[128 + lane];
+    S.meta[b] = M;
+    S.prep[b] = st;
+    e.done = 0;
+    e.ask_quote = 0.0; e.bid_quote = 0.0;
+    e.a_ntr = 0; e.a_on = 0; e.b_ntr = 0; e.b_on = 0;
+    e.ep_reward = e.ep_pnl = e.ep_bandh = 0.0;
+    e.total_ticks = e.market_buys = e.market_sells = 0;
+    e.tick_ab = e.tick_pos = 0;
+    if (M.init_ok) {
+        const int k = M.k_warm;
+        const Track t1 = c.track(k - 1);
+        e.k = k;
+        e.pf = t1.rec_last;   // Initialise's closing SkipUntil(market time), intraday.cpp:130
+        e.rec_cur = t1.rec_last;
+        e.mid = t1.mid;
+        e.time_ms = t1.time_ms;
+        if (k >= 2) { const Track t0 = c.track(k - 2); e.rec_last = t0.rec_last; e.mid_prev = t0.mid; }
+        else { e.rec_last = M.rec_cur0; e.mid_prev = M.mid0; }
+        e.events += (i64)(t1.rec_last + 1);  // records 0..rec_last were consumed by Initialise
+        place_orders(c, e, 1, 1);
+        LHdr& h = S.hdr[b];
+        const int last = h.slot_cur ^ 1;
+        f32* v = S.vars + ((size_t)b * 3 + last) * 16;
+        f32* vf = S.vars + ((size_t)b * 3 + 2) * 16;
+        const Track tk = state_track(c, e);
+        for (int i = 0; i < P.V; i++) {
+            v[i] = (f32)get_variable(c, e, P.vars[i], tk);
+            vf[i] = v[i];
+        }
+        h.zero_mask &= ~(1 << last);
+        S.verdict[(size_t)b * LOB_VD_STRIDE + 67] = 0;
+    } else {
+        // Initialise() == false: out of data before the windows filled
+        e.k = M.n_track;
+        e.pf = M.rec_cur0;
+        e.rec_cur = M.ex_cur; e.rec_last = M.ex_last; e.time_ms = M.ex_time;
+        e.mid = 0.0; e.mid_prev = 0.0;
+        e.events += (i64)(S.n_events > 0 ? S.n_events - 1 : 0);
+        e.done = 2;
+    }
+    S.hdr[b].stepped = 0;
+    S.hdr[b].done = e.done;
+    S.hdr[b].time_ms = e.time_ms;
+    S.mk_slot[b] = -1;  // the memo table is emptied at every reset: the first act of the episode takes the general path
+    S.mk_slot_last[b] = -1;
+    env_store(S, b, e);
+    atomicAdd((u64*)&S.counters[1], (u64)(e.events - ev0));  // warm-up events count as consumed
+}
+
 // End of an episode: the pre-pass has walked the window arithmetic to the END of
 // the stream, but an episode may stop earlier (market close).  Regenerate the
 // window sums exactly as they stood after the `k` events the episode consumed
@@ -218,6 +313,33 @@ __global__ void __launch_bounds__(64) prepass_extend_kernel(const DevParams* __r
     if (st.k >= k_stop) return;
     EnvCtx c(P, S, b, &tick_lds);
     prepass_run<TM>(c, st, M, k_stop, true);
+    S.meta[b] = M;
+    S.prep[b] = st;
+}
+
+// ... the same on two waves per 64 books
+template <int TM>
+__global__ void __launch_bounds__(128, 2) prepass_extend2_kernel(const DevParams* __restrict__ Pp, DevState S) {
+    const DevParams& P = *Pp;
+    __shared__ TickLds tick_lds;
+    __shared__ PreXch xch[2];
+    stage_ticks(P, tick_lds);
+    const int role = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 64 + lane;
+    const bool in = t < S.B;
+    const int b = in ? t : S.B - 1;
+    BookMeta M = S.meta[b];
+    PrepState st = S.prep[b];
+    const int k_stop = S.k[b] + S.track_len - LOB_TRACK_MARGIN;
+    const bool on = in && !M.complete && st.k < k_stop;
+    EnvCtx c(P, S, b, &tick_lds);
+    prepass_run2<TM>(c, st, M, k_stop, on, role, xch, lane);
+    f64* hand = reinterpret_cast<f64*>(&xch[0]);
+    __syncthreads();
+    if (role == 1) { hand[lane] = st.ewma_up; hand[64 + lane] = st.ewma_down; hand[128 + lane] = st.tp_val; }
+    __syncthreads();
+    if (role != 0 || !on) return;
+    st.ewma_up = hand[lane]; st.ewma_down = hand[64 + lane]; st.tp_val = hand[128 + lane];
     S.meta[b] = M;
     S.prep[b] = st;
 }

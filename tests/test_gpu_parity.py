@@ -516,6 +516,33 @@ def test_books_per_wave_and_group_choices(monkeypatch, env_lanes, reset_lanes, g
     orc.close()
 
 
+def test_prepass_on_two_waves_per_64_books(monkeypatch):
+    """LOB_PREPASS_ROLES=1: the market pre-pass with the book side and the window side of every event on two waves of a block
+    (reset2_kernel / prepass_extend2_kernel, lob_env.h prepass_run2 -- opt-in: measured slower than one wave).  Same track, same
+    windows: engine against the oracle through two episodes, and through a stream longer than the track ring (the resumed
+    pre-pass)."""
+    monkeypatch.setenv("LOB_PREPASS_ROLES", "1")
+    B = 1100
+    p, g, rec, eng, orc = make(depth=10, n_events=150, B=B, algo=abi.ALGO_QLAMBDA, theta_mode=abi.THETA_SHARED, mem=1 << 20)
+    for episode in range(2):
+        eng.reset(); orc.reset()
+        for step in range(8):
+            eng.td_step(1); orc.td_step(1)
+            compare_learner_step(eng, orc, "two-wave pre-pass episode %d step %d" % (episode, step), exact=False, rtol=1e-9)
+        eng.clear_inventory(); orc.clear_inventory()
+        eng.handle_terminal(); orc.handle_terminal()
+    eng.close(); orc.close()
+    monkeypatch.setenv("LOB_TRACK_RING", "256")
+    monkeypatch.setenv("LOB_TRACK_REFILL", "16")
+    p, g, rec, eng, orc = make(depth=5, n_events=900, B=70, algo=abi.ALGO_SARSA, theta_mode=abi.THETA_SHARED, mem=1 << 18)
+    eng.reset(); orc.reset()
+    for step in range(260):
+        eng.td_step(1); orc.td_step(1)
+        if step % 20 == 19:
+            compare_learner_step(eng, orc, "two-wave pre-pass, ring, step %d" % step, exact=False, rtol=1e-9)
+    eng.close(); orc.close()
+
+
 @pytest.mark.parametrize("algo", [abi.ALGO_SARSA, abi.ALGO_QLAMBDA])
 def test_group0_memo_on_off_identical(monkeypatch, algo):
     """Shared theta evaluates the group-0 part of Q once per distinct (inventory, quote distances)
