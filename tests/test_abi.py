@@ -163,5 +163,5 @@ def test_traffic_table_is_what_the_committed_counter_passes_give(tmp_path):
     import subprocess
     import sys
     out = str(tmp_path / "traffic.json")
-    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_traffic.py"), "r03", out], stdout=subprocess.DEVNULL)
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_traffic.py"), "r04", out], stdout=subprocess.DEVNULL)
     assert json.load(open(out)) == json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
