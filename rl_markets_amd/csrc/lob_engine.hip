@@ -45,6 +45,7 @@ struct lob_engine {
     hipEvent_t ev_reg_go = nullptr, ev_reg_done = nullptr;  // tile registry kernels on stream2 beside the learner kernels (lob_kernels.h registry_kernel)
     hipEvent_t ev_rest_go = nullptr, ev_rest_done = nullptr;  // learn_q_rest_kernel on stream2 beside the trace kernels
     bool rest_side = true;      // (LOB_REST_SIDE=0: on the main stream, as before; A/B switch)
+    bool acc_fuse = true;       // Q(lambda), the pair kernel + the lane-per-generation trace kernel: updates added to their slots there, accumulate_kernel over a list (LOB_ACC_FUSE=0: over every book; A/B switch)
     bool acc_block = true;      // SARSA(lambda): accumulate_block_kernel (LOB_ACC_BLOCK=0: accumulate_kernel; A/B switch)
     int env_step_lanes = 64;    // books per wave of env_step_kernel (LOB_ENV_STEP_LANES=32: two half-full waves per SIMD; experiment)
     bool prepass_roles = false; // the pre-pass on two waves per 64 books (reset2_kernel / prepass_extend2_kernel; LOB_PREPASS_ROLES=1): measured slower, opt-in
@@ -303,6 +304,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     HIPCHK_E(hipEventCreateWithFlags(&e->ev_rest_done, hipEventDisableTiming | hipEventDisableSystemFence));
     if (const char* g = getenv("LOB_REST_SIDE")) e->rest_side = !(g[0] == '0');
     if (const char* g = getenv("LOB_ACC_BLOCK")) e->acc_block = !(g[0] == '0');
+    if (const char* g = getenv("LOB_ACC_FUSE")) e->acc_fuse = !(g[0] == '0');
     if (const char* g = getenv("LOB_ENV_STEP_LANES")) { if (atoi(g) == 32) e->env_step_lanes = 32; }
     if (const char* g = getenv("LOB_PREPASS_ROLES")) e->prepass_roles = g[0] == '1';
     if (hipHostMalloc((void**)&e->rest_hint, sizeof(i32), hipHostMallocMapped) == hipSuccess) {
@@ -504,6 +506,9 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
         if (rc == LOB_OK) rc = dev_alloc(e, &S.tr_list_n, 2);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.tr_list2, B);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.tr_list2_n, 2);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.acc_list, B);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.acc_list_n, 2);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.acc_pend, B);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.mk_slot, B);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.mk_slot_last, B);
         if (rc == LOB_OK && hipMemsetAsync(S.mk_hash, 0xff, ms * 8, e->stream) != hipSuccess) rc = LOB_EHIP;
@@ -876,6 +881,8 @@ int lob_reset(lob_engine* e) {
     HIPCHK(hipMemsetAsync(e->S.slow_n, 0, 4 * sizeof(i32), e->stream));
     HIPCHK(hipMemsetAsync(e->S.tr_list_n, 0, 2 * sizeof(i32), e->stream));
     HIPCHK(hipMemsetAsync(e->S.tr_list2_n, 0, 2 * sizeof(i32), e->stream));
+    HIPCHK(hipMemsetAsync(e->S.acc_list_n, 0, 2 * sizeof(i32), e->stream));
+    HIPCHK(hipMemsetAsync(e->S.acc_pend, 0, (size_t)e->B, e->stream));
     if (e->half_open) {
         // a step abandoned between lob_td_step_begin and lob_td_step_end (a weight exchange that failed): its learner half never
         // ran, so the double-buffered lists are where the step found them -- the survivors of the combine table wait in the
@@ -1026,6 +1033,12 @@ int lob_get_book(lob_engine* e, int32_t book, lob_book_dump* out) { return lob_g
 // groups, each running act -> env -> learn on its own stream; both groups only
 // READ theta, so the synchronous-batch semantic is unchanged.  The update of all
 // books runs on the main stream after both groups have joined.
+// SARSA(lambda): every book keeps all its generations -- sums per slot inside 1 024-book blocks first (accumulate_block_kernel).
+// The same for Q(lambda) once most actions are greedy (P(greedy) = 1 - eps + eps / 9 > 0.7: more than three live generations per book)
+static bool acc_blocked(const lob_engine* e) {
+    const bool many_gens = e->P.algo == LOB_ALGO_SARSA || (e->P.algo == LOB_ALGO_QLAMBDA && e->P.policy == LOB_POLICY_EPS_GREEDY && e->P.epsilon < 0.34);
+    return e->acc_block && e->P.memo && many_gens && e->B >= 4 * LOB_ACB_BLOCK;
+}
 // accumulate_kernel's lanes per book (log2): one lane per trace generation.  Two books per wave measured
 // best for both SARSA(lambda) (all trace_kmax generations alive) and Watkins's Q(lambda) at eps = 0.8 (1-2
 // alive; 8 lanes per book: 0.035 ms, 16: 0.030, 32: 0.029, 64: 0.036).  LOB_ACC_LANES=8|16|32|64 overrides.
@@ -1057,6 +1070,7 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
         }
         const bool fast = e->P.memo != 0;  // (implies one group)
         bool rest_pending = false;
+        bool acc_fused = false;  // (this step: see the learn kernel's launch)
         const bool dq = e->P.algo == LOB_ALGO_DOUBLE_Q;  // (fast && dq: every step without usable hit lists takes the general act kernel over the whole batch)
         const int lpar = first ? (e->list_par ^= 1) : e->list_par;
         e->last_par = par;
@@ -1127,7 +1141,7 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                     else if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_QLAMBDA, 0>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, e->P, e->S, rnd, par, lpar, sid);
                     else if (e->P.sarsa_lanes) {
                         // a lane per generation; the wave-per-book kernel for the books it leaves on the list
-                        hipLaunchKernelGGL(trace_lane_kernel<LOB_ALGO_SARSA>, dim3((nb + LOB_TS_BLOCK / 32 - 1) / (LOB_TS_BLOCK / 32)), dim3(LOB_TS_BLOCK), 0, st, e->P, e->S, lpar, sid);
+                        hipLaunchKernelGGL(trace_lane_kernel<LOB_ALGO_SARSA>, dim3((nb + LOB_TS_BLOCK / 32 - 1) / (LOB_TS_BLOCK / 32)), dim3(LOB_TS_BLOCK), 0, st, e->P, e->S, lpar, sid, 0);
                         hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_SARSA, 1>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, e->P, e->S, rnd, par, lpar, sid);
                     }
                     else hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_SARSA, 0>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, e->P, e->S, rnd, par, lpar, sid);
@@ -1136,11 +1150,14 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                     TimedLaunch t(e, "learn_kernel", st);
                     if (lanes) {
                         const bool pair = e->q_pair && e->P.M < (1ll << 27) && !dq;  // (its LDS rows hold tile indices in 27 bits; one weight vector)
+                        // the updates added to their slots by this kernel and trace_lane_kernel (lob_state.h acc_list): Q(lambda) while its
+                        // books keep few generations (else accumulate_block_kernel's sums per block win)
+                        acc_fused = pair && fuse && e->acc_fuse && e->P.combine && e->P.sarsa_lanes && e->P.algo == LOB_ALGO_QLAMBDA && !acc_blocked(e) && G == 1;
                         const int gq = pair ? std::min(LOB_QP_OCC * e->n_cus, (nb + LOB_QP_BOOKS - 1) / LOB_QP_BOOKS) : std::min(e->n_cus, (nb + LOB_QL_BLOCK - 1) / LOB_QL_BLOCK);
                         const size_t lds = pair ? qpair_lds_bytes(e->P.cwords4) : qlane_lds_bytes(e->P.cwords4);
 #define LOB_QL_LAUNCH(A, VT, TR)                                                                                                                            \
     do {                                                                                                                                                    \
-        if (pair) hipLaunchKernelGGL((learn_q_pair_kernel<A, VT, TR>), dim3(gq), dim3(LOB_QP_BLOCK), lds, st, e->P, e->S, rnd, lpar, ver, sid);             \
+        if (pair) hipLaunchKernelGGL((learn_q_pair_kernel<A, VT, TR>), dim3(gq), dim3(LOB_QP_BLOCK), lds, st, e->P, e->S, rnd, lpar, ver, sid, acc_fused ? 1 : 0); \
         else hipLaunchKernelGGL((learn_q_lane_kernel<A, VT, TR>), dim3(gq), dim3(LOB_QL_BLOCK), lds, st, e->P, e->S, rnd, lpar, ver, sid);                  \
     } while (0)
                         if (dq) {  // (lob_create: only with the fused trace step)
@@ -1185,7 +1202,7 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                     // the listed books (their traces survive the step): a lane per generation, then the wave-per-book kernel for
                     // those the lane kernel hands on
                     if (e->P.sarsa_lanes)
-                        hipLaunchKernelGGL(trace_lane_kernel<LOB_ALGO_QLAMBDA>, dim3(std::min(4 * e->n_cus, (nb + LOB_TS_BLOCK / 32 - 1) / (LOB_TS_BLOCK / 32))), dim3(LOB_TS_BLOCK), 0, st, e->P, e->S, lpar, sid);
+                        hipLaunchKernelGGL(trace_lane_kernel<LOB_ALGO_QLAMBDA>, dim3(std::min(4 * e->n_cus, (nb + LOB_TS_BLOCK / 32 - 1) / (LOB_TS_BLOCK / 32))), dim3(LOB_TS_BLOCK), 0, st, e->P, e->S, lpar, sid, acc_fused ? 1 : 0);
                     hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_QLAMBDA, 2>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, e->P, e->S, rnd, par, lpar, sid);
                 }
             } else if (mode == 0) {
@@ -1207,13 +1224,19 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                 TimedLaunch t(e, "accumulate_kernel");
                 // SARSA(lambda): every book keeps all its generations -- sums per slot inside 1 024-book blocks first.  The same for
                 // Q(lambda) once most actions are greedy (P(greedy) = 1 - eps + eps / 9 > 0.7: more than three live generations per book)
-                const bool many_gens = e->P.algo == LOB_ALGO_SARSA || (e->P.algo == LOB_ALGO_QLAMBDA && e->P.policy == LOB_POLICY_EPS_GREEDY && e->P.epsilon < 0.34);
-                if (e->acc_block && e->P.memo && many_gens && e->B >= 4 * LOB_ACB_BLOCK) {
+                if (acc_blocked(e)) {
                     hipLaunchKernelGGL(accumulate_block_kernel, dim3((e->B + LOB_ACB_BLOCK - 1) / LOB_ACB_BLOCK, e->P.trace_kmax), dim3(LOB_ACB_BLOCK), 0, e->stream, e->P, e->S, par, e->step_id);
+                } else if (acc_fused) {
+                    // what the fused accumulation left: a few hundred books (the grid's waves stride over the list)
+                    const int sh = acc_lanes_shift(e);
+                    const int waves = (std::min(e->B, 4096) + (64 >> sh) - 1) / (64 >> sh);
+                    hipLaunchKernelGGL(accumulate_kernel, dim3((waves + LOB_WAVES_PER_BLOCK - 1) / LOB_WAVES_PER_BLOCK), dim3(LOB_BLOCK), 0, e->stream, e->P, e->S, par, sh, e->step_id,
+                                       (const i32*)e->S.acc_list, (const i32*)&e->S.acc_list_n[lpar]);
                 } else {
                     const int sh = acc_lanes_shift(e);
                     const int waves = (e->B + (64 >> sh) - 1) / (64 >> sh);
-                    hipLaunchKernelGGL(accumulate_kernel, dim3((waves + LOB_WAVES_PER_BLOCK - 1) / LOB_WAVES_PER_BLOCK), dim3(LOB_BLOCK), 0, e->stream, e->P, e->S, par, sh, e->step_id);
+                    hipLaunchKernelGGL(accumulate_kernel, dim3((waves + LOB_WAVES_PER_BLOCK - 1) / LOB_WAVES_PER_BLOCK), dim3(LOB_BLOCK), 0, e->stream, e->P, e->S, par, sh, e->step_id,
+                                       (const i32*)nullptr, (const i32*)nullptr);
                 }
             }
             {

@@ -280,6 +280,7 @@ __global__ void __launch_bounds__(LOB_FAST_BLOCK) act_fast_kernel(DevParams P, D
         S.slow_n[(lpar ^ 1) * 2 + 1] = 0;
         S.tr_list_n[lpar ^ 1] = 0;
         S.tr_list2_n[lpar ^ 1] = 0;
+        S.acc_list_n[lpar ^ 1] = 0;
     }
     const FastLds L = fast_stage(fast_lds_raw, P, S, rnd_g, NB, false);
     const int w = threadIdx.x >> 6;
@@ -476,6 +477,7 @@ __global__ void __launch_bounds__(LOB_LIGHT_BLOCK) act_light_kernel(DevParams P,
         S.slow_n[(lpar ^ 1) * 2 + 1] = 0;
         S.tr_list_n[lpar ^ 1] = 0;
         S.tr_list2_n[lpar ^ 1] = 0;
+        S.acc_list_n[lpar ^ 1] = 0;
     }
     const int b = blockIdx.x * LOB_LIGHT_BLOCK + threadIdx.x;
     if (b >= S.B) return;
@@ -661,8 +663,10 @@ __global__ void __launch_bounds__(LOB_LIGHT_BLOCK) trace_light_kernel(DevParams 
 // wave-per-book kernel: SARSA on `tr_list` (trace_fast_kernel<SARSA, 1>), Q(lambda) on `tr_list2` (trace_fast_kernel<.., 2>).
 // Same stores as learn_traces for the books it takes.
 #define LOB_TS_BLOCK 256
+// acc_fuse (Q(lambda)): every generation's update is added to its slot as soon as the slot is known (acc_generation); a book
+// the learn kernel handed back (its TD error is not known yet: acc_pend) or this kernel hands on goes on acc_list.
 template <int ALGO>
-__global__ void __launch_bounds__(LOB_TS_BLOCK, 5) trace_lane_kernel(DevParams P, DevState S, int lpar, int sid) {
+__global__ void __launch_bounds__(LOB_TS_BLOCK, 5) trace_lane_kernel(DevParams P, DevState S, int lpar, int sid, int acc_fuse) {
     constexpr bool QL = ALGO == LOB_ALGO_QLAMBDA;
     const int lane = threadIdx.x & 63, k = lane & 31, half = lane >> 5, grp = threadIdx.x >> 5;
     const int n_todo = QL ? S.tr_list_n[lpar] : S.B;
@@ -687,6 +691,8 @@ __global__ void __launch_bounds__(LOB_TS_BLOCK, 5) trace_lane_kernel(DevParams P
         const int q0 = tile_quant(vl.x), q1 = tile_quant(vl.y), q2 = tile_quant(vl.z);
         const int4 lid = *reinterpret_cast<const int4*>(S.mk_ident + (size_t)ls * 4);
         const int action = h.action;
+        const bool fuse_acc = QL && acc_fuse != 0;
+        const bool td_pending = fuse_acc && S.acc_pend[bb] != 0;  // (handed back by the learn kernel)
         int n_old = h.tr_n;
         if (n_old > P.trace_kmax - 1) n_old = P.trace_kmax - 1;
         if (QL && action != LOB_TRL_AMAX(ent)) n_old = 0;  // Watkins's cut (QLearn::UpdateTraces, agent.cpp:272-280: traces.decay(0.0))
@@ -732,11 +738,17 @@ __global__ void __launch_bounds__(LOB_TS_BLOCK, 5) trace_lane_kernel(DevParams P
                     if (QL) S.tr_list2[atomicAdd(&S.tr_list2_n[lpar], 1)] = ent;
                     else S.tr_list[atomicAdd(&S.tr_list_n[lpar], 1)] = b;
                     atomicAdd((unsigned long long*)&S.counters[6], 1ull);
+                    if (fuse_acc) S.acc_list[atomicAdd(&S.acc_list_n[lpar], 1)] = b;  // (the wave-per-book kernel does its traces: all its generations are accumulate_kernel's)
                 }
                 continue;
             }
         }
         if (!stepped) continue;
+        if (td_pending && k == 0) S.acc_list[atomicAdd(&S.acc_list_n[lpar], 1)] = b;
+        const bool add_here = fuse_acc && !td_pending;
+        const f64 upd32 = h.upd / (f64)LOB_N_TILINGS;
+        const int xcd = add_here ? acc_copy(S, (int)(blockIdx.x * (LOB_TS_BLOCK / 64) + (threadIdx.x >> 6))) : 0;
+        bool acc_failed = false;
         if (cand != 0 && n_amb_new != 0) {
             const i32* to = S.mk_tiles + ((size_t)so * LOB_N_ACTIONS + (sg.w & 15)) * 32;
             uint32_t c = cand;
@@ -768,6 +780,8 @@ __global__ void __launch_bounds__(LOB_TS_BLOCK, 5) trace_lane_kernel(DevParams P
                     cb_claim_finish(S, pend);
                 }
             }
+            // (old age k: age k + 1 after this step's decay)
+            if (add_here && m2 && !acc_generation(S, gi, m2, upd32 * (f64)P.trace_pow[k + 1], xcd)) acc_failed = true;
         }
         // ---- the new generation: the chosen action's 32 tiles, all alive ----
         const int nh = (h.tr_head + 1) & (G - 1);
@@ -794,6 +808,11 @@ __global__ void __launch_bounds__(LOB_TS_BLOCK, 5) trace_lane_kernel(DevParams P
                 cb_claim_issue(S, pend, q0, q1, q2, action, 0xffffffffu, (int)ni);
                 cb_claim_finish(S, pend);
             }
+            if (add_here && !acc_generation(S, ni, 0xffffffffu, upd32 * (f64)P.trace_pow[0], xcd)) acc_failed = true;
+        }
+        if (add_here) {  // a generation without a slot: the book goes on the list once, for the direct path only
+            const u64 fl = __ballot(acc_failed);
+            if ((uint32_t)(fl >> (half * 32)) && k == 0) S.acc_list[atomicAdd(&S.acc_list_n[lpar], 1)] = (i32)((uint32_t)b | 0x80000000u);
         }
     }
 }
@@ -1317,7 +1336,10 @@ __host__ __device__ inline size_t qpair_lds_bytes(int /*cwords4*/) {
            (size_t)LOB_QP_BLOCK * LOB_QD_HCAP * 4;
 }
 template <int ALGO, int VT, bool TR>
-__global__ void __launch_bounds__(LOB_QP_BLOCK) learn_q_pair_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g, int lpar, u64 ver, int sid) {
+// acc_fuse (Q(lambda), TR): the update of a book whose step leaves ONE new generation is added to that generation's slot right
+// here, by the lane that has just computed the TD error (acc_generation); the listed books' by trace_lane_kernel; what neither
+// can finish goes on acc_list for accumulate_kernel.
+__global__ void __launch_bounds__(LOB_QP_BLOCK) learn_q_pair_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g, int lpar, u64 ver, int sid, int acc_fuse) {
     static_assert(ALGO == LOB_ALGO_SARSA || ALGO == LOB_ALGO_QLAMBDA, "one weight vector");
     static_assert(!TR || ALGO == LOB_ALGO_QLAMBDA, "the fused trace step is Watkins's");
     extern __shared__ __align__(16) unsigned char fast_lds_raw[];
@@ -1437,6 +1459,8 @@ __global__ void __launch_bounds__(LOB_QP_BLOCK) learn_q_pair_kernel(DevParams P,
 #pragma unroll
             for (int a = 0; a < LOB_N_ACTIONS; a++) xc[a] = qs[a];
             reinterpret_cast<int*>(xc + LOB_N_ACTIONS)[0] = (walk && n <= LOB_QP_CAP1) ? n : -1;
+            // (1 + the ring slot of the generation a light step creates, for the group-2 lane's addition to its slot; 0: listed)
+            reinterpret_cast<int*>(xc + LOB_N_ACTIONS)[1] = (TR && stepped && tlight) ? 1 + ((h.tr_head + 1) & (P.trace_gens - 1)) : 0;
             // ---- UpdateTraces, second half (see learn_q_lane_kernel) ----
             if (TR) {
                 const bool listed = stepped && !tlight;
@@ -1491,18 +1515,27 @@ __global__ void __launch_bounds__(LOB_QP_BLOCK) learn_q_pair_kernel(DevParams P,
 #pragma unroll
             for (int i = 0; i < LOB_QP_CAP2; i++) v2[i] = (walk && n <= LOB_QP_CAP2 && i < n) ? S.theta[row[1 + i] & 0x7ffffffu] : 0.0;  // (n beyond the row: entries not written)
         }
+        if (TR && acc_fuse && !second) { cb_claim_finish(S, pend); pend.active = false; }  // (the group-2 lane adds to the slot after the barrier)
         __syncthreads();
         if (!second) {
             cb_claim_finish(S, pend);
         } else {
             // ---- group-2 lane: Q, argmax, the TD error, the rest of the hit list ----
             const int n1 = reinterpret_cast<const int*>(xc + LOB_N_ACTIONS)[0];
+            const int light_code = TR ? reinterpret_cast<const int*>(xc + LOB_N_ACTIONS)[1] : 0;
+            const bool light = light_code != 0;
             if (stepped) {
                 if (!(walk && n1 >= 0 && n <= LOB_QP_CAP2 && n1 + n <= LOB_HL_CAP)) {
                     // no (valid) memo record, or a half-list longer than its row: the general kernel takes the book
                     const int pos = atomicAdd(&S.slow_n[lpar * 2 + 1], 1);
                     S.slow_list[(size_t)S.B + pos] = b;
                     recp[0] = LOB_HL_NONE;
+                    // (its TD error comes later: every generation of the book is accumulate_kernel's -- a light book goes on the
+                    // list here, a listed one when trace_lane_kernel meets it)
+                    if (TR && acc_fuse) {
+                        if (light) S.acc_list[atomicAdd(&S.acc_list_n[lpar], 1)] = b;
+                        else S.acc_pend[b] = 1;
+                    }
                 } else {
                     f64 qs[LOB_N_ACTIONS];
 #pragma unroll
@@ -1519,9 +1552,17 @@ __global__ void __launch_bounds__(LOB_QP_BLOCK) learn_q_pair_kernel(DevParams P,
                     // Q(s, a) / the RNG counter after the trace step, as the group-1 lane left them
                     const f64 q_sa = xc[LOB_N_ACTIONS + 1];
                     Rng g{P.seed, P.book_id_offset + (u64)b, reinterpret_cast<const u64*>(xc)[LOB_N_ACTIONS + 2]};
-                    learn_delta_single<ALGO>(P, hp, h, qs, q_sa, g, 0);
+                    const f64 delta = learn_delta_single<ALGO>(P, hp, h, qs, q_sa, g, 0);
                     recp[0] = (u64)(n1 + n);
                     for (int i = 0; i < n; i++) recp[1 + n1 + i] = ql_unpack(row[1 + i]);
+                    if (TR && acc_fuse && !light) S.acc_pend[b] = 0;
+                    if (TR && acc_fuse && light) {
+                        // the book's one generation (age 0, all 32 tiles alive): alpha delta / 32 x e(0) into its slot
+                        const size_t gi = (size_t)b * P.trace_gens + (light_code - 1);
+                        const f64 val = (P.alpha * delta) / (f64)LOB_N_TILINGS * (f64)P.trace_pow[0];
+                        if (!acc_generation(S, gi, 0xffffffffu, val, acc_copy(S, (int)(blockIdx.x * (LOB_QP_BLOCK / 64) + (threadIdx.x >> 6)))))
+                            S.acc_list[atomicAdd(&S.acc_list_n[lpar], 1)] = (i32)((uint32_t)b | 0x80000000u);
+                    }
                 }
             } else if (real) {
                 recp[0] = LOB_HL_NONE;

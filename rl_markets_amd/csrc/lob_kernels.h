@@ -1068,7 +1068,7 @@ __device__ __forceinline__ void learn_traces(const DevParams& P, const DevState&
 // UpdateWeights of SARSA / QLearn (agent.cpp:282-311) once Q(to_state, .) is known: the TD error and
 // the header stores.
 template <int ALGO>
-__device__ __forceinline__ void learn_delta_single(const DevParams& P, LHdr* hp, const LHdr& h, const f64* qs_to, f64 q_sa, Rng& g, int lane,
+__device__ __forceinline__ f64 learn_delta_single(const DevParams& P, LHdr* hp, const LHdr& h, const f64* qs_to, f64 q_sa, Rng& g, int lane,
                                                    const f64* rho = nullptr, f64* rl_t = nullptr) {
     static_assert(ALGO != LOB_ALGO_DOUBLE_Q, "two weight vectors: see learn_book");
     const f64 F_term = P.gamma * 0.0 - 0.0;  // potentials are identically 0 (base.cpp:239-242)
@@ -1092,6 +1092,7 @@ __device__ __forceinline__ void learn_delta_single(const DevParams& P, LHdr* hp,
         hp->upd = P.alpha * delta;
         hp->rng_ctr = g.ctr;
     }
+    return delta;
 }
 
 // Agent::HandleTransition up to (not including) updateQ: UpdateTraces +
@@ -1432,11 +1433,75 @@ __global__ void rho_delta_apply_kernel(f64* rho, f64* sync_slot, const f64* delt
 // update_kernel does.  Watkins's Q(lambda) leaves 1-2 live generations per book at exploration rates
 // near 1, so a whole wave per book is a chain of four dependent look-ups run 65 536 times for two lanes of
 // work; 8 books per wave run the same chain 8 192 times.
-__global__ void __launch_bounds__(LOB_BLOCK) accumulate_kernel(DevParams P, DevState S, int par, int lpb_shift, int sid) {
+// which copy of the slots' sums this wave adds to (one per XCD, DevState::cb_reps)
+__device__ inline int acc_copy(const DevState& S, int wave) {
+    int xcd = 0;
+    if (S.cb_reps > 1) {
+        unsigned x;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+        xcd = (int)(x & (unsigned)(S.cb_reps - 1));
+        if (S.cb_reps > 8) xcd = (int)(x & 7u) * (S.cb_reps >> 3) + (wave & ((S.cb_reps >> 3) - 1));
+    }
+    return xcd;
+}
+// ONE generation's update (`val` = alpha delta / 32 x its eligibility) added to the slot of its (identity, mask), as a lane of
+// accumulate_kernel does it: the slot on record, its identity compared in full once (LOB_CBS_VERIFIED), the probe sequence
+// if it was displaced.  False: no slot (table crowded / hash shared by two identities) -- tr_cbslot is set to -1 and the caller
+// leaves the generation to accumulate_kernel's direct path, which must wait until nobody reads theta.
+__device__ inline bool acc_generation(const DevState& S, size_t gi, uint32_t mask, f64 val, int xcd) {
+    const int cs = S.tr_cbslot[gi];
+    const bool known = cs >= 0 && (cs & LOB_CBS_VERIFIED);
+    uint32_t s = (uint32_t)cs & (uint32_t)(S.cb_slots - 1);
+    bool found = known;
+    if (!known) {
+        const int4 sg = *reinterpret_cast<const int4*>(S.tr_sig + gi * 4);
+        if (cs >= 0) {
+            const int4 id = *reinterpret_cast<const int4*>(S.cb_ident + (size_t)s * 8);
+            const uint32_t idm = (uint32_t)S.cb_ident[(size_t)s * 8 + 4];
+            found = id.x == sg.x && id.y == sg.y && id.z == sg.z && id.w == sg.w && idm == mask;
+        }
+        if (!found) {
+            const u64 hsh = cb_hash(sg.x, sg.y, sg.z, sg.w, mask);
+            s = (uint32_t)hsh & (uint32_t)(S.cb_slots - 1);
+            for (int probe = 0; probe < LOB_CB_PROBES; probe++) {
+                const u64 kk = S.cb_key[s];
+                if (kk == hsh) {
+                    const i32* id = S.cb_ident + (size_t)s * 8;
+                    found = id[0] == sg.x && id[1] == sg.y && id[2] == sg.z && id[3] == sg.w && (uint32_t)id[4] == mask;
+                    if (found) break;
+                }
+                if (kk == LOB_CB_EMPTY) break;
+                s = (s + 1) & (uint32_t)(S.cb_slots - 1);
+            }
+        }
+        S.tr_cbslot[gi] = found ? (i32)(s | LOB_CBS_VERIFIED) : -1;
+    }
+    if (!found) return false;
+    __hip_atomic_fetch_add(&S.cb_acc[((size_t)xcd * S.cb_slots + s) * 2], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!(S.cb_touch[s] & 1u)) atomicOr(&S.cb_touch[s], 1u);
+    return true;
+}
+// `list` (or null: every book): accumulate_kernel over the books the fused accumulation left (lob_state.h acc_list); an entry
+// with bit 31 takes only the book's generations without a slot.
+__global__ void __launch_bounds__(LOB_BLOCK) accumulate_kernel(DevParams P, DevState S, int par, int lpb_shift, int sid, const i32* __restrict__ list = nullptr,
+                                                               const i32* __restrict__ list_n = nullptr) {
     const int lane = threadIdx.x & 63;
     const int lpb = 1 << lpb_shift, sub = lane & (lpb - 1);
     const int wave = blockIdx.x * LOB_WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    const int b = (wave << (6 - lpb_shift)) + (lane >> lpb_shift);
+    const int n_waves = gridDim.x * LOB_WAVES_PER_BLOCK;
+    const int nl = list ? *list_n : 0;
+    // (the list: the grid's waves stride over it; every book: one pass)
+#pragma unroll 1
+    for (int wv = wave;; wv += n_waves) {
+    int b = (wv << (6 - lpb_shift)) + (lane >> lpb_shift);
+    bool direct_only = false;
+    if (list) {
+        if ((wv << (6 - lpb_shift)) >= nl) break;  // (wave-uniform)
+        const bool have = b < nl;
+        const uint32_t ent = have ? (uint32_t)list[b] : 0u;
+        direct_only = have && (ent >> 31) != 0;
+        b = have ? (int)(ent & 0x7fffffffu) : S.B;
+    }
     int n = 0, head = 0, target = 0;
     f64 scaled = 0.0;
     if (b < S.B) {
@@ -1454,14 +1519,7 @@ __global__ void __launch_bounds__(LOB_BLOCK) accumulate_kernel(DevParams P, DevS
     const i32* tr_sig = S.tr_sig + (size_t)bb * G * 4;
     // the sums are kept in S.cb_reps copies, one per XCD (apply_kernel adds them up): the additions to a popular generation's
     // slot queue up behind each other at one address
-    int xcd = 0;
-    if (S.cb_reps > 1) {
-        unsigned x;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
-        xcd = (int)(x & (unsigned)(S.cb_reps - 1));
-        // (more than one copy per XCD -- LOB_ACC_REPS=16|32|64, an experiment: the waves of an XCD spread over cb_reps / 8 copies)
-        if (S.cb_reps > 8) xcd = (int)(x & 7u) * (S.cb_reps >> 3) + (wave & ((S.cb_reps >> 3) - 1));
-    }
+    const int xcd = acc_copy(S, wave);  // (more than one copy per XCD -- LOB_ACC_REPS=16|32|64, an experiment: the waves of an XCD spread over cb_reps / 8 copies)
     for (int base = 0; base < G; base += lpb) {
         const int age = base + sub;
         if (!__any(age < n)) break;
@@ -1475,6 +1533,7 @@ __global__ void __launch_bounds__(LOB_BLOCK) accumulate_kernel(DevParams P, DevS
         }
         // LOB_CBS_VERIFIED: an earlier step has compared this slot's identity with the generation's, and neither has changed since
         // (a claim rewrites tr_cbslot; the slot cannot have been freed: the generation added to it in every step in between)
+        if (direct_only && cs >= 0) mask = 0;  // (its update is in its slot already: acc_generation)
         const bool known = mask != 0 && cs >= 0 && (cs & LOB_CBS_VERIFIED);
         if (mask != 0 && !known) sg = *reinterpret_cast<const int4*>(tr_sig + slot * 4);
         bool direct = false;
@@ -1534,6 +1593,8 @@ __global__ void __launch_bounds__(LOB_BLOCK) accumulate_kernel(DevParams P, DevS
                 }
             }
         }
+    }
+    if (!list) break;
     }
 }
 
@@ -1770,6 +1831,7 @@ __global__ void __launch_bounds__(256) memo_kernel(DevParams P, DevState S, cons
         S.slow_n[reset_lpar * 2 + 1] = 0;
         S.tr_list_n[reset_lpar] = 0;
         S.tr_list2_n[reset_lpar] = 0;
+        S.acc_list_n[reset_lpar] = 0;
     }
     __shared__ f64 vals[4][LOB_N_ACTIONS * LOB_QSTRIDE];
     __shared__ uint32_t rnd[2048 + 32];

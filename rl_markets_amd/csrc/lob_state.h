@@ -322,6 +322,13 @@ struct DevState {
     i32* tr_list_n;      // [2 parities]
     i32* tr_list2;       // [B] Q(lambda): the entries of `tr_list` the lane-per-generation kernel (trace_lane_kernel) hands on to the wave-per-book one
     i32* tr_list2_n;     // [2 parities]
+    // The accumulation of a generation's update where its slot is resolved (learn_q_pair_kernel for the books whose step leaves one
+    // new generation, trace_lane_kernel for the others): what they cannot finish goes on this list for accumulate_kernel --
+    // entry = book (every generation of the book: its TD error was not known yet, or its trace step was handed on), or
+    // book | 1 << 31 (only the book's generations without a slot: the direct, tile-by-tile path must wait until nobody reads theta).
+    i32* acc_list;       // [B]
+    i32* acc_list_n;     // [2 parities]
+    uint8_t* acc_pend;   // [B] the learn kernel handed the book back (its TD error comes with learn_q_rest_kernel): trace_lane_kernel must not add its update yet
     i32* slow_list;      // [2 kinds: act, learn][B]
     i32* slow_n;         // [2 parities][2 kinds]
     // Hit-list carry-over learn_q(t) -> act(t+1) (lob_fast.h act_light_kernel): the Q evaluation of the TD target and the
