@@ -282,7 +282,9 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
 void lob_destroy(lob_engine* e);
 
 /* Replaces Intraday::LoadData (src/environment/intraday.cpp:141-150):
- * upload host records / synthesise the same records directly in HBM. */
+ * upload host records / synthesise the same records directly in HBM.
+ * 2 <= n_events < 2^21 (LOB_EINVAL otherwise: the per-book TickStatistics counters are 21 bits wide, one count per agent
+ * step, and an agent step consumes at least one event). */
 int lob_load_events(lob_engine* e, const uint32_t* host_records, int32_t n_events);
 int lob_gen_events_device(lob_engine* e, const lob_gen_params* g);
 /* One recorded stream replayed by every book (BASELINE config 5: a converted LOBSTER day):

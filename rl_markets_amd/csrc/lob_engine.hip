@@ -671,6 +671,9 @@ static int finalize_episode(lob_engine* e) {
 
 // n_rows: records to allocate (B * n_events for per-book streams, the stream length for a replayed one)
 static int set_records(lob_engine* e, int32_t n_events, size_t n_rows) {
+    // (the six TickStatistics counters of a book are 21-bit fields, lob_state.h tick_ab / tick_pos: one count per agent step, at
+    // most one agent step per event)
+    if (n_events >= (1 << 21)) { lob_set_error("an episode of 2^21 events or more: the per-book tick statistics count to 2^21 - 1"); return LOB_EINVAL; }
     { int rc = finalize_episode(e); if (rc) return rc; }  // needs the old stream
     // the old stream is gone from here on, whatever happens below: no kernel may see a freed pointer
     e->have_events = false;

@@ -770,18 +770,23 @@ __global__ void __launch_bounds__(LOB_TS_BLOCK, 5) trace_lane_kernel(DevParams P
         if (m) {
             const uint32_t m2 = m & ~hit;
             if (m2 != m) S.tr_alive[gi] = m2;
+            bool cs_here = true;  // (`cs` is what tr_cbslot[gi] holds)
             if (m2 && (m2 != m || cs < 0)) {  // (an unchanged generation keeps the slot it has: the table persists, lob_learn.h)
                 const u64 ch = cb_hash(sg.x, sg.y, sg.z, sg.w, m2);
                 const uint32_t home = (uint32_t)ch & (uint32_t)(S.cb_slots - 1);
-                if (S.cb_key[home] == ch) S.tr_cbslot[gi] = (i32)home;  // (thousands of books hold this very generation: look before the compare-and-swap)
+                if (S.cb_key[home] == ch) { cs = (i32)home; S.tr_cbslot[gi] = cs; }  // (thousands of books hold this very generation: look before the compare-and-swap)
                 else {
                     CbPending pend;
                     cb_claim_issue(S, pend, sg.x, sg.y, sg.z, sg.w, m2, (int)gi);
                     cb_claim_finish(S, pend);
+                    cs_here = false;
                 }
             }
             // (old age k: age k + 1 after this step's decay)
-            if (add_here && m2 && !acc_generation(S, gi, m2, upd32 * (f64)P.trace_pow[k + 1], xcd)) acc_failed = true;
+            if (add_here && m2) {
+                const f64 val = upd32 * (f64)P.trace_pow[k + 1];
+                if (!(cs_here ? acc_generation_at(S, gi, cs, sg, m2, val, xcd) : acc_generation(S, gi, m2, val, xcd))) acc_failed = true;
+            }
         }
         // ---- the new generation: the chosen action's 32 tiles, all alive ----
         const int nh = (h.tr_head + 1) & (G - 1);
@@ -802,13 +807,18 @@ __global__ void __launch_bounds__(LOB_TS_BLOCK, 5) trace_lane_kernel(DevParams P
             if (!QL) hp->td = S.qs_last[(size_t)b * LOB_N_ACTIONS + action];  // Q(s, a), for the TD error
             const u64 ch = cb_hash(q0, q1, q2, action, 0xffffffffu);
             const uint32_t home = (uint32_t)ch & (uint32_t)(S.cb_slots - 1);
-            if (S.cb_key[home] == ch) S.tr_cbslot[ni] = (i32)home;
+            bool at_home = false;
+            if (S.cb_key[home] == ch) { S.tr_cbslot[ni] = (i32)home; at_home = true; }
             else {
                 CbPending pend;
                 cb_claim_issue(S, pend, q0, q1, q2, action, 0xffffffffu, (int)ni);
                 cb_claim_finish(S, pend);
             }
-            if (add_here && !acc_generation(S, ni, 0xffffffffu, upd32 * (f64)P.trace_pow[0], xcd)) acc_failed = true;
+            if (add_here) {
+                const f64 val = upd32 * (f64)P.trace_pow[0];
+                if (!(at_home ? acc_generation_at(S, ni, (int)home, make_int4(q0, q1, q2, action), 0xffffffffu, val, xcd) : acc_generation(S, ni, 0xffffffffu, val, xcd)))
+                    acc_failed = true;
+            }
         }
         if (add_here) {  // a generation without a slot: the book goes on the list once, for the direct path only
             const u64 fl = __ballot(acc_failed);
@@ -1459,8 +1469,9 @@ __global__ void __launch_bounds__(LOB_QP_BLOCK) learn_q_pair_kernel(DevParams P,
 #pragma unroll
             for (int a = 0; a < LOB_N_ACTIONS; a++) xc[a] = qs[a];
             reinterpret_cast<int*>(xc + LOB_N_ACTIONS)[0] = (walk && n <= LOB_QP_CAP1) ? n : -1;
-            // (1 + the ring slot of the generation a light step creates, for the group-2 lane's addition to its slot; 0: listed)
-            reinterpret_cast<int*>(xc + LOB_N_ACTIONS)[1] = (TR && stepped && tlight) ? 1 + ((h.tr_head + 1) & (P.trace_gens - 1)) : 0;
+            // for the group-2 lane's addition to the slot of the generation a light step creates -- 0: listed, else bits 0-5: 1 + the
+            // generation's ring slot, bits 6-30: 1 + the combine slot this lane has put on record for it (0: a claim is on its way)
+            uint32_t light_code = (TR && stepped && tlight) ? 1u + (uint32_t)((h.tr_head + 1) & (P.trace_gens - 1)) : 0u;
             // ---- UpdateTraces, second half (see learn_q_lane_kernel) ----
             if (TR) {
                 const bool listed = stepped && !tlight;
@@ -1500,13 +1511,18 @@ __global__ void __launch_bounds__(LOB_QP_BLOCK) learn_q_pair_kernel(DevParams P,
                         const u64 seen = atomicCAS((unsigned long long*)&claimed[(ch >> 40) & 511], (unsigned long long)LOB_CB_EMPTY, (unsigned long long)ch);
                         if (seen != ch && S.cb_key[(uint32_t)ch & (uint32_t)(S.cb_slots - 1)] != ch)
                             cb_claim_issue(S, pend, tq0, tq1, tq2, action, 0xffffffffu, b * G + nh);
-                        else S.tr_cbslot[(size_t)b * G + nh] = (i32)((uint32_t)ch & (uint32_t)(S.cb_slots - 1));
+                        else {
+                            const uint32_t home = (uint32_t)ch & (uint32_t)(S.cb_slots - 1);
+                            S.tr_cbslot[(size_t)b * G + nh] = (i32)home;
+                            light_code |= (home + 1u) << 6;
+                        }
                     }
                 }
                 // Q(s, a) and the RNG counter after the trace step's draws: for the general kernel if the book is handed back
                 if (stepped) { hp->td = q_sa; hp->rng_ctr = g.ctr; }
             }
             // ... and for the group-2 lane
+            reinterpret_cast<uint32_t*>(xc + LOB_N_ACTIONS)[1] = light_code;
             xc[LOB_N_ACTIONS + 1] = q_sa;
             reinterpret_cast<u64*>(xc)[LOB_N_ACTIONS + 2] = g.ctr;
         } else {
@@ -1522,7 +1538,7 @@ __global__ void __launch_bounds__(LOB_QP_BLOCK) learn_q_pair_kernel(DevParams P,
         } else {
             // ---- group-2 lane: Q, argmax, the TD error, the rest of the hit list ----
             const int n1 = reinterpret_cast<const int*>(xc + LOB_N_ACTIONS)[0];
-            const int light_code = TR ? reinterpret_cast<const int*>(xc + LOB_N_ACTIONS)[1] : 0;
+            const uint32_t light_code = TR ? reinterpret_cast<const uint32_t*>(xc + LOB_N_ACTIONS)[1] : 0u;
             const bool light = light_code != 0;
             if (stepped) {
                 if (!(walk && n1 >= 0 && n <= LOB_QP_CAP2 && n1 + n <= LOB_HL_CAP)) {
@@ -1558,10 +1574,16 @@ __global__ void __launch_bounds__(LOB_QP_BLOCK) learn_q_pair_kernel(DevParams P,
                     if (TR && acc_fuse && !light) S.acc_pend[b] = 0;
                     if (TR && acc_fuse && light) {
                         // the book's one generation (age 0, all 32 tiles alive): alpha delta / 32 x e(0) into its slot
-                        const size_t gi = (size_t)b * P.trace_gens + (light_code - 1);
+                        const size_t gi = (size_t)b * P.trace_gens + ((light_code & 63u) - 1u);
                         const f64 val = (P.alpha * delta) / (f64)LOB_N_TILINGS * (f64)P.trace_pow[0];
-                        if (!acc_generation(S, gi, 0xffffffffu, val, acc_copy(S, (int)(blockIdx.x * (LOB_QP_BLOCK / 64) + (threadIdx.x >> 6)))))
-                            S.acc_list[atomicAdd(&S.acc_list_n[lpar], 1)] = (i32)((uint32_t)b | 0x80000000u);
+                        const int xcd = acc_copy(S, (int)(blockIdx.x * (LOB_QP_BLOCK / 64) + (threadIdx.x >> 6)));
+                        const uint32_t hs = (light_code >> 6) & 0x1ffffffu;
+                        bool added;
+                        if (hs) {  // (the slot the group-1 lane recorded; the generation's signature = last_state's triple + the action)
+                            const float4 vl = (h.slot_cur ^ 1) ? vr[1][0] : vr[0][0];
+                            added = acc_generation_at(S, gi, (int)(hs - 1u), make_int4(tile_quant(vl.x), tile_quant(vl.y), tile_quant(vl.z), h.action), 0xffffffffu, val, xcd);
+                        } else added = acc_generation(S, gi, 0xffffffffu, val, xcd);
+                        if (!added) S.acc_list[atomicAdd(&S.acc_list_n[lpar], 1)] = (i32)((uint32_t)b | 0x80000000u);
                     }
                 }
             } else if (real) {

@@ -1448,13 +1448,14 @@ __device__ inline int acc_copy(const DevState& S, int wave) {
 // accumulate_kernel does it: the slot on record, its identity compared in full once (LOB_CBS_VERIFIED), the probe sequence
 // if it was displaced.  False: no slot (table crowded / hash shared by two identities) -- tr_cbslot is set to -1 and the caller
 // leaves the generation to accumulate_kernel's direct path, which must wait until nobody reads theta.
-__device__ inline bool acc_generation(const DevState& S, size_t gi, uint32_t mask, f64 val, int xcd) {
-    const int cs = S.tr_cbslot[gi];
+// (`cs` = tr_cbslot[gi] and `sg` = the generation's signature as the caller holds them in registers: nothing is loaded again)
+__device__ inline bool acc_generation_at(const DevState& S, size_t gi, int cs, int4 sg, uint32_t mask, f64 val, int xcd) {
     const bool known = cs >= 0 && (cs & LOB_CBS_VERIFIED);
     uint32_t s = (uint32_t)cs & (uint32_t)(S.cb_slots - 1);
     bool found = known;
+    uint32_t touch = 0;
+    if (cs >= 0) touch = S.cb_touch[s];  // (beside the identity's words)
     if (!known) {
-        const int4 sg = *reinterpret_cast<const int4*>(S.tr_sig + gi * 4);
         if (cs >= 0) {
             const int4 id = *reinterpret_cast<const int4*>(S.cb_ident + (size_t)s * 8);
             const uint32_t idm = (uint32_t)S.cb_ident[(size_t)s * 8 + 4];
@@ -1473,13 +1474,20 @@ __device__ inline bool acc_generation(const DevState& S, size_t gi, uint32_t mas
                 if (kk == LOB_CB_EMPTY) break;
                 s = (s + 1) & (uint32_t)(S.cb_slots - 1);
             }
+            if (found) touch = S.cb_touch[s];
         }
         S.tr_cbslot[gi] = found ? (i32)(s | LOB_CBS_VERIFIED) : -1;
     }
     if (!found) return false;
     __hip_atomic_fetch_add(&S.cb_acc[((size_t)xcd * S.cb_slots + s) * 2], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (!(S.cb_touch[s] & 1u)) atomicOr(&S.cb_touch[s], 1u);
+    if (!(touch & 1u)) atomicOr(&S.cb_touch[s], 1u);
     return true;
+}
+__device__ inline bool acc_generation(const DevState& S, size_t gi, uint32_t mask, f64 val, int xcd) {
+    const int cs = S.tr_cbslot[gi];
+    int4 sg = make_int4(0, 0, 0, 0);
+    if (!(cs >= 0 && (cs & LOB_CBS_VERIFIED))) sg = *reinterpret_cast<const int4*>(S.tr_sig + gi * 4);
+    return acc_generation_at(S, gi, cs, sg, mask, val, xcd);
 }
 // `list` (or null: every book): accumulate_kernel over the books the fused accumulation left (lob_state.h acc_list); an entry
 // with bit 31 takes only the book's generations without a slot.

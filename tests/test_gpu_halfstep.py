@@ -57,3 +57,18 @@ def test_reset_abandons_a_half_done_step():
     np.testing.assert_allclose(eng.theta(), orc.theta(), rtol=1e-9, atol=1e-12)
     eng.close()
     orc.close()
+
+
+def test_an_episode_longer_than_the_tick_counters_is_refused():
+    """The TickStatistics counters are 21-bit fields (lob_state.h tick_ab / tick_pos): a stream of 2^21 events or more is
+    refused when it is loaded -- before anything is allocated -- and the stream in place stays usable."""
+    p, rec, eng = _make(B=8)
+    g = engine.default_gen_params()
+    g.n_events = 1 << 21
+    with pytest.raises(engine.LobError) as ei:
+        eng.gen_events(g)
+    assert ei.value.code == abi.LOB_EINVAL and "2^21" in str(ei.value)
+    eng.reset()
+    eng.td_step(5)             # (the 300-event stream loaded before is still there)
+    assert eng.get_books(0, 1)[0].total_ticks == 5
+    eng.close()
