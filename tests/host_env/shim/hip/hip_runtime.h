@@ -29,4 +29,12 @@ static inline unsigned long long atomicCAS(unsigned long long* p, unsigned long 
 static inline uint32_t atomicOr(uint32_t* p, uint32_t v) { const uint32_t o = *p; *p |= v; return o; }
 static inline int atomicAdd(int* p, int v) { const int o = *p; *p += v; return o; }
 static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { const unsigned long long o = *p; *p += v; return o; }
+// (wave-level intrinsics of code the host tests never call -- prepass_run's cooperative row fetch -- so that it still parses)
+#define __forceinline__ inline
+#define __builtin_amdgcn_fence(...) ((void)0)
+#define __builtin_amdgcn_wave_barrier() ((void)0)
+#define __builtin_amdgcn_s_barrier() ((void)0)
+static inline unsigned long long __ballot(int p) { return p ? 1ull : 0ull; }
+static inline int __any(int p) { return p; }
+static const struct { unsigned x, y, z; } threadIdx = {0, 0, 0};
 #endif
