@@ -45,6 +45,7 @@ struct lob_engine {
     hipEvent_t ev_reg_go = nullptr, ev_reg_done = nullptr;  // tile registry kernels on stream2 beside the learner kernels (lob_kernels.h registry_kernel)
     hipEvent_t ev_rest_go = nullptr, ev_rest_done = nullptr;  // learn_q_rest_kernel on stream2 beside the trace kernels
     bool rest_side = true;      // (LOB_REST_SIDE=0: on the main stream, as before; A/B switch)
+    long long flow[4] = {0, 0, 0, 0};  // lob_debug_flow: learner steps by the shape of their update (see there)
     bool acc_fuse = true;       // Q(lambda), the pair kernel + the lane-per-generation trace kernel: updates added to their slots there, accumulate_kernel over a list (LOB_ACC_FUSE=0: over every book; A/B switch)
     bool acc_block = true;      // SARSA(lambda): accumulate_block_kernel (LOB_ACC_BLOCK=0: accumulate_kernel; A/B switch)
     int env_step_lanes = 64;    // books per wave of env_step_kernel (LOB_ENV_STEP_LANES=32: two half-full waves per SIMD; experiment)
@@ -1074,6 +1075,7 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
         const bool fast = e->P.memo != 0;  // (implies one group)
         bool rest_pending = false;
         bool acc_fused = false;  // (this step: see the learn kernel's launch)
+        bool rest_side_now = false;
         const bool dq = e->P.algo == LOB_ALGO_DOUBLE_Q;  // (fast && dq: every step without usable hit lists takes the general act kernel over the whole batch)
         const int lpar = first ? (e->list_par ^= 1) : e->list_par;
         e->last_par = par;
@@ -1197,6 +1199,7 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                     if (side) {
                         HIPCHK(hipEventRecord(e->ev_rest_done, e->stream2));
                         rest_pending = true;
+                        rest_side_now = true;
                     }
                 }
                 if (e->P.sarsa_lanes && !e->reg_fork_late) { int rc = registry_fork(e, st, rnd, par); if (rc) return rc; }
@@ -1227,6 +1230,8 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                 TimedLaunch t(e, "accumulate_kernel");
                 // SARSA(lambda): every book keeps all its generations -- sums per slot inside 1 024-book blocks first.  The same for
                 // Q(lambda) once most actions are greedy (P(greedy) = 1 - eps + eps / 9 > 0.7: more than three live generations per book)
+                e->flow[acc_blocked(e) ? 2 : acc_fused ? 0 : 3]++;
+                if (rest_side_now) e->flow[1]++;
                 if (acc_blocked(e)) {
                     hipLaunchKernelGGL(accumulate_block_kernel, dim3((e->B + LOB_ACB_BLOCK - 1) / LOB_ACB_BLOCK, e->P.trace_kmax), dim3(LOB_ACB_BLOCK), 0, e->stream, e->P, e->S, par, e->step_id);
                 } else if (acc_fused) {
@@ -1695,6 +1700,16 @@ extern "C" int lob_debug_fastpath(lob_engine* e, int64_t* out, int32_t n_out) {
     if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
     hipFree(d);
     HIPCHK(err);
+    return LOB_OK;
+}
+
+// Diagnostics (not part of include/lob_engine.h): learner steps (combined update) since lob_create by the shape of their update
+// -- [0] updates added to their slots by the learn / trace kernels, accumulate_kernel over the list they left (Q(lambda)),
+// [1] steps whose learn_q_rest_kernel ran beside the trace kernels on the second stream, [2] accumulate_block_kernel,
+// [3] accumulate_kernel over every book.  The tests use it to know which path they have compared with the oracle.
+extern "C" int lob_debug_flow(lob_engine* e, int64_t out[4]) {
+    if (!e || !out) return LOB_EINVAL;
+    for (int i = 0; i < 4; i++) out[i] = e->flow[i];
     return LOB_OK;
 }
 

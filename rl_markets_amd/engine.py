@@ -253,6 +253,14 @@ class Engine:
         self._check(self.lib.lob_get_path_stats(self.h, _ptr(c)))
         return c
 
+    def flow_stats(self):
+        """lob_debug_flow (a diagnostic export, not in include/lob_engine.h): learner steps by the shape of their combined update."""
+        c = np.zeros(4, np.int64)
+        fn = self.lib.lob_debug_flow
+        fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_void_p]
+        self._check(fn(self.h, _ptr(c)))
+        return {"added_in_place": int(c[0]), "rest_on_side_stream": int(c[1]), "block_sums": int(c[2]), "every_book": int(c[3])}
+
     def fastpath_stats(self):
         """lob_debug_fastpath (a diagnostic export, not in include/lob_engine.h): written weights and the live books' hit-list lengths."""
         n = 4 + 257

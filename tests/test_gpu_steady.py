@@ -181,6 +181,7 @@ def test_reset_then_weight_load_then_steps(monkeypatch):
 
 
 # ---- the randomised configuration sweep with the timed kernels forced on ------------------------------------
+FLOWS = []       # (variant, algorithm, Engine.flow_stats()) of every case: which update path it has compared with the oracle
 CUT_SHORT = []   # cases the shadow oracle ended early (a chaotic configuration proves nothing beyond that step): reported below
 
 
@@ -189,6 +190,8 @@ VARIANTS = {
     "lane": {"LOB_Q_LANES": "1", "LOB_Q_PAIR": "0", "LOB_FUSE_ACT": "1"},
     "pair": {"LOB_Q_LANES": "1", "LOB_Q_PAIR": "1", "LOB_FUSE_ACT": "1"},
     "pair_nofuse": {"LOB_Q_LANES": "1", "LOB_Q_PAIR": "1", "LOB_NO_FUSE": "1", "LOB_FUSE_ACT": "1"},
+    # (Q(lambda): "pair" adds the updates to their slots inside the learn / trace kernels; here accumulate_kernel does, over every book)
+    "pair_acc_pass": {"LOB_Q_LANES": "1", "LOB_Q_PAIR": "1", "LOB_FUSE_ACT": "1", "LOB_ACC_FUSE": "0"},
 }
 
 
@@ -247,6 +250,11 @@ def test_random_configuration_timed_kernels(monkeypatch, seed, variant):
             break
         eng.clear_inventory(); orc.clear_inventory(); shadow.clear_inventory()
         eng.handle_terminal(); orc.handle_terminal(); shadow.handle_terminal()
+    # which update path the comparison above has been through
+    flow = eng.flow_stats()
+    FLOWS.append((variant, p.algo, flow))
+    if variant == "pair_acc_pass":
+        assert flow["added_in_place"] == 0, flow
     if not chaotic:
         drift = float(np.abs(orc.theta() - shadow.theta()).max())
         np.testing.assert_allclose(eng.theta(), orc.theta(), rtol=1e-9, atol=max(1e-12, 100.0 * drift))
@@ -264,3 +272,17 @@ def test_zz_report_cases_cut_short():
     n = len(VARIANTS) * (int(os.environ.get("LOB_FUZZ_SEEDS", "32")) // 2)
     print("timed-kernel sweep: %d of %d cases cut short by the shadow oracle%s" % (len(CUT_SHORT), n, (": " + "; ".join(CUT_SHORT)) if CUT_SHORT else ""))
     assert len(CUT_SHORT) <= n // 4
+
+
+def test_zz_update_paths_the_sweep_went_through():
+    """(after the sweep)  The Q(lambda) cases of the "pair" variant must have had their updates added to the slots inside the
+    learn / trace kernels (Engine.flow_stats), those of "pair_acc_pass" by accumulate_kernel over every book: both shapes of
+    the combined update have then been compared with the oracle step by step."""
+    if not FLOWS:
+        pytest.skip("the sweep did not run in this session")
+    ql = [(v, f) for v, a, f in FLOWS if a == abi.ALGO_QLAMBDA]
+    in_place = [f for v, f in ql if v == "pair" and f["added_in_place"] > 0 and f["every_book"] == 0]
+    whole = [f for v, f in ql if v == "pair_acc_pass" and f["every_book"] > 0]
+    print("Q(lambda) cases with updates added in place: %d, with the accumulate pass over every book: %d" % (len(in_place), len(whole)))
+    assert len(in_place) >= 3 and len(whole) >= 3
+    assert all(f["added_in_place"] == 0 for v, f in ql if v != "pair" and v != "lane")
