@@ -1158,6 +1158,9 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                         // the updates added to their slots by this kernel and trace_lane_kernel (lob_state.h acc_list): Q(lambda) while its
                         // books keep few generations (else accumulate_block_kernel's sums per block win)
                         acc_fused = pair && fuse && e->acc_fuse && e->P.combine && e->P.sarsa_lanes && e->P.algo == LOB_ALGO_QLAMBDA && !acc_blocked(e) && G == 1;
+                        // (not while the learn kernel hands most books back -- a dense theta: every one of them would go on the list
+                        // through one counter; the list's length of a few steps ago, as launch_env_fused reads it)
+                        if (e->rest_hint && *(volatile i32*)e->rest_hint > std::max(1024, e->B / 16)) acc_fused = false;
                         const int gq = pair ? std::min(LOB_QP_OCC * e->n_cus, (nb + LOB_QP_BOOKS - 1) / LOB_QP_BOOKS) : std::min(e->n_cus, (nb + LOB_QL_BLOCK - 1) / LOB_QL_BLOCK);
                         const size_t lds = pair ? qpair_lds_bytes(e->P.cwords4) : qlane_lds_bytes(e->P.cwords4);
 #define LOB_QL_LAUNCH(A, VT, TR)                                                                                                                            \
