@@ -152,6 +152,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--books", type=int, default=65536, help="books per GPU")
     ap.add_argument("--depth", type=int, default=10)
+    ap.add_argument("--move-prob", type=float, default=None,
+                    help="experiment: probability that an event of the synthetic stream moves the touch (default: the generator's 0.35); 1.0 makes every env-step one event long")
     ap.add_argument("--algo", default="q_lambda", choices=["q_lambda", "sarsa", "double_q"])
     ap.add_argument("--memory-size", type=int, default=20000000)
     ap.add_argument("--events", type=int, default=0, help="events per book (0 = 64 warm-up + 2048)")
@@ -211,6 +213,8 @@ def main():
         p.epsilon = args.epsilon
     g = engine.default_gen_params()
     g.n_events = args.events if args.events else 64 + 2048
+    if args.move_prob is not None:
+        g.move_prob_q16 = min(65535, int(args.move_prob * 65536))
     need = 64 + 6 * (args.steps + args.warmup)
     if g.n_events < 64 + 3 * (args.steps + args.warmup):
         g.n_events = need
@@ -411,6 +415,7 @@ def main():
                                                                    args.memory_size),
                 "books_per_gpu": args.books, "depth": args.depth, "events_per_book": g.n_events,
                 "events_per_step": round(eps, 4), "live_traces_per_book": round(n_live, 1),
+                "move_prob": args.move_prob,   # (None: the generator's default; an experiment knob otherwise)
                 "env_steps": steps_done, "reset_ms_per_episode": round(reset_ms, 2), "steps_per_episode": round(steps_per_episode, 1),
                 # diagnostics of the fast paths (lob_get_path_stats), per timed step where cumulative
                 "paths": {"trace_lane_handed_back_per_step": round(float(ps1[0] - ps0[0]) / max(args.steps, 1), 1),
