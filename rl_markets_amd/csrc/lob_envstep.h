@@ -97,6 +97,9 @@ __global__ void __launch_bounds__(64, EnvStepOcc<LANES>::waves) env_step_kernel(
     EnvR& e = lds_env[threadIdx.x & (LANES - 1)].e;  // (the idle upper half of a 32-book wave writes the slots of lanes that do nothing with them)
     if (LANES == 64 || threadIdx.x < LANES) e = er;
     __syncthreads();
+#ifdef LOB_PROF
+    const long long t_r1 = clock64();  // (round 1 is in: its scalars have gone to LDS)
+#endif
 
     // ---- who steps, and from which list (act_light_book) ----------------------------------------------------------------
     const int cur_slot = h0.slot_cur ^ 1;  // swap(state, last_state)
@@ -154,6 +157,10 @@ __global__ void __launch_bounds__(64, EnvStepOcc<LANES>::waves) env_step_kernel(
     }
     rm_prep(S.pnl_ups, B, b, wu);
     rm_prep(S.pnl_downs, B, b, wd);
+#ifdef LOB_PROF
+    __builtin_amdgcn_s_waitcnt(0);     // (the instrumented build waits for round 2 here, to time it apart from the arithmetic that follows)
+    const long long t_r2 = clock64();
+#endif
 
     // ---- the action (act_light_book, from here on) ------------------------------------------------------------------------
     int action = 0;
@@ -260,7 +267,12 @@ __global__ void __launch_bounds__(64, EnvStepOcc<LANES>::waves) env_step_kernel(
         c.pre_n_track = m_n_track;
         c.pre_complete = m_complete;
         c.prof_start(S.prof, threadIdx.x & 63, t_entry);
-        c.mark(30);  // rounds 1 and 2, action selection
+#ifdef LOB_PROF
+        c.acc_[0] += t_r1 - t_entry;   // [20] launch, round 1, scalars to LDS
+        c.acc_[11] += t_r2 - t_r1;     // [31] round 2 issued and in
+        c.pt_ = t_r2;
+#endif
+        c.mark(30);  // action selection (uninstrumented: from the launch, rounds 1 and 2 included)
         const i64 ev0 = e.events;
         StepAgg g;
         step_prologue(c, e, action, g, cur);

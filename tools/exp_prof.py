@@ -45,13 +45,14 @@ names = {0: "act: headers, memo records, state variables", 1: "act: tile hashing
          11: "trace: old generations (scan, stores, claim issue)", 12: "trace: new generation + claim issue", 18: "trace: header stores, previous book's claims",
          13: "learn_q: headers, memo records, state variables", 14: "learn_q: tile hashing", 15: "learn_q: coarse filter (LDS)",
          16: "learn_q: exact map for the coarse hits", 17: "learn_q: written weights + ordered continuation", 19: "learn_q: argmax / delta / header stores"}
-names.update({30: "env: action selection (hit list replay), launch to here", 20: "env: agent scalars, first track entry, two rows in",
+names.update({30: "env: action selection (hit list replay, policy, header stores)", 20: "env: launch, round 1 (loads addressed by the book id), scalars to LDS",
+              31: "env: round 2 (memo record, listed weights, track entries, rows) issued and in",
               21: "env: DoAction (quotes, tick conversions, queue position)", 22: "env: hot copy LDS -> registers, order keys",
               23: "env: per pass (lane 0's own): loop top, next entry / row requested", 24: "env: per pass (lane 0's own): the pass",
               25: "env: waiting for the wave's slowest lane", 26: "env: hot copy back", 27: "env: PnL windows",
               28: "env: state variables (track entry, 8 variables, memo look-up issued)", 29: "env: agent scalars out, memo claim"})
 print("(clocks per wave ITERATION: the Q kernels take LOB_FAST_NB books per iteration and stamp the batch on its first book's row)")
-for lo, hi, nm, idx in ((20, 32, "env_kernel (per WAVE-step: 64 books; the per-pass rows are summed over lane 0's passes)", (30, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29)), (0, 8, "act_kernel", range(0, 8)), (8, 20, "trace_kernel", (8, 9, 10, 11, 12, 18)), (13, 20, "learn_q kernel", (13, 14, 15, 16, 17, 19))):
+for lo, hi, nm, idx in ((20, 32, "env_kernel (per WAVE-step: 64 books; the per-pass rows are summed over lane 0's passes)", (20, 31, 30, 21, 22, 23, 24, 25, 26, 27, 28, 29)), (0, 8, "act_kernel", range(0, 8)), (8, 20, "trace_kernel", (8, 9, 10, 11, 12, 18)), (13, 20, "learn_q kernel", (13, 14, 15, 16, 17, 19))):
     tot = sum(d[i] for i in idx)
     print("%s: %.0f clocks per wave" % (nm, tot))
     for i in idx:
