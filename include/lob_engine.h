@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LOB_ABI_VERSION 4
+#define LOB_ABI_VERSION 5
 
 #define LOB_N_ACTIONS 9   /* reference Intraday::DoAction table, src/environment/intraday.cpp:181-219 */
 #define LOB_N_TILINGS 32  /* config/example.yaml:18 (compile-time in the kernels) */
@@ -201,11 +201,16 @@ typedef struct lob_book_dump {
     int32_t total_ticks;       /* TickStatistics::total_ticks */
     int32_t n_traces;          /* live eligibility traces */
     /* TradeStatistics / TickStatistics of the episode (include/environment/statistics.h:19-50): what Base::ClearInventory
-     * (base.cpp:339-349) and Base::UpdateStats (base.cpp:412-442) count; ask/bid_transactions are ask/bid_n_transacted above,
-     * the reference never touches the placed / cancelled / "no ..." counters */
+     * (base.cpp:339-349) and Base::UpdateStats (base.cpp:412-442) count; the reference never touches the placed / cancelled /
+     * "no ..." counters */
     int32_t market_buys, market_sells;
     int32_t ticks_with_ask, ticks_with_bid, ticks_with_both;
     int32_t ticks_with_position, ticks_long, ticks_short;
+    /* TradeStatistics::ask_transactions / bid_transactions: ask/bid_n_transacted AS OF THE LAST DECISION -- Base::UpdateStats
+     * (base.cpp:415-416) copies them when performAction has placed its orders (base.cpp:278), before the step's events run;
+     * what the step's own events fill shows here one decision later (after an episode's last step: never).  getTotalTransactions /
+     * getOrderRatio / writeStats (base.cpp:451-473) read these. */
+    int32_t ask_transactions, bid_transactions;
 } lob_book_dump;
 
 typedef struct lob_engine lob_engine;

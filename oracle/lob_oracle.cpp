@@ -636,6 +636,7 @@ struct Env {
     double ep_reward = 0, ep_pnl = 0, ep_bandh = 0;
     int total_ticks = 0, market_buys = 0, market_sells = 0;
     int ticks_with_ask = 0, ticks_with_bid = 0, ticks_with_both = 0, ticks_with_position = 0, ticks_long = 0, ticks_short = 0;  // TickStatistics
+    int ask_transactions = 0, bid_transactions = 0;  // TradeStatistics: n_transacted of the two books as of the last UpdateStats (base.cpp:415-416)
     int64_t events_consumed = 0;
 
     Env(const lob_params& p, const uint32_t* r, int ne)
@@ -819,6 +820,7 @@ struct Env {
         ep_reward = ep_pnl = ep_bandh = 0;  // ClearStats
         total_ticks = market_buys = market_sells = 0;
         ticks_with_ask = ticks_with_bid = ticks_with_both = ticks_with_position = ticks_long = ticks_short = 0;
+        ask_transactions = bid_transactions = 0;
         spread_window.clear(); tp_mp.clear(); f_midprice.clear(); f_volatility.clear();
         f_vwap_numer.clear(); f_vwap_denom.clear(); pnl_ups.clear(); pnl_downs.clear();
         f_ask_tx.clear(); f_bid_tx.clear();
@@ -846,7 +848,8 @@ struct Env {
         momentum_pnl_step = 0.0;
         DoAction(action);
         CheckOrders();
-        total_ticks++;  // UpdateStats (base.cpp:412-442)
+        ask_transactions = ask.n_transacted_; bid_transactions = bid.n_transacted_;  // UpdateStats (base.cpp:412-442)
+        total_ticks++;
         {
             const bool has_ask = ask.order_count() > 0, has_bid = bid.order_count() > 0;
             if (has_ask) ticks_with_ask++;
@@ -972,6 +975,7 @@ struct Env {
         d.market_buys = market_buys; d.market_sells = market_sells;
         d.ticks_with_ask = ticks_with_ask; d.ticks_with_bid = ticks_with_bid; d.ticks_with_both = ticks_with_both;
         d.ticks_with_position = ticks_with_position; d.ticks_long = ticks_long; d.ticks_short = ticks_short;
+        d.ask_transactions = ask_transactions; d.bid_transactions = bid_transactions;
     }
 };
 

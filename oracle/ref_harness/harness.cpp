@@ -183,6 +183,7 @@ public:
         d.market_buys = trade_stats.market_buys; d.market_sells = trade_stats.market_sells;
         d.ticks_with_ask = tick_stats.ticks_with_ask; d.ticks_with_bid = tick_stats.ticks_with_bid; d.ticks_with_both = tick_stats.ticks_with_both;
         d.ticks_with_position = tick_stats.ticks_with_position; d.ticks_long = tick_stats.ticks_long; d.ticks_short = tick_stats.ticks_short;
+        d.ask_transactions = trade_stats.ask_transactions; d.bid_transactions = trade_stats.bid_transactions;
     }
 };
 

@@ -99,6 +99,7 @@ class BookDump(C.Structure):
         ("cursor", C.c_int32), ("terminal", C.c_int32), ("total_ticks", C.c_int32), ("n_traces", C.c_int32),
         ("market_buys", C.c_int32), ("market_sells", C.c_int32), ("ticks_with_ask", C.c_int32), ("ticks_with_bid", C.c_int32),
         ("ticks_with_both", C.c_int32), ("ticks_with_position", C.c_int32), ("ticks_long", C.c_int32), ("ticks_short", C.c_int32),
+        ("ask_transactions", C.c_int32), ("bid_transactions", C.c_int32),
     ]
 
 

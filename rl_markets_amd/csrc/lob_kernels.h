@@ -132,6 +132,7 @@ __global__ void __launch_bounds__(RB) reset_kernel(const DevParams* __restrict__
     e.ep_reward = e.ep_pnl = e.ep_bandh = 0.0;
     e.total_ticks = e.market_buys = e.market_sells = 0;
     e.tick_ab = e.tick_pos = 0;
+    e.ntr_snap = 0;
     if (M.init_ok) {
         const int k = M.k_warm;
         const Track t1 = c.track(k - 1);
@@ -229,6 +230,7 @@ __global__ void __launch_bounds__(128, 2) reset2_kernel(const DevParams* __restr
     e.ep_reward = e.ep_pnl = e.ep_bandh = 0.0;
     e.total_ticks = e.market_buys = e.market_sells = 0;
     e.tick_ab = e.tick_pos = 0;
+    e.ntr_snap = 0;
     if (M.init_ok) {
         const int k = M.k_warm;
         const Track t1 = c.track(k - 1);
@@ -2351,6 +2353,7 @@ __global__ void dump_kernel(const DevParams* __restrict__ Pp, DevState S, int fi
     d.total_ticks = e.total_ticks;
     d.market_buys = e.market_buys; d.market_sells = e.market_sells;
     d.ticks_with_ask = (i32)(e.tick_ab & 0x1fffff); d.ticks_with_bid = (i32)((e.tick_ab >> 21) & 0x1fffff); d.ticks_with_both = (i32)((e.tick_ab >> 42) & 0x1fffff);
+    d.ask_transactions = (i32)(uint32_t)e.ntr_snap; d.bid_transactions = (i32)(uint32_t)(e.ntr_snap >> 32);
     d.ticks_with_position = (i32)(e.tick_pos & 0x1fffff); d.ticks_long = (i32)((e.tick_pos >> 21) & 0x1fffff); d.ticks_short = (i32)((e.tick_pos >> 42) & 0x1fffff);
     int n_tr = 0;
     {

@@ -68,6 +68,9 @@ typedef float f32;
     /* TickStatistics (Base::UpdateStats, base.cpp:412-442), three 21-bit counters per word: with_ask | with_bid << 21 |         \
      * with_both << 42, and with_position | long << 21 | short << 42 (an episode has < 2^21 steps) */                          \
     X(i64, tick_ab) X(i64, tick_pos)                                                                                           \
+    /* TradeStatistics::ask_transactions | bid_transactions << 32: a_ntr / b_ntr as Base::UpdateStats copies them at decision     \
+     * time (base.cpp:415-416), before the step's events */                                                                   \
+    X(i64, ntr_snap)                                                                                                          \
     X(i64, events)    /* depth records consumed (incl. warm-up) */                                             \
     /* per side: n_transacted_ + the single live order (quirk Q13); otk = ToTicks(order price) */             \
     X(i32, a_ntr) X(i32, a_on) X(f64, a_opx) X(i64, a_osz) X(i64, a_oqh) X(i64, a_oqt) X(i64, a_oex) X(i64, a_oiq) X(i32, a_otk) \

@@ -284,11 +284,11 @@ public:
     // Base::getTotalTransactions / getOrderRatio (base.cpp:463-473; "nTr" and the denominator of "Ppt" in src/main.cpp:234-236)
     int getTotalTransactions(int b = 0) {
         lob_book_dump d = book(b);
-        return d.ask_n_transacted + d.bid_n_transacted + d.market_buys + d.market_sells;
+        return d.ask_transactions + d.bid_transactions + d.market_buys + d.market_sells;
     }
     float getOrderRatio(int b = 0) {
         lob_book_dump d = book(b);
-        return float(d.ask_n_transacted + d.bid_n_transacted) / (d.market_buys + d.market_sells);
+        return float(d.ask_transactions + d.bid_transactions) / (d.market_buys + d.market_sells);
     }
     // Base::writeStats (base.cpp:451-456): experiment, tick and trade statistics are each written to the SAME path, truncating
     // it (statistics.cpp:12,36,70) -- what survives is TradeStatistics::write, eight lines (quirk Q17).  The reference never
@@ -300,8 +300,8 @@ public:
         ofs << "bids_placed," << 0 << std::endl;
         ofs << "asks_cancelled," << 0 << std::endl;
         ofs << "bids_cancelled," << 0 << std::endl;
-        ofs << "ask_transactions," << d.ask_n_transacted << std::endl;
-        ofs << "bid_transactions," << d.bid_n_transacted << std::endl;
+        ofs << "ask_transactions," << d.ask_transactions << std::endl;
+        ofs << "bid_transactions," << d.bid_transactions << std::endl;
         ofs << "market_sells," << d.market_sells << std::endl;
         ofs << "market_buys," << d.market_buys << std::endl;
     }

@@ -92,7 +92,7 @@ class GpuIntraday : public Base {
         episode_stats.bandh = last_.episode_bandh;
         tick_stats.total_ticks = last_.total_ticks;
         // TradeStatistics / TickStatistics (statistics.h:19-50): Base::getTotalTransactions / getOrderRatio / writeStats read these
-        trade_stats.ask_transactions = last_.ask_n_transacted; trade_stats.bid_transactions = last_.bid_n_transacted;
+        trade_stats.ask_transactions = last_.ask_transactions; trade_stats.bid_transactions = last_.bid_transactions;  // (the snapshot of the last UpdateStats)
         trade_stats.market_buys = last_.market_buys; trade_stats.market_sells = last_.market_sells;
         tick_stats.ticks_with_ask = last_.ticks_with_ask; tick_stats.ticks_with_bid = last_.ticks_with_bid;
         tick_stats.ticks_with_both = last_.ticks_with_both; tick_stats.ticks_with_position = last_.ticks_with_position;

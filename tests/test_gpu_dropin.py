@@ -123,10 +123,11 @@ def test_train_call_sequence_over_the_gpu_learner_one_book(tmp_path):
     e = eps[0]
     assert e["reward"] == last["episode_reward"] and e["steps"] >= int(fx["steps"])
     # the fixture's last record is the state BEFORE RunEpisode's closing ClearInventory: one more market order may follow
-    ntr = int(last["ask_n_transacted"] + last["bid_n_transacted"] + last["market_buys"] + last["market_sells"])
+    # (TradeStatistics::ask/bid_transactions: the books' n_transacted as of the last decision, base.cpp:415-416)
+    ntr = int(last["ask_transactions"] + last["bid_transactions"] + last["market_buys"] + last["market_sells"])
     assert e["nTr"] in (ntr, ntr + 1)
-    want = ["asks_placed,0", "bids_placed,0", "asks_cancelled,0", "bids_cancelled,0", "ask_transactions,%d" % last["ask_n_transacted"],
-            "bid_transactions,%d" % last["bid_n_transacted"]]
+    want = ["asks_placed,0", "bids_placed,0", "asks_cancelled,0", "bids_cancelled,0", "ask_transactions,%d" % last["ask_transactions"],
+            "bid_transactions,%d" % last["bid_transactions"]]
     assert stats.splitlines()[:6] == want and stats.splitlines()[6].startswith("market_sells,") and len(stats.splitlines()) == 8
 
 

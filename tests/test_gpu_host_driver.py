@@ -42,11 +42,11 @@ def test_lob_run_single_book_matches_oracle(tmp_path):
     # Base::writeStats as the reference leaves it (quirk Q17: three writers truncate one path, the trade statistics survive) and
     # the nTr line of src/main.cpp:234-236
     bk = r["book"]
-    ntr = int(bk["ask_n_transacted"] + bk["bid_n_transacted"] + bk["market_buys"] + bk["market_sells"])
+    ntr = int(bk["ask_transactions"] + bk["bid_transactions"] + bk["market_buys"] + bk["market_sells"])   # (as of the last decision: base.cpp:415-416)
     assert [l for l in rows if l.startswith("stats,")][0].split(",")[1] == str(ntr)
     assert open(stats_file).read().splitlines() == [
-        "asks_placed,0", "bids_placed,0", "asks_cancelled,0", "bids_cancelled,0", "ask_transactions,%d" % bk["ask_n_transacted"],
-        "bid_transactions,%d" % bk["bid_n_transacted"], "market_sells,%d" % bk["market_sells"], "market_buys,%d" % bk["market_buys"]]
+        "asks_placed,0", "bids_placed,0", "asks_cancelled,0", "bids_cancelled,0", "ask_transactions,%d" % bk["ask_transactions"],
+        "bid_transactions,%d" % bk["bid_transactions"], "market_sells,%d" % bk["market_sells"], "market_buys,%d" % bk["market_buys"]]
     assert float(pnl) == pytest.approx(r["book"]["episode_pnl"], rel=1e-9)
     # EpsilonGreedy::HandleTerminal(0): eps = eps_init * (floor/init)^(0/T) = eps_init
     assert float(eps) == pytest.approx(0.8)

@@ -33,7 +33,7 @@ def make(depth=5, trades=2, n_events=500, B=4, algo=abi.ALGO_SARSA, theta_mode=a
 
 def test_no_cpu_fallback_symbols():
     lib = abi.load()
-    assert lib.lob_abi_version() == 4
+    assert lib.lob_abi_version() == 5
 
 
 def test_features_match_oracle():
