@@ -47,6 +47,8 @@ struct lob_engine {
     bool rest_side = true;      // (LOB_REST_SIDE=0: on the main stream, as before; A/B switch)
     long long flow[4] = {0, 0, 0, 0};  // lob_debug_flow: learner steps by the shape of their update (see there)
     bool acc_fuse = true;       // Q(lambda), the pair kernel + the lane-per-generation trace kernel: updates added to their slots there, accumulate_kernel over a list (LOB_ACC_FUSE=0: over every book; A/B switch)
+    bool acc_batches_set = false;
+    int acc_batches = LOB_ACB_K;  // accumulate_block_kernel: batches of 1 024 books per block (LOB_ACC_BATCHES=1|2|4|8; A/B switch)
     bool acc_block = true;      // SARSA(lambda): accumulate_block_kernel (LOB_ACC_BLOCK=0: accumulate_kernel; A/B switch)
     int env_step_lanes = 64;    // books per wave of env_step_kernel (LOB_ENV_STEP_LANES=32: two half-full waves per SIMD; experiment)
     bool prepass_roles = false; // the pre-pass on two waves per 64 books (reset2_kernel / prepass_extend2_kernel; LOB_PREPASS_ROLES=1): measured slower, opt-in
@@ -306,6 +308,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     if (const char* g = getenv("LOB_REST_SIDE")) e->rest_side = !(g[0] == '0');
     if (const char* g = getenv("LOB_ACC_BLOCK")) e->acc_block = !(g[0] == '0');
     if (const char* g = getenv("LOB_ACC_FUSE")) e->acc_fuse = !(g[0] == '0');
+    if (const char* g = getenv("LOB_ACC_BATCHES")) { const int v = atoi(g); if (v >= 1 && v <= 16) { e->acc_batches = v; e->acc_batches_set = true; } }
     if (const char* g = getenv("LOB_ENV_STEP_LANES")) { if (atoi(g) == 32) e->env_step_lanes = 32; }
     if (const char* g = getenv("LOB_PREPASS_ROLES")) e->prepass_roles = g[0] == '1';
     if (hipHostMalloc((void**)&e->rest_hint, sizeof(i32), hipHostMallocMapped) == hipSuccess) {
@@ -1236,7 +1239,10 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                 e->flow[acc_blocked(e) ? 2 : acc_fused ? 0 : 3]++;
                 if (rest_side_now) e->flow[1]++;
                 if (acc_blocked(e)) {
-                    hipLaunchKernelGGL(accumulate_block_kernel, dim3((e->B + LOB_ACB_BLOCK - 1) / LOB_ACB_BLOCK, e->P.trace_kmax), dim3(LOB_ACB_BLOCK), 0, e->stream, e->P, e->S, par, e->step_id);
+                    // (batches per block: SARSA(lambda) 80 us with one, 89 with two or four -- its blocks are bound by their LDS insertions, not by what
+                    // they send to memory; mostly-greedy Q(lambda) 58 -> 50 us with four)
+                    const int nbat = e->acc_batches_set ? e->acc_batches : (e->P.algo == LOB_ALGO_SARSA ? 1 : std::max(1, std::min(e->acc_batches, e->B / (16 * LOB_ACB_BLOCK))));
+                    hipLaunchKernelGGL(accumulate_block_kernel, dim3((e->B + LOB_ACB_BLOCK * nbat - 1) / (LOB_ACB_BLOCK * nbat), e->P.trace_kmax), dim3(LOB_ACB_BLOCK), 0, e->stream, e->P, e->S, par, e->step_id, nbat);
                 } else if (acc_fused) {
                     // what the fused accumulation left: a few hundred books (the grid's waves stride over the list)
                     const int sh = acc_lanes_shift(e);

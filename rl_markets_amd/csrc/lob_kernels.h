@@ -1616,16 +1616,29 @@ __global__ void __launch_bounds__(LOB_BLOCK) accumulate_kernel(DevParams P, DevS
 // their holders among the block's books.  Slot look-up, verification and the direct path as in accumulate_kernel.
 #define LOB_ACB_BLOCK 1024
 #define LOB_ACB_TAB 2048
-__global__ void __launch_bounds__(LOB_ACB_BLOCK) accumulate_block_kernel(DevParams P, DevState S, int par, int sid) {
+#ifndef LOB_ACB_K
+#define LOB_ACB_K 4      /* batches of LOB_ACB_BLOCK books per block */
+#endif
+__global__ void __launch_bounds__(LOB_ACB_BLOCK) accumulate_block_kernel(DevParams P, DevState S, int par, int sid, int n_batches) {
     __shared__ i32 keys[LOB_ACB_TAB];
     __shared__ f64 sums[LOB_ACB_TAB];
-    __shared__ i32 any_active;
     const int lane = threadIdx.x & 63;
     for (int i = threadIdx.x; i < LOB_ACB_TAB; i += LOB_ACB_BLOCK) { keys[i] = -1; sums[i] = 0.0; }
-    if (threadIdx.x == 0) any_active = 0;
     __syncthreads();
-    const int b = blockIdx.x * LOB_ACB_BLOCK + threadIdx.x;
     const int age = blockIdx.y;
+    int xcd = 0;
+    if (S.cb_reps > 1) {
+        unsigned x;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+        xcd = (int)(x & (unsigned)(S.cb_reps - 1));
+        if (S.cb_reps > 8) xcd = (int)(x & 7u) * (S.cb_reps >> 3) + (int)(blockIdx.x & ((S.cb_reps >> 3) - 1));
+    }
+    // n_batches (up to LOB_ACB_K, fewer for a small batch of books: the batches are a chain) of LOB_ACB_BLOCK books share the block's table: what a block sends to memory at the end is one addition per
+    // DISTINCT slot among its books, and the distinct slots grow far slower than the books (the popular generations are held by
+    // a few per cent of all books each)
+#pragma unroll 1
+    for (int kb = 0; kb < n_batches; kb++) {
+    const int b = (blockIdx.x * n_batches + kb) * LOB_ACB_BLOCK + threadIdx.x;
     int n = 0, head = 0;
     f64 scaled = 0.0;
     if (b < S.B) {
@@ -1633,9 +1646,7 @@ __global__ void __launch_bounds__(LOB_ACB_BLOCK) accumulate_block_kernel(DevPara
         if (h.stepped) { n = h.tr_n; head = h.tr_head; scaled = h.upd / (f64)LOB_N_TILINGS; }
     }
     const bool mine = age < n;
-    if (__any(mine) && lane == 0) any_active = 1;
-    __syncthreads();
-    if (!any_active) return;  // (block-uniform: no book of the block has a generation this old)
+    if (!__syncthreads_or(mine ? 1 : 0)) continue;  // (block-uniform: no book of the batch has a generation this old)
     const int G = P.trace_gens;
     const int bb = b < S.B ? b : 0;
     const int slot = (head - age + G) & (G - 1);
@@ -1688,13 +1699,6 @@ __global__ void __launch_bounds__(LOB_ACB_BLOCK) accumulate_block_kernel(DevPara
         }
         spilled = !placed;
     }
-    int xcd = 0;
-    if (S.cb_reps > 1) {
-        unsigned x;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
-        xcd = (int)(x & (unsigned)(S.cb_reps - 1));
-        if (S.cb_reps > 8) xcd = (int)(x & 7u) * (S.cb_reps >> 3) + (int)(blockIdx.x & ((S.cb_reps >> 3) - 1));
-    }
     if (spilled) {  // (a crowded block table: straight to the slot)
         __hip_atomic_fetch_add(&S.cb_acc[((size_t)xcd * S.cb_slots + s) * 2], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (!(S.cb_touch[s] & 1u)) atomicOr(&S.cb_touch[s], 1u);
@@ -1723,6 +1727,7 @@ __global__ void __launch_bounds__(LOB_ACB_BLOCK) accumulate_block_kernel(DevPara
             }
         }
     }
+    }  // (batches)
     __syncthreads();
     for (int i = threadIdx.x; i < LOB_ACB_TAB; i += LOB_ACB_BLOCK) {
         const i32 k = keys[i];

@@ -127,6 +127,28 @@ def test_lane_learner_kernel_for_large_tables(algo):
     orc.close()
 
 
+@pytest.mark.parametrize("batches", ["1", "4"])
+def test_mostly_greedy_q_lambda_block_sums(monkeypatch, batches):
+    """Q(lambda) late in the epsilon schedule (0.05: hardly any Watkins cut, books keep their generations like SARSA's): the
+    combined update goes through accumulate_block_kernel -- sums per slot in a block's LDS table first, one or several batches
+    of 1 024 books per block (LOB_ACC_BATCHES) -- 32 768 books, 30 steps against the oracle, and the flow counter says so."""
+    monkeypatch.setenv("LOB_ACC_BATCHES", batches)
+    B = 32768
+    p, eng, orc = make(B, abi.ALGO_QLAMBDA, n_events=200, epsilon=0.05)
+    eng.reset()
+    orc.reset()
+    for step in range(30):
+        eng.td_step(1)
+        orc.td_step(1)
+        if step < 3 or step % 9 == 0 or step >= 27:
+            compare_learner_step(eng, orc, "greedy batches %s step %d" % (batches, step), exact=False, rtol=1e-9)
+    np.testing.assert_allclose(eng.theta(), orc.theta(), rtol=1e-9, atol=1e-12)
+    flow = eng.flow_stats()
+    assert flow["block_sums"] == 30 and flow["added_in_place"] == 0 and flow["every_book"] == 0, flow
+    eng.close()
+    orc.close()
+
+
 def test_preloaded_theta_with_a_million_written_weights():
     """The state a long training run is in, at scale: 32 768 books acting from a weight vector with 1.2 M non-zero entries
     (6 % of the table: a hit list would need ~50 entries, so most books take the in-kernel full evaluation and the
