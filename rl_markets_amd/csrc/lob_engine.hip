@@ -1160,7 +1160,7 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                         const bool pair = e->q_pair && e->P.M < (1ll << 27) && !dq;  // (its LDS rows hold tile indices in 27 bits; one weight vector)
                         // the updates added to their slots by this kernel and trace_lane_kernel (lob_state.h acc_list): Q(lambda) while its
                         // books keep few generations (else accumulate_block_kernel's sums per block win)
-                        acc_fused = pair && fuse && e->acc_fuse && e->P.combine && e->P.sarsa_lanes && e->P.algo == LOB_ALGO_QLAMBDA && !acc_blocked(e) && G == 1;
+                        acc_fused = fuse && e->acc_fuse && e->P.combine && e->P.sarsa_lanes && (e->P.algo == LOB_ALGO_QLAMBDA || dq) && !acc_blocked(e) && G == 1;
                         // (not while the learn kernel hands most books back -- a dense theta: every one of them would go on the list
                         // through one counter; the list's length of a few steps ago, as launch_env_fused reads it)
                         if (e->rest_hint && *(volatile i32*)e->rest_hint > std::max(1024, e->B / 16)) acc_fused = false;
@@ -1169,11 +1169,11 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
 #define LOB_QL_LAUNCH(A, VT, TR)                                                                                                                            \
     do {                                                                                                                                                    \
         if (pair) hipLaunchKernelGGL((learn_q_pair_kernel<A, VT, TR>), dim3(gq), dim3(LOB_QP_BLOCK), lds, st, e->P, e->S, rnd, lpar, ver, sid, acc_fused ? 1 : 0); \
-        else hipLaunchKernelGGL((learn_q_lane_kernel<A, VT, TR>), dim3(gq), dim3(LOB_QL_BLOCK), lds, st, e->P, e->S, rnd, lpar, ver, sid);                  \
+        else hipLaunchKernelGGL((learn_q_lane_kernel<A, VT, TR>), dim3(gq), dim3(LOB_QL_BLOCK), lds, st, e->P, e->S, rnd, lpar, ver, sid, acc_fused ? 1 : 0); \
     } while (0)
                         if (dq) {  // (lob_create: only with the fused trace step)
-                            if (e->P.V == 8) hipLaunchKernelGGL((learn_q_lane_kernel<LOB_ALGO_DOUBLE_Q, 8, true>), dim3(gq), dim3(LOB_QL_BLOCK), lds, st, e->P, e->S, rnd, lpar, ver, sid);
-                            else hipLaunchKernelGGL((learn_q_lane_kernel<LOB_ALGO_DOUBLE_Q, 0, true>), dim3(gq), dim3(LOB_QL_BLOCK), lds, st, e->P, e->S, rnd, lpar, ver, sid);
+                            if (e->P.V == 8) hipLaunchKernelGGL((learn_q_lane_kernel<LOB_ALGO_DOUBLE_Q, 8, true>), dim3(gq), dim3(LOB_QL_BLOCK), lds, st, e->P, e->S, rnd, lpar, ver, sid, acc_fused ? 1 : 0);
+                            else hipLaunchKernelGGL((learn_q_lane_kernel<LOB_ALGO_DOUBLE_Q, 0, true>), dim3(gq), dim3(LOB_QL_BLOCK), lds, st, e->P, e->S, rnd, lpar, ver, sid, acc_fused ? 1 : 0);
                         }
                         else if (fuse) { if (e->P.V == 8) LOB_QL_LAUNCH(LOB_ALGO_QLAMBDA, 8, true); else LOB_QL_LAUNCH(LOB_ALGO_QLAMBDA, 0, true); }
                         else if (e->P.algo == LOB_ALGO_QLAMBDA) { if (e->P.V == 8) LOB_QL_LAUNCH(LOB_ALGO_QLAMBDA, 8, false); else LOB_QL_LAUNCH(LOB_ALGO_QLAMBDA, 0, false); }

@@ -747,6 +747,7 @@ __global__ void __launch_bounds__(LOB_TS_BLOCK, 5) trace_lane_kernel(DevParams P
         if (td_pending && k == 0) S.acc_list[atomicAdd(&S.acc_list_n[lpar], 1)] = b;
         const bool add_here = fuse_acc && !td_pending;
         const f64 upd32 = h.upd / (f64)LOB_N_TILINGS;
+        const int vec = h.stepped == 2 ? 1 : 0;  // (double Q: the learn kernel's coin)
         const int xcd = add_here ? acc_copy(S, (int)(blockIdx.x * (LOB_TS_BLOCK / 64) + (threadIdx.x >> 6))) : 0;
         bool acc_failed = false;
         if (cand != 0 && n_amb_new != 0) {
@@ -785,7 +786,7 @@ __global__ void __launch_bounds__(LOB_TS_BLOCK, 5) trace_lane_kernel(DevParams P
             // (old age k: age k + 1 after this step's decay)
             if (add_here && m2) {
                 const f64 val = upd32 * (f64)P.trace_pow[k + 1];
-                if (!(cs_here ? acc_generation_at(S, gi, cs, sg, m2, val, xcd) : acc_generation(S, gi, m2, val, xcd))) acc_failed = true;
+                if (!(cs_here ? acc_generation_at(S, gi, cs, sg, m2, val, xcd, vec) : acc_generation(S, gi, m2, val, xcd, vec))) acc_failed = true;
             }
         }
         // ---- the new generation: the chosen action's 32 tiles, all alive ----
@@ -816,7 +817,7 @@ __global__ void __launch_bounds__(LOB_TS_BLOCK, 5) trace_lane_kernel(DevParams P
             }
             if (add_here) {
                 const f64 val = upd32 * (f64)P.trace_pow[0];
-                if (!(at_home ? acc_generation_at(S, ni, (int)home, make_int4(q0, q1, q2, action), 0xffffffffu, val, xcd) : acc_generation(S, ni, 0xffffffffu, val, xcd)))
+                if (!(at_home ? acc_generation_at(S, ni, (int)home, make_int4(q0, q1, q2, action), 0xffffffffu, val, xcd, vec) : acc_generation(S, ni, 0xffffffffu, val, xcd, vec)))
                     acc_failed = true;
             }
         }
@@ -1129,7 +1130,9 @@ __device__ __forceinline__ void ql_group_d(const DevParams& P, const DevState& S
 // the RNG counter are settled here).  The look-ups of the trace part are issued at the top and consumed after the
 // tile walk, whose arithmetic hides them.
 template <int ALGO, int VT, bool TR>
-__global__ void __launch_bounds__(LOB_QL_BLOCK) learn_q_lane_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g, int lpar, u64 ver, int sid) {
+// acc_fuse (TR): as learn_q_pair_kernel -- the update of a book whose step leaves one new generation is added to that generation's
+// slot here (double Q: in the sums of the vector the coin picked).
+__global__ void __launch_bounds__(LOB_QL_BLOCK) learn_q_lane_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g, int lpar, u64 ver, int sid, int acc_fuse) {
     // (LOB_ALGO_DOUBLE_Q: DoubleQLearn on the fast path -- both weight vectors share the triples, the tiles, the maps and the
     // hit list; Q_a and Q_b continue from the memo's two records; its trace step is Watkins's, argmax over Q_a)
     static_assert(!TR || ALGO == LOB_ALGO_QLAMBDA || ALGO == LOB_ALGO_DOUBLE_Q, "the fused trace step is Watkins's");
@@ -1269,6 +1272,10 @@ __global__ void __launch_bounds__(LOB_QL_BLOCK) learn_q_lane_kernel(DevParams P,
             S.slow_list[(size_t)S.B + pos] = b;
             recp[0] = LOB_HL_NONE;
             cb_claim_finish(S, pend);
+            if (TR && acc_fuse) {  // (its TD error comes later: accumulate_kernel takes every generation of the book)
+                if (tlight) S.acc_list[atomicAdd(&S.acc_list_n[lpar], 1)] = b;
+                else S.acc_pend[b] = 1;
+            }
             continue;
         }
         f64 qs[LOB_N_ACTIONS];
@@ -1291,6 +1298,8 @@ __global__ void __launch_bounds__(LOB_QL_BLOCK) learn_q_lane_kernel(DevParams P,
                 for (int c = 0; c < LOB_N_ACTIONS; c++) qs[c] = a == c ? qs[c] + x : qs[c];
             }
         }
+        f64 delta;
+        int vec = 0;  // (double Q: the vector the update goes into)
         if (ALGO == LOB_ALGO_DOUBLE_Q) {
             // Q_b(s', .) the same way: the memo's record under theta_b (written by the same memo_kernel launch: same version) + the
             // same additions with theta_b's weights
@@ -1314,13 +1323,24 @@ __global__ void __launch_bounds__(LOB_QL_BLOCK) learn_q_lane_kernel(DevParams P,
                     for (int c = 0; c < LOB_N_ACTIONS; c++) qb[c] = a == c ? qb[c] + x : qb[c];
                 }
             }
-            learn_delta_double<false>(P, S, hp, h, b, qs, qb, q_sa, g, 0, nullptr);
+            delta = learn_delta_double<false>(P, S, hp, h, b, qs, qb, q_sa, g, 0, nullptr, &vec);
         } else {
-            learn_delta_single<ALGO == LOB_ALGO_DOUBLE_Q ? LOB_ALGO_SARSA : ALGO>(P, hp, h, qs, q_sa, g, 0);
+            delta = learn_delta_single<ALGO == LOB_ALGO_DOUBLE_Q ? LOB_ALGO_SARSA : ALGO>(P, hp, h, qs, q_sa, g, 0);
         }
         recp[0] = (u64)n;
         for (int i = 0; i < n; i++) recp[1 + i] = row[1 + i];
         cb_claim_finish(S, pend);
+        if (TR && acc_fuse) {
+            if (tlight) {
+                // the book's one generation (age 0, all 32 tiles alive): alpha delta / 32 x e(0) into its slot
+                const size_t gi = (size_t)b * P.trace_gens + ((h.tr_head + 1) & (P.trace_gens - 1));
+                const f64 val = (P.alpha * delta) / (f64)LOB_N_TILINGS * (f64)P.trace_pow[0];
+                if (!acc_generation(S, gi, 0xffffffffu, val, acc_copy(S, (int)(blockIdx.x * (LOB_QL_BLOCK / 64) + (threadIdx.x >> 6))), vec))
+                    S.acc_list[atomicAdd(&S.acc_list_n[lpar], 1)] = (i32)((uint32_t)b | 0x80000000u);
+            } else {
+                S.acc_pend[b] = 0;
+            }
+        }
     }
 }
 

@@ -1193,8 +1193,8 @@ __device__ inline void mt64_twist_lane(u64* x) {
     x[LOB_MT_N - 1] = mt64_mix(x[LOB_MT_N - 1], x[0], x[LOB_MT_M - 1]);
 }
 template <bool WAVE>
-__device__ __forceinline__ void learn_delta_double(const DevParams& P, const DevState& S, LHdr* hp, const LHdr& h, int b, const f64* qs_to, const f64* qb_to,
-                                                   f64 q_sa, Rng& g, int lane, u64* lds) {
+__device__ __forceinline__ f64 learn_delta_double(const DevParams& P, const DevState& S, LHdr* hp, const LHdr& h, int b, const f64* qs_to, const f64* qb_to,
+                                                  f64 q_sa, Rng& g, int lane, u64* lds, int* vector_out = nullptr) {
     const f64 reward = h.reward;
     const f64 F_term = P.gamma * 0.0 - 0.0;  // potentials are identically 0 (base.cpp:239-242)
     const int action = h.action;
@@ -1226,6 +1226,8 @@ __device__ __forceinline__ void learn_delta_double(const DevParams& P, const Dev
         hp->upd = P.alpha * delta;
         hp->rng_ctr = g.ctr;
     }
+    if (vector_out) *vector_out = target - 1;  // 0: theta, 1: theta_b
+    return delta;
 }
 template <int ALGO>
 __device__ __forceinline__ void learn_q_book(const DevParams& P, const DevState& S, LearnLds& L, int w, int lane, int b) {
@@ -1451,7 +1453,8 @@ __device__ inline int acc_copy(const DevState& S, int wave) {
 // if it was displaced.  False: no slot (table crowded / hash shared by two identities) -- tr_cbslot is set to -1 and the caller
 // leaves the generation to accumulate_kernel's direct path, which must wait until nobody reads theta.
 // (`cs` = tr_cbslot[gi] and `sg` = the generation's signature as the caller holds them in registers: nothing is loaded again)
-__device__ inline bool acc_generation_at(const DevState& S, size_t gi, int cs, int4 sg, uint32_t mask, f64 val, int xcd) {
+// (`target` 0: theta, 1: theta_b -- double Q, the vector the book's coin picked)
+__device__ inline bool acc_generation_at(const DevState& S, size_t gi, int cs, int4 sg, uint32_t mask, f64 val, int xcd, int target = 0) {
     const bool known = cs >= 0 && (cs & LOB_CBS_VERIFIED);
     uint32_t s = (uint32_t)cs & (uint32_t)(S.cb_slots - 1);
     bool found = known;
@@ -1481,15 +1484,15 @@ __device__ inline bool acc_generation_at(const DevState& S, size_t gi, int cs, i
         S.tr_cbslot[gi] = found ? (i32)(s | LOB_CBS_VERIFIED) : -1;
     }
     if (!found) return false;
-    __hip_atomic_fetch_add(&S.cb_acc[((size_t)xcd * S.cb_slots + s) * 2], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (!(touch & 1u)) atomicOr(&S.cb_touch[s], 1u);
+    __hip_atomic_fetch_add(&S.cb_acc[((size_t)xcd * S.cb_slots + s) * 2 + target], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!(touch & (1u << target))) atomicOr(&S.cb_touch[s], 1u << target);
     return true;
 }
-__device__ inline bool acc_generation(const DevState& S, size_t gi, uint32_t mask, f64 val, int xcd) {
+__device__ inline bool acc_generation(const DevState& S, size_t gi, uint32_t mask, f64 val, int xcd, int target = 0) {
     const int cs = S.tr_cbslot[gi];
     int4 sg = make_int4(0, 0, 0, 0);
     if (!(cs >= 0 && (cs & LOB_CBS_VERIFIED))) sg = *reinterpret_cast<const int4*>(S.tr_sig + gi * 4);
-    return acc_generation_at(S, gi, cs, sg, mask, val, xcd);
+    return acc_generation_at(S, gi, cs, sg, mask, val, xcd, target);
 }
 // `list` (or null: every book): accumulate_kernel over the books the fused accumulation left (lob_state.h acc_list); an entry
 // with bit 31 takes only the book's generations without a slot.
