@@ -298,7 +298,10 @@ def main():
         eps = events_done / max(steps_done, 1)
         steps_per_episode = max((g.n_events - 64) / max(eps, 1e-9), 1.0)   # an episode = the stream after the 64-event warm-up
         traffic_file = {}
-        tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        # counter figures of THIS configuration's kernels (tools/final_validation.sh -> profiles/pmc_traffic_<cfg>.json; the headline's
+        # file keeps its old name); a configuration without a tracked counter file reports traffic null, never another one's bytes
+        cfg_key = config_key(args)
+        tf = os.path.join(ROOT, "profiles", "pmc_traffic.json" if cfg_key == "c3" else "pmc_traffic_%s.json" % cfg_key)
         if os.path.exists(tf):
             try:
                 traffic_file = json.load(open(tf))
@@ -407,12 +410,14 @@ def main():
             "sustained": sustained,
             "dense_theta": dense,
             "config": {
-                "workload": (("C5: %d books replaying one recorded %d-level stream from per-book phases, reward pnl_damped, %s, "
-                              if args.replay else "C3: %d parallel synthetic %d-level books per GPU, %s with eligibility traces, ") +
+                "workload": (workload_label(args, world) + ": " +
+                             ("%d books replaying one recorded %d-level stream from per-book phases, reward pnl_damped, %s, "
+                              if args.replay else "%d parallel synthetic %d-level books per GPU, %s with eligibility traces, ") +
                              "tile-coded linear Q (32 tilings x 3 groups x 9 actions), memory_size %d, "
                              "shared theta, synchronous-batch TD") % (args.books, args.depth,
                                                                    {"q_lambda": "Q(lambda)", "sarsa": "SARSA(lambda)", "double_q": "double Q(lambda)"}[args.algo],
                                                                    args.memory_size),
+                "traffic_profile": cfg_key,
                 "books_per_gpu": args.books, "depth": args.depth, "events_per_book": g.n_events,
                 "events_per_step": round(eps, 4), "live_traces_per_book": round(n_live, 1),
                 "move_prob": args.move_prob,   # (None: the generator's default; an experiment knob otherwise)
@@ -443,6 +448,31 @@ def main():
             pass
         sys.stdout.flush()
         print(result, flush=True)
+
+
+def workload_label(args, world):
+    """Which of BASELINE.json's configurations this run is -- or that it is none of them."""
+    plain = args.depth == 10 and args.memory_size == 20000000 and args.epsilon is None and args.move_prob is None
+    if args.replay:
+        return "C5" if plain and args.books == 65536 else "C5-shaped (not a BASELINE configuration)"
+    if plain and args.books == 4096 and args.algo == "sarsa" and world == 1:
+        return "C2"
+    if plain and args.books == 65536 and args.algo == "q_lambda":
+        return "C3" if world == 1 else "C4" if world == 8 else "C4-shaped (65 536 books per GPU on %d GPUs)" % world
+    return "variant of C3 (not a BASELINE configuration)"
+
+
+def config_key(args):
+    """The tracked counter profile this run's `traffic` figures come from (profiles/pmc_traffic*.json)."""
+    if args.replay:
+        return "c5"
+    if args.books == 4096 and args.algo == "sarsa":
+        return "c2"
+    if args.books != 65536 or args.move_prob is not None:
+        return "other"
+    if args.epsilon is not None:
+        return "eps%s" % ("%g" % args.epsilon).replace("0.", "").replace(".", "_") if args.algo == "q_lambda" else "other"
+    return {"q_lambda": "c3", "sarsa": "sarsa", "double_q": "double_q"}[args.algo]
 
 
 ALWAYS_TIMED = ("prepass_extend_kernel", "delta_begin_kernel", "delta_apply_kernel", "reset_kernel")

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LOB_ABI_VERSION 5
+#define LOB_ABI_VERSION 6
 
 #define LOB_N_ACTIONS 9   /* reference Intraday::DoAction table, src/environment/intraday.cpp:181-219 */
 #define LOB_N_TILINGS 32  /* config/example.yaml:18 (compile-time in the kernels) */
@@ -149,7 +149,11 @@ typedef struct lob_params {
     uint64_t seed;              /* counter-based policy RNG seed (DESIGN.md "RNG") */
     uint64_t book_id_offset;    /* global id of local book 0 (multi-GPU shards) */
     int32_t policy;             /* LOB_POLICY_* */
-    int32_t _pad_policy;
+    int32_t random_init;        /* learning.random_init (src/rl/agent.cpp:37-39,190-192): 0 = every weight +0.0; 1 = every weight 2u - 1, u
+                                 * drawn in index order from the agent's own std::mt19937_64 (debug.random_seed; theta, then theta_b
+                                 * of the double agents) -- private theta: every book's agent draws its own vectors (seed + global
+                                 * book id, as for the coin); shared theta: the one vector is global book 0's agent's, whatever
+                                 * shard this engine holds, and that agent's generator moves on as in the reference */
     double tau;                 /* Boltzmann temperature (schedule host-side, lob_set_tau) */
     double beta;                /* learning.beta: step size of the average reward rho (R-learning agents) */
 } lob_params;
@@ -288,7 +292,7 @@ void lob_destroy(lob_engine* e);
 
 /* Replaces Intraday::LoadData (src/environment/intraday.cpp:141-150):
  * upload host records / synthesise the same records directly in HBM.
- * 2 <= n_events < 2^21 (LOB_EINVAL otherwise: the per-book TickStatistics counters are 21 bits wide, one count per agent
+ * 2 <= n_events (an int32: the per-book TickStatistics counters are 32-bit like the reference's ints, one count per agent
  * step, and an agent step consumes at least one event). */
 int lob_load_events(lob_engine* e, const uint32_t* host_records, int32_t n_events);
 int lob_gen_events_device(lob_engine* e, const lob_gen_params* g);
@@ -336,6 +340,10 @@ int lob_td_step(lob_engine* e, int32_t n_steps);
  * lob_td_step(e, 1), bit for bit. */
 int lob_td_step_begin(lob_engine* e);
 int lob_td_step_end(lob_engine* e);
+/* 1 if this engine can split a step (always, except an experiments build run with two book groups, LOB_GROUPS=2): the
+ * caller that cannot split runs the whole step and exchanges after it -- asked for explicitly instead of being inferred
+ * from a LOB_ESTATE of lob_td_step_begin, which has other causes (no reset, a half step left open). */
+int lob_td_split_supported(lob_engine* e);
 /* Backtester::_step (serial.cpp:124-137): greedy action, no learning. */
 int lob_eval_step(lob_engine* e, int32_t n_steps);
 /* Agent::HandleTerminal (src/rl/agent.cpp:103-109): traces.decay(0). The

@@ -1157,6 +1157,23 @@ oracle_learner* oracle_create(const lob_params* p, int32_t n_books, const uint32
             o->agent_unif.emplace_back(0.0, 1.0);
         }
     }
+    if (p->random_init) {
+        // learning.random_init (src/rl/agent.cpp:37-39; DoubleAgent::DoubleAgent, agent.cpp:190-192):
+        //   generate(&theta[0], &theta[MEMORY_SIZE], [this]() { return 2.0*unif_dist(gen)-1.0; });
+        // theta first, theta_b after it, from the agent's own generator, which then goes on to toss DoubleQLearn's coin.
+        // Private theta: every book's agent draws its own vectors.  Shared theta (no counterpart in the reference beyond one
+        // book): the one vector is global book 0's agent's -- the same on every shard --, and that agent's generator moves on
+        // where the book lives (book_id_offset == 0).
+        const bool dq = !o->theta_b.empty();
+        for (int t = 0; t < nt; t++) {
+            const bool own = p->theta_mode == LOB_THETA_PRIVATE || p->book_id_offset == 0;
+            std::mt19937_64 local((unsigned)(p->seed + (p->theta_mode == LOB_THETA_PRIVATE ? p->book_id_offset + (uint64_t)t : 0ull)));
+            std::mt19937_64& gen = dq && own ? o->agent_gen[t] : local;
+            std::uniform_real_distribution<double> unif_dist(0.0, 1.0);
+            std::generate(o->theta[t].begin(), o->theta[t].end(), [&]() { return 2.0 * unif_dist(gen) - 1.0; });
+            if (dq) std::generate(o->theta_b[t].begin(), o->theta_b[t].end(), [&]() { return 2.0 * unif_dist(gen) - 1.0; });
+        }
+    }
     o->traces.resize(n_books);
     o->vars.resize(n_books);
     o->last_vars.resize(n_books);

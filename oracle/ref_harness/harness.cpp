@@ -286,6 +286,7 @@ static std::string make_yaml(const Args& a, const std::string& path) {
     f << "    gamma: " << a.get("gamma", "0.975") << "\n    lambda: " << a.get("lambda", "0.85") << "\n";
     f << "    omega: 1.0\n    alpha_start: " << a.get("alpha", "0.001") << "\n    alpha_floor: " << a.get("alpha", "0.001") << "\n";
     f << "    beta: " << a.get("beta", "0.005") << "\n";  // RLearn / OnlineRLearn (src/rl/agent.cpp:357-412)
+    if (a.geti("random_init", 0)) f << "    random_init: true\n";  // Agent::Agent, src/rl/agent.cpp:37-39
     f << "policy:\n    type: epsilon_greedy\n    eps_init: 0.8\n    eps_floor: 0.0001\n    eps_T: 800\n";
     f << "    spread_lookback: " << a.geti("lb_spread", 45) << "\n";
     f << "reward:\n    measure: " << a.get("reward", "pnl_damped") << "\n";

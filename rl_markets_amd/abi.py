@@ -64,7 +64,7 @@ class Params(_Strict):
         ("group_weights", C.c_double * 3), ("gamma", C.c_double), ("lambda_", C.c_double),
         ("alpha", C.c_double), ("epsilon", C.c_double),
         ("algo", C.c_int32), ("theta_mode", C.c_int32), ("seed", C.c_uint64), ("book_id_offset", C.c_uint64),
-        ("policy", C.c_int32), ("_pad_policy", C.c_int32), ("tau", C.c_double), ("beta", C.c_double),
+        ("policy", C.c_int32), ("random_init", C.c_int32), ("tau", C.c_double), ("beta", C.c_double),
     ]
 
 
@@ -161,6 +161,7 @@ def load():
         "lob_get_books": (C.c_int, [vp, C.c_int32, C.c_int32, vp]),
         "lob_td_step": (C.c_int, [vp, C.c_int32]),
         "lob_td_step_begin": (C.c_int, [vp]),
+        "lob_td_split_supported": (C.c_int, [vp]),
         "lob_td_step_end": (C.c_int, [vp]),
         "lob_eval_step": (C.c_int, [vp, C.c_int32]),
         "lob_handle_terminal": (C.c_int, [vp]),

@@ -207,24 +207,40 @@ static int theta_allreduce_impl(lob_engine* e, lob_comm* c, ExchangeStamp& x) {
         // Which exchange: decided ONCE, by all ranks together -- sparse only if every rank can and wants to (a rank whose engine
         // has no exact map, or whose environment says LOB_DENSE_EXCHANGE=1, would otherwise enter a different collective than
         // its peers and all of them would wait for ever).  One tiny host-side all-reduce, at the first exchange.
+        // The same reduction carries every rank's allocation result: the sparse exchange's buffers (the gathered maps, the union,
+        // the block offsets) are made HERE, before any collective of the data path, and a rank that could not makes every rank
+        // return the error together -- from then on nothing is allocated between two collectives.
         const char* df = getenv("LOB_DENSE_EXCHANGE");
         double dense_wanted = ((df && df[0] == '1') || !lob_delta_sparse_supported(e)) ? 1.0 : 0.0;
-        rc = lob_comm_reduce_host_f64(c, &dense_wanted, 1, LOB_COMM_MAX);
+        int rc_alloc = LOB_OK;
+        if (dense_wanted == 0.0) {
+            uint32_t *own = nullptr, *gather = nullptr;
+            int64_t words = 0;
+            rc_alloc = lob_delta_sparse_maps(e, c->world, &own, &gather, &words);
+        }
+        double agreed = rc_alloc != LOB_OK ? 2.0 : dense_wanted;
+        rc = lob_comm_reduce_host_f64(c, &agreed, 1, LOB_COMM_MAX);
         if (rc) return rc;
-        c->mode = dense_wanted > 0.0 ? 0 : 1;
+        if (agreed > 1.0) {
+            if (rc_alloc == LOB_OK) lob_set_error("lob_theta_allreduce: another rank could not allocate the exchange's buffers");
+            return rc_alloc != LOB_OK ? rc_alloc : LOB_ENOMEM;
+        }
+        c->mode = agreed > 0.0 ? 0 : 1;
     }
     hipEventRecord(x.ev[0], st);
     if (c->mode == 1) {
         // maps all-gathered -> union -> packed deltas all-reduced -> scattered back (include/lob_engine.h)
         uint32_t *own = nullptr, *gather = nullptr;
         int64_t words = 0;
+        // (no allocation from here on -- see above --: what can still fail between the two collectives is the HIP / RCCL runtime
+        // itself, and that ends the communicator for every rank: ncclCommAbort territory, not a recoverable local error)
         rc = lob_delta_sparse_maps(e, c->world, &own, &gather, &words);
         if (rc) return rc;
         rc = lob_comm_allgather_u32(c, own, gather, words, st);
         if (rc) return rc;
         double* buf = nullptr;
         int64_t count = 0;
-        rc = lob_delta_sparse_pack(e, c->world, &buf, &count);
+        rc = lob_delta_sparse_pack(e, c->world, &buf, &count);   // (the union is the same on every rank: so is `count`)
         if (rc) return rc;
         hipEventRecord(x.ev[1], st);
         if (count > 0) rc = lob_comm_allreduce_f64(c, buf, count, st);

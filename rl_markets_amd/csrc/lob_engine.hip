@@ -1,6 +1,9 @@
 // Host side of the C ABI (include/lob_engine.h): device memory management,
 // kernel launches on one HIP stream, HIP-event kernel timing.  gfx950 only;
-// there is no CPU execution path in this file.
+// there is no CPU execution path in this file.  (One of the library's four translation units, lob_launch.h: the environment,
+// pre-pass and fast learner kernels are compiled in lob_tu_env.hip / lob_tu_prepass.hip / lob_tu_learn.hip.)
+#define LOB_TU_SPLIT 1
+#define LOB_TU_MAIN 1
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
@@ -15,7 +18,7 @@
 #include "lob_internal.h"
 #include "lob_fast.h"
 #include "lob_kernels.h"
-#include "lob_envstep.h"
+#include "lob_launch.h"
 
 #define HIPCHK(expr)                                                                         \
     do {                                                                                     \
@@ -25,6 +28,9 @@
             return LOB_EHIP;                                                                 \
         }                                                                                    \
     } while (0)
+
+#define LOB_HINT_RING 64
+#define LOB_HINT_LAG 16
 
 struct KTimer {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
@@ -45,15 +51,27 @@ struct lob_engine {
     hipEvent_t ev_reg_go = nullptr, ev_reg_done = nullptr;  // tile registry kernels on stream2 beside the learner kernels (lob_kernels.h registry_kernel)
     hipEvent_t ev_rest_go = nullptr, ev_rest_done = nullptr;  // learn_q_rest_kernel on stream2 beside the trace kernels
     bool rest_side = true;      // (LOB_REST_SIDE=0: on the main stream, as before; A/B switch)
-    long long flow[4] = {0, 0, 0, 0};  // lob_debug_flow: learner steps by the shape of their update (see there)
+    long long flow[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // lob_debug_flow: learner steps by the shape of their update / action selection (see there)
     bool acc_fuse = true;       // Q(lambda), the pair kernel + the lane-per-generation trace kernel: updates added to their slots there, accumulate_kernel over a list (LOB_ACC_FUSE=0: over every book; A/B switch)
     bool acc_batches_set = false;
     int acc_batches = LOB_ACB_K;  // accumulate_block_kernel: batches of 1 024 books per block (LOB_ACC_BATCHES=1|2|4|8; A/B switch)
     bool acc_block = true;      // SARSA(lambda): accumulate_block_kernel (LOB_ACC_BLOCK=0: accumulate_kernel; A/B switch)
     int env_step_lanes = 64;    // books per wave of env_step_kernel (LOB_ENV_STEP_LANES=32: two half-full waves per SIMD; experiment)
     bool prepass_roles = false; // the pre-pass on two waves per 64 books (reset2_kernel / prepass_extend2_kernel; LOB_PREPASS_ROLES=1): measured slower, opt-in
-    i32* rest_hint = nullptr;   // host-mapped word learn_q_rest_kernel writes its list's length to
-    i32* rest_hint_dev = nullptr;
+    // learn_q_rest_kernel reports its list's length (the books the lane learn kernels handed back) through host-mapped memory:
+    // a ring of LOB_HINT_RING words, one per learner step, each with an event recorded behind the kernel that writes it.  The
+    // step launched now reads the word of LOB_HINT_LAG steps ago after waiting for THAT event (long past, unless the host is
+    // more than LOB_HINT_LAG steps ahead of the device -- then it waits: the device still has that many steps queued), so which
+    // path a step takes is a function of the run, not of the host's timing.  The first LOB_HINT_LAG steps after
+    // lob_reset / lob_theta_set / a weight exchange read 0.
+    u64* rest_hint = nullptr;   // word = (step tag) << 32 | count: the host checks the tag, so it never reads a word the device has not written yet
+    u64* rest_hint_dev = nullptr;
+    hipEvent_t hint_ev[LOB_HINT_RING] = {};
+    long long hint_step = 0;    // learner steps (fast path) since the hints were last void
+    unsigned long long hint_serial = 0;  // launches of learn_q_rest_kernel since lob_create (the tag of a ring word)
+    uint32_t hint_tags[LOB_HINT_RING] = {};
+    int hint_now = 0;           // the hint this step goes by (run_steps)
+    int force_general = -1;     // LOB_MOSTLY_GENERAL=0|1: the work-list act path never / always (tests); -1: by the hint
     int rest_recent = 0;        // steps left to keep the launch on the second stream after the last non-empty list seen
     bool reg_pending = false;
     bool reg_fork_late = false;
@@ -241,6 +259,8 @@ int check_device_errors(lob_engine* e) {
 
 extern "C" {
 
+static int theta_random_init(lob_engine* e);
+
 int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine** out) {
     if (!p || !out || n_books < 1) { lob_set_error("lob_create: bad argument"); return LOB_EINVAL; }
     if (p->abi_version != LOB_ABI_VERSION) { lob_set_error("lob_create: ABI version mismatch"); return LOB_EINVAL; }
@@ -308,20 +328,26 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     if (const char* g = getenv("LOB_REST_SIDE")) e->rest_side = !(g[0] == '0');
     if (const char* g = getenv("LOB_ACC_BLOCK")) e->acc_block = !(g[0] == '0');
     if (const char* g = getenv("LOB_ACC_FUSE")) e->acc_fuse = !(g[0] == '0');
-    if (const char* g = getenv("LOB_ACC_BATCHES")) { const int v = atoi(g); if (v >= 1 && v <= 16) { e->acc_batches = v; e->acc_batches_set = true; } }
-    if (const char* g = getenv("LOB_ENV_STEP_LANES")) { if (atoi(g) == 32) e->env_step_lanes = 32; }
-    if (const char* g = getenv("LOB_PREPASS_ROLES")) e->prepass_roles = g[0] == '1';
-    if (hipHostMalloc((void**)&e->rest_hint, sizeof(i32), hipHostMallocMapped) == hipSuccess) {
-        *e->rest_hint = 0;
+    if (const char* g = getenv("LOB_ACC_BATCHES")) { const int v = atoi(g); if (v == 1 || v == 2 || v == 4 || v == 8) { e->acc_batches = v; e->acc_batches_set = true; } }
+    // (the variants measured and lost -- NOTES.md "Round 4" -- exist in -DLOB_EXPERIMENTS builds only, tools/exp_variants.sh; a
+    // product build ignores their switches)
+    const bool exps = lobk_experiments() != 0;
+    if (const char* g = getenv("LOB_ENV_STEP_LANES")) { if (exps && atoi(g) == 32) e->env_step_lanes = 32; }
+    if (const char* g = getenv("LOB_PREPASS_ROLES")) e->prepass_roles = exps && g[0] == '1';
+    if (hipHostMalloc((void**)&e->rest_hint, LOB_HINT_RING * sizeof(u64), hipHostMallocMapped) == hipSuccess) {
+        memset(e->rest_hint, 0, LOB_HINT_RING * sizeof(u64));
         if (hipHostGetDevicePointer((void**)&e->rest_hint_dev, e->rest_hint, 0) != hipSuccess) e->rest_hint_dev = nullptr;
     } else e->rest_hint = nullptr;   // (no hint: the launch stays on the main stream)
+    if (!e->rest_hint_dev && e->rest_hint) { hipHostFree(e->rest_hint); e->rest_hint = nullptr; }
+    for (int i = 0; i < LOB_HINT_RING && e->rest_hint; i++) HIPCHK_E(hipEventCreateWithFlags(&e->hint_ev[i], hipEventDisableTiming | hipEventDisableSystemFence));
+    if (const char* g = getenv("LOB_MOSTLY_GENERAL")) e->force_general = g[0] == '1' ? 1 : g[0] == '0' ? 0 : -1;
     // Optional (LOB_GROUPS=2): two book groups pipelined on two streams so that the latency-bound env
     // kernel of one group runs beside a gather kernel of the other.  It paid 7 % before the market
     // track made the env kernel cheap; now one group is as fast and gives clean per-kernel timings.
     e->n_groups = 1;
-    if (const char* g = getenv("LOB_GROUPS")) { int v = atoi(g); if (v >= 1 && v <= 2) e->n_groups = v; }
-    // experiment / test switches for the books-per-wave choice of the lane-per-book kernels
-    if (const char* g = getenv("LOB_ENV_LANES")) { int v = atoi(g); if (v == 16 || v == 32 || v == 64 || v == 256) e->env_lanes = v; }
+    if (const char* g = getenv("LOB_GROUPS")) { int v = atoi(g); if (exps && v >= 1 && v <= 2) e->n_groups = v; }
+    // experiment / test switches for the books-per-wave choice of the lane-per-book kernels (32 and 256 = env_compact_kernel: experiments)
+    if (const char* g = getenv("LOB_ENV_LANES")) { int v = atoi(g); if (v == 16 || v == 64 || (exps && (v == 32 || v == 256))) e->env_lanes = v; }
     if (const char* g = getenv("LOB_TRACK_RING")) { int v = atoi(g); if (v >= 256 && v <= (1 << 20) && (v & (v - 1)) == 0) e->track_ring = v; }
     if (const char* g = getenv("LOB_TRACK_REFILL")) { int v = atoi(g); if (v >= 1) e->track_refill = v; }
     if (const char* g = getenv("LOB_ACC_LANES")) { int v = atoi(g); if (v == 8 || v == 16 || v == 32 || v == 64) e->acc_shift = v == 8 ? 3 : v == 16 ? 4 : v == 32 ? 5 : 6; }
@@ -332,10 +358,10 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     if (const char* g = getenv("LOB_NO_TLIGHT")) e->t_light = !(g[0] == '1');
     if (const char* g = getenv("LOB_Q_PAIR")) e->q_pair = !(g[0] == '0');
     if (const char* g = getenv("LOB_NO_FUSE")) e->no_fuse = g[0] == '1';
-    if (const char* g = getenv("LOB_REG_FORK")) e->reg_fork_late = g[0] == 'l';
+    if (const char* g = getenv("LOB_REG_FORK")) e->reg_fork_late = exps && g[0] == 'l';
     if (const char* g = getenv("LOB_ENV_STEP")) e->env_step = !(g[0] == '0');
     if (const char* g = getenv("LOB_INLINE_GENERAL")) e->inline_general = !(g[0] == '0');
-    if (const char* g = getenv("LOB_RESET_LANES")) { int v = atoi(g); if (v == 16 || v == 32 || v == 64) e->reset_lanes = v; }
+    if (const char* g = getenv("LOB_RESET_LANES")) { int v = atoi(g); if (v == 64 || (exps && (v == 16 || v == 32))) e->reset_lanes = v; }
 
     // ---- DevParams ----
     DevParams& P = e->P;
@@ -483,7 +509,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
         // 25 generations per book, and the greedy books crowd onto a few (triple, action) pairs: 0.44 ms per step with one copy at
         // epsilon = 0.01).  One copy per XCD for every algorithm on the fast path; apply_kernel adds them up.
         S.cb_reps = P.memo ? 8 : 1;
-        if (const char* g = getenv("LOB_ACC_REPS")) { int v = atoi(g); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) S.cb_reps = v; }
+        if (const char* g = getenv("LOB_ACC_REPS")) { int v = atoi(g); if (v == 1 || v == 2 || v == 4 || v == 8 || (exps && (v == 16 || v == 32 || v == 64))) S.cb_reps = v; }
         if (rc == LOB_OK) rc = dev_alloc(e, &S.cb_acc, (size_t)S.cb_reps * slots * 2);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.cb_touch, (size_t)slots);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.cb_list, 2 * (size_t)slots);
@@ -559,24 +585,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
         if (P.memo) {
             const int q_lds = (int)fast_lds_bytes(P.cwords4, LOB_FAST_NB, false), tr_lds = (int)trace_lds_bytes();
             hipError_t er = hipFuncSetAttribute((const void*)act_fast_kernel<LOB_FAST_NB>, hipFuncAttributeMaxDynamicSharedMemorySize, q_lds);
-            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_fast_kernel<LOB_ALGO_SARSA, LOB_FAST_NB>, hipFuncAttributeMaxDynamicSharedMemorySize, q_lds);
-            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_fast_kernel<LOB_ALGO_QLAMBDA, LOB_FAST_NB>, hipFuncAttributeMaxDynamicSharedMemorySize, q_lds);
-            const int ql_lds = (int)qlane_lds_bytes(P.cwords4);
-            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_lane_kernel<LOB_ALGO_SARSA, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ql_lds);
-            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_lane_kernel<LOB_ALGO_QLAMBDA, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ql_lds);
-            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_lane_kernel<LOB_ALGO_SARSA, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ql_lds);
-            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_lane_kernel<LOB_ALGO_QLAMBDA, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ql_lds);
-            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_lane_kernel<LOB_ALGO_QLAMBDA, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ql_lds);
-            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_lane_kernel<LOB_ALGO_QLAMBDA, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ql_lds);
-            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_lane_kernel<LOB_ALGO_DOUBLE_Q, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ql_lds);
-            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_lane_kernel<LOB_ALGO_DOUBLE_Q, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ql_lds);
-            const int qp_lds = (int)qpair_lds_bytes(P.cwords4);
-            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_pair_kernel<LOB_ALGO_SARSA, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, qp_lds);
-            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_pair_kernel<LOB_ALGO_QLAMBDA, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, qp_lds);
-            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_pair_kernel<LOB_ALGO_SARSA, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, qp_lds);
-            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_pair_kernel<LOB_ALGO_QLAMBDA, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, qp_lds);
-            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_pair_kernel<LOB_ALGO_QLAMBDA, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, qp_lds);
-            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)learn_q_pair_kernel<LOB_ALGO_QLAMBDA, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, qp_lds);
+            if (er == hipSuccess) er = lobk_learn_set_lds(q_lds, (int)qlane_lds_bytes(P.cwords4), (int)qpair_lds_bytes(P.cwords4));
             if (er == hipSuccess) er = hipFuncSetAttribute((const void*)trace_fast_kernel<LOB_ALGO_SARSA, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, tr_lds);
             if (er == hipSuccess) er = hipFuncSetAttribute((const void*)trace_fast_kernel<LOB_ALGO_SARSA, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, tr_lds);
             if (er == hipSuccess) er = hipFuncSetAttribute((const void*)trace_fast_kernel<LOB_ALGO_QLAMBDA, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, tr_lds);
@@ -632,6 +641,10 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
         HIPCHK_E(hipStreamSynchronize(e->stream));
     }
 #undef HIPCHK_E
+    if (p->random_init) {
+        const int rc_init = theta_random_init(e);
+        if (rc_init != LOB_OK) { lob_destroy(e); return rc_init; }
+    }
     *out = e;
     return LOB_OK;
 }
@@ -648,6 +661,7 @@ void lob_destroy(lob_engine* e) {
     if (e->ev_reg_go) hipEventDestroy(e->ev_reg_go);
     if (e->ev_reg_done) hipEventDestroy(e->ev_reg_done);
     if (e->rest_hint) hipHostFree(e->rest_hint);
+    for (int i = 0; i < LOB_HINT_RING; i++) if (e->hint_ev[i]) hipEventDestroy(e->hint_ev[i]);
     if (e->ev_rest_go) hipEventDestroy(e->ev_rest_go);
     if (e->ev_rest_done) hipEventDestroy(e->ev_rest_done);
     if (e->stream2) hipStreamDestroy(e->stream2);
@@ -658,15 +672,52 @@ void lob_destroy(lob_engine* e) {
     if (e->track_dev) hipFree(e->track_dev);
     if (e->dump_dev) hipFree(e->dump_dev);
     if (e->spx_gather) hipFree(e->spx_gather);
-    if (e->spx_buf) hipFree(e->spx_buf);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
 }
 
+// learning.random_init (src/rl/agent.cpp:37-39, DoubleAgent: 190-192): generate(&theta[0], &theta[M], 2.0 * unif_dist(gen) - 1.0)
+// with the agent's own std::mt19937_64 -- theta first, then theta_b, and the generator goes on to toss DoubleQLearn's coin from
+// where the initialisation left it.  Done on the host (a sequential generator: 20 M draws take a tenth of a second, once per
+// engine) with the same restatement of the generator the device uses for the coin (lob_learn.h), loaded through lob_theta_set
+// (maps, memo records).  Private theta: every book's agent draws its own vectors.  Shared theta: global book 0's agent draws the
+// one vector, on every shard the same; its generator's new state is installed where that book lives (book_id_offset == 0).
+struct HostMt64 {
+    u64 x[LOB_MT_N];
+    int idx;
+    explicit HostMt64(u64 seed) { mt64_seed(x, seed); idx = LOB_MT_N; }
+    u64 draw() {
+        if (idx >= LOB_MT_N) {  // the sequential in-place twist (the device does the same block in three phases, mt64_twist_wave)
+            for (int i = 0; i < LOB_MT_N; i++) x[i] = mt64_mix(x[i], x[(i + 1) % LOB_MT_N], x[(i + LOB_MT_M) % LOB_MT_N]);
+            idx = 0;
+        }
+        return mt64_temper(x[idx++]);
+    }
+};
+static int theta_random_init(lob_engine* e) {
+    const bool priv = e->P.theta_private != 0, dq = e->P.algo == LOB_ALGO_DOUBLE_Q;
+    const int nt = priv ? e->B : 1;
+    std::vector<f64> v((size_t)e->P.M);
+    for (int t = 0; t < nt; t++) {
+        HostMt64 g((u64)(uint32_t)(e->P.seed + (priv ? e->P.book_id_offset + (u64)t : 0ull)));
+        for (int vec = 0; vec < (dq ? 2 : 1); vec++) {
+            for (size_t i = 0; i < v.size(); i++) v[i] = 2.0 * mt64_canonical(g.draw()) - 1.0;
+            int rc = lob_theta_set(e, vec * nt + t, v.data(), (int64_t)e->P.M);
+            if (rc) return rc;
+        }
+        if (dq && (priv || e->P.book_id_offset == 0)) {  // Agent::gen of the book whose agent has just drawn: where the coin continues
+            const i32 idx = g.idx;
+            HIPCHK(hipMemcpyAsync(e->S.mt_state + (size_t)t * LOB_MT_N, g.x, sizeof g.x, hipMemcpyHostToDevice, e->stream));
+            HIPCHK(hipMemcpyAsync(e->S.mt_idx + t, &idx, sizeof idx, hipMemcpyHostToDevice, e->stream));
+            HIPCHK(hipStreamSynchronize(e->stream));
+        }
+    }
+    return LOB_OK;
+}
+
 static int finalize_episode(lob_engine* e) {
     if (!e->episode_open) return LOB_OK;
-    if (e->P.T <= 2) hipLaunchKernelGGL(finalize_kernel<2>, dim3(grid_lanes(e->B)), dim3(256), 0, e->stream, (const DevParams*)e->P_dev, e->S);
-    else hipLaunchKernelGGL(finalize_kernel<LOB_MAX_TRADES>, dim3(grid_lanes(e->B)), dim3(256), 0, e->stream, (const DevParams*)e->P_dev, e->S);
+    lobk_finalize(e->stream, e->P.T <= 2, (const DevParams*)e->P_dev, e->S);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(e->stream));
     e->episode_open = false;
@@ -675,9 +726,8 @@ static int finalize_episode(lob_engine* e) {
 
 // n_rows: records to allocate (B * n_events for per-book streams, the stream length for a replayed one)
 static int set_records(lob_engine* e, int32_t n_events, size_t n_rows) {
-    // (the six TickStatistics counters of a book are 21-bit fields, lob_state.h tick_ab / tick_pos: one count per agent step, at
-    // most one agent step per event)
-    if (n_events >= (1 << 21)) { lob_set_error("an episode of 2^21 events or more: the per-book tick statistics count to 2^21 - 1"); return LOB_EINVAL; }
+    // (the TickStatistics counters of a book are 32-bit like the reference's ints, lob_state.h tick_ab / tick_pos / tick_both: one count
+    // per agent step, at most one agent step per event, n_events < 2^31 -- a recorded day of millions of rows is fine)
     { int rc = finalize_episode(e); if (rc) return rc; }  // needs the old stream
     // the old stream is gone from here on, whatever happens below: no kernel may see a freed pointer
     e->have_events = false;
@@ -719,8 +769,7 @@ static int upload_records(lob_engine* e, const uint32_t* host_records, size_t n_
     if (hipMalloc((void**)&tmp, bytes) != hipSuccess) { lob_set_error("hipMalloc(upload buffer) failed"); return LOB_ENOMEM; }
     hipError_t err = hipMemcpyAsync(tmp, host_records, bytes, hipMemcpyHostToDevice, e->stream);
     if (err == hipSuccess) {
-        hipLaunchKernelGGL(repack_kernel, dim3((unsigned)((n_records + 255) / 256)), dim3(256), 0, e->stream, (const uint32_t*)tmp, e->P.D, e->P.T,
-                           n_records, e->records_dev);
+        lobk_repack(e->stream, (const uint32_t*)tmp, e->P.D, e->P.T, n_records, e->records_dev);
         err = hipGetLastError();
     }
     if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
@@ -775,8 +824,7 @@ int lob_gen_events_device(lob_engine* e, const lob_gen_params* g) {
     HIPCHK(hipSetDevice(e->device));
     int rc = set_records(e, g->n_events, (size_t)e->B * g->n_events);
     if (rc != LOB_OK) return rc;
-    hipLaunchKernelGGL(gen_events_kernel, dim3(grid_lanes(e->B)), dim3(256), 0, e->stream, *g, e->P.D, e->P.T,
-                       e->P.book_id_offset, e->B, e->records_dev);
+    lobk_gen_events(e->stream, *g, e->P.D, e->P.T, e->P.book_id_offset, e->B, e->records_dev);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(e->stream));
     return LOB_OK;
@@ -784,40 +832,17 @@ int lob_gen_events_device(lob_engine* e, const lob_gen_params* g) {
 
 // env_kernel with 64 books per wave, or 16 when the batch is too small to give every SIMD a wave
 static void launch_env(lob_engine* e, hipStream_t st, const i32* actions, int count_updates, int b0, int nb, int par) {
+    // (LOB_ENV_LANES: 16 | 64 forced; 32, and 256 = the event loop compacted across 256-book blocks, in experiment builds)
     const int force = e->env_lanes;
-    const int sid = e->step_id;
-    // learner / backtester steps with the event loop compacted across 256-book blocks
-    // (opt-in: measured no faster than env_kernel<64> -- DESIGN.md "env kernel" -- because a step is a chain of
-    // dependent look-ups per event and the block keeps its LDS until its unluckiest book is done)
-    if (!actions && force == 256) {
-        hipLaunchKernelGGL(env_compact_kernel, dim3((nb + LOB_ENVC_BLOCK - 1) / LOB_ENVC_BLOCK), dim3(LOB_ENVC_BLOCK), 0, st,
-                           (const DevParams*)e->P_dev, e->S, count_updates, b0, nb, sid, par);
-        return;
-    }
-    const DevParams* Pd = (const DevParams*)e->P_dev;
-    const bool t2 = e->P.T <= 2;  // the merged trade list of a pass in 2 register slots instead of LOB_MAX_TRADES
-#define LOB_ENV_LAUNCH(L, TM) hipLaunchKernelGGL((env_kernel<L, TM>), dim3((nb + L - 1) / L), dim3(L), 0, st, Pd, e->S, actions, count_updates, b0, nb, sid, par)
-    if (force == 32) {
-        if (t2) LOB_ENV_LAUNCH(32, 2); else LOB_ENV_LAUNCH(32, LOB_MAX_TRADES);
-    } else if (force == 16 || (force == 0 && e->B <= 16384)) {
-        if (t2) LOB_ENV_LAUNCH(16, 2); else LOB_ENV_LAUNCH(16, LOB_MAX_TRADES);
-    } else {
-        if (t2) LOB_ENV_LAUNCH(64, 2); else LOB_ENV_LAUNCH(64, LOB_MAX_TRADES);
-    }
-#undef LOB_ENV_LAUNCH
+    const int lanes = force ? force : (e->B <= 16384 ? 16 : 64);
+    lobk_env(st, lanes, e->P.T <= 2, (const DevParams*)e->P_dev, e->S, actions, count_updates, b0, nb, e->step_id, par);
 }
 // Long streams: let the pre-pass run on every `track_refill` steps (lob_kernels.h prepass_extend_kernel)
 static void maybe_refill_track(lob_engine* e) {
     if (!e->chunked || ++e->steps_since_fill < e->track_refill) return;
     e->steps_since_fill = 0;
     TimedLaunch t(e, "prepass_extend_kernel", nullptr, true);
-    if (e->prepass_roles) {
-        if (e->P.T <= 2) hipLaunchKernelGGL(prepass_extend2_kernel<2>, dim3((e->B + 63) / 64), dim3(128), 0, e->stream, (const DevParams*)e->P_dev, e->S);
-        else hipLaunchKernelGGL(prepass_extend2_kernel<LOB_MAX_TRADES>, dim3((e->B + 63) / 64), dim3(128), 0, e->stream, (const DevParams*)e->P_dev, e->S);
-        return;
-    }
-    if (e->P.T <= 2) hipLaunchKernelGGL(prepass_extend_kernel<2>, dim3((e->B + 63) / 64), dim3(64), 0, e->stream, (const DevParams*)e->P_dev, e->S);
-    else hipLaunchKernelGGL(prepass_extend_kernel<LOB_MAX_TRADES>, dim3((e->B + 63) / 64), dim3(64), 0, e->stream, (const DevParams*)e->P_dev, e->S);
+    lobk_prepass_extend(e->stream, e->P.T <= 2, e->prepass_roles, (const DevParams*)e->P_dev, e->S);
 }
 // S0 of every group-0 triple on this step's list (lob_kernels.h memo_kernel): `which` 0 = for learn_kernel
 // (theta_t), 1 = for the next act_kernel (after the update)
@@ -838,22 +863,18 @@ static void launch_env_fused(lob_engine* e, hipStream_t st, int par, int lpar, u
     // the work list to the general act kernel and env_kernel<64, 2, 2> as before (either version is correct for any step).
     // ... and while MOST books have no usable list (a dense weight vector -- learning.random_init, a loaded checkpoint: every tile
     // lies on a written weight and no list fits a record): one wave per book in the general act kernel is far better than a
-    // 64-lane wave going through its books one at a time.  The learn kernels hand the same books back: their list's length,
-    // reported through the host-mapped word (a few steps late), tells.
-    const bool mostly_general = e->rest_hint && *(volatile i32*)e->rest_hint > e->B / 16;
+    // 64-lane wave going through its books one at a time.  The learn kernels hand the same books back: their list's length
+    // of LOB_HINT_LAG steps ago (lob_engine::rest_hint) tells.
+    const bool mostly_general = e->force_general >= 0 ? e->force_general == 1 : e->hint_now > e->B / 16;
     const bool half_waves = e->env_step_lanes == 32 && t2 && e->env_step && e->P.algo != LOB_ALGO_DOUBLE_Q;  // (experiment: LOB_ENV_STEP_LANES=32)
     const bool inline_general = t2 && e->env_step && e->inline_general && e->steps_on_lists >= 1 && !mostly_general && !half_waves;
     e->steps_on_lists++;
+    e->flow[inline_general ? 4 : mostly_general ? 5 : 6]++;
     const bool dq = e->P.algo == LOB_ALGO_DOUBLE_Q;  // (then t2 && env_step: lob_create)
     {
         TimedLaunch t(e, "env_kernel", st);
-        if (inline_general && dq) hipLaunchKernelGGL((env_step_kernel<true, true>), dim3((nb + 63) / 64), dim3(64), 0, st, Pd, e->S, sid, par, F1, (const uint32_t*)e->rnd_dev);
-        else if (dq) hipLaunchKernelGGL((env_step_kernel<false, true>), dim3((nb + 63) / 64), dim3(64), 0, st, Pd, e->S, sid, par, F1, (const uint32_t*)e->rnd_dev);
-        else if (half_waves) hipLaunchKernelGGL((env_step_kernel<false, false, 32>), dim3((nb + 31) / 32), dim3(64), 0, st, Pd, e->S, sid, par, F1, (const uint32_t*)e->rnd_dev);
-        else if (inline_general) hipLaunchKernelGGL(env_step_kernel<true>, dim3((nb + 63) / 64), dim3(64), 0, st, Pd, e->S, sid, par, F1, (const uint32_t*)e->rnd_dev);
-        else if (t2 && e->env_step) hipLaunchKernelGGL(env_step_kernel<false>, dim3((nb + 63) / 64), dim3(64), 0, st, Pd, e->S, sid, par, F1, (const uint32_t*)e->rnd_dev);
-        else if (t2) hipLaunchKernelGGL((env_kernel<64, 2, 1>), dim3((nb + 63) / 64), dim3(64), 0, st, Pd, e->S, (const i32*)nullptr, 1, 0, nb, sid, par, F1);
-        else hipLaunchKernelGGL((env_kernel<64, LOB_MAX_TRADES, 1>), dim3((nb + 63) / 64), dim3(64), 0, st, Pd, e->S, (const i32*)nullptr, 1, 0, nb, sid, par, F1);
+        if (t2 && e->env_step) lobk_env_step(st, inline_general, dq, half_waves, Pd, e->S, nb, sid, par, F1, (const uint32_t*)e->rnd_dev);
+        else lobk_env_mode(st, t2, 1, Pd, e->S, nb, sid, par, F1);
     }
     if (inline_general) return;
     {
@@ -863,8 +884,7 @@ static void launch_env_fused(lob_engine* e, hipStream_t st, int par, int lpar, u
     }
     {
         TimedLaunch t(e, "env_rest_kernel", st);
-        if (t2) hipLaunchKernelGGL((env_kernel<64, 2, 2>), dim3((nb + 63) / 64), dim3(64), 0, st, Pd, e->S, (const i32*)nullptr, 1, 0, nb, sid, par, F2);
-        else hipLaunchKernelGGL((env_kernel<64, LOB_MAX_TRADES, 2>), dim3((nb + 63) / 64), dim3(64), 0, st, Pd, e->S, (const i32*)nullptr, 1, 0, nb, sid, par, F2);
+        lobk_env_mode(st, t2, 2, Pd, e->S, nb, sid, par, F2);
     }
 }
 
@@ -911,24 +931,15 @@ int lob_reset(lob_engine* e) {
     }
     {
         TimedLaunch t(e, "reset_kernel", nullptr, true);
-        const int rb = e->reset_lanes;
-        const DevParams* Pd = (const DevParams*)e->P_dev;
-        const bool t2 = e->P.T <= 2;
-#define LOB_RESET_LAUNCH(L, TM) hipLaunchKernelGGL((reset_kernel<L, TM>), dim3((e->B + L - 1) / L), dim3(L), 0, e->stream, Pd, e->S)
-        if (e->prepass_roles && rb == 64) {  // the pre-pass on two waves per 64 books (LOB_PREPASS_ROLES=0: one)
-            if (t2) hipLaunchKernelGGL(reset2_kernel<2>, dim3((e->B + 63) / 64), dim3(128), 0, e->stream, Pd, e->S);
-            else hipLaunchKernelGGL(reset2_kernel<LOB_MAX_TRADES>, dim3((e->B + 63) / 64), dim3(128), 0, e->stream, Pd, e->S);
-        }
-        else if (rb == 32) { if (t2) LOB_RESET_LAUNCH(32, 2); else LOB_RESET_LAUNCH(32, LOB_MAX_TRADES); }
-        else if (rb == 16) { if (t2) LOB_RESET_LAUNCH(16, 2); else LOB_RESET_LAUNCH(16, LOB_MAX_TRADES); }
-        else { if (t2) LOB_RESET_LAUNCH(64, 2); else LOB_RESET_LAUNCH(64, LOB_MAX_TRADES); }
-#undef LOB_RESET_LAUNCH
+        lobk_reset(e->stream, e->reset_lanes, e->P.T <= 2, e->prepass_roles, (const DevParams*)e->P_dev, e->S);
     }
     HIPCHK(hipGetLastError());
     e->was_reset = true;
     e->episode_open = true;
     e->steps_since_fill = 0;
     e->hits_ok = false;
+    e->hint_step = 0;   // (the hand-back counts of the episode before say nothing about this one's first steps)
+    e->rest_recent = 0;
     e->half_open = false;  // (a step begun before the reset -- e.g. an exchange that failed between the halves -- is abandoned with the episode)
     return check_device_errors(e);
 }
@@ -972,7 +983,7 @@ int lob_get_state(lob_engine* e, float* host_out) {
     HIPCHK(hipSetDevice(e->device));
     f32* d = nullptr;
     HIPCHK(hipMalloc((void**)&d, (size_t)e->B * e->P.V * 4));
-    hipLaunchKernelGGL(get_state_kernel, dim3(grid_lanes(e->B)), dim3(256), 0, e->stream, (const DevParams*)e->P_dev, e->S, d, (f64*)nullptr);
+    lobk_get_state(e->stream, (const DevParams*)e->P_dev, e->S, d, (f64*)nullptr);
     hipError_t err = hipMemcpyAsync(host_out, d, (size_t)e->B * e->P.V * 4, hipMemcpyDeviceToHost, e->stream);
     hipStreamSynchronize(e->stream);
     hipFree(d);
@@ -986,7 +997,7 @@ int lob_get_reward(lob_engine* e, double* host_out) {
     HIPCHK(hipSetDevice(e->device));
     f64* d = nullptr;
     HIPCHK(hipMalloc((void**)&d, (size_t)e->B * 8));
-    hipLaunchKernelGGL(get_state_kernel, dim3(grid_lanes(e->B)), dim3(256), 0, e->stream, (const DevParams*)e->P_dev, e->S, (f32*)nullptr, d);
+    lobk_get_state(e->stream, (const DevParams*)e->P_dev, e->S, (f32*)nullptr, d);
     hipError_t err = hipMemcpyAsync(host_out, d, (size_t)e->B * 8, hipMemcpyDeviceToHost, e->stream);
     hipStreamSynchronize(e->stream);
     hipFree(d);
@@ -1014,7 +1025,7 @@ int lob_clear_inventory(lob_engine* e) {
     if (rc) return rc;
     if ((rc = not_mid_step(e, "lob_clear_inventory"))) return rc;
     HIPCHK(hipSetDevice(e->device));
-    hipLaunchKernelGGL(clear_inventory_kernel, dim3(grid_lanes(e->B)), dim3(256), 0, e->stream, (const DevParams*)e->P_dev, e->S);
+    lobk_clear_inventory(e->stream, (const DevParams*)e->P_dev, e->S);
     e->hits_ok = false;
     HIPCHK(hipGetLastError());
     return check_device_errors(e);
@@ -1028,7 +1039,7 @@ int lob_get_books(lob_engine* e, int32_t first, int32_t n, lob_book_dump* out) {
         HIPCHK(hipMalloc((void**)&e->dump_dev, (size_t)n * sizeof(lob_book_dump)));
         e->dump_cap = n;
     }
-    hipLaunchKernelGGL(dump_kernel, dim3((n + 63) / 64), dim3(64), 0, e->stream, (const DevParams*)e->P_dev, e->S, first, n, e->dump_dev);
+    lobk_dump(e->stream, (const DevParams*)e->P_dev, e->S, first, n, e->dump_dev);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, e->dump_dev, (size_t)n * sizeof(lob_book_dump), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -1076,6 +1087,19 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
             HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
         }
         const bool fast = e->P.memo != 0;  // (implies one group)
+        if (first) {
+            // the learn kernels' hand-back count of LOB_HINT_LAG learner steps ago (0 until that many have run since the hints were void)
+            e->hint_now = 0;
+            if (fast && mode == 0 && e->rest_hint && e->hint_step >= LOB_HINT_LAG) {
+                const int hs = (int)((e->hint_step - LOB_HINT_LAG) % LOB_HINT_RING);
+                HIPCHK(hipEventSynchronize(e->hint_ev[hs]));
+                // (the kernel is done; its store to host memory is a system-scope atomic and carries the launch's tag: wait for that very word)
+                u64 w = *(volatile u64*)(e->rest_hint + hs);
+                for (int spin = 0; (uint32_t)(w >> 32) != e->hint_tags[hs] && spin < (1 << 22); spin++) w = *(volatile u64*)(e->rest_hint + hs);
+                if ((uint32_t)(w >> 32) != e->hint_tags[hs]) { lob_set_error("the learn kernels' hand-back count never arrived in host memory"); return LOB_EHIP; }
+                e->hint_now = (int)(uint32_t)w;
+            }
+        }
         bool rest_pending = false;
         bool acc_fused = false;  // (this step: see the learn kernel's launch)
         bool rest_side_now = false;
@@ -1163,24 +1187,11 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                         acc_fused = fuse && e->acc_fuse && e->P.combine && e->P.sarsa_lanes && (e->P.algo == LOB_ALGO_QLAMBDA || dq) && !acc_blocked(e) && G == 1;
                         // (not while the learn kernel hands most books back -- a dense theta: every one of them would go on the list
                         // through one counter; the list's length of a few steps ago, as launch_env_fused reads it)
-                        if (e->rest_hint && *(volatile i32*)e->rest_hint > std::max(1024, e->B / 16)) acc_fused = false;
+                        if (e->hint_now > std::max(1024, e->B / 16)) acc_fused = false;
                         const int gq = pair ? std::min(LOB_QP_OCC * e->n_cus, (nb + LOB_QP_BOOKS - 1) / LOB_QP_BOOKS) : std::min(e->n_cus, (nb + LOB_QL_BLOCK - 1) / LOB_QL_BLOCK);
                         const size_t lds = pair ? qpair_lds_bytes(e->P.cwords4) : qlane_lds_bytes(e->P.cwords4);
-#define LOB_QL_LAUNCH(A, VT, TR)                                                                                                                            \
-    do {                                                                                                                                                    \
-        if (pair) hipLaunchKernelGGL((learn_q_pair_kernel<A, VT, TR>), dim3(gq), dim3(LOB_QP_BLOCK), lds, st, e->P, e->S, rnd, lpar, ver, sid, acc_fused ? 1 : 0); \
-        else hipLaunchKernelGGL((learn_q_lane_kernel<A, VT, TR>), dim3(gq), dim3(LOB_QL_BLOCK), lds, st, e->P, e->S, rnd, lpar, ver, sid, acc_fused ? 1 : 0); \
-    } while (0)
-                        if (dq) {  // (lob_create: only with the fused trace step)
-                            if (e->P.V == 8) hipLaunchKernelGGL((learn_q_lane_kernel<LOB_ALGO_DOUBLE_Q, 8, true>), dim3(gq), dim3(LOB_QL_BLOCK), lds, st, e->P, e->S, rnd, lpar, ver, sid, acc_fused ? 1 : 0);
-                            else hipLaunchKernelGGL((learn_q_lane_kernel<LOB_ALGO_DOUBLE_Q, 0, true>), dim3(gq), dim3(LOB_QL_BLOCK), lds, st, e->P, e->S, rnd, lpar, ver, sid, acc_fused ? 1 : 0);
-                        }
-                        else if (fuse) { if (e->P.V == 8) LOB_QL_LAUNCH(LOB_ALGO_QLAMBDA, 8, true); else LOB_QL_LAUNCH(LOB_ALGO_QLAMBDA, 0, true); }
-                        else if (e->P.algo == LOB_ALGO_QLAMBDA) { if (e->P.V == 8) LOB_QL_LAUNCH(LOB_ALGO_QLAMBDA, 8, false); else LOB_QL_LAUNCH(LOB_ALGO_QLAMBDA, 0, false); }
-                        else { if (e->P.V == 8) LOB_QL_LAUNCH(LOB_ALGO_SARSA, 8, false); else LOB_QL_LAUNCH(LOB_ALGO_SARSA, 0, false); }
-#undef LOB_QL_LAUNCH
-                    } else if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL((learn_q_fast_kernel<LOB_ALGO_QLAMBDA, LOB_FAST_NB>), dim3(gf), dim3(LOB_FAST_BLOCK), fast_lds_bytes(e->P.cwords4, LOB_FAST_NB, false), st, e->P, e->S, rnd, lpar, ver);
-                    else hipLaunchKernelGGL((learn_q_fast_kernel<LOB_ALGO_SARSA, LOB_FAST_NB>), dim3(gf), dim3(LOB_FAST_BLOCK), fast_lds_bytes(e->P.cwords4, LOB_FAST_NB, false), st, e->P, e->S, rnd, lpar, ver);
+                        lobk_learn_q(st, pair, e->P.algo, e->P.V == 8, fuse, gq, lds, e->P, e->S, rnd, lpar, ver, sid, acc_fused ? 1 : 0);
+                    } else lobk_learn_q_fast(st, e->P.algo, gf, fast_lds_bytes(e->P.cwords4, LOB_FAST_NB, false), e->P, e->S, rnd, lpar, ver);
                 }
                 {
                     // The books the lane kernels hand back (a list that is empty in most steps, a handful of books in the others).
@@ -1188,7 +1199,7 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                     // them on the second stream: nothing they do depends on it -- the update kernels wait for both.
                     // (worth it only while books ARE handed back -- an empty launch is cheaper than the two cross-stream waits: the
                     // kernel reports its list's length through a host-mapped word, read here a few steps late)
-                    if (e->rest_hint && *(volatile i32*)e->rest_hint > 0) e->rest_recent = 64;
+                    if (e->hint_now > 0) e->rest_recent = 64;
                     else if (e->rest_recent > 0) e->rest_recent--;
                     const bool side = fuse && e->rest_side && e->rest_recent > 0;
                     hipStream_t rs = side ? e->stream2 : st;
@@ -1198,9 +1209,13 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                     }
                     {
                         TimedLaunch t(e, "learn_rest_kernel", rs);
-                        if (dq) hipLaunchKernelGGL(learn_q_rest_kernel<LOB_ALGO_DOUBLE_Q>, dim3(gl), dim3(LOB_BLOCK), 0, rs, e->P, e->S, rnd, learn_list, learn_n, e->rest_hint_dev);
-                        else if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL(learn_q_rest_kernel<LOB_ALGO_QLAMBDA>, dim3(gl), dim3(LOB_BLOCK), 0, rs, e->P, e->S, rnd, learn_list, learn_n, e->rest_hint_dev);
-                        else hipLaunchKernelGGL(learn_q_rest_kernel<LOB_ALGO_SARSA>, dim3(gl), dim3(LOB_BLOCK), 0, rs, e->P, e->S, rnd, learn_list, learn_n, e->rest_hint_dev);
+                        const int hs = (int)(e->hint_step % LOB_HINT_RING);
+                        u64* hint_dev = e->rest_hint ? e->rest_hint_dev + hs : nullptr;
+                        const uint32_t hint_tag = (uint32_t)(++e->hint_serial);
+                        if (dq) hipLaunchKernelGGL(learn_q_rest_kernel<LOB_ALGO_DOUBLE_Q>, dim3(gl), dim3(LOB_BLOCK), 0, rs, e->P, e->S, rnd, learn_list, learn_n, hint_dev, hint_tag);
+                        else if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL(learn_q_rest_kernel<LOB_ALGO_QLAMBDA>, dim3(gl), dim3(LOB_BLOCK), 0, rs, e->P, e->S, rnd, learn_list, learn_n, hint_dev, hint_tag);
+                        else hipLaunchKernelGGL(learn_q_rest_kernel<LOB_ALGO_SARSA>, dim3(gl), dim3(LOB_BLOCK), 0, rs, e->P, e->S, rnd, learn_list, learn_n, hint_dev, hint_tag);
+                        if (e->rest_hint) { HIPCHK(hipEventRecord(e->hint_ev[hs], rs)); e->hint_tags[hs] = hint_tag; e->hint_step++; }
                     }
                     if (side) {
                         HIPCHK(hipEventRecord(e->ev_rest_done, e->stream2));
@@ -1298,6 +1313,7 @@ int lob_td_step_begin(lob_engine* e) {
     if (e->B >= 1024 && e->n_groups > 1) { lob_set_error("lob_td_step_begin: not with two book groups (LOB_GROUPS=2)"); return LOB_ESTATE; }
     return run_steps(e, 1, 0, 1);
 }
+int lob_td_split_supported(lob_engine* e) { return e && !(e->B >= 1024 && e->n_groups > 1) ? 1 : 0; }
 int lob_td_step_end(lob_engine* e) {
     int rc = need_reset(e, "lob_td_step_end");
     if (rc) return rc;
@@ -1385,6 +1401,8 @@ int lob_theta_set(lob_engine* e, int32_t which, const double* host_in, int64_t c
     }
     e->theta_ver++;  // memo records computed under the old weights are void
     e->hits_ok = false;
+    e->hint_step = 0;  // (... and so is what the learn kernels handed back under them)
+    e->rest_recent = 0;
     hipLaunchKernelGGL(rebuild_nz_kernel, dim3(1024), dim3(256), 0, e->stream, (const f64*)th, nz, e->S.nz_epoch, e->P.M);
     if (e->P.memo && (th == e->S.theta || th == e->S.theta_b)) {  // (double Q: one pair of maps for both vectors)
         // the maps keep the bits they have (monotone: the tiles of live trace generations stay marked, whatever the
@@ -1587,12 +1605,13 @@ int lob_delta_sparse_maps(lob_engine* e, int32_t world, uint32_t** dev_own, uint
         if (rc == LOB_OK) rc = dev_alloc(e, &e->spx_total, 1);
         if (rc != LOB_OK) return rc;
     }
-    if (!e->spx_buf) {
-        // every buffer of the exchange exists before its first collective starts: a rank that failed to allocate between two
-        // collectives would leave the others waiting in the second.  The union has at most M entries.
-        HIPCHK(hipMalloc((void**)&e->spx_buf, (size_t)e->P.M * 8));
-        e->spx_cap = e->P.M;
-    }
+    // every buffer of the exchange exists before its first collective starts (lob_theta_allreduce calls this once BEFORE the ranks
+    // agree on the exchange's form, and a rank that failed here makes all of them fail together): a rank that failed to allocate
+    // between two collectives would leave the others waiting in the second.  The packed deltas go into the dense exchange's
+    // scratch vector (lob_delta_init: M doubles, idle while the exchange is sparse): the union has at most M entries, and
+    // nothing of that size is allocated for it.
+    e->spx_buf = e->S.delta;
+    e->spx_cap = e->P.M;
     *dev_own = e->S.theta_nzx;
     *dev_gather = e->spx_gather;
     *words = W;
@@ -1677,6 +1696,10 @@ int lob_kernel_time_ms(lob_engine* e, const char* kernel, double* avg_ms, int64_
 
 }  // extern "C"
 
+// Diagnostics (not part of include/lob_engine.h): 1 in a -DLOB_EXPERIMENTS build -- the kernel variants measured and lost
+// (env_compact_kernel, the two-wave pre-pass, 32-lane env_step_kernel, two book groups, ...) exist and their switches work.
+extern "C" int lob_experiments_enabled(void) { return lobk_experiments(); }
+
 // Diagnostics (not part of include/lob_engine.h): phase clocks of a -DLOB_PROF build, summed over books
 // (tools/exp_prof.py); LOB_ESTATE on a regular build.
 extern "C" int lob_debug_prof(lob_engine* e, int64_t out[LOB_PROF_N]) {
@@ -1715,10 +1738,13 @@ extern "C" int lob_debug_fastpath(lob_engine* e, int64_t* out, int32_t n_out) {
 // Diagnostics (not part of include/lob_engine.h): learner steps (combined update) since lob_create by the shape of their update
 // -- [0] updates added to their slots by the learn / trace kernels, accumulate_kernel over the list they left (Q(lambda)),
 // [1] steps whose learn_q_rest_kernel ran beside the trace kernels on the second stream, [2] accumulate_block_kernel,
-// [3] accumulate_kernel over every book.  The tests use it to know which path they have compared with the oracle.
-extern "C" int lob_debug_flow(lob_engine* e, int64_t out[4]) {
+// [3] accumulate_kernel over every book; steps with the action selection inside the env kernel (launch_env_fused): [4] books without a
+// usable hit list served in-kernel (act_book), [5] through the work list to the wave-per-book act kernel because the learn
+// kernels' hand-back count said most books have none (a dense theta), [6] through the work list for another reason (the first
+// step on lists, LOB_INLINE_GENERAL=0).  The tests use it to know which path they have compared with the oracle.
+extern "C" int lob_debug_flow(lob_engine* e, int64_t out[8]) {
     if (!e || !out) return LOB_EINVAL;
-    for (int i = 0; i < 4; i++) out[i] = e->flow[i];
+    for (int i = 0; i < 8; i++) out[i] = e->flow[i];
     return LOB_OK;
 }
 

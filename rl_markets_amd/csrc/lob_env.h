@@ -1013,8 +1013,9 @@ __device__ inline void step_prologue(const EnvCtx& c, EnvR& e, int action, StepA
     e.total_ticks++;  // UpdateStats (base.cpp:412-442): occupancy of the two quotes and of the inventory at decision time
     {
         const i64 ha = e.a_on ? 1 : 0, hb = e.b_on ? 1 : 0;
-        e.tick_ab += ha | (hb << 21) | ((ha & hb) << 42);
-        e.tick_pos += (i64)(e.position != 0) | ((i64)(e.position > 0) << 21) | ((i64)(e.position < 0) << 42);
+        e.tick_ab += ha | (hb << 32);
+        e.tick_both += (i32)(ha & hb);
+        e.tick_pos += (i64)(e.position > 0) | ((i64)(e.position < 0) << 32);
         e.ntr_snap = (i64)(uint32_t)e.a_ntr | ((i64)(uint32_t)e.b_ntr << 32);
     }
     g.r = get_reward(c, e);

@@ -470,6 +470,7 @@ __device__ inline bool act_light_book(const DevParams& P, const DevState& S, int
     if ((int)(threadIdx.x & 63) == __builtin_ctzll(act)) atomicAdd((unsigned long long*)&S.counters[5], (unsigned long long)__builtin_popcountll(act));
     return true;
 }
+#if LOB_IN_MAIN
 __global__ void __launch_bounds__(LOB_LIGHT_BLOCK) act_light_kernel(DevParams P, DevState S, int par, int lpar, u64 ver, int sid_prev) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         S.mk_count[par] = 0;
@@ -485,6 +486,7 @@ __global__ void __launch_bounds__(LOB_LIGHT_BLOCK) act_light_kernel(DevParams P,
     int action;
     act_light_book(P, S, b, h, lpar, ver, S.hl_dirty[0] == sid_prev, action);
 }
+#endif
 
 // Agent::UpdateTraces for every book that stepped (learn_traces), the first half of learn_book; leaves
 // Q(s, a) in LHdr::td and the RNG counter after its draws in LHdr::rng_ctr for the second half
@@ -571,6 +573,7 @@ __global__ void __launch_bounds__(LOB_TRACE_BLOCK, LOB_TRACE_OCC) trace_fast_ker
 // generation is then the chosen action's 32 tiles, all alive, copied from the slot's record (memo_kernel wrote them),
 // and nothing is looked up in any set.  At an exploration rate of 0.8 that is 7 books in 10; the others go on the list
 // of the wave-per-book kernel.  Same draws, same stores as learn_traces for these books.
+#if LOB_IN_MAIN
 __global__ void __launch_bounds__(LOB_LIGHT_BLOCK) trace_light_kernel(DevParams P, DevState S, int lpar) {
     // Slot claims of the combined update: thousands of books hold the very same generation, and compare-and-swaps on one
     // address queue up behind each other.  The block elects one claimant per distinct generation first (LDS).
@@ -647,6 +650,7 @@ __global__ void __launch_bounds__(LOB_LIGHT_BLOCK) trace_light_kernel(DevParams 
         } else S.tr_cbslot[(size_t)b * G + nh] = (i32)((uint32_t)ch & (uint32_t)(S.cb_slots - 1));
     }
 }
+#endif
 
 // Agent::UpdateTraces with a LANE per trace generation, 32 lanes per book, for the books whose older generations survive the
 // step: every book of SARSA(lambda) (no Watkins cut: a book keeps its trace_kmax - 1 latest generations), the books of Watkins's

@@ -14,6 +14,33 @@
 
 #include "lob_state.h"
 #include "lob_stream.h"
+#include "lob_launch.h"
+
+// The engine library is built from four translation units (lob_launch.h).  The kernel TEMPLATES of these headers are only
+// compiled where they are launched; the plain kernels are compiled in the unit that launches them: LOB_TU_SPLIT + one of
+// LOB_TU_MAIN / LOB_TU_ENV / LOB_TU_PREPASS / LOB_TU_LEARN says which unit this is (neither: one unit holds everything, as the
+// experiment builds of tools/ and the host-side tests of the device headers do).
+#if !defined(LOB_TU_SPLIT)
+#define LOB_IN_MAIN 1
+#define LOB_IN_ENV 1
+#define LOB_IN_PREPASS 1
+#else
+#if defined(LOB_TU_MAIN)
+#define LOB_IN_MAIN 1
+#else
+#define LOB_IN_MAIN 0
+#endif
+#if defined(LOB_TU_ENV)
+#define LOB_IN_ENV 1
+#else
+#define LOB_IN_ENV 0
+#endif
+#if defined(LOB_TU_PREPASS)
+#define LOB_IN_PREPASS 1
+#else
+#define LOB_IN_PREPASS 0
+#endif
+#endif
 
 // The venue's tick table for the lane-per-book kernels, in LDS: Market::ToTicks / ToPrice index it with a
 // per-lane band, and a chain of such look-ups from global memory (six conversions per DoAction, four or
@@ -68,6 +95,7 @@ static_assert(sizeof(EnvSlot) * 256 <= 160 * 1024, "one 256-lane block per CU mu
 static_assert(LOB_BLOCK >= LOB_NZ_WORDS && 512 % LOB_BLOCK == 0 || LOB_BLOCK % 512 == 0, "block 0 clears one nz_new buffer; the block stages the 512 x 16 B hash table");
 
 // ---------------------------------------------------------------------------
+#if LOB_IN_PREPASS
 __global__ void gen_events_kernel(lob_gen_params g, int D, int T, u64 first_book, int B, uint32_t* out) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
@@ -83,7 +111,9 @@ __global__ void gen_events_kernel(lob_gen_params g, int D, int T, u64 first_book
             *reinterpret_cast<uint4*>(dst + i) = make_uint4(drec[i], drec[i + 1], drec[i + 2], drec[i + 3]);
     }
 }
+#endif
 // Uploaded streams: ABI records (lob_engine.h) -> device records, one thread per record.
+#if LOB_IN_PREPASS
 __global__ void repack_kernel(const uint32_t* __restrict__ src, int D, int T, size_t n_records, uint32_t* dst) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_records) return;
@@ -94,6 +124,7 @@ __global__ void repack_kernel(const uint32_t* __restrict__ src, int D, int T, si
     for (int k = 0; k < Wd; k += 4)
         *reinterpret_cast<uint4*>(dst + i * Wd + k) = make_uint4(drec[k], drec[k + 1], drec[k + 2], drec[k + 3]);
 }
+#endif
 
 // ---------------------------------------------------------------------------
 // Base::Initialise + Intraday::Initialise (base.cpp:123-135, intraday.cpp:103-138)
@@ -131,7 +162,7 @@ __global__ void __launch_bounds__(RB) reset_kernel(const DevParams* __restrict__
     e.a_ntr = 0; e.a_on = 0; e.b_ntr = 0; e.b_on = 0;
     e.ep_reward = e.ep_pnl = e.ep_bandh = 0.0;
     e.total_ticks = e.market_buys = e.market_sells = 0;
-    e.tick_ab = e.tick_pos = 0;
+    e.tick_ab = e.tick_pos = 0; e.tick_both = 0;
     e.ntr_snap = 0;
     if (M.init_ok) {
         const int k = M.k_warm;
@@ -229,7 +260,7 @@ __global__ void __launch_bounds__(128, 2) reset2_kernel(const DevParams* __restr
     e.a_ntr = 0; e.a_on = 0; e.b_ntr = 0; e.b_on = 0;
     e.ep_reward = e.ep_pnl = e.ep_bandh = 0.0;
     e.total_ticks = e.market_buys = e.market_sells = 0;
-    e.tick_ab = e.tick_pos = 0;
+    e.tick_ab = e.tick_pos = 0; e.tick_both = 0;
     e.ntr_snap = 0;
     if (M.init_ok) {
         const int k = M.k_warm;
@@ -347,6 +378,7 @@ __global__ void __launch_bounds__(128, 2) prepass_extend2_kernel(const DevParams
 }
 
 // Evaluate getState() for every book (lob_get_state): lane per book.
+#if LOB_IN_ENV
 __global__ void __launch_bounds__(256) get_state_kernel(const DevParams* __restrict__ Pp, DevState S, f32* out /*[B][V]*/, f64* reward /*[B] or null*/) {
     const DevParams& P = *Pp;  // parameters read through the scalar cache, never copied to scratch
     __shared__ TickLds tick_lds;
@@ -362,6 +394,7 @@ __global__ void __launch_bounds__(256) get_state_kernel(const DevParams* __restr
     }
     if (reward) reward[b] = get_reward(c, e);
 }
+#endif
 
 // performAction for every book that has an action pending (S.stepped).
 // mode 0: learner step (new vars go to `state` = slot_cur); mode 1: host
@@ -379,12 +412,7 @@ __global__ void __launch_bounds__(256) get_state_kernel(const DevParams* __restr
 //         book without a valid list goes on the act work list and is skipped; after the general act kernel has served the
 //         list, MODE 2 takes its books' steps.
 // MODE 2: the books of the work list `list` (`*list_n` entries).
-struct EnvFuse {  // MODE 1 / 2
-    const i32* list;
-    const i32* list_n;
-    int lpar, sid_prev;
-    u64 ver;
-};
+// (struct EnvFuse: lob_launch.h)
 __device__ inline bool act_light_book(const DevParams& P, const DevState& S, int b, const LHdr& h, int lpar, u64 ver, bool dirty, int& action);
 template <int LOB_ENV_BLOCK, int TM, int MODE = 0>
 __global__ void __launch_bounds__(LOB_ENV_BLOCK) env_kernel(const DevParams* __restrict__ Pp, DevState S, const i32* host_actions, int count_updates, int b0, int nb,
@@ -518,6 +546,7 @@ struct EnvCompactSlot {
 };
 static_assert(sizeof(EnvCompactSlot) * LOB_ENVC_BLOCK + 2 * 2 * LOB_ENVC_BLOCK + LOB_ENVC_BLOCK + 64 <= 80 * 1024, "two blocks per CU");
 
+#if LOB_IN_ENV && defined(LOB_EXPERIMENTS)  // (opt-in LOB_ENV_LANES=256: measured no faster than env_kernel<64>, NOTES.md)
 __global__ void __launch_bounds__(LOB_ENVC_BLOCK) env_compact_kernel(const DevParams* __restrict__ Pp, DevState S, int count_updates, int b0, int nb,
                                                                      int step_id, int par) {
     const DevParams& P = *Pp;  // parameters read through the scalar cache, never copied to scratch
@@ -634,8 +663,10 @@ __global__ void __launch_bounds__(LOB_ENVC_BLOCK) env_compact_kernel(const DevPa
         if (count_updates) atomicAdd((u64*)&S.counters[3], (u64)d_steps);  // every stepped book gets one TD update
     }
 }
+#endif
 
 // Base::ClearInventory for every book (Runner::RunEpisode epilogue, serial.cpp:31)
+#if LOB_IN_ENV
 __global__ void __launch_bounds__(256) clear_inventory_kernel(const DevParams* __restrict__ Pp, DevState S) {
     const DevParams& P = *Pp;  // parameters read through the scalar cache, never copied to scratch
     __shared__ TickLds tick_lds;
@@ -648,6 +679,7 @@ __global__ void __launch_bounds__(256) clear_inventory_kernel(const DevParams* _
     clear_inventory(c, e);
     env_store(S, b, e);
 }
+#endif
 
 // ---------------------------------------------------------------------------
 // Shared LDS image of a learner block.
@@ -1255,12 +1287,13 @@ __device__ __forceinline__ void learn_q_book(const DevParams& P, const DevState&
     }
 }
 template <int ALGO>
-// `hint` (host-mapped memory, or null): the list's length, for the host to see without a synchronisation -- a few steps late,
-// which is all it needs to decide whether this launch is worth a place beside the trace kernels on the second stream.
+// `hint` (host-mapped memory, or null): the list's length tagged with this launch's serial number, for the host to read
+// LOB_HINT_LAG steps later (lob_engine.hip: which act / accumulate path a step takes, whether this launch runs beside the trace kernels).
 __global__ void __launch_bounds__(LOB_BLOCK) learn_q_rest_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g,
-                                                                 const i32* __restrict__ list, const i32* __restrict__ list_n, i32* hint) {
+                                                                 const i32* __restrict__ list, const i32* __restrict__ list_n, u64* hint, uint32_t hint_tag) {
     __shared__ LearnLds L;
-    if (hint && blockIdx.x == 0 && threadIdx.x == 0) *hint = *list_n;
+    if (hint && blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store(hint, ((u64)hint_tag << 32) | (u64)(uint32_t)*list_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (*list_n == 0) return;  // nothing handed back: the usual case
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     learn_stage_table(rnd_g, L);
@@ -1295,6 +1328,7 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
 }
 
 // Agent::updateQ (agent.cpp:137-142): theta[f] += (alpha*delta / N_TILINGS) * e[f]
+#if LOB_IN_MAIN
 __global__ void __launch_bounds__(LOB_BLOCK) update_kernel(DevParams P, DevState S, int par, int sid) {
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b = __builtin_amdgcn_readfirstlane(blockIdx.x * LOB_WAVES_PER_BLOCK + w);
@@ -1349,12 +1383,14 @@ __global__ void __launch_bounds__(LOB_BLOCK) update_kernel(DevParams P, DevState
         }
     }
 }
+#endif
 
 // RLearn / OnlineRLearn::UpdateWeights after updateQ (agent.cpp:382-385, 407-410):
 //     nQ = Q + update;  if (nQ - maxQ(from_state) < 1e-7) rho += beta * (reward - rho + target - nQ)
 // with maxQ(from_state) under the weights the update has just written (one more Q evaluation of last_state; its argmax
 // draws are the last of the book's step).  Every book reads rho_t; the increments are summed (rho_inc) and folded in by
 // rho_fold_kernel -- the batch semantic of theta.  One wave per book, as learn_kernel.
+#if LOB_IN_MAIN
 __global__ void __launch_bounds__(LOB_BLOCK) rho_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g) {
     __shared__ LearnLds L;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1404,9 +1440,11 @@ __global__ void __launch_bounds__(LOB_BLOCK) rho_kernel(DevParams P, DevState S,
         }
     }
 }
+#endif
 // rho_{t+1} = rho_t + the MEAN of the step's increments: the reference's shared Agent applies them one after the other
 // (each relative to the rho the one before left: a contraction), which a sum of n increments all relative to rho_t is
 // not -- beta * n > 2 diverges.  One contributor (one book, or private weights): the increment itself, bit for bit.
+#if LOB_IN_MAIN
 __global__ void rho_fold_kernel(DevState S, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1415,18 +1453,23 @@ __global__ void rho_fold_kernel(DevState S, int n) {
     S.rho_inc[i] = 0.0;
     S.rho_cnt[i] = 0;
 }
+#endif
 // Multi-GPU exchange of the shared rho (two extra slots behind the weights' delta: [rho - rho_sync, 1.0]; the all-reduce
 // sums both, so the second is the number of ranks and rho <- rho_sync + mean of the ranks' changes)
+#if LOB_IN_MAIN
 __global__ void rho_delta_begin_kernel(const f64* rho, const f64* sync_slot, f64* delta_slots) {
     delta_slots[0] = rho[0] - sync_slot[0];
     delta_slots[1] = 1.0;
 }
+#endif
+#if LOB_IN_MAIN
 __global__ void rho_delta_apply_kernel(f64* rho, f64* sync_slot, const f64* delta_slots) {
     const f64 n = delta_slots[1];
     const f64 r = sync_slot[0] + (n > 0.0 ? delta_slots[0] / n : 0.0);
     rho[0] = r;
     sync_slot[0] = r;
 }
+#endif
 
 // ---- combined update (shared theta) --------------------------------------------------------------
 // accumulate_kernel: ONE LANE per trace generation, `1 << lpb_shift` lanes per book (a book with more
@@ -1496,6 +1539,7 @@ __device__ inline bool acc_generation(const DevState& S, size_t gi, uint32_t mas
 }
 // `list` (or null: every book): accumulate_kernel over the books the fused accumulation left (lob_state.h acc_list); an entry
 // with bit 31 takes only the book's generations without a slot.
+#if LOB_IN_MAIN
 __global__ void __launch_bounds__(LOB_BLOCK) accumulate_kernel(DevParams P, DevState S, int par, int lpb_shift, int sid, const i32* __restrict__ list = nullptr,
                                                                const i32* __restrict__ list_n = nullptr) {
     const int lane = threadIdx.x & 63;
@@ -1610,6 +1654,7 @@ __global__ void __launch_bounds__(LOB_BLOCK) accumulate_kernel(DevParams P, DevS
         if (!list) break;
     }
 }
+#endif
 
 // accumulate_block_kernel: the same sums for SARSA(lambda), whose every book keeps ~25 live generations -- 1.6 M additions per step
 // landing on fewer than 10 k slots, bound by the rate of f64 atomics (11 G/s) however the addresses are spread.  A block takes
@@ -1622,6 +1667,7 @@ __global__ void __launch_bounds__(LOB_BLOCK) accumulate_kernel(DevParams P, DevS
 #ifndef LOB_ACB_K
 #define LOB_ACB_K 4      /* batches of LOB_ACB_BLOCK books per block */
 #endif
+#if LOB_IN_MAIN
 __global__ void __launch_bounds__(LOB_ACB_BLOCK) accumulate_block_kernel(DevParams P, DevState S, int par, int sid, int n_batches) {
     __shared__ i32 keys[LOB_ACB_TAB];
     __shared__ f64 sums[LOB_ACB_TAB];
@@ -1739,11 +1785,13 @@ __global__ void __launch_bounds__(LOB_ACB_BLOCK) accumulate_block_kernel(DevPara
         if (!(S.cb_touch[(uint32_t)k] & 1u)) atomicOr(&S.cb_touch[(uint32_t)k], 1u);
     }
 }
+#endif
 
 // apply_kernel: one wave per occupied slot (the step's list, lob_learn.h).  Touched this step: theta[tile] += the summed update
 // for the live tiles of the slot's generation -- the 32 indices follow from its identity (quantised triple + action; all 0 for
 // a constructor-zero State: learn_traces) --, maintain the written-weights map and the carry-over filter, hand the slot on to
 // the next step's list.  Not touched: no stepped book holds the generation any more, free the slot.
+#if LOB_IN_MAIN
 __global__ void __launch_bounds__(256) apply_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g, int par, int sid) {
     __shared__ uint32_t rnd[2048 + 32];
     __shared__ int n_surv;
@@ -1832,6 +1880,7 @@ __global__ void __launch_bounds__(256) apply_kernel(DevParams P, DevState S, con
         S.cb_count[seg] = 0;
     }
 }
+#endif
 
 // Group-0 memo: S0(a) = the first 32 terms of Agent::getQ (agent.cpp:117-135), sum over the tilings of
 // w0 * theta[group-0 tile], in the reference's order, for every triple on this step's list.  One wave
@@ -1842,6 +1891,7 @@ __global__ void __launch_bounds__(256) apply_kernel(DevParams P, DevState S, con
 // `reset_lpar` >= 0 (the step's last launch, which 1): also what an act kernel does before anything else -- empty the lists this
 // step has consumed -- so that the next step may start with env_kernel<.., 1>, whose blocks append to them from the first
 // instruction on.
+#if LOB_IN_MAIN
 __global__ void __launch_bounds__(256) memo_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g, int par, int which, u64 ver, int reset_lpar) {
     if (reset_lpar >= 0 && blockIdx.x == 0 && threadIdx.x == 0) {
         S.mk_count[par ^ 1] = 0;               // the next step's list of memo slots
@@ -1946,6 +1996,7 @@ __global__ void __launch_bounds__(256) memo_kernel(DevParams P, DevState S, cons
         S.mk_markcount[0] = 0;
     }
 }
+#endif
 
 // Tile registry (lob_state.h ow_tab; trace_lane_kernel): the memo slots on this step's list whose tiles are not registered yet --
 // new triples, a few dozen per step -- enter their 288 tiles, learn which of them lie on an index another tile uses (mk_amb) and
@@ -1953,6 +2004,7 @@ __global__ void __launch_bounds__(256) memo_kernel(DevParams P, DevState S, cons
 // learner kernels: nothing of what it writes is needed before the next step's trace kernel (a slot new in step t is nobody's
 // last_state before step t + 1; bits that appear early in mk_amb of older slots only widen the set of tile pairs the lane
 // kernel compares index by index, and equal indices are the ground truth).
+#if LOB_IN_MAIN
 __global__ void __launch_bounds__(256) registry_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g, int par) {
     __shared__ uint32_t rnd[2048 + 32];
     {
@@ -2029,8 +2081,10 @@ __global__ void __launch_bounds__(256) registry_kernel(DevParams P, DevState S, 
         }
     }
 }
+#endif
 // ... and the indices that launch found ambiguous for the first time are marked in every registered slot that holds them (the
 // slots registered since then know already: tile_register looks at the bitmap).  Same stream, right after it.
+#if LOB_IN_MAIN
 __global__ void __launch_bounds__(256) registry_scan_kernel(DevState S, int par) {
     int n_new = S.amb_new_n[par];
     if (n_new > S.amb_cap) n_new = S.amb_cap;
@@ -2057,23 +2111,29 @@ __global__ void __launch_bounds__(256) registry_scan_kernel(DevState S, int par)
         }
     }
 }
+#endif
 
 // Agent::gen(seed) for every book: std::mt19937_64 seeded with (unsigned)(seed + global book id)
+#if LOB_IN_MAIN
 __global__ void mt_init_kernel(DevParams P, DevState S) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= S.B) return;
     mt64_seed(S.mt_state + (size_t)b * LOB_MT_N, (u64)(uint32_t)(P.seed + P.book_id_offset + (u64)b));
     S.mt_idx[b] = LOB_MT_N;  // first draw regenerates the block
 }
+#endif
 
 // Agent::HandleTerminal: traces.decay(0.0) (agent.cpp:103-109)
+#if LOB_IN_MAIN
 __global__ void clear_traces_kernel(DevState S) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < S.B) S.hdr[b].tr_n = 0;
 }
+#endif
 
 // State::newState(vector<float>&) + getFeatures / Agent::getQ for n free-standing
 // states (lob_features / lob_q_values).  Wave per state.
+#if LOB_IN_MAIN
 __global__ void __launch_bounds__(LOB_BLOCK) features_kernel(DevParams P, const f64* __restrict__ theta,
                                                              const uint32_t* __restrict__ nz, const uint32_t* __restrict__ rnd_g, const f32* vars,
                                                              int n, i32* out_idx, f64* out_q) {
@@ -2100,13 +2160,17 @@ __global__ void __launch_bounds__(LOB_BLOCK) features_kernel(DevParams P, const 
         if (lane < LOB_N_ACTIONS) out_q[(size_t)s * LOB_N_ACTIONS + lane] = qs[lane];
     }
 }
+#endif
 
 // ---- multi-GPU weight exchange --------------------------------------------
+#if LOB_IN_MAIN
 __global__ void delta_begin_kernel(const f64* __restrict__ theta, const f64* __restrict__ sync, f64* delta, i64 M) {
     i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     const i64 stride = (i64)gridDim.x * blockDim.x;
     for (; i < M; i += stride) delta[i] = theta[i] - sync[i];
 }
+#endif
+#if LOB_IN_MAIN
 __global__ void delta_apply_kernel(f64* theta, f64* sync, const f64* __restrict__ delta, uint32_t* nz, i32* nz_epoch, i64 M,
                                    uint32_t* nzx, uint32_t* nzc, int cshift, uint32_t* nzd, const uint32_t* nzd_terms) {
     i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2132,6 +2196,7 @@ __global__ void delta_apply_kernel(f64* theta, f64* sync, const f64* __restrict_
         }
     }
 }
+#endif
 // ---- sparse weight exchange (shared theta on the fast path) ---------------------------------------------------------------
 // The exact written-weights map theta_nzx (one bit per weight, 2.5 MB at M = 20 M) enumerates every weight a step of this
 // rank has touched or is about to: a few hundred thousand of 20 M.  The ranks all-gather their maps; the UNION, in index
@@ -2140,6 +2205,7 @@ __global__ void delta_apply_kernel(f64* theta, f64* sync, const f64* __restrict_
 // weight whose delta is non-zero on some rank has its bit set there, so the sum equals the dense exchange's term by term.
 #define LOB_SPX_BLOCK 256
 // union of the gathered maps + set bits per block
+#if LOB_IN_MAIN
 __global__ void __launch_bounds__(LOB_SPX_BLOCK) sparse_union_kernel(const uint32_t* __restrict__ gathered, int world, i64 words, uint32_t* u_map, i32* block_cnt) {
     __shared__ i32 red[LOB_SPX_BLOCK / 64];
     const i64 w = (i64)blockIdx.x * LOB_SPX_BLOCK + threadIdx.x;
@@ -2158,7 +2224,9 @@ __global__ void __launch_bounds__(LOB_SPX_BLOCK) sparse_union_kernel(const uint3
         block_cnt[blockIdx.x] = t;
     }
 }
+#endif
 // exclusive scan of the block counts (one block; a few thousand entries) + the total
+#if LOB_IN_MAIN
 __global__ void __launch_bounds__(1024) sparse_scan_kernel(const i32* __restrict__ block_cnt, int n_blocks, i64* block_off, i64* total) {
     __shared__ i64 part[1024];
     const int per = (n_blocks + 1023) / 1024;
@@ -2176,6 +2244,7 @@ __global__ void __launch_bounds__(1024) sparse_scan_kernel(const i32* __restrict
     i64 run = part[threadIdx.x];
     for (int i = lo; i < hi; i++) { block_off[i] = run; run += block_cnt[i]; }
 }
+#endif
 // position of a word's first set bit in the compact vector: block offset + exclusive prefix of the popcounts inside the block
 __device__ inline i64 sparse_word_base(uint32_t u, const i64* block_off, i32* lds) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -2191,6 +2260,7 @@ __device__ inline i64 sparse_word_base(uint32_t u, const i64* block_off, i32* ld
     for (int i = 0; i < wv; i++) before += lds[i];
     return block_off[blockIdx.x] + before + incl - c;
 }
+#if LOB_IN_MAIN
 __global__ void __launch_bounds__(LOB_SPX_BLOCK) sparse_pack_kernel(const uint32_t* __restrict__ u_map, i64 words, const i64* __restrict__ block_off,
                                                                     const f64* __restrict__ theta, const f64* __restrict__ sync, f64* buf) {
     __shared__ i32 lds[LOB_SPX_BLOCK / 64];
@@ -2203,8 +2273,10 @@ __global__ void __launch_bounds__(LOB_SPX_BLOCK) sparse_pack_kernel(const uint32
         buf[p++] = theta[f] - sync[f];
     }
 }
+#endif
 // theta = theta_sync + sum(delta), theta_sync = theta for the weights of the union; the maps take the union's bits (a set bit
 // only means "fetch the weight": a weight another rank marked but has not written yet reads as +0.0)
+#if LOB_IN_MAIN
 __global__ void __launch_bounds__(LOB_SPX_BLOCK) sparse_apply_kernel(const uint32_t* __restrict__ u_map, i64 words, const i64* __restrict__ block_off,
                                                                      f64* theta, f64* sync, const f64* __restrict__ buf, uint32_t* nz, i32* nz_epoch,
                                                                      uint32_t* nzx, uint32_t* nzc, int cshift, uint32_t* nzd, const uint32_t* nzd_terms, i64 M) {
@@ -2241,7 +2313,9 @@ __global__ void __launch_bounds__(LOB_SPX_BLOCK) sparse_apply_kernel(const uint3
         if ((nz[LOB_NZ_WORD(f0)] & nzm) != nzm) atomicOr(&nz[LOB_NZ_WORD(f0)], nzm);
     }
 }
+#endif
 // the fast path's maps after lob_theta_set (both cleared by the caller first): bit = (theta != +0.0 bitwise)
+#if LOB_IN_MAIN
 __global__ void rebuild_nzx_kernel(const f64* __restrict__ theta, uint32_t* nzx, uint32_t* nzc, int cshift, i64 M) {
     i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     const i64 stride = (i64)gridDim.x * blockDim.x;
@@ -2253,7 +2327,9 @@ __global__ void rebuild_nzx_kernel(const f64* __restrict__ theta, uint32_t* nzx,
         }
     }
 }
+#endif
 // ... and the map folded over the actions from the exact one (gather form: no atomics; monotone like the exact map)
+#if LOB_IN_MAIN
 __global__ void rebuild_nzd_kernel(const uint32_t* __restrict__ nzx, uint32_t* nzd, const uint32_t* __restrict__ terms18, i64 M) {
     const i64 words = M / 32 + 1;
     uint32_t t[18];
@@ -2279,7 +2355,9 @@ __global__ void rebuild_nzd_kernel(const uint32_t* __restrict__ nzx, uint32_t* n
         if (out2 & ~nzd[words + w]) nzd[words + w] |= out2;
     }
 }
+#endif
 // rebuild the bitmap after lob_theta_set: bit = (theta != +0.0 bitwise)
+#if LOB_IN_MAIN
 __global__ void rebuild_nz_kernel(const f64* __restrict__ theta, uint32_t* nz, i32* nz_epoch, i64 M) {
     i64 wi = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (wi == 0) atomicAdd(nz_epoch, 1);
@@ -2294,8 +2372,10 @@ __global__ void rebuild_nz_kernel(const f64* __restrict__ theta, uint32_t* nz, i
         nz[wi] = m;
     }
 }
+#endif
 
 // ---- parity dump -------------------------------------------------------------
+#if LOB_IN_ENV
 __global__ void dump_kernel(const DevParams* __restrict__ Pp, DevState S, int first, int n, lob_book_dump* out) {
     const DevParams& P = *Pp;  // parameters read through the scalar cache, never copied to scratch
     __shared__ TickLds tick_lds;
@@ -2360,9 +2440,9 @@ __global__ void dump_kernel(const DevParams* __restrict__ Pp, DevState S, int fi
     d.terminal = e.done == 2 ? 2 : (is_open(P, e.time_ms) ? 0 : 1);
     d.total_ticks = e.total_ticks;
     d.market_buys = e.market_buys; d.market_sells = e.market_sells;
-    d.ticks_with_ask = (i32)(e.tick_ab & 0x1fffff); d.ticks_with_bid = (i32)((e.tick_ab >> 21) & 0x1fffff); d.ticks_with_both = (i32)((e.tick_ab >> 42) & 0x1fffff);
+    d.ticks_with_ask = (i32)(uint32_t)e.tick_ab; d.ticks_with_bid = (i32)(uint32_t)(e.tick_ab >> 32); d.ticks_with_both = e.tick_both;
     d.ask_transactions = (i32)(uint32_t)e.ntr_snap; d.bid_transactions = (i32)(uint32_t)(e.ntr_snap >> 32);
-    d.ticks_with_position = (i32)(e.tick_pos & 0x1fffff); d.ticks_long = (i32)((e.tick_pos >> 21) & 0x1fffff); d.ticks_short = (i32)((e.tick_pos >> 42) & 0x1fffff);
+    d.ticks_long = (i32)(uint32_t)e.tick_pos; d.ticks_short = (i32)(uint32_t)(e.tick_pos >> 32); d.ticks_with_position = d.ticks_long + d.ticks_short;
     int n_tr = 0;
     {
         const int ng = S.hdr[b].tr_n, head = S.hdr[b].tr_head;
@@ -2374,11 +2454,13 @@ __global__ void dump_kernel(const DevParams* __restrict__ Pp, DevState S, int fi
     d.n_traces = n_tr;
     out[t] = d;
 }
+#endif
 
 // Diagnostics of the fast path (lob_debug_fastpath; not on the step): how many weights the exact written-weights map shows,
 // and the distribution of the live books' hit-list lengths.  out: [0] written weights, [1] live books, [2] live books without a
 // list, [3] sum of the lengths, [4 + n] books whose list has n entries (n = LOB_FP_BINS - 1: that many or more).
 #define LOB_FP_BINS 257
+#if LOB_IN_MAIN
 __global__ void fastpath_stats_kernel(DevState S, i64 M, int have_lists, i64* out) {
     __shared__ i32 hist[LOB_FP_BINS];
     __shared__ i32 s_none, s_live;
@@ -2407,5 +2489,6 @@ __global__ void fastpath_stats_kernel(DevState S, i64 M, int have_lists, i64* ou
         atomicAdd((u64*)&out[2], (u64)s_none); atomicAdd((u64*)&out[3], (u64)s_sum);
     }
 }
+#endif
 
 #endif

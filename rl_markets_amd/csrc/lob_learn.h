@@ -445,7 +445,7 @@ __host__ __device__ inline void mt64_seed(u64* x, u64 seed) {
     x[0] = seed;
     for (int i = 1; i < LOB_MT_N; i++) x[i] = 6364136223846793005ull * (x[i - 1] ^ (x[i - 1] >> 62)) + (u64)i;
 }
-__device__ inline u64 mt64_mix(u64 xi, u64 xi1, u64 xm) {
+__host__ __device__ inline u64 mt64_mix(u64 xi, u64 xi1, u64 xm) {
     const u64 y = (xi & 0xFFFFFFFF80000000ull) | (xi1 & 0x7FFFFFFFull);
     return xm ^ (y >> 1) ^ ((y & 1ull) ? 0xB5026F5AA96619E9ull : 0ull);
 }
@@ -492,7 +492,7 @@ __device__ inline void mt64_twist_wave(u64* gstate, u64* lds, int lane) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local");
     __builtin_amdgcn_wave_barrier();
 }
-__device__ inline u64 mt64_temper(u64 z) {
+__host__ __device__ inline u64 mt64_temper(u64 z) {
     z ^= (z >> 29) & 0x5555555555555555ull;
     z ^= (z << 17) & 0x71D67FFFEDA60000ull;
     z ^= (z << 37) & 0xFFF7EEE000000000ull;
@@ -501,7 +501,7 @@ __device__ inline u64 mt64_temper(u64 z) {
 }
 // std::uniform_real_distribution<double>(0,1)(mt19937_64) in libstdc++ =
 // generate_canonical<double,53>: one draw, double(u) / 2^64, clamped below 1.
-__device__ inline f64 mt64_canonical(u64 u) {
+__host__ __device__ inline f64 mt64_canonical(u64 u) {
     f64 r = (f64)u * 5.421010862427522e-20;  // 2^-64
     if (r >= 1.0) r = 0.99999999999999989;   // nextafter(1.0, 0.0)
     return r;

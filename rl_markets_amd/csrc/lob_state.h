@@ -65,9 +65,10 @@ typedef float f32;
     X(i32, total_ticks)                                                                                        \
     X(i32, market_buys)                                                                                        \
     X(i32, market_sells)                                                                                       \
-    /* TickStatistics (Base::UpdateStats, base.cpp:412-442), three 21-bit counters per word: with_ask | with_bid << 21 |         \
-     * with_both << 42, and with_position | long << 21 | short << 42 (an episode has < 2^21 steps) */                          \
-    X(i64, tick_ab) X(i64, tick_pos)                                                                                           \
+    /* TickStatistics (Base::UpdateStats, base.cpp:412-442): plain 32-bit counters like the reference's ints, two per word --    \
+     * with_ask | with_bid << 32 and long << 0 | short << 32 (with_position = long + short) -- and with_both in the 4 bytes the   \
+     * three ints above leave before the next 8-byte field (a step consumes at least one event, n_events < 2^31) */              \
+    X(i32, tick_both) X(i64, tick_ab) X(i64, tick_pos)                                                                         \
     /* TradeStatistics::ask_transactions | bid_transactions << 32: a_ntr / b_ntr as Base::UpdateStats copies them at decision     \
      * time (base.cpp:415-416), before the step's events */                                                                   \
     X(i64, ntr_snap)                                                                                                          \

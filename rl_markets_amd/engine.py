@@ -172,6 +172,10 @@ class Engine:
     def td_step_end(self):
         self._check(self.lib.lob_td_step_end(self.h))
 
+    def td_split_supported(self):
+        """Whether td_step_begin / td_step_end are available with this engine configuration (lob_td_split_supported)."""
+        return bool(self.lib.lob_td_split_supported(self.h))
+
     def eval_step(self, n=1):
         self._check(self.lib.lob_eval_step(self.h, n))
 
@@ -255,11 +259,12 @@ class Engine:
 
     def flow_stats(self):
         """lob_debug_flow (a diagnostic export, not in include/lob_engine.h): learner steps by the shape of their combined update."""
-        c = np.zeros(4, np.int64)
+        c = np.zeros(8, np.int64)
         fn = self.lib.lob_debug_flow
         fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_void_p]
         self._check(fn(self.h, _ptr(c)))
-        return {"added_in_place": int(c[0]), "rest_on_side_stream": int(c[1]), "block_sums": int(c[2]), "every_book": int(c[3])}
+        return {"added_in_place": int(c[0]), "rest_on_side_stream": int(c[1]), "block_sums": int(c[2]), "every_book": int(c[3]),
+                "act_inline_general": int(c[4]), "act_work_list_dense": int(c[5]), "act_work_list_other": int(c[6])}
 
     def fastpath_stats(self):
         """lob_debug_fastpath (a diagnostic export, not in include/lob_engine.h): written weights and the live books' hit-list lengths."""

@@ -114,6 +114,15 @@ public:
     double num(const std::string& k, double d) const { return kv_.count(k) ? std::stod(kv_.at(k)) : d; }
     long integer(const std::string& k) const { return std::stol(str(k)); }
     long integer(const std::string& k, long d) const { return kv_.count(k) ? std::stol(kv_.at(k)) : d; }
+    // YAML 1.1 booleans as yaml-cpp's as<bool>() takes them (y / yes / true / on, n / no / false / off, any case)
+    bool boolean(const std::string& k, bool d) const {
+        if (!kv_.count(k)) return d;
+        std::string v = kv_.at(k);
+        for (auto& ch : v) ch = (char)tolower((unsigned char)ch);
+        if (v == "y" || v == "yes" || v == "true" || v == "on") return true;
+        if (v == "n" || v == "no" || v == "false" || v == "off") return false;
+        throw std::runtime_error("[Config] not a boolean: " + k + ": " + kv_.at(k));
+    }
     const std::vector<std::string>& list(const std::string& k) const {
         auto it = seq_.find(k);
         if (it == seq_.end()) throw std::runtime_error("[Config] missing sequence " + k);
@@ -203,6 +212,7 @@ public:
         else throw std::invalid_argument("Unknown learning algorithm: " + algo);  // as src/main.cpp:187-188
         if (p.algo >= LOB_ALGO_R_LEARN) p.beta = num("learning.beta");  // (required, as c["learning"]["beta"].as<double>())
         p.seed = (uint64_t)integer("debug.random_seed", 1994);
+        p.random_init = boolean("learning.random_init", false) ? 1 : 0;  // agent.cpp:37-39: theta (and theta_b) = 2u - 1 from the agent's generator
         return p;
     }
 };
@@ -406,7 +416,6 @@ class Learner : public Runner {
     lob_comm* comm_ = nullptr;  // multi-GPU: the shared Agent* of main.cpp:196-206 becomes a periodic all-reduce
     int sync_every_ = 64;
     unsigned long since_sync_ = 0;
-    bool split_ok_ = true;  // lob_td_step_begin / _end available (not with LOB_GROUPS=2)
 
 protected:
     bool _step(Agent*) override {
@@ -419,15 +428,14 @@ protected:
             // the sync step carries the exchange between its two halves: no cached action-selection data is live there
             // (include/lob_engine.h lob_td_step_begin)
             if (n > 1) check(lob_td_step(environment.handle(), n - 1), "Learner::_step");
-            const int rc_begin = split_ok_ ? lob_td_step_begin(environment.handle()) : LOB_ESTATE;
-            if (rc_begin == LOB_ESTATE) {
-                // no half steps with this engine configuration (two book groups): the whole step, then the exchange -- correct
-                // too, the exchange then voids the cached action-selection data of one step
-                split_ok_ = false;
+            if (!lob_td_split_supported(environment.handle())) {
+                // no half steps with this engine configuration (an experiments build with two book groups): the whole step, then
+                // the exchange -- correct too, the exchange then voids the cached action-selection data of one step.  Asked for
+                // explicitly: a LOB_ESTATE from lob_td_step_begin has other causes and is reported as the error it is.
                 check(lob_td_step(environment.handle(), 1), "Learner::_step");
                 check(lob_theta_allreduce(environment.handle(), comm_), "Learner::_step (weight exchange)");
             } else {
-                check(rc_begin, "Learner::_step");
+                check(lob_td_step_begin(environment.handle()), "Learner::_step");
                 check(lob_theta_allreduce(environment.handle(), comm_), "Learner::_step (weight exchange)");
                 check(lob_td_step_end(environment.handle()), "Learner::_step");
             }

@@ -3,7 +3,7 @@
 // n episodes on synthetic streams, evaluate greedily, print the per-episode
 // rows of the reference's training_log (serial.cpp:81-88) for book 0.
 //
-//   lob_run -c config/engine.yaml [-n books] [-e episodes] [-a sarsa|q_learn|double_q_learn|r_learn|online_r_learn|double_r_learn] [--events N] [--depth D]
+//   lob_run -c config/engine.yaml [-n books] [-e episodes (default: training.n_episodes)] [-a sarsa|q_learn|double_q_learn|r_learn|online_r_learn|double_r_learn] [--events N] [--depth D]
 //           [--theta out.bin] [--profit-log profit_log.csv]
 //           [--gpus N [--sync-every K]]   one process per GPU (forked here), -n books EACH, book ids rank * n ..,
 //            delta-theta all-reduced over RCCL/xGMI every K steps (include/lob_comm.h): the stand-in for the
@@ -75,7 +75,7 @@ int main(int argc, char** argv) {
 static int run(int argc, char** argv, int rank, int world, const std::string& rdzv) {
     std::string cfg_path, algo, theta_out, profit_log, stats_out, md, tas, lob_ob, lob_msg;
     int lob_levels = 0;
-    int books = 1, episodes = 1, events = 2112, depth = 5, sync_every = 64;
+    int books = 1, episodes = -1, events = 2112, depth = 5, sync_every = 64;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto next = [&]() { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(1); } return std::string(argv[++i]); };
@@ -101,6 +101,9 @@ static int run(int argc, char** argv, int rank, int world, const std::string& rd
         if (!algo.empty()) c.set("learning.algorithm", algo);  // CLI override, main.cpp:342-347
         std::string ticker = c.has("data.symbols") ? c.list("data.symbols").at(0) : "HSBA.L";
         lob_params p = c.to_params(ticker, depth, 2);
+        // training.n_episodes (src/main.cpp:91 reads it into n_train_episodes -- a required key there too --, train() runs until that
+        // many episodes are done, main.cpp:53-77); -e overrides it (the reference has no such flag: its tests edit the yaml)
+        if (episodes < 0) episodes = (int)c.integer("training.n_episodes");
         p.book_id_offset = (uint64_t)rank * (uint64_t)books;  // global book ids: streams and RNG draws do not depend on the sharding
         lob::BatchedIntraday env(p, books, rank);
         lob_comm* comm = nullptr;

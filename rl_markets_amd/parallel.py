@@ -36,7 +36,10 @@ class ShardedLearner:
         self.sync_every = int(sync_every)
         self.steps = 0
         self.n_syncs = 0
-        self._split_ok = True
+        # half steps (the exchange inside the sync step): asked of the backend explicitly -- a LOB_ESTATE from td_step_begin has
+        # other causes (no reset, a half step left open) and must surface as the error it is
+        q = getattr(backend, "td_split_supported", None)
+        self._split_ok = hasattr(backend, "td_step_begin") and (q() if q is not None else True)
         if self.comm is not None:
             backend.delta_init()
 
@@ -61,20 +64,12 @@ class ShardedLearner:
             if sync_now and split and self._split_ok:
                 if chunk > 1:
                     self.backend.td_step(chunk - 1)
-                try:
-                    self.backend.td_step_begin()
-                except Exception as ex:
-                    if getattr(ex, "code", None) != -4:   # LOB_ESTATE: no half steps with this engine configuration (LOB_GROUPS=2)
-                        raise
-                    # ... then the whole step followed by the exchange, as before the split existed: correct too, the exchange
-                    # voids the cached action-selection data of one step
-                    self._split_ok = False
-                    self.backend.td_step(1)
-                    self.sync_weights()
-                else:
-                    self.sync_weights()
-                    self.backend.td_step_end()
+                self.backend.td_step_begin()
+                self.sync_weights()
+                self.backend.td_step_end()
             else:
+                # (no half steps with this backend / engine configuration: the whole step followed by the exchange, as before the
+                # split existed -- correct too, the exchange then voids the cached action-selection data of one step)
                 self.backend.td_step(chunk)
                 if sync_now:
                     self.sync_weights()
@@ -96,6 +91,9 @@ class EngineBackend:
 
     def td_step_end(self):
         self.eng.td_step_end()
+
+    def td_split_supported(self):
+        return self.eng.td_split_supported()
 
     def delta_init(self):
         self.eng.delta_init()

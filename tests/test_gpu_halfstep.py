@@ -59,16 +59,19 @@ def test_reset_abandons_a_half_done_step():
     orc.close()
 
 
-def test_an_episode_longer_than_the_tick_counters_is_refused():
-    """The TickStatistics counters are 21-bit fields (lob_state.h tick_ab / tick_pos): a stream of 2^21 events or more is
-    refused when it is loaded -- before anything is allocated -- and the stream in place stays usable."""
-    p, rec, eng = _make(B=8)
+def test_a_stream_of_more_than_two_million_events_is_accepted():
+    """The TickStatistics counters are plain 32-bit counters like the reference's ints (lob_state.h tick_ab / tick_pos /
+    tick_both; round 4 packed them in 21-bit fields and refused streams of 2^21 events: a 2-6 M-row LOBSTER day):
+    a stream of 2^21 + 7 events per book loads (the track is a ring for such a stream), resets and steps, and the counters add up."""
+    p, rec, eng = _make(B=2)
     g = engine.default_gen_params()
-    g.n_events = 1 << 21
-    with pytest.raises(engine.LobError) as ei:
-        eng.gen_events(g)
-    assert ei.value.code == abi.LOB_EINVAL and "2^21" in str(ei.value)
+    g.n_events = (1 << 21) + 7
+    eng.gen_events(g)
     eng.reset()
-    eng.td_step(5)             # (the 300-event stream loaded before is still there)
-    assert eng.get_books(0, 1)[0].total_ticks == 5
+    eng.td_step(40)
+    for d in eng.get_books(0, 2):
+        assert d.total_ticks == 40
+        assert d.ticks_with_position == d.ticks_long + d.ticks_short <= 40
+        assert max(d.ticks_with_ask, d.ticks_with_bid) <= 40 and d.ticks_with_both <= min(d.ticks_with_ask, d.ticks_with_bid)
+        assert d.ticks_with_ask + d.ticks_with_bid - d.ticks_with_both <= 40
     eng.close()

@@ -37,7 +37,7 @@ def _params(first, algo):
 def _worker(out_dir, algo):
     """One rank: RANK / LOCAL_RANK / WORLD_SIZE / LOB_RDZV from spawn_ranks."""
     sys.path.insert(0, ROOT)
-    from rl_markets_amd import engine, launch
+    from rl_markets_amd import abi, engine, launch
     from rl_markets_amd.comm import RcclComm
     from rl_markets_amd.parallel import EngineBackend, ShardedLearner
     rank, local_rank, world = launch.rank_env()
@@ -52,6 +52,8 @@ def _worker(out_dir, algo):
     eng.sync()
     st = comm.exchange_stats()
     np.save(os.path.join(out_dir, "theta_%d.npy" % rank), eng.theta())
+    if int(algo) == abi.ALGO_DOUBLE_Q:
+        np.save(os.path.join(out_dir, "theta_b_%d.npy" % rank), eng.theta(1))
     json.dump({"stats": st, "counters": [int(v) for v in eng.counters()], "n_syncs": sl.n_syncs}, open(os.path.join(out_dir, "info_%d.json" % rank), "w"))
     comm.barrier()
     comm.close()
@@ -70,7 +72,10 @@ def _oracle_schedule(world, algo):
         o = ol.Oracle(p, rec)
         o.reset()
         shards.append(o)
+    from rl_markets_amd import abi
+    double = algo == abi.ALGO_DOUBLE_Q   # DoubleAgent::theta_b (src/rl/agent.cpp:185-264) travels with theta: [theta | theta_b] in one exchange
     sync = np.zeros_like(shards[0].theta(0))
+    sync_b = np.zeros_like(sync)
     done = 0
     while done < STEPS:
         chunk = min(SYNC - done % SYNC, STEPS - done)
@@ -85,6 +90,11 @@ def _oracle_schedule(world, algo):
             for o in shards:
                 o.theta(0)[:] = sync + total
             sync = shards[0].theta(0).copy()
+            if double:
+                total_b = sum(o.theta_b(0) - sync_b for o in shards)
+                for o in shards:
+                    o.theta_b(0)[:] = sync_b + total_b
+                sync_b = shards[0].theta_b(0).copy()
             for o in shards:
                 o.td_step_end()
     return shards
@@ -106,16 +116,22 @@ def _run(tmp_path, world, algo, extra_env=None):
         th = np.load(tmp_path / ("theta_%d.npy" % r))
         assert np.count_nonzero(th) > 1000
         np.testing.assert_allclose(th, shards[r].theta(0), rtol=1e-9, atol=1e-12)
+        if os.path.exists(tmp_path / ("theta_b_%d.npy" % r)):
+            thb = np.load(tmp_path / ("theta_b_%d.npy" % r))
+            assert np.count_nonzero(thb) > 500
+            np.testing.assert_allclose(thb, shards[r].theta_b(0), rtol=1e-9, atol=1e-12)
     for o in shards:
         o.close()
     return [json.load(open(tmp_path / ("info_%d.json" % r))) for r in range(world)]
 
 
-@pytest.mark.parametrize("exchange", ["sparse", "dense"])
-def test_one_rank_through_the_multi_rank_harness(tmp_path, exchange):
-    """The harness itself, on any box with a GPU: one rank, a one-rank RCCL communicator, the whole exchange path."""
+@pytest.mark.parametrize("exchange,algo_name", [("sparse", "q_lambda"), ("dense", "q_lambda"), ("dense", "double_q")])
+def test_one_rank_through_the_multi_rank_harness(tmp_path, exchange, algo_name):
+    """The harness itself, on any box with a GPU: one rank, a one-rank RCCL communicator, the whole exchange path -- double Q
+    (two weight vectors in one exchange, always dense) included, against the oracle schedule's theta AND theta_b."""
     from rl_markets_amd import abi
-    info = _run(tmp_path, 1, abi.ALGO_QLAMBDA, {"LOB_DENSE_EXCHANGE": "1"} if exchange == "dense" else None)
+    algo = {"q_lambda": abi.ALGO_QLAMBDA, "double_q": abi.ALGO_DOUBLE_Q}[algo_name]
+    info = _run(tmp_path, 1, algo, {"LOB_DENSE_EXCHANGE": "1"} if exchange == "dense" else None)
     assert info[0]["stats"]["sparse"] == (0 if exchange == "dense" else STEPS // SYNC)
 
 
@@ -128,10 +144,10 @@ def test_two_ranks_over_rccl(tmp_path, exchange, algo_name):
     if gpu_count() < 2:
         pytest.skip("needs two visible GPUs")
     algo = {"q_lambda": abi.ALGO_QLAMBDA, "sarsa": abi.ALGO_SARSA, "double_q": abi.ALGO_DOUBLE_Q}[algo_name]
-    if algo == abi.ALGO_DOUBLE_Q:
-        pytest.skip("(the oracle schedule above sums theta only: double Q's second vector is covered on one device, tests/test_gpu_delta_exchange.py)")
+    # (double Q carries two vectors and has no sparse form: the ranks agree on the dense exchange by themselves, lob_comm.cpp)
+    dense = exchange == "dense" or algo == abi.ALGO_DOUBLE_Q
     info = _run(tmp_path, 2, algo, {"LOB_DENSE_EXCHANGE": "1"} if exchange == "dense" else None)
-    assert info[0]["stats"]["sparse"] == (0 if exchange == "dense" else STEPS // SYNC)
+    assert info[0]["stats"]["sparse"] == (0 if dense else STEPS // SYNC)
     assert info[0]["stats"]["bytes_per_exchange"] == info[1]["stats"]["bytes_per_exchange"] > 0
 
 

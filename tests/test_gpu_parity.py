@@ -3,6 +3,8 @@
 tests/test_oracle_vs_reference.py and tests/golden/).  Bit-exact for book /
 order / state / reward / RNG; learned weights bit-exact for private theta and
 within 1e-9 relative for shared theta (f64 atomic ordering)."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -31,9 +33,17 @@ def make(depth=5, trades=2, n_events=500, B=4, algo=abi.ALGO_SARSA, theta_mode=a
     return p, g, rec, eng, orc
 
 
+def experiments_build():
+    """-DLOB_EXPERIMENTS (tools/exp_variants.sh; LOB_ENGINE_LIB points the tests at that library): the kernel variants measured and
+    lost exist -- a product build ignores their switches, so their parity tests would only repeat the product kernels'."""
+    fn = abi.load().lob_experiments_enabled
+    fn.restype, fn.argtypes = C.c_int, []
+    return fn() == 1
+
+
 def test_no_cpu_fallback_symbols():
     lib = abi.load()
-    assert lib.lob_abi_version() == 5
+    assert lib.lob_abi_version() == 6
 
 
 def test_features_match_oracle():
@@ -149,6 +159,54 @@ def test_td_shared_theta(algo):
     th, oth = eng.theta(), orc.theta()
     assert np.array_equal(th != 0, oth != 0)
     np.testing.assert_allclose(th, oth, rtol=1e-9, atol=1e-12)  # north-star tolerance: 1e-5 relative
+
+
+@pytest.mark.parametrize("algo", [abi.ALGO_SARSA, abi.ALGO_QLAMBDA, abi.ALGO_DOUBLE_Q, abi.ALGO_DOUBLE_R_LEARN])
+@pytest.mark.parametrize("theta_mode,first_book", [(abi.THETA_PRIVATE, 100), (abi.THETA_SHARED, 0), (abi.THETA_SHARED, 7)])
+def test_random_init_weights(algo, theta_mode, first_book):
+    """learning.random_init: true (src/rl/agent.cpp:37-39; DoubleAgent, agent.cpp:190-192): theta -- then theta_b -- filled with
+    2u - 1 from the agent's own std::mt19937_64, which goes on to toss the double agents' coin from where the fill left it.  The
+    oracle does this with libstdc++'s generator and distribution exactly as the reference does (pinned against the reference
+    itself by tests/test_oracle_ref_sweep.py); the engine draws the same numbers with its own restatement of the generator
+    (lob_engine.hip theta_random_init).  Private theta: every book's agent its own vectors, bit for bit, coin included.  Shared
+    theta: the vector of global book 0's agent on every shard (first_book 7: the same weights as first_book 0, and no book of the
+    shard has spent draws on them)."""
+    B = 6 if theta_mode == abi.THETA_PRIVATE else 48
+    p, g, rec, eng, orc = make(n_events=300, B=B, algo=algo, theta_mode=theta_mode, mem=1 << 14, first_book=first_book, seed=(1 << 33) + 77,
+                               random_init=1, beta=0.01)
+    nt = B if theta_mode == abi.THETA_PRIVATE else 1
+    double = algo in (abi.ALGO_DOUBLE_Q, abi.ALGO_DOUBLE_R_LEARN)
+    for t in range(nt):
+        th = eng.theta(t)
+        np.testing.assert_array_equal(th, orc.theta(t))
+        assert th.min() >= -1.0 and th.max() < 1.0 and abs(th.mean()) < 0.05 and np.count_nonzero(th) >= th.size - 2
+        if double:
+            np.testing.assert_array_equal(eng.theta(nt + t), orc.theta_b(t))
+            assert not np.array_equal(eng.theta(nt + t), th)
+    if theta_mode == abi.THETA_SHARED and first_book:
+        p0 = engine.default_params()
+        for f, _ in abi.Params._fields_:
+            setattr(p0, f, getattr(p, f))
+        p0.book_id_offset = 0
+        e0 = engine.Engine(p0, 2)
+        np.testing.assert_array_equal(e0.theta(), eng.theta())       # every shard starts from the same vector
+        e0.close()
+    eng.reset()
+    orc.reset()
+    exact = theta_mode == abi.THETA_PRIVATE
+    for step in range(40):
+        eng.td_step(1)
+        orc.td_step(1)
+        compare_learner_step(eng, orc, "random_init algo %d step %d" % (algo, step), exact=exact, rtol=1e-9)
+    for t in range(nt):
+        if exact:
+            np.testing.assert_array_equal(eng.theta(t), orc.theta(t))
+        else:
+            np.testing.assert_allclose(eng.theta(t), orc.theta(t), rtol=1e-9, atol=1e-12)
+        if double:
+            np.testing.assert_allclose(eng.theta(nt + t), orc.theta_b(t), rtol=0 if exact else 1e-9, atol=0 if exact else 1e-12)
+    eng.close()
+    orc.close()
 
 
 def test_eval_step_greedy():
@@ -492,6 +550,8 @@ def test_books_per_wave_and_group_choices(monkeypatch, env_lanes, reset_lanes, g
     reset_kernel<16|32|64>)
     and both step pipelines (one group / two groups on two streams) against the oracle on 10-level
     books: the launch shape must not show in the results.  (lob_create reads the switches.)"""
+    if (env_lanes in (32, 256) or reset_lanes in (16, 32) or groups == 2) and not experiments_build():
+        pytest.skip("a kernel variant measured and lost: compiled with -DLOB_EXPERIMENTS only (tools/exp_variants.sh)")
     monkeypatch.setenv("LOB_ENV_LANES", str(env_lanes))
     monkeypatch.setenv("LOB_RESET_LANES", str(reset_lanes))
     monkeypatch.setenv("LOB_GROUPS", str(groups))
@@ -521,6 +581,8 @@ def test_prepass_on_two_waves_per_64_books(monkeypatch):
     (reset2_kernel / prepass_extend2_kernel, lob_env.h prepass_run2 -- opt-in: measured slower than one wave).  Same track, same
     windows: engine against the oracle through two episodes, and through a stream longer than the track ring (the resumed
     pre-pass)."""
+    if not experiments_build():
+        pytest.skip("a kernel variant measured and lost: compiled with -DLOB_EXPERIMENTS only (tools/exp_variants.sh)")
     monkeypatch.setenv("LOB_PREPASS_ROLES", "1")
     B = 1100
     p, g, rec, eng, orc = make(depth=10, n_events=150, B=B, algo=abi.ALGO_QLAMBDA, theta_mode=abi.THETA_SHARED, mem=1 << 20)

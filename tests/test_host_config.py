@@ -22,10 +22,10 @@ int main(int argc, char** argv) {
         lob::Config c(argv[1]);
         for (int i = 2; i + 1 < argc; i += 2) c.set(argv[i], argv[i + 1]);
         lob_params p = c.to_params("HSBA.L");
-        std::printf("%d %d %.17g %.17g %.17g %.17g %.17g %d %.17g %d %d %lld %d %d %d %d %d %d %d\n", (int)p.algo, (int)p.policy, p.beta, p.epsilon,
+        std::printf("%d %d %.17g %.17g %.17g %.17g %.17g %d %.17g %d %d %lld %d %d %d %d %d %d %d %d\n", (int)p.algo, (int)p.policy, p.beta, p.epsilon,
                     p.tau, p.gamma, p.alpha, (int)p.target_price, (double)p.group_weights[2], (int)p.n_tilings, (int)p.n_actions,
                     (long long)p.memory_size, (int)p.quote_mode, (int)p.market.n_bands, (int)p.lb_rsi, (int)p.lb_vwap,
-                    (int)p.lb_pnl, (int)p.lb_spread, (int)p.lb_target);
+                    (int)p.lb_pnl, (int)p.lb_spread, (int)p.lb_target, (int)p.random_init);
     } catch (const std::exception& e) {
         std::fprintf(stderr, "EXC %s\n", e.what());
         return 3;
@@ -59,7 +59,7 @@ def fields(out):
     return dict(algo=int(f[0]), policy=int(f[1]), beta=float(f[2]), epsilon=float(f[3]), tau=float(f[4]), gamma=float(f[5]),
                 alpha=float(f[6]), target_price=int(f[7]), gw2=float(f[8]), n_tilings=int(f[9]), n_actions=int(f[10]),
                 memory_size=int(f[11]), quote_mode=int(f[12]), n_bands=int(f[13]), lb_rsi=int(f[14]), lb_vwap=int(f[15]),
-                lb_pnl=int(f[16]), lb_spread=int(f[17]), lb_target=int(f[18]))
+                lb_pnl=int(f[16]), lb_spread=int(f[17]), lb_target=int(f[18]), random_init=int(f[19]))
 
 
 def test_engine_yaml_is_the_reference_example(probe):
@@ -96,6 +96,16 @@ def test_r_learning_requires_beta(probe, tmp_path):
     assert fields(probe(str(y), learning__algorithm="q_learn"))["algo"] == abi.ALGO_QLAMBDA
     out = probe(str(y), learning__algorithm="r_learn")
     assert out.returncode == 3 and "learning.beta" in out.stderr   # YAML::Node::as<double>() on a missing key throws
+
+
+def test_random_init_is_read_like_agent_cpp(probe):
+    """learning.random_init (src/rl/agent.cpp:37-39: c["learning"]["random_init"].as<bool>(false)): absent = false; yaml-cpp's
+    boolean spellings; anything else throws as YAML's bad conversion does."""
+    assert fields(probe())["random_init"] == 0
+    for v, want in (("true", 1), ("True", 1), ("yes", 1), ("on", 1), ("false", 0), ("no", 0), ("OFF", 0)):
+        assert fields(probe(learning__random_init=v))["random_init"] == want, v
+    out = probe(learning__random_init="maybe")
+    assert out.returncode == 3 and "learning.random_init" in out.stderr
 
 
 def test_policy_factory(probe):

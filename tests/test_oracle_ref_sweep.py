@@ -170,11 +170,20 @@ def test_random_configuration_against_the_reference(seed):
         # --theta_in does): every term of getQ's 96-term sums is live from the first step on
         th0 = None
         rt = np.random.default_rng(41000 + seed)
-        if rt.integers(0, 4) == 0 and p.memory_size <= (1 << 20):
+        kind = int(rt.integers(0, 8))
+        if kind < 2 and p.memory_size <= (1 << 20):
             th0 = rt.normal(0.0, float(rt.choice([1e-6, 1e-2, 10.0])), size=p.memory_size)
             th0[rt.integers(0, p.memory_size, size=p.memory_size // 8)] = 0.0
             x["theta_in"] = os.path.join(td, "theta_in.bin")
             th0.tofile(x["theta_in"])
+        elif kind == 2 and p.memory_size <= (1 << 20):
+            # ... and one in eight from learning.random_init: true -- the reference's own Agent / DoubleAgent constructors fill
+            # theta (and theta_b) with 2u - 1 from Agent::gen (src/rl/agent.cpp:37-39,190-192), which then tosses DoubleQLearn's coin
+            # (one agent per book = private theta: the agent that draws the vector is this book's own, seed + global book id;
+            # a SHARED vector is global book 0's agent's whatever the shard -- include/lob_engine.h lob_params::random_init)
+            x["random_init"] = 1
+            p.random_init = 1
+            p.theta_mode = abi.THETA_PRIVATE
         out = ref_or_failed_init(p, rec, "seed %d" % seed, trades=p.max_trades, algo=algo, mem=p.memory_size, seed=p.seed,
                                  rng_stream=p.book_id_offset, eps=p.epsilon, extra=x)
         if out is None:

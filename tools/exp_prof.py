@@ -15,8 +15,8 @@ lib = os.path.join(out_dir, "liblob_engine.so")
 os.makedirs(out_dir, exist_ok=True)
 srcs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".cpp", ".h"))]
 if not os.path.exists(lib) or any(os.path.getmtime(s) > os.path.getmtime(lib) for s in srcs):
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-                           "-Wno-unused-value", "-DLOB_PROF", "-o", lib, os.path.join(csrc, "lob_engine.hip"), os.path.join(csrc, "lob_host.cpp")])
+    import __graft_entry__ as ge
+    ge.build_engine(lib, ("-DLOB_PROF",), os.path.join(out_dir, "_obj"))
 if "--build-only" in sys.argv:
     sys.exit(0)
 

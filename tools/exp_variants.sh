@@ -7,10 +7,14 @@
 # BENCH_ARGS adds bench.py flags.  Every run is under `timeout`.
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 CS=rl_markets_amd/csrc
+# (the library's translation units compiled in parallel and linked: __graft_entry__.build_engine; the kernel variants measured
+# and lost -- env_compact_kernel, the two-wave pre-pass, 32-lane env_step_kernel, two book groups, LOB_REG_FORK, LOB_ACC_REPS > 8,
+# 16 / 32-lane reset kernels -- exist only with -DLOB_EXPERIMENTS:   tools/exp_variants.sh build "exp:-DLOB_EXPERIMENTS"
+# then LOB_ENGINE_LIB=$PWD/rl_markets_amd/csrc/_var/exp/liblob_engine.so python -m pytest tests -m gpu -k "books_per_wave or two_waves")
 build_one() {
   mkdir -p $CS/_var/$1
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -Wno-unused-value $2 \
-     -o $CS/_var/$1/liblob_engine.so $CS/lob_engine.hip $CS/lob_host.cpp 2>/dev/null
+  python -c "import sys, __graft_entry__ as g; g.build_engine(sys.argv[1], sys.argv[2].split(), sys.argv[3])" \
+     $PWD/$CS/_var/$1/liblob_engine.so "$2" $PWD/$CS/_var/$1/_obj 2>/dev/null
 }
 run_one() {
   echo -n "$1 "

@@ -12,9 +12,12 @@ if "--csv" in sys.argv:
     i = sys.argv.index("--csv")
     csv_path = sys.argv[i + 1]
     del sys.argv[i:i + 2]
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "--cuda-device-only", "-c",
-       "-Rpass-analysis=kernel-resource-usage", "-Wno-unused-value", "-o", "/dev/null", "lob_engine.hip"] + sys.argv[1:]
-out = subprocess.run(cmd, cwd=CSRC, stderr=subprocess.PIPE, stdout=subprocess.PIPE, text=True).stderr
+# (the library's four device translation units, rl_markets_amd/csrc/lob_launch.h, compiled side by side)
+units = ["lob_engine.hip", "lob_tu_env.hip", "lob_tu_prepass.hip", "lob_tu_learn.hip"]
+procs = [subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "--cuda-device-only", "-c",
+                           "-Rpass-analysis=kernel-resource-usage", "-Wno-unused-value", "-o", "/dev/null", u] + sys.argv[1:],
+                          cwd=CSRC, stderr=subprocess.PIPE, stdout=subprocess.PIPE, text=True) for u in units]
+out = "".join(pr.communicate()[1] for pr in procs)
 try:
     filt = subprocess.run(["c++filt"], input=out, stdout=subprocess.PIPE, text=True).stdout
 except FileNotFoundError:
@@ -40,7 +43,7 @@ for line in filt.splitlines():
                          cur.get("VGPRs Spill"), cur.get("ScratchSize [bytes/lane]"), cur.get("Occupancy [waves/SIMD]"), cur.get("LDS Size [bytes/block]")))
 if csv_path:
     with open(csv_path, "w") as fh:
-        fh.write("# hipcc --offload-arch=gfx950 -O3 -Rpass-analysis=kernel-resource-usage of rl_markets_amd/csrc/lob_engine.hip (tools/kernel_resources.py);"
+        fh.write("# hipcc --offload-arch=gfx950 -O3 -Rpass-analysis=kernel-resource-usage of the four translation units of rl_markets_amd/csrc (tools/kernel_resources.py);"
                  " occupancy = waves per SIMD the register / LDS budget allows; dynamic LDS (the fast learner kernels) is not included\n")
         fh.write("kernel,vgprs,agprs,sgprs,sgprs_spilled,vgprs_spilled,scratch_bytes_per_lane,occupancy_waves_per_simd,static_lds_bytes_per_block\n")
         for r in rows:
