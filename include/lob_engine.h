@@ -349,6 +349,15 @@ int lob_eval_step(lob_engine* e, int32_t n_steps);
 /* Agent::HandleTerminal (src/rl/agent.cpp:103-109): traces.decay(0). The
  * alpha / epsilon schedules are evaluated by the host adaptor. */
 int lob_handle_terminal(lob_engine* e);
+
+/* Replaces the `model_log` logger of Agent::HandleTransition (src/rl/agent.cpp:53-59,93-100: `_agg_delta += abs(delta)`, and
+ * every 1000 updates one row `_agg_delta / 1000`).  After lob_model_log_enable(e, 1) every learner step adds the stepped books'
+ * |delta| to a running aggregate on the device; once it holds 1000 updates or more, a row aggregate / count is written and
+ * both start again.  One book: the reference's rows exactly (the count reaches 1000 one update at a time).  A batch: a row
+ * per step once the batch has 1000 books, the mean |delta| of the step.  lob_model_log_read hands over the rows written since
+ * the last read (at most `cap`; `n_lost`, if not NULL: rows that did not fit the device ring of 8192 or `cap`). */
+int lob_model_log_enable(lob_engine* e, int32_t on);
+int lob_model_log_read(lob_engine* e, double* rows, int32_t cap, int32_t* n_rows, int64_t* n_lost);
 int lob_set_alpha(lob_engine* e, double alpha);
 int lob_set_epsilon(lob_engine* e, double epsilon);
 int lob_set_tau(lob_engine* e, double tau);

@@ -990,6 +990,9 @@ struct oracle_learner {
     std::vector<std::unique_ptr<Env>> env;
     std::vector<std::vector<double>> theta;    // 1 (shared) or B (private)
     std::vector<std::vector<double>> theta_b;  // DoubleAgent::theta_b (agent.cpp:188)
+    double ml_agg = 0.0;                        // Agent::_agg_delta / _update_counter and the rows handed to "model_log" (agent.cpp:93-100)
+    int64_t ml_cnt = 0;
+    std::vector<double> ml_rows;
     std::vector<std::mt19937_64> agent_gen;    // Agent::gen (agent.cpp:31): the DoubleQLearn coin
     std::vector<std::uniform_real_distribution<double>> agent_unif;
     std::vector<Traces> traces;
@@ -1359,6 +1362,22 @@ static int oracle_td_step_impl(oracle_learner* o, int32_t n_steps, int half) {
             o->have_from = true;
             continue;
         }
+        // model_log (Agent::HandleTransition, agent.cpp:93-100): _agg_delta += abs(delta); every 1000 updates a row _agg_delta /
+        // 1000 and both start again.  The batch adds a step's |delta| in book order and writes a row once the aggregate holds 1000
+        // updates or more (one book: the count reaches 1000 one update at a time -- the reference's rows exactly)
+        {
+            double s = 0.0;
+            int64_t n = 0;
+            for (int b = 0; b < o->B; b++)
+                if (has[b]) { s += std::fabs(o->recs[b].td); n++; }
+            o->ml_agg += s;
+            o->ml_cnt += n;
+            if (o->ml_cnt >= 1000) {
+                o->ml_rows.push_back(o->ml_agg / (double)o->ml_cnt);
+                o->ml_agg = 0.0;
+                o->ml_cnt = 0;
+            }
+        }
         // write phase: updateQ (agent.cpp:137-142) for every book, book order
         for (int b = 0; b < o->B; b++) {
             if (!has[b]) continue;
@@ -1397,6 +1416,12 @@ static int oracle_td_step_impl(oracle_learner* o, int32_t n_steps, int half) {
 }
 
 int oracle_td_step(oracle_learner* o, int32_t n_steps) { return oracle_td_step_impl(o, n_steps, 0); }
+// the model_log rows so far (never cleared)
+int32_t oracle_model_log(oracle_learner* o, double* rows, int32_t cap) {
+    const int32_t n = (int32_t)std::min<size_t>(o->ml_rows.size(), (size_t)cap);
+    for (int32_t i = 0; i < n; i++) rows[i] = o->ml_rows[i];
+    return (int32_t)o->ml_rows.size();
+}
 // One step in two halves (lob_td_step_begin / lob_td_step_end): whatever changes the weights in between (a multi-GPU
 // exchange) is seen by the second half's evaluations of the NEW state only.
 int oracle_td_step_begin(oracle_learner* o) { return oracle_td_step_impl(o, 1, 1); }

@@ -50,6 +50,8 @@ oracle_learner* oracle_create(const lob_params* p, int32_t n_books, const uint32
 void oracle_destroy(oracle_learner* o);
 int oracle_reset(oracle_learner* o);                       /* Runner::RunEpisode prologue */
 int oracle_td_step(oracle_learner* o, int32_t n_steps);    /* n x Learner::_step */
+/* the rows Agent::HandleTransition hands to its "model_log" logger (src/rl/agent.cpp:93-100), all of them so far; returns their number */
+int32_t oracle_model_log(oracle_learner* o, double* rows, int32_t cap);
 /* one step in two halves (lob_td_step_begin / _end): a change of the weights in between reaches only the new state's Q */
 int oracle_td_step_begin(oracle_learner* o);
 int oracle_td_step_end(oracle_learner* o);

@@ -455,8 +455,13 @@ static int run_episode(const Args& a, Config& c, ProbeEnv& env, const std::strin
         }
         fclose(f);
     }
-    printf("{\"steps\": %ld, \"end\": %d, \"ends\": [%s], \"rng_ctr\": %llu, \"sizeof_steprec\": %zu}\n", steps, end_reason,
-           ends.c_str(), (unsigned long long)g_ctr, sizeof(StepRec));
+    // what Agent::HandleTransition handed to its "model_log" logger (agent.cpp:93-100: one row per 1000 updates)
+    std::string ml;
+    if (auto lg = spdlog::get("model_log"))
+        for (auto& row : lg->rows)
+            if (row.size() == 1) { char buf[64]; snprintf(buf, sizeof buf, "%s%.17g", ml.empty() ? "" : ", ", row[0]); ml += buf; }
+    printf("{\"steps\": %ld, \"end\": %d, \"ends\": [%s], \"rng_ctr\": %llu, \"sizeof_steprec\": %zu, \"model_log\": [%s]}\n", steps, end_reason,
+           ends.c_str(), (unsigned long long)g_ctr, sizeof(StepRec), ml.c_str());
     return 0;
 }
 
@@ -574,6 +579,13 @@ static int run_dropin_learner(const Args& a, Config& c, environment::GpuIntraday
             for (size_t i = 0; i < row.size(); i++) printf("%s%.17g", i ? ", " : "", row[i]);
             printf("]}\n");
         }
+    }
+    if (auto ml = spdlog::get("model_log")) {      // ... and to the model_log logger (Agent::HandleTransition's rows, agent.cpp:93-100)
+        printf("{\"model_log\": [");
+        bool first = true;
+        for (auto& row : ml->rows)
+            if (row.size() == 1) { printf("%s%.17g", first ? "" : ", ", row[0]); first = false; }
+        printf("]}\n");
     }
     if (a.kv.count("stats_out")) base.writeStats(a.get("stats_out"));
     if (a.kv.count("theta_out")) {

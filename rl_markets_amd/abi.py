@@ -162,6 +162,8 @@ def load():
         "lob_td_step": (C.c_int, [vp, C.c_int32]),
         "lob_td_step_begin": (C.c_int, [vp]),
         "lob_td_split_supported": (C.c_int, [vp]),
+        "lob_model_log_enable": (C.c_int, [vp, C.c_int32]),
+        "lob_model_log_read": (C.c_int, [vp, vp, C.c_int32, vp, vp]),
         "lob_td_step_end": (C.c_int, [vp]),
         "lob_eval_step": (C.c_int, [vp, C.c_int32]),
         "lob_handle_terminal": (C.c_int, [vp]),

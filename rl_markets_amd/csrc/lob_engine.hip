@@ -55,7 +55,8 @@ struct lob_engine {
     bool acc_fuse = true;       // Q(lambda), the pair kernel + the lane-per-generation trace kernel: updates added to their slots there, accumulate_kernel over a list (LOB_ACC_FUSE=0: over every book; A/B switch)
     bool acc_batches_set = false;
     int acc_batches = LOB_ACB_K;  // accumulate_block_kernel: batches of 1 024 books per block (LOB_ACC_BATCHES=1|2|4|8; A/B switch)
-    bool acc_block = true;      // SARSA(lambda): accumulate_block_kernel (LOB_ACC_BLOCK=0: accumulate_kernel; A/B switch)
+    bool acc_block = true;      // SARSA(lambda): sums per block first (LOB_ACC_BLOCK=0: accumulate_kernel; A/B switch)
+    bool acc_dense = true;      // ... in a direct-indexed LDS array by the slots' dense ids, accumulate_dense_kernel (LOB_ACC_DENSE=0: accumulate_block_kernel's hash table; A/B switch)
     int env_step_lanes = 64;    // books per wave of env_step_kernel (LOB_ENV_STEP_LANES=32: two half-full waves per SIMD; experiment)
     bool prepass_roles = false; // the pre-pass on two waves per 64 books (reset2_kernel / prepass_extend2_kernel; LOB_PREPASS_ROLES=1): measured slower, opt-in
     // learn_q_rest_kernel reports its list's length (the books the lane learn kernels handed back) through host-mapped memory:
@@ -121,6 +122,7 @@ struct lob_engine {
     int dump_cap = 0;
     bool have_events = false, was_reset = false;
     bool episode_open = false;  // a pre-pass ran and its window sums have not been rolled back to the stop point yet
+    bool model_log = false;     // lob_model_log_enable: the step sums |delta| (td_stats_kernel)
     bool timing = false;
     int acc_shift = -1;     // accumulate_kernel lanes per book (log2); -1: chosen from the algorithm and epsilon
     int timing_period = 1;  // kernels of every n-th step are timed (two event records per launch are not free: 9 % at n = 1)
@@ -327,6 +329,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     HIPCHK_E(hipEventCreateWithFlags(&e->ev_rest_done, hipEventDisableTiming | hipEventDisableSystemFence));
     if (const char* g = getenv("LOB_REST_SIDE")) e->rest_side = !(g[0] == '0');
     if (const char* g = getenv("LOB_ACC_BLOCK")) e->acc_block = !(g[0] == '0');
+    if (const char* g = getenv("LOB_ACC_DENSE")) e->acc_dense = !(g[0] == '0');
     if (const char* g = getenv("LOB_ACC_FUSE")) e->acc_fuse = !(g[0] == '0');
     if (const char* g = getenv("LOB_ACC_BATCHES")) { const int v = atoi(g); if (v == 1 || v == 2 || v == 4 || v == 8) { e->acc_batches = v; e->acc_batches_set = true; } }
     // (the variants measured and lost -- NOTES.md "Round 4" -- exist in -DLOB_EXPERIMENTS builds only, tools/exp_variants.sh; a
@@ -516,6 +519,41 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
         S.cb_segs = std::min(2048, slots / 4);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.cb_count, 2 * (size_t)S.cb_segs);
         if (rc == LOB_OK && hipMemsetAsync(S.cb_key, 0xff, (size_t)slots * 8, e->stream) != hipSuccess) rc = LOB_EHIP;
+        // dense ids of the slots (lob_state.h; accumulate_dense_kernel): for the algorithms whose update can come to sum per block
+        // (SARSA(lambda) always, Q(lambda) once most actions are greedy), on the fast path, big batches
+        const bool dense_ok = P.memo && P.combine && e->acc_dense && e->acc_block && (P.algo == LOB_ALGO_SARSA || P.algo == LOB_ALGO_QLAMBDA) &&
+                              (long long)n_books >= 4 * LOB_ACB_BLOCK && P.trace_gens <= LOB_TRACE_GENS;
+        if (dense_ok) {
+            if (rc == LOB_OK) rc = dev_alloc(e, &S.cb_dense, (size_t)slots);
+            if (rc == LOB_OK) rc = dev_alloc(e, &S.cb_free, (size_t)LOB_CBD_CAP);
+            if (rc == LOB_OK) rc = dev_alloc(e, &S.cb_free_n, 16);
+            if (rc == LOB_OK) rc = dev_alloc(e, &S.tr_cbd, B * (size_t)P.trace_gens);
+            if (rc == LOB_OK) rc = dev_alloc(e, &S.cb_part, (size_t)LOB_ACD_MAX_BLOCKS * LOB_CBD_CAP);
+            if (rc == LOB_OK) rc = dev_alloc(e, &S.cb_red, (size_t)LOB_ACD_GROUPS * LOB_CBD_CAP);
+            if (rc == LOB_OK && hipMemsetAsync(S.cb_dense, 0xff, (size_t)slots * 4, e->stream) != hipSuccess) rc = LOB_EHIP;
+            if (rc == LOB_OK && hipMemsetAsync(S.tr_cbd, 0xff, B * (size_t)P.trace_gens * 8, e->stream) != hipSuccess) rc = LOB_EHIP;
+            if (rc == LOB_OK) {
+                // list x: the ids = x mod 8, the lowest on top; nothing handed out yet
+                // (LOB_CBD_IDS=n: only n ids in all, for the tests -- most slots then go without one)
+                std::vector<i32> fl(LOB_CBD_CAP), fn(16);
+                const int per = LOB_CBD_CAP / 8;
+                int have = per;
+                if (const char* g = getenv("LOB_CBD_IDS")) { const int v = atoi(g); if (v >= 8 && v <= LOB_CBD_CAP) have = v / 8; }
+                S.cb_ids = have * 8;
+                for (int x = 0; x < 8; x++) {
+                    for (int i = 0; i < have; i++) fl[(size_t)x * per + i] = (have - 1 - i) * 8 + x;
+                    fn[2 * x] = have;
+                    fn[2 * x + 1] = have;
+                }
+                if (hipMemcpyAsync(S.cb_free, fl.data(), fl.size() * 4, hipMemcpyHostToDevice, e->stream) != hipSuccess ||
+                    hipMemcpyAsync(S.cb_free_n, fn.data(), fn.size() * 4, hipMemcpyHostToDevice, e->stream) != hipSuccess ||
+                    hipStreamSynchronize(e->stream) != hipSuccess) rc = LOB_EHIP;
+            }
+            if (rc == LOB_OK && hipFuncSetAttribute((const void*)accumulate_dense_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)acd_lds_bytes()) != hipSuccess) {
+                lob_set_error("hipFuncSetAttribute(accumulate_dense_kernel: dynamic LDS)");
+                rc = LOB_EHIP;
+            }
+        }
     }
     {
         S.mk_slots = 1 << 16;
@@ -925,6 +963,7 @@ int lob_reset(lob_engine* e) {
         HIPCHK(hipMemsetAsync(e->S.amb_flag, 0, sizeof(i32), e->stream));
         HIPCHK(hipMemsetAsync(e->S.mk_all_n, 0, sizeof(i32), e->stream));
         HIPCHK(hipMemsetAsync(e->S.tr_cbslot, 0xff, (size_t)e->B * e->P.trace_gens * 4, e->stream));  // (slots of books that stopped stepping may be gone)
+        if (e->S.tr_cbd) HIPCHK(hipMemsetAsync(e->S.tr_cbd, 0xff, (size_t)e->B * e->P.trace_gens * 8, e->stream));
         HIPCHK(hipMemsetAsync(e->S.counters + 7, 0, sizeof(i64), e->stream));
         e->P.epi_epoch++;
         { int rc = push_params(e); if (rc) return rc; }
@@ -1107,6 +1146,7 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
         const int lpar = first ? (e->list_par ^= 1) : e->list_par;
         e->last_par = par;
         if (mode == 0) e->S.cb_par = par;  // (DevState goes to the kernels by value: the launches below see it)
+        e->S.cb_dense_on = e->S.cb_dense && acc_blocked(e) ? 1 : 0;  // (slots claimed from here on take a dense id)
         for (int g = 0; g < G; g++) {
             hipStream_t st = g == 0 ? e->stream : e->stream2;
             const int b0 = (int)((long long)e->B * g / G), nb = (int)((long long)e->B * (g + 1) / G) - b0;
@@ -1246,14 +1286,29 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
         if (!second) { e->half_open = true; continue; }
         e->half_open = false;
         if (rest_pending) { HIPCHK(hipStreamWaitEvent(e->stream, e->ev_rest_done, 0)); rest_pending = false; }
+        if (mode == 0 && e->model_log) {  // every stepped book's TD error is final here
+            TimedLaunch t(e, "td_stats_kernel");
+            const int nblk = std::min(LOB_ML_BLOCKS, (e->B + 255) / 256), per = (e->B + nblk - 1) / nblk;
+            hipLaunchKernelGGL(td_stats_kernel, dim3(nblk), dim3(256), 0, e->stream, e->S, per);
+            hipLaunchKernelGGL(td_stats_fold_kernel, dim3(1), dim3(64), 0, e->stream, e->S, nblk);
+        }
         if (mode == 0 && e->P.combine) {
+            int dense_blocks = 0;
             {
                 TimedLaunch t(e, "accumulate_kernel");
                 // SARSA(lambda): every book keeps all its generations -- sums per slot inside 1 024-book blocks first.  The same for
                 // Q(lambda) once most actions are greedy (P(greedy) = 1 - eps + eps / 9 > 0.7: more than three live generations per book)
                 e->flow[acc_blocked(e) ? 2 : acc_fused ? 0 : 3]++;
+                if (acc_blocked(e) && e->S.cb_dense) e->flow[7]++;
                 if (rest_side_now) e->flow[1]++;
-                if (acc_blocked(e)) {
+                if (acc_blocked(e) && e->S.cb_dense) {
+                    // sums by the slots' dense ids in a direct-indexed LDS array, one block per CU (accumulate_dense_kernel)
+                    dense_blocks = std::min(std::min(e->n_cus, LOB_ACD_MAX_BLOCKS), (e->B + 255) / 256);
+                    const int bpb = ((e->B + dense_blocks - 1) / dense_blocks + 31) / 32 * 32;
+                    dense_blocks = (e->B + bpb - 1) / bpb;
+                    hipLaunchKernelGGL(accumulate_dense_kernel, dim3(dense_blocks), dim3(LOB_ACD_BLOCK), acd_lds_bytes(), e->stream, e->P, e->S, par, e->step_id, bpb);
+                    hipLaunchKernelGGL(reduce_dense_kernel, dim3((e->S.cb_ids + 255) / 256, LOB_ACD_GROUPS), dim3(256), 0, e->stream, e->S, dense_blocks);
+                } else if (acc_blocked(e)) {
                     // (batches per block: SARSA(lambda) 80 us with one, 89 with two or four -- its blocks are bound by their LDS insertions, not by what
                     // they send to memory; mostly-greedy Q(lambda) 58 -> 50 us with four)
                     const int nbat = e->acc_batches_set ? e->acc_batches : (e->P.algo == LOB_ALGO_SARSA ? 1 : std::max(1, std::min(e->acc_batches, e->B / (16 * LOB_ACB_BLOCK))));
@@ -1274,7 +1329,7 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
             {
                 TimedLaunch t(e, "apply_kernel");
                 const int blocks = e->S.cb_segs;
-                hipLaunchKernelGGL(apply_kernel, dim3(blocks), dim3(256), 0, e->stream, e->P, e->S, rnd, par, e->step_id);
+                hipLaunchKernelGGL(apply_kernel, dim3(blocks), dim3(256), 0, e->stream, e->P, e->S, rnd, par, e->step_id, dense_blocks);
             }
             if (e->P.sarsa_lanes && e->reg_fork_late) { int rc = registry_fork(e, e->stream, rnd, par); if (rc) return rc; }
         } else if (mode == 0) {
@@ -1326,6 +1381,39 @@ int lob_eval_step(lob_engine* e, int32_t n_steps) {
     if (n_steps < 0) return LOB_EINVAL;
     if (e->half_open) { lob_set_error("lob_eval_step: a learner step is half done"); return LOB_ESTATE; }
     return run_steps(e, n_steps, 1);
+}
+
+int lob_model_log_enable(lob_engine* e, int32_t on) {
+    if (!e) return LOB_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    if (on && !e->S.ml_part) {
+        int rc = dev_alloc(e, &e->S.ml_part, (size_t)LOB_ML_BLOCKS);
+        if (rc == LOB_OK) rc = dev_alloc(e, &e->S.ml_npart, (size_t)LOB_ML_BLOCKS);
+        if (rc == LOB_OK) rc = dev_alloc(e, &e->S.ml_agg, 1);
+        if (rc == LOB_OK) rc = dev_alloc(e, &e->S.ml_cnt, 2);
+        if (rc == LOB_OK) rc = dev_alloc(e, &e->S.ml_rows, (size_t)LOB_ML_ROWS);
+        if (rc != LOB_OK) return rc;
+    }
+    e->model_log = on != 0;
+    return LOB_OK;
+}
+int lob_model_log_read(lob_engine* e, double* rows, int32_t cap, int32_t* n_rows, int64_t* n_lost) {
+    if (!e || !rows || cap < 0 || !n_rows) return LOB_EINVAL;
+    *n_rows = 0;
+    if (n_lost) *n_lost = 0;
+    if (!e->S.ml_part) return LOB_OK;
+    HIPCHK(hipSetDevice(e->device));
+    i64 cnt[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(cnt, e->S.ml_cnt, sizeof cnt, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const i64 kept = std::min<i64>(cnt[1], LOB_ML_ROWS), n = std::min<i64>(kept, cap);
+    if (n > 0) HIPCHK(hipMemcpyAsync(rows, e->S.ml_rows, (size_t)n * 8, hipMemcpyDeviceToHost, e->stream));
+    // the rows are handed over once: the counter starts again (the running aggregate stays)
+    HIPCHK(hipMemsetAsync(e->S.ml_cnt + 1, 0, sizeof(i64), e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    *n_rows = (int32_t)n;
+    if (n_lost) *n_lost = cnt[1] - n;   // rows beyond the ring (LOB_ML_ROWS between two reads) or beyond `cap`
+    return LOB_OK;
 }
 
 int lob_handle_terminal(lob_engine* e) {
@@ -1741,7 +1829,8 @@ extern "C" int lob_debug_fastpath(lob_engine* e, int64_t* out, int32_t n_out) {
 // [3] accumulate_kernel over every book; steps with the action selection inside the env kernel (launch_env_fused): [4] books without a
 // usable hit list served in-kernel (act_book), [5] through the work list to the wave-per-book act kernel because the learn
 // kernels' hand-back count said most books have none (a dense theta), [6] through the work list for another reason (the first
-// step on lists, LOB_INLINE_GENERAL=0).  The tests use it to know which path they have compared with the oracle.
+// step on lists, LOB_INLINE_GENERAL=0); [7] of the steps counted under [2], those whose sums went through the dense ids
+// (accumulate_dense_kernel).  The tests use it to know which path they have compared with the oracle.
 extern "C" int lob_debug_flow(lob_engine* e, int64_t out[8]) {
     if (!e || !out) return LOB_EINVAL;
     for (int i = 0; i < 8; i++) out[i] = e->flow[i];

@@ -685,13 +685,21 @@ __global__ void __launch_bounds__(LOB_TS_BLOCK, 5) trace_lane_kernel(DevParams P
         const int ent = QL ? S.tr_list[in ? t : 0] : t;
         const int b = QL ? LOB_TRL_BOOK(ent) : ent;
         const int bb = in ? b : 0;
+        // Everything addressed by the book alone is asked for in ONE round trip: the header, the memo slot, BOTH State rows (which
+        // one is last_state is in the header) and this lane's generation -- the lane is the generation's RING SLOT, not its age
+        // (the age follows from the header's ring head afterwards), so its words do not wait for the header.
+        const size_t gi = (size_t)bb * G + k;
         const LHdr h = S.hdr[bb];
-        const bool stepped = in && h.stepped != 0;
         const int lslot = S.mk_slot_last[bb];
+        const float4 v0 = *reinterpret_cast<const float4*>(S.vars + (size_t)bb * 48), v1 = *reinterpret_cast<const float4*>(S.vars + (size_t)bb * 48 + 16);
+        const uint32_t m_raw = S.tr_alive[gi];
+        const int4 sg_raw = *reinterpret_cast<const int4*>(S.tr_sig + gi * 4);
+        const int tag_raw = S.tr_mslot[gi], cs_raw = S.tr_cbslot[gi];
+        const bool stepped = in && h.stepped != 0;
         const int ls = lslot >= 0 ? lslot : 0;
         const int last = h.slot_cur ^ 1;
         const bool zero_last = (h.zero_mask >> last) & 1;
-        const float4 vl = *reinterpret_cast<const float4*>(S.vars + (size_t)bb * 48 + last * 16);
+        const float4 vl = last ? v1 : v0;
         const int q0 = tile_quant(vl.x), q1 = tile_quant(vl.y), q2 = tile_quant(vl.z);
         const int4 lid = *reinterpret_cast<const int4*>(S.mk_ident + (size_t)ls * 4);
         const int action = h.action;
@@ -702,18 +710,13 @@ __global__ void __launch_bounds__(LOB_TS_BLOCK, 5) trace_lane_kernel(DevParams P
         if (QL && action != LOB_TRL_AMAX(ent)) n_old = 0;  // Watkins's cut (QLearn::UpdateTraces, agent.cpp:272-280: traces.decay(0.0))
         bool ok = lslot >= 0 && !zero_last && lid.x == q0 && lid.y == q1 && lid.z == q2 && lid.w == 1 && S.mk_tiles_ok[ls] == 3 && reg_ok &&
                   q0 >= lim && q1 >= lim && q2 >= lim;
-        // ---- this lane's generation (age k) ----
-        const int slot = (h.tr_head - k + G) & (G - 1);
-        const size_t gi = (size_t)bb * G + slot;
-        uint32_t m = 0;
-        int4 sg = make_int4(0, 0, 0, 0);
-        int tag = -1, cs = -1;
-        if (stepped && k < n_old) {
-            m = S.tr_alive[gi];
-            sg = *reinterpret_cast<const int4*>(S.tr_sig + gi * 4);
-            tag = S.tr_mslot[gi];
-            cs = S.tr_cbslot[gi];
-        }
+        // ---- this lane's generation: ring slot k, age (head - k) mod G; age G - 1 is the slot the new generation goes to ----
+        const int age = (h.tr_head - k) & (G - 1);
+        const bool has_old = stepped && age < n_old;
+        const uint32_t m = has_old ? m_raw : 0u;
+        const int4 sg = has_old ? sg_raw : make_int4(0, 0, 0, 0);
+        const int tag = has_old ? tag_raw : -1;
+        int cs = has_old ? cs_raw : -1;
         // (the new generation's tile, ahead of its use: the chain of dependent look-ups is what this kernel's time is made of)
         const i32 N = S.mk_tiles[((size_t)ls * LOB_N_ACTIONS + action) * 32 + k];
         const uint32_t marked = S.mk_marked[ls];
@@ -787,9 +790,9 @@ __global__ void __launch_bounds__(LOB_TS_BLOCK, 5) trace_lane_kernel(DevParams P
                     cs_here = false;
                 }
             }
-            // (old age k: age k + 1 after this step's decay)
+            // (old age `age`: age + 1 after this step's decay)
             if (add_here && m2) {
-                const f64 val = upd32 * (f64)P.trace_pow[k + 1];
+                const f64 val = upd32 * (f64)P.trace_pow[age + 1];
                 if (!(cs_here ? acc_generation_at(S, gi, cs, sg, m2, val, xcd, vec) : acc_generation(S, gi, m2, val, xcd, vec))) acc_failed = true;
             }
         }
@@ -802,7 +805,7 @@ __global__ void __launch_bounds__(LOB_TS_BLOCK, 5) trace_lane_kernel(DevParams P
             if (k == 0) atomicOr(&S.mk_marked[lslot], 1u << action);
         }
         S.tr_idx[ni * 32 + k] = N;
-        if (k == 31) {  // (n_old <= 31: this lane has no old generation)
+        if (age == G - 1) {  // (ring slot nh; n_old <= G - 1: this lane has no old generation)
             LHdr* hp = S.hdr + b;
             S.tr_alive[ni] = 0xffffffffu;
             S.tr_mslot[ni] = lslot | tag_epoch;

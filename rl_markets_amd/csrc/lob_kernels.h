@@ -1525,6 +1525,7 @@ __device__ inline bool acc_generation_at(const DevState& S, size_t gi, int cs, i
             if (found) touch = S.cb_touch[s];
         }
         S.tr_cbslot[gi] = found ? (i32)(s | LOB_CBS_VERIFIED) : -1;
+        if (S.tr_cbd) S.tr_cbd[gi] = ~0ull;  // (accumulate_dense_kernel's record of the slot's dense id: not looked up here)
     }
     if (!found) return false;
     __hip_atomic_fetch_add(&S.cb_acc[((size_t)xcd * S.cb_slots + s) * 2 + target], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1616,7 +1617,10 @@ __global__ void __launch_bounds__(LOB_BLOCK) accumulate_kernel(DevParams P, DevS
                         s = (s + 1) & (uint32_t)(S.cb_slots - 1);
                     }
                 }
-                if (found && !known) S.tr_cbslot[(size_t)bb * G + slot] = (i32)(s | LOB_CBS_VERIFIED);
+                if (found && !known) {
+                    S.tr_cbslot[(size_t)bb * G + slot] = (i32)(s | LOB_CBS_VERIFIED);
+                    if (S.tr_cbd) S.tr_cbd[(size_t)bb * G + slot] = ~0ull;
+                }
                 if (found) {
                     __hip_atomic_fetch_add(&S.cb_acc[((size_t)xcd * S.cb_slots + s) * 2 + target], scaled * (f64)P.trace_pow[age], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (!(S.cb_touch[s] & (1u << target))) atomicOr(&S.cb_touch[s], 1u << target);
@@ -1732,7 +1736,10 @@ __global__ void __launch_bounds__(LOB_ACB_BLOCK) accumulate_block_kernel(DevPara
                     s = (s + 1) & (uint32_t)(S.cb_slots - 1);
                 }
             }
-            if (found && !known) S.tr_cbslot[(size_t)bb * G + slot] = (i32)(s | LOB_CBS_VERIFIED);
+            if (found && !known) {
+                S.tr_cbslot[(size_t)bb * G + slot] = (i32)(s | LOB_CBS_VERIFIED);
+                if (S.tr_cbd) S.tr_cbd[(size_t)bb * G + slot] = ~0ull;
+            }
             direct = !found;
         }
         // the block's sums per slot
@@ -1787,12 +1794,219 @@ __global__ void __launch_bounds__(LOB_ACB_BLOCK) accumulate_block_kernel(DevPara
 }
 #endif
 
+// accumulate_dense_kernel: the same sums once more, without the table.  A block of accumulate_block_kernel is bound by its
+// insertions -- a compare-and-swap on the key, then the addition, popular slots queueing -- not by what it sends to memory
+// (NOTES.md "Round 4").  Here every occupied slot has a DENSE id below LOB_CBD_CAP (lob_state.h cb_dense: handed out when the
+// slot is claimed), a generation keeps the id of its slot beside the slot (tr_cbd, valid while tr_cbslot names the same slot,
+// verified), and a block adds the terms of its books into a direct-indexed LDS array of doubles: one ds_add_f64 and one
+// ds_or_b32 (which ids got a term: a sum of 0.0 must still count as a touch, or apply_kernel would free a slot somebody holds)
+// per generation, nothing returned, nothing compared.  The block then writes its array out as its row of cb_part -- plain
+// stores; an id without a term carries LOB_ACD_MARK -- and apply_kernel, which walks the occupied slots anyway, adds the rows
+// of a slot's id up: no atomic reaches memory for a slot with an id.  Mapping: 32 lanes per book, lane = RING SLOT (not age: the
+// three per-generation loads do not wait for the header then), four books' worth of loads in flight per lane.  A generation
+// whose record is stale takes accumulate_block_kernel's look-up (identity compared in full once, probe sequence if displaced)
+// and renews it; a slot without an id, or a generation without a slot, goes the old way (atomics on cb_acc / tile by tile).
+#define LOB_ACD_BLOCK 1024
+#define LOB_ACD_UNROLL 4
+__host__ __device__ inline size_t acd_lds_bytes() { return (size_t)LOB_CBD_CAP * 8 + (size_t)LOB_CBD_CAP / 8 + (size_t)(LOB_TRACE_GENS + 1) * 4; }
+// ids below this were (or may have been) handed out: the deepest any free list has been drained
+// (list x starts with ids x, 8 + x, ... lowest on top: position p from the bottom holds id (depth - 1 - p) * 8 + x, so a list
+// drained down to p entries has handed out ids below (depth - p) * 8; `cb_ids` = 8 * depth)
+__device__ inline int cbd_high_water(const DevState& S) {
+    int deepest = S.cb_ids / 8;
+    for (int x = 0; x < 8; x++) deepest = min(deepest, S.cb_free_n[2 * x + 1]);
+    return (S.cb_ids / 8 - deepest) * 8;
+}
+#if LOB_IN_MAIN
+__global__ void __launch_bounds__(LOB_ACD_BLOCK) accumulate_dense_kernel(DevParams P, DevState S, int par, int sid, int books_per_block) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char acd_raw[];
+    f64* sums = reinterpret_cast<f64*>(acd_raw);
+    uint32_t* touched = reinterpret_cast<uint32_t*>(acd_raw + (size_t)LOB_CBD_CAP * 8);
+    f32* pw = reinterpret_cast<f32*>(acd_raw + (size_t)LOB_CBD_CAP * 8 + (size_t)LOB_CBD_CAP / 8);
+    const int tid = threadIdx.x, lane = tid & 63, l = tid & 31, grp = tid >> 5;
+    const int n_hi = cbd_high_water(S);
+    for (int i = tid; i < n_hi; i += LOB_ACD_BLOCK) sums[i] = 0.0;
+    for (int i = tid; i < (n_hi + 31) / 32; i += LOB_ACD_BLOCK) touched[i] = 0u;
+    if (tid <= LOB_TRACE_GENS) pw[tid] = P.trace_pow[tid];
+    __syncthreads();
+    const int G = P.trace_gens, gmask = G - 1;
+    const int xcd = acc_copy(S, (int)blockIdx.x);
+    const int b_lo = blockIdx.x * books_per_block, b_hi = min(b_lo + books_per_block, S.B);
+    const uint32_t smask = (uint32_t)(S.cb_slots - 1);
+    // LOB_ACD_BLOCK / 32 books per pass, LOB_ACD_UNROLL passes' loads in flight together; G / 32 ring slots per lane
+#pragma unroll 1
+    for (int b0 = b_lo; b0 < b_hi; b0 += (LOB_ACD_BLOCK / 32) * LOB_ACD_UNROLL) {
+#pragma unroll 1
+        for (int ks = l; ks < G; ks += 32) {
+            uint32_t m_[LOB_ACD_UNROLL];
+            i32 cs_[LOB_ACD_UNROLL], n_[LOB_ACD_UNROLL], head_[LOB_ACD_UNROLL], st_[LOB_ACD_UNROLL];
+            u64 pd_[LOB_ACD_UNROLL];
+            f64 upd_[LOB_ACD_UNROLL];
+#pragma unroll
+            for (int u = 0; u < LOB_ACD_UNROLL; u++) {
+                const int b = b0 + u * (LOB_ACD_BLOCK / 32) + grp;
+                const bool in = b < b_hi;
+                const size_t gi = (size_t)(in ? b : b_lo) * G + ks;
+                const LHdr& h = S.hdr[in ? b : b_lo];
+                st_[u] = in ? h.stepped : 0;
+                n_[u] = h.tr_n;
+                head_[u] = h.tr_head;
+                upd_[u] = h.upd;
+                m_[u] = S.tr_alive[gi];
+                cs_[u] = S.tr_cbslot[gi];
+                pd_[u] = S.tr_cbd[gi];
+            }
+            // A generation whose record is stale (every generation a step has created or changed: a tenth of them) needs its
+            // signature, the slot's identity and the slot's id: asked for together for all the passes in flight, before any is
+            // looked at -- one more round trip per batch of passes, not three dependent ones per pass.
+            int4 sg_[LOB_ACD_UNROLL], id_[LOB_ACD_UNROLL];
+            uint32_t idm_[LOB_ACD_UNROLL], mask_[LOB_ACD_UNROLL];
+            i32 dd_[LOB_ACD_UNROLL];
+            bool fast_[LOB_ACD_UNROLL];
+#pragma unroll
+            for (int u = 0; u < LOB_ACD_UNROLL; u++) {
+                const int b = b0 + u * (LOB_ACD_BLOCK / 32) + grp;
+                const int bb = b < b_hi ? b : b_lo;
+                const size_t gi = (size_t)bb * G + ks;
+                const int age = (head_[u] - ks) & gmask;
+                const bool mine = st_[u] != 0 && age < n_[u];
+                mask_[u] = mine ? m_[u] : 0u;
+                const int cs = cs_[u];
+                const uint32_t s = (uint32_t)cs & smask;
+                const bool known = cs >= 0 && (cs & LOB_CBS_VERIFIED);
+                fast_[u] = mask_[u] != 0 && known && (uint32_t)(pd_[u] >> 32) == s;
+                sg_[u] = make_int4(0, 0, 0, 0); id_[u] = make_int4(0, 0, 0, 0); idm_[u] = 0u; dd_[u] = -1;
+                if (mask_[u] != 0 && !fast_[u]) {
+                    if (!known) sg_[u] = *reinterpret_cast<const int4*>(S.tr_sig + gi * 4);
+                    if (cs >= 0) {
+                        if (!known) {
+                            id_[u] = *reinterpret_cast<const int4*>(S.cb_ident + (size_t)s * 8);
+                            idm_[u] = (uint32_t)S.cb_ident[(size_t)s * 8 + 4];  // (0 in a free slot; mask != 0 here)
+                        }
+                        dd_[u] = S.cb_dense[s];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < LOB_ACD_UNROLL; u++) {
+                const int b = b0 + u * (LOB_ACD_BLOCK / 32) + grp;
+                const int bb = b < b_hi ? b : b_lo;
+                const size_t gi = (size_t)bb * G + ks;
+                const int age = (head_[u] - ks) & gmask;
+                const uint32_t mask = mask_[u];
+                const int cs = cs_[u];
+                const f64 val = upd_[u] / (f64)LOB_N_TILINGS * (f64)pw[age];
+                uint32_t s = (uint32_t)cs & smask;
+                bool found = false, direct = false;
+                i32 d = -1;
+                if (mask) {
+                    if (fast_[u]) { found = true; d = (i32)(uint32_t)pd_[u]; }  // (the usual case)
+                    else {
+                        const bool known = cs >= 0 && (cs & LOB_CBS_VERIFIED);
+                        const int4 sg = sg_[u];
+                        found = known;
+                        d = dd_[u];
+                        if (!known) {
+                            // the slot the generation's claim ended on (or, for a claim another lane made, the hash's home slot)
+                            if (cs >= 0) found = id_[u].x == sg.x && id_[u].y == sg.y && id_[u].z == sg.z && id_[u].w == sg.w && idm_[u] == mask;
+                            if (!found) {  // (a displaced slot: walk the probe sequence)
+                                const u64 hsh = cb_hash(sg.x, sg.y, sg.z, sg.w, mask);
+                                s = (uint32_t)hsh & smask;
+                                for (int probe = 0; probe < LOB_CB_PROBES; probe++) {
+                                    const u64 kk = S.cb_key[s];
+                                    if (kk == hsh) {
+                                        const i32* id = S.cb_ident + (size_t)s * 8;
+                                        found = id[0] == sg.x && id[1] == sg.y && id[2] == sg.z && id[3] == sg.w && (uint32_t)id[4] == mask;
+                                        if (found) break;  // (another identity with this hash: the claim may have walked on past it)
+                                    }
+                                    if (kk == LOB_CB_EMPTY) break;
+                                    s = (s + 1) & smask;
+                                }
+                                if (found) d = S.cb_dense[s];
+                            }
+                            if (found) S.tr_cbslot[gi] = (i32)(s | LOB_CBS_VERIFIED);
+                        }
+                        if (found) S.tr_cbd[gi] = ((u64)s << 32) | (u64)(uint32_t)d;
+                        direct = !found;
+                    }
+                }
+                if (found) {
+                    if (d >= 0) {
+                        unsafeAtomicAdd(&sums[d], val);                  // (LDS: ds_add_f64, nothing returned)
+                        atomicOr(&touched[d >> 5], 1u << (d & 31));      // (ds_or_b32)
+                    } else {  // (a slot without an id: straight to its sums)
+                        __hip_atomic_fetch_add(&S.cb_acc[((size_t)xcd * S.cb_slots + s) * 2], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (!(S.cb_touch[s] & 1u)) atomicOr(&S.cb_touch[s], 1u);
+                    }
+                }
+                u64 todo = __ballot(direct);
+                while (todo) {  // rare: a generation without a slot, applied tile by tile by the whole wave (as accumulate_kernel)
+                    const int src = __builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    const int d_b = __shfl(bb, src), d_ks = __shfl(ks, src);
+                    const uint32_t m = __shfl(mask, src);
+                    const f64 d_val = readlane_f64(val, src);
+                    const int j = lane & 31;
+                    if (lane < 32 && ((m >> j) & 1u)) {
+                        const i32 f = S.tr_idx[((size_t)d_b * G + d_ks) * 32 + j];
+                        __hip_atomic_fetch_add(&S.theta[f], d_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (P.memo) nzx_mark_late(P, S, f, sid);
+                        const uint32_t bit = LOB_NZ_BIT(f);
+                        if (!(S.theta_nz[LOB_NZ_WORD(f)] & bit)) {
+                            const uint32_t old = atomicOr(&S.theta_nz[LOB_NZ_WORD(f)], bit);
+                            if (!(old & bit) && P.carry_verdicts) {
+                                i32* nz_new = S.nz_new + par * LOB_NZ_WORDS;
+                                atomicAdd(&nz_new[0], 1);
+                                atomicOr((uint32_t*)&nz_new[LOB_NZ_FILTER + (LOB_NZ_WORD(f) & (LOB_NZ_FILTER - 1))], bit);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // the block's row: every id that may be in use, whether this block met it or not (apply_kernel reads all rows of a slot's id)
+    u64* row = reinterpret_cast<u64*>(S.cb_part) + (size_t)blockIdx.x * LOB_CBD_CAP;
+    for (int i = tid; i < n_hi; i += LOB_ACD_BLOCK)
+        row[i] = ((touched[i >> 5] >> (i & 31)) & 1u) ? (u64)__double_as_longlong(sums[i]) : LOB_ACD_MARK;
+}
+#endif
+
+// reduce_dense_kernel: the rows of accumulate_dense_kernel's blocks added up by id, LOB_ACD_GROUPS partial rows out (group g = the
+// blocks g * per .. (g + 1) * per - 1, in that order) -- consecutive threads take consecutive ids, so every load is one
+// contiguous line; apply_kernel then reads LOB_ACD_GROUPS values per slot the way it reads the per-XCD copies of cb_acc.  (The
+// first version let every wave of apply_kernel read its slot's id from all 256 rows: four loads of 64 scattered lines per slot,
+// apply_kernel 0.026 -> 0.059 ms.)
+#define LOB_ACD_GROUPS 8
+#if LOB_IN_MAIN
+__global__ void __launch_bounds__(256) reduce_dense_kernel(DevState S, int dense_blocks) {
+    const int n_hi = cbd_high_water(S);
+    const int id = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
+    if (id >= n_hi) return;
+    const int per = (dense_blocks + LOB_ACD_GROUPS - 1) / LOB_ACD_GROUPS;
+    const int r0 = g * per, r1 = min(r0 + per, dense_blocks);
+    const u64* part = reinterpret_cast<const u64*>(S.cb_part) + id;
+    f64 acc = 0.0;
+    bool any = false;
+#pragma unroll 8
+    for (int r = r0; r < r1; r++) {
+        const u64 raw = part[(size_t)r * LOB_CBD_CAP];
+        if (raw != LOB_ACD_MARK) { any = true; acc += __longlong_as_double((long long)raw); }
+    }
+    reinterpret_cast<u64*>(S.cb_red)[(size_t)g * LOB_CBD_CAP + id] = any ? (u64)__double_as_longlong(acc) : LOB_ACD_MARK;
+}
+#endif
+
 // apply_kernel: one wave per occupied slot (the step's list, lob_learn.h).  Touched this step: theta[tile] += the summed update
 // for the live tiles of the slot's generation -- the 32 indices follow from its identity (quantised triple + action; all 0 for
 // a constructor-zero State: learn_traces) --, maintain the written-weights map and the carry-over filter, hand the slot on to
 // the next step's list.  Not touched: no stepped book holds the generation any more, free the slot.
 #if LOB_IN_MAIN
-__global__ void __launch_bounds__(256) apply_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g, int par, int sid) {
+// `dense_blocks` > 0: accumulate_dense_kernel + reduce_dense_kernel ran this step -- a slot with a dense id also gets the
+// LOB_ACD_GROUPS partial sums of cb_red at its id (lane x reads group x's; LOB_ACD_MARK = no block of the group had a term for
+// it), and counts as touched if any holds a term.  A slot that is freed hands its id back to the list it came from.
+__global__ void __launch_bounds__(256) apply_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g, int par, int sid, int dense_blocks) {
     __shared__ uint32_t rnd[2048 + 32];
     __shared__ int n_surv;
     // one block per segment of the table: its list, its survivors -- no counter shared between blocks
@@ -1831,10 +2045,25 @@ __global__ void __launch_bounds__(256) apply_kernel(DevParams P, DevState S, con
                 v1 += readlane_f64(c1, x);
             }
         }
-        if (touch == 0) {  // (wave-uniform)
+        const i32 did = S.cb_dense ? S.cb_dense[s] : -1;
+        bool dense_touch = false;
+        if (dense_blocks > 0 && did >= 0) {
+            u64 raw = LOB_ACD_MARK;
+            if (lane < LOB_ACD_GROUPS) raw = reinterpret_cast<const u64*>(S.cb_red)[(size_t)lane * LOB_CBD_CAP + did];
+            const bool have = raw != LOB_ACD_MARK;
+            const f64 x = have ? __longlong_as_double((long long)raw) : 0.0;
+            dense_touch = __any(have);
+            for (int g = 0; g < LOB_ACD_GROUPS; g++) v0 += readlane_f64(x, g);  // (in the order of the groups)
+        }
+        if (touch == 0 && !dense_touch) {  // (wave-uniform)
             if (lane == 0) {
                 S.cb_key[s] = LOB_CB_EMPTY;
                 S.cb_ident[(size_t)s * 8 + 4] = 0;
+                if (did >= 0) {  // the id goes back on the list it came from (ids = x mod 8 belong to list x)
+                    S.cb_dense[s] = -1;
+                    const int x = did & 7;
+                    S.cb_free[(size_t)x * (LOB_CBD_CAP / 8) + atomicAdd(&S.cb_free_n[2 * x], 1)] = did;
+                }
             }
             continue;
         }
@@ -1850,7 +2079,7 @@ __global__ void __launch_bounds__(256) apply_kernel(DevParams P, DevState S, con
         }
         // lanes 0-31 serve theta, lanes 32-63 theta_b (double Q)
         const int t = lane >> 5;
-        if (((touch >> t) & 1u) && ((mask >> j) & 1u)) {
+        if ((((touch | (dense_touch ? 1u : 0u)) >> t) & 1u) && ((mask >> j) & 1u)) {
             f64* theta = t ? S.theta_b : S.theta;
             uint32_t* nz = t ? S.theta_b_nz : S.theta_nz;
             __hip_atomic_fetch_add(&theta[f], t ? v1 : v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2120,6 +2349,46 @@ __global__ void mt_init_kernel(DevParams P, DevState S) {
     if (b >= S.B) return;
     mt64_seed(S.mt_state + (size_t)b * LOB_MT_N, (u64)(uint32_t)(P.seed + P.book_id_offset + (u64)b));
     S.mt_idx[b] = LOB_MT_N;  // first draw regenerates the block
+}
+#endif
+
+// model_log (lob_state.h ml_*): sum of |delta| over the stepped books of this step, a partial per block (thread t of block k takes
+// the books k * per + t, + 256, ...; the block adds its threads' sums up in a fixed tree) ...
+#if LOB_IN_MAIN
+__global__ void __launch_bounds__(256) td_stats_kernel(DevState S, int per) {
+    __shared__ f64 red[256];
+    __shared__ i32 cnt[256];
+    const int lo = blockIdx.x * per, hi = min(lo + per, S.B);
+    f64 a = 0.0;
+    i32 n = 0;
+    for (int b = lo + (int)threadIdx.x; b < hi; b += 256) {
+        const LHdr& h = S.hdr[b];
+        if (h.stepped) { a += fabs(h.td); n++; }
+    }
+    red[threadIdx.x] = a;
+    cnt[threadIdx.x] = n;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) { red[threadIdx.x] += red[threadIdx.x + off]; cnt[threadIdx.x] += cnt[threadIdx.x + off]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { S.ml_part[blockIdx.x] = red[0]; S.ml_npart[blockIdx.x] = cnt[0]; }
+}
+// ... and the partials in order into the running aggregate; a row once it holds 1000 updates or more (agent.cpp:95-99)
+__global__ void td_stats_fold_kernel(DevState S, int n_blocks) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    f64 agg = S.ml_agg[0];
+    i64 cnt = S.ml_cnt[0];
+    for (int k = 0; k < n_blocks; k++) { agg += S.ml_part[k]; cnt += S.ml_npart[k]; }
+    if (cnt >= 1000) {
+        const i64 row = S.ml_cnt[1];
+        if (row < LOB_ML_ROWS) S.ml_rows[row] = agg / (f64)cnt;
+        S.ml_cnt[1] = row + 1;
+        agg = 0.0;
+        cnt = 0;
+    }
+    S.ml_agg[0] = agg;
+    S.ml_cnt[0] = cnt;
 }
 #endif
 

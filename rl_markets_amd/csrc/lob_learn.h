@@ -195,6 +195,18 @@ __device__ inline u64 cb_hash(int q0, int q1, int q2, int code, uint32_t mask) {
 // The claim is split in two so that the CAS round trip overlaps the Q(s', .) evaluation:
 // cb_claim_issue fires the first probe's CAS, cb_claim_finish (much later) looks at the answer,
 // writes the identity if it won, and only then walks on along the probe sequence if it has to.
+// A dense id for a slot just claimed (lob_state.h cb_dense): popped from this XCD's free list, -1 if that is empty.  Only claim
+// winners pop (the trace / learn kernels), only apply_kernel pushes: the two never run together.
+__device__ inline i32 cbd_pop(const DevState& S) {
+    if (!S.cb_dense_on) return -1;
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    x &= 7u;
+    const i32 have = atomicSub(&S.cb_free_n[2 * x], 1);
+    if (have <= 0) { atomicAdd(&S.cb_free_n[2 * x], 1); return -1; }
+    if (have - 1 < S.cb_free_n[2 * x + 1]) atomicMin(&S.cb_free_n[2 * x + 1], have - 1);  // (rare: only while the peak grows)
+    return S.cb_free[(size_t)x * (LOB_CBD_CAP / 8) + have - 1];
+}
 struct CbPending {
     u64 h, old;
     uint32_t s, mask;
@@ -218,6 +230,7 @@ __device__ inline void cb_claim_finish(const DevState& S, const CbPending& c) {
         if (old == LOB_CB_EMPTY) {
             i32* id = S.cb_ident + (size_t)s * 8;
             id[0] = c.q0; id[1] = c.q1; id[2] = c.q2; id[3] = c.code; id[4] = (i32)c.mask; id[5] = c.src;
+            if (S.cb_dense) S.cb_dense[s] = cbd_pop(S);
             const int seg = S.cb_par * S.cb_segs + (int)(s & (uint32_t)(S.cb_segs - 1));
             const int pos = atomicAdd(&S.cb_count[seg], 1);
             S.cb_list[(size_t)seg * (S.cb_slots / S.cb_segs) + pos] = (i32)s;  // (an occupied slot is on its segment's list exactly once: it fits)

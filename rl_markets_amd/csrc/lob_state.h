@@ -169,6 +169,11 @@ struct __attribute__((aligned(64))) LHdr {
     f64 upd;        // alpha * delta to scatter
 };
 
+#define LOB_CBD_CAP 16384        /* dense slot ids: 128 KB of doubles in LDS */
+#define LOB_ACD_MAX_BLOCKS 256   /* accumulate_dense_kernel: one block per CU */
+#define LOB_ACD_MARK 0x7ff4000000000001ull /* a signalling NaN: no sum of terms is this bit pattern (arithmetic only produces quiet NaNs) */
+#define LOB_ML_BLOCKS 256
+#define LOB_ML_ROWS 8192
 #define LOB_PERSIST_N 32
 #define LOB_PROF_N 32
 #define LOB_MK_REC 10         /* doubles per memo record: S0 of the nine actions + the theta version it was computed under */
@@ -265,6 +270,21 @@ struct DevState {
     i32 cb_reps;         // copies of cb_acc ([cb_reps][cb_slots][2]): 1, or 8 = one per XCD (accumulate_kernel)
     i32 cb_segs;         // power of two <= cb_slots / 4: apply_kernel's grid
     i32 cb_par;          // parity of the current learner step (set by the host before the step's launches)
+    // Dense ids of the occupied slots (accumulate_dense_kernel, lob_kernels.h): SARSA(lambda) -- and Q(lambda) once most actions are
+    // greedy -- adds 1.6 M terms per step to ~10 k slots.  A slot that is claimed while `cb_dense_on` gets an id < LOB_CBD_CAP from
+    // one of eight free lists (one per XCD: a single list's counter would queue every claim of the chip behind it); a block of
+    // the kernel then sums its books' terms in a direct-indexed LDS array of LOB_CBD_CAP doubles -- no hash table, no
+    // compare-and-swap -- and writes the array out as its row of `cb_part`; apply_kernel adds the rows up.  A slot without an id
+    // (lists empty, claimed before the mode was on) takes the atomics on cb_acc as before.
+    i32* cb_dense;       // [cb_slots] id of the slot, -1: none
+    i32* cb_free;        // [8][LOB_CBD_CAP / 8] stacks of free ids: list x holds the ids = x mod 8, lowest on top at the start
+    i32* cb_free_n;      // [8][2]: entries on the stack, and the fewest it has ever held (ids >= 8 * (cap / 8 - that) were never out)
+    u64* tr_cbd;         // [B][trace_gens] slot << 32 | id (0xffffffff: the slot has none) as the kernel found them when it last
+                         //   compared the generation's identity with the slot's; valid while tr_cbslot still names that slot, verified
+    f64* cb_part;        // [LOB_ACD_MAX_BLOCKS][LOB_CBD_CAP] the blocks' sums by id (LOB_ACD_MARK: no term this step)
+    f64* cb_red;         // [LOB_ACD_GROUPS = 8][LOB_CBD_CAP] ... added up per group of blocks (reduce_dense_kernel), for apply_kernel
+    i32 cb_ids;          // ids in all (LOB_CBD_CAP; fewer with LOB_CBD_IDS, for the tests)
+    i32 cb_dense_on;     // claims take ids (set by the host with the algorithm / epsilon: lob_engine.hip acc_blocked)
     // Verdict carry-over: learn(t) saves, per book, which group-1/2 tiles of s' hit a written
     // weight (9 bits per tiling); act(t+1) evaluates the same state and reuses them instead of 576
     // bitmap look-ups, OR-ed with a small filter of the bits the update in between newly set.
@@ -350,6 +370,16 @@ struct DevState {
     f64* rho_inc;
     i32* rho_cnt;     // books that contributed to rho_inc this step
     f64* rl_t;        // [B]
+    // model_log (Agent::HandleTransition, src/rl/agent.cpp:93-100: _agg_delta += |delta|; every 1000 updates one row _agg_delta /
+    // 1000): per learner step the stepped books' |delta| are summed (td_stats_kernel: a partial per block, td_stats_fold_kernel:
+    // the partials in order), added to the running aggregate, and once at least 1000 updates are in it a row aggregate / count is
+    // written and both start again -- one book: exactly the reference's rows; a batch of 1000 books or more: a row per step, the
+    // mean |delta| over the batch.  Off until lob_model_log_enable.
+    f64* ml_part;     // [LOB_ML_BLOCKS] a step's partial sums
+    i32* ml_npart;    // [LOB_ML_BLOCKS] ... and counts
+    f64* ml_agg;      // [1] the running aggregate
+    i64* ml_cnt;      // [2] updates in it; rows written since the last lob_model_log_read
+    f64* ml_rows;     // [LOB_ML_ROWS]
     f64* theta_sync;  // [M] (multi-GPU) or null
     f64* delta;       // [M] scratch for the all-reduce or null
     i64* counters;    // [8] device counters

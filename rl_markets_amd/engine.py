@@ -172,6 +172,16 @@ class Engine:
     def td_step_end(self):
         self._check(self.lib.lob_td_step_end(self.h))
 
+    def model_log_enable(self, on=True):
+        """lob_model_log_enable: mean |delta| rows as the reference's `model_log` logger writes them (src/rl/agent.cpp:93-100)."""
+        self._check(self.lib.lob_model_log_enable(self.h, 1 if on else 0))
+
+    def model_log_read(self, cap=8192):
+        rows = np.zeros(cap, np.float64)
+        n, lost = C.c_int32(0), C.c_int64(0)
+        self._check(self.lib.lob_model_log_read(self.h, _ptr(rows), cap, C.byref(n), C.byref(lost)))
+        return rows[:n.value].copy(), int(lost.value)
+
     def td_split_supported(self):
         """Whether td_step_begin / td_step_end are available with this engine configuration (lob_td_split_supported)."""
         return bool(self.lib.lob_td_split_supported(self.h))
@@ -264,7 +274,8 @@ class Engine:
         fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_void_p]
         self._check(fn(self.h, _ptr(c)))
         return {"added_in_place": int(c[0]), "rest_on_side_stream": int(c[1]), "block_sums": int(c[2]), "every_book": int(c[3]),
-                "act_inline_general": int(c[4]), "act_work_list_dense": int(c[5]), "act_work_list_other": int(c[6])}
+                "act_inline_general": int(c[4]), "act_work_list_dense": int(c[5]), "act_work_list_other": int(c[6]),
+                "dense_sums": int(c[7])}
 
     def fastpath_stats(self):
         """lob_debug_fastpath (a diagnostic export, not in include/lob_engine.h): written weights and the live books' hit-list lengths."""

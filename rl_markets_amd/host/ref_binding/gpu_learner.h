@@ -78,6 +78,8 @@ class GpuLearner : public Runner {
     int steps_per_call_;
     unsigned long _step_counter = 0;
     int _episode_counter = 0;
+    bool model_log_on_ = false;
+    std::vector<double> ml_rows_ = std::vector<double>(8192);
 
     static void check(int rc, const char* what) {
         if (rc != LOB_OK) throw std::runtime_error(std::string(what) + ": " + lob_last_error());
@@ -88,6 +90,15 @@ protected:
     bool _step(rl::Agent*) override {
         check(lob_td_step(genv_.handle(), steps_per_call_), "GpuLearner::_step");
         _step_counter += (unsigned long)steps_per_call_;
+        // Agent::HandleTransition's `model_log` rows (agent.cpp:93-100: mean |delta| per 1000 updates): the engine aggregates on
+        // the device; what it has written since the last call goes to the logger the Agent's constructor registered
+        if (model_log_on_) {
+            if (auto log = spdlog::get("model_log")) {
+                int32_t n = 0;
+                check(lob_model_log_read(genv_.handle(), ml_rows_.data(), (int32_t)ml_rows_.size(), &n, nullptr), "GpuLearner::_step (model_log)");
+                for (int32_t i = 0; i < n; i++) log->info(ml_rows_[(size_t)i]);
+            }
+        }
         int64_t cnt[4];
         check(lob_get_counters(genv_.handle(), cnt), "GpuLearner::_step");
         return cnt[2] == 0;
@@ -119,6 +130,10 @@ public:
         rl::GpuAgent* ga = dynamic_cast<rl::GpuAgent*>(m);
         if (!ga) throw std::invalid_argument("GpuLearner::RunEpisode: the agent must be an rl::GpuAgent");
         _step_counter = 0;
+        if (!model_log_on_ && spdlog::get("model_log")) {   // (registered by Agent::Agent when logging.log_learning is on, agent.cpp:53-59)
+            check(lob_model_log_enable(genv_.handle(), 1), "GpuLearner (model_log)");
+            model_log_on_ = true;
+        }
         push_schedules(m, ga);                          // the agent's and the policy's objects are the source of truth
         environment.resetStats();
         if (!environment.Initialise()) return false;   // lob_reset of every book

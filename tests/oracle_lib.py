@@ -152,6 +152,14 @@ class Oracle:
         p = self.lib.oracle_theta(self.h, which)
         return np.ctypeslib.as_array(p, shape=(self.params.memory_size,))
 
+    def model_log(self, cap=65536):
+        """Rows of the reference's `model_log` logger so far (Agent::HandleTransition, src/rl/agent.cpp:93-100)."""
+        rows = np.zeros(cap, np.float64)
+        self.lib.oracle_model_log.restype = C.c_int32
+        self.lib.oracle_model_log.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        n = self.lib.oracle_model_log(self.h, ptr(rows), cap)
+        return rows[:min(n, cap)].copy()
+
     def theta_b(self, which=0):
         p = self.lib.oracle_theta_b(self.h, which)
         return np.ctypeslib.as_array(p, shape=(self.params.memory_size,))

@@ -13,7 +13,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from rl_markets_amd import engine
+from rl_markets_amd import abi, engine
 from tests import oracle_lib as ol
 from tests.golden.make_golden import TRAJ_CASES, gen_for
 from tests.test_oracle_golden import GOLD
@@ -107,6 +107,37 @@ def _run_learner(tmp_path, name, books, episodes=1, extra=()):
     for e, row in zip(eps, tlog):
         assert row == [e["episode"], e["reward"], e["pnl"], e["steps"], e["descr"]]
     return case, rec, eps, _sparse_theta(th), open(st).read()
+
+
+@pytest.mark.skipif(not os.path.exists(DROPIN), reason="oracle/_ref/ref_dropin is built where the reference checkout is (make -C oracle dropin)")
+def test_gpu_learner_writes_the_model_log_rows(tmp_path):
+    """The `model_log` logger (Agent::HandleTransition, src/rl/agent.cpp:93-100: the mean |delta| of every 1000 updates): GpuLearner
+    hands the engine's rows (lob_model_log_read) to the logger the reference's own Agent constructor registered.  One book over an
+    episode of more than 3000 updates: the rows the all-CPU reference writes (the oracle's, pinned on them by
+    tests/test_oracle_golden.py), bit for bit."""
+    from tests import oracle_lib as ol
+    n_events, book = 8000, 5
+    g = engine.default_gen_params()
+    g.n_events = n_events
+    rec = engine.gen_stream_host(g, 5, 2, book, 1)
+    sp = str(tmp_path / "s.bin")
+    rec[0].tofile(sp)
+    res = subprocess.run([DROPIN, "dropin_learner", "--stream", sp, "--events", str(n_events), "--book", "0", "--depth", "5", "--trades", "2",
+                          "--algo", "sarsa", "--mem", str(1 << 16), "--seed", "1994", "--rng_stream", str(book), "--eps", "0.8", "--books", "1",
+                          "--episodes", "1", "--tmp", str(tmp_path / "h")], capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
+    lines = [json.loads(l) for l in res.stdout.strip().splitlines() if l.startswith("{")]
+    rows = [d["model_log"] for d in lines if "model_log" in d]
+    assert len(rows) == 1
+    p = engine.default_params()
+    p.memory_size, p.algo, p.book_id_offset = 1 << 16, abi.ALGO_SARSA, book
+    o = ol.Oracle(p, rec)
+    o.reset()
+    o.td_step(6000)
+    want = o.model_log()
+    assert len(want) >= 3
+    np.testing.assert_array_equal(np.array(rows[0]), want)
+    o.close()
 
 
 @pytest.mark.skipif(not os.path.exists(DROPIN), reason="oracle/_ref/ref_dropin is built where the reference checkout is (make -C oracle dropin)")

@@ -209,6 +209,35 @@ def test_random_init_weights(algo, theta_mode, first_book):
     orc.close()
 
 
+@pytest.mark.parametrize("B,theta_mode,algo", [(1, abi.THETA_PRIVATE, abi.ALGO_SARSA), (3, abi.THETA_PRIVATE, abi.ALGO_DOUBLE_Q),
+                                               (1500, abi.THETA_SHARED, abi.ALGO_QLAMBDA), (40000, abi.THETA_SHARED, abi.ALGO_SARSA)])
+def test_model_log_rows(B, theta_mode, algo):
+    """lob_model_log_enable / lob_model_log_read: the rows of the reference's `model_log` logger (Agent::HandleTransition,
+    src/rl/agent.cpp:93-100 -- mean |delta| per 1000 updates; the oracle's rows are pinned on the reference's own by
+    tests/test_oracle_golden.py).  One book: the reference's rows bit for bit; a few books: a row every time the running count
+    reaches 1000; a batch of 1000 books or more: a row per learner step (the mean |delta| over the batch; the big batch also
+    goes through the lane-per-book learner kernels and learn_q_rest_kernel)."""
+    n_steps = 2300 if B <= 3 else (40 if B < 5000 else 12)
+    p, g, rec, eng, orc = make(depth=5 if B <= 3 else 10, n_events=4200 if B <= 3 else 300, B=B, algo=algo, theta_mode=theta_mode,
+                               mem=1 << 16 if B <= 3 else 1 << 20)
+    eng.model_log_enable()
+    eng.reset(); orc.reset()
+    eng.td_step(n_steps); orc.td_step(n_steps)
+    rows, lost = eng.model_log_read()
+    want = orc.model_log()
+    assert lost == 0 and len(rows) == len(want) == (n_steps * B // 1000 if B <= 3 else n_steps)
+    if theta_mode == abi.THETA_PRIVATE and B == 1:
+        np.testing.assert_array_equal(rows, want)
+    else:
+        np.testing.assert_allclose(rows, want, rtol=1e-9)
+    assert np.all(rows > 0)
+    eng.td_step(3); orc.td_step(3)
+    rows2, _ = eng.model_log_read()          # (handed over once: only what was written since)
+    np.testing.assert_allclose(rows2, orc.model_log()[len(want):], rtol=1e-9)
+    eng.close()
+    orc.close()
+
+
 def test_eval_step_greedy():
     B = 8
     p, g, rec, eng, orc = make(n_events=400, B=B, theta_mode=abi.THETA_SHARED)

@@ -133,6 +133,7 @@ def test_mostly_greedy_q_lambda_block_sums(monkeypatch, batches):
     combined update goes through accumulate_block_kernel -- sums per slot in a block's LDS table first, one or several batches
     of 1 024 books per block (LOB_ACC_BATCHES) -- 32 768 books, 30 steps against the oracle, and the flow counter says so."""
     monkeypatch.setenv("LOB_ACC_BATCHES", batches)
+    monkeypatch.setenv("LOB_ACC_DENSE", "0")     # (the hash-table kernel; the dense-id kernel that replaced it by default: below)
     B = 32768
     p, eng, orc = make(B, abi.ALGO_QLAMBDA, n_events=200, epsilon=0.05)
     eng.reset()
@@ -144,7 +145,38 @@ def test_mostly_greedy_q_lambda_block_sums(monkeypatch, batches):
             compare_learner_step(eng, orc, "greedy batches %s step %d" % (batches, step), exact=False, rtol=1e-9)
     np.testing.assert_allclose(eng.theta(), orc.theta(), rtol=1e-9, atol=1e-12)
     flow = eng.flow_stats()
-    assert flow["block_sums"] == 30 and flow["added_in_place"] == 0 and flow["every_book"] == 0, flow
+    assert flow["block_sums"] == 30 and flow["added_in_place"] == 0 and flow["every_book"] == 0 and flow["dense_sums"] == 0, flow
+    eng.close()
+    orc.close()
+
+
+@pytest.mark.parametrize("ids", ["all", "64", "off"])
+@pytest.mark.parametrize("algo,eps", [(abi.ALGO_SARSA, 0.8), (abi.ALGO_QLAMBDA, 0.05)], ids=["sarsa", "greedy_qlambda"])
+def test_block_sums_by_dense_slot_ids(monkeypatch, algo, eps, ids):
+    """accumulate_dense_kernel: SARSA(lambda)'s update (every book keeps all its generations: 25 terms per book and step onto a
+    few thousand combine slots) and mostly-greedy Q(lambda)'s, summed per block in an LDS array indexed by the slots' dense
+    ids and added up by apply_kernel -- 16 384 books, 40 steps and the start of a second episode against the oracle.  `64`: only
+    64 ids exist (LOB_CBD_IDS), so most slots go without one and take the atomics on their sums, in the same launch; `off`
+    (LOB_ACC_DENSE=0): accumulate_block_kernel's hash table, the kernel this one replaced."""
+    if ids == "off":
+        monkeypatch.setenv("LOB_ACC_DENSE", "0")
+    elif ids != "all":
+        monkeypatch.setenv("LOB_CBD_IDS", ids)
+    B = 16384
+    p, eng, orc = make(B, algo, n_events=260, epsilon=eps)
+    for episode, n_steps in ((0, 40), (1, 6)):
+        eng.reset(); orc.reset()
+        for step in range(n_steps):
+            eng.td_step(1); orc.td_step(1)
+            if step < 3 or step % 6 == 0 or step >= n_steps - 2:
+                compare_learner_step(eng, orc, "dense ids %s algo %d episode %d step %d" % (ids, algo, episode, step), exact=False, rtol=1e-9)
+        eng.clear_inventory(); orc.clear_inventory()
+        eng.handle_terminal(); orc.handle_terminal()
+    th, oth = eng.theta(), orc.theta()
+    assert np.array_equal(th != 0, oth != 0) and np.count_nonzero(th) > 10000
+    np.testing.assert_allclose(th, oth, rtol=1e-9, atol=1e-12)
+    flow = eng.flow_stats()
+    assert flow["block_sums"] == 46 and flow["dense_sums"] == (0 if ids == "off" else 46), flow
     eng.close()
     orc.close()
 

@@ -5,6 +5,7 @@ six full Intraday+Agent episodes, 263 x 9 x 96 tile indices at three memory
 sizes, the hash table and ~4000 tick conversions on seven venues, bit-exact."""
 import ctypes as C
 import glob
+import tempfile
 import os
 
 import numpy as np
@@ -81,7 +82,8 @@ def test_tick_maths_match_reference(ticker):
 def _params_for(over, algo, book):
     p = engine.default_params()
     p.memory_size = 1 << 20
-    p.algo = {"sarsa": abi.ALGO_SARSA, "q_learn": abi.ALGO_QLAMBDA, "r_learn": abi.ALGO_R_LEARN, "online_r_learn": abi.ALGO_ONLINE_R_LEARN}[algo]
+    p.algo = {"sarsa": abi.ALGO_SARSA, "q_learn": abi.ALGO_QLAMBDA, "double_q_learn": abi.ALGO_DOUBLE_Q, "r_learn": abi.ALGO_R_LEARN,
+              "online_r_learn": abi.ALGO_ONLINE_R_LEARN}[algo]
     p.book_id_offset = book
     for k, v in over.items():
         if k.startswith("_"):
@@ -152,6 +154,33 @@ def test_live_reference_run_matches_oracle():
     nz = np.nonzero(th)[0]
     np.testing.assert_array_equal(nz, theta[0])
     np.testing.assert_array_equal(th[nz], theta[1])
+
+
+@pytest.mark.skipif(not ol.have_ref(), reason="oracle/_ref/ref_harness not built")
+@pytest.mark.parametrize("algo,code", [("sarsa", abi.ALGO_SARSA), ("double_q_learn", abi.ALGO_DOUBLE_Q)])
+def test_model_log_rows_match_the_reference(algo, code):
+    """Agent::HandleTransition's `model_log` (src/rl/agent.cpp:93-100: _agg_delta += abs(delta), every 1000 updates the row
+    _agg_delta / 1000): the reference's own rows, read back from its logger by the harness over an episode of more than 3000
+    updates, against the oracle's -- bit for bit."""
+    g = engine.default_gen_params()
+    g.n_events = 8000
+    book = 5
+    rec = engine.gen_stream_host(g, 5, 2, book, 1)
+    x = {"agent_seed": 1994 + book}     # Agent::gen (the double agents' coin): seed + global book id, as the oracle seeds it
+    with tempfile.TemporaryDirectory() as td:
+        if "double" in algo:
+            x["theta_b_out"] = os.path.join(td, "tb.bin")
+        traj, info, theta = ol.run_ref_episode(rec[0], algo=algo, mem=1 << 16, rng_stream=book, extra=x)
+    rows = np.array(info["model_log"])
+    assert int(info["steps"]) >= 3000 and len(rows) == int(info["steps"]) // 1000
+    p = _params_for({}, algo, book)
+    p.memory_size = 1 << 16
+    o = ol.Oracle(p, rec)
+    o.reset()
+    o.td_step(int(info["steps"]) + 1)
+    np.testing.assert_array_equal(o.model_log(), rows)
+    assert np.all(rows > 0)
+    o.close()
 
 
 from tests.golden.make_golden import MULTI_CASES  # noqa: E402
