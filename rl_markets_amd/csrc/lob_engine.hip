@@ -1213,7 +1213,9 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                     else if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_QLAMBDA, 0>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, e->P, e->S, rnd, par, lpar, sid);
                     else if (e->P.sarsa_lanes) {
                         // a lane per generation; the wave-per-book kernel for the books it leaves on the list
-                        hipLaunchKernelGGL(trace_lane_kernel<LOB_ALGO_SARSA>, dim3((nb + LOB_TS_BLOCK / 32 - 1) / (LOB_TS_BLOCK / 32)), dim3(LOB_TS_BLOCK), 0, st, e->P, e->S, lpar, sid, 0);
+                        static const int ts_lds = getenv("LOB_TS_LDS") ? atoi(getenv("LOB_TS_LDS")) : 0, ts_grid = getenv("LOB_TS_GRID") ? atoi(getenv("LOB_TS_GRID")) : 0;  // (experiment)
+                        const int ts_full = (nb + LOB_TS_BLOCK / 32 - 1) / (LOB_TS_BLOCK / 32);
+                        hipLaunchKernelGGL(trace_lane_kernel<LOB_ALGO_SARSA>, dim3(ts_grid > 0 ? std::min(ts_grid, ts_full) : ts_full), dim3(LOB_TS_BLOCK), ts_lds, st, e->P, e->S, lpar, sid, 0);
                         hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_SARSA, 1>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, e->P, e->S, rnd, par, lpar, sid);
                     }
                     else hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_SARSA, 0>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, e->P, e->S, rnd, par, lpar, sid);
@@ -1221,7 +1223,8 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                 {
                     TimedLaunch t(e, "learn_kernel", st);
                     if (lanes) {
-                        const bool pair = e->q_pair && e->P.M < (1ll << 27) && !dq;  // (its LDS rows hold tile indices in 27 bits; one weight vector)
+                        static const bool dq_pair = !(getenv("LOB_DQ_PAIR") && getenv("LOB_DQ_PAIR")[0] == '0');  // (A/B switch: double Q on one lane per book)
+                        const bool pair = e->q_pair && e->P.M < (1ll << 27) && (!dq || dq_pair);  // (its LDS rows hold tile indices in 27 bits)
                         // the updates added to their slots by this kernel and trace_lane_kernel (lob_state.h acc_list): Q(lambda) while its
                         // books keep few generations (else accumulate_block_kernel's sums per block win)
                         acc_fused = fuse && e->acc_fuse && e->P.combine && e->P.sarsa_lanes && (e->P.algo == LOB_ALGO_QLAMBDA || dq) && !acc_blocked(e) && G == 1;
@@ -1250,12 +1253,13 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                     {
                         TimedLaunch t(e, "learn_rest_kernel", rs);
                         const int hs = (int)(e->hint_step % LOB_HINT_RING);
-                        u64* hint_dev = e->rest_hint ? e->rest_hint_dev + hs : nullptr;
+                        static const bool no_hint = getenv("LOB_NO_HINT") != nullptr;  // (experiment)
+                        u64* hint_dev = e->rest_hint && !no_hint ? e->rest_hint_dev + hs : nullptr;
                         const uint32_t hint_tag = (uint32_t)(++e->hint_serial);
                         if (dq) hipLaunchKernelGGL(learn_q_rest_kernel<LOB_ALGO_DOUBLE_Q>, dim3(gl), dim3(LOB_BLOCK), 0, rs, e->P, e->S, rnd, learn_list, learn_n, hint_dev, hint_tag);
                         else if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL(learn_q_rest_kernel<LOB_ALGO_QLAMBDA>, dim3(gl), dim3(LOB_BLOCK), 0, rs, e->P, e->S, rnd, learn_list, learn_n, hint_dev, hint_tag);
                         else hipLaunchKernelGGL(learn_q_rest_kernel<LOB_ALGO_SARSA>, dim3(gl), dim3(LOB_BLOCK), 0, rs, e->P, e->S, rnd, learn_list, learn_n, hint_dev, hint_tag);
-                        if (e->rest_hint) { HIPCHK(hipEventRecord(e->hint_ev[hs], rs)); e->hint_tags[hs] = hint_tag; e->hint_step++; }
+                        if (e->rest_hint && !no_hint) { HIPCHK(hipEventRecord(e->hint_ev[hs], rs)); e->hint_tags[hs] = hint_tag; e->hint_step++; }
                     }
                     if (side) {
                         HIPCHK(hipEventRecord(e->ev_rest_done, e->stream2));

@@ -1367,7 +1367,7 @@ __global__ void __launch_bounds__(LOB_QL_BLOCK) learn_q_lane_kernel(DevParams P,
 #define LOB_QP_CAP2 14  /* entries of the group-2 half */
 #define LOB_QP_ROW1 23  /* u32 per lane in LDS (entries packed in 32 bits: tables below 2^27 weights) */
 #define LOB_QP_ROW2 15
-#define LOB_QP_XCH 12   /* f64 per book handed from the group-1 lane to the group-2 lane: S0 + group-1 additions (9), entries (-1: none), Q(s, a), RNG counter */
+#define LOB_QP_XCH 21   /* f64 per book handed from the group-1 lane to the group-2 lane: S0 + group-1 additions (9), entries (-1: none), Q(s, a), RNG counter; double Q: the same nine sums under theta_b */
 __host__ __device__ inline size_t qpair_lds_bytes(int /*cwords4*/) {
     return (size_t)(2048 + 32) * 4 + (size_t)LOB_QP_BOOKS * (LOB_QP_ROW1 + LOB_QP_ROW2 + 2) * 4 + (size_t)LOB_QP_BOOKS * LOB_QP_XCH * 8 +
            (size_t)LOB_QP_BLOCK * LOB_QD_HCAP * 4;
@@ -1376,9 +1376,14 @@ template <int ALGO, int VT, bool TR>
 // acc_fuse (Q(lambda), TR): the update of a book whose step leaves ONE new generation is added to that generation's slot right
 // here, by the lane that has just computed the TD error (acc_generation); the listed books' by trace_lane_kernel; what neither
 // can finish goes on acc_list for accumulate_kernel.
+// LOB_ALGO_DOUBLE_Q (DoubleQLearn, agent.cpp:185-264,315-353; as learn_q_lane_kernel<LOB_ALGO_DOUBLE_Q>): both weight vectors share the
+// triples, the tiles, the folded map and the hit list -- each lane walks its group ONCE and fetches theta AND theta_b for its
+// hits; Q_a and Q_b continue from the memo's two records; the coin of the book's mt19937_64, the TD error and the addition to
+// the slot (in the sums of the vector the coin picked) are the group-2 lane's; the trace step is Watkins's over Q_a.
 __global__ void __launch_bounds__(LOB_QP_BLOCK) learn_q_pair_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g, int lpar, u64 ver, int sid, int acc_fuse) {
-    static_assert(ALGO == LOB_ALGO_SARSA || ALGO == LOB_ALGO_QLAMBDA, "one weight vector");
-    static_assert(!TR || ALGO == LOB_ALGO_QLAMBDA, "the fused trace step is Watkins's");
+    constexpr bool DQ = ALGO == LOB_ALGO_DOUBLE_Q;
+    static_assert(!TR || ALGO == LOB_ALGO_QLAMBDA || DQ, "the fused trace step is Watkins's");
+    static_assert(!DQ || TR, "double Q: with the fused trace step only");
     extern __shared__ __align__(16) unsigned char fast_lds_raw[];
     __shared__ u64 claimed[512];  // (as trace_light_kernel)
     uint32_t* rnd = reinterpret_cast<uint32_t*>(fast_lds_raw);
@@ -1433,6 +1438,7 @@ __global__ void __launch_bounds__(LOB_QP_BLOCK) learn_q_pair_kernel(DevParams P,
         CbPending pend;
         pend.active = false;
         f64 v2[LOB_QP_CAP2];  // (group-2 lane) the weights of its entries
+        f64 v2b[DQ ? LOB_QP_CAP2 : 1];  // ... under theta_b
         if (!second) {
             // ---- group-1 lane: the trace step's decisions, the group-1 walk, S0 + its additions, the trace step's stores ----
             Rng g{P.seed, P.book_id_offset + (u64)bb, h.rng_ctr};
@@ -1495,6 +1501,34 @@ __global__ void __launch_bounds__(LOB_QP_BLOCK) learn_q_pair_kernel(DevParams P,
             }
 #pragma unroll
             for (int a = 0; a < LOB_N_ACTIONS; a++) xc[a] = qs[a];
+            if (DQ) {
+                // Q_b the same way: the memo's record under theta_b (the same memo_kernel launch: same version) + the same additions
+                // with theta_b's weights
+                const f64* recb = S.mk_rec_b + (size_t)ms * LOB_MK_REC;
+                f64 qb[LOB_N_ACTIONS];
+#pragma unroll
+                for (int a = 0; a < LOB_N_ACTIONS; a++) qb[a] = walk ? recb[a] : 0.0;
+                if (walk && n <= LOB_QP_CAP1) {
+                    for (int i0 = 0; i0 < n; i0 += 4) {
+                        u64 ent[4];
+                        f64 v[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) ent[u] = i0 + u < n ? ql_unpack(row[1 + i0 + u]) : 0ull;
+#pragma unroll
+                        for (int u = 0; u < 4; u++) v[u] = i0 + u < n ? S.theta_b[(uint32_t)ent[u]] : 0.0;
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            if (v[u] == 0.0) continue;
+                            const int a = (int)(ent[u] >> 32) & 15;
+                            const f64 x = ((ent[u] >> 36) & 1ull ? w2 : w1) * v[u];
+#pragma unroll
+                            for (int c = 0; c < LOB_N_ACTIONS; c++) qb[c] = a == c ? qb[c] + x : qb[c];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < LOB_N_ACTIONS; a++) xc[12 + a] = qb[a];
+            }
             reinterpret_cast<int*>(xc + LOB_N_ACTIONS)[0] = (walk && n <= LOB_QP_CAP1) ? n : -1;
             // for the group-2 lane's addition to the slot of the generation a light step creates -- 0: listed, else bits 0-5: 1 + the
             // generation's ring slot, bits 6-30: 1 + the combine slot this lane has put on record for it (0: a claim is on its way)
@@ -1557,6 +1591,10 @@ __global__ void __launch_bounds__(LOB_QP_BLOCK) learn_q_pair_kernel(DevParams P,
             if (walk) ql_group_d<2, VT, LOB_QP_CAP2, uint32_t>(P, S, rnd, act_terms, q, hits, row, n);
 #pragma unroll
             for (int i = 0; i < LOB_QP_CAP2; i++) v2[i] = (walk && n <= LOB_QP_CAP2 && i < n) ? S.theta[row[1 + i] & 0x7ffffffu] : 0.0;  // (n beyond the row: entries not written)
+            if (DQ) {
+#pragma unroll
+                for (int i = 0; i < LOB_QP_CAP2; i++) v2b[DQ ? i : 0] = (walk && n <= LOB_QP_CAP2 && i < n) ? S.theta_b[row[1 + i] & 0x7ffffffu] : 0.0;
+            }
         }
         if (TR && acc_fuse && !second) { cb_claim_finish(S, pend); pend.active = false; }  // (the group-2 lane adds to the slot after the barrier)
         __syncthreads();
@@ -1595,7 +1633,25 @@ __global__ void __launch_bounds__(LOB_QP_BLOCK) learn_q_pair_kernel(DevParams P,
                     // Q(s, a) / the RNG counter after the trace step, as the group-1 lane left them
                     const f64 q_sa = xc[LOB_N_ACTIONS + 1];
                     Rng g{P.seed, P.book_id_offset + (u64)b, reinterpret_cast<const u64*>(xc)[LOB_N_ACTIONS + 2]};
-                    const f64 delta = learn_delta_single<ALGO>(P, hp, h, qs, q_sa, g, 0);
+                    f64 delta;
+                    int vec = 0;  // (double Q: the vector the update goes into)
+                    if (DQ) {
+                        f64 qb[LOB_N_ACTIONS];
+#pragma unroll
+                        for (int a = 0; a < LOB_N_ACTIONS; a++) qb[a] = xc[12 + a];
+#pragma unroll
+                        for (int i = 0; i < LOB_QP_CAP2; i++) {
+                            if (i < n && v2b[DQ ? i : 0] != 0.0) {
+                                const int a = (int)(row[1 + i] >> 27) & 15;
+                                const f64 x = w2 * v2b[DQ ? i : 0];
+#pragma unroll
+                                for (int c = 0; c < LOB_N_ACTIONS; c++) qb[c] = a == c ? qb[c] + x : qb[c];
+                            }
+                        }
+                        delta = learn_delta_double<false>(P, S, hp, h, b, qs, qb, q_sa, g, 0, nullptr, &vec);
+                    } else {
+                        delta = learn_delta_single<DQ ? LOB_ALGO_SARSA : ALGO>(P, hp, h, qs, q_sa, g, 0);
+                    }
                     recp[0] = (u64)(n1 + n);
                     for (int i = 0; i < n; i++) recp[1 + n1 + i] = ql_unpack(row[1 + i]);
                     if (TR && acc_fuse && !light) S.acc_pend[b] = 0;
@@ -1608,8 +1664,8 @@ __global__ void __launch_bounds__(LOB_QP_BLOCK) learn_q_pair_kernel(DevParams P,
                         bool added;
                         if (hs) {  // (the slot the group-1 lane recorded; the generation's signature = last_state's triple + the action)
                             const float4 vl = (h.slot_cur ^ 1) ? vr[1][0] : vr[0][0];
-                            added = acc_generation_at(S, gi, (int)(hs - 1u), make_int4(tile_quant(vl.x), tile_quant(vl.y), tile_quant(vl.z), h.action), 0xffffffffu, val, xcd);
-                        } else added = acc_generation(S, gi, 0xffffffffu, val, xcd);
+                            added = acc_generation_at(S, gi, (int)(hs - 1u), make_int4(tile_quant(vl.x), tile_quant(vl.y), tile_quant(vl.z), h.action), 0xffffffffu, val, xcd, vec);
+                        } else added = acc_generation(S, gi, 0xffffffffu, val, xcd, vec);
                         if (!added) S.acc_list[atomicAdd(&S.acc_list_n[lpar], 1)] = (i32)((uint32_t)b | 0x80000000u);
                     }
                 }

@@ -17,10 +17,7 @@
 
 void lobk_learn_q(hipStream_t st, bool pair, int algo, bool v8, bool tr, int grid, size_t lds, const DevParams& P, const DevState& S, const uint32_t* rnd, int lpar, u64 ver,
                   int sid, int acc_fuse) {
-    if (algo == LOB_ALGO_DOUBLE_Q) {   // (only with the fused Watkins trace step: lob_create; a lane per book)
-        if (v8) hipLaunchKernelGGL((learn_q_lane_kernel<LOB_ALGO_DOUBLE_Q, 8, true>), dim3(grid), dim3(LOB_QL_BLOCK), lds, st, P, S, rnd, lpar, ver, sid, acc_fuse);
-        else hipLaunchKernelGGL((learn_q_lane_kernel<LOB_ALGO_DOUBLE_Q, 0, true>), dim3(grid), dim3(LOB_QL_BLOCK), lds, st, P, S, rnd, lpar, ver, sid, acc_fuse);
-    }
+    if (algo == LOB_ALGO_DOUBLE_Q) LOB_QL_VT(LOB_ALGO_DOUBLE_Q, true);   // (only with the fused Watkins trace step: lob_create)
     else if (algo == LOB_ALGO_QLAMBDA && tr) LOB_QL_VT(LOB_ALGO_QLAMBDA, true);
     else if (algo == LOB_ALGO_QLAMBDA) LOB_QL_VT(LOB_ALGO_QLAMBDA, false);
     else LOB_QL_VT(LOB_ALGO_SARSA, false);
@@ -50,6 +47,8 @@ hipError_t lobk_learn_set_lds(int fast_lds, int lane_lds, int pair_lds) {
     LOB_SET((learn_q_pair_kernel<LOB_ALGO_QLAMBDA, 8, false>), pair_lds);
     LOB_SET((learn_q_pair_kernel<LOB_ALGO_QLAMBDA, 0, true>), pair_lds);
     LOB_SET((learn_q_pair_kernel<LOB_ALGO_QLAMBDA, 8, true>), pair_lds);
+    LOB_SET((learn_q_pair_kernel<LOB_ALGO_DOUBLE_Q, 0, true>), pair_lds);
+    LOB_SET((learn_q_pair_kernel<LOB_ALGO_DOUBLE_Q, 8, true>), pair_lds);
 #undef LOB_SET
     return er;
 }

@@ -307,7 +307,8 @@ CUT_SHORT = []   # cases the shadow oracle ended early (a chaotic configuration 
 
 
 VARIANTS = {
-    "dq_lane": {"LOB_Q_LANES": "1", "LOB_FUSE_ACT": "1"},   # DoubleQLearn through env_step_kernel<., true> / learn_q_lane_kernel<LOB_ALGO_DOUBLE_Q>
+    "dq_lane": {"LOB_Q_LANES": "1", "LOB_FUSE_ACT": "1", "LOB_DQ_PAIR": "0"},   # DoubleQLearn through env_step_kernel<., true> / learn_q_lane_kernel<LOB_ALGO_DOUBLE_Q>
+    "dq_pair": {"LOB_Q_LANES": "1", "LOB_FUSE_ACT": "1"},                       # ... / learn_q_pair_kernel<LOB_ALGO_DOUBLE_Q> (two lanes per book: the default)
     "lane": {"LOB_Q_LANES": "1", "LOB_Q_PAIR": "0", "LOB_FUSE_ACT": "1"},
     "pair": {"LOB_Q_LANES": "1", "LOB_Q_PAIR": "1", "LOB_FUSE_ACT": "1"},
     "pair_nofuse": {"LOB_Q_LANES": "1", "LOB_Q_PAIR": "1", "LOB_NO_FUSE": "1", "LOB_FUSE_ACT": "1"},
@@ -332,7 +333,7 @@ def test_random_configuration_timed_kernels(monkeypatch, seed, variant):
     p.theta_mode = abi.THETA_SHARED
     p.algo = int(r.choice([abi.ALGO_SARSA, abi.ALGO_QLAMBDA]))
     B = int(r.choice([3, 64, 130, 300]))
-    if variant == "dq_lane":
+    if variant.startswith("dq_"):
         p.algo = abi.ALGO_DOUBLE_Q
         p.max_trades = min(p.max_trades, 2)   # (its fused env kernel is the two-trade-slot one; more slots: the general kernels)
         g.trade2_prob_q16 = g.trade2_prob_q16 if p.max_trades > 1 else 0
