@@ -51,6 +51,10 @@ struct lob_engine {
     hipEvent_t ev_reg_go = nullptr, ev_reg_done = nullptr;  // tile registry kernels on stream2 beside the learner kernels (lob_kernels.h registry_kernel)
     hipEvent_t ev_rest_go = nullptr, ev_rest_done = nullptr;  // learn_q_rest_kernel on stream2 beside the trace kernels
     bool rest_side = true;      // (LOB_REST_SIDE=0: on the main stream, as before; A/B switch)
+    bool rest_merge = true;     // the fused Q(lambda) / double Q flow: trace_rest_kernel (LOB_REST_MERGE=0: trace_fast_kernel<., 2> + accumulate_kernel over its list; A/B switch)
+    bool dq_pair = true;        // double Q(lambda): learn_q_pair_kernel<DOUBLE_Q> (LOB_DQ_PAIR=0: a lane per book, learn_q_lane_kernel; A/B switch)
+    int ts_lds = 0, ts_grid = 0; // (experiments: trace_lane_kernel<SARSA> with dynamic LDS / a persistent grid)
+    bool no_hint = false;       // (experiment: learn_q_rest_kernel without its report to the host)
     long long flow[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // lob_debug_flow: learner steps by the shape of their update / action selection (see there)
     bool acc_fuse = true;       // Q(lambda), the pair kernel + the lane-per-generation trace kernel: updates added to their slots there, accumulate_kernel over a list (LOB_ACC_FUSE=0: over every book; A/B switch)
     bool acc_batches_set = false;
@@ -327,14 +331,25 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     HIPCHK_E(hipEventCreateWithFlags(&e->ev_reg_done, hipEventDisableTiming | hipEventDisableSystemFence));
     HIPCHK_E(hipEventCreateWithFlags(&e->ev_rest_go, hipEventDisableTiming | hipEventDisableSystemFence));
     HIPCHK_E(hipEventCreateWithFlags(&e->ev_rest_done, hipEventDisableTiming | hipEventDisableSystemFence));
-    if (const char* g = getenv("LOB_REST_SIDE")) e->rest_side = !(g[0] == '0');
-    if (const char* g = getenv("LOB_ACC_BLOCK")) e->acc_block = !(g[0] == '0');
+    // Runtime switches.  Honoured by every build: the A/B switches of first-class paths that the parity tests force on or off at
+    // sizes that would not select them (LOB_TRACE_LANES, LOB_Q_LANES, LOB_Q_PAIR, LOB_DQ_PAIR, LOB_NO_TLIGHT, LOB_NO_MEMO, LOB_NO_LIGHT,
+    // LOB_NO_FUSE, LOB_NO_COMBINE, LOB_NO_CARRY, LOB_MOSTLY_GENERAL, LOB_FUSE_ACT, LOB_ENV_LANES=16|64, LOB_ACC_LANES, LOB_ACC_FUSE,
+    // LOB_ACC_DENSE, LOB_ACC_BATCHES, LOB_REST_MERGE), the table sizes the tests squeeze (LOB_CB_SLOTS, LOB_OW_SLOTS, LOB_AMB_CAP, LOB_CBD_IDS), the track
+    // ring (LOB_TRACK_RING, LOB_TRACK_REFILL) and the exchange's form (LOB_DENSE_EXCHANGE, lob_comm.cpp).  The switches of variants
+    // measured and lost, and of timing experiments, only by a -DLOB_EXPERIMENTS build (tools/exp_variants.sh; NOTES.md): `exps`.
+    const bool exps = lobk_experiments() != 0;
+    if (const char* g = getenv("LOB_REST_SIDE")) e->rest_side = !(exps && g[0] == '0');
+    if (const char* g = getenv("LOB_ACC_BLOCK")) e->acc_block = !(exps && g[0] == '0');
+    if (const char* g = getenv("LOB_DQ_PAIR")) e->dq_pair = !(g[0] == '0');
+    if (const char* g = getenv("LOB_REST_MERGE")) e->rest_merge = !(g[0] == '0');
+    if (exps) {
+        if (const char* g = getenv("LOB_TS_LDS")) e->ts_lds = atoi(g);
+        if (const char* g = getenv("LOB_TS_GRID")) e->ts_grid = atoi(g);
+        e->no_hint = getenv("LOB_NO_HINT") != nullptr;
+    }
     if (const char* g = getenv("LOB_ACC_DENSE")) e->acc_dense = !(g[0] == '0');
     if (const char* g = getenv("LOB_ACC_FUSE")) e->acc_fuse = !(g[0] == '0');
     if (const char* g = getenv("LOB_ACC_BATCHES")) { const int v = atoi(g); if (v == 1 || v == 2 || v == 4 || v == 8) { e->acc_batches = v; e->acc_batches_set = true; } }
-    // (the variants measured and lost -- NOTES.md "Round 4" -- exist in -DLOB_EXPERIMENTS builds only, tools/exp_variants.sh; a
-    // product build ignores their switches)
-    const bool exps = lobk_experiments() != 0;
     if (const char* g = getenv("LOB_ENV_STEP_LANES")) { if (exps && atoi(g) == 32) e->env_step_lanes = 32; }
     if (const char* g = getenv("LOB_PREPASS_ROLES")) e->prepass_roles = exps && g[0] == '1';
     if (hipHostMalloc((void**)&e->rest_hint, LOB_HINT_RING * sizeof(u64), hipHostMallocMapped) == hipSuccess) {
@@ -355,15 +370,15 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     if (const char* g = getenv("LOB_TRACK_REFILL")) { int v = atoi(g); if (v >= 1) e->track_refill = v; }
     if (const char* g = getenv("LOB_ACC_LANES")) { int v = atoi(g); if (v == 8 || v == 16 || v == 32 || v == 64) e->acc_shift = v == 8 ? 3 : v == 16 ? 4 : v == 32 ? 5 : 6; }
     if (const char* g = getenv("LOB_NO_LIGHT")) e->light = !(g[0] == '1');
-    if (const char* g = getenv("LOB_NO_FUSE_ACT")) e->fuse_act = !(g[0] == '1');
+    if (const char* g = getenv("LOB_NO_FUSE_ACT")) e->fuse_act = !(exps && g[0] == '1');
     if (const char* g = getenv("LOB_FUSE_ACT")) e->force_fuse_act = g[0] == '1';  // (also for small batches: the tests)
     if (const char* g = getenv("LOB_Q_LANES")) e->q_lanes = g[0] == '1' ? 1 : 0;
     if (const char* g = getenv("LOB_NO_TLIGHT")) e->t_light = !(g[0] == '1');
     if (const char* g = getenv("LOB_Q_PAIR")) e->q_pair = !(g[0] == '0');
     if (const char* g = getenv("LOB_NO_FUSE")) e->no_fuse = g[0] == '1';
     if (const char* g = getenv("LOB_REG_FORK")) e->reg_fork_late = exps && g[0] == 'l';
-    if (const char* g = getenv("LOB_ENV_STEP")) e->env_step = !(g[0] == '0');
-    if (const char* g = getenv("LOB_INLINE_GENERAL")) e->inline_general = !(g[0] == '0');
+    if (const char* g = getenv("LOB_ENV_STEP")) e->env_step = !(exps && g[0] == '0');
+    if (const char* g = getenv("LOB_INLINE_GENERAL")) e->inline_general = !(exps && g[0] == '0');
     if (const char* g = getenv("LOB_RESET_LANES")) { int v = atoi(g); if (v == 64 || (exps && (v == 16 || v == 32))) e->reset_lanes = v; }
 
     // ---- DevParams ----
@@ -408,7 +423,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
             int n_cus = e->n_cus;
             if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) n_cus = prop.multiProcessorCount;
             const bool q_lanes = e->q_lanes >= 0 ? e->q_lanes == 1 : (long long)n_books >= (long long)LOB_QL_BLOCK * n_cus / 2;
-            const char* dqf = getenv("LOB_DQ_FAST");
+            const char* dqf = exps ? getenv("LOB_DQ_FAST") : nullptr;
             P.memo = q_lanes && e->t_light && !e->no_fuse && e->light && e->fuse_act && e->env_step && e->env_lanes == 0 && P.T <= 2 && P.combine &&
                      P.trace_gens == 32 && (n_books >= 1024 || e->force_fuse_act) && !(dqf && dqf[0] == '0');
         }
@@ -417,7 +432,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
         // SARSA(lambda): the trace step with a lane per generation (trace_sarsa_kernel, lob_fast.h) + the tile registry it needs
         // ... for every book of SARSA(lambda); for Q(lambda) where the lane-per-book learn kernel takes the light trace steps and
         // lists the books that keep their traces (the same condition as in run_steps: big batches; LOB_TRACE_LANES=0 switches it off)
-        const char* sl = getenv("LOB_SARSA_LANES");
+        const char* sl = exps ? getenv("LOB_SARSA_LANES") : nullptr;
         const char* tl = getenv("LOB_TRACE_LANES");
         bool lanes_ok = P.memo && P.combine && P.trace_gens == 32 && !(sl && sl[0] == '0') && !(tl && tl[0] == '0');
         if (lanes_ok && (P.algo == LOB_ALGO_QLAMBDA || dq)) {
@@ -512,7 +527,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
         // 25 generations per book, and the greedy books crowd onto a few (triple, action) pairs: 0.44 ms per step with one copy at
         // epsilon = 0.01).  One copy per XCD for every algorithm on the fast path; apply_kernel adds them up.
         S.cb_reps = P.memo ? 8 : 1;
-        if (const char* g = getenv("LOB_ACC_REPS")) { int v = atoi(g); if (v == 1 || v == 2 || v == 4 || v == 8 || (exps && (v == 16 || v == 32 || v == 64))) S.cb_reps = v; }
+        if (const char* g = getenv("LOB_ACC_REPS")) { int v = atoi(g); if (exps && (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64)) S.cb_reps = v; }
         if (rc == LOB_OK) rc = dev_alloc(e, &S.cb_acc, (size_t)S.cb_reps * slots * 2);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.cb_touch, (size_t)slots);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.cb_list, 2 * (size_t)slots);
@@ -629,6 +644,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
             if (er == hipSuccess) er = hipFuncSetAttribute((const void*)trace_fast_kernel<LOB_ALGO_QLAMBDA, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, tr_lds);
             if (er == hipSuccess) er = hipFuncSetAttribute((const void*)trace_fast_kernel<LOB_ALGO_QLAMBDA, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, tr_lds);
             if (er == hipSuccess) er = hipFuncSetAttribute((const void*)trace_fast_kernel<LOB_ALGO_QLAMBDA, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, tr_lds);
+            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)trace_rest_kernel<LOB_ALGO_QLAMBDA>, hipFuncAttributeMaxDynamicSharedMemorySize, tr_lds);
             if (er != hipSuccess && rc == LOB_OK) { lob_set_error(std::string("hipFuncSetAttribute(dynamic LDS): ") + hipGetErrorString(er)); rc = LOB_EHIP; }
         }
     }
@@ -1141,6 +1157,7 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
         }
         bool rest_pending = false;
         bool acc_fused = false;  // (this step: see the learn kernel's launch)
+        bool rest_merged = false;  // ... and then trace_rest_kernel instead of trace_fast_kernel<., 2> + accumulate_kernel over its list
         bool rest_side_now = false;
         const bool dq = e->P.algo == LOB_ALGO_DOUBLE_Q;  // (fast && dq: every step without usable hit lists takes the general act kernel over the whole batch)
         const int lpar = first ? (e->list_par ^= 1) : e->list_par;
@@ -1213,9 +1230,10 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                     else if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_QLAMBDA, 0>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, e->P, e->S, rnd, par, lpar, sid);
                     else if (e->P.sarsa_lanes) {
                         // a lane per generation; the wave-per-book kernel for the books it leaves on the list
-                        static const int ts_lds = getenv("LOB_TS_LDS") ? atoi(getenv("LOB_TS_LDS")) : 0, ts_grid = getenv("LOB_TS_GRID") ? atoi(getenv("LOB_TS_GRID")) : 0;  // (experiment)
+                        // (LOB_TS_GRID / LOB_TS_LDS, experiments: fewer, persistent blocks / dynamic LDS to throttle the occupancy -- halving
+                        // it costs 28 %, a persistent grid changes nothing: NOTES.md "Round 5")
                         const int ts_full = (nb + LOB_TS_BLOCK / 32 - 1) / (LOB_TS_BLOCK / 32);
-                        hipLaunchKernelGGL(trace_lane_kernel<LOB_ALGO_SARSA>, dim3(ts_grid > 0 ? std::min(ts_grid, ts_full) : ts_full), dim3(LOB_TS_BLOCK), ts_lds, st, e->P, e->S, lpar, sid, 0);
+                        hipLaunchKernelGGL(trace_lane_kernel<LOB_ALGO_SARSA>, dim3(e->ts_grid > 0 ? std::min(e->ts_grid, ts_full) : ts_full), dim3(LOB_TS_BLOCK), e->ts_lds, st, e->P, e->S, lpar, sid, 0);
                         hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_SARSA, 1>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, e->P, e->S, rnd, par, lpar, sid);
                     }
                     else hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_SARSA, 0>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, e->P, e->S, rnd, par, lpar, sid);
@@ -1223,17 +1241,17 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                 {
                     TimedLaunch t(e, "learn_kernel", st);
                     if (lanes) {
-                        static const bool dq_pair = !(getenv("LOB_DQ_PAIR") && getenv("LOB_DQ_PAIR")[0] == '0');  // (A/B switch: double Q on one lane per book)
-                        const bool pair = e->q_pair && e->P.M < (1ll << 27) && (!dq || dq_pair);  // (its LDS rows hold tile indices in 27 bits)
+                        const bool pair = e->q_pair && e->P.M < (1ll << 27) && (!dq || e->dq_pair);  // (its LDS rows hold tile indices in 27 bits)
                         // the updates added to their slots by this kernel and trace_lane_kernel (lob_state.h acc_list): Q(lambda) while its
                         // books keep few generations (else accumulate_block_kernel's sums per block win)
                         acc_fused = fuse && e->acc_fuse && e->P.combine && e->P.sarsa_lanes && (e->P.algo == LOB_ALGO_QLAMBDA || dq) && !acc_blocked(e) && G == 1;
                         // (not while the learn kernel hands most books back -- a dense theta: every one of them would go on the list
                         // through one counter; the list's length of a few steps ago, as launch_env_fused reads it)
                         if (e->hint_now > std::max(1024, e->B / 16)) acc_fused = false;
+                        rest_merged = acc_fused && e->rest_merge;
                         const int gq = pair ? std::min(LOB_QP_OCC * e->n_cus, (nb + LOB_QP_BOOKS - 1) / LOB_QP_BOOKS) : std::min(e->n_cus, (nb + LOB_QL_BLOCK - 1) / LOB_QL_BLOCK);
                         const size_t lds = pair ? qpair_lds_bytes(e->P.cwords4) : qlane_lds_bytes(e->P.cwords4);
-                        lobk_learn_q(st, pair, e->P.algo, e->P.V == 8, fuse, gq, lds, e->P, e->S, rnd, lpar, ver, sid, acc_fused ? 1 : 0);
+                        lobk_learn_q(st, pair, e->P.algo, e->P.V == 8, fuse, gq, lds, e->P, e->S, rnd, lpar, ver, sid, acc_fused ? (rest_merged ? 2 : 1) : 0);
                     } else lobk_learn_q_fast(st, e->P.algo, gf, fast_lds_bytes(e->P.cwords4, LOB_FAST_NB, false), e->P, e->S, rnd, lpar, ver);
                 }
                 {
@@ -1253,7 +1271,7 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                     {
                         TimedLaunch t(e, "learn_rest_kernel", rs);
                         const int hs = (int)(e->hint_step % LOB_HINT_RING);
-                        static const bool no_hint = getenv("LOB_NO_HINT") != nullptr;  // (experiment)
+                        const bool no_hint = e->no_hint;  // (experiment: the hint's store to host memory costs the kernel 3.5 us and the step nothing)
                         u64* hint_dev = e->rest_hint && !no_hint ? e->rest_hint_dev + hs : nullptr;
                         const uint32_t hint_tag = (uint32_t)(++e->hint_serial);
                         if (dq) hipLaunchKernelGGL(learn_q_rest_kernel<LOB_ALGO_DOUBLE_Q>, dim3(gl), dim3(LOB_BLOCK), 0, rs, e->P, e->S, rnd, learn_list, learn_n, hint_dev, hint_tag);
@@ -1273,8 +1291,9 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                     // the listed books (their traces survive the step): a lane per generation, then the wave-per-book kernel for
                     // those the lane kernel hands on
                     if (e->P.sarsa_lanes)
-                        hipLaunchKernelGGL(trace_lane_kernel<LOB_ALGO_QLAMBDA>, dim3(std::min(4 * e->n_cus, (nb + LOB_TS_BLOCK / 32 - 1) / (LOB_TS_BLOCK / 32))), dim3(LOB_TS_BLOCK), 0, st, e->P, e->S, lpar, sid, acc_fused ? 1 : 0);
-                    hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_QLAMBDA, 2>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, e->P, e->S, rnd, par, lpar, sid);
+                        hipLaunchKernelGGL(trace_lane_kernel<LOB_ALGO_QLAMBDA>, dim3(std::min(4 * e->n_cus, (nb + LOB_TS_BLOCK / 32 - 1) / (LOB_TS_BLOCK / 32))), dim3(LOB_TS_BLOCK), 0, st, e->P, e->S, lpar, sid, acc_fused ? (rest_merged ? 2 : 1) : 0);
+                    // (rest_merged: what the lane kernel hands on is served by trace_rest_kernel, in the place of accumulate_kernel below)
+                    if (!rest_merged) hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_QLAMBDA, 2>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, e->P, e->S, rnd, par, lpar, sid);
                 }
             } else if (mode == 0) {
                 TimedLaunch t(e, "learn_kernel", st);
@@ -1317,6 +1336,10 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                     // they send to memory; mostly-greedy Q(lambda) 58 -> 50 us with four)
                     const int nbat = e->acc_batches_set ? e->acc_batches : (e->P.algo == LOB_ALGO_SARSA ? 1 : std::max(1, std::min(e->acc_batches, e->B / (16 * LOB_ACB_BLOCK))));
                     hipLaunchKernelGGL(accumulate_block_kernel, dim3((e->B + LOB_ACB_BLOCK * nbat - 1) / (LOB_ACB_BLOCK * nbat), e->P.trace_kmax), dim3(LOB_ACB_BLOCK), 0, e->stream, e->P, e->S, par, e->step_id, nbat);
+                } else if (rest_merged) {
+                    // the books the lane trace kernel handed on (trace step + their sums) and what the fused accumulation left, in one launch
+                    hipLaunchKernelGGL(trace_rest_kernel<LOB_ALGO_QLAMBDA>, dim3(std::min(e->n_cus, (std::min(e->B, 4096) + LOB_TRACE_WAVES - 1) / LOB_TRACE_WAVES)), dim3(LOB_TRACE_BLOCK),
+                                       trace_lds_bytes(), e->stream, e->P, e->S, rnd, par, lpar, e->step_id, acc_lanes_shift(e));
                 } else if (acc_fused) {
                     // what the fused accumulation left: a few hundred books (the grid's waves stride over the list)
                     const int sh = acc_lanes_shift(e);

@@ -567,6 +567,85 @@ __global__ void __launch_bounds__(LOB_TRACE_BLOCK, LOB_TRACE_OCC) trace_fast_ker
     }
     cb_claim_finish(S, prev);
 }
+// trace_rest_kernel: the two near-empty launches behind trace_lane_kernel in the fused Q(lambda) / double Q flow --
+// trace_fast_kernel<., 2> over what the lane kernel hands on (`tr_list2`) and accumulate_kernel over what the fused accumulation
+// left (`acc_list`) -- as ONE: in most steps both lists hold nothing or a handful of books, and such a launch costs its 5-6 us
+// of dependency whatever its grid (NOTES.md "Round 4").  The one ordering the two had between them -- a book's generations are
+// added up after its trace step -- is kept inside a wave: the wave that runs a handed-on book's trace step finishes the step's
+// claim at once and adds the book's generations up itself (accumulate_generations), and trace_lane_kernel (acc_fuse = 2) no
+// longer puts such a book on `acc_list`.  Its TD error is final: learn_q_rest_kernel runs before trace_lane_kernel in this flow.
+template <int ALGO>
+__global__ void __launch_bounds__(LOB_TRACE_BLOCK, LOB_TRACE_OCC) trace_rest_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g, int par, int lpar, int sid,
+                                                                                    int lpb_shift) {
+    extern __shared__ __align__(16) unsigned char fast_lds_raw[];
+    // this step's update appends to nz_new[par]; the list the general act path reads is nz_new[par ^ 1] (as trace_fast_kernel)
+    if (blockIdx.x == 0 && threadIdx.x < LOB_NZ_WORDS) {
+        S.nz_new[par * LOB_NZ_WORDS + threadIdx.x] = 0;
+        S.nz_new[(2 + par) * LOB_NZ_WORDS + threadIdx.x] = 0;
+    }
+    const int n_tr = S.tr_list2_n[lpar], n_acc = S.acc_list_n[lpar];
+    if (n_tr == 0 && n_acc == 0) return;  // the usual case
+    const int w = threadIdx.x >> 6;
+    const int wave = blockIdx.x * LOB_TRACE_WAVES + w, n_waves = gridDim.x * LOB_TRACE_WAVES;
+    const int xcd = acc_copy(S, wave);
+    int lane_ = threadIdx.x & 63;
+    if (n_tr > 0) {  // (block-uniform)
+        uint32_t* rnd = reinterpret_cast<uint32_t*>(fast_lds_raw);
+        uint32_t* act_terms = rnd + 2048;
+        f32* vars = reinterpret_cast<f32*>(act_terms + 32) + w * 48;
+        u64* tab = reinterpret_cast<u64*>(reinterpret_cast<f32*>(act_terms + 32) + LOB_TRACE_WAVES * 48) + (size_t)w * LOB_HSLOTS;
+        for (int i = threadIdx.x; i < 512; i += LOB_TRACE_BLOCK) reinterpret_cast<uint4*>(rnd)[i] = reinterpret_cast<const uint4*>(rnd_g)[i];
+        if (threadIdx.x < 27) act_terms[threadIdx.x] = rnd_g[2048 + threadIdx.x];
+        for (int i = threadIdx.x & 63; i < LOB_TSLOTS / 4; i += 64)  // every wave's tile set starts (and is handed on) empty
+            reinterpret_cast<uint4*>(tab)[i] = make_uint4(LOB_NOTILE, LOB_NOTILE, LOB_NOTILE, LOB_NOTILE);
+        __syncthreads();
+#pragma unroll 1
+        for (int t = wave; t < n_tr; t += n_waves) {
+            asm volatile("" : "+v"(lane_));
+            const int lane = lane_;
+            const int ent = __builtin_amdgcn_readfirstlane(S.tr_list2[t]);
+            const int b = LOB_TRL_BOOK(ent);
+            const LHdr h = S.hdr[b];
+            const int lslot = P.memo ? S.mk_slot_last[b] : -1;
+            f64 qs_last[LOB_N_ACTIONS];
+#pragma unroll
+            for (int a = 0; a < LOB_N_ACTIONS; a++) qs_last[a] = S.qs_last[(size_t)b * LOB_N_ACTIONS + a];
+            if (!h.stepped) continue;
+            const int4 lid = *reinterpret_cast<const int4*>(S.mk_ident + (size_t)(lslot >= 0 ? lslot : 0) * 4);
+            Prof pf;
+            pf.start(S.prof, b, lane);
+            learn_stage_vars(S.vars + (size_t)b * 48, vars, lane);
+            const int last = h.slot_cur ^ 1;
+            const bool zero_last = (h.zero_mask >> last) & 1;
+            const int qvl = tile_quant(vars[last * 16 + (lane & 15)]);
+            const bool lmatch = lslot >= 0 && !zero_last && lid.x == __builtin_amdgcn_readlane(qvl, 0) && lid.y == __builtin_amdgcn_readlane(qvl, 1) &&
+                                lid.z == __builtin_amdgcn_readlane(qvl, 2);
+            Rng g{P.seed, P.book_id_offset + (u64)b, h.rng_ctr};
+            CbPending pend;
+            bool dup = false;
+            int mtag = -1;
+            if (P.sarsa_lanes && lmatch && S.mk_tiles_ok[lslot] == 3) mtag = lslot | ((P.epi_epoch & 0x7fff) << 16);
+            learn_traces<ALGO>(P, S, b, h, rnd, act_terms, tab, false, vars + last * 16, zero_last, qs_last, g, lane, pend, pf, lmatch ? lid.w : 0, &dup,
+                               LOB_TRL_AMAX(ent), sid, mtag);
+            if (lmatch && lid.w == 0 && lane == 0) S.mk_ident[(size_t)lslot * 4 + 3] = dup ? 2 : 1;
+            cb_claim_finish(S, pend);  // (at once: the generation's slot is looked up right below)
+            // the book's generations as the trace step has left them (header, masks, slots: this wave's own stores)
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+            __builtin_amdgcn_wave_barrier();
+            accumulate_generations(P, S, par, sid, xcd, 64, lane, b, false, lane);
+        }
+    }
+    // ---- what the fused accumulation left (accumulate_kernel over `acc_list`) ----
+    const int lane = threadIdx.x & 63;
+    const int lpb = 1 << lpb_shift, sub = lane & (lpb - 1);
+#pragma unroll 1
+    for (int wv = wave; (wv << (6 - lpb_shift)) < n_acc; wv += n_waves) {
+        const int i = (wv << (6 - lpb_shift)) + (lane >> lpb_shift);
+        const bool have = i < n_acc;
+        const uint32_t ent = have ? (uint32_t)S.acc_list[i] : 0u;
+        accumulate_generations(P, S, par, sid, xcd, lpb, sub, have ? (int)(ent & 0x7fffffffu) : S.B, have && (ent >> 31) != 0, lane);
+    }
+}
 // Agent::UpdateTraces with one LANE per book, for the books whose step leaves no older generation behind -- Watkins's
 // cut after an exploratory action (QLearn::UpdateTraces, agent.cpp:272-280: traces.decay(0.0)), or no traces yet --
 // and whose last_state has a memo slot with its 288 group-0 tiles on record and known to be distinct: the new
@@ -745,7 +824,9 @@ __global__ void __launch_bounds__(LOB_TS_BLOCK, 5) trace_lane_kernel(DevParams P
                     if (QL) S.tr_list2[atomicAdd(&S.tr_list2_n[lpar], 1)] = ent;
                     else S.tr_list[atomicAdd(&S.tr_list_n[lpar], 1)] = b;
                     atomicAdd((unsigned long long*)&S.counters[6], 1ull);
-                    if (fuse_acc) S.acc_list[atomicAdd(&S.acc_list_n[lpar], 1)] = b;  // (the wave-per-book kernel does its traces: all its generations are accumulate_kernel's)
+                    // (the wave-per-book kernel does its traces: all its generations are accumulate_kernel's -- or, acc_fuse = 2,
+                    // trace_rest_kernel's own wave adds them up right behind the trace step)
+                    if (fuse_acc && acc_fuse != 2) S.acc_list[atomicAdd(&S.acc_list_n[lpar], 1)] = b;
                 }
                 continue;
             }

@@ -1538,6 +1538,103 @@ __device__ inline bool acc_generation(const DevState& S, size_t gi, uint32_t mas
     if (!(cs >= 0 && (cs & LOB_CBS_VERIFIED))) sg = *reinterpret_cast<const int4*>(S.tr_sig + gi * 4);
     return acc_generation_at(S, gi, cs, sg, mask, val, xcd, target);
 }
+// The generations of ONE book (per lane group of `lpb` lanes: lane `sub` of the group takes the ages sub, sub + lpb, ...) added to
+// their slots; `direct_only`: only those without a slot.  Called by whole waves (the direct path ballots): accumulate_kernel with
+// 64 >> lpb_shift books per wave, trace_rest_kernel with one.
+__device__ __forceinline__ void accumulate_generations(const DevParams& P, const DevState& S, int par, int sid, int xcd, int lpb, int sub, int b, bool direct_only, int lane) {
+    int n = 0, head = 0, target = 0;
+    f64 scaled = 0.0;
+    if (b < S.B) {
+        const LHdr& h = S.hdr[b];
+        if (h.stepped) {
+            n = h.tr_n;
+            head = h.tr_head;
+            scaled = h.upd / (f64)LOB_N_TILINGS;
+            target = h.stepped == 2 ? 1 : 0;
+        }
+    }
+    const int G = P.trace_gens;
+    const int bb = b < S.B ? b : 0;
+    const uint32_t* tr_alive = S.tr_alive + (size_t)bb * G;
+    const i32* tr_sig = S.tr_sig + (size_t)bb * G * 4;
+    for (int base = 0; base < G; base += lpb) {
+        const int age = base + sub;
+        if (!__any(age < n)) break;
+        const int slot = (head - age + G) & (G - 1);
+        uint32_t mask = 0;
+        int4 sg = make_int4(0, 0, 0, 0);
+        int cs = -1;
+        if (age < n) {
+            mask = tr_alive[slot];
+            cs = S.tr_cbslot[(size_t)bb * G + slot];  // where the generation's claim ended (cb_claim_finish)
+        }
+        // LOB_CBS_VERIFIED: an earlier step has compared this slot's identity with the generation's, and neither has changed since
+        // (a claim rewrites tr_cbslot; the slot cannot have been freed: the generation added to it in every step in between)
+        if (direct_only && cs >= 0) mask = 0;  // (its update is in its slot already: acc_generation)
+        const bool known = mask != 0 && cs >= 0 && (cs & LOB_CBS_VERIFIED);
+        if (mask != 0 && !known) sg = *reinterpret_cast<const int4*>(tr_sig + slot * 4);
+        bool direct = false;
+        if (mask) {
+            bool found = known;
+            uint32_t s = (uint32_t)cs & (uint32_t)(S.cb_slots - 1);
+            if (!known && cs >= 0) {  // the slot the generation's claim ended on (or, for a claim another lane made, the hash's home slot)
+                const int4 id = *reinterpret_cast<const int4*>(S.cb_ident + (size_t)s * 8);
+                const uint32_t idm = (uint32_t)S.cb_ident[(size_t)s * 8 + 4];  // (0 in a free slot; mask != 0 here)
+                found = id.x == sg.x && id.y == sg.y && id.z == sg.z && id.w == sg.w && idm == mask;
+            }
+            if (!found) {  // (a displaced slot: walk the probe sequence)
+                const u64 hsh = cb_hash(sg.x, sg.y, sg.z, sg.w, mask);
+                s = (uint32_t)hsh & (uint32_t)(S.cb_slots - 1);
+                for (int probe = 0; probe < LOB_CB_PROBES; probe++) {
+                    const u64 kk = S.cb_key[s];
+                    if (kk == hsh) {
+                        const i32* id = S.cb_ident + (size_t)s * 8;
+                        found = id[0] == sg.x && id[1] == sg.y && id[2] == sg.z && id[3] == sg.w && (uint32_t)id[4] == mask;
+                        if (found) break;  // (another identity with this hash: the claim may have walked on past it)
+                    }
+                    if (kk == LOB_CB_EMPTY) break;
+                    s = (s + 1) & (uint32_t)(S.cb_slots - 1);
+                }
+            }
+            if (found && !known) {
+                S.tr_cbslot[(size_t)bb * G + slot] = (i32)(s | LOB_CBS_VERIFIED);
+                if (S.tr_cbd) S.tr_cbd[(size_t)bb * G + slot] = ~0ull;
+            }
+            if (found) {
+                __hip_atomic_fetch_add(&S.cb_acc[((size_t)xcd * S.cb_slots + s) * 2 + target], scaled * (f64)P.trace_pow[age], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!(S.cb_touch[s] & (1u << target))) atomicOr(&S.cb_touch[s], 1u << target);
+            } else {
+                direct = true;
+            }
+        }
+        u64 todo = __ballot(direct);
+        while (todo) {  // rare: apply these generations tile by tile, the whole wave per generation
+            const int src = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int d_b = __shfl(bb, src), d_age = __shfl(age, src), d_head = __shfl(head, src), d_t = __shfl(target, src);
+            const uint32_t m = __shfl(mask, src);
+            const f64 d_scaled = readlane_f64(scaled, src);
+            f64* theta = d_t ? S.theta_b : S.theta;
+            uint32_t* nz = d_t ? S.theta_b_nz : S.theta_nz;
+            const int sl = (d_head - d_age + G) & (G - 1);
+            const int j = lane & 31;
+            if (lane < 32 && ((m >> j) & 1u)) {
+                const i32 f = S.tr_idx[((size_t)d_b * G + sl) * 32 + j];
+                __hip_atomic_fetch_add(&theta[f], d_scaled * (f64)P.trace_pow[d_age], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (P.memo) nzx_mark_late(P, S, f, sid);  // (one map for both weight vectors of double Q: written in either)
+                const uint32_t bit = LOB_NZ_BIT(f);
+                if (!(nz[LOB_NZ_WORD(f)] & bit)) {
+                    const uint32_t old = atomicOr(&nz[LOB_NZ_WORD(f)], bit);
+                    if (!(old & bit) && P.carry_verdicts) {
+                        i32* nz_new = S.nz_new + (2 * d_t + par) * LOB_NZ_WORDS;
+                        atomicAdd(&nz_new[0], 1);
+                        atomicOr((uint32_t*)&nz_new[LOB_NZ_FILTER + (LOB_NZ_WORD(f) & (LOB_NZ_FILTER - 1))], bit);
+                    }
+                }
+            }
+        }
+    }
+}
 // `list` (or null: every book): accumulate_kernel over the books the fused accumulation left (lob_state.h acc_list); an entry
 // with bit 31 takes only the book's generations without a slot.
 #if LOB_IN_MAIN
@@ -1548,6 +1645,9 @@ __global__ void __launch_bounds__(LOB_BLOCK) accumulate_kernel(DevParams P, DevS
     const int wave = blockIdx.x * LOB_WAVES_PER_BLOCK + (threadIdx.x >> 6);
     const int n_waves = gridDim.x * LOB_WAVES_PER_BLOCK;
     const int nl = list ? *list_n : 0;
+    // the sums are kept in S.cb_reps copies, one per XCD (apply_kernel adds them up): the additions to a popular generation's
+    // slot queue up behind each other at one address
+    const int xcd = acc_copy(S, wave);  // (more than one copy per XCD -- LOB_ACC_REPS=16|32|64, an experiment: the waves of an XCD spread over cb_reps / 8 copies)
     // (the list: the grid's waves stride over it; every book: one pass)
 #pragma unroll 1
     for (int wv = wave;; wv += n_waves) {
@@ -1560,101 +1660,7 @@ __global__ void __launch_bounds__(LOB_BLOCK) accumulate_kernel(DevParams P, DevS
             direct_only = have && (ent >> 31) != 0;
             b = have ? (int)(ent & 0x7fffffffu) : S.B;
         }
-        int n = 0, head = 0, target = 0;
-        f64 scaled = 0.0;
-        if (b < S.B) {
-            const LHdr& h = S.hdr[b];
-            if (h.stepped) {
-                n = h.tr_n;
-                head = h.tr_head;
-                scaled = h.upd / (f64)LOB_N_TILINGS;
-                target = h.stepped == 2 ? 1 : 0;
-            }
-        }
-        const int G = P.trace_gens;
-        const int bb = b < S.B ? b : 0;
-        const uint32_t* tr_alive = S.tr_alive + (size_t)bb * G;
-        const i32* tr_sig = S.tr_sig + (size_t)bb * G * 4;
-        // the sums are kept in S.cb_reps copies, one per XCD (apply_kernel adds them up): the additions to a popular generation's
-        // slot queue up behind each other at one address
-        const int xcd = acc_copy(S, wave);  // (more than one copy per XCD -- LOB_ACC_REPS=16|32|64, an experiment: the waves of an XCD spread over cb_reps / 8 copies)
-        for (int base = 0; base < G; base += lpb) {
-            const int age = base + sub;
-            if (!__any(age < n)) break;
-            const int slot = (head - age + G) & (G - 1);
-            uint32_t mask = 0;
-            int4 sg = make_int4(0, 0, 0, 0);
-            int cs = -1;
-            if (age < n) {
-                mask = tr_alive[slot];
-                cs = S.tr_cbslot[(size_t)bb * G + slot];  // where the generation's claim ended (cb_claim_finish)
-            }
-            // LOB_CBS_VERIFIED: an earlier step has compared this slot's identity with the generation's, and neither has changed since
-            // (a claim rewrites tr_cbslot; the slot cannot have been freed: the generation added to it in every step in between)
-            if (direct_only && cs >= 0) mask = 0;  // (its update is in its slot already: acc_generation)
-            const bool known = mask != 0 && cs >= 0 && (cs & LOB_CBS_VERIFIED);
-            if (mask != 0 && !known) sg = *reinterpret_cast<const int4*>(tr_sig + slot * 4);
-            bool direct = false;
-            if (mask) {
-                bool found = known;
-                uint32_t s = (uint32_t)cs & (uint32_t)(S.cb_slots - 1);
-                if (!known && cs >= 0) {  // the slot the generation's claim ended on (or, for a claim another lane made, the hash's home slot)
-                    const int4 id = *reinterpret_cast<const int4*>(S.cb_ident + (size_t)s * 8);
-                    const uint32_t idm = (uint32_t)S.cb_ident[(size_t)s * 8 + 4];  // (0 in a free slot; mask != 0 here)
-                    found = id.x == sg.x && id.y == sg.y && id.z == sg.z && id.w == sg.w && idm == mask;
-                }
-                if (!found) {  // (a displaced slot: walk the probe sequence)
-                    const u64 hsh = cb_hash(sg.x, sg.y, sg.z, sg.w, mask);
-                    s = (uint32_t)hsh & (uint32_t)(S.cb_slots - 1);
-                    for (int probe = 0; probe < LOB_CB_PROBES; probe++) {
-                        const u64 kk = S.cb_key[s];
-                        if (kk == hsh) {
-                            const i32* id = S.cb_ident + (size_t)s * 8;
-                            found = id[0] == sg.x && id[1] == sg.y && id[2] == sg.z && id[3] == sg.w && (uint32_t)id[4] == mask;
-                            if (found) break;  // (another identity with this hash: the claim may have walked on past it)
-                        }
-                        if (kk == LOB_CB_EMPTY) break;
-                        s = (s + 1) & (uint32_t)(S.cb_slots - 1);
-                    }
-                }
-                if (found && !known) {
-                    S.tr_cbslot[(size_t)bb * G + slot] = (i32)(s | LOB_CBS_VERIFIED);
-                    if (S.tr_cbd) S.tr_cbd[(size_t)bb * G + slot] = ~0ull;
-                }
-                if (found) {
-                    __hip_atomic_fetch_add(&S.cb_acc[((size_t)xcd * S.cb_slots + s) * 2 + target], scaled * (f64)P.trace_pow[age], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (!(S.cb_touch[s] & (1u << target))) atomicOr(&S.cb_touch[s], 1u << target);
-                } else {
-                    direct = true;
-                }
-            }
-            u64 todo = __ballot(direct);
-            while (todo) {  // rare: apply these generations tile by tile, the whole wave per generation
-                const int src = __builtin_ctzll(todo);
-                todo &= todo - 1;
-                const int d_b = __shfl(bb, src), d_age = __shfl(age, src), d_head = __shfl(head, src), d_t = __shfl(target, src);
-                const uint32_t m = __shfl(mask, src);
-                const f64 d_scaled = readlane_f64(scaled, src);
-                f64* theta = d_t ? S.theta_b : S.theta;
-                uint32_t* nz = d_t ? S.theta_b_nz : S.theta_nz;
-                const int sl = (d_head - d_age + G) & (G - 1);
-                const int j = lane & 31;
-                if (lane < 32 && ((m >> j) & 1u)) {
-                    const i32 f = S.tr_idx[((size_t)d_b * G + sl) * 32 + j];
-                    __hip_atomic_fetch_add(&theta[f], d_scaled * (f64)P.trace_pow[d_age], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (P.memo) nzx_mark_late(P, S, f, sid);  // (one map for both weight vectors of double Q: written in either)
-                    const uint32_t bit = LOB_NZ_BIT(f);
-                    if (!(nz[LOB_NZ_WORD(f)] & bit)) {
-                        const uint32_t old = atomicOr(&nz[LOB_NZ_WORD(f)], bit);
-                        if (!(old & bit) && P.carry_verdicts) {
-                            i32* nz_new = S.nz_new + (2 * d_t + par) * LOB_NZ_WORDS;
-                            atomicAdd(&nz_new[0], 1);
-                            atomicOr((uint32_t*)&nz_new[LOB_NZ_FILTER + (LOB_NZ_WORD(f) & (LOB_NZ_FILTER - 1))], bit);
-                        }
-                    }
-                }
-            }
-        }
+        accumulate_generations(P, S, par, sid, xcd, lpb, sub, b, direct_only, lane);
         if (!list) break;
     }
 }

@@ -312,6 +312,9 @@ VARIANTS = {
     "lane": {"LOB_Q_LANES": "1", "LOB_Q_PAIR": "0", "LOB_FUSE_ACT": "1"},
     "pair": {"LOB_Q_LANES": "1", "LOB_Q_PAIR": "1", "LOB_FUSE_ACT": "1"},
     "pair_nofuse": {"LOB_Q_LANES": "1", "LOB_Q_PAIR": "1", "LOB_NO_FUSE": "1", "LOB_FUSE_ACT": "1"},
+    # ("pair": what the lane trace kernel hands on and what the fused accumulation left are served by ONE launch, trace_rest_kernel;
+    # here by trace_fast_kernel<., 2> + accumulate_kernel over its list, the two launches it replaced)
+    "pair_rest_split": {"LOB_Q_LANES": "1", "LOB_Q_PAIR": "1", "LOB_FUSE_ACT": "1", "LOB_REST_MERGE": "0"},
     # (Q(lambda): "pair" adds the updates to their slots inside the learn / trace kernels; here accumulate_kernel does, over every book)
     "pair_acc_pass": {"LOB_Q_LANES": "1", "LOB_Q_PAIR": "1", "LOB_FUSE_ACT": "1", "LOB_ACC_FUSE": "0"},
 }
@@ -412,8 +415,8 @@ def test_zz_update_paths_the_sweep_went_through():
     if not FLOWS:
         pytest.skip("the sweep did not run in this session")
     ql = [(v, f) for v, a, f in FLOWS if a == abi.ALGO_QLAMBDA]
-    in_place = [f for v, f in ql if v == "pair" and f["added_in_place"] > 0 and f["every_book"] == 0]
+    in_place = [f for v, f in ql if v in ("pair", "pair_rest_split") and f["added_in_place"] > 0 and f["every_book"] == 0]
     whole = [f for v, f in ql if v == "pair_acc_pass" and f["every_book"] > 0]
     print("Q(lambda) cases with updates added in place: %d, with the accumulate pass over every book: %d" % (len(in_place), len(whole)))
-    assert len(in_place) >= 3 and len(whole) >= 3
-    assert all(f["added_in_place"] == 0 for v, f in ql if v != "pair" and v != "lane")
+    assert len(in_place) >= 6 and len(whole) >= 3
+    assert all(f["added_in_place"] == 0 for v, f in ql if v not in ("pair", "pair_rest_split", "lane"))
