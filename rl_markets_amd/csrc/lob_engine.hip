@@ -1163,7 +1163,14 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
         const int lpar = first ? (e->list_par ^= 1) : e->list_par;
         e->last_par = par;
         if (mode == 0) e->S.cb_par = par;  // (DevState goes to the kernels by value: the launches below see it)
-        e->S.cb_dense_on = e->S.cb_dense && acc_blocked(e) ? 1 : 0;  // (slots claimed from here on take a dense id)
+        {
+            // slots claimed from here on take a dense id while the update sums per block.  The generations' records of their slots'
+            // ids (tr_cbd) are only kept up by accumulate_dense_kernel: whenever the mode comes on (epsilon has fallen below 0.34,
+            // lob_set_epsilon), every record is void -- the kernels that verified slots meanwhile did not look ids up
+            const int on = e->S.cb_dense && acc_blocked(e) ? 1 : 0;
+            if (on && !e->S.cb_dense_on) HIPCHK(hipMemsetAsync(e->S.tr_cbd, 0xff, (size_t)e->B * e->P.trace_gens * 8, e->stream));
+            e->S.cb_dense_on = on;
+        }
         for (int g = 0; g < G; g++) {
             hipStream_t st = g == 0 ? e->stream : e->stream2;
             const int b0 = (int)((long long)e->B * g / G), nb = (int)((long long)e->B * (g + 1) / G) - b0;

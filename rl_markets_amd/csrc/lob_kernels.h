@@ -1525,7 +1525,8 @@ __device__ inline bool acc_generation_at(const DevState& S, size_t gi, int cs, i
             if (found) touch = S.cb_touch[s];
         }
         S.tr_cbslot[gi] = found ? (i32)(s | LOB_CBS_VERIFIED) : -1;
-        if (S.tr_cbd) S.tr_cbd[gi] = ~0ull;  // (accumulate_dense_kernel's record of the slot's dense id: not looked up here)
+        // (accumulate_dense_kernel's record of the slot's dense id, tr_cbd, is not kept up here: this path only runs while the
+        // dense sums are off, and the host voids every record when it turns them on -- lob_engine.hip run_steps)
     }
     if (!found) return false;
     __hip_atomic_fetch_add(&S.cb_acc[((size_t)xcd * S.cb_slots + s) * 2 + target], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1596,10 +1597,7 @@ __device__ __forceinline__ void accumulate_generations(const DevParams& P, const
                     s = (s + 1) & (uint32_t)(S.cb_slots - 1);
                 }
             }
-            if (found && !known) {
-                S.tr_cbslot[(size_t)bb * G + slot] = (i32)(s | LOB_CBS_VERIFIED);
-                if (S.tr_cbd) S.tr_cbd[(size_t)bb * G + slot] = ~0ull;
-            }
+            if (found && !known) S.tr_cbslot[(size_t)bb * G + slot] = (i32)(s | LOB_CBS_VERIFIED);
             if (found) {
                 __hip_atomic_fetch_add(&S.cb_acc[((size_t)xcd * S.cb_slots + s) * 2 + target], scaled * (f64)P.trace_pow[age], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (!(S.cb_touch[s] & (1u << target))) atomicOr(&S.cb_touch[s], 1u << target);
@@ -1742,10 +1740,7 @@ __global__ void __launch_bounds__(LOB_ACB_BLOCK) accumulate_block_kernel(DevPara
                     s = (s + 1) & (uint32_t)(S.cb_slots - 1);
                 }
             }
-            if (found && !known) {
-                S.tr_cbslot[(size_t)bb * G + slot] = (i32)(s | LOB_CBS_VERIFIED);
-                if (S.tr_cbd) S.tr_cbd[(size_t)bb * G + slot] = ~0ull;
-            }
+            if (found && !known) S.tr_cbslot[(size_t)bb * G + slot] = (i32)(s | LOB_CBS_VERIFIED);
             direct = !found;
         }
         // the block's sums per slot

@@ -198,7 +198,6 @@ __device__ inline u64 cb_hash(int q0, int q1, int q2, int code, uint32_t mask) {
 // A dense id for a slot just claimed (lob_state.h cb_dense): popped from this XCD's free list, -1 if that is empty.  Only claim
 // winners pop (the trace / learn kernels), only apply_kernel pushes: the two never run together.
 __device__ inline i32 cbd_pop(const DevState& S) {
-    if (!S.cb_dense_on) return -1;
     unsigned x;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
     x &= 7u;
@@ -230,7 +229,7 @@ __device__ inline void cb_claim_finish(const DevState& S, const CbPending& c) {
         if (old == LOB_CB_EMPTY) {
             i32* id = S.cb_ident + (size_t)s * 8;
             id[0] = c.q0; id[1] = c.q1; id[2] = c.q2; id[3] = c.code; id[4] = (i32)c.mask; id[5] = c.src;
-            if (S.cb_dense) S.cb_dense[s] = cbd_pop(S);
+            if (S.cb_dense_on) S.cb_dense[s] = cbd_pop(S);  // (off: the entry is -1 already -- apply_kernel leaves it so when it frees a slot)
             const int seg = S.cb_par * S.cb_segs + (int)(s & (uint32_t)(S.cb_segs - 1));
             const int pos = atomicAdd(&S.cb_count[seg], 1);
             S.cb_list[(size_t)seg * (S.cb_slots / S.cb_segs) + pos] = (i32)s;  // (an occupied slot is on its segment's list exactly once: it fits)

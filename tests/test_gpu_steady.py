@@ -8,6 +8,7 @@ maps filling up, lists voided by a weight exchange, a second episode.  Here they
 the oracle step by step through exactly that (reference: Learner::_step / Runner::RunEpisode,
 src/experiment/serial.cpp:18-34,53-70).  The oracle's read phase runs on the host's cores
 (ORACLE_THREADS, tests/conftest.py); the engine is the thing checked."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -177,6 +178,33 @@ def test_block_sums_by_dense_slot_ids(monkeypatch, algo, eps, ids):
     np.testing.assert_allclose(th, oth, rtol=1e-9, atol=1e-12)
     flow = eng.flow_stats()
     assert flow["block_sums"] == 46 and flow["dense_sums"] == (0 if ids == "off" else 46), flow
+    eng.close()
+    orc.close()
+
+
+def test_dense_sums_come_on_and_go_off_with_epsilon(monkeypatch):
+    """The exploration rate decides which shape the combined update takes (lob_engine.hip acc_blocked: Q(lambda) below 0.34 sums per
+    block by dense slot ids, above it the updates are added to their slots inside the learn / trace kernels), and
+    lob_set_epsilon may move it at any step: slots claimed while the dense sums are off have no id, generations verified
+    meanwhile carry no record of one, and every record is void when the mode comes back on.  16 384 books, epsilon 0.8 ->
+    0.05 -> 0.8 -> 0.05 inside one episode, every phase against the oracle.  (LOB_Q_LANES=1: the lane learner kernels, which add in
+    place, at this batch size.)"""
+    monkeypatch.setenv("LOB_Q_LANES", "1")
+    B = 16384
+    p, eng, orc = make(B, abi.ALGO_QLAMBDA, n_events=300, epsilon=0.8)
+    eng.reset(); orc.reset()
+    step = 0
+    for eps, n in ((0.8, 12), (0.05, 14), (0.8, 10), (0.05, 14)):
+        eng.set_epsilon(eps)
+        ol.load().oracle_set_epsilon(orc.h, C.c_double(eps))
+        for i in range(n):
+            eng.td_step(1); orc.td_step(1)
+            if i < 2 or i >= n - 2 or i % 4 == 0:
+                compare_learner_step(eng, orc, "epsilon %g, step %d" % (eps, step), exact=False, rtol=1e-9)
+            step += 1
+    flow = eng.flow_stats()
+    assert flow["dense_sums"] == 28 and flow["added_in_place"] >= 18, flow
+    np.testing.assert_allclose(eng.theta(), orc.theta(), rtol=1e-9, atol=1e-12)
     eng.close()
     orc.close()
 
