@@ -76,11 +76,13 @@ __global__ void __launch_bounds__(64, EnvStepOcc<LANES>::waves) env_step_kernel(
     const int k0 = S.k[b], rc0 = S.rec_cur[b];
     const int mslot = S.mk_slot[b];
     const bool dirty = S.hl_dirty[0] == F.sid_prev;
-    // the hit list: its first 128 bytes (the count and 15 entries: all of it but for a book in a thousand) now, the rest below
-    ulonglong2 hl[LOB_HL_REC / 2];
+    // the hit list: its first 128 bytes (the count and 15 entries: all of it but for a book in a thousand) now, entries 15-22
+    // below, the ones beyond LOB_HL_CAP (a book in ten thousand: up to LOB_HL_MAX) in a pass of their own behind the replay
+    constexpr int HLQ = LOB_HL_ROW / 2;
+    ulonglong2 hl[HLQ];
     const ulonglong2* hl_p = reinterpret_cast<const ulonglong2*>(S.hl_rec + (size_t)b * LOB_HL_REC);
 #pragma unroll
-    for (int i = 0; i < LOB_HL_REC / 2; i++) hl[i] = i < 8 ? hl_p[i] : make_ulonglong2(0ull, 0ull);
+    for (int i = 0; i < HLQ; i++) hl[i] = i < 8 ? hl_p[i] : make_ulonglong2(0ull, 0ull);
     EnvR er;
     env_load(S, b, er);
     RMReg wu, wd;
@@ -109,7 +111,7 @@ __global__ void __launch_bounds__(64, EnvStepOcc<LANES>::waves) env_step_kernel(
     bool ok = alive && open && !dirty && !((h0.zero_mask >> (cur_slot ^ 1)) & 1) && mslot >= 0 && n_list >= 0;
     if (ok && n_list > 15) {  // (a round trip of its own, for the waves that hold such a book)
 #pragma unroll
-        for (int i = 8; i < LOB_HL_REC / 2; i++) hl[i] = hl_p[i];
+        for (int i = 8; i < HLQ; i++) hl[i] = hl_p[i];
     }
 
     // ---- round 2: everything addressed by what round 1 brought ----------------------------------------------------------
@@ -193,6 +195,27 @@ __global__ void __launch_bounds__(64, EnvStepOcc<LANES>::waves) env_step_kernel(
                         for (int a = 0; a < LOB_N_ACTIONS; a++) q[a] = a_ == a ? q[a] + x_ : q[a];
                     }
                 }
+                // the additions beyond LOB_HL_CAP, in their order behind the others: entries and weights fetched here (two round
+                // trips for the wave that holds such a book -- instead of a whole-wave evaluation of all 128 terms for the book)
+                constexpr int NT = LOB_HL_MAX - LOB_HL_CAP;
+                u64 te[NT];
+                if (n_list > LOB_HL_CAP) {
+                    const u64* tp = S.hl_rec + (size_t)b * LOB_HL_REC + 1 + LOB_HL_CAP;
+#pragma unroll
+                    for (int j = 0; j < NT; j++) te[j] = LOB_HL_CAP + j < n_list ? tp[j] : 0ull;
+                    f64 tv[NT];
+#pragma unroll
+                    for (int j = 0; j < NT; j++) tv[j] = LOB_HL_CAP + j < n_list ? S.theta[(uint32_t)te[j]] : 0.0;
+#pragma unroll
+                    for (int j = 0; j < NT; j++) {
+                        if (LOB_HL_CAP + j < n_list && tv[j] != 0.0) {
+                            const int a_ = (int)(te[j] >> 32) & 15;
+                            const f64 x_ = ((te[j] >> 36) & 1ull ? w2 : w1) * tv[j];
+#pragma unroll
+                            for (int a = 0; a < LOB_N_ACTIONS; a++) q[a] = a_ == a ? q[a] + x_ : q[a];
+                        }
+                    }
+                }
 #pragma unroll
                 for (int a = 0; a < LOB_N_ACTIONS; a++) S.qs_last[(size_t)b * LOB_N_ACTIONS + a] = q[a];
                 if (DQ) {
@@ -208,6 +231,20 @@ __global__ void __launch_bounds__(64, EnvStepOcc<LANES>::waves) env_step_kernel(
                             const f64 x_ = ((ent >> 36) & 1ull ? w2 : w1) * v;
 #pragma unroll
                             for (int a = 0; a < LOB_N_ACTIONS; a++) qb[a] = a_ == a ? qb[a] + x_ : qb[a];
+                        }
+                    }
+                    if (n_list > LOB_HL_CAP) {  // (the same additions under theta_b)
+                        f64 tv[NT];
+#pragma unroll
+                        for (int j = 0; j < NT; j++) tv[j] = LOB_HL_CAP + j < n_list ? S.theta_b[(uint32_t)te[j]] : 0.0;
+#pragma unroll
+                        for (int j = 0; j < NT; j++) {
+                            if (LOB_HL_CAP + j < n_list && tv[j] != 0.0) {
+                                const int a_ = (int)(te[j] >> 32) & 15;
+                                const f64 x_ = ((te[j] >> 36) & 1ull ? w2 : w1) * tv[j];
+#pragma unroll
+                                for (int a = 0; a < LOB_N_ACTIONS; a++) qb[a] = a_ == a ? qb[a] + x_ : qb[a];
+                            }
                         }
                     }
 #pragma unroll

@@ -116,7 +116,7 @@ __device__ __forceinline__ uint32_t fast_base(const DevParams& P, int qv, int la
 // inside the wave.  No branches on per-book conditions in here: a book that is not `go` computes on
 // whatever its (valid) inputs are and its result is ignored by the caller.
 // WR: also put each book's hit list (lob_state.h) -- the additions made below, in their order -- into the wave's LDS
-// rows `buf` (NB x LOB_HL_REC u64: the staged state variables are not needed any more) and return the counts
+// rows `buf` (NB x LOB_HL_ROW u64: the staged state variables are not needed any more) and return the counts
 // (`o_cnt[k]`, above LOB_HL_CAP: no list); hit_list_store sends them to memory.  Order of the additions for action a:
 // group-1 tilings ascending with w1, the same again with w2, group-2 tilings ascending with w2 -- whether or not the
 // weight is non-zero YET: it is marked, the next update may write it.
@@ -218,7 +218,7 @@ __device__ __forceinline__ void q_values_fast(const DevParams& P, const DevState
                 const int below = (int)__builtin_amdgcn_mbcnt_hi(hi_m, __builtin_amdgcn_mbcnt_lo(lo, 0u));  // set bits of mb below this lane
                 const int p = cnt + (hi ? nlo + below : below);
                 if (mine) {
-                    u64* row = buf + k * LOB_HL_REC + 1;
+                    u64* row = buf + k * LOB_HL_ROW + 1;
                     const u64 ent = (u64)(uint32_t)idx[k][a] | ((u64)a << 32);
                     if (p < LOB_HL_CAP) row[p] = hi ? ent | (1ull << 36) : ent;
                     if (!hi && p + nlo < LOB_HL_CAP) row[p + nlo] = ent | (1ull << 36);
@@ -251,7 +251,7 @@ __device__ __forceinline__ void hit_list_store(const DevState& S, int lane, cons
     for (int k = 0; k < NB; k++) {
         if (wr_b[k] < 0) continue;  // wave-uniform
         const int n = cnt[k] <= LOB_HL_CAP ? cnt[k] : -1;
-        if (lane <= n || lane == 0) S.hl_rec[(size_t)wr_b[k] * LOB_HL_REC + lane] = lane == 0 ? (n < 0 ? LOB_HL_NONE : (u64)n) : buf[k * LOB_HL_REC + lane];
+        if (lane <= n || lane == 0) S.hl_rec[(size_t)wr_b[k] * LOB_HL_REC + lane] = lane == 0 ? (n < 0 ? LOB_HL_NONE : (u64)n) : buf[k * LOB_HL_ROW + lane];
     }
 }
 
@@ -1578,7 +1578,7 @@ __global__ void __launch_bounds__(LOB_QP_BLOCK) learn_q_pair_kernel(DevParams P,
                         for (int c = 0; c < LOB_N_ACTIONS; c++) qs[c] = a == c ? qs[c] + x : qs[c];
                     }
                 }
-                for (int i = 0; i < n && i < LOB_HL_CAP; i++) recp[1 + i] = ql_unpack(row[1 + i]);  // its part of the book's hit list
+                for (int i = 0; i < n && i < LOB_HL_MAX; i++) recp[1 + i] = ql_unpack(row[1 + i]);  // its part of the book's hit list
             }
 #pragma unroll
             for (int a = 0; a < LOB_N_ACTIONS; a++) xc[a] = qs[a];
@@ -1687,7 +1687,7 @@ __global__ void __launch_bounds__(LOB_QP_BLOCK) learn_q_pair_kernel(DevParams P,
             const uint32_t light_code = TR ? reinterpret_cast<const uint32_t*>(xc + LOB_N_ACTIONS)[1] : 0u;
             const bool light = light_code != 0;
             if (stepped) {
-                if (!(walk && n1 >= 0 && n <= LOB_QP_CAP2 && n1 + n <= LOB_HL_CAP)) {
+                if (!(walk && n1 >= 0 && n <= LOB_QP_CAP2 && n1 + n <= LOB_HL_MAX)) {
                     // no (valid) memo record, or a half-list longer than its row: the general kernel takes the book
                     const int pos = atomicAdd(&S.slow_n[lpar * 2 + 1], 1);
                     S.slow_list[(size_t)S.B + pos] = b;

@@ -178,8 +178,14 @@ struct __attribute__((aligned(64))) LHdr {
 #define LOB_PROF_N 32
 #define LOB_MK_REC 10         /* doubles per memo record: S0 of the nine actions + the theta version it was computed under */
 #define LOB_MK_PROBES 16
-#define LOB_HL_CAP 23         /* additions per book a hit list can hold (the mean is 5-6 at 125 k written weights of 20 M) */
-#define LOB_HL_REC 24         /* u64 per book: [0] the count, then the additions: 192 bytes */
+#define LOB_HL_CAP 23         /* additions of a hit list that the kernels keep in registers / LDS rows (the mean is 8, the 99th percentile 17, once
+                               * the written set has saturated at 160 k weights of 20 M) */
+#define LOB_HL_ROW 24         /* u64 per LDS row of the wave-per-book kernels: the count + LOB_HL_CAP additions */
+#define LOB_HL_MAX 35         /* additions per book a record can hold: the two-lanes-per-book learn kernel writes up to that many, and the
+                               * act side replays the ones beyond LOB_HL_CAP in a pass of their own -- in a long run 8-11 books per step
+                               * had 24 and more, and each of them cost a whole-wave evaluation in learn_q_rest_kernel AND in the env kernel
+                               * (16-40 us of a 250-300 us step: NOTES.md "Round 5") */
+#define LOB_HL_REC 36         /* u64 per book: [0] the count, then the additions: 288 bytes */
 #define LOB_VD_STRIDE 72      /* u16 per book: 64 verdicts + epoch lo/hi + slot + valid, padded to 144 B */
 /* theta's "ever written" map: one bit per LOB_NZ_GRAN = 8 consecutive weights (312 KB at M = 20M, so
  * it stays L2-resident under the streaming traffic; one bit per weight, 2.5 MB, did not).  A set
@@ -361,7 +367,7 @@ struct DevState {
     // creates the generation, before learn_q looks.  So learn_q leaves, per book, the ordered list of additions
     // Agent::getQ makes beyond the memoised group-0 sum: entry = tile index | action << 32 | (weight w2 ? 1 : 0) << 36.
     u64* hl_rec;         // [B][LOB_HL_REC]: [0] = number of entries, or ~0: no list (not evaluated by the fast learn kernel, or more
-                         //   than LOB_HL_CAP); [1 + i] = entry i
+                         //   than it can record: LOB_HL_MAX, LOB_HL_CAP from the kernels with one lane or one wave per book); [1 + i] = entry i
     i32* hl_dirty;       // [1] step id of the last update that set a map bit AFTER learn_q had looked (voids every list)
     // R-learning agents (RLearn / OnlineRLearn, src/rl/agent.cpp:357-412): the average reward rho of each agent -- one per weight
     // vector: [1] shared, [B] private --, the sum of a step's increments (folded in by rho_fold_kernel: every book reads rho_t),

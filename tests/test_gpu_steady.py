@@ -209,6 +209,45 @@ def test_dense_sums_come_on_and_go_off_with_epsilon(monkeypatch):
     orc.close()
 
 
+@pytest.mark.parametrize("algo", [abi.ALGO_QLAMBDA, abi.ALGO_DOUBLE_Q], ids=["qlambda", "double_q"])
+def test_hit_lists_longer_than_the_replay_registers(algo):
+    """A hit-list record holds up to LOB_HL_MAX = 35 additions; the env kernel replays 23 from registers and the ones beyond in a
+    pass of their own (two round trips for the wave that holds such a book, instead of handing the book to the whole-wave
+    evaluations of act_book and learn_q_rest_kernel: in a long run 8-11 books per step are that long).  Here a pre-loaded theta with
+    2.5 % of its weights written makes such lists the rule: 32 768 books, 14 steps against the oracle, and the statistics say that
+    thousands of live books act from lists of 24-35 entries."""
+    B = 32768
+    p, eng, orc = make(B, algo, n_events=200)
+    rng = np.random.default_rng(23)
+    th = np.zeros(p.memory_size)
+    idx = rng.choice(p.memory_size, size=500000, replace=False)
+    th[idx] = rng.normal(0.0, 0.01, size=idx.size)
+    eng.reset(); orc.reset()
+    eng.set_theta(th)
+    orc.theta()[:] = th
+    if algo == abi.ALGO_DOUBLE_Q:
+        thb = np.zeros(p.memory_size)
+        thb[idx[::2]] = rng.normal(0.0, 0.01, size=idx[::2].size)
+        eng.set_theta(thb, 1)
+        orc.theta_b()[:] = thb
+    light0 = light_books(eng)
+    for step in range(14):
+        eng.td_step(1); orc.td_step(1)
+        if step < 3 or step % 3 == 1:
+            compare_learner_step(eng, orc, "long lists, step %d" % step, exact=False, rtol=1e-9)
+    st = eng.fastpath_stats()
+    long_lists = int(st["hist"][24:36].sum())
+    print("long lists: %d of %d live books hold 24-35 entries (mean %s, max %s), %d without a list" %
+          (long_lists, st["live_books"], st["list_len_mean"], st["list_len_max"], st["books_without_list"]))
+    assert long_lists > 2000 and st["list_len_max"] > 28
+    assert light_books(eng) - light0 > 10 * long_lists
+    np.testing.assert_allclose(eng.theta(), orc.theta(), rtol=1e-9, atol=1e-12)
+    if algo == abi.ALGO_DOUBLE_Q:
+        np.testing.assert_allclose(eng.theta(1), orc.theta_b(), rtol=1e-9, atol=1e-12)
+    eng.close()
+    orc.close()
+
+
 def test_preloaded_theta_with_a_million_written_weights():
     """The state a long training run is in, at scale: 32 768 books acting from a weight vector with 1.2 M non-zero entries
     (6 % of the table: a hit list would need ~50 entries, so most books take the in-kernel full evaluation and the
