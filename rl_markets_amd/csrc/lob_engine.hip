@@ -31,6 +31,7 @@
 
 #define LOB_HINT_RING 64
 #define LOB_HINT_LAG 16
+#define LOB_HINT_EVERY 8   /* the count goes to host memory in every 8th learner step only: the store costs the kernel that makes it 3.5 us */
 
 struct KTimer {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
@@ -60,6 +61,7 @@ struct lob_engine {
     bool acc_batches_set = false;
     int acc_batches = LOB_ACB_K;  // accumulate_block_kernel: batches of 1 024 books per block (LOB_ACC_BATCHES=1|2|4|8; A/B switch)
     bool acc_block = true;      // SARSA(lambda): sums per block first (LOB_ACC_BLOCK=0: accumulate_kernel; A/B switch)
+    bool dense_ever = false;    // the dense sums have been on at some step: slots may hold dense ids (apply_kernel frees them with their slots)
     bool acc_dense = true;      // ... in a direct-indexed LDS array by the slots' dense ids, accumulate_dense_kernel (LOB_ACC_DENSE=0: accumulate_block_kernel's hash table; A/B switch)
     int env_step_lanes = 64;    // books per wave of env_step_kernel (LOB_ENV_STEP_LANES=32: two half-full waves per SIMD; experiment)
     bool prepass_roles = false; // the pre-pass on two waves per 64 books (reset2_kernel / prepass_extend2_kernel; LOB_PREPASS_ROLES=1): measured slower, opt-in
@@ -1146,7 +1148,8 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
             // the learn kernels' hand-back count of LOB_HINT_LAG learner steps ago (0 until that many have run since the hints were void)
             e->hint_now = 0;
             if (fast && mode == 0 && e->rest_hint && e->hint_step >= LOB_HINT_LAG) {
-                const int hs = (int)((e->hint_step - LOB_HINT_LAG) % LOB_HINT_RING);
+                // (the latest reporting step that is at least LOB_HINT_LAG steps old)
+                const int hs = (int)(((e->hint_step - LOB_HINT_LAG) / LOB_HINT_EVERY * LOB_HINT_EVERY) % LOB_HINT_RING);
                 HIPCHK(hipEventSynchronize(e->hint_ev[hs]));
                 // (the kernel is done; its store to host memory is a system-scope atomic and carries the launch's tag: wait for that very word)
                 u64 w = *(volatile u64*)(e->rest_hint + hs);
@@ -1168,6 +1171,7 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
             // ids (tr_cbd) are only kept up by accumulate_dense_kernel: whenever the mode comes on (epsilon has fallen below 0.34,
             // lob_set_epsilon), every record is void -- the kernels that verified slots meanwhile did not look ids up
             const int on = e->S.cb_dense && acc_blocked(e) ? 1 : 0;
+            if (on) e->dense_ever = true;
             if (on && !e->S.cb_dense_on) HIPCHK(hipMemsetAsync(e->S.tr_cbd, 0xff, (size_t)e->B * e->P.trace_gens * 8, e->stream));
             e->S.cb_dense_on = on;
         }
@@ -1279,12 +1283,14 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                         TimedLaunch t(e, "learn_rest_kernel", rs);
                         const int hs = (int)(e->hint_step % LOB_HINT_RING);
                         const bool no_hint = e->no_hint;  // (experiment: the hint's store to host memory costs the kernel 3.5 us and the step nothing)
-                        u64* hint_dev = e->rest_hint && !no_hint ? e->rest_hint_dev + hs : nullptr;
+                        const bool reports = e->rest_hint && !no_hint && e->hint_step % LOB_HINT_EVERY == 0;
+                        u64* hint_dev = reports ? e->rest_hint_dev + hs : nullptr;
                         const uint32_t hint_tag = (uint32_t)(++e->hint_serial);
                         if (dq) hipLaunchKernelGGL(learn_q_rest_kernel<LOB_ALGO_DOUBLE_Q>, dim3(gl), dim3(LOB_BLOCK), 0, rs, e->P, e->S, rnd, learn_list, learn_n, hint_dev, hint_tag);
                         else if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL(learn_q_rest_kernel<LOB_ALGO_QLAMBDA>, dim3(gl), dim3(LOB_BLOCK), 0, rs, e->P, e->S, rnd, learn_list, learn_n, hint_dev, hint_tag);
                         else hipLaunchKernelGGL(learn_q_rest_kernel<LOB_ALGO_SARSA>, dim3(gl), dim3(LOB_BLOCK), 0, rs, e->P, e->S, rnd, learn_list, learn_n, hint_dev, hint_tag);
-                        if (e->rest_hint && !no_hint) { HIPCHK(hipEventRecord(e->hint_ev[hs], rs)); e->hint_tags[hs] = hint_tag; e->hint_step++; }
+                        if (reports) { HIPCHK(hipEventRecord(e->hint_ev[hs], rs)); e->hint_tags[hs] = hint_tag; }
+                        if (e->rest_hint && !no_hint) e->hint_step++;
                     }
                     if (side) {
                         HIPCHK(hipEventRecord(e->ev_rest_done, e->stream2));
@@ -1363,7 +1369,8 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
             {
                 TimedLaunch t(e, "apply_kernel");
                 const int blocks = e->S.cb_segs;
-                hipLaunchKernelGGL(apply_kernel, dim3(blocks), dim3(256), 0, e->stream, e->P, e->S, rnd, par, e->step_id, dense_blocks);
+                // (dense_blocks -1: no slot has ever been given a dense id -- apply_kernel does not look any up)
+                hipLaunchKernelGGL(apply_kernel, dim3(blocks), dim3(256), 0, e->stream, e->P, e->S, rnd, par, e->step_id, e->dense_ever ? dense_blocks : -1);
             }
             if (e->P.sarsa_lanes && e->reg_fork_late) { int rc = registry_fork(e, e->stream, rnd, par); if (rc) return rc; }
         } else if (mode == 0) {

@@ -2006,7 +2006,8 @@ __global__ void __launch_bounds__(256) reduce_dense_kernel(DevState S, int dense
 #if LOB_IN_MAIN
 // `dense_blocks` > 0: accumulate_dense_kernel + reduce_dense_kernel ran this step -- a slot with a dense id also gets the
 // LOB_ACD_GROUPS partial sums of cb_red at its id (lane x reads group x's; LOB_ACD_MARK = no block of the group had a term for
-// it), and counts as touched if any holds a term.  A slot that is freed hands its id back to the list it came from.
+// it), and counts as touched if any holds a term.  A slot that is freed hands its id back to the list it came from.  (< 0: no
+// slot has ever been given an id -- nothing is looked up.)
 __global__ void __launch_bounds__(256) apply_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g, int par, int sid, int dense_blocks) {
     __shared__ uint32_t rnd[2048 + 32];
     __shared__ int n_surv;
@@ -2046,7 +2047,7 @@ __global__ void __launch_bounds__(256) apply_kernel(DevParams P, DevState S, con
                 v1 += readlane_f64(c1, x);
             }
         }
-        const i32 did = S.cb_dense ? S.cb_dense[s] : -1;
+        const i32 did = (S.cb_dense && dense_blocks >= 0) ? S.cb_dense[s] : -1;
         bool dense_touch = false;
         if (dense_blocks > 0 && did >= 0) {
             u64 raw = LOB_ACD_MARK;
