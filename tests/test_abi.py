@@ -158,10 +158,13 @@ def test_product_does_not_reference_the_oracle():
 
 
 def test_traffic_table_is_what_the_committed_counter_passes_give(tmp_path):
-    """profiles/pmc_traffic.json (bench.py's roofline.traffic) regenerated from the committed rocprofv3 counter summary."""
+    """profiles/pmc_traffic*.json (bench.py's roofline.traffic, one file per quoted configuration) regenerated from the committed
+    rocprofv3 counter summaries of the round."""
     import json
     import subprocess
     import sys
-    out = str(tmp_path / "traffic.json")
-    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_traffic.py"), "r04", out], stdout=subprocess.DEVNULL)
-    assert json.load(open(out)) == json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    for tag, name in (("r05", "pmc_traffic.json"), ("r05_sarsa", "pmc_traffic_sarsa.json"), ("r05_c2", "pmc_traffic_c2.json"),
+                      ("r05_double_q", "pmc_traffic_double_q.json"), ("r05_c5", "pmc_traffic_c5.json"), ("r05_eps01", "pmc_traffic_eps01.json")):
+        out = str(tmp_path / name)
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_traffic.py"), tag, out], stdout=subprocess.DEVNULL)
+        assert json.load(open(out)) == json.load(open(os.path.join(ROOT, "profiles", name))), name
