@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(64, EnvStepOcc<LANES>::waves) env_step_kernel(
     static_assert(LANES == 64 || !INLINE_GENERAL, "the half-full variant leaves the books without a list to the work list");
     const DevParams& P = *Pp;
     __shared__ TickLds tick_lds;
-    __shared__ EnvSlot lds_env[LANES];
+    __shared__ EnvSlot lds_env[LANES == 64 ? 64 : LANES + 1];  // (32-book waves: one more slot, for the idle upper half -- below)
     __shared__ LearnLds1 lds_learn;
 #ifdef LOB_PROF
     const long long t_entry = clock64();
@@ -96,7 +96,9 @@ __global__ void __launch_bounds__(64, EnvStepOcc<LANES>::waves) env_step_kernel(
         tick_lds.lb[i] = tk_lb; tick_lds.tick[i] = tk_tick; tick_lds.cum[i] = tk_cum; tick_lds.pp[i] = tk_pp; tick_lds.pt[i] = tk_pt;
     }
     if (threadIdx.x == 0) tick_lds.n = P.n_bands;
-    EnvR& e = lds_env[threadIdx.x & (LANES - 1)].e;  // (the idle upper half of a 32-book wave writes the slots of lanes that do nothing with them)
+    // (the idle upper half of a 32-book wave -- the experiments build's LOB_ENV_STEP_LANES=32 -- shares ONE slot of its own: whatever those
+    // lanes may come to store through `e`, no live lane's registers are there)
+    EnvR& e = lds_env[LANES == 64 || threadIdx.x < LANES ? (threadIdx.x & (LANES - 1)) : LANES].e;
     if (LANES == 64 || threadIdx.x < LANES) e = er;
     __syncthreads();
 #ifdef LOB_PROF

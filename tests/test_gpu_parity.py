@@ -605,6 +605,26 @@ def test_books_per_wave_and_group_choices(monkeypatch, env_lanes, reset_lanes, g
     orc.close()
 
 
+def test_env_step_kernel_with_32_books_per_wave(monkeypatch):
+    """LOB_ENV_STEP_LANES=32 (experiments build: env_step_kernel<false, false, 32>, two half-full waves per SIMD -- measured slower, 0.158
+    against 0.098 ms): the fused action selection + step with the upper half of every wave idle, against the oracle (the
+    idle lanes have a slot of their own)."""
+    if not experiments_build():
+        pytest.skip("a kernel variant measured and lost: compiled with -DLOB_EXPERIMENTS only (tools/exp_variants.sh)")
+    monkeypatch.setenv("LOB_ENV_STEP_LANES", "32")
+    monkeypatch.setenv("LOB_FUSE_ACT", "1")
+    monkeypatch.setenv("LOB_Q_LANES", "1")
+    B = 1100
+    p, g, rec, eng, orc = make(depth=10, n_events=150, B=B, algo=abi.ALGO_QLAMBDA, theta_mode=abi.THETA_SHARED, mem=1 << 20)
+    eng.reset(); orc.reset()
+    for step in range(16):
+        eng.td_step(1); orc.td_step(1)
+        compare_learner_step(eng, orc, "32 books per wave, step %d" % step, exact=False, rtol=1e-9)
+    np.testing.assert_allclose(eng.theta(), orc.theta(), rtol=1e-9, atol=1e-12)
+    eng.close()
+    orc.close()
+
+
 def test_prepass_on_two_waves_per_64_books(monkeypatch):
     """LOB_PREPASS_ROLES=1: the market pre-pass with the book side and the window side of every event on two waves of a block
     (reset2_kernel / prepass_extend2_kernel, lob_env.h prepass_run2 -- opt-in: measured slower than one wave).  Same track, same
