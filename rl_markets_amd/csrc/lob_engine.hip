@@ -52,7 +52,7 @@ struct lob_engine {
     hipEvent_t ev_reg_go = nullptr, ev_reg_done = nullptr;  // tile registry kernels on stream2 beside the learner kernels (lob_kernels.h registry_kernel)
     hipEvent_t ev_rest_go = nullptr, ev_rest_done = nullptr;  // learn_q_rest_kernel on stream2 beside the trace kernels
     bool rest_side = true;      // (LOB_REST_SIDE=0: on the main stream, as before; A/B switch)
-    bool rest_merge = true;     // the fused Q(lambda) / double Q flow: trace_rest_kernel (LOB_REST_MERGE=0: trace_fast_kernel<., 2> + accumulate_kernel over its list; A/B switch)
+    bool rest_merge = true;     // the fused Q(lambda) / double Q flow: trace_rest_kernel (LOB_REST_MERGE=0: learn_q_rest_kernel + trace_fast_kernel<., 2> + accumulate_kernel over its list; A/B switch)
     bool dq_pair = true;        // double Q(lambda): learn_q_pair_kernel<DOUBLE_Q> (LOB_DQ_PAIR=0: a lane per book, learn_q_lane_kernel; A/B switch)
     int ts_lds = 0, ts_grid = 0; // (experiments: trace_lane_kernel<SARSA> with dynamic LDS / a persistent grid)
     bool no_hint = false;       // (experiment: learn_q_rest_kernel without its report to the host)
@@ -594,6 +594,8 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
         if (rc == LOB_OK) rc = dev_alloc(e, &S.acc_list, B);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.acc_list_n, 2);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.acc_pend, B);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.dir_list, P.combine ? B * (size_t)P.trace_gens : 1);
+        if (rc == LOB_OK) rc = dev_alloc(e, &S.dir_list_n, 2);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.mk_slot, B);
         if (rc == LOB_OK) rc = dev_alloc(e, &S.mk_slot_last, B);
         if (rc == LOB_OK && hipMemsetAsync(S.mk_hash, 0xff, ms * 8, e->stream) != hipSuccess) rc = LOB_EHIP;
@@ -647,6 +649,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
             if (er == hipSuccess) er = hipFuncSetAttribute((const void*)trace_fast_kernel<LOB_ALGO_QLAMBDA, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, tr_lds);
             if (er == hipSuccess) er = hipFuncSetAttribute((const void*)trace_fast_kernel<LOB_ALGO_QLAMBDA, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, tr_lds);
             if (er == hipSuccess) er = hipFuncSetAttribute((const void*)trace_rest_kernel<LOB_ALGO_QLAMBDA>, hipFuncAttributeMaxDynamicSharedMemorySize, tr_lds);
+            if (er == hipSuccess) er = hipFuncSetAttribute((const void*)trace_rest_kernel<LOB_ALGO_DOUBLE_Q>, hipFuncAttributeMaxDynamicSharedMemorySize, tr_lds);
             if (er != hipSuccess && rc == LOB_OK) { lob_set_error(std::string("hipFuncSetAttribute(dynamic LDS): ") + hipGetErrorString(er)); rc = LOB_EHIP; }
         }
     }
@@ -654,7 +657,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     if (rc == LOB_OK) rc = dev_alloc(e, &S.nz_new, 4 * LOB_NZ_WORDS);
     if (rc == LOB_OK) rc = dev_alloc(e, &S.verdict_b, P.algo == LOB_ALGO_DOUBLE_Q ? B * 64 : 1);
     if (rc == LOB_OK) rc = dev_alloc(e, &S.nz_epoch, 1);
-    if (rc == LOB_OK) rc = dev_alloc(e, &S.counters, 8);
+    if (rc == LOB_OK) rc = dev_alloc(e, &S.counters, 16);  // ([8]: generations apply_kernel applied from trace_rest_kernel's list, lob_debug_deferred)
     if (rc == LOB_OK) rc = dev_alloc(e, &S.error_flag, 1);
 #ifdef LOB_PROF
     if (rc == LOB_OK) rc = dev_alloc(e, &S.prof, B * LOB_PROF_N);
@@ -966,6 +969,7 @@ int lob_reset(lob_engine* e) {
     HIPCHK(hipMemsetAsync(e->S.tr_list2_n, 0, 2 * sizeof(i32), e->stream));
     HIPCHK(hipMemsetAsync(e->S.acc_list_n, 0, 2 * sizeof(i32), e->stream));
     HIPCHK(hipMemsetAsync(e->S.acc_pend, 0, (size_t)e->B, e->stream));
+    if (e->S.dir_list_n) HIPCHK(hipMemsetAsync(e->S.dir_list_n, 0, 2 * sizeof(i32), e->stream));
     if (e->half_open) {
         // a step abandoned between lob_td_step_begin and lob_td_step_end (a weight exchange that failed): its learner half never
         // ran, so the double-buffered lists are where the step found them -- the survivors of the combine table wait in the
@@ -1265,7 +1269,7 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                         lobk_learn_q(st, pair, e->P.algo, e->P.V == 8, fuse, gq, lds, e->P, e->S, rnd, lpar, ver, sid, acc_fused ? (rest_merged ? 2 : 1) : 0);
                     } else lobk_learn_q_fast(st, e->P.algo, gf, fast_lds_bytes(e->P.cwords4, LOB_FAST_NB, false), e->P, e->S, rnd, lpar, ver);
                 }
-                {
+                if (!rest_merged) {   // (rest_merged: trace_rest_kernel serves the books handed back too, behind the lane trace kernel)
                     // The books the lane kernels hand back (a list that is empty in most steps, a handful of books in the others).
                     // When trace kernels follow on the main stream (the fused Q(lambda) / double Q flow), this launch runs beside
                     // them on the second stream: nothing they do depends on it -- the update kernels wait for both.
@@ -1350,9 +1354,20 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                     const int nbat = e->acc_batches_set ? e->acc_batches : (e->P.algo == LOB_ALGO_SARSA ? 1 : std::max(1, std::min(e->acc_batches, e->B / (16 * LOB_ACB_BLOCK))));
                     hipLaunchKernelGGL(accumulate_block_kernel, dim3((e->B + LOB_ACB_BLOCK * nbat - 1) / (LOB_ACB_BLOCK * nbat), e->P.trace_kmax), dim3(LOB_ACB_BLOCK), 0, e->stream, e->P, e->S, par, e->step_id, nbat);
                 } else if (rest_merged) {
-                    // the books the lane trace kernel handed on (trace step + their sums) and what the fused accumulation left, in one launch
-                    hipLaunchKernelGGL(trace_rest_kernel<LOB_ALGO_QLAMBDA>, dim3(std::min(e->n_cus, (std::min(e->B, 4096) + LOB_TRACE_WAVES - 1) / LOB_TRACE_WAVES)), dim3(LOB_TRACE_BLOCK),
-                                       trace_lds_bytes(), e->stream, e->P, e->S, rnd, par, lpar, e->step_id, acc_lanes_shift(e));
+                    // the books the learn kernel handed back (TD error + their sums), the books the lane trace kernel handed on (trace
+                    // step + their sums) and what the fused accumulation left, in one launch; it reports the hand-back count to the
+                    // host as learn_q_rest_kernel does in the other flows
+                    const int hs = (int)(e->hint_step % LOB_HINT_RING);
+                    const bool reports = e->rest_hint && !e->no_hint && e->hint_step % LOB_HINT_EVERY == 0;
+                    u64* hint_dev = reports ? e->rest_hint_dev + hs : nullptr;
+                    const uint32_t hint_tag = (uint32_t)(++e->hint_serial);
+                    const dim3 rg(std::min(e->n_cus, (std::min(e->B, 4096) + LOB_TRACE_WAVES - 1) / LOB_TRACE_WAVES));
+                    if (e->P.algo == LOB_ALGO_DOUBLE_Q)
+                        hipLaunchKernelGGL(trace_rest_kernel<LOB_ALGO_DOUBLE_Q>, rg, dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), e->stream, e->P, e->S, rnd, par, lpar, e->step_id, acc_lanes_shift(e), hint_dev, hint_tag);
+                    else
+                        hipLaunchKernelGGL(trace_rest_kernel<LOB_ALGO_QLAMBDA>, rg, dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), e->stream, e->P, e->S, rnd, par, lpar, e->step_id, acc_lanes_shift(e), hint_dev, hint_tag);
+                    if (reports) { HIPCHK(hipEventRecord(e->hint_ev[hs], e->stream)); e->hint_tags[hs] = hint_tag; }
+                    if (e->rest_hint && !e->no_hint) e->hint_step++;
                 } else if (acc_fused) {
                     // what the fused accumulation left: a few hundred books (the grid's waves stride over the list)
                     const int sh = acc_lanes_shift(e);
@@ -1890,6 +1905,15 @@ extern "C" int lob_debug_light(lob_engine* e, int64_t out[2]) {
     HIPCHK(hipStreamSynchronize(e->stream));
     out[0] = c[5];
     out[1] = d;
+    return LOB_OK;
+}
+
+// Diagnostics (not part of include/lob_engine.h): generations without a combine slot that trace_rest_kernel left to apply_kernel so far.
+extern "C" int lob_debug_deferred(lob_engine* e, int64_t out[1]) {
+    if (!e || !out) return LOB_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemcpyAsync(out, e->S.counters + 8, sizeof(i64), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
     return LOB_OK;
 }
 

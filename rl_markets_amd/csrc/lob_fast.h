@@ -567,28 +567,53 @@ __global__ void __launch_bounds__(LOB_TRACE_BLOCK, LOB_TRACE_OCC) trace_fast_ker
     }
     cb_claim_finish(S, prev);
 }
-// trace_rest_kernel: the two near-empty launches behind trace_lane_kernel in the fused Q(lambda) / double Q flow --
-// trace_fast_kernel<., 2> over what the lane kernel hands on (`tr_list2`) and accumulate_kernel over what the fused accumulation
-// left (`acc_list`) -- as ONE: in most steps both lists hold nothing or a handful of books, and such a launch costs its 5-6 us
-// of dependency whatever its grid (NOTES.md "Round 4").  The one ordering the two had between them -- a book's generations are
-// added up after its trace step -- is kept inside a wave: the wave that runs a handed-on book's trace step finishes the step's
-// claim at once and adds the book's generations up itself (accumulate_generations), and trace_lane_kernel (acc_fuse = 2) no
-// longer puts such a book on `acc_list`.  Its TD error is final: learn_q_rest_kernel runs before trace_lane_kernel in this flow.
+// trace_rest_kernel: the near-empty launches around trace_lane_kernel in the fused Q(lambda) / double Q flow -- learn_q_rest_kernel
+// over the books the lane learn kernel hands back (the `learn` work list), trace_fast_kernel<., 2> over what the lane trace
+// kernel hands on (`tr_list2`) and accumulate_kernel over what the fused accumulation left (`acc_list`) -- as ONE: in most steps
+// the three lists hold nothing or a handful of books, and every such launch is a dependency of the step whatever its grid
+// (NOTES.md "Round 4", "Round 5").  The orderings they had between them move inside a wave: a book that needs more than one of the
+// three gets them from ONE wave, in order -- TD error (learn_q_book), trace step (learn_traces), then its generations added up
+// (accumulate_generations) -- and nobody else touches it: the learn kernel flags a handed-back book in acc_pend (bit 0) instead
+// of listing it for the accumulation, trace_lane_kernel (acc_fuse = 2) flags a handed-on book (bit 1) and lists neither kind on
+// `acc_list`.  A wave's learn_q_book READS theta while other waves are adding generations up: nothing in this kernel may write
+// theta -- a generation without a slot, which accumulate_kernel applies tile by tile, goes on `dir_list` for apply_kernel
+// (accumulate_generations, `defer`).  ALGO: the learn side's (Q(lambda) or double Q); the trace step is Watkins's in both.
+// `hint`: as learn_q_rest_kernel's (the hand-back count for the host).
 template <int ALGO>
-__global__ void __launch_bounds__(LOB_TRACE_BLOCK, LOB_TRACE_OCC) trace_rest_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g, int par, int lpar, int sid,
-                                                                                    int lpb_shift) {
+__global__ void __launch_bounds__(LOB_TRACE_BLOCK) trace_rest_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g, int par, int lpar, int sid,
+                                                                     int lpb_shift, u64* hint, uint32_t hint_tag) {
     extern __shared__ __align__(16) unsigned char fast_lds_raw[];
+    __shared__ LearnLds L;  // (learn_q_book: waves 0-3 of the block)
     // this step's update appends to nz_new[par]; the list the general act path reads is nz_new[par ^ 1] (as trace_fast_kernel)
     if (blockIdx.x == 0 && threadIdx.x < LOB_NZ_WORDS) {
         S.nz_new[par * LOB_NZ_WORDS + threadIdx.x] = 0;
         S.nz_new[(2 + par) * LOB_NZ_WORDS + threadIdx.x] = 0;
     }
-    const int n_tr = S.tr_list2_n[lpar], n_acc = S.acc_list_n[lpar];
-    if (n_tr == 0 && n_acc == 0) return;  // the usual case
+    const int n_learn = S.slow_n[lpar * 2 + 1], n_tr = S.tr_list2_n[lpar], n_acc = S.acc_list_n[lpar];
+    if (hint && blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store(hint, ((u64)hint_tag << 32) | (u64)(uint32_t)n_learn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (n_learn == 0 && n_tr == 0 && n_acc == 0) return;  // the usual case
+    if (n_learn > 0 && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd((u64*)&S.counters[4], (u64)n_learn);  // (lob_get_path_stats [7])
     const int w = threadIdx.x >> 6;
     const int wave = blockIdx.x * LOB_TRACE_WAVES + w, n_waves = gridDim.x * LOB_TRACE_WAVES;
     const int xcd = acc_copy(S, wave);
     int lane_ = threadIdx.x & 63;
+    const i32* learn_list = S.slow_list + S.B;
+    if (n_learn > 0) learn_stage_table(rnd_g, L);  // (block-uniform; ends in a block barrier)
+    // ---- the books the learn kernel handed back (and that the lane trace kernel did not hand on as well): TD error, then their sums ----
+    if (n_learn > 0 && w < LOB_WAVES_PER_BLOCK) {
+#pragma unroll 1
+        for (int t = blockIdx.x * LOB_WAVES_PER_BLOCK + w; t < n_learn; t += gridDim.x * LOB_WAVES_PER_BLOCK) {
+            asm volatile("" : "+v"(lane_));
+            const int lane = lane_;
+            const int b = __builtin_amdgcn_readfirstlane(learn_list[t]);
+            if (S.acc_pend[b] & 2) continue;  // (its trace step comes first: below)
+            learn_q_book<ALGO>(P, S, L, w, lane, b);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+            __builtin_amdgcn_wave_barrier();
+            accumulate_generations(P, S, par, sid, xcd, 64, lane, b, false, lane, true);
+        }
+    }
     if (n_tr > 0) {  // (block-uniform)
         uint32_t* rnd = reinterpret_cast<uint32_t*>(fast_lds_raw);
         uint32_t* act_terms = rnd + 2048;
@@ -599,40 +624,48 @@ __global__ void __launch_bounds__(LOB_TRACE_BLOCK, LOB_TRACE_OCC) trace_rest_ker
         for (int i = threadIdx.x & 63; i < LOB_TSLOTS / 4; i += 64)  // every wave's tile set starts (and is handed on) empty
             reinterpret_cast<uint4*>(tab)[i] = make_uint4(LOB_NOTILE, LOB_NOTILE, LOB_NOTILE, LOB_NOTILE);
         __syncthreads();
+        // ---- the books the lane trace kernel handed on: (TD error if that is pending too,) trace step, then their sums ----
+        if (w < LOB_WAVES_PER_BLOCK) {
 #pragma unroll 1
-        for (int t = wave; t < n_tr; t += n_waves) {
-            asm volatile("" : "+v"(lane_));
-            const int lane = lane_;
-            const int ent = __builtin_amdgcn_readfirstlane(S.tr_list2[t]);
-            const int b = LOB_TRL_BOOK(ent);
-            const LHdr h = S.hdr[b];
-            const int lslot = P.memo ? S.mk_slot_last[b] : -1;
-            f64 qs_last[LOB_N_ACTIONS];
+            for (int t = blockIdx.x * LOB_WAVES_PER_BLOCK + w; t < n_tr; t += gridDim.x * LOB_WAVES_PER_BLOCK) {
+                asm volatile("" : "+v"(lane_));
+                const int lane = lane_;
+                const int ent = __builtin_amdgcn_readfirstlane(S.tr_list2[t]);
+                const int b = LOB_TRL_BOOK(ent);
+                if (S.acc_pend[b] & 1) {  // (handed back by the learn kernel as well: n_learn > 0, the table is staged)
+                    learn_q_book<ALGO>(P, S, L, w, lane, b);
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+                    __builtin_amdgcn_wave_barrier();
+                }
+                const LHdr h = S.hdr[b];
+                const int lslot = P.memo ? S.mk_slot_last[b] : -1;
+                f64 qs_last[LOB_N_ACTIONS];
 #pragma unroll
-            for (int a = 0; a < LOB_N_ACTIONS; a++) qs_last[a] = S.qs_last[(size_t)b * LOB_N_ACTIONS + a];
-            if (!h.stepped) continue;
-            const int4 lid = *reinterpret_cast<const int4*>(S.mk_ident + (size_t)(lslot >= 0 ? lslot : 0) * 4);
-            Prof pf;
-            pf.start(S.prof, b, lane);
-            learn_stage_vars(S.vars + (size_t)b * 48, vars, lane);
-            const int last = h.slot_cur ^ 1;
-            const bool zero_last = (h.zero_mask >> last) & 1;
-            const int qvl = tile_quant(vars[last * 16 + (lane & 15)]);
-            const bool lmatch = lslot >= 0 && !zero_last && lid.x == __builtin_amdgcn_readlane(qvl, 0) && lid.y == __builtin_amdgcn_readlane(qvl, 1) &&
-                                lid.z == __builtin_amdgcn_readlane(qvl, 2);
-            Rng g{P.seed, P.book_id_offset + (u64)b, h.rng_ctr};
-            CbPending pend;
-            bool dup = false;
-            int mtag = -1;
-            if (P.sarsa_lanes && lmatch && S.mk_tiles_ok[lslot] == 3) mtag = lslot | ((P.epi_epoch & 0x7fff) << 16);
-            learn_traces<ALGO>(P, S, b, h, rnd, act_terms, tab, false, vars + last * 16, zero_last, qs_last, g, lane, pend, pf, lmatch ? lid.w : 0, &dup,
-                               LOB_TRL_AMAX(ent), sid, mtag);
-            if (lmatch && lid.w == 0 && lane == 0) S.mk_ident[(size_t)lslot * 4 + 3] = dup ? 2 : 1;
-            cb_claim_finish(S, pend);  // (at once: the generation's slot is looked up right below)
-            // the book's generations as the trace step has left them (header, masks, slots: this wave's own stores)
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
-            __builtin_amdgcn_wave_barrier();
-            accumulate_generations(P, S, par, sid, xcd, 64, lane, b, false, lane);
+                for (int a = 0; a < LOB_N_ACTIONS; a++) qs_last[a] = S.qs_last[(size_t)b * LOB_N_ACTIONS + a];
+                if (!h.stepped) continue;
+                const int4 lid = *reinterpret_cast<const int4*>(S.mk_ident + (size_t)(lslot >= 0 ? lslot : 0) * 4);
+                Prof pf;
+                pf.start(S.prof, b, lane);
+                learn_stage_vars(S.vars + (size_t)b * 48, vars, lane);
+                const int last = h.slot_cur ^ 1;
+                const bool zero_last = (h.zero_mask >> last) & 1;
+                const int qvl = tile_quant(vars[last * 16 + (lane & 15)]);
+                const bool lmatch = lslot >= 0 && !zero_last && lid.x == __builtin_amdgcn_readlane(qvl, 0) && lid.y == __builtin_amdgcn_readlane(qvl, 1) &&
+                                    lid.z == __builtin_amdgcn_readlane(qvl, 2);
+                Rng g{P.seed, P.book_id_offset + (u64)b, h.rng_ctr};
+                CbPending pend;
+                bool dup = false;
+                int mtag = -1;
+                if (P.sarsa_lanes && lmatch && S.mk_tiles_ok[lslot] == 3) mtag = lslot | ((P.epi_epoch & 0x7fff) << 16);
+                learn_traces<LOB_ALGO_QLAMBDA>(P, S, b, h, rnd, act_terms, tab, false, vars + last * 16, zero_last, qs_last, g, lane, pend, pf, lmatch ? lid.w : 0, &dup,
+                                               LOB_TRL_AMAX(ent), sid, mtag);
+                if (lmatch && lid.w == 0 && lane == 0) S.mk_ident[(size_t)lslot * 4 + 3] = dup ? 2 : 1;
+                cb_claim_finish(S, pend);  // (at once: the generation's slot is looked up right below)
+                // the book's generations as the trace step has left them (header, masks, slots: this wave's own stores)
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+                __builtin_amdgcn_wave_barrier();
+                accumulate_generations(P, S, par, sid, xcd, 64, lane, b, false, lane, true);
+            }
         }
     }
     // ---- what the fused accumulation left (accumulate_kernel over `acc_list`) ----
@@ -643,7 +676,7 @@ __global__ void __launch_bounds__(LOB_TRACE_BLOCK, LOB_TRACE_OCC) trace_rest_ker
         const int i = (wv << (6 - lpb_shift)) + (lane >> lpb_shift);
         const bool have = i < n_acc;
         const uint32_t ent = have ? (uint32_t)S.acc_list[i] : 0u;
-        accumulate_generations(P, S, par, sid, xcd, lpb, sub, have ? (int)(ent & 0x7fffffffu) : S.B, have && (ent >> 31) != 0, lane);
+        accumulate_generations(P, S, par, sid, xcd, lpb, sub, have ? (int)(ent & 0x7fffffffu) : S.B, have && (ent >> 31) != 0, lane, true);
     }
 }
 // Agent::UpdateTraces with one LANE per book, for the books whose step leaves no older generation behind -- Watkins's
@@ -783,7 +816,7 @@ __global__ void __launch_bounds__(LOB_TS_BLOCK, 5) trace_lane_kernel(DevParams P
         const int4 lid = *reinterpret_cast<const int4*>(S.mk_ident + (size_t)ls * 4);
         const int action = h.action;
         const bool fuse_acc = QL && acc_fuse != 0;
-        const bool td_pending = fuse_acc && S.acc_pend[bb] != 0;  // (handed back by the learn kernel)
+        const bool td_pending = fuse_acc && (S.acc_pend[bb] & 1) != 0;  // (handed back by the learn kernel)
         int n_old = h.tr_n;
         if (n_old > P.trace_kmax - 1) n_old = P.trace_kmax - 1;
         if (QL && action != LOB_TRL_AMAX(ent)) n_old = 0;  // Watkins's cut (QLearn::UpdateTraces, agent.cpp:272-280: traces.decay(0.0))
@@ -827,12 +860,13 @@ __global__ void __launch_bounds__(LOB_TS_BLOCK, 5) trace_lane_kernel(DevParams P
                     // (the wave-per-book kernel does its traces: all its generations are accumulate_kernel's -- or, acc_fuse = 2,
                     // trace_rest_kernel's own wave adds them up right behind the trace step)
                     if (fuse_acc && acc_fuse != 2) S.acc_list[atomicAdd(&S.acc_list_n[lpar], 1)] = b;
+                    if (acc_fuse == 2) S.acc_pend[b] = (uint8_t)((td_pending ? 1 : 0) | 2);  // (bit 1: its trace step is trace_rest_kernel's too)
                 }
                 continue;
             }
         }
         if (!stepped) continue;
-        if (td_pending && k == 0) S.acc_list[atomicAdd(&S.acc_list_n[lpar], 1)] = b;
+        if (td_pending && k == 0 && acc_fuse != 2) S.acc_list[atomicAdd(&S.acc_list_n[lpar], 1)] = b;  // (acc_fuse 2: the work list names it already)
         const bool add_here = fuse_acc && !td_pending;
         const f64 upd32 = h.upd / (f64)LOB_N_TILINGS;
         const int vec = h.stepped == 2 ? 1 : 0;  // (double Q: the learn kernel's coin)
@@ -1360,7 +1394,8 @@ __global__ void __launch_bounds__(LOB_QL_BLOCK) learn_q_lane_kernel(DevParams P,
             S.slow_list[(size_t)S.B + pos] = b;
             recp[0] = LOB_HL_NONE;
             cb_claim_finish(S, pend);
-            if (TR && acc_fuse) {  // (its TD error comes later: accumulate_kernel takes every generation of the book)
+            if (TR && acc_fuse == 2) S.acc_pend[b] = 1;  // (trace_rest_kernel computes its TD error and adds its generations up: the work list names it)
+            else if (TR && acc_fuse) {  // (its TD error comes later: accumulate_kernel takes every generation of the book)
                 if (tlight) S.acc_list[atomicAdd(&S.acc_list_n[lpar], 1)] = b;
                 else S.acc_pend[b] = 1;
             }
@@ -1428,6 +1463,7 @@ __global__ void __launch_bounds__(LOB_QL_BLOCK) learn_q_lane_kernel(DevParams P,
             } else {
                 S.acc_pend[b] = 0;
             }
+            if (acc_fuse == 2 && tlight) S.acc_pend[b] = 0;  // (every stepped book's flag is current: trace_rest_kernel reads it for whatever list names the book)
         }
     }
 }
@@ -1694,7 +1730,8 @@ __global__ void __launch_bounds__(LOB_QP_BLOCK) learn_q_pair_kernel(DevParams P,
                     recp[0] = LOB_HL_NONE;
                     // (its TD error comes later: every generation of the book is accumulate_kernel's -- a light book goes on the
                     // list here, a listed one when trace_lane_kernel meets it)
-                    if (TR && acc_fuse) {
+                    if (TR && acc_fuse == 2) S.acc_pend[b] = 1;  // (trace_rest_kernel: its TD error and its sums, from the work list)
+                    else if (TR && acc_fuse) {
                         if (light) S.acc_list[atomicAdd(&S.acc_list_n[lpar], 1)] = b;
                         else S.acc_pend[b] = 1;
                     }
@@ -1735,7 +1772,7 @@ __global__ void __launch_bounds__(LOB_QP_BLOCK) learn_q_pair_kernel(DevParams P,
                     }
                     recp[0] = (u64)(n1 + n);
                     for (int i = 0; i < n; i++) recp[1 + n1 + i] = ql_unpack(row[1 + i]);
-                    if (TR && acc_fuse && !light) S.acc_pend[b] = 0;
+                    if (TR && acc_fuse && (!light || acc_fuse == 2)) S.acc_pend[b] = 0;  // (acc_fuse 2: every stepped book's flag is current)
                     if (TR && acc_fuse && light) {
                         // the book's one generation (age 0, all 32 tiles alive): alpha delta / 32 x e(0) into its slot
                         const size_t gi = (size_t)b * P.trace_gens + ((light_code & 63u) - 1u);

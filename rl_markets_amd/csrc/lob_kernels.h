@@ -1539,10 +1539,34 @@ __device__ inline bool acc_generation(const DevState& S, size_t gi, uint32_t mas
     if (!(cs >= 0 && (cs & LOB_CBS_VERIFIED))) sg = *reinterpret_cast<const int4*>(S.tr_sig + gi * 4);
     return acc_generation_at(S, gi, cs, sg, mask, val, xcd, target);
 }
+// ONE generation without a slot, the whole wave: its update (`scaled` x e(age)) onto the weights of its live tiles (`m`), with
+// the written-weights maps kept up as apply_kernel does for a slot's tiles.  Only while nobody reads theta.
+__device__ inline void apply_generation_directly(const DevParams& P, const DevState& S, int par, int sid, int b, int sl, int age, uint32_t m, f64 scaled, int target, int lane) {
+    f64* theta = target ? S.theta_b : S.theta;
+    uint32_t* nz = target ? S.theta_b_nz : S.theta_nz;
+    const int j = lane & 31;
+    if (lane < 32 && ((m >> j) & 1u)) {
+        const i32 f = S.tr_idx[((size_t)b * P.trace_gens + sl) * 32 + j];
+        __hip_atomic_fetch_add(&theta[f], scaled * (f64)P.trace_pow[age], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (P.memo) nzx_mark_late(P, S, f, sid);  // (one map for both weight vectors of double Q: written in either)
+        const uint32_t bit = LOB_NZ_BIT(f);
+        if (!(nz[LOB_NZ_WORD(f)] & bit)) {
+            const uint32_t old = atomicOr(&nz[LOB_NZ_WORD(f)], bit);
+            if (!(old & bit) && P.carry_verdicts) {
+                i32* nz_new = S.nz_new + (2 * target + par) * LOB_NZ_WORDS;
+                atomicAdd(&nz_new[0], 1);
+                atomicOr((uint32_t*)&nz_new[LOB_NZ_FILTER + (LOB_NZ_WORD(f) & (LOB_NZ_FILTER - 1))], bit);
+            }
+        }
+    }
+}
 // The generations of ONE book (per lane group of `lpb` lanes: lane `sub` of the group takes the ages sub, sub + lpb, ...) added to
 // their slots; `direct_only`: only those without a slot.  Called by whole waves (the direct path ballots): accumulate_kernel with
 // 64 >> lpb_shift books per wave, trace_rest_kernel with one.
-__device__ __forceinline__ void accumulate_generations(const DevParams& P, const DevState& S, int par, int sid, int xcd, int lpb, int sub, int b, bool direct_only, int lane) {
+// `defer` (trace_rest_kernel, where other waves read theta meanwhile): a generation without a slot is not applied here but put on
+// `dir_list` for apply_kernel (apply_deferred_generations).
+__device__ __forceinline__ void accumulate_generations(const DevParams& P, const DevState& S, int par, int sid, int xcd, int lpb, int sub, int b, bool direct_only, int lane,
+                                                       bool defer = false) {
     int n = 0, head = 0, target = 0;
     f64 scaled = 0.0;
     if (b < S.B) {
@@ -1605,6 +1629,10 @@ __device__ __forceinline__ void accumulate_generations(const DevParams& P, const
                 direct = true;
             }
         }
+        if (defer) {  // (wave-uniform)
+            if (direct) S.dir_list[atomicAdd(&S.dir_list_n[par], 1)] = bb * G + slot;
+            continue;
+        }
         u64 todo = __ballot(direct);
         while (todo) {  // rare: apply these generations tile by tile, the whole wave per generation
             const int src = __builtin_ctzll(todo);
@@ -1612,25 +1640,26 @@ __device__ __forceinline__ void accumulate_generations(const DevParams& P, const
             const int d_b = __shfl(bb, src), d_age = __shfl(age, src), d_head = __shfl(head, src), d_t = __shfl(target, src);
             const uint32_t m = __shfl(mask, src);
             const f64 d_scaled = readlane_f64(scaled, src);
-            f64* theta = d_t ? S.theta_b : S.theta;
-            uint32_t* nz = d_t ? S.theta_b_nz : S.theta_nz;
             const int sl = (d_head - d_age + G) & (G - 1);
-            const int j = lane & 31;
-            if (lane < 32 && ((m >> j) & 1u)) {
-                const i32 f = S.tr_idx[((size_t)d_b * G + sl) * 32 + j];
-                __hip_atomic_fetch_add(&theta[f], d_scaled * (f64)P.trace_pow[d_age], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (P.memo) nzx_mark_late(P, S, f, sid);  // (one map for both weight vectors of double Q: written in either)
-                const uint32_t bit = LOB_NZ_BIT(f);
-                if (!(nz[LOB_NZ_WORD(f)] & bit)) {
-                    const uint32_t old = atomicOr(&nz[LOB_NZ_WORD(f)], bit);
-                    if (!(old & bit) && P.carry_verdicts) {
-                        i32* nz_new = S.nz_new + (2 * d_t + par) * LOB_NZ_WORDS;
-                        atomicAdd(&nz_new[0], 1);
-                        atomicOr((uint32_t*)&nz_new[LOB_NZ_FILTER + (LOB_NZ_WORD(f) & (LOB_NZ_FILTER - 1))], bit);
-                    }
-                }
-            }
+            apply_generation_directly(P, S, par, sid, d_b, sl, d_age, m, d_scaled, d_t, lane);
         }
+    }
+}
+// apply_kernel's share of trace_rest_kernel's work: the generations it found without a slot (`dir_list`: book x G + ring slot),
+// applied tile by tile now that nobody reads theta -- the grid's waves stride over the list (empty in most steps).  The list of
+// the other parity, consumed a step ago, is emptied for the next step.
+__device__ inline void apply_deferred_generations(const DevParams& P, const DevState& S, int par, int sid, int wave, int n_waves, int lane) {
+    if (!S.dir_list) return;
+    if (wave == 0 && lane == 0) S.dir_list_n[par ^ 1] = 0;
+    const int n = S.dir_list_n[par];
+    if (n > 0 && wave == 0 && lane == 0) atomicAdd((u64*)&S.counters[8], (u64)n);  // (lob_debug_deferred)
+    const int G = P.trace_gens;
+    for (int i = wave; i < n; i += n_waves) {
+        const int ent = S.dir_list[i];
+        const int b = ent / G, sl = ent & (G - 1);
+        const LHdr& h = S.hdr[b];
+        const int age = (h.tr_head - sl) & (G - 1);
+        apply_generation_directly(P, S, par, sid, b, sl, age, S.tr_alive[(size_t)b * G + sl], h.upd / (f64)LOB_N_TILINGS, h.stepped == 2 ? 1 : 0, lane);
     }
 }
 // `list` (or null: every book): accumulate_kernel over the books the fused accumulation left (lob_state.h acc_list); an entry
@@ -2013,6 +2042,7 @@ __global__ void __launch_bounds__(256) apply_kernel(DevParams P, DevState S, con
     __shared__ int n_surv;
     // one block per segment of the table: its list, its survivors -- no counter shared between blocks
     const int seg = par * S.cb_segs + blockIdx.x, seg_next = (par ^ 1) * S.cb_segs + blockIdx.x, cap = S.cb_slots / S.cb_segs;
+    apply_deferred_generations(P, S, par, sid, (int)(blockIdx.x * 4 + (threadIdx.x >> 6)), (int)(gridDim.x * 4), (int)(threadIdx.x & 63));
     const int count = S.cb_count[seg];
     if (count == 0) return;  // (block-uniform)
     {

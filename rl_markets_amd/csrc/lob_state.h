@@ -358,7 +358,12 @@ struct DevState {
     // book | 1 << 31 (only the book's generations without a slot: the direct, tile-by-tile path must wait until nobody reads theta).
     i32* acc_list;       // [B]
     i32* acc_list_n;     // [2 parities]
-    uint8_t* acc_pend;   // [B] the learn kernel handed the book back (its TD error comes with learn_q_rest_kernel): trace_lane_kernel must not add its update yet
+    uint8_t* acc_pend;   // [B] bit 0: the learn kernel handed the book back (its TD error comes later): trace_lane_kernel must not add its update yet;
+                         //     bit 1 (trace_rest_kernel's flow): trace_lane_kernel handed the book's trace step on
+    // trace_rest_kernel's generations without a slot (book x trace_gens + ring slot), applied tile by tile by apply_kernel: other
+    // waves of trace_rest_kernel read theta (learn_q_book) while it adds generations up
+    i32* dir_list;       // [B x trace_gens] (a generation is listed at most once per step)
+    i32* dir_list_n;     // [2 parities of the combine table's lists: apply_kernel empties the one it consumed a step ago]
     i32* slow_list;      // [2 kinds: act, learn][B]
     i32* slow_n;         // [2 parities][2 kinds]
     // Hit-list carry-over learn_q(t) -> act(t+1) (lob_fast.h act_light_kernel): the Q evaluation of the TD target and the

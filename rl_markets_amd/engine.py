@@ -277,6 +277,14 @@ class Engine:
                 "act_inline_general": int(c[4]), "act_work_list_dense": int(c[5]), "act_work_list_other": int(c[6]),
                 "dense_sums": int(c[7])}
 
+    def deferred_generations(self):
+        """lob_debug_deferred (a diagnostic export): generations without a combine slot that trace_rest_kernel left to apply_kernel so far."""
+        c = np.zeros(1, np.int64)
+        fn = self.lib.lob_debug_deferred
+        fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_void_p]
+        self._check(fn(self.h, _ptr(c)))
+        return int(c[0])
+
     def fastpath_stats(self):
         """lob_debug_fastpath (a diagnostic export, not in include/lob_engine.h): written weights and the live books' hit-list lengths."""
         n = 4 + 257

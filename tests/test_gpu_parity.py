@@ -811,6 +811,54 @@ def test_q_lane_kernel_on_off_identical(monkeypatch, algo, mem, n_vars, pair):
     np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-9, atol=1e-12)
 
 
+@pytest.mark.parametrize("pair", ["0", "1"])
+@pytest.mark.parametrize("algo", [abi.ALGO_QLAMBDA, abi.ALGO_DOUBLE_Q])
+@pytest.mark.parametrize("mem,slots", [(1 << 12, 0), (1 << 16, 256), (1 << 20, 0)])
+def test_rest_kernel_merged_against_oracle_and_split(monkeypatch, algo, mem, slots, pair):
+    """The fused Q(lambda) / double Q flow's rare paths in ONE launch (trace_rest_kernel: a handed-back book's TD error, a handed-on
+    book's trace step, their sums) against the oracle step by step, and against the three launches it replaces (LOB_REST_MERGE=0).
+    A 4 096-weight table hands most books back AND on; a 256-slot combine table leaves most generations without a slot -- in
+    the merged kernel those wait for apply_kernel (other waves read theta meanwhile: the fold of round 5 that applied them on the
+    spot was off by 6e-3 in one book's TD error at step 9 of exactly this configuration), counted by lob_debug_deferred."""
+    B = 192
+    monkeypatch.setenv("LOB_Q_LANES", "1")
+    monkeypatch.setenv("LOB_FUSE_ACT", "1")   # (double Q's fast path at fewer than 1 024 books)
+    monkeypatch.setenv("LOB_Q_PAIR", pair)
+    if slots:
+        monkeypatch.setenv("LOB_CB_SLOTS", str(slots))
+    out = []
+    for merge in ("1", "0"):
+        monkeypatch.setenv("LOB_REST_MERGE", merge)
+        p, g, rec, eng, orc = make(depth=5, n_events=500, B=B, algo=algo, theta_mode=abi.THETA_SHARED, mem=mem, epsilon=0.3)
+        eng.reset()
+        orc.reset()
+        trail = []
+        for step in range(40):
+            eng.td_step(1)
+            orc.td_step(1)
+            compare_learner_step(eng, orc, "merge %s step %d" % (merge, step), exact=False, rtol=1e-9)
+            trail.append((eng.last_actions().copy(), eng.last_td().copy(), bytes(eng.get_books())))
+        np.testing.assert_allclose(eng.theta(), orc.theta(), rtol=1e-9, atol=1e-12)
+        ps, fl, dg = eng.path_stats(), eng.flow_stats(), eng.deferred_generations()
+        print("merge", merge, "handed on", int(ps[0]), "handed back", int(ps[7]), "deferred generations", dg, fl)
+        assert fl["added_in_place"] >= 38, fl
+        if merge == "1":
+            if mem == 1 << 12:
+                assert ps[7] > 4 * B and ps[0] > 0, ps      # books handed back in every step, some handed on as well
+            if slots:
+                assert dg > B, dg                           # generations without a slot: applied by apply_kernel
+        else:
+            assert dg == 0
+        out.append((trail, eng.theta()))
+        eng.close()
+        orc.close()
+    for k, ((a0, t0, b0), (a1, t1, b1)) in enumerate(zip(out[0][0], out[1][0])):
+        np.testing.assert_array_equal(a0, a1, err_msg="actions, step %d" % k)
+        assert b0 == b1, "books differ at step %d" % k
+        np.testing.assert_allclose(t0, t1, rtol=1e-9, atol=1e-12, err_msg="td, step %d" % k)
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-9, atol=1e-12)
+
+
 @pytest.mark.parametrize("lanes", ["0", "1"])
 @pytest.mark.parametrize("mem,eps", [(1 << 12, 0.8), (1 << 22, 0.8), (1 << 22, 0.1)])
 def test_trace_light_kernel_on_off_identical(monkeypatch, mem, eps, lanes):
