@@ -393,7 +393,8 @@ int lob_get_counters(lob_engine* e, int64_t out[4]);
  * [1] books whose action came from the hit-list replay (the light action selection), [2] memo slots registered this episode,
  * [3] weight indices found ambiguous this episode (tile registry), [4] 1 if the registry overflowed this episode,
  * [5] memo slots in use in the latest step, [6] books whose action the fused env kernel had to evaluate in full (no usable hit
- * list: act_book in-kernel), [7] books the lane learn kernels handed back to the wave-per-book learn_q_rest_kernel. */
+ * list: act_book in-kernel), [7] books the lane learn kernels handed back to the wave-per-book evaluation (trace_rest_kernel /
+ * learn_q_rest_kernel). */
 int lob_get_path_stats(lob_engine* e, int64_t out[8]);
 
 /* ---- multi-GPU weight exchange ---------------------------
