@@ -496,5 +496,7 @@ def test_zz_update_paths_the_sweep_went_through():
     in_place = [f for v, f in ql if v in ("pair", "pair_rest_split") and f["added_in_place"] > 0 and f["every_book"] == 0]
     whole = [f for v, f in ql if v == "pair_acc_pass" and f["every_book"] > 0]
     print("Q(lambda) cases with updates added in place: %d, with the accumulate pass over every book: %d" % (len(in_place), len(whole)))
+    if os.environ.get("PYTEST_XDIST_WORKER"):
+        pytest.skip("under pytest-xdist this process has seen only its share of the sweep")
     assert len(in_place) >= 6 and len(whole) >= 3
     assert all(f["added_in_place"] == 0 for v, f in ql if v not in ("pair", "pair_rest_split", "lane"))
