@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "lob_internal.h"
@@ -821,18 +822,71 @@ static int set_records(lob_engine* e, int32_t n_events, size_t n_rows) {
     return LOB_OK;
 }
 
-// host ABI records -> HBM in the device layout (through a temporary device copy)
+// host ABI records -> HBM in the device layout.  Small uploads: one pageable copy into a temporary device buffer, one repack.
+// Big ones (the 26.6 GB of 65 536 private streams): 64 MB pieces through two pinned staging buffers -- a few host threads copy
+// piece k + 1 into its buffer while the DMA engine and the repack kernel are on piece k -- so the hand-over runs at what the
+// slower of the host's memcpy and the link gives instead of the runtime's pageable path, and the temporary device copy is two
+// pieces, not another whole stream.
 static int upload_records(lob_engine* e, const uint32_t* host_records, size_t n_records) {
-    uint32_t* tmp = nullptr;
-    const size_t bytes = n_records * e->P.W * 4;
-    if (hipMalloc((void**)&tmp, bytes) != hipSuccess) { lob_set_error("hipMalloc(upload buffer) failed"); return LOB_ENOMEM; }
-    hipError_t err = hipMemcpyAsync(tmp, host_records, bytes, hipMemcpyHostToDevice, e->stream);
-    if (err == hipSuccess) {
-        lobk_repack(e->stream, (const uint32_t*)tmp, e->P.D, e->P.T, n_records, e->records_dev);
-        err = hipGetLastError();
+    const size_t rec_bytes = (size_t)e->P.W * 4;
+    const size_t bytes = n_records * rec_bytes;
+    const size_t piece_recs = std::max<size_t>(1, ((size_t)64 << 20) / rec_bytes);
+    if (n_records <= 2 * piece_recs) {
+        uint32_t* tmp = nullptr;
+        if (hipMalloc((void**)&tmp, bytes) != hipSuccess) { lob_set_error("hipMalloc(upload buffer) failed"); return LOB_ENOMEM; }
+        hipError_t err = hipMemcpyAsync(tmp, host_records, bytes, hipMemcpyHostToDevice, e->stream);
+        if (err == hipSuccess) {
+            lobk_repack(e->stream, (const uint32_t*)tmp, e->P.D, e->P.T, n_records, e->records_dev);
+            err = hipGetLastError();
+        }
+        if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+        hipFree(tmp);
+        if (err != hipSuccess) { lob_set_error(std::string("record upload: ") + hipGetErrorString(err)); return LOB_EHIP; }
+        return LOB_OK;
     }
-    if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
-    hipFree(tmp);
+    const size_t piece_bytes = piece_recs * rec_bytes;
+    void* pinned[2] = {nullptr, nullptr};
+    uint32_t* tmp[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    hipError_t err = hipSuccess;
+    for (int i = 0; i < 2 && err == hipSuccess; i++) {
+        err = hipHostMalloc(&pinned[i], piece_bytes, hipHostMallocDefault);
+        if (err == hipSuccess) err = hipMalloc((void**)&tmp[i], piece_bytes);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
+    }
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt < 1 ? 1 : nt > 8 ? 8 : nt;
+    const size_t n_pieces = (n_records + piece_recs - 1) / piece_recs;
+    for (size_t k = 0; k < n_pieces && err == hipSuccess; k++) {
+        const int i = (int)(k & 1);
+        const size_t r0 = k * piece_recs, nr = std::min(piece_recs, n_records - r0), nb = nr * rec_bytes;
+        if (k >= 2) err = hipEventSynchronize(done[i]);  // (piece k - 2 has left this staging buffer and its device copy)
+        if (err != hipSuccess) break;
+        {
+            const char* src = reinterpret_cast<const char*>(host_records) + r0 * rec_bytes;
+            char* dst = reinterpret_cast<char*>(pinned[i]);
+            std::vector<std::thread> th;
+            for (unsigned t = 1; t < nt; t++) {
+                const size_t a = nb * t / nt, b = nb * (t + 1) / nt;
+                th.emplace_back([=] { memcpy(dst + a, src + a, b - a); });
+            }
+            memcpy(dst, src, nb / nt);
+            for (auto& t : th) t.join();
+        }
+        err = hipMemcpyAsync(tmp[i], pinned[i], nb, hipMemcpyHostToDevice, e->stream);
+        if (err == hipSuccess) {
+            lobk_repack(e->stream, (const uint32_t*)tmp[i], e->P.D, e->P.T, nr, e->records_dev + r0 * (size_t)e->P.Wd);
+            err = hipGetLastError();
+        }
+        if (err == hipSuccess) err = hipEventRecord(done[i], e->stream);
+    }
+    const hipError_t err2 = hipStreamSynchronize(e->stream);
+    if (err == hipSuccess) err = err2;
+    for (int i = 0; i < 2; i++) {
+        if (done[i]) hipEventDestroy(done[i]);
+        if (tmp[i]) hipFree(tmp[i]);
+        if (pinned[i]) hipHostFree(pinned[i]);
+    }
     if (err != hipSuccess) { lob_set_error(std::string("record upload: ") + hipGetErrorString(err)); return LOB_EHIP; }
     return LOB_OK;
 }

@@ -110,6 +110,22 @@ def test_stream_generator_is_deterministic_and_valid():
     assert lib.lob_validate_stream(bad.ctypes.data_as(C.c_void_p), 10, 2, 4, 300) == abi.LOB_EDATA
 
 
+def test_big_streams_are_validated_by_threads_and_report_the_first_book():
+    """Streams of 2^18 records and more are checked by several host threads over contiguous book ranges: the offence reported is
+    that of the lowest book (its first event), as the serial scan reports it."""
+    g = engine.default_gen_params()
+    g.n_events = 600
+    a = engine.gen_stream_host(g, 10, 2, 0, 512)
+    lib = abi.load()
+    assert lib.lob_validate_stream(a.ctypes.data_as(C.c_void_p), 10, 2, 512, 600) == 0
+    bad = a.copy()
+    bad[400, 7, 2] = bad[400, 7, 3]      # duplicate ask price key, a book of a later range
+    bad[37, 500, 0] = 5                  # time goes backwards
+    bad[37, 9, 2] = bad[37, 9, 3]
+    assert lib.lob_validate_stream(bad.ctypes.data_as(C.c_void_p), 10, 2, 512, 600) == abi.LOB_EDATA
+    assert lib.lob_last_error().startswith(b"book 37 event 9 ")
+
+
 def test_bad_params_rejected():
     lib = abi.load()
     p = engine.default_params()
