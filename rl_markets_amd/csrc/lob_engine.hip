@@ -831,7 +831,7 @@ static int upload_records(lob_engine* e, const uint32_t* host_records, size_t n_
     const size_t rec_bytes = (size_t)e->P.W * 4;
     const size_t bytes = n_records * rec_bytes;
     const size_t piece_recs = std::max<size_t>(1, ((size_t)64 << 20) / rec_bytes);
-    if (n_records <= 2 * piece_recs) {
+    auto one_copy = [&]() -> int {
         uint32_t* tmp = nullptr;
         if (hipMalloc((void**)&tmp, bytes) != hipSuccess) { lob_set_error("hipMalloc(upload buffer) failed"); return LOB_ENOMEM; }
         hipError_t err = hipMemcpyAsync(tmp, host_records, bytes, hipMemcpyHostToDevice, e->stream);
@@ -843,7 +843,8 @@ static int upload_records(lob_engine* e, const uint32_t* host_records, size_t n_
         hipFree(tmp);
         if (err != hipSuccess) { lob_set_error(std::string("record upload: ") + hipGetErrorString(err)); return LOB_EHIP; }
         return LOB_OK;
-    }
+    };
+    if (n_records <= 2 * piece_recs) return one_copy();
     const size_t piece_bytes = piece_recs * rec_bytes;
     void* pinned[2] = {nullptr, nullptr};
     uint32_t* tmp[2] = {nullptr, nullptr};
@@ -853,6 +854,15 @@ static int upload_records(lob_engine* e, const uint32_t* host_records, size_t n_
         err = hipHostMalloc(&pinned[i], piece_bytes, hipHostMallocDefault);
         if (err == hipSuccess) err = hipMalloc((void**)&tmp[i], piece_bytes);
         if (err == hipSuccess) err = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
+    }
+    if (err != hipSuccess) {  // (no pinned memory to be had -- a locked-memory limit: the one-copy path needs none)
+        (void)hipGetLastError();
+        for (int i = 0; i < 2; i++) {
+            if (done[i]) hipEventDestroy(done[i]);
+            if (tmp[i]) hipFree(tmp[i]);
+            if (pinned[i]) hipHostFree(pinned[i]);
+        }
+        return one_copy();
     }
     unsigned nt = std::thread::hardware_concurrency();
     nt = nt < 1 ? 1 : nt > 8 ? 8 : nt;
