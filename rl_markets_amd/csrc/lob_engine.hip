@@ -11,8 +11,11 @@
 #include <string.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <map>
+#include <mutex>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -71,7 +74,9 @@ struct lob_engine {
     // step launched now reads the word of LOB_HINT_LAG steps ago after waiting for THAT event (long past, unless the host is
     // more than LOB_HINT_LAG steps ahead of the device -- then it waits: the device still has that many steps queued), so which
     // path a step takes is a function of the run, not of the host's timing.  The first LOB_HINT_LAG steps after
-    // lob_reset / lob_theta_set / a weight exchange read 0.
+    // lob_reset / lob_theta_set read 0.  A weight exchange (lob_delta_apply / lob_delta_sparse_apply) does NOT void the counts:
+    // it runs every 64 steps, the written set only grows by the union of the ranks', and which books have no usable hit list
+    // hardly changes -- voiding them would send a quarter of a dense-theta run's steps down the slower path.
     u64* rest_hint = nullptr;   // word = (step tag) << 32 | count: the host checks the tag, so it never reads a word the device has not written yet
     u64* rest_hint_dev = nullptr;
     hipEvent_t hint_ev[LOB_HINT_RING] = {};
@@ -360,7 +365,8 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
         if (hipHostGetDevicePointer((void**)&e->rest_hint_dev, e->rest_hint, 0) != hipSuccess) e->rest_hint_dev = nullptr;
     } else e->rest_hint = nullptr;   // (no hint: the launch stays on the main stream)
     if (!e->rest_hint_dev && e->rest_hint) { hipHostFree(e->rest_hint); e->rest_hint = nullptr; }
-    for (int i = 0; i < LOB_HINT_RING && e->rest_hint; i++) HIPCHK_E(hipEventCreateWithFlags(&e->hint_ev[i], hipEventDisableTiming | hipEventDisableSystemFence));
+    // (these events DO fence to system scope: the host reads the word the kernel in front of them stored to host memory)
+    for (int i = 0; i < LOB_HINT_RING && e->rest_hint; i++) HIPCHK_E(hipEventCreateWithFlags(&e->hint_ev[i], hipEventDisableTiming));
     if (const char* g = getenv("LOB_MOSTLY_GENERAL")) e->force_general = g[0] == '1' ? 1 : g[0] == '0' ? 0 : -1;
     // Optional (LOB_GROUPS=2): two book groups pipelined on two streams so that the latency-bound env
     // kernel of one group runs beside a gather kernel of the other.  It paid 7 % before the market
@@ -822,16 +828,70 @@ static int set_records(lob_engine* e, int32_t n_events, size_t n_rows) {
     return LOB_OK;
 }
 
+// A few host threads that copy one piece into a pinned staging buffer together, started once per upload (round 5 started and joined
+// up to seven per 64 MB piece: ~2 900 thread creations for 26.6 GB).  std::thread's constructor throws when the process may not
+// start another thread; the pool then runs with the workers it got -- none at all is fine, the caller's thread copies alone.
+struct CopyPool {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    char* dst = nullptr;
+    const char* src = nullptr;
+    size_t nb = 0;
+    unsigned long long gen = 0;
+    unsigned pending = 0;
+    bool quit = false;
+    unsigned parts() const { return (unsigned)th.size() + 1; }
+    explicit CopyPool(unsigned want) {
+        try {
+            for (unsigned t = 1; t < want; t++) th.emplace_back([this, t] { worker(t); });
+        } catch (const std::system_error&) {
+        }
+    }
+    void worker(unsigned t) {
+        unsigned long long seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_go.wait(lk, [&] { return quit || gen != seen; });
+            if (quit) return;
+            seen = gen;
+            char* d = dst; const char* s = src; const size_t n = nb; const unsigned np = parts();
+            lk.unlock();
+            if (t < np) { const size_t a = n * t / np, b = n * (t + 1) / np; memcpy(d + a, s + a, b - a); }
+            lk.lock();
+            if (--pending == 0) cv_done.notify_one();
+        }
+    }
+    void copy(char* d, const char* s, size_t n) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            dst = d; src = s; nb = n; pending = (unsigned)th.size(); gen++;
+        }
+        cv_go.notify_all();
+        memcpy(d, s, n / parts());
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return pending == 0; });
+    }
+    ~CopyPool() {
+        { std::lock_guard<std::mutex> lk(mu); quit = true; }
+        cv_go.notify_all();
+        for (auto& t : th) t.join();
+    }
+};
+
 // host ABI records -> HBM in the device layout.  Small uploads: one pageable copy into a temporary device buffer, one repack.
 // Big ones (the 26.6 GB of 65 536 private streams): 64 MB pieces through two pinned staging buffers -- a few host threads copy
 // piece k + 1 into its buffer while the DMA engine and the repack kernel are on piece k -- so the hand-over runs at what the
 // slower of the host's memcpy and the link gives instead of the runtime's pageable path, and the temporary device copy is two
-// pieces, not another whole stream.
+// pieces, not another whole stream.  Without pinned memory (a locked-memory limit; LOB_UPLOAD_PINNED=0 forces it, for the tests)
+// the same pieces go from the caller's pageable memory directly: slower, and still two pieces of device memory, never a second
+// whole stream.
 static int upload_records(lob_engine* e, const uint32_t* host_records, size_t n_records) {
     const size_t rec_bytes = (size_t)e->P.W * 4;
     const size_t bytes = n_records * rec_bytes;
-    const size_t piece_recs = std::max<size_t>(1, ((size_t)64 << 20) / rec_bytes);
-    auto one_copy = [&]() -> int {
+    size_t piece_recs = std::max<size_t>(1, ((size_t)64 << 20) / rec_bytes);
+    if (const char* g = getenv("LOB_UPLOAD_PIECE_RECS")) { const long v = atol(g); if (v >= 1) piece_recs = (size_t)v; }  // (tests: many small pieces)
+    if (n_records <= 2 * piece_recs) {
         uint32_t* tmp = nullptr;
         if (hipMalloc((void**)&tmp, bytes) != hipSuccess) { lob_set_error("hipMalloc(upload buffer) failed"); return LOB_ENOMEM; }
         hipError_t err = hipMemcpyAsync(tmp, host_records, bytes, hipMemcpyHostToDevice, e->stream);
@@ -843,60 +903,65 @@ static int upload_records(lob_engine* e, const uint32_t* host_records, size_t n_
         hipFree(tmp);
         if (err != hipSuccess) { lob_set_error(std::string("record upload: ") + hipGetErrorString(err)); return LOB_EHIP; }
         return LOB_OK;
-    };
-    if (n_records <= 2 * piece_recs) return one_copy();
+    }
     const size_t piece_bytes = piece_recs * rec_bytes;
     void* pinned[2] = {nullptr, nullptr};
     uint32_t* tmp[2] = {nullptr, nullptr};
     hipEvent_t done[2] = {nullptr, nullptr};
-    hipError_t err = hipSuccess;
-    for (int i = 0; i < 2 && err == hipSuccess; i++) {
-        err = hipHostMalloc(&pinned[i], piece_bytes, hipHostMallocDefault);
-        if (err == hipSuccess) err = hipMalloc((void**)&tmp[i], piece_bytes);
-        if (err == hipSuccess) err = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
-    }
-    if (err != hipSuccess) {  // (no pinned memory to be had -- a locked-memory limit: the one-copy path needs none)
-        (void)hipGetLastError();
+    auto release = [&]() {
         for (int i = 0; i < 2; i++) {
             if (done[i]) hipEventDestroy(done[i]);
             if (tmp[i]) hipFree(tmp[i]);
             if (pinned[i]) hipHostFree(pinned[i]);
         }
-        return one_copy();
+    };
+    hipError_t err = hipSuccess;
+    for (int i = 0; i < 2 && err == hipSuccess; i++) {
+        err = hipMalloc((void**)&tmp[i], piece_bytes);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
     }
+    if (err != hipSuccess) { release(); lob_set_error("hipMalloc(upload pieces) failed"); return LOB_ENOMEM; }
+    bool use_pinned = true;
+    if (const char* g = getenv("LOB_UPLOAD_PINNED")) use_pinned = !(g[0] == '0');
+    for (int i = 0; i < 2 && use_pinned; i++)
+        if (hipHostMalloc(&pinned[i], piece_bytes, hipHostMallocDefault) != hipSuccess) {   // (no pinned memory to be had: the pageable pieces below)
+            (void)hipGetLastError();
+            pinned[i] = nullptr;
+            use_pinned = false;
+        }
+    if (!use_pinned) for (int i = 0; i < 2; i++) if (pinned[i]) { hipHostFree(pinned[i]); pinned[i] = nullptr; }
     unsigned nt = std::thread::hardware_concurrency();
     nt = nt < 1 ? 1 : nt > 8 ? 8 : nt;
-    const size_t n_pieces = (n_records + piece_recs - 1) / piece_recs;
-    for (size_t k = 0; k < n_pieces && err == hipSuccess; k++) {
-        const int i = (int)(k & 1);
-        const size_t r0 = k * piece_recs, nr = std::min(piece_recs, n_records - r0), nb = nr * rec_bytes;
-        if (k >= 2) err = hipEventSynchronize(done[i]);  // (piece k - 2 has left this staging buffer and its device copy)
-        if (err != hipSuccess) break;
-        {
+    int rc = LOB_OK;
+    try {
+        CopyPool pool(use_pinned ? nt : 1);
+        const size_t n_pieces = (n_records + piece_recs - 1) / piece_recs;
+        for (size_t k = 0; k < n_pieces && err == hipSuccess; k++) {
+            const int i = (int)(k & 1);
+            const size_t r0 = k * piece_recs, nr = std::min(piece_recs, n_records - r0), nb = nr * rec_bytes;
+            if (k >= 2) err = hipEventSynchronize(done[i]);  // (piece k - 2 has left this staging buffer and its device copy)
+            if (err != hipSuccess) break;
             const char* src = reinterpret_cast<const char*>(host_records) + r0 * rec_bytes;
-            char* dst = reinterpret_cast<char*>(pinned[i]);
-            std::vector<std::thread> th;
-            for (unsigned t = 1; t < nt; t++) {
-                const size_t a = nb * t / nt, b = nb * (t + 1) / nt;
-                th.emplace_back([=] { memcpy(dst + a, src + a, b - a); });
+            if (use_pinned) {
+                pool.copy(reinterpret_cast<char*>(pinned[i]), src, nb);
+                err = hipMemcpyAsync(tmp[i], pinned[i], nb, hipMemcpyHostToDevice, e->stream);
+            } else {
+                err = hipMemcpyAsync(tmp[i], src, nb, hipMemcpyHostToDevice, e->stream);   // (pageable: the runtime stages it, synchronously)
             }
-            memcpy(dst, src, nb / nt);
-            for (auto& t : th) t.join();
+            if (err == hipSuccess) {
+                lobk_repack(e->stream, (const uint32_t*)tmp[i], e->P.D, e->P.T, nr, e->records_dev + r0 * (size_t)e->P.Wd);
+                err = hipGetLastError();
+            }
+            if (err == hipSuccess) err = hipEventRecord(done[i], e->stream);
         }
-        err = hipMemcpyAsync(tmp[i], pinned[i], nb, hipMemcpyHostToDevice, e->stream);
-        if (err == hipSuccess) {
-            lobk_repack(e->stream, (const uint32_t*)tmp[i], e->P.D, e->P.T, nr, e->records_dev + r0 * (size_t)e->P.Wd);
-            err = hipGetLastError();
-        }
-        if (err == hipSuccess) err = hipEventRecord(done[i], e->stream);
+    } catch (const std::exception& ex) {   // (nothing may cross the C ABI)
+        lob_set_error(std::string("record upload: ") + ex.what());
+        rc = LOB_ENOMEM;
     }
     const hipError_t err2 = hipStreamSynchronize(e->stream);
     if (err == hipSuccess) err = err2;
-    for (int i = 0; i < 2; i++) {
-        if (done[i]) hipEventDestroy(done[i]);
-        if (tmp[i]) hipFree(tmp[i]);
-        if (pinned[i]) hipHostFree(pinned[i]);
-    }
+    release();
+    if (rc != LOB_OK) return rc;
     if (err != hipSuccess) { lob_set_error(std::string("record upload: ") + hipGetErrorString(err)); return LOB_EHIP; }
     return LOB_OK;
 }
@@ -1221,9 +1286,10 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                 HIPCHK(hipEventSynchronize(e->hint_ev[hs]));
                 // (the kernel is done; its store to host memory is a system-scope atomic and carries the launch's tag: wait for that very word)
                 u64 w = *(volatile u64*)(e->rest_hint + hs);
-                for (int spin = 0; (uint32_t)(w >> 32) != e->hint_tags[hs] && spin < (1 << 22); spin++) w = *(volatile u64*)(e->rest_hint + hs);
-                if ((uint32_t)(w >> 32) != e->hint_tags[hs]) { lob_set_error("the learn kernels' hand-back count never arrived in host memory"); return LOB_EHIP; }
-                e->hint_now = (int)(uint32_t)w;
+                for (int spin = 0; (uint32_t)(w >> 32) != e->hint_tags[hs] && spin < (1 << 16); spin++) w = *(volatile u64*)(e->rest_hint + hs);
+                // The count only chooses between two correct paths: a word that has still not arrived (a loaded host, a slow link)
+                // is no reason to abort training -- this step goes by "no book handed back" 
+                e->hint_now = (uint32_t)(w >> 32) == e->hint_tags[hs] ? (int)(uint32_t)w : 0;
             }
         }
         bool rest_pending = false;
@@ -1390,12 +1456,17 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
         if (!second) { e->half_open = true; continue; }
         e->half_open = false;
         if (rest_pending) { HIPCHK(hipStreamWaitEvent(e->stream, e->ev_rest_done, 0)); rest_pending = false; }
-        if (mode == 0 && e->model_log) {  // every stepped book's TD error is final here
+        // model_log: the step's |delta| sums, launched where every stepped book's TD error is final -- behind trace_rest_kernel in
+        // the merged flow (a book the learn kernel handed back still carries Q(s, a) in LHdr::td until that kernel's learn_q_book
+        // has run: ADVICE r5), in front of the update kernels everywhere else
+        auto td_stats = [&]() {
+            if (!(mode == 0 && e->model_log)) return;
             TimedLaunch t(e, "td_stats_kernel");
             const int nblk = std::min(LOB_ML_BLOCKS, (e->B + 255) / 256), per = (e->B + nblk - 1) / nblk;
             hipLaunchKernelGGL(td_stats_kernel, dim3(nblk), dim3(256), 0, e->stream, e->S, per);
             hipLaunchKernelGGL(td_stats_fold_kernel, dim3(1), dim3(64), 0, e->stream, e->S, nblk);
-        }
+        };
+        if (!rest_merged) td_stats();
         if (mode == 0 && e->P.combine) {
             int dense_blocks = 0;
             {
@@ -1445,6 +1516,7 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                                        (const i32*)nullptr, (const i32*)nullptr);
                 }
             }
+            if (rest_merged) td_stats();
             {
                 TimedLaunch t(e, "apply_kernel");
                 const int blocks = e->S.cb_segs;

@@ -1,5 +1,6 @@
 // Host-only part of the C ABI (no GPU needed): parameter defaults, venue tick
 // tables, host tick maths, synthetic stream generation and stream validation.
+#include <system_error>
 #include <thread>
 #include <limits.h>
 #include <math.h>
@@ -268,8 +269,15 @@ int lob_validate_stream(const uint32_t* rec, int32_t D, int32_t T, int32_t n_boo
     };
     if (nt == 1) work(0);
     else {
+        // (std::thread's constructor throws std::system_error when the process may not start another thread -- a container's pids
+        // limit, RLIMIT_NPROC: no exception may cross the C ABI, so the ranges whose thread could not be started are scanned here)
         std::vector<std::thread> th;
-        for (unsigned k = 0; k < nt; k++) th.emplace_back(work, k);
+        unsigned started = 0;
+        try {
+            for (; started < nt; started++) th.emplace_back(work, started);
+        } catch (const std::system_error&) {
+        }
+        for (unsigned k = started; k < nt; k++) work(k);
         for (auto& t : th) t.join();
     }
     for (unsigned k = 0; k < nt; k++)   // (ranges ascend with k: the first slot with an offence holds the lowest book)

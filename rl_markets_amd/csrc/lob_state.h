@@ -371,6 +371,18 @@ struct DevState {
     // group-1/2 tiles fall on a written weight -- the trace kernel marks a new generation's tiles in the maps when it
     // creates the generation, before learn_q looks.  So learn_q leaves, per book, the ordered list of additions
     // Agent::getQ makes beyond the memoised group-0 sum: entry = tile index | action << 32 | (weight w2 ? 1 : 0) << 36.
+    // What a learn kernel READS that a trace kernel of the SAME step WRITES -- why SARSA(lambda)'s trace kernels run in front of its
+    // learn kernels and may not run beside them (round 5 tried: not bit-clean, the reader "not found"; found in round 6):
+    //   1. LHdr::td       trace_lane_kernel<SARSA> / trace_fast_kernel<SARSA, .> leave Q(s, a) there for the TD error (avoidable: qs_last);
+    //   2. the written-weights maps theta_nzx / theta_nzd / theta_nzc (and mk_marked): the trace step MARKS the new generation's 32
+    //      group-0 tiles (nzx_mark) -- the weights the update of this very step is going to write.  The learn kernel decides by
+    //      those maps which group-1/2 tiles of s' go on the hit list below.  A tile of s' that hashes onto one of the new
+    //      generation's weights is still exactly 0.0 when the learn kernel sums Q(s', .), so its TD error is right either way --
+    //      but a list built BEFORE the mark lacks the entry, and the next step's replay (after the update has made the weight
+    //      non-zero) drops that addition: the 2e-4 TD errors of three books in 16 384 that round 5 saw one step later.
+    //      Watkins's flow, where the lane trace kernel does run after the learn kernel, marks through nzx_mark_late, which
+    //      records the step in hl_dirty and so voids every list; SARSA(lambda)'s order makes the marks early instead.
+    //   3. nothing else: tr_head / tr_n / tr_idx / tr_alive / tr_sig / tr_mslot / tr_cbslot are read by the update kernels only.
     u64* hl_rec;         // [B][LOB_HL_REC]: [0] = number of entries, or ~0: no list (not evaluated by the fast learn kernel, or more
                          //   than it can record: LOB_HL_MAX, LOB_HL_CAP from the kernels with one lane or one wave per book); [1 + i] = entry i
     i32* hl_dirty;       // [1] step id of the last update that set a map bit AFTER learn_q had looked (voids every list)

@@ -75,3 +75,27 @@ def test_a_stream_of_more_than_two_million_events_is_accepted():
         assert max(d.ticks_with_ask, d.ticks_with_bid) <= 40 and d.ticks_with_both <= min(d.ticks_with_ask, d.ticks_with_bid)
         assert d.ticks_with_ask + d.ticks_with_bid - d.ticks_with_both <= 40
     eng.close()
+
+
+@pytest.mark.parametrize("pinned", ["1", "0"], ids=["pinned_pieces", "pageable_pieces"])
+def test_the_piecewise_upload_paths_hand_over_the_same_stream(monkeypatch, pinned):
+    """lob_load_events on the path big streams take: pieces through two pinned staging buffers filled by a
+    persistent pool of host threads -- or, when no pinned memory is to be had (LOB_UPLOAD_PINNED=0 forces that branch), the same
+    pieces straight from the caller's pageable memory; never a second whole-stream temporary.  Pieces of 1 000 records here
+    (LOB_UPLOAD_PIECE_RECS) so that a small stream goes through dozens of them, a ragged last piece included; the books must then
+    be the books of the one-copy path, bit for bit, through 30 learner steps."""
+    p, rec, eng0 = _make(B=48)
+    eng0.reset()
+    eng0.td_step(30)
+    want = bytes(eng0.get_books())
+    th0 = eng0.theta()
+    eng0.close()
+    monkeypatch.setenv("LOB_UPLOAD_PIECE_RECS", "1000")
+    monkeypatch.setenv("LOB_UPLOAD_PINNED", pinned)
+    eng = engine.Engine(p, 48)
+    eng.load_events(rec)
+    eng.reset()
+    eng.td_step(30)
+    assert bytes(eng.get_books()) == want
+    np.testing.assert_allclose(eng.theta(), th0, rtol=1e-9, atol=1e-12)
+    eng.close()
