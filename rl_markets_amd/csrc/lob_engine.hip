@@ -50,6 +50,13 @@ struct lob_engine {
     DevParams P;
     DevParams* P_dev = nullptr;  // device copy for the lane-per-book kernels
     DevState S;
+    // The device-resident copy of S, at one address for the engine's lifetime (S.self): kernels that take the state by POINTER read
+    // the fields they need where they need them, through the scalar cache -- 1 728 bytes of by-value kernel arguments are loaded at
+    // the kernel's entry, live across all of it and cost env_step_kernel 104 spilled scalar registers + 160 vector registers parked
+    // in AGPRs (round 6).  Kept up by sync_state() before every launch sequence; the two words a step changes (cb_par,
+    // cb_dense_on) are never read through the pointer: they travel as scalar arguments.
+    DevState* S_dev = nullptr;
+    DevState S_pushed;
     hipStream_t stream = nullptr;   // main stream (all API calls)
     hipStream_t stream2 = nullptr;  // second book group of the step pipeline
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_stagger = nullptr;
@@ -183,6 +190,8 @@ template <class T> int dev_alloc(lob_engine* e, T** p, size_t count) {
     return LOB_OK;
 }
 
+template <class T> int dev_alloc(lob_engine* e, GP<T>* p, size_t count) { return dev_alloc(e, &p->p, count); }
+
 // The registry kernels of the previous learner step (stream2) must be done before anything else looks at what they write.
 static int registry_join(lob_engine* e) {
     if (e->reg_pending) {
@@ -201,6 +210,20 @@ static int registry_fork(lob_engine* e, hipStream_t st, const uint32_t* rnd, int
     hipLaunchKernelGGL(registry_scan_kernel, dim3(256), dim3(256), 0, e->stream2, e->S, par);
     HIPCHK(hipEventRecord(e->ev_reg_done, e->stream2));
     e->reg_pending = true;
+    return LOB_OK;
+}
+// The device copy of DevState follows the host's (rare: a stream loaded, the exchange's buffers allocated, model_log switched on).
+int sync_state(lob_engine* e) {
+    DevState now = e->S;
+    now.cb_par = 0;
+    now.cb_dense_on = 0;
+    now.self = e->S_dev;
+    if (memcmp(&now, &e->S_pushed, sizeof(DevState)) == 0) return LOB_OK;
+    if (hipMemcpyAsync(e->S_dev, &now, sizeof(DevState), hipMemcpyHostToDevice, e->stream) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess) {
+        lob_set_error("state upload failed");
+        return LOB_EHIP;
+    }
+    e->S_pushed = now;
     return LOB_OK;
 }
 int push_params(lob_engine* e) {
@@ -673,6 +696,8 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     S.nzd_terms = e->rnd_dev ? e->rnd_dev + 2048 + LOB_N_ACTIONS : nullptr;  // term[1][.], term[2][.] (filled below)
     if (rc == LOB_OK) rc = dev_alloc(e, &e->actions_dev, B);
     if (rc == LOB_OK) rc = dev_alloc(e, &e->P_dev, 1);
+    if (rc == LOB_OK) rc = dev_alloc(e, &e->S_dev, 1);
+    if (rc == LOB_OK) { S.self = e->S_dev; memset(&e->S_pushed, 0xff, sizeof(DevState)); }
     if (rc == LOB_OK) rc = push_params(e);
     if (rc != LOB_OK) { lob_destroy(e); return rc; }
     // the two rl::State objects start with constructor zeros (src/rl/state.cpp:10-19)
@@ -1082,6 +1107,7 @@ int lob_reset(lob_engine* e) {
     HIPCHK(hipSetDevice(e->device));
     { int rc = finalize_episode(e); if (rc) return rc; }
     { int rc = registry_join(e); if (rc) return rc; }
+    { int rc = sync_state(e); if (rc) return rc; }
     // the memo table starts empty every episode (reset_kernel voids every book's slot)
     HIPCHK(hipMemsetAsync(e->S.mk_hash, 0xff, (size_t)e->S.mk_slots * 8, e->stream));
     HIPCHK(hipMemsetAsync(e->S.mk_tiles_ok, 0, (size_t)e->S.mk_slots * 4, e->stream));
@@ -1264,6 +1290,7 @@ static int acc_lanes_shift(const lob_engine* e) {
 static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
     const bool first = half != 2, second = half != 1;
     HIPCHK(hipSetDevice(e->device));
+    { int rc = sync_state(e); if (rc) return rc; }
     const int G = e->B >= 1024 ? e->n_groups : 1;  // small batches: one group (an empty group would be an empty launch)
     const uint32_t* rnd = (const uint32_t*)e->rnd_dev;
     for (int s = 0; s < n_steps; s++) {
@@ -1396,7 +1423,7 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                         rest_merged = acc_fused && e->rest_merge;
                         const int gq = pair ? std::min(LOB_QP_OCC * e->n_cus, (nb + LOB_QP_BOOKS - 1) / LOB_QP_BOOKS) : std::min(e->n_cus, (nb + LOB_QL_BLOCK - 1) / LOB_QL_BLOCK);
                         const size_t lds = pair ? qpair_lds_bytes(e->P.cwords4) : qlane_lds_bytes(e->P.cwords4);
-                        lobk_learn_q(st, pair, e->P.algo, e->P.V == 8, fuse, gq, lds, e->P, e->S, rnd, lpar, ver, sid, acc_fused ? (rest_merged ? 2 : 1) : 0);
+                        lobk_learn_q(st, pair, e->P.algo, e->P.V == 8, fuse, gq, lds, e->P, (const DevParams*)e->P_dev, e->S, rnd, lpar, ver, sid, acc_fused ? (rest_merged ? 2 : 1) : 0);
                     } else lobk_learn_q_fast(st, e->P.algo, gf, fast_lds_bytes(e->P.cwords4, LOB_FAST_NB, false), e->P, e->S, rnd, lpar, ver);
                 }
                 if (!rest_merged) {   // (rest_merged: trace_rest_kernel serves the books handed back too, behind the lane trace kernel)

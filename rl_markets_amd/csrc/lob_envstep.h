@@ -46,9 +46,15 @@ __device__ inline Track track_load(const Track* p) {
 // stalls if they fit; they only fit by spilling, see NOTES).
 template <int LANES> struct EnvStepOcc { static constexpr int waves = LANES == 64 ? 1 : 2; };
 template <bool INLINE_GENERAL, bool DQ = false, int LANES = 64>
-__global__ void __launch_bounds__(64, EnvStepOcc<LANES>::waves) env_step_kernel(const DevParams* __restrict__ Pp, DevState S, int step_id, int par, EnvFuse F, const uint32_t* __restrict__ rnd_g) {
+__global__ void __launch_bounds__(64, EnvStepOcc<LANES>::waves) env_step_kernel(const DevParams* __restrict__ Pp, const DevState* __restrict__ Sp, int step_id, int par, EnvFuse F,
+                                                                                  const uint32_t* __restrict__ rnd_g) {
     static_assert(LANES == 64 || !INLINE_GENERAL, "the half-full variant leaves the books without a list to the work list");
     const DevParams& P = *Pp;
+    // The state through its device-resident copy (lob_state.h DevState::self), not as 1.7 KB of by-value arguments that are all
+    // loaded at the kernel's entry and live across it: 104 spilled scalar registers and 160 vector registers parked in AGPRs ->
+    // 13 and 26 (round 6).  The kernel's time did not follow (0.101 -> 0.099-0.103 ms: it is not bound by those instructions);
+    // double Q's variant, which spilled more, gained 4 us.
+    const DevState& S = *Sp;
     __shared__ TickLds tick_lds;
     __shared__ EnvSlot lds_env[LANES == 64 ? 64 : LANES + 1];  // (32-book waves: one more slot, for the idle upper half -- below)
     __shared__ LearnLds1 lds_learn;

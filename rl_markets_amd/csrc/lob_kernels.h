@@ -136,6 +136,8 @@ __global__ void repack_kernel(const uint32_t* __restrict__ src, int D, int T, si
 // RB books per block (= per wave when RB <= 64): the kernel needs the whole register file of a lane,
 // so at most two waves share a SIMD; with 32 books per wave those two hide each other's latency.
 template <int RB, int TM>
+// (the state BY VALUE here: read through its device-resident copy the kernel spills nothing to scratch -- 176 spilled scalar
+// registers -> 10, 180 bytes of scratch per lane -> 0 -- and takes the same 16.5-16.7 ms: round 6)
 __global__ void __launch_bounds__(RB) reset_kernel(const DevParams* __restrict__ Pp, DevState S) {
     const DevParams& P = *Pp;
     __shared__ TickLds tick_lds;
@@ -1997,7 +1999,7 @@ __global__ void __launch_bounds__(LOB_ACD_BLOCK) accumulate_dense_kernel(DevPara
     }
     __syncthreads();
     // the block's row: every id that may be in use, whether this block met it or not (apply_kernel reads all rows of a slot's id)
-    u64* row = reinterpret_cast<u64*>(S.cb_part) + (size_t)blockIdx.x * LOB_CBD_CAP;
+    u64* row = reinterpret_cast<u64*>(+S.cb_part) + (size_t)blockIdx.x * LOB_CBD_CAP;
     for (int i = tid; i < n_hi; i += LOB_ACD_BLOCK)
         row[i] = ((touched[i >> 5] >> (i & 31)) & 1u) ? (u64)__double_as_longlong(sums[i]) : LOB_ACD_MARK;
 }
@@ -2016,7 +2018,7 @@ __global__ void __launch_bounds__(256) reduce_dense_kernel(DevState S, int dense
     if (id >= n_hi) return;
     const int per = (dense_blocks + LOB_ACD_GROUPS - 1) / LOB_ACD_GROUPS;
     const int r0 = g * per, r1 = min(r0 + per, dense_blocks);
-    const u64* part = reinterpret_cast<const u64*>(S.cb_part) + id;
+    const u64* part = reinterpret_cast<const u64*>(+S.cb_part) + id;
     f64 acc = 0.0;
     bool any = false;
 #pragma unroll 8
@@ -2024,7 +2026,7 @@ __global__ void __launch_bounds__(256) reduce_dense_kernel(DevState S, int dense
         const u64 raw = part[(size_t)r * LOB_CBD_CAP];
         if (raw != LOB_ACD_MARK) { any = true; acc += __longlong_as_double((long long)raw); }
     }
-    reinterpret_cast<u64*>(S.cb_red)[(size_t)g * LOB_CBD_CAP + id] = any ? (u64)__double_as_longlong(acc) : LOB_ACD_MARK;
+    reinterpret_cast<u64*>(+S.cb_red)[(size_t)g * LOB_CBD_CAP + id] = any ? (u64)__double_as_longlong(acc) : LOB_ACD_MARK;
 }
 #endif
 
@@ -2081,7 +2083,7 @@ __global__ void __launch_bounds__(256) apply_kernel(DevParams P, DevState S, con
         bool dense_touch = false;
         if (dense_blocks > 0 && did >= 0) {
             u64 raw = LOB_ACD_MARK;
-            if (lane < LOB_ACD_GROUPS) raw = reinterpret_cast<const u64*>(S.cb_red)[(size_t)lane * LOB_CBD_CAP + did];
+            if (lane < LOB_ACD_GROUPS) raw = reinterpret_cast<const u64*>(+S.cb_red)[(size_t)lane * LOB_CBD_CAP + did];
             const bool have = raw != LOB_ACD_MARK;
             const f64 x = have ? __longlong_as_double((long long)raw) : 0.0;
             dense_touch = __any(have);
@@ -2161,6 +2163,13 @@ __global__ void __launch_bounds__(256) memo_kernel(DevParams P, DevState S, cons
         S.tr_list_n[reset_lpar] = 0;
         S.tr_list2_n[reset_lpar] = 0;
         S.acc_list_n[reset_lpar] = 0;
+    }
+    // the two words of the state a step changes, for the kernels that read the state through its device-resident copy (S.self,
+    // lob_engine.hip sync_state): this launch (which 0) is in front of every kernel of the step that claims combine slots
+    if (which == 0 && blockIdx.x == 0 && threadIdx.x == 0 && S.self) {
+        DevState* w = const_cast<DevState*>(S.self);
+        w->cb_par = S.cb_par;
+        w->cb_dense_on = S.cb_dense_on;
     }
     __shared__ f64 vals[4][LOB_N_ACTIONS * LOB_QSTRIDE];
     __shared__ uint32_t rnd[2048 + 32];

@@ -22,6 +22,28 @@ typedef int i32;
 typedef double f64;
 typedef float f32;
 
+// A pointer READ FROM the device-resident DevState (kernels that take the state by pointer) is a generic pointer to the compiler:
+// its loads and stores become flat_ instructions, which count as LDS traffic too and wait for it.  The round trip through the
+// global address space tells InferAddressSpaces what the pointer is (a kernel ARGUMENT is promoted by itself).
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class T> __device__ __forceinline__ T* lob_g(T* p) {
+    // (through an integer: a pointer-to-pointer round trip is folded away before the address spaces are inferred)
+    return (T*)(__attribute__((address_space(1))) T*)(unsigned long long)p;
+}
+#else
+template <class T> inline T* lob_g(T* p) { return p; }
+#endif
+
+// Pointer members of the device state.  On the device every use goes through lob_g (above): whether the structure arrived as a
+// kernel argument or is read from its device-resident copy, the memory instructions are global_, never flat_.  One pointer wide,
+// trivially copyable: the layout is that of the plain pointers it replaces.
+template <class T> struct GP {
+    T* p;
+    __host__ __device__ __forceinline__ operator T*() const { return lob_g(p); }
+    __host__ __device__ __forceinline__ T* operator->() const { return lob_g(p); }
+    __host__ __device__ __forceinline__ GP& operator=(T* q) { p = q; return *this; }
+};
+
 // name, window-size parameter
 #define LOB_ROLLING_MEANS(X) \
     X(f_midprice)            \
@@ -199,19 +221,19 @@ struct __attribute__((aligned(64))) LHdr {
 #define LOB_NZ_NEW_MAX 256    /* above this many new weights the filter is too dense to help: full look-ups */
 
 struct RMPtrs {  // RollingMean<double>
-    f64* ring;   // [w][B]
-    i32* cnt;
-    i32* head;
-    f64* sum;
-    f64* mean;
-    f64* s;
+    GP<f64> ring;   // [w][B]
+    GP<i32> cnt;
+    GP<i32> head;
+    GP<f64> sum;
+    GP<f64> mean;
+    GP<f64> s;
     i32 w;
 };
 struct AccPtrs {  // Accumulator<double>
-    f64* ring;
-    i32* cnt;
-    i32* head;
-    f64* sum;
+    GP<f64> ring;
+    GP<i32> cnt;
+    GP<i32> head;
+    GP<f64> sum;
     i32 w;
 };
 
@@ -219,10 +241,10 @@ struct DevState {
     i32 B;
     i32 D, T, W;       // depth, trade slots, record words
     i32 n_events;
-    const uint32_t* records;  // device layout: [B][n_events][Wd], or one replayed stream [n_total][Wd] when rec_phase is set
-    const i64* rec_phase;     // [B] first record of each book's n_events-long window (lob_load_events_shared), else null
+    GP<const uint32_t> records;  // device layout: [B][n_events][Wd], or one replayed stream [n_total][Wd] when rec_phase is set
+    GP<const i64> rec_phase;     // [B] first record of each book's n_events-long window (lob_load_events_shared), else null
 
-#define X(t, n) t* n;
+#define X(t, n) GP<t> n;
     LOB_ENV_FIELDS(X)
 #undef X
 #define X(n) RMPtrs n;
@@ -236,42 +258,42 @@ struct DevState {
     // `track_len` events has its whole track resident (index = k); a longer one (a recorded day of
     // tens of thousands of events) keeps a ring of the `track_len` (a power of two) latest entries per
     // book, refilled every few steps (prepass_extend_kernel): index = k & track_mask.
-    Track* track;      // [B][track_len]
+    GP<Track> track;      // [B][track_len]
     i32 track_len, track_mask;
-    BookMeta* meta;    // [B]
-    PrepState* prep;   // [B]
-    f64* ewma_up;      // [B] return_ups / return_downs EWMA means (persist across episodes)
-    f64* ewma_down;
-    f64* tp_val;       // [B] TargetPrice::val_ (persists)
-    f64* persist;      // [LOB_PERSIST_N][B] window sums at episode start (exact replay of quirk Q7)
-    i32* k_stop;       // [B] events consumed by the previous episode (for the replay)
+    GP<BookMeta> meta;    // [B]
+    GP<PrepState> prep;   // [B]
+    GP<f64> ewma_up;      // [B] return_ups / return_downs EWMA means (persist across episodes)
+    GP<f64> ewma_down;
+    GP<f64> tp_val;       // [B] TargetPrice::val_ (persists)
+    GP<f64> persist;      // [LOB_PERSIST_N][B] window sums at episode start (exact replay of quirk Q7)
+    GP<i32> k_stop;       // [B] events consumed by the previous episode (for the replay)
 
-    LHdr* hdr;      // [B]
-    f32* vars;      // [B][3][16]  the two rl::State objects' state_vars + the latest getState()
-    f64* qs_last;   // [B][9] Q(last_state, .) of the current step
-    i32* tr_idx;    // [B][P.trace_gens][32]
-    uint32_t* tr_alive;  // [B][P.trace_gens]
+    GP<LHdr> hdr;      // [B]
+    GP<f32> vars;      // [B][3][16]  the two rl::State objects' state_vars + the latest getState()
+    GP<f64> qs_last;   // [B][9] Q(last_state, .) of the current step
+    GP<i32> tr_idx;    // [B][P.trace_gens][32]
+    GP<uint32_t> tr_alive;  // [B][P.trace_gens]
 
-    f64* theta;       // [M] or [B][M]
-    f64* theta_b;        // DoubleAgent::theta_b (LOB_ALGO_DOUBLE_Q), same shape as theta, or null
-    uint32_t* theta_b_nz;
-    f64* qs_last_b;      // [B][9] Qb(last_state, .)
-    u64* mt_state;       // [B][312] std::mt19937_64 state of each book's Agent::gen (DoubleQLearn coin)
-    i32* mt_idx;         // [B]
+    GP<f64> theta;       // [M] or [B][M]
+    GP<f64> theta_b;        // DoubleAgent::theta_b (LOB_ALGO_DOUBLE_Q), same shape as theta, or null
+    GP<uint32_t> theta_b_nz;
+    GP<f64> qs_last_b;      // [B][9] Qb(last_state, .)
+    GP<u64> mt_state;       // [B][312] std::mt19937_64 state of each book's Agent::gen (DoubleQLearn coin)
+    GP<i32> mt_idx;         // [B]
     // Combined update (shared theta; DESIGN.md "generation combining"): many books hold the SAME trace
     // generation -- the live tiles one (group-0 state, action) left behind -- so their updates are
     // summed per distinct (generation identity, alive mask) first and applied to theta once.
-    i32* tr_sig;         // [B][trace_gens][4]: q0, q1, q2 (= (int)floor(32 x) of the three group-0 variables), action | zero << 8
-    i32* tr_cbslot;      // [B][trace_gens] slot of cb_key the generation's claim of THIS step ended on (-1: none), cb_claim_finish
-    i32* tr_mslot;       // [B][trace_gens] SARSA lane path (lob_fast.h trace_sarsa_kernel): memo slot of the generation's triple |
+    GP<i32> tr_sig;         // [B][trace_gens][4]: q0, q1, q2 (= (int)floor(32 x) of the three group-0 variables), action | zero << 8
+    GP<i32> tr_cbslot;      // [B][trace_gens] slot of cb_key the generation's claim of THIS step ended on (-1: none), cb_claim_finish
+    GP<i32> tr_mslot;       // [B][trace_gens] SARSA lane path (lob_fast.h trace_sarsa_kernel): memo slot of the generation's triple |
                          //   (episode epoch & 0x7fff) << 16, or -1: not known / slot's tiles not registered (DevParams::sarsa_lanes)
-    u64* cb_key;         // [cb_slots] 64-bit hash of (signature, mask), ~0 = empty
-    i32* cb_ident;       // [cb_slots][8]: q0, q1, q2, code, mask (0: free slot), the generation that claimed it (book * trace_gens + slot), -, -
-    f64* cb_acc;         // [cb_slots][2]: summed update for theta / theta_b
-    uint32_t* cb_touch;  // [cb_slots] bit 0: theta gets an update this step, bit 1: theta_b
-    i32* cb_list;        // [2 parities][cb_segs][cb_slots / cb_segs] the occupied slots, slot s in segment s & (cb_segs - 1): survivors of
+    GP<u64> cb_key;         // [cb_slots] 64-bit hash of (signature, mask), ~0 = empty
+    GP<i32> cb_ident;       // [cb_slots][8]: q0, q1, q2, code, mask (0: free slot), the generation that claimed it (book * trace_gens + slot), -, -
+    GP<f64> cb_acc;         // [cb_slots][2]: summed update for theta / theta_b
+    GP<uint32_t> cb_touch;  // [cb_slots] bit 0: theta gets an update this step, bit 1: theta_b
+    GP<i32> cb_list;        // [2 parities][cb_segs][cb_slots / cb_segs] the occupied slots, slot s in segment s & (cb_segs - 1): survivors of
                          //   the previous step (apply_kernel, one block per segment: no global counter), then this step's claims
-    i32* cb_count;       // [2][cb_segs]
+    GP<i32> cb_count;       // [2][cb_segs]
     i32 cb_slots;        // power of two
     i32 cb_reps;         // copies of cb_acc ([cb_reps][cb_slots][2]): 1, or 8 = one per XCD (accumulate_kernel)
     i32 cb_segs;         // power of two <= cb_slots / 4: apply_kernel's grid
@@ -282,90 +304,90 @@ struct DevState {
     // the kernel then sums its books' terms in a direct-indexed LDS array of LOB_CBD_CAP doubles -- no hash table, no
     // compare-and-swap -- and writes the array out as its row of `cb_part`; apply_kernel adds the rows up.  A slot without an id
     // (lists empty, claimed before the mode was on) takes the atomics on cb_acc as before.
-    i32* cb_dense;       // [cb_slots] id of the slot, -1: none
-    i32* cb_free;        // [8][LOB_CBD_CAP / 8] stacks of free ids: list x holds the ids = x mod 8, lowest on top at the start
-    i32* cb_free_n;      // [8][2]: entries on the stack, and the fewest it has ever held (ids >= 8 * (cap / 8 - that) were never out)
-    u64* tr_cbd;         // [B][trace_gens] slot << 32 | id (0xffffffff: the slot has none) as the kernel found them when it last
+    GP<i32> cb_dense;       // [cb_slots] id of the slot, -1: none
+    GP<i32> cb_free;        // [8][LOB_CBD_CAP / 8] stacks of free ids: list x holds the ids = x mod 8, lowest on top at the start
+    GP<i32> cb_free_n;      // [8][2]: entries on the stack, and the fewest it has ever held (ids >= 8 * (cap / 8 - that) were never out)
+    GP<u64> tr_cbd;         // [B][trace_gens] slot << 32 | id (0xffffffff: the slot has none) as the kernel found them when it last
                          //   compared the generation's identity with the slot's; valid while tr_cbslot still names that slot, verified
-    f64* cb_part;        // [LOB_ACD_MAX_BLOCKS][LOB_CBD_CAP] the blocks' sums by id (LOB_ACD_MARK: no term this step)
-    f64* cb_red;         // [LOB_ACD_GROUPS = 8][LOB_CBD_CAP] ... added up per group of blocks (reduce_dense_kernel), for apply_kernel
+    GP<f64> cb_part;        // [LOB_ACD_MAX_BLOCKS][LOB_CBD_CAP] the blocks' sums by id (LOB_ACD_MARK: no term this step)
+    GP<f64> cb_red;         // [LOB_ACD_GROUPS = 8][LOB_CBD_CAP] ... added up per group of blocks (reduce_dense_kernel), for apply_kernel
     i32 cb_ids;          // ids in all (LOB_CBD_CAP; fewer with LOB_CBD_IDS, for the tests)
     i32 cb_dense_on;     // claims take ids (set by the host with the algorithm / epsilon: lob_engine.hip acc_blocked)
     // Verdict carry-over: learn(t) saves, per book, which group-1/2 tiles of s' hit a written
     // weight (9 bits per tiling); act(t+1) evaluates the same state and reuses them instead of 576
     // bitmap look-ups, OR-ed with a small filter of the bits the update in between newly set.
-    uint16_t* verdict;   // [B][LOB_VD_STRIDE] u16: [2 groups][32 tilings], then epoch (2 x u16), slot, valid
-    uint16_t* verdict_b; // [B][64]: the same for theta_b (double Q; shares the tag of `verdict`)
-    i32* nz_new;         // [2 targets: theta, theta_b][2 parities][LOB_NZ_WORDS]: count + filter of the map bits an update set for the first time
-    i32* nz_epoch;       // [1] bumped whenever theta / the bitmap change outside update_kernel
-    uint32_t* theta_nz;  // bitmap, bit i set once theta[i] has ever been written: clear bit => theta[i] == +0.0
+    GP<uint16_t> verdict;   // [B][LOB_VD_STRIDE] u16: [2 groups][32 tilings], then epoch (2 x u16), slot, valid
+    GP<uint16_t> verdict_b; // [B][64]: the same for theta_b (double Q; shares the tag of `verdict`)
+    GP<i32> nz_new;         // [2 targets: theta, theta_b][2 parities][LOB_NZ_WORDS]: count + filter of the map bits an update set for the first time
+    GP<i32> nz_epoch;       // [1] bumped whenever theta / the bitmap change outside update_kernel
+    GP<uint32_t> theta_nz;  // bitmap, bit i set once theta[i] has ever been written: clear bit => theta[i] == +0.0
     // Group-0 memo (shared theta; DESIGN.md "group-0 memo"): the first 32 of Q's 128 ordered terms --
     // the group-0 partial sum S0(a) = sum_j w0 * theta[tile(q0, q1, q2, a, j)] -- depend on the state
     // only through the three quantised group-0 variables (inventory, quote distances: a few hundred
     // distinct triples among 65 536 books), and the ordered sum STARTS with them.  So S0 is
     // evaluated once per distinct triple and theta version (memo_kernel) and every book continues
     // the sum from its triple's S0 with whatever group-1/2 weights are non-zero.
-    u64* mk_hash;        // [mk_slots] 64-bit hash of the triple, ~0 = empty (claimed by env_kernel)
-    i32* mk_ident;       // [mk_slots][4]: q0, q1, q2 (written by the claim winner, compared in full by the readers), and whether two of
+    GP<u64> mk_hash;        // [mk_slots] 64-bit hash of the triple, ~0 = empty (claimed by env_kernel)
+    GP<i32> mk_ident;       // [mk_slots][4]: q0, q1, q2 (written by the claim winner, compared in full by the readers), and whether two of
                          //   the triple's 288 group-0 tiles coincide: 0 not known yet, 1 no, 2 yes (learnt by the trace kernel)
-    i32* mk_stamp;       // [mk_slots] step id of the last claim: first toucher of a step appends the slot to the list
-    i32* mk_list;        // [2 parities][mk_slots] slots in use this step
-    i32* mk_count;       // [2]
-    f64* mk_rec;         // [2: theta_t for learn, theta_{t+1} for the next act][mk_slots][LOB_MK_REC]: S0[9], theta version tag
-    f64* mk_rec_b;       // the same under theta_b (double Q on the fast path: both vectors share the triples, the tiles and the maps), or null
-    i32* mk_tiles;       // [mk_slots][9][32] the triple's 288 group-0 tile indices (action, tiling), written by memo_kernel the first time
+    GP<i32> mk_stamp;       // [mk_slots] step id of the last claim: first toucher of a step appends the slot to the list
+    GP<i32> mk_list;        // [2 parities][mk_slots] slots in use this step
+    GP<i32> mk_count;       // [2]
+    GP<f64> mk_rec;         // [2: theta_t for learn, theta_{t+1} for the next act][mk_slots][LOB_MK_REC]: S0[9], theta version tag
+    GP<f64> mk_rec_b;       // the same under theta_b (double Q on the fast path: both vectors share the triples, the tiles and the maps), or null
+    GP<i32> mk_tiles;       // [mk_slots][9][32] the triple's 288 group-0 tile indices (action, tiling), written by memo_kernel the first time
                          //   the slot is on a step's list: the lane-per-book trace kernel copies a generation from here
-    i32* mk_tiles_ok;    // [mk_slots] bit 0: mk_tiles[slot] is filled; bit 1: ... and every tile is in the registry (ow_tab)
-    uint32_t* mk_marked; // [mk_slots] bit a: the 32 tiles of (triple, action a) are marked in the written-weights maps
-    i32* mk_marklist;    // [mk_slots] (slot * 16 + action) pairs whose tiles act_light_kernel wants marked: memo_kernel (which 0) does it,
-    i32* mk_markcount;   // [1]          a wave per pair, before the learn kernel looks; reset by memo_kernel (which 1)
+    GP<i32> mk_tiles_ok;    // [mk_slots] bit 0: mk_tiles[slot] is filled; bit 1: ... and every tile is in the registry (ow_tab)
+    GP<uint32_t> mk_marked; // [mk_slots] bit a: the 32 tiles of (triple, action a) are marked in the written-weights maps
+    GP<i32> mk_marklist;    // [mk_slots] (slot * 16 + action) pairs whose tiles act_light_kernel wants marked: memo_kernel (which 0) does it,
+    GP<i32> mk_markcount;   // [1]          a wave per pair, before the learn kernel looks; reset by memo_kernel (which 1)
     // Tile registry of the SARSA lane path: which weight indices are shared by two DIFFERENT group-0 tiles of the episode's
     // memo slots (a collision of the hash -- or of its 2048-entry table: coordinates 2048 apart, permuted terms).  Two tiles
     // are the same tile when tiling, action and the three coordinates & 2047 agree; every other pair on one index is
     // "ambiguous".  A generation loses a tile to a new state either because the two triples fall in the same tile of that tiling
     // (pure arithmetic on the quantised coordinates) or through an ambiguous index -- and only the latter needs the indices.
-    u64* ow_tab;         // [ow_slots] index << 32 | first registrant (slot * 288 + action * 32 + tiling), ~0 = empty
+    GP<u64> ow_tab;         // [ow_slots] index << 32 | first registrant (slot * 288 + action * 32 + tiling), ~0 = empty
     i32 ow_slots;        // power of two
-    uint32_t* amb_bits;  // [M / 32 + 1] bit f: index f is ambiguous
-    i32* amb_new;        // [2 parities][amb_cap] indices that became ambiguous in this step's memo_kernel (which 0) ...
-    i32* amb_new_n;      // [2]   ... its launch which 1 marks them in mk_amb of every registered slot
+    GP<uint32_t> amb_bits;  // [M / 32 + 1] bit f: index f is ambiguous
+    GP<i32> amb_new;        // [2 parities][amb_cap] indices that became ambiguous in this step's memo_kernel (which 0) ...
+    GP<i32> amb_new_n;      // [2]   ... its launch which 1 marks them in mk_amb of every registered slot
     i32 amb_cap;
-    i32* amb_flag;       // [1] sticky until the next reset: amb_new overflowed (the lane path is off)
-    uint32_t* mk_amb;    // [mk_slots][9] bit j: tile (slot, action, tiling j) lies on an ambiguous index
-    i32* mk_all;         // [mk_slots] registered slots, in registration order
-    i32* mk_all_n;       // [1]
-    i32* mk_slot;        // [B] slot of the book's latest state (-1: none)
-    i32* mk_slot_last;   // [B] slot of the state before that (the learner's last_state in the next step)
+    GP<i32> amb_flag;       // [1] sticky until the next reset: amb_new overflowed (the lane path is off)
+    GP<uint32_t> mk_amb;    // [mk_slots][9] bit j: tile (slot, action, tiling j) lies on an ambiguous index
+    GP<i32> mk_all;         // [mk_slots] registered slots, in registration order
+    GP<i32> mk_all_n;       // [1]
+    GP<i32> mk_slot;        // [B] slot of the book's latest state (-1: none)
+    GP<i32> mk_slot_last;   // [B] slot of the state before that (the learner's last_state in the next step)
     i32 mk_slots;        // power of two
     // Fast learner path (lob_fast.h): exact "ever written" map of the shared theta (one bit per weight) and
     // its coarse image (one bit per 2^cshift weights) that every CU keeps in LDS; work lists of the books
     // the fast kernels hand back to the general ones.
-    uint32_t* theta_nzx; // [M / 32 + 1]
-    uint32_t* theta_nzc; // [cwords4 * 4]
+    GP<uint32_t> theta_nzx; // [M / 32 + 1]
+    GP<uint32_t> theta_nzc; // [cwords4 * 4]
     // The exact map folded over the actions (learn_q_pair_kernel): the nine tiles of one tiling of group 1 / 2 are
     // (s + term[g][a]) mod M for ONE hash sum s, so bit s of group g's map = OR over a of theta_nzx[(s + term[g][a]) mod M]
     // answers "does any of this tiling's nine tiles lie on a written weight" with one look-up instead of nine (93 % of the
     // tilings: none, at 160 k written weights of 20 M).  Set with the exact bit, wherever that is set (nzd_mark).
-    uint32_t* theta_nzd;      // [2: tile group 1, 2][M / 32 + 1]
-    const uint32_t* nzd_terms; // [18]: term[1][0..8], term[2][0..8] (the engine's hash table + 2048 + 9)
-    i32* tr_list;        // [B] books the lane-per-book trace kernel leaves to the wave-per-book one
-    i32* tr_list_n;      // [2 parities]
-    i32* tr_list2;       // [B] Q(lambda): the entries of `tr_list` the lane-per-generation kernel (trace_lane_kernel) hands on to the wave-per-book one
-    i32* tr_list2_n;     // [2 parities]
+    GP<uint32_t> theta_nzd;      // [2: tile group 1, 2][M / 32 + 1]
+    GP<const uint32_t> nzd_terms; // [18]: term[1][0..8], term[2][0..8] (the engine's hash table + 2048 + 9)
+    GP<i32> tr_list;        // [B] books the lane-per-book trace kernel leaves to the wave-per-book one
+    GP<i32> tr_list_n;      // [2 parities]
+    GP<i32> tr_list2;       // [B] Q(lambda): the entries of `tr_list` the lane-per-generation kernel (trace_lane_kernel) hands on to the wave-per-book one
+    GP<i32> tr_list2_n;     // [2 parities]
     // The accumulation of a generation's update where its slot is resolved (learn_q_pair_kernel for the books whose step leaves one
     // new generation, trace_lane_kernel for the others): what they cannot finish goes on this list for accumulate_kernel --
     // entry = book (every generation of the book: its TD error was not known yet, or its trace step was handed on), or
     // book | 1 << 31 (only the book's generations without a slot: the direct, tile-by-tile path must wait until nobody reads theta).
-    i32* acc_list;       // [B]
-    i32* acc_list_n;     // [2 parities]
-    uint8_t* acc_pend;   // [B] bit 0: the learn kernel handed the book back (its TD error comes later): trace_lane_kernel must not add its update yet;
+    GP<i32> acc_list;       // [B]
+    GP<i32> acc_list_n;     // [2 parities]
+    GP<uint8_t> acc_pend;   // [B] bit 0: the learn kernel handed the book back (its TD error comes later): trace_lane_kernel must not add its update yet;
                          //     bit 1 (trace_rest_kernel's flow): trace_lane_kernel handed the book's trace step on
     // trace_rest_kernel's generations without a slot (book x trace_gens + ring slot), applied tile by tile by apply_kernel: other
     // waves of trace_rest_kernel read theta (learn_q_book) while it adds generations up
-    i32* dir_list;       // [B x trace_gens] (a generation is listed at most once per step)
-    i32* dir_list_n;     // [2 parities of the combine table's lists: apply_kernel empties the one it consumed a step ago]
-    i32* slow_list;      // [2 kinds: act, learn][B]
-    i32* slow_n;         // [2 parities][2 kinds]
+    GP<i32> dir_list;       // [B x trace_gens] (a generation is listed at most once per step)
+    GP<i32> dir_list_n;     // [2 parities of the combine table's lists: apply_kernel empties the one it consumed a step ago]
+    GP<i32> slow_list;      // [2 kinds: act, learn][B]
+    GP<i32> slow_n;         // [2 parities][2 kinds]
     // Hit-list carry-over learn_q(t) -> act(t+1) (lob_fast.h act_light_kernel): the Q evaluation of the TD target and the
     // next step's action selection are over the SAME State, and between them only the weights change, not WHICH
     // group-1/2 tiles fall on a written weight -- the trace kernel marks a new generation's tiles in the maps when it
@@ -383,31 +405,32 @@ struct DevState {
     //      Watkins's flow, where the lane trace kernel does run after the learn kernel, marks through nzx_mark_late, which
     //      records the step in hl_dirty and so voids every list; SARSA(lambda)'s order makes the marks early instead.
     //   3. nothing else: tr_head / tr_n / tr_idx / tr_alive / tr_sig / tr_mslot / tr_cbslot are read by the update kernels only.
-    u64* hl_rec;         // [B][LOB_HL_REC]: [0] = number of entries, or ~0: no list (not evaluated by the fast learn kernel, or more
+    GP<u64> hl_rec;         // [B][LOB_HL_REC]: [0] = number of entries, or ~0: no list (not evaluated by the fast learn kernel, or more
                          //   than it can record: LOB_HL_MAX, LOB_HL_CAP from the kernels with one lane or one wave per book); [1 + i] = entry i
-    i32* hl_dirty;       // [1] step id of the last update that set a map bit AFTER learn_q had looked (voids every list)
+    GP<i32> hl_dirty;       // [1] step id of the last update that set a map bit AFTER learn_q had looked (voids every list)
     // R-learning agents (RLearn / OnlineRLearn, src/rl/agent.cpp:357-412): the average reward rho of each agent -- one per weight
     // vector: [1] shared, [B] private --, the sum of a step's increments (folded in by rho_fold_kernel: every book reads rho_t),
     // and per book the bootstrap value the TD error used (maxQ(to_state) / Q(to_state, a')), which the rho update needs again
-    f64* rho;
-    f64* rho_inc;
-    i32* rho_cnt;     // books that contributed to rho_inc this step
-    f64* rl_t;        // [B]
+    GP<f64> rho;
+    GP<f64> rho_inc;
+    GP<i32> rho_cnt;     // books that contributed to rho_inc this step
+    GP<f64> rl_t;        // [B]
     // model_log (Agent::HandleTransition, src/rl/agent.cpp:93-100: _agg_delta += |delta|; every 1000 updates one row _agg_delta /
     // 1000): per learner step the stepped books' |delta| are summed (td_stats_kernel: a partial per block, td_stats_fold_kernel:
     // the partials in order), added to the running aggregate, and once at least 1000 updates are in it a row aggregate / count is
     // written and both start again -- one book: exactly the reference's rows; a batch of 1000 books or more: a row per step, the
     // mean |delta| over the batch.  Off until lob_model_log_enable.
-    f64* ml_part;     // [LOB_ML_BLOCKS] a step's partial sums
-    i32* ml_npart;    // [LOB_ML_BLOCKS] ... and counts
-    f64* ml_agg;      // [1] the running aggregate
-    i64* ml_cnt;      // [2] updates in it; rows written since the last lob_model_log_read
-    f64* ml_rows;     // [LOB_ML_ROWS]
-    f64* theta_sync;  // [M] (multi-GPU) or null
-    f64* delta;       // [M] scratch for the all-reduce or null
-    i64* counters;    // [8] device counters
-    i64* prof;        // [B][LOB_PROF_N] clock64 per phase of the learner kernels (-DLOB_PROF builds only, tools/exp_prof.py), else null
-    i32* error_flag;  // [1] bits: reference-would-throw conditions
+    GP<f64> ml_part;     // [LOB_ML_BLOCKS] a step's partial sums
+    GP<i32> ml_npart;    // [LOB_ML_BLOCKS] ... and counts
+    GP<f64> ml_agg;      // [1] the running aggregate
+    GP<i64> ml_cnt;      // [2] updates in it; rows written since the last lob_model_log_read
+    GP<f64> ml_rows;     // [LOB_ML_ROWS]
+    GP<f64> theta_sync;  // [M] (multi-GPU) or null
+    GP<f64> delta;       // [M] scratch for the all-reduce or null
+    GP<i64> counters;    // [8] device counters
+    GP<i64> prof;        // [B][LOB_PROF_N] clock64 per phase of the learner kernels (-DLOB_PROF builds only, tools/exp_prof.py), else null
+    GP<i32> error_flag;  // [1] bits: reference-would-throw conditions
+    const DevState* self;  // the device-resident copy of this very structure (kernels that take the state by pointer; lob_engine.hip push_state)
 };
 
 // Parameters copied to the device once (kernel argument, uniform).

@@ -50,17 +50,19 @@ void lobk_env_mode(hipStream_t st, bool t2, int mode, const DevParams* Pd, const
 void lobk_env_step(hipStream_t st, bool inline_general, bool dq, bool half_waves, const DevParams* Pd, const DevState& S, int nb, int sid, int par, const EnvFuse& F,
                    const uint32_t* rnd) {
     const dim3 grid((nb + 63) / 64), block(64);
+#define LOB_S_ARG S.self   // (the state's device-resident copy: lob_engine.hip sync_state)
 #ifdef LOB_EXPERIMENTS
     if (half_waves && !dq && !inline_general) {  // LOB_ENV_STEP_LANES=32: two half-full waves per SIMD (measured slower, NOTES.md)
-        hipLaunchKernelGGL((env_step_kernel<false, false, 32>), dim3((nb + 31) / 32), block, 0, st, Pd, S, sid, par, F, rnd);
+        hipLaunchKernelGGL((env_step_kernel<false, false, 32>), dim3((nb + 31) / 32), block, 0, st, Pd, LOB_S_ARG, sid, par, F, rnd);
         return;
     }
 #endif
     (void)half_waves;
-    if (inline_general && dq) hipLaunchKernelGGL((env_step_kernel<true, true>), grid, block, 0, st, Pd, S, sid, par, F, rnd);
-    else if (dq) hipLaunchKernelGGL((env_step_kernel<false, true>), grid, block, 0, st, Pd, S, sid, par, F, rnd);
-    else if (inline_general) hipLaunchKernelGGL(env_step_kernel<true>, grid, block, 0, st, Pd, S, sid, par, F, rnd);
-    else hipLaunchKernelGGL(env_step_kernel<false>, grid, block, 0, st, Pd, S, sid, par, F, rnd);
+    if (inline_general && dq) hipLaunchKernelGGL((env_step_kernel<true, true>), grid, block, 0, st, Pd, LOB_S_ARG, sid, par, F, rnd);
+    else if (dq) hipLaunchKernelGGL((env_step_kernel<false, true>), grid, block, 0, st, Pd, LOB_S_ARG, sid, par, F, rnd);
+    else if (inline_general) hipLaunchKernelGGL(env_step_kernel<true>, grid, block, 0, st, Pd, LOB_S_ARG, sid, par, F, rnd);
+    else hipLaunchKernelGGL(env_step_kernel<false>, grid, block, 0, st, Pd, LOB_S_ARG, sid, par, F, rnd);
+#undef LOB_S_ARG
 }
 
 void lobk_clear_inventory(hipStream_t st, const DevParams* Pd, const DevState& S) {
