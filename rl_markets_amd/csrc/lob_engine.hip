@@ -33,6 +33,9 @@
         }                                                                                    \
     } while (0)
 
+// parameters and state of the kernels that take them by pointer (lob_state.h LOB_PS_ARGS): their device-resident copies
+#define LOB_PS(e) (const DevParams*)(e)->P_dev, (e)->S.self
+
 #define LOB_HINT_RING 64
 #define LOB_HINT_LAG 16
 #define LOB_HINT_EVERY 8   /* the count goes to host memory in every 8th learner step only: the store costs the kernel that makes it 3.5 us */
@@ -206,7 +209,7 @@ static int registry_join(lob_engine* e) {
 static int registry_fork(lob_engine* e, hipStream_t st, const uint32_t* rnd, int par) {
     HIPCHK(hipEventRecord(e->ev_reg_go, st));
     HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_reg_go, 0));
-    hipLaunchKernelGGL(registry_kernel, dim3(64), dim3(256), 0, e->stream2, e->P, e->S, rnd, par);
+    hipLaunchKernelGGL(registry_kernel, dim3(64), dim3(256), 0, e->stream2, LOB_PS(e), rnd, par);
     hipLaunchKernelGGL(registry_scan_kernel, dim3(256), dim3(256), 0, e->stream2, e->S, par);
     HIPCHK(hipEventRecord(e->ev_reg_done, e->stream2));
     e->reg_pending = true;
@@ -1092,8 +1095,8 @@ static void launch_env_fused(lob_engine* e, hipStream_t st, int par, int lpar, u
     if (inline_general) return;
     {
         TimedLaunch t(e, "act_rest_kernel", st);
-        if (dq) hipLaunchKernelGGL((act_kernel<LOB_ALGO_DOUBLE_Q, true>), dim3(gl), dim3(LOB_BLOCK), 0, st, e->P, e->S, (const uint32_t*)e->rnd_dev, 0, 0, e->B, par, act_list, act_n);
-        else hipLaunchKernelGGL((act_kernel<LOB_ALGO_SARSA, true>), dim3(gl), dim3(LOB_BLOCK), 0, st, e->P, e->S, (const uint32_t*)e->rnd_dev, 0, 0, e->B, par, act_list, act_n);
+        if (dq) hipLaunchKernelGGL((act_kernel<LOB_ALGO_DOUBLE_Q, true>), dim3(gl), dim3(LOB_BLOCK), 0, st, LOB_PS(e), (const uint32_t*)e->rnd_dev, 0, 0, e->B, par, act_list, act_n);
+        else hipLaunchKernelGGL((act_kernel<LOB_ALGO_SARSA, true>), dim3(gl), dim3(LOB_BLOCK), 0, st, LOB_PS(e), (const uint32_t*)e->rnd_dev, 0, 0, e->B, par, act_list, act_n);
     }
     {
         TimedLaunch t(e, "env_rest_kernel", st);
@@ -1357,18 +1360,18 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                 {
                     TimedLaunch t(e, "act_kernel", st);
                     if (mode == 0 && e->hits_ok && e->light)
-                        hipLaunchKernelGGL(act_light_kernel, dim3((nb + LOB_LIGHT_BLOCK - 1) / LOB_LIGHT_BLOCK), dim3(LOB_LIGHT_BLOCK), 0, st, e->P, e->S, par, lpar, ver, e->step_id - 1);
+                        hipLaunchKernelGGL(act_light_kernel, dim3((nb + LOB_LIGHT_BLOCK - 1) / LOB_LIGHT_BLOCK), dim3(LOB_LIGHT_BLOCK), 0, st, LOB_PS(e), par, lpar, ver, e->step_id - 1);
                     else
-                        hipLaunchKernelGGL(act_fast_kernel<LOB_FAST_NB>, dim3(gf), dim3(LOB_FAST_BLOCK), fast_lds_bytes(e->P.cwords4, LOB_FAST_NB, false), st, e->P, e->S, rnd, mode, par, lpar, ver);
+                        hipLaunchKernelGGL(act_fast_kernel<LOB_FAST_NB>, dim3(gf), dim3(LOB_FAST_BLOCK), fast_lds_bytes(e->P.cwords4, LOB_FAST_NB, false), st, LOB_PS(e), rnd, mode, par, lpar, ver);
                 }
                 {
                     TimedLaunch t(e, "act_rest_kernel", st);
-                    hipLaunchKernelGGL((act_kernel<LOB_ALGO_SARSA, true>), dim3(gl), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, mode, 0, e->B, par, act_list, act_n);
+                    hipLaunchKernelGGL((act_kernel<LOB_ALGO_SARSA, true>), dim3(gl), dim3(LOB_BLOCK), 0, st, LOB_PS(e), rnd, mode, 0, e->B, par, act_list, act_n);
                 }
             } else {
                 TimedLaunch t(e, "act_kernel", st);
-                if (e->P.algo == LOB_ALGO_DOUBLE_Q) hipLaunchKernelGGL((act_kernel<LOB_ALGO_DOUBLE_Q, false>), dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, mode, b0, nb, par, (const i32*)nullptr, (const i32*)nullptr);
-                else hipLaunchKernelGGL((act_kernel<LOB_ALGO_SARSA, false>), dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, mode, b0, nb, par, (const i32*)nullptr, (const i32*)nullptr);
+                if (e->P.algo == LOB_ALGO_DOUBLE_Q) hipLaunchKernelGGL((act_kernel<LOB_ALGO_DOUBLE_Q, false>), dim3(gw), dim3(LOB_BLOCK), 0, st, LOB_PS(e), rnd, mode, b0, nb, par, (const i32*)nullptr, (const i32*)nullptr);
+                else hipLaunchKernelGGL((act_kernel<LOB_ALGO_SARSA, false>), dim3(gw), dim3(LOB_BLOCK), 0, st, LOB_PS(e), rnd, mode, b0, nb, par, (const i32*)nullptr, (const i32*)nullptr);
             }
             if (G > 1 && g == 0) HIPCHK(hipEventRecord(e->ev_stagger, st));
             if (!fused_act) {
@@ -1378,6 +1381,8 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
             }  // first half
             if (!second) continue;
             if (fast) launch_memo(e, par, mode == 0 ? 0 : 1);  // learner: S0 under theta_t for learn_kernel; backtester: for the next act
+            // (... and, which 0, the step's cb_par / cb_dense_on into the state's device-resident copy; without a memo launch:)
+            else if (mode == 0 && e->P.combine) hipLaunchKernelGGL(step_words_kernel, dim3(1), dim3(1), 0, st, e->S_dev, e->S.cb_par, e->S.cb_dense_on);
             // (the previous learner step's registry kernels have had the update kernels of their own step, and this step's env and
             // memo kernels, to finish beside: what they write is read from here on -- the dup flags by the light trace step, the
             // rest by trace_lane_kernel)
@@ -1394,21 +1399,21 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                 if (tl && !fuse) {
                     // a lane per book where the step leaves no older generation behind, the wave-per-book kernel for the rest
                     TimedLaunch t(e, "trace_light_kernel", st);
-                    hipLaunchKernelGGL(trace_light_kernel, dim3((nb + LOB_LIGHT_BLOCK - 1) / LOB_LIGHT_BLOCK), dim3(LOB_LIGHT_BLOCK), 0, st, e->P, e->S, lpar);
+                    hipLaunchKernelGGL(trace_light_kernel, dim3((nb + LOB_LIGHT_BLOCK - 1) / LOB_LIGHT_BLOCK), dim3(LOB_LIGHT_BLOCK), 0, st, LOB_PS(e), lpar);
                 }
                 if (!fuse) {
                     TimedLaunch t(e, "trace_kernel", st);
-                    if (tl) hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_QLAMBDA, 1>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, e->P, e->S, rnd, par, lpar, sid);
-                    else if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_QLAMBDA, 0>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, e->P, e->S, rnd, par, lpar, sid);
+                    if (tl) hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_QLAMBDA, 1>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, LOB_PS(e), rnd, par, lpar, sid);
+                    else if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_QLAMBDA, 0>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, LOB_PS(e), rnd, par, lpar, sid);
                     else if (e->P.sarsa_lanes) {
                         // a lane per generation; the wave-per-book kernel for the books it leaves on the list
                         // (LOB_TS_GRID / LOB_TS_LDS, experiments: fewer, persistent blocks / dynamic LDS to throttle the occupancy -- halving
                         // it costs 28 %, a persistent grid changes nothing: NOTES.md "Round 5")
                         const int ts_full = (nb + LOB_TS_BLOCK / 32 - 1) / (LOB_TS_BLOCK / 32);
-                        hipLaunchKernelGGL(trace_lane_kernel<LOB_ALGO_SARSA>, dim3(e->ts_grid > 0 ? std::min(e->ts_grid, ts_full) : ts_full), dim3(LOB_TS_BLOCK), e->ts_lds, st, e->P, e->S, lpar, sid, 0);
-                        hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_SARSA, 1>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, e->P, e->S, rnd, par, lpar, sid);
+                        hipLaunchKernelGGL(trace_lane_kernel<LOB_ALGO_SARSA>, dim3(e->ts_grid > 0 ? std::min(e->ts_grid, ts_full) : ts_full), dim3(LOB_TS_BLOCK), e->ts_lds, st, LOB_PS(e), lpar, sid, 0);
+                        hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_SARSA, 1>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, LOB_PS(e), rnd, par, lpar, sid);
                     }
-                    else hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_SARSA, 0>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, e->P, e->S, rnd, par, lpar, sid);
+                    else hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_SARSA, 0>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, LOB_PS(e), rnd, par, lpar, sid);
                 }
                 {
                     TimedLaunch t(e, "learn_kernel", st);
@@ -1423,8 +1428,8 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                         rest_merged = acc_fused && e->rest_merge;
                         const int gq = pair ? std::min(LOB_QP_OCC * e->n_cus, (nb + LOB_QP_BOOKS - 1) / LOB_QP_BOOKS) : std::min(e->n_cus, (nb + LOB_QL_BLOCK - 1) / LOB_QL_BLOCK);
                         const size_t lds = pair ? qpair_lds_bytes(e->P.cwords4) : qlane_lds_bytes(e->P.cwords4);
-                        lobk_learn_q(st, pair, e->P.algo, e->P.V == 8, fuse, gq, lds, e->P, (const DevParams*)e->P_dev, e->S, rnd, lpar, ver, sid, acc_fused ? (rest_merged ? 2 : 1) : 0);
-                    } else lobk_learn_q_fast(st, e->P.algo, gf, fast_lds_bytes(e->P.cwords4, LOB_FAST_NB, false), e->P, e->S, rnd, lpar, ver);
+                        lobk_learn_q(st, pair, e->P.algo, e->P.V == 8, fuse, gq, lds, (const DevParams*)e->P_dev, e->S, rnd, lpar, ver, sid, acc_fused ? (rest_merged ? 2 : 1) : 0);
+                    } else lobk_learn_q_fast(st, e->P.algo, gf, fast_lds_bytes(e->P.cwords4, LOB_FAST_NB, false), (const DevParams*)e->P_dev, e->S, rnd, lpar, ver);
                 }
                 if (!rest_merged) {   // (rest_merged: trace_rest_kernel serves the books handed back too, behind the lane trace kernel)
                     // The books the lane kernels hand back (a list that is empty in most steps, a handful of books in the others).
@@ -1447,9 +1452,9 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                         const bool reports = e->rest_hint && !no_hint && e->hint_step % LOB_HINT_EVERY == 0;
                         u64* hint_dev = reports ? e->rest_hint_dev + hs : nullptr;
                         const uint32_t hint_tag = (uint32_t)(++e->hint_serial);
-                        if (dq) hipLaunchKernelGGL(learn_q_rest_kernel<LOB_ALGO_DOUBLE_Q>, dim3(gl), dim3(LOB_BLOCK), 0, rs, e->P, e->S, rnd, learn_list, learn_n, hint_dev, hint_tag);
-                        else if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL(learn_q_rest_kernel<LOB_ALGO_QLAMBDA>, dim3(gl), dim3(LOB_BLOCK), 0, rs, e->P, e->S, rnd, learn_list, learn_n, hint_dev, hint_tag);
-                        else hipLaunchKernelGGL(learn_q_rest_kernel<LOB_ALGO_SARSA>, dim3(gl), dim3(LOB_BLOCK), 0, rs, e->P, e->S, rnd, learn_list, learn_n, hint_dev, hint_tag);
+                        if (dq) hipLaunchKernelGGL(learn_q_rest_kernel<LOB_ALGO_DOUBLE_Q>, dim3(gl), dim3(LOB_BLOCK), 0, rs, LOB_PS(e), rnd, learn_list, learn_n, hint_dev, hint_tag);
+                        else if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL(learn_q_rest_kernel<LOB_ALGO_QLAMBDA>, dim3(gl), dim3(LOB_BLOCK), 0, rs, LOB_PS(e), rnd, learn_list, learn_n, hint_dev, hint_tag);
+                        else hipLaunchKernelGGL(learn_q_rest_kernel<LOB_ALGO_SARSA>, dim3(gl), dim3(LOB_BLOCK), 0, rs, LOB_PS(e), rnd, learn_list, learn_n, hint_dev, hint_tag);
                         if (reports) { HIPCHK(hipEventRecord(e->hint_ev[hs], rs)); e->hint_tags[hs] = hint_tag; }
                         if (e->rest_hint && !no_hint) e->hint_step++;
                     }
@@ -1465,15 +1470,15 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                     // the listed books (their traces survive the step): a lane per generation, then the wave-per-book kernel for
                     // those the lane kernel hands on
                     if (e->P.sarsa_lanes)
-                        hipLaunchKernelGGL(trace_lane_kernel<LOB_ALGO_QLAMBDA>, dim3(std::min(4 * e->n_cus, (nb + LOB_TS_BLOCK / 32 - 1) / (LOB_TS_BLOCK / 32))), dim3(LOB_TS_BLOCK), 0, st, e->P, e->S, lpar, sid, acc_fused ? (rest_merged ? 2 : 1) : 0);
+                        hipLaunchKernelGGL(trace_lane_kernel<LOB_ALGO_QLAMBDA>, dim3(std::min(4 * e->n_cus, (nb + LOB_TS_BLOCK / 32 - 1) / (LOB_TS_BLOCK / 32))), dim3(LOB_TS_BLOCK), 0, st, LOB_PS(e), lpar, sid, acc_fused ? (rest_merged ? 2 : 1) : 0);
                     // (rest_merged: what the lane kernel hands on is served by trace_rest_kernel, in the place of accumulate_kernel below)
-                    if (!rest_merged) hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_QLAMBDA, 2>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, e->P, e->S, rnd, par, lpar, sid);
+                    if (!rest_merged) hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_QLAMBDA, 2>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, LOB_PS(e), rnd, par, lpar, sid);
                 }
             } else if (mode == 0) {
                 TimedLaunch t(e, "learn_kernel", st);
-                if (e->P.algo == LOB_ALGO_DOUBLE_Q) hipLaunchKernelGGL((learn_kernel<LOB_ALGO_DOUBLE_Q, false>), dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, b0, nb, par, (const i32*)nullptr, (const i32*)nullptr);
-                else if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL((learn_kernel<LOB_ALGO_QLAMBDA, false>), dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, b0, nb, par, (const i32*)nullptr, (const i32*)nullptr);
-                else hipLaunchKernelGGL((learn_kernel<LOB_ALGO_SARSA, false>), dim3(gw), dim3(LOB_BLOCK), 0, st, e->P, e->S, rnd, b0, nb, par, (const i32*)nullptr, (const i32*)nullptr);
+                if (e->P.algo == LOB_ALGO_DOUBLE_Q) hipLaunchKernelGGL((learn_kernel<LOB_ALGO_DOUBLE_Q, false>), dim3(gw), dim3(LOB_BLOCK), 0, st, LOB_PS(e), rnd, b0, nb, par, (const i32*)nullptr, (const i32*)nullptr);
+                else if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL((learn_kernel<LOB_ALGO_QLAMBDA, false>), dim3(gw), dim3(LOB_BLOCK), 0, st, LOB_PS(e), rnd, b0, nb, par, (const i32*)nullptr, (const i32*)nullptr);
+                else hipLaunchKernelGGL((learn_kernel<LOB_ALGO_SARSA, false>), dim3(gw), dim3(LOB_BLOCK), 0, st, LOB_PS(e), rnd, b0, nb, par, (const i32*)nullptr, (const i32*)nullptr);
             }
         }
         if (G > 1) {
@@ -1508,13 +1513,13 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                     dense_blocks = std::min(std::min(e->n_cus, LOB_ACD_MAX_BLOCKS), (e->B + 255) / 256);
                     const int bpb = ((e->B + dense_blocks - 1) / dense_blocks + 31) / 32 * 32;
                     dense_blocks = (e->B + bpb - 1) / bpb;
-                    hipLaunchKernelGGL(accumulate_dense_kernel, dim3(dense_blocks), dim3(LOB_ACD_BLOCK), acd_lds_bytes(), e->stream, e->P, e->S, par, e->step_id, bpb);
+                    hipLaunchKernelGGL(accumulate_dense_kernel, dim3(dense_blocks), dim3(LOB_ACD_BLOCK), acd_lds_bytes(), e->stream, LOB_PS(e), par, e->step_id, bpb);
                     hipLaunchKernelGGL(reduce_dense_kernel, dim3((e->S.cb_ids + 255) / 256, LOB_ACD_GROUPS), dim3(256), 0, e->stream, e->S, dense_blocks);
                 } else if (acc_blocked(e)) {
                     // (batches per block: SARSA(lambda) 80 us with one, 89 with two or four -- its blocks are bound by their LDS insertions, not by what
                     // they send to memory; mostly-greedy Q(lambda) 58 -> 50 us with four)
                     const int nbat = e->acc_batches_set ? e->acc_batches : (e->P.algo == LOB_ALGO_SARSA ? 1 : std::max(1, std::min(e->acc_batches, e->B / (16 * LOB_ACB_BLOCK))));
-                    hipLaunchKernelGGL(accumulate_block_kernel, dim3((e->B + LOB_ACB_BLOCK * nbat - 1) / (LOB_ACB_BLOCK * nbat), e->P.trace_kmax), dim3(LOB_ACB_BLOCK), 0, e->stream, e->P, e->S, par, e->step_id, nbat);
+                    hipLaunchKernelGGL(accumulate_block_kernel, dim3((e->B + LOB_ACB_BLOCK * nbat - 1) / (LOB_ACB_BLOCK * nbat), e->P.trace_kmax), dim3(LOB_ACB_BLOCK), 0, e->stream, LOB_PS(e), par, e->step_id, nbat);
                 } else if (rest_merged) {
                     // the books the learn kernel handed back (TD error + their sums), the books the lane trace kernel handed on (trace
                     // step + their sums) and what the fused accumulation left, in one launch; it reports the hand-back count to the
@@ -1525,21 +1530,21 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                     const uint32_t hint_tag = (uint32_t)(++e->hint_serial);
                     const dim3 rg(std::min(e->n_cus, (std::min(e->B, 4096) + LOB_TRACE_WAVES - 1) / LOB_TRACE_WAVES));
                     if (e->P.algo == LOB_ALGO_DOUBLE_Q)
-                        hipLaunchKernelGGL(trace_rest_kernel<LOB_ALGO_DOUBLE_Q>, rg, dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), e->stream, e->P, e->S, rnd, par, lpar, e->step_id, acc_lanes_shift(e), hint_dev, hint_tag);
+                        hipLaunchKernelGGL(trace_rest_kernel<LOB_ALGO_DOUBLE_Q>, rg, dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), e->stream, LOB_PS(e), rnd, par, lpar, e->step_id, acc_lanes_shift(e), hint_dev, hint_tag);
                     else
-                        hipLaunchKernelGGL(trace_rest_kernel<LOB_ALGO_QLAMBDA>, rg, dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), e->stream, e->P, e->S, rnd, par, lpar, e->step_id, acc_lanes_shift(e), hint_dev, hint_tag);
+                        hipLaunchKernelGGL(trace_rest_kernel<LOB_ALGO_QLAMBDA>, rg, dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), e->stream, LOB_PS(e), rnd, par, lpar, e->step_id, acc_lanes_shift(e), hint_dev, hint_tag);
                     if (reports) { HIPCHK(hipEventRecord(e->hint_ev[hs], e->stream)); e->hint_tags[hs] = hint_tag; }
                     if (e->rest_hint && !e->no_hint) e->hint_step++;
                 } else if (acc_fused) {
                     // what the fused accumulation left: a few hundred books (the grid's waves stride over the list)
                     const int sh = acc_lanes_shift(e);
                     const int waves = (std::min(e->B, 4096) + (64 >> sh) - 1) / (64 >> sh);
-                    hipLaunchKernelGGL(accumulate_kernel, dim3((waves + LOB_WAVES_PER_BLOCK - 1) / LOB_WAVES_PER_BLOCK), dim3(LOB_BLOCK), 0, e->stream, e->P, e->S, par, sh, e->step_id,
+                    hipLaunchKernelGGL(accumulate_kernel, dim3((waves + LOB_WAVES_PER_BLOCK - 1) / LOB_WAVES_PER_BLOCK), dim3(LOB_BLOCK), 0, e->stream, LOB_PS(e), par, sh, e->step_id,
                                        (const i32*)e->S.acc_list, (const i32*)&e->S.acc_list_n[lpar]);
                 } else {
                     const int sh = acc_lanes_shift(e);
                     const int waves = (e->B + (64 >> sh) - 1) / (64 >> sh);
-                    hipLaunchKernelGGL(accumulate_kernel, dim3((waves + LOB_WAVES_PER_BLOCK - 1) / LOB_WAVES_PER_BLOCK), dim3(LOB_BLOCK), 0, e->stream, e->P, e->S, par, sh, e->step_id,
+                    hipLaunchKernelGGL(accumulate_kernel, dim3((waves + LOB_WAVES_PER_BLOCK - 1) / LOB_WAVES_PER_BLOCK), dim3(LOB_BLOCK), 0, e->stream, LOB_PS(e), par, sh, e->step_id,
                                        (const i32*)nullptr, (const i32*)nullptr);
                 }
             }
@@ -1548,12 +1553,12 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                 TimedLaunch t(e, "apply_kernel");
                 const int blocks = e->S.cb_segs;
                 // (dense_blocks -1: no slot has ever been given a dense id -- apply_kernel does not look any up)
-                hipLaunchKernelGGL(apply_kernel, dim3(blocks), dim3(256), 0, e->stream, e->P, e->S, rnd, par, e->step_id, e->dense_ever ? dense_blocks : -1);
+                hipLaunchKernelGGL(apply_kernel, dim3(blocks), dim3(256), 0, e->stream, LOB_PS(e), rnd, par, e->step_id, e->dense_ever ? dense_blocks : -1);
             }
             if (e->P.sarsa_lanes && e->reg_fork_late) { int rc = registry_fork(e, e->stream, rnd, par); if (rc) return rc; }
         } else if (mode == 0) {
             TimedLaunch t(e, "update_kernel");
-            hipLaunchKernelGGL(update_kernel, dim3(grid_waves(e->B)), dim3(LOB_BLOCK), 0, e->stream, e->P, e->S, par, e->step_id);
+            hipLaunchKernelGGL(update_kernel, dim3(grid_waves(e->B)), dim3(LOB_BLOCK), 0, e->stream, LOB_PS(e), par, e->step_id);
         }
         if (mode == 0 && e->P.r_learn) {
             // R-learning: the average reward rho, after updateQ (rho_kernel, lob_kernels.h)

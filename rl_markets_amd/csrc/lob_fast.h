@@ -271,8 +271,9 @@ __device__ inline void fast_hand_back(const DevState& S, int kind, int lpar, int
 // Learner::_step / Backtester::_step prologue for every book (see act_book), NB books of a wave at a time.
 // `lpar`: parity of the work lists of this step.
 template <int NB>
-__global__ void __launch_bounds__(LOB_FAST_BLOCK) act_fast_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g, int mode,
+__global__ void __launch_bounds__(LOB_FAST_BLOCK) act_fast_kernel(LOB_PS_ARGS, const uint32_t* __restrict__ rnd_g, int mode,
                                                                   int par, int lpar, u64 ver) {
+    LOB_PS_REFS
     extern __shared__ __align__(16) unsigned char fast_lds_raw[];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         S.mk_count[par] = 0;  // this step's env_kernel starts a new list of memo slots
@@ -471,7 +472,8 @@ __device__ inline bool act_light_book(const DevParams& P, const DevState& S, int
     return true;
 }
 #if LOB_IN_MAIN
-__global__ void __launch_bounds__(LOB_LIGHT_BLOCK) act_light_kernel(DevParams P, DevState S, int par, int lpar, u64 ver, int sid_prev) {
+__global__ void __launch_bounds__(LOB_LIGHT_BLOCK) act_light_kernel(LOB_PS_ARGS, int par, int lpar, u64 ver, int sid_prev) {
+    LOB_PS_REFS
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         S.mk_count[par] = 0;
         S.slow_n[(lpar ^ 1) * 2 + 0] = 0;
@@ -499,8 +501,9 @@ __global__ void __launch_bounds__(LOB_LIGHT_BLOCK) act_light_kernel(DevParams P,
 #define LOB_TRL_BOOK(x) ((x) & 0x7ffffff)
 #define LOB_TRL_AMAX(x) ((int)((uint32_t)(x) >> 27))
 template <int ALGO, int LIST>
-__global__ void __launch_bounds__(LOB_TRACE_BLOCK, LOB_TRACE_OCC) trace_fast_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g, int par, int lpar,
+__global__ void __launch_bounds__(LOB_TRACE_BLOCK, LOB_TRACE_OCC) trace_fast_kernel(LOB_PS_ARGS, const uint32_t* __restrict__ rnd_g, int par, int lpar,
                                                                                     int sid) {
+    LOB_PS_REFS
     extern __shared__ __align__(16) unsigned char fast_lds_raw[];
     // this step's update appends to nz_new[par]; the list the general act path reads is nz_new[par ^ 1]
     if (blockIdx.x == 0 && threadIdx.x < LOB_NZ_WORDS) {
@@ -580,8 +583,9 @@ __global__ void __launch_bounds__(LOB_TRACE_BLOCK, LOB_TRACE_OCC) trace_fast_ker
 // (accumulate_generations, `defer`).  ALGO: the learn side's (Q(lambda) or double Q); the trace step is Watkins's in both.
 // `hint`: as learn_q_rest_kernel's (the hand-back count for the host).
 template <int ALGO>
-__global__ void __launch_bounds__(LOB_TRACE_BLOCK) trace_rest_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g, int par, int lpar, int sid,
+__global__ void __launch_bounds__(LOB_TRACE_BLOCK) trace_rest_kernel(LOB_PS_ARGS, const uint32_t* __restrict__ rnd_g, int par, int lpar, int sid,
                                                                      int lpb_shift, u64* hint, uint32_t hint_tag) {
+    LOB_PS_REFS
     extern __shared__ __align__(16) unsigned char fast_lds_raw[];
     __shared__ LearnLds L;  // (learn_q_book: waves 0-3 of the block)
     // this step's update appends to nz_new[par]; the list the general act path reads is nz_new[par ^ 1] (as trace_fast_kernel)
@@ -686,7 +690,8 @@ __global__ void __launch_bounds__(LOB_TRACE_BLOCK) trace_rest_kernel(DevParams P
 // and nothing is looked up in any set.  At an exploration rate of 0.8 that is 7 books in 10; the others go on the list
 // of the wave-per-book kernel.  Same draws, same stores as learn_traces for these books.
 #if LOB_IN_MAIN
-__global__ void __launch_bounds__(LOB_LIGHT_BLOCK) trace_light_kernel(DevParams P, DevState S, int lpar) {
+__global__ void __launch_bounds__(LOB_LIGHT_BLOCK) trace_light_kernel(LOB_PS_ARGS, int lpar) {
+    LOB_PS_REFS
     // Slot claims of the combined update: thousands of books hold the very same generation, and compare-and-swaps on one
     // address queue up behind each other.  The block elects one claimant per distinct generation first (LDS).
     __shared__ u64 claimed[512];
@@ -782,7 +787,8 @@ __global__ void __launch_bounds__(LOB_LIGHT_BLOCK) trace_light_kernel(DevParams 
 // acc_fuse (Q(lambda)): every generation's update is added to its slot as soon as the slot is known (acc_generation); a book
 // the learn kernel handed back (its TD error is not known yet: acc_pend) or this kernel hands on goes on acc_list.
 template <int ALGO>
-__global__ void __launch_bounds__(LOB_TS_BLOCK, 5) trace_lane_kernel(DevParams P, DevState S, int lpar, int sid, int acc_fuse) {
+__global__ void __launch_bounds__(LOB_TS_BLOCK, 5) trace_lane_kernel(LOB_PS_ARGS, int lpar, int sid, int acc_fuse) {
+    LOB_PS_REFS
     constexpr bool QL = ALGO == LOB_ALGO_QLAMBDA;
     const int lane = threadIdx.x & 63, k = lane & 31, half = lane >> 5, grp = threadIdx.x >> 5;
     const int n_todo = QL ? S.tr_list_n[lpar] : S.B;
@@ -980,8 +986,9 @@ static_assert(offsetof(LHdr, slot_cur) == 8 && offsetof(LHdr, stepped) == 20 && 
 
 // The second half of learn_book: Q(to_state, .), the TD error of SARSA / QLearn::UpdateWeights (agent.cpp:282-311).
 template <int ALGO, int NB>
-__global__ void __launch_bounds__(LOB_FAST_BLOCK) learn_q_fast_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g, int lpar,
+__global__ void __launch_bounds__(LOB_FAST_BLOCK) learn_q_fast_kernel(LOB_PS_ARGS, const uint32_t* __restrict__ rnd_g, int lpar,
                                                                       u64 ver) {
+    LOB_PS_REFS
     static_assert(ALGO == LOB_ALGO_SARSA || ALGO == LOB_ALGO_QLAMBDA, "one weight vector");
     extern __shared__ __align__(16) unsigned char fast_lds_raw[];
     const FastLds L = fast_stage(fast_lds_raw, P, S, rnd_g, NB, false);
@@ -1254,7 +1261,8 @@ __device__ __forceinline__ void ql_group_d(const DevParams& P, const DevState& S
 template <int ALGO, int VT, bool TR>
 // acc_fuse (TR): as learn_q_pair_kernel -- the update of a book whose step leaves one new generation is added to that generation's
 // slot here (double Q: in the sums of the vector the coin picked).
-__global__ void __launch_bounds__(LOB_QL_BLOCK) learn_q_lane_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g, int lpar, u64 ver, int sid, int acc_fuse) {
+__global__ void __launch_bounds__(LOB_QL_BLOCK) learn_q_lane_kernel(LOB_PS_ARGS, const uint32_t* __restrict__ rnd_g, int lpar, u64 ver, int sid, int acc_fuse) {
+    LOB_PS_REFS
     // (LOB_ALGO_DOUBLE_Q: DoubleQLearn on the fast path -- both weight vectors share the triples, the tiles, the maps and the
     // hit list; Q_a and Q_b continue from the memo's two records; its trace step is Watkins's, argmax over Q_a)
     static_assert(!TR || ALGO == LOB_ALGO_QLAMBDA || ALGO == LOB_ALGO_DOUBLE_Q, "the fused trace step is Watkins's");

@@ -821,9 +821,10 @@ __device__ __forceinline__ void act_book(const DevParams& P, const DevState& S, 
 // Whole batch (`list` null: wave t handles book b0 + t) or a work list of book ids (`list`, `*list_n`
 // entries; a fixed grid strides over it).
 template <int ALGO, bool LIST>
-__global__ void __launch_bounds__(LOB_BLOCK) act_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g,
+__global__ void __launch_bounds__(LOB_BLOCK) act_kernel(LOB_PS_ARGS, const uint32_t* __restrict__ rnd_g,
                                                         int mode, int b0, int nb, int par, const i32* __restrict__ list,
                                                         const i32* __restrict__ list_n) {
+    LOB_PS_REFS
     __shared__ LearnLds L;
     if (LIST && *list_n == 0) return;  // nothing handed back by the fast path: the usual case
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1291,8 +1292,9 @@ __device__ __forceinline__ void learn_q_book(const DevParams& P, const DevState&
 template <int ALGO>
 // `hint` (host-mapped memory, or null): the list's length tagged with this launch's serial number, for the host to read
 // LOB_HINT_LAG steps later (lob_engine.hip: which act / accumulate path a step takes, whether this launch runs beside the trace kernels).
-__global__ void __launch_bounds__(LOB_BLOCK) learn_q_rest_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g,
+__global__ void __launch_bounds__(LOB_BLOCK) learn_q_rest_kernel(LOB_PS_ARGS, const uint32_t* __restrict__ rnd_g,
                                                                  const i32* __restrict__ list, const i32* __restrict__ list_n, u64* hint, uint32_t hint_tag) {
+    LOB_PS_REFS
     __shared__ LearnLds L;
     if (hint && blockIdx.x == 0 && threadIdx.x == 0)
         __hip_atomic_store(hint, ((u64)hint_tag << 32) | (u64)(uint32_t)*list_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1307,8 +1309,9 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_q_rest_kernel(DevParams P, De
 }
 
 template <int ALGO, bool LIST>
-__global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g,
+__global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(LOB_PS_ARGS, const uint32_t* __restrict__ rnd_g,
                                                           int b0, int nb, int par, const i32* __restrict__ list, const i32* __restrict__ list_n) {
+    LOB_PS_REFS
     __shared__ LearnLds L;
     if (LIST && *list_n == 0) return;
     // this step's update appends to nz_new[par]; the list act reads is nz_new[par ^ 1]
@@ -1331,7 +1334,8 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_kernel(DevParams P, DevState 
 
 // Agent::updateQ (agent.cpp:137-142): theta[f] += (alpha*delta / N_TILINGS) * e[f]
 #if LOB_IN_MAIN
-__global__ void __launch_bounds__(LOB_BLOCK) update_kernel(DevParams P, DevState S, int par, int sid) {
+__global__ void __launch_bounds__(LOB_BLOCK) update_kernel(LOB_PS_ARGS, int par, int sid) {
+    LOB_PS_REFS
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b = __builtin_amdgcn_readfirstlane(blockIdx.x * LOB_WAVES_PER_BLOCK + w);
     if (b >= S.B) return;
@@ -1667,8 +1671,9 @@ __device__ inline void apply_deferred_generations(const DevParams& P, const DevS
 // `list` (or null: every book): accumulate_kernel over the books the fused accumulation left (lob_state.h acc_list); an entry
 // with bit 31 takes only the book's generations without a slot.
 #if LOB_IN_MAIN
-__global__ void __launch_bounds__(LOB_BLOCK) accumulate_kernel(DevParams P, DevState S, int par, int lpb_shift, int sid, const i32* __restrict__ list = nullptr,
+__global__ void __launch_bounds__(LOB_BLOCK) accumulate_kernel(LOB_PS_ARGS, int par, int lpb_shift, int sid, const i32* __restrict__ list = nullptr,
                                                                const i32* __restrict__ list_n = nullptr) {
+    LOB_PS_REFS
     const int lane = threadIdx.x & 63;
     const int lpb = 1 << lpb_shift, sub = lane & (lpb - 1);
     const int wave = blockIdx.x * LOB_WAVES_PER_BLOCK + (threadIdx.x >> 6);
@@ -1707,7 +1712,8 @@ __global__ void __launch_bounds__(LOB_BLOCK) accumulate_kernel(DevParams P, DevS
 #define LOB_ACB_K 4      /* batches of LOB_ACB_BLOCK books per block */
 #endif
 #if LOB_IN_MAIN
-__global__ void __launch_bounds__(LOB_ACB_BLOCK) accumulate_block_kernel(DevParams P, DevState S, int par, int sid, int n_batches) {
+__global__ void __launch_bounds__(LOB_ACB_BLOCK) accumulate_block_kernel(LOB_PS_ARGS, int par, int sid, int n_batches) {
+    LOB_PS_REFS
     __shared__ i32 keys[LOB_ACB_TAB];
     __shared__ f64 sums[LOB_ACB_TAB];
     const int lane = threadIdx.x & 63;
@@ -1850,7 +1856,8 @@ __device__ inline int cbd_high_water(const DevState& S) {
     return (S.cb_ids / 8 - deepest) * 8;
 }
 #if LOB_IN_MAIN
-__global__ void __launch_bounds__(LOB_ACD_BLOCK) accumulate_dense_kernel(DevParams P, DevState S, int par, int sid, int books_per_block) {
+__global__ void __launch_bounds__(LOB_ACD_BLOCK) accumulate_dense_kernel(LOB_PS_ARGS, int par, int sid, int books_per_block) {
+    LOB_PS_REFS
     extern __shared__ __attribute__((aligned(16))) unsigned char acd_raw[];
     f64* sums = reinterpret_cast<f64*>(acd_raw);
     uint32_t* touched = reinterpret_cast<uint32_t*>(acd_raw + (size_t)LOB_CBD_CAP * 8);
@@ -2039,7 +2046,8 @@ __global__ void __launch_bounds__(256) reduce_dense_kernel(DevState S, int dense
 // LOB_ACD_GROUPS partial sums of cb_red at its id (lane x reads group x's; LOB_ACD_MARK = no block of the group had a term for
 // it), and counts as touched if any holds a term.  A slot that is freed hands its id back to the list it came from.  (< 0: no
 // slot has ever been given an id -- nothing is looked up.)
-__global__ void __launch_bounds__(256) apply_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g, int par, int sid, int dense_blocks) {
+__global__ void __launch_bounds__(256) apply_kernel(LOB_PS_ARGS, const uint32_t* __restrict__ rnd_g, int par, int sid, int dense_blocks) {
+    LOB_PS_REFS
     __shared__ uint32_t rnd[2048 + 32];
     __shared__ int n_surv;
     // one block per segment of the table: its list, its survivors -- no counter shared between blocks
@@ -2275,7 +2283,8 @@ __global__ void __launch_bounds__(256) memo_kernel(DevParams P, DevState S, cons
 // last_state before step t + 1; bits that appear early in mk_amb of older slots only widen the set of tile pairs the lane
 // kernel compares index by index, and equal indices are the ground truth).
 #if LOB_IN_MAIN
-__global__ void __launch_bounds__(256) registry_kernel(DevParams P, DevState S, const uint32_t* __restrict__ rnd_g, int par) {
+__global__ void __launch_bounds__(256) registry_kernel(LOB_PS_ARGS, const uint32_t* __restrict__ rnd_g, int par) {
+    LOB_PS_REFS
     __shared__ uint32_t rnd[2048 + 32];
     {
         const uint4* src = reinterpret_cast<const uint4*>(rnd_g);
@@ -2430,6 +2439,15 @@ __global__ void td_stats_fold_kernel(DevState S, int n_blocks) {
     }
     S.ml_agg[0] = agg;
     S.ml_cnt[0] = cnt;
+}
+#endif
+
+// The two words of the state a learner step changes, into its device-resident copy (lob_engine.hip sync_state) -- for the flows
+// without a memo_kernel launch in front of the kernels that claim combine slots (memo_kernel does this itself).
+#if LOB_IN_MAIN
+__global__ void step_words_kernel(DevState* self, int cb_par, int cb_dense_on) {
+    self->cb_par = cb_par;
+    self->cb_dense_on = cb_dense_on;
 }
 #endif
 

@@ -42,9 +42,9 @@ void lobk_finalize(hipStream_t st, bool t2, const DevParams* Pd, const DevState&
 
 // ---- lob_tu_learn.hip ----
 // learn_q_pair_kernel / learn_q_lane_kernel<algo, vt, tr>: vt = 8 when the state has eight variables (else 0)
-void lobk_learn_q(hipStream_t st, bool pair, int algo, bool v8, bool tr, int grid, size_t lds, const DevParams& P, const DevParams* Pd, const DevState& S, const uint32_t* rnd,
+void lobk_learn_q(hipStream_t st, bool pair, int algo, bool v8, bool tr, int grid, size_t lds, const DevParams* Pd, const DevState& S, const uint32_t* rnd,
                   int lpar, u64 ver, int sid, int acc_fuse);
-void lobk_learn_q_fast(hipStream_t st, int algo, int grid, size_t lds, const DevParams& P, const DevState& S, const uint32_t* rnd, int lpar, u64 ver);
+void lobk_learn_q_fast(hipStream_t st, int algo, int grid, size_t lds, const DevParams* Pd, const DevState& S, const uint32_t* rnd, int lpar, u64 ver);
 // hipFuncAttributeMaxDynamicSharedMemorySize of every instantiation above
 hipError_t lobk_learn_set_lds(int fast_lds, int lane_lds, int pair_lds);
 

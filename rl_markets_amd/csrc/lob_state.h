@@ -474,6 +474,12 @@ struct DevParams {
     u64 seed, book_id_offset;
 };
 
+// Kernels take the parameters and the state through their device-resident copies (lob_engine.hip P_dev / DevState::self), not as
+// 3 KB of by-value arguments: the fields are loaded where they are used instead of all at the kernel's entry (scalar-register
+// spills: learn_q_pair_kernel 145 -> 10, trace_rest_kernel 81 -> ..., NOTES.md "Round 6").
+#define LOB_PS_ARGS const DevParams* __restrict__ Pp, const DevState* __restrict__ Sp
+#define LOB_PS_REFS const DevParams& P = *Pp; const DevState& S = *Sp;
+
 #define LOB_ERR_BAD_ORDER_PRICE 1  /* Order ctor would throw (src/market/order.cpp:22-27) */
 #define LOB_ERR_BAD_LEVEL 2        /* ApplyChanges would throw (src/market/book.cpp:74-77) */
 #define LOB_ERR_UNDEF_PRICE 4

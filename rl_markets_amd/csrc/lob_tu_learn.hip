@@ -7,8 +7,8 @@
 #include "lob_internal.h"
 #include "lob_fast.h"
 
-#define LOB_QL_ARGS dim3(grid), dim3(pair ? LOB_QP_BLOCK : LOB_QL_BLOCK), lds, st, P, S, rnd, lpar, ver, sid, acc_fuse
-#define LOB_QP_ARGS dim3(grid), dim3(LOB_QP_BLOCK), lds, st, Pd, S.self, rnd, lpar, ver, sid, acc_fuse   // (learn_q_pair_kernel: parameters and state by pointer)
+#define LOB_QL_ARGS dim3(grid), dim3(pair ? LOB_QP_BLOCK : LOB_QL_BLOCK), lds, st, Pd, S.self, rnd, lpar, ver, sid, acc_fuse
+#define LOB_QP_ARGS LOB_QL_ARGS
 #define LOB_QL_ONE(A, VT, TR)                                                        \
     do {                                                                             \
         if (pair) hipLaunchKernelGGL((learn_q_pair_kernel<A, VT, TR>), LOB_QP_ARGS); \
@@ -16,7 +16,7 @@
     } while (0)
 #define LOB_QL_VT(A, TR) do { if (v8) LOB_QL_ONE(A, 8, TR); else LOB_QL_ONE(A, 0, TR); } while (0)
 
-void lobk_learn_q(hipStream_t st, bool pair, int algo, bool v8, bool tr, int grid, size_t lds, const DevParams& P, const DevParams* Pd, const DevState& S, const uint32_t* rnd,
+void lobk_learn_q(hipStream_t st, bool pair, int algo, bool v8, bool tr, int grid, size_t lds, const DevParams* Pd, const DevState& S, const uint32_t* rnd,
                   int lpar, u64 ver, int sid, int acc_fuse) {
     if (algo == LOB_ALGO_DOUBLE_Q) LOB_QL_VT(LOB_ALGO_DOUBLE_Q, true);   // (only with the fused Watkins trace step: lob_create)
     else if (algo == LOB_ALGO_QLAMBDA && tr) LOB_QL_VT(LOB_ALGO_QLAMBDA, true);
@@ -24,9 +24,9 @@ void lobk_learn_q(hipStream_t st, bool pair, int algo, bool v8, bool tr, int gri
     else LOB_QL_VT(LOB_ALGO_SARSA, false);
 }
 
-void lobk_learn_q_fast(hipStream_t st, int algo, int grid, size_t lds, const DevParams& P, const DevState& S, const uint32_t* rnd, int lpar, u64 ver) {
-    if (algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL((learn_q_fast_kernel<LOB_ALGO_QLAMBDA, LOB_FAST_NB>), dim3(grid), dim3(LOB_FAST_BLOCK), lds, st, P, S, rnd, lpar, ver);
-    else hipLaunchKernelGGL((learn_q_fast_kernel<LOB_ALGO_SARSA, LOB_FAST_NB>), dim3(grid), dim3(LOB_FAST_BLOCK), lds, st, P, S, rnd, lpar, ver);
+void lobk_learn_q_fast(hipStream_t st, int algo, int grid, size_t lds, const DevParams* Pd, const DevState& S, const uint32_t* rnd, int lpar, u64 ver) {
+    if (algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL((learn_q_fast_kernel<LOB_ALGO_QLAMBDA, LOB_FAST_NB>), dim3(grid), dim3(LOB_FAST_BLOCK), lds, st, Pd, S.self, rnd, lpar, ver);
+    else hipLaunchKernelGGL((learn_q_fast_kernel<LOB_ALGO_SARSA, LOB_FAST_NB>), dim3(grid), dim3(LOB_FAST_BLOCK), lds, st, Pd, S.self, rnd, lpar, ver);
 }
 
 hipError_t lobk_learn_set_lds(int fast_lds, int lane_lds, int pair_lds) {
