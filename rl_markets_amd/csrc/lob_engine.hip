@@ -78,6 +78,7 @@ struct lob_engine {
     bool dense_ever = false;    // the dense sums have been on at some step: slots may hold dense ids (apply_kernel frees them with their slots)
     bool acc_dense = true;      // ... in a direct-indexed LDS array by the slots' dense ids, accumulate_dense_kernel (LOB_ACC_DENSE=0: accumulate_block_kernel's hash table; A/B switch)
     int env_step_lanes = 64;    // books per wave of env_step_kernel (LOB_ENV_STEP_LANES=32: two half-full waves per SIMD; experiment)
+    int env16_max = 4096;       // largest batch that takes env_step16_kernel (16 lanes per book) instead of env_step_kernel (LOB_ENV16_MAX; 0: never)
     bool prepass_roles = false; // the pre-pass on two waves per 64 books (reset2_kernel / prepass_extend2_kernel; LOB_PREPASS_ROLES=1): measured slower, opt-in
     // learn_q_rest_kernel reports its list's length (the books the lane learn kernels handed back) through host-mapped memory:
     // a ring of LOB_HINT_RING words, one per learner step, each with an event recorded behind the kernel that writes it.  The
@@ -140,6 +141,7 @@ struct lob_engine {
     i64* phase_dev = nullptr;  // replayed stream: first record of every book's window
     Track* track_dev = nullptr;
     i32* actions_dev = nullptr;
+    i64* cnt_sum = nullptr;     // the striped device counters added up (read_counters)
     lob_book_dump* dump_dev = nullptr;
     int dump_cap = 0;
     bool have_events = false, was_reset = false;
@@ -385,6 +387,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     if (const char* g = getenv("LOB_ACC_FUSE")) e->acc_fuse = !(g[0] == '0');
     if (const char* g = getenv("LOB_ACC_BATCHES")) { const int v = atoi(g); if (v == 1 || v == 2 || v == 4 || v == 8) { e->acc_batches = v; e->acc_batches_set = true; } }
     if (const char* g = getenv("LOB_ENV_STEP_LANES")) { if (exps && atoi(g) == 32) e->env_step_lanes = 32; }
+    if (const char* g = getenv("LOB_ENV16_MAX")) { const int v = atoi(g); if (v >= 0) e->env16_max = v; }
     if (const char* g = getenv("LOB_PREPASS_ROLES")) e->prepass_roles = exps && g[0] == '1';
     if (hipHostMalloc((void**)&e->rest_hint, LOB_HINT_RING * sizeof(u64), hipHostMallocMapped) == hipSuccess) {
         memset(e->rest_hint, 0, LOB_HINT_RING * sizeof(u64));
@@ -690,7 +693,9 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     if (rc == LOB_OK) rc = dev_alloc(e, &S.nz_new, 4 * LOB_NZ_WORDS);
     if (rc == LOB_OK) rc = dev_alloc(e, &S.verdict_b, P.algo == LOB_ALGO_DOUBLE_Q ? B * 64 : 1);
     if (rc == LOB_OK) rc = dev_alloc(e, &S.nz_epoch, 1);
-    if (rc == LOB_OK) rc = dev_alloc(e, &S.counters, 16);  // ([8]: generations apply_kernel applied from trace_rest_kernel's list, lob_debug_deferred)
+    // (striped: lob_state.h cnt_add; [8]: generations apply_kernel applied from trace_rest_kernel's list, lob_debug_deferred)
+    if (rc == LOB_OK) rc = dev_alloc(e, &S.counters, (size_t)LOB_CNT_STRIPES * LOB_CNT_STRIDE);
+    if (rc == LOB_OK) rc = dev_alloc(e, &e->cnt_sum, 16);
     if (rc == LOB_OK) rc = dev_alloc(e, &S.error_flag, 1);
 #ifdef LOB_PROF
     if (rc == LOB_OK) rc = dev_alloc(e, &S.prof, B * LOB_PROF_N);
@@ -1089,7 +1094,9 @@ static void launch_env_fused(lob_engine* e, hipStream_t st, int par, int lpar, u
     const bool dq = e->P.algo == LOB_ALGO_DOUBLE_Q;  // (then t2 && env_step: lob_create)
     {
         TimedLaunch t(e, "env_kernel", st);
-        if (t2 && e->env_step) lobk_env_step(st, inline_general, dq, half_waves, Pd, e->S, nb, sid, par, F1, (const uint32_t*)e->rnd_dev);
+        // (batches up to env16_max books: a book's levels across 16 lanes, four books per wave -- env_step16_kernel)
+        const bool lanes16 = !dq && nb <= e->env16_max;
+        if (t2 && e->env_step) lobk_env_step(st, inline_general, dq, half_waves, lanes16, Pd, e->S, nb, sid, par, F1, (const uint32_t*)e->rnd_dev);
         else lobk_env_mode(st, t2, 1, Pd, e->S, nb, sid, par, F1);
     }
     if (inline_general) return;
@@ -1144,7 +1151,7 @@ int lob_reset(lob_engine* e) {
         HIPCHK(hipMemsetAsync(e->S.mk_all_n, 0, sizeof(i32), e->stream));
         HIPCHK(hipMemsetAsync(e->S.tr_cbslot, 0xff, (size_t)e->B * e->P.trace_gens * 4, e->stream));  // (slots of books that stopped stepping may be gone)
         if (e->S.tr_cbd) HIPCHK(hipMemsetAsync(e->S.tr_cbd, 0xff, (size_t)e->B * e->P.trace_gens * 8, e->stream));
-        HIPCHK(hipMemsetAsync(e->S.counters + 7, 0, sizeof(i64), e->stream));
+        hipLaunchKernelGGL(counters_zero_kernel, dim3(1), dim3(LOB_CNT_STRIPES), 0, e->stream, +e->S.counters, 7);
         e->P.epi_epoch++;
         { int rc = push_params(e); if (rc) return rc; }
     }
@@ -1794,12 +1801,20 @@ int lob_get_traces(lob_engine* e, int32_t book, int32_t* idx, float* elig, int32
     return LOB_OK;
 }
 
+// the striped device counters, summed on the device, into c[16] (asynchronous: the caller synchronises the stream)
+static int read_counters(lob_engine* e, i64* c) {
+    hipLaunchKernelGGL(counters_fold_kernel, dim3(1), dim3(LOB_CNT_STRIPES), 0, e->stream, (const i64*)e->S.counters, e->cnt_sum);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c, e->cnt_sum, 16 * sizeof(i64), hipMemcpyDeviceToHost, e->stream));
+    return LOB_OK;
+}
+
 int lob_get_counters(lob_engine* e, int64_t out[4]) {
     if (!e || !out) return LOB_EINVAL;
     HIPCHK(hipSetDevice(e->device));
-    i64 c[8];
+    i64 c[16];
     std::vector<i32> done(e->B);
-    HIPCHK(hipMemcpyAsync(c, e->S.counters, sizeof c, hipMemcpyDeviceToHost, e->stream));
+    { int rc = read_counters(e, c); if (rc) return rc; }
     HIPCHK(hipMemcpyAsync(done.data(), e->S.done, (size_t)e->B * 4, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     i64 live = 0;
@@ -1812,9 +1827,9 @@ int lob_get_path_stats(lob_engine* e, int64_t out[8]) {
     if (!e || !out) return LOB_EINVAL;
     HIPCHK(hipSetDevice(e->device));
     { int rc = registry_join(e); if (rc) return rc; }
-    i64 c[8];
+    i64 c[16];
     i32 n_all = 0, flag = 0, mk_n[2] = {0, 0};
-    HIPCHK(hipMemcpyAsync(c, e->S.counters, sizeof c, hipMemcpyDeviceToHost, e->stream));
+    { int rc = read_counters(e, c); if (rc) return rc; }
     HIPCHK(hipMemcpyAsync(mk_n, e->S.mk_count, sizeof mk_n, hipMemcpyDeviceToHost, e->stream));
     if (e->P.sarsa_lanes) {
         HIPCHK(hipMemcpyAsync(&n_all, e->S.mk_all_n, 4, hipMemcpyDeviceToHost, e->stream));
@@ -2066,9 +2081,9 @@ extern "C" int lob_debug_flow(lob_engine* e, int64_t out[8]) {
 extern "C" int lob_debug_light(lob_engine* e, int64_t out[2]) {
     if (!e || !out) return LOB_EINVAL;
     HIPCHK(hipSetDevice(e->device));
-    i64 c[8];
+    i64 c[16];
     i32 d = 0;
-    HIPCHK(hipMemcpyAsync(c, e->S.counters, sizeof c, hipMemcpyDeviceToHost, e->stream));
+    { int rc = read_counters(e, c); if (rc) return rc; }
     HIPCHK(hipMemcpyAsync(&d, e->S.hl_dirty, sizeof d, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     out[0] = c[5];
@@ -2080,8 +2095,10 @@ extern "C" int lob_debug_light(lob_engine* e, int64_t out[2]) {
 extern "C" int lob_debug_deferred(lob_engine* e, int64_t out[1]) {
     if (!e || !out) return LOB_EINVAL;
     HIPCHK(hipSetDevice(e->device));
-    HIPCHK(hipMemcpyAsync(out, e->S.counters + 8, sizeof(i64), hipMemcpyDeviceToHost, e->stream));
+    i64 c[16];
+    { int rc = read_counters(e, c); if (rc) return rc; }
     HIPCHK(hipStreamSynchronize(e->stream));
+    out[0] = c[8];
     return LOB_OK;
 }
 

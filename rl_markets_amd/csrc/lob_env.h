@@ -513,6 +513,78 @@ __device__ inline i64 full_volume(const EnvCtx& c, const RowFull& R, int side, f
     return hit ? (i64)(i32)v : 0;
 }
 
+__device__ inline void row_resolve(const EnvCtx&, const RowFull&) {}
+// best prices of a snapshot held as RowFull (the quotes in LOB_QUOTE_BOOK mode)
+__device__ inline f64 row_best_px(const RowFull& R, int side) { return (f64)__uint_as_float(side == 0 ? R.apx[0] : R.bpx[0]); }
+
+#if defined(__HIP__)
+// ---- the same snapshot with its LEVELS ACROSS LANES: 16 lanes per book (env_step16_kernel, lob_envstep.h) ---------------------
+// Small batches leave most of the chip idle under the lane-per-book kernels (4 096 books: 64 waves on 1 024 SIMDs, each a chain
+// of ~10 000 dependent instructions for 64 books).  Here a book is 16 lanes of a wave: the 14 quads of its 224-byte record are ONE
+// coalesced load (lane i takes quad i: a wave fetches four records as four contiguous runs), a 64-word LDS row per book turns
+// them into "lane l holds level l of the four arrays", and what Book does level by level becomes wave arithmetic:
+//   Book::volume(price) / last_volume (book.cpp:200-222)   every level's lane compares its 1e-4 key, the group's 16 bits of the
+//                                                          wave ballot name the level, its lane hands the volume over;
+//   Ask/BidBook::WalkTheBook (book.cpp:431-456,514-539)    executed-so-far = an exclusive prefix sum of the level volumes across
+//                                                          the group's lanes, l_ex = min(lvol, size - prefix) in every lane at once,
+//                                                          "filled" = the ballot of prefix + lvol >= size; only the two f64 sums
+//                                                          (proxy, value) are then added up in level order, lane by lane, so that
+//                                                          they round as the reference's loop does.
+// Everything of the step that is not per level (orders, inventory, PnL, reward, state variables) is replicated in the group's 16
+// lanes: same instructions, same values, lane 0 stores.  Control flow is uniform within a group, so its lanes reach every
+// cross-lane operation together.
+struct RowLev {
+    mutable uint4 q;                           // this lane's quad of the record, as loaded (lane li < Wd / 4)
+    mutable uint32_t apx, avol, bpx, bvol;     // level li of the four arrays (0 beyond the depth / without a snapshot), once resolved
+    uint32_t* stage;                           // the book's LDS staging row (64 words)
+    int li;                                    // lane within the group
+    mutable bool pending;                      // `q` has arrived (or is on its way) and is not transposed yet
+    bool none;                                 // no snapshot (record < 0): every price reads as undefined
+    __device__ __forceinline__ void resolve(const EnvCtx& c) const {
+        if (!pending) return;
+        const int D = c.P.D, D4 = drec_pad4(D);
+        if (li < (c.P.Wd >> 2)) reinterpret_cast<uint4*>(stage)[li] = q;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local");
+        __builtin_amdgcn_wave_barrier();
+        const bool in = li < D && !none;
+        const int l = li < D ? li : 0;
+        const uint32_t a = stage[4 + l], av = stage[4 + D4 + l], b = stage[4 + 2 * D4 + l], bv = stage[4 + 3 * D4 + l];
+        apx = in ? a : 0u; avol = in ? av : 0u; bpx = in ? b : 0u; bvol = in ? bv : 0u;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local");   // (the row may be written again right away)
+        __builtin_amdgcn_wave_barrier();
+        pending = false;
+    }
+};
+// the group's 16 bits of a wave ballot
+__device__ __forceinline__ uint32_t grp_ballot(bool p) { return (uint32_t)(__ballot(p) >> (threadIdx.x & 48)) & 0xffffu; }
+__device__ inline void row_full_load(const EnvCtx& c, int rec, RowLev& R) {
+    const uint4* r = reinterpret_cast<const uint4*>(c.row(rec < 0 ? 0 : rec));
+    const int nq = c.P.Wd >> 2;
+    R.q = r[R.li < nq ? R.li : nq - 1];   // one 16-byte load per lane: the record's quads, contiguous
+    R.none = rec < 0;
+    R.pending = true;
+}
+__device__ inline void row_resolve(const EnvCtx& c, const RowLev& R) { R.resolve(c); }
+__device__ inline f64 row_best_px(const RowLev& R, int side) {   // (resolved by the caller: place_orders below)
+    return (f64)__uint_as_float(__shfl(side == 0 ? R.apx : R.bpx, 0, 16));
+}
+// Book::volume(price) by ballot: the level whose key matches (unique per side: lob_validate_stream; the sequential form keeps
+// the LAST match, so does this)
+__device__ inline i64 rowlev_volume(const EnvCtx& c, const RowLev& R, int side, f64 k) {
+    R.resolve(c);
+    const f32 p = __uint_as_float(side == 0 ? R.apx : R.bpx);
+    const uint32_t m = grp_ballot(p != 0.0f && key4((f64)p) == k);
+    const uint32_t v = __shfl(side == 0 ? R.avol : R.bvol, m ? 31 - __clz(m) : 0, 16);
+    return m ? (i64)(i32)v : 0;
+}
+__device__ inline i64 full_volume(const EnvCtx& c, const RowLev& R, int side, f64 price) { return rowlev_volume(c, R, side, key4(price)); }
+__device__ inline void row_volumes_k(const EnvCtx& c, bool a_on, bool b_on, f64 ka, f64 kb, const RowLev& L, i64& a_v, i64& b_v) {
+    const i64 va = rowlev_volume(c, L, 0, ka), vb = rowlev_volume(c, L, 1, kb);
+    a_v = a_on ? va : 0;
+    b_v = b_on ? vb : 0;
+}
+#endif
+
 // RiskManager::CheckOrders (src/environment/risk_manager.cpp:26-32)
 __device__ inline void check_orders(const DevParams& P, EnvR& e) {
     if (e.position >= P.pos_ub) e.b_on = 0;
@@ -522,7 +594,8 @@ __device__ inline void check_orders(const DevParams& P, EnvR& e) {
 // RiskManager::PlaceOrder with ORDER_LIMIT == 1 (risk_manager.cpp:61-99) +
 // Book::PlaceOrder (book.cpp:250-261): cancel whatever rests, place a new
 // order queued behind the displayed volume at that price.
-__device__ inline void place_one(const EnvCtx& c, EnvR& e, int side, f64 price, i32 price_ticks, const RowFull& cur) {
+template <class ROW>
+__device__ inline void place_one(const EnvCtx& c, EnvR& e, int side, f64 price, i32 price_ticks, const ROW& cur) {
     if (!(price > 0.0)) c.err(LOB_ERR_BAD_ORDER_PRICE);
     i64 qh = full_volume(c, cur, side, price);
     if (side == 0) {
@@ -534,14 +607,16 @@ __device__ inline void place_one(const EnvCtx& c, EnvR& e, int side, f64 price, 
 
 // Intraday::_place_orders + l2p_ (src/environment/intraday.cpp:64-82,164-173)
 // `cur` = the level arrays of e.rec_cur (row_full_load)
-__device__ inline void place_orders(const EnvCtx& c, EnvR& e, int al, int bl, const RowFull& cur) {
+template <class ROW>
+__device__ inline void place_orders(const EnvCtx& c, EnvR& e, int al, int bl, const ROW& cur) {
     const DevParams& P = c.P;
     e.ask_level = al;
     e.bid_level = bl;
     int ta, tb;
     int band = 0, band_t = 0;  // (to_ticks_hint / to_price_hint: the six conversions of a re-quote fall in one band)
     if (P.quote_mode == LOB_QUOTE_BOOK) {
-        const f64 ap0 = (f64)__uint_as_float(cur.apx[0]), bp0 = (f64)__uint_as_float(cur.bpx[0]);
+        row_resolve(c, cur);
+        const f64 ap0 = row_best_px(cur, 0), bp0 = row_best_px(cur, 1);
         if (ap0 == 0.0 || bp0 == 0.0) c.err(LOB_ERR_UNDEF_PRICE);
         ta = lobh::to_ticks_hint((*c.tk), ap0, band) + al;
         tb = lobh::to_ticks_hint((*c.tk), bp0, band) - bl;
@@ -608,8 +683,61 @@ __device__ inline void market_order(const EnvCtx& c, EnvR& e, i64 size, i64& out
     out_value = value;
 }
 
+#if defined(__HIP__)
+// ... the same walk with the levels across the group's lanes (RowLev above): prefix sum + ballot instead of the loop
+__device__ inline void market_order(const EnvCtx& c, EnvR& e, i64 size, i64& out_vol, f64& out_proxy, f64& out_value, const RowLev& cur) {
+    out_vol = 0; out_proxy = 0.0; out_value = 0.0;
+    if (e.rec_cur < 0) c.err(LOB_ERR_UNDEF_PRICE);
+    const f64 mip = e.mid;
+    if (size == 0) return;
+    const int side = size > 0 ? 0 : 1;
+    const i64 abs_size = size < 0 ? -size : size;
+    i64 tv;  // cumulative total_volume_ (quirk Q1) of the side being walked: as in the lane-per-book form
+    if (e.done == 2) tv = side == 0 ? c.S.prep[c.b].a_tv : c.S.prep[c.b].b_tv;
+    else tv = c.pre_prev ? (side == 0 ? c.pre_prev->a_tv : c.pre_prev->b_tv) : (side == 0 ? c.track(e.k - 1).a_tv : c.track(e.k - 1).b_tv);
+    if (abs_size > tv) return;
+    cur.resolve(c);
+    const f32 pf = __uint_as_float(side == 0 ? cur.apx : cur.bpx);
+    const bool level = cur.li < c.P.D && pf != 0.0f;                  // (a level the loop does not skip)
+    const i64 lvol = level ? (i64)(i32)(side == 0 ? cur.avol : cur.bvol) : 0;
+    // executed before this level = exclusive prefix sum of the level volumes over the group's lanes
+    i64 incl = lvol;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+        const i64 up = __shfl_up(incl, d, 16);
+        if (cur.li >= d) incl += up;
+    }
+    const i64 before = incl - lvol;
+    // the loop stops taking levels once `executed >= abs_size`: a level takes part while the volume before it is short of the size
+    const bool takes = level && before < abs_size;
+    const i64 left = abs_size - before;
+    const i64 l_ex = takes ? (lvol < left ? lvol : left) : 0;
+    const uint32_t fills = grp_ballot(takes && before + l_ex >= abs_size);   // the level at which the order is complete
+    // total executed: the last lane's inclusive sum, capped
+    const i64 total = __shfl(incl, 15, 16);
+    const i64 executed = total < abs_size ? total : abs_size;
+    // the two f64 sums in level order (a level that does not take part contributes an exact +0.0: x - 0.0 == x, x + 0.0 == x for
+    // every x these sums can hold -- they start at +0.0 and `value` of a bid walk only grows)
+    const f64 p = (f64)pf;
+    const f64 t_proxy = takes ? (f64)l_ex * fabs(p - mip) : 0.0;
+    const f64 t_value = takes ? (f64)l_ex * p : 0.0;
+    f64 proxy = 0.0, value = 0.0;
+    for (int l = 0; l < c.P.D; l++) {
+        const f64 tp = __shfl(t_proxy, l, 16), tvl = __shfl(t_value, l, 16);
+        proxy -= tp;
+        if (side == 0) value -= tvl;
+        else value += tvl;
+    }
+    if (fills) { if (side == 0) e.a_ntr++; else e.b_ntr++; }
+    out_vol = side == 0 ? executed : -executed;
+    out_proxy = proxy;
+    out_value = value;
+}
+#endif
+
 // Base::ClearInventory (base.cpp:339-349) + RiskManager::ClearInventory/MarketOrder
-__device__ inline void clear_inventory(const EnvCtx& c, EnvR& e, const RowFull& cur) {
+template <class ROW>
+__device__ inline void clear_inventory(const EnvCtx& c, EnvR& e, const ROW& cur) {
     i64 v; f64 proxy, value;
     market_order(c, e, -e.position, v, proxy, value, cur);
     e.position += v;
@@ -626,7 +754,8 @@ __device__ inline void clear_inventory(const EnvCtx& c, EnvR& e) {
 }
 
 // Intraday::DoAction (intraday.cpp:176-220)
-__device__ inline void do_action(const EnvCtx& c, EnvR& e, int action, const RowFull& cur) {
+template <class ROW>
+__device__ inline void do_action(const EnvCtx& c, EnvR& e, int action, const ROW& cur) {
     int al, bl;
     switch (action) {
         case 0: al = 1; bl = 1; break;
@@ -988,7 +1117,8 @@ __device__ inline bool next_state(const EnvCtx& c, EnvR& e, const TrackHead& t, 
 // the lane that owns the book (perform_action) or by whichever lane of the block is free
 // (env_compact_kernel): the running sums of the loop live in `StepAgg`.
 // up to the first NextState: DoAction, CheckOrders, UpdateStats, the reward of the action itself
-__device__ inline void step_prologue(const EnvCtx& c, EnvR& e, int action, StepAgg& g, const RowFull& cur) {
+template <class ROW>
+__device__ inline void step_prologue(const EnvCtx& c, EnvR& e, int action, StepAgg& g, const ROW& cur) {
     const DevParams& P = c.P;
     if (c.pre_n_track >= 0) {
         g.n_track = c.pre_n_track;
@@ -1164,8 +1294,8 @@ __device__ inline void row_volumes_k(const EnvCtx& c, bool a_on, bool b_on, f64 
     b_v = (b_on && fb) ? (i64)(i32)vb : 0;
 }
 // one pass: 0 = another event follows, 1 = the step is complete.  `L` = the level arrays of row t.rec_first.
-template <class TH>  // TrackHead64, or the whole Track entry
-__device__ inline int pass_fast(const EnvCtx& c, EnvR& h, StepAgg& g, const TH& t, RowFull& L, const FastKeys& K, const f64* spread_mean = nullptr) {
+template <class TH, class ROW>  // TrackHead64, or the whole Track entry; RowFull, or RowLev (levels across 16 lanes)
+__device__ inline int pass_fast(const EnvCtx& c, EnvR& h, StepAgg& g, const TH& t, ROW& L, const FastKeys& K, const f64* spread_mean = nullptr) {
     const DevParams& P = c.P;
     h.pnl_step = 0.0;
     const f64 tp0 = (f64)t.tr_px[0], tp1 = (f64)t.tr_px[1];
@@ -1268,8 +1398,8 @@ __device__ inline int pass_fast(const EnvCtx& c, EnvR& h, StepAgg& g, const TH& 
 // entry and the next row before it starts on its own.  TE = TrackHead64, or Track when the caller wants the last completed
 // event's whole entry back in `t` (the state extraction reads its second half).  Returns the last pass's status (1: step
 // complete, 2: out of data).
-template <class TE>
-__device__ inline int event_loop_fast(const EnvCtx& c, EnvR& e, StepAgg& g, TE& t, RowFull L) {
+template <class TE, class ROW>
+__device__ inline int event_loop_fast(const EnvCtx& c, EnvR& e, StepAgg& g, TE& t, ROW L) {
     EnvR h = e;  // registers from here to the end of the loop
     const FastKeys K{key4(h.a_opx), key4(h.b_opx)};
     c.mark(22);  // hot copy
@@ -1286,7 +1416,7 @@ __device__ inline int event_loop_fast(const EnvCtx& c, EnvR& e, StepAgg& g, TE& 
         bool have_next_row = false;
         if (fast) {
             if (t.rec_first != h.rec_cur + 1) row_full_load(c, t.rec_first, L);
-            RowFull Ln;  // next pass's first row, in flight during this one
+            ROW Ln = L;  // next pass's first row, in flight during this one
             { const int rn = t.rec_last + 1; row_full_load(c, rn < last_row ? rn : last_row, Ln); }
             c.mark(23);  // loop top: next entry / next row requested
             st = pass_fast(c, h, g, t, L, K, sizeof(TE) == sizeof(Track) ? &reinterpret_cast<const Track*>(&t)->spread_mean : nullptr);

@@ -277,7 +277,7 @@ __global__ void __launch_bounds__(64, EnvStepOcc<LANES>::waves) env_step_kernel(
                     atomicOr(&S.mk_marked[mslot], 1u << action);
                 }
                 const u64 act = __ballot(1);
-                if ((int)(threadIdx.x & 63) == __builtin_ctzll(act)) atomicAdd((unsigned long long*)&S.counters[5], (unsigned long long)__builtin_popcountll(act));
+                if ((int)(threadIdx.x & 63) == __builtin_ctzll(act)) cnt_add(S, 5, (unsigned long long)__builtin_popcountll(act));
                 go = true;
             }
         }
@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(64, EnvStepOcc<LANES>::waves) env_step_kernel(
         // on it as in act_kernel (act_book: swap, terminal check, Q(last_state, .), policy, header, tile marks)
         u64 todo = __ballot(valid && alive && open && !ok);
         if (todo) {
-            if (threadIdx.x == 0) atomicAdd((u64*)&S.counters[2], (u64)__builtin_popcountll(todo));  // (lob_get_path_stats [6])
+            if (threadIdx.x == 0) cnt_add(S, 2, (u64)__builtin_popcountll(todo));  // (lob_get_path_stats [6])
             const uint4* src = reinterpret_cast<const uint4*>(rnd_g);
             uint4* dst = reinterpret_cast<uint4*>(lds_learn.rnd);
             for (int i = threadIdx.x; i < 512; i += 64) dst[i] = src[i];
@@ -370,9 +370,246 @@ __global__ void __launch_bounds__(64, EnvStepOcc<LANES>::waves) env_step_kernel(
         d_events += __shfl_down(d_events, off);
     }
     if ((threadIdx.x & 63) == 0 && (d_steps | d_events)) {
-        atomicAdd((u64*)&S.counters[0], (u64)d_steps);
-        atomicAdd((u64*)&S.counters[1], (u64)d_events);
-        atomicAdd((u64*)&S.counters[3], (u64)d_steps);  // every stepped book gets one TD update
+        cnt_add(S, 0, (u64)d_steps);
+        cnt_add(S, 1, (u64)d_events);
+        cnt_add(S, 3, (u64)d_steps);  // every stepped book gets one TD update
+    }
+}
+
+
+// ---- the same step with a book's LEVELS ACROSS LANES: 16 lanes per book, four books per wave (RowLev, lob_env.h) -----------------
+// For the batches that leave the chip idle under the lane-per-book kernel (4 096 books: 64 of its waves on 1 024 SIMDs): 16 x the
+// waves, each on four books instead of 64 -- a wave waits for the longest of four steps, not of 64, and executes the branches of
+// four books, not the union of 64.  What is per level is wave arithmetic:
+//   * a record is one coalesced 16-byte load per lane (14 lanes x 16 B = the 224-byte row), turned into "lane l = level l" through
+//     a 64-word LDS row; Book::volume / WalkTheBook by ballot and prefix sum (lob_env.h, RowLev);
+//   * the hit list is a lane-parallel gather -- lane i fetches entries i, 16 + i, 32 + i and their weights: three loads instead of
+//     35 -- followed by the ORDERED reduction Agent::getQ prescribes (entry j's product is handed round by lane j & 15);
+//   * everything that is per book (orders, inventory, PnL, reward, state variables, the memo claim) is replicated in the 16 lanes
+//     of the group -- the same instructions on the same values; the group's first lane stores.
+// The arithmetic is env_step_kernel's, call for call (the row-consuming routines are templates over the row type).  One weight
+// vector, two trade slots per record.
+#define LOB_ENV16_BOOKS 4
+template <bool INLINE_GENERAL>
+__global__ void __launch_bounds__(64) env_step16_kernel(const DevParams* __restrict__ Pp, const DevState* __restrict__ Sp, int step_id, int par, EnvFuse F,
+                                                        const uint32_t* __restrict__ rnd_g) {
+    const DevParams& P = *Pp;
+    const DevState& S = *Sp;
+    __shared__ TickLds tick_lds;
+    __shared__ __align__(16) uint32_t lds_row[LOB_ENV16_BOOKS][64];  // RowLev's staging rows
+    __shared__ LearnLds1 lds_learn;
+    const int grp = (int)threadIdx.x >> 4, li = (int)threadIdx.x & 15;
+    const bool lead = li == 0;
+    const int t = blockIdx.x * LOB_ENV16_BOOKS + grp;
+    const bool valid = t < S.B;
+    const int b = valid ? t : S.B - 1;
+    const int B = S.B;
+
+    // ---- round 1: everything addressed by the book id (replicated: the 16 lanes of a group ask for the same words) ----------
+    if (threadIdx.x < LOB_MAX_BANDS) {
+        const int i = threadIdx.x;
+        tick_lds.lb[i] = P.band_lb[i]; tick_lds.tick[i] = P.band_tick[i]; tick_lds.cum[i] = P.band_cum[i]; tick_lds.pp[i] = P.band_pp[i]; tick_lds.pt[i] = P.band_pt[i];
+    }
+    if (threadIdx.x == 0) tick_lds.n = P.n_bands;
+    EnvCtx c(P, S, b, &tick_lds);
+    LHdr* hp = S.hdr + b;
+    const LHdr h0 = *hp;
+    const int k0 = S.k[b], rc0 = S.rec_cur[b];
+    const int mslot = S.mk_slot[b];
+    const bool dirty = S.hl_dirty[0] == F.sid_prev;
+    // the hit list, lane-parallel: the count for everybody, entries li, 16 + li, 32 + li for this lane
+    const u64* hl_p = S.hl_rec + (size_t)b * LOB_HL_REC;
+    const u64 hl_n = hl_p[0];
+    u64 ent[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) ent[j] = 16 * j + li < LOB_HL_MAX ? hl_p[1 + 16 * j + li] : 0ull;
+    EnvR er;
+    env_load(S, b, er);
+    RMReg wu, wd;
+    rm_load(S.pnl_ups, b, wu);
+    rm_load(S.pnl_downs, b, wd);
+    const int m_n_track = S.meta[b].n_track, m_complete = S.meta[b].complete;
+    EnvR e = er;   // (in registers: this kernel holds no 56-word rows -- and 16 lanes writing one LDS word serialise)
+    __syncthreads();
+
+    // ---- who steps, and from which list ---------------------------------------------------------------------------------------
+    const int cur_slot = h0.slot_cur ^ 1;  // swap(state, last_state)
+    const bool alive = valid && !h0.done;
+    const bool open = is_open(P, h0.time_ms);
+    const int n_list = hl_n == LOB_HL_NONE ? -1 : (int)hl_n;
+    bool ok = alive && open && !dirty && !((h0.zero_mask >> (cur_slot ^ 1)) & 1) && mslot >= 0 && n_list >= 0;
+
+    // ---- round 2: everything addressed by what round 1 brought ----------------------------------------------------------------
+    const int ms = mslot >= 0 ? mslot : 0;
+    const MemoRec rec = *reinterpret_cast<const MemoRec*>(S.mk_rec + ((size_t)S.mk_slots + ms) * LOB_MK_REC);  // [1]: after the last update
+    const int tiles_ok = S.mk_tiles_ok[ms];
+    const uint32_t mk_bits = S.mk_marked[ms];
+    f64 wv[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) wv[j] = (ok && 16 * j + li < n_list) ? S.theta[(uint32_t)ent[j]] : 0.0;
+    const int kk = k0 > 0 ? k0 : 1;
+    Track tprev;
+    {
+        const uint4* q = reinterpret_cast<const uint4*>(&c.track(kk - 1));
+        const uint4 w4 = q[4], w5 = q[5];
+        uint4* d = reinterpret_cast<uint4*>(&tprev);
+#pragma unroll
+        for (int i = 0; i < 8; i++) d[i] = make_uint4(0, 0, 0, 0);
+        d[4] = w4; d[5] = w5;
+    }
+    Track tcur = track_load(&c.track(k0));
+    RowLev cur, first;
+    cur.stage = first.stage = lds_row[grp];
+    cur.li = first.li = li;
+    cur.pending = first.pending = false;
+    row_full_load(c, rc0, cur);
+    {
+        const int last_row = S.n_events - 1;
+        row_full_load(c, rc0 + 1 < last_row ? rc0 + 1 : last_row, first);
+    }
+    rm_prep(S.pnl_ups, B, b, wu);
+    rm_prep(S.pnl_downs, B, b, wd);
+
+    // ---- the action ------------------------------------------------------------------------------------------------------------
+    int action = 0;
+    bool go = false;
+    if (valid) {
+        if (h0.done) {
+            if (lead) hp->stepped = 0;
+        } else if (!open) {  // environment.isTerminal()
+            if (lead) { hp->slot_cur = cur_slot; hp->done = 1; hp->stepped = 0; S.done[b] = 1; }
+        } else {
+            ok = ok && rec.ver == F.ver;
+            if (!ok) {
+                if (!INLINE_GENERAL && lead) {
+                    const int pos = atomicAdd(&S.slow_n[F.lpar * 2 + 0], 1);
+                    S.slow_list[pos] = b;
+                }
+            } else {
+                f64 q[LOB_N_ACTIONS];
+#pragma unroll
+                for (int a = 0; a < LOB_N_ACTIONS; a++) q[a] = rec.s0[a];
+                const f64 w1 = P.w1, w2 = P.w2;
+                // the ordered reduction: addition j is entry j's, wherever it was fetched (n_list is the group's: its lanes loop together)
+                for (int j = 0; j < n_list; j++) {
+                    const int jj = j >> 4;
+                    const u64 en = __shfl(jj == 0 ? ent[0] : jj == 1 ? ent[1] : ent[2], j & 15, 16);
+                    const f64 v = __shfl(jj == 0 ? wv[0] : jj == 1 ? wv[1] : wv[2], j & 15, 16);
+                    if (v != 0.0) {  // (+0.0 added to a sum that is never -0.0)
+                        const int a_ = (int)(en >> 32) & 15;
+                        const f64 x_ = ((en >> 36) & 1ull ? w2 : w1) * v;
+#pragma unroll
+                        for (int a = 0; a < LOB_N_ACTIONS; a++) q[a] = a_ == a ? q[a] + x_ : q[a];
+                    }
+                }
+                if (li < LOB_N_ACTIONS) S.qs_last[(size_t)b * LOB_N_ACTIONS + li] = sel9(q, li);
+                Rng g{P.seed, P.book_id_offset + (u64)b, h0.rng_ctr};
+                action = policy_sample(P, q, false, g);
+                if (lead) {
+                    hp->slot_cur = cur_slot;
+                    hp->action = action;
+                    hp->stepped = 1;
+                    hp->rng_ctr = g.ctr;
+                    const uint32_t marked = tiles_ok ? mk_bits : 0x1ffu;
+                    if (!((marked >> action) & 1u)) {
+                        const int pos = atomicAdd(&S.mk_markcount[0], 1);
+                        if (pos < S.mk_slots) S.mk_marklist[pos] = mslot * 16 + action;
+                        else mark_generation(P, S, mslot, action);
+                        atomicOr(&S.mk_marked[mslot], 1u << action);
+                    }
+                }
+                go = true;
+            }
+        }
+    }
+    {   // (lob_get_path_stats [1]: books acted on from their hit list)
+        const u64 act = __ballot(go && lead);
+        if (threadIdx.x == 0 && act) cnt_add(S, 5, (unsigned long long)__builtin_popcountll(act));
+    }
+    if (INLINE_GENERAL) {
+        // the books the replay could not serve: Agent::action in full, one book at a time, the whole wave on it (act_book)
+        u64 todo = __ballot(lead && valid && alive && open && !ok);
+        if (todo) {
+            if (threadIdx.x == 0) cnt_add(S, 2, (u64)__builtin_popcountll(todo));  // (lob_get_path_stats [6])
+            const uint4* src = reinterpret_cast<const uint4*>(rnd_g);
+            uint4* dst = reinterpret_cast<uint4*>(lds_learn.rnd);
+            for (int i = threadIdx.x; i < 512; i += 64) dst[i] = src[i];
+            if (threadIdx.x < 27) lds_learn.act_terms[threadIdx.x] = rnd_g[2048 + threadIdx.x];
+            wave_lds_fence();
+            while (todo) {
+                const int src_lane = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const int b_src = __builtin_amdgcn_readlane(b, src_lane);
+                int act = -1;
+                act_book<LOB_ALGO_SARSA, LearnLds1>(P, S, lds_learn, 0, (int)threadIdx.x, b_src, 0, par, &act);
+                if (grp == (src_lane >> 4) && act >= 0) { action = act; go = true; }
+            }
+        }
+    }
+
+    // ---- performAction (replicated in the group; the row look-ups are the group's) ----------------------------------------------
+    i64 d_steps = 0, d_events = 0;
+    if (go) {
+        c.pre_prev = &tprev;
+        c.pre_n_track = m_n_track;
+        c.pre_complete = m_complete;
+        const i64 ev0 = e.events;
+        StepAgg g;
+        step_prologue(c, e, action, g, cur);
+        const int st = event_loop_fast(c, e, g, tcur, first);
+        bool claim = false;
+        u64 claim_k = 0;
+        int claim_stamp = 0, claim_q0 = 0, claim_q1 = 0, claim_q2 = 0;
+        d_events = e.events - ev0;
+        if (st != 2) {
+            step_epilogue_pre(c, e, g, wu, wd);
+            const int cs = cur_slot;
+            f32* v = S.vars + ((size_t)b * 3 + cs) * 16;
+            f32* vf = S.vars + ((size_t)b * 3 + 2) * 16;
+            int qg[3] = {0, 0, 0};
+            for (int i = 0; i < P.V; i++) {
+                const f32 x = (f32)get_variable(c, e, P.vars[i], tcur);  // tcur = the entry of the last completed event (state_track)
+                if (lead) { v[i] = x; vf[i] = x; }
+                if (i < 3) qg[i] = tile_quant(x);
+            }
+            if (P.memo) {
+                const uint32_t s0 = (uint32_t)mk_hash3(qg[0], qg[1], qg[2]) & (uint32_t)(S.mk_slots - 1);
+                claim_k = S.mk_hash[s0];
+                claim_stamp = S.mk_stamp[s0];
+                claim_q0 = qg[0]; claim_q1 = qg[1]; claim_q2 = qg[2];
+                claim = true;
+            }
+            const f64 rw = get_reward(c, e, &tcur.spread_mean);
+            if (lead) {
+                hp->zero_mask = h0.zero_mask & ~(1 << cs);
+                S.verdict[(size_t)b * LOB_VD_STRIDE + 67] = 0;  // a State changed: saved verdicts are void until learn saves new ones
+                hp->reward = rw;
+                hp->stepped = 1;
+            }
+            d_steps = 1;
+        } else {
+            if (lead) hp->stepped = 0;
+        }
+        if (lead) {
+            hp->done = e.done;
+            hp->time_ms = e.time_ms;
+            env_store(S, b, e);
+            if (claim) {
+                S.mk_slot_last[b] = mslot;
+                S.mk_slot[b] = mk_claim(S, claim_q0, claim_q1, claim_q2, step_id, par, claim_k, claim_stamp);
+            }
+        }
+    }
+    // one atomic per wave for the counters (every book counted once: by its first lane)
+    if (!lead) { d_steps = 0; d_events = 0; }
+    for (int off = 32; off > 0; off >>= 1) {
+        d_steps += __shfl_down(d_steps, off);
+        d_events += __shfl_down(d_events, off);
+    }
+    if ((threadIdx.x & 63) == 0 && (d_steps | d_events)) {
+        cnt_add(S, 0, (u64)d_steps);
+        cnt_add(S, 1, (u64)d_events);
+        cnt_add(S, 3, (u64)d_steps);  // every stepped book gets one TD update
     }
 }
 

@@ -468,7 +468,7 @@ __device__ inline bool act_light_book(const DevParams& P, const DevState& S, int
         atomicOr(&S.mk_marked[mslot], 1u << action);
     }
     const u64 act = __ballot(1);
-    if ((int)(threadIdx.x & 63) == __builtin_ctzll(act)) atomicAdd((unsigned long long*)&S.counters[5], (unsigned long long)__builtin_popcountll(act));
+    if ((int)(threadIdx.x & 63) == __builtin_ctzll(act)) cnt_add(S, 5, (unsigned long long)__builtin_popcountll(act));
     return true;
 }
 #if LOB_IN_MAIN
@@ -597,7 +597,7 @@ __global__ void __launch_bounds__(LOB_TRACE_BLOCK) trace_rest_kernel(LOB_PS_ARGS
     if (hint && blockIdx.x == 0 && threadIdx.x == 0)
         __hip_atomic_store(hint, ((u64)hint_tag << 32) | (u64)(uint32_t)n_learn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (n_learn == 0 && n_tr == 0 && n_acc == 0) return;  // the usual case
-    if (n_learn > 0 && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd((u64*)&S.counters[4], (u64)n_learn);  // (lob_get_path_stats [7])
+    if (n_learn > 0 && blockIdx.x == 0 && threadIdx.x == 0) cnt_add(S, 4, (u64)n_learn);  // (lob_get_path_stats [7])
     const int w = threadIdx.x >> 6;
     const int wave = blockIdx.x * LOB_TRACE_WAVES + w, n_waves = gridDim.x * LOB_TRACE_WAVES;
     const int xcd = acc_copy(S, wave);
@@ -862,7 +862,7 @@ __global__ void __launch_bounds__(LOB_TS_BLOCK, 5) trace_lane_kernel(LOB_PS_ARGS
                 if (k == 0 && stepped) {  // (nothing of the book has been touched)
                     if (QL) S.tr_list2[atomicAdd(&S.tr_list2_n[lpar], 1)] = ent;
                     else S.tr_list[atomicAdd(&S.tr_list_n[lpar], 1)] = b;
-                    atomicAdd((unsigned long long*)&S.counters[6], 1ull);
+                    cnt_add(S, 6, 1ull);
                     // (the wave-per-book kernel does its traces: all its generations are accumulate_kernel's -- or, acc_fuse = 2,
                     // trace_rest_kernel's own wave adds them up right behind the trace step)
                     if (fuse_acc && acc_fuse != 2) S.acc_list[atomicAdd(&S.acc_list_n[lpar], 1)] = b;

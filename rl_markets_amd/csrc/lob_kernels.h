@@ -206,7 +206,7 @@ __global__ void __launch_bounds__(RB) reset_kernel(const DevParams* __restrict__
     S.mk_slot[b] = -1;  // the memo table is emptied at every reset: the first act of the episode takes the general path
     S.mk_slot_last[b] = -1;
     env_store(S, b, e);
-    atomicAdd((u64*)&S.counters[1], (u64)(e.events - ev0));  // warm-up events count as consumed
+    cnt_add(S, 1, (u64)(e.events - ev0));  // warm-up events count as consumed
 }
 
 // reset_kernel<64, TM> with the pre-pass on two waves per 64 books (lob_env.h prepass_run2): wave 0 of the block is the books'
@@ -302,7 +302,7 @@ __global__ void __launch_bounds__(128, 2) reset2_kernel(const DevParams* __restr
     S.mk_slot[b] = -1;  // the memo table is emptied at every reset: the first act of the episode takes the general path
     S.mk_slot_last[b] = -1;
     env_store(S, b, e);
-    atomicAdd((u64*)&S.counters[1], (u64)(e.events - ev0));  // warm-up events count as consumed
+    cnt_add(S, 1, (u64)(e.events - ev0));  // warm-up events count as consumed
 }
 
 // End of an episode: the pre-pass has walked the window arithmetic to the END of
@@ -525,9 +525,9 @@ __global__ void __launch_bounds__(LOB_ENV_BLOCK) env_kernel(const DevParams* __r
         d_events += __shfl_down(d_events, off);
     }
     if ((threadIdx.x & 63) == 0 && (d_steps | d_events)) {
-        atomicAdd((u64*)&S.counters[0], (u64)d_steps);
-        atomicAdd((u64*)&S.counters[1], (u64)d_events);
-        if (count_updates) atomicAdd((u64*)&S.counters[3], (u64)d_steps);  // every stepped book gets one TD update
+        cnt_add(S, 0, (u64)d_steps);
+        cnt_add(S, 1, (u64)d_events);
+        if (count_updates) cnt_add(S, 3, (u64)d_steps);  // every stepped book gets one TD update
     }
 }
 
@@ -660,9 +660,9 @@ __global__ void __launch_bounds__(LOB_ENVC_BLOCK) env_compact_kernel(const DevPa
         d_events += __shfl_down(d_events, off);
     }
     if (lane == 0 && (d_steps | d_events)) {
-        atomicAdd((u64*)&S.counters[0], (u64)d_steps);
-        atomicAdd((u64*)&S.counters[1], (u64)d_events);
-        if (count_updates) atomicAdd((u64*)&S.counters[3], (u64)d_steps);  // every stepped book gets one TD update
+        cnt_add(S, 0, (u64)d_steps);
+        cnt_add(S, 1, (u64)d_events);
+        if (count_updates) cnt_add(S, 3, (u64)d_steps);  // every stepped book gets one TD update
     }
 }
 #endif
@@ -1302,7 +1302,7 @@ __global__ void __launch_bounds__(LOB_BLOCK) learn_q_rest_kernel(LOB_PS_ARGS, co
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     learn_stage_table(rnd_g, L);
     const int n = *list_n;
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd((u64*)&S.counters[4], (u64)n);  // (lob_get_path_stats [7])
+    if (blockIdx.x == 0 && threadIdx.x == 0) cnt_add(S, 4, (u64)n);  // (lob_get_path_stats [7])
 #pragma unroll 1
     for (int i = __builtin_amdgcn_readfirstlane(blockIdx.x * LOB_WAVES_PER_BLOCK + w); i < n; i += gridDim.x * LOB_WAVES_PER_BLOCK)
         learn_q_book<ALGO>(P, S, L, w, lane, __builtin_amdgcn_readfirstlane(list[i]));
@@ -1658,7 +1658,7 @@ __device__ inline void apply_deferred_generations(const DevParams& P, const DevS
     if (!S.dir_list) return;
     if (wave == 0 && lane == 0) S.dir_list_n[par ^ 1] = 0;
     const int n = S.dir_list_n[par];
-    if (n > 0 && wave == 0 && lane == 0) atomicAdd((u64*)&S.counters[8], (u64)n);  // (lob_debug_deferred)
+    if (n > 0 && wave == 0 && lane == 0) cnt_add(S, 8, (u64)n);  // (lob_debug_deferred)
     const int G = P.trace_gens;
     for (int i = wave; i < n; i += n_waves) {
         const int ent = S.dir_list[i];
@@ -2440,6 +2440,21 @@ __global__ void td_stats_fold_kernel(DevState S, int n_blocks) {
     S.ml_agg[0] = agg;
     S.ml_cnt[0] = cnt;
 }
+#endif
+
+// The striped device counters (lob_state.h cnt_add) added up for the host: out[i] = sum over the stripes of counter i.
+#if LOB_IN_MAIN
+__global__ void __launch_bounds__(LOB_CNT_STRIPES) counters_fold_kernel(const i64* __restrict__ cnt, i64* out) {
+    __shared__ i64 part[LOB_CNT_STRIPES][16];
+    for (int i = 0; i < 16; i++) part[threadIdx.x][i] = cnt[(size_t)threadIdx.x * LOB_CNT_STRIDE + i];
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        i64 acc = 0;
+        for (int st = 0; st < LOB_CNT_STRIPES; st++) acc += part[st][threadIdx.x];
+        out[threadIdx.x] = acc;
+    }
+}
+__global__ void counters_zero_kernel(i64* cnt, int idx) { cnt[(size_t)threadIdx.x * LOB_CNT_STRIDE + idx] = 0; }
 #endif
 
 // The two words of the state a learner step changes, into its device-resident copy (lob_engine.hip sync_state) -- for the flows

@@ -26,8 +26,9 @@ void lobk_env(hipStream_t st, int lanes, bool t2, const DevParams* Pd, const Dev
 // env_kernel<64, TM, mode>: 1 = action selection fused (books without a list go on the work list), 2 = the work list's books
 void lobk_env_mode(hipStream_t st, bool t2, int mode, const DevParams* Pd, const DevState& S, int nb, int sid, int par, const EnvFuse& F);
 // env_step_kernel<inline_general, dq> (two trade slots); half_waves: <false, false, 32> (experiments)
-void lobk_env_step(hipStream_t st, bool inline_general, bool dq, bool half_waves, const DevParams* Pd, const DevState& S, int nb, int sid, int par, const EnvFuse& F,
-                   const uint32_t* rnd);
+// `lanes16`: env_step16_kernel<inline_general> -- a book's levels across 16 lanes, four books per wave (small batches; one weight vector)
+void lobk_env_step(hipStream_t st, bool inline_general, bool dq, bool half_waves, bool lanes16, const DevParams* Pd, const DevState& S, int nb, int sid, int par,
+                   const EnvFuse& F, const uint32_t* rnd);
 void lobk_clear_inventory(hipStream_t st, const DevParams* Pd, const DevState& S);
 void lobk_get_state(hipStream_t st, const DevParams* Pd, const DevState& S, f32* out, f64* reward);
 void lobk_dump(hipStream_t st, const DevParams* Pd, const DevState& S, int first, int n, lob_book_dump* out);

@@ -427,7 +427,7 @@ struct DevState {
     GP<f64> ml_rows;     // [LOB_ML_ROWS]
     GP<f64> theta_sync;  // [M] (multi-GPU) or null
     GP<f64> delta;       // [M] scratch for the all-reduce or null
-    GP<i64> counters;    // [8] device counters
+    GP<i64> counters;    // [LOB_CNT_STRIPES][LOB_CNT_STRIDE] device counters, striped (cnt_add below; the host sums the stripes)
     GP<i64> prof;        // [B][LOB_PROF_N] clock64 per phase of the learner kernels (-DLOB_PROF builds only, tools/exp_prof.py), else null
     GP<i32> error_flag;  // [1] bits: reference-would-throw conditions
     const DevState* self;  // the device-resident copy of this very structure (kernels that take the state by pointer; lob_engine.hip push_state)
@@ -479,6 +479,21 @@ struct DevParams {
 // spills: learn_q_pair_kernel 145 -> 10, trace_rest_kernel 81 -> ..., NOTES.md "Round 6").
 #define LOB_PS_ARGS const DevParams* __restrict__ Pp, const DevState* __restrict__ Sp
 #define LOB_PS_REFS const DevParams& P = *Pp; const DevState& S = *Sp;
+
+// Device counters (env-steps, events, path statistics): LOB_CNT_STRIPES copies, LOB_CNT_STRIDE words apart; a block adds to the copy
+// blockIdx.x selects and the host sums the copies when it reads.  Round 6: the three end-of-wave atomics of env_step_kernel onto ONE
+// cache line -- 1 024 waves finishing together, ~4.5 ns per atomic at the memory side -- held the kernel's completion back by 18 us of
+// its 103 (0.103 -> 0.085 ms with the counters compiled out: what five rounds of phase clocks could not see, because no wave waits
+// for a fire-and-forget atomic; the kernel's end does).
+#define LOB_CNT_STRIPES 256
+#define LOB_CNT_STRIDE 64   /* i64 per stripe: 512 bytes, 16 used */
+#if defined(__HIP__)
+__device__ __forceinline__ void cnt_add(const DevState& S, int idx, unsigned long long v) {
+    atomicAdd(reinterpret_cast<unsigned long long*>(+S.counters) + (size_t)(blockIdx.x & (LOB_CNT_STRIPES - 1)) * LOB_CNT_STRIDE + idx, v);
+}
+#else   // (the device headers compiled as host code by tests/host_env: one "block")
+inline void cnt_add(const DevState& S, int idx, unsigned long long v) { S.counters.p[idx] += (i64)v; }
+#endif
 
 #define LOB_ERR_BAD_ORDER_PRICE 1  /* Order ctor would throw (src/market/order.cpp:22-27) */
 #define LOB_ERR_BAD_LEVEL 2        /* ApplyChanges would throw (src/market/book.cpp:74-77) */

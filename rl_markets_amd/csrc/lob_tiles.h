@@ -108,7 +108,7 @@ __device__ inline int tile_register(const DevState& S, const int4& id, int s, in
                 const uint32_t was = atomicOr(word, bit);
                 if (!(was & bit)) {
                     const int pos = atomicAdd(&S.amb_new_n[par], 1);
-                    atomicAdd((unsigned long long*)&S.counters[7], 1ull);
+                    cnt_add(S, 7, 1ull);
                     if (pos < S.amb_cap) S.amb_new[(size_t)par * S.amb_cap + pos] = tile;
                     else S.amb_flag[0] = 1;
                 }

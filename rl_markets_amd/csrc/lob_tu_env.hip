@@ -47,9 +47,15 @@ void lobk_env_mode(hipStream_t st, bool t2, int mode, const DevParams* Pd, const
     }
 }
 
-void lobk_env_step(hipStream_t st, bool inline_general, bool dq, bool half_waves, const DevParams* Pd, const DevState& S, int nb, int sid, int par, const EnvFuse& F,
-                   const uint32_t* rnd) {
+void lobk_env_step(hipStream_t st, bool inline_general, bool dq, bool half_waves, bool lanes16, const DevParams* Pd, const DevState& S, int nb, int sid, int par,
+                   const EnvFuse& F, const uint32_t* rnd) {
     const dim3 grid((nb + 63) / 64), block(64);
+    if (lanes16 && !dq) {
+        const dim3 g16((nb + LOB_ENV16_BOOKS - 1) / LOB_ENV16_BOOKS);
+        if (inline_general) hipLaunchKernelGGL(env_step16_kernel<true>, g16, block, 0, st, Pd, S.self, sid, par, F, rnd);
+        else hipLaunchKernelGGL(env_step16_kernel<false>, g16, block, 0, st, Pd, S.self, sid, par, F, rnd);
+        return;
+    }
 #define LOB_S_ARG S.self   // (the state's device-resident copy: lob_engine.hip sync_state)
 #ifdef LOB_EXPERIMENTS
     if (half_waves && !dq && !inline_general) {  // LOB_ENV_STEP_LANES=32: two half-full waves per SIMD (measured slower, NOTES.md)

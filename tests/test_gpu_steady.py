@@ -506,6 +506,9 @@ VARIANTS = {
     "dq_pair": {"LOB_Q_LANES": "1", "LOB_FUSE_ACT": "1"},                       # ... / learn_q_pair_kernel<LOB_ALGO_DOUBLE_Q> (two lanes per book: the default)
     "lane": {"LOB_Q_LANES": "1", "LOB_Q_PAIR": "0", "LOB_FUSE_ACT": "1"},
     "pair": {"LOB_Q_LANES": "1", "LOB_Q_PAIR": "1", "LOB_FUSE_ACT": "1"},
+    # (batches of up to 4 096 books take env_step16_kernel -- a book's levels across 16 lanes -- by themselves, so every other variant
+    # of this sweep runs it; here the lane-per-book env_step_kernel that the large batches use)
+    "pair_env64": {"LOB_Q_LANES": "1", "LOB_Q_PAIR": "1", "LOB_FUSE_ACT": "1", "LOB_ENV16_MAX": "0"},
     "pair_nofuse": {"LOB_Q_LANES": "1", "LOB_Q_PAIR": "1", "LOB_NO_FUSE": "1", "LOB_FUSE_ACT": "1"},
     # ("pair": what the lane trace kernel hands on and what the fused accumulation left are served by ONE launch, trace_rest_kernel;
     # here by trace_fast_kernel<., 2> + accumulate_kernel over its list, the two launches it replaced)
