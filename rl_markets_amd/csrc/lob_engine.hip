@@ -136,6 +136,21 @@ struct lob_engine {
     i64* spx_total = nullptr;
     f64* spx_buf = nullptr;
     int64_t spx_cap = 0, spx_count = 0;
+    // The exchange without a host synchronisation: the packed vector's length is a host argument of the
+    // collective, and the union's true size is only known on the device.  So the ranks exchange a FIXED count -- spx_fixed, the
+    // same on every rank because it is a function of the union sizes of the exchanges before, which are the same on every rank --
+    // with the tail behind the union zero-filled, and every exchange leaves its union's size in pinned host memory behind an event
+    // that the NEXT exchange (64 steps later: long past) reads.  The union only grows, ever more slowly (the written set saturates):
+    // an exchange goes without a synchronisation when the last size + twice the last increase still fits spx_fixed; the first two
+    // exchanges, and any whose prediction does not fit, take the exact count with a synchronisation and set spx_fixed to at least
+    // twice it.  A union that outgrows the count anyway (its growth more than doubled from one interval to the next) loses nothing:
+    // the entries beyond it keep theta - theta_sync and travel with the next exchange (counted: lob_debug_exchange; the parity
+    // tests of the exchange assert that it never happens in them).
+    i64* spx_total_host = nullptr;   // pinned
+    hipEvent_t spx_ev = nullptr;
+    int64_t spx_fixed = 1 << 18, spx_last_total = -1, spx_prev_total = -1;
+    bool spx_ev_pending = false;
+    long long spx_nosync = 0, spx_synced = 0, spx_overflows = 0;
     uint32_t* rnd_dev = nullptr;
     uint32_t* records_dev = nullptr;
     i64* phase_dev = nullptr;  // replayed stream: first record of every book's window
@@ -771,6 +786,8 @@ void lob_destroy(lob_engine* e) {
     if (e->track_dev) hipFree(e->track_dev);
     if (e->dump_dev) hipFree(e->dump_dev);
     if (e->spx_gather) hipFree(e->spx_gather);
+    if (e->spx_ev) hipEventDestroy(e->spx_ev);
+    if (e->spx_total_host) hipHostFree(e->spx_total_host);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
 }
@@ -1931,6 +1948,13 @@ int lob_delta_sparse_maps(lob_engine* e, int32_t world, uint32_t** dev_own, uint
         if (rc == LOB_OK) rc = dev_alloc(e, &e->spx_block_off, (size_t)nb);
         if (rc == LOB_OK) rc = dev_alloc(e, &e->spx_total, 1);
         if (rc != LOB_OK) return rc;
+        // (without pinned memory for the size hand-over every exchange synchronises, as before)
+        if (hipHostMalloc((void**)&e->spx_total_host, sizeof(i64), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); e->spx_total_host = nullptr; }
+        if (e->spx_total_host && hipEventCreateWithFlags(&e->spx_ev, hipEventDisableTiming) != hipSuccess) { hipHostFree(e->spx_total_host); e->spx_total_host = nullptr; }
+        // (the first fixed count: a 64th of the table, 4 096 .. 262 144 entries; LOB_SPX_COUNT: the tests' small one)
+        e->spx_fixed = std::max<int64_t>(4096, std::min<int64_t>(1 << 18, e->P.M / 64));
+        if (const char* g = getenv("LOB_SPX_COUNT")) { const long long v = atoll(g); if (v >= 64) e->spx_fixed = v; }
+        e->spx_fixed = std::min<int64_t>(e->spx_fixed, e->P.M);
     }
     // every buffer of the exchange exists before its first collective starts (lob_theta_allreduce calls this once BEFORE the ranks
     // agree on the exchange's form, and a rank that failed here makes all of them fail together): a rank that failed to allocate
@@ -1957,20 +1981,45 @@ int lob_delta_sparse_pack(lob_engine* e, int32_t world, double** dev_buf, int64_
         hipLaunchKernelGGL(sparse_union_kernel, dim3(nb), dim3(LOB_SPX_BLOCK), 0, e->stream, (const uint32_t*)e->spx_gather, (int)world, (i64)W, e->spx_union, e->spx_block_cnt);
         hipLaunchKernelGGL(sparse_scan_kernel, dim3(1), dim3(1024), 0, e->stream, (const i32*)e->spx_block_cnt, nb, e->spx_block_off, e->spx_total);
     }
-    // the collective needs the element count on the host: the one synchronisation of an exchange
-    i64 total = 0;
-    HIPCHK(hipMemcpyAsync(&total, e->spx_total, sizeof total, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
-    if (total > e->spx_cap) { lob_set_error("lob_delta_sparse_pack: more union entries than weights"); return LOB_ESTATE; }  // (cannot happen: cap = M)
-    e->spx_count = total;
+    // the union's size of the exchange BEFORE this one (its copy to pinned memory has had a whole exchange interval to land)
+    if (e->spx_ev_pending) {
+        HIPCHK(hipEventSynchronize(e->spx_ev));
+        if (e->spx_total_host[0] != e->spx_last_total) { e->spx_prev_total = e->spx_last_total; e->spx_last_total = e->spx_total_host[0]; }
+        e->spx_ev_pending = false;
+        if (e->spx_last_total > e->spx_count) e->spx_overflows++;   // (that exchange left entries for this one)
+    }
+    const bool no_sync = e->spx_total_host && e->spx_last_total >= 0 && e->spx_prev_total >= 0 &&
+                         e->spx_last_total + 2 * std::max<int64_t>(e->spx_last_total - e->spx_prev_total, 0) <= e->spx_fixed;
+    i64 count_now;
+    if (no_sync) {
+        count_now = e->spx_fixed;
+        e->spx_nosync++;
+    } else {
+        // the exact count, with the one synchronisation the exchange used to need every time
+        i64 total = 0;
+        HIPCHK(hipMemcpyAsync(&total, e->spx_total, sizeof total, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        if (total > e->spx_cap) { lob_set_error("lob_delta_sparse_pack: more union entries than weights"); return LOB_ESTATE; }  // (cannot happen: cap = M)
+        while (e->spx_fixed < 2 * total && e->spx_fixed < e->spx_cap) e->spx_fixed = std::min<int64_t>(e->spx_fixed * 2, e->spx_cap);
+        if (total != e->spx_last_total) { e->spx_prev_total = e->spx_last_total; e->spx_last_total = total; }
+        count_now = total;
+        e->spx_synced++;
+    }
+    e->spx_count = count_now;
     {
         TimedLaunch t(e, "delta_begin_kernel", nullptr, true);
         hipLaunchKernelGGL(sparse_pack_kernel, dim3(nb), dim3(LOB_SPX_BLOCK), 0, e->stream, (const uint32_t*)e->spx_union, (i64)W, (const i64*)e->spx_block_off,
-                           (const f64*)e->S.theta, (const f64*)e->S.theta_sync, e->spx_buf);
+                           (const f64*)e->S.theta, (const f64*)e->S.theta_sync, e->spx_buf, (i64)count_now);
+        if (no_sync) hipLaunchKernelGGL(sparse_tail_kernel, dim3(64), dim3(256), 0, e->stream, e->spx_buf, (const i64*)e->spx_total, (i64)count_now);
+    }
+    if (e->spx_total_host) {   // this exchange's union size, for the next one
+        HIPCHK(hipMemcpyAsync(e->spx_total_host, e->spx_total, sizeof(i64), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipEventRecord(e->spx_ev, e->stream));
+        e->spx_ev_pending = true;
     }
     HIPCHK(hipGetLastError());
     *dev_buf = e->spx_buf;
-    *count = total;
+    *count = count_now;
     return LOB_OK;
 }
 int lob_delta_sparse_apply(lob_engine* e) {
@@ -1985,7 +2034,7 @@ int lob_delta_sparse_apply(lob_engine* e) {
         TimedLaunch t(e, "delta_apply_kernel", nullptr, true);
         hipLaunchKernelGGL(sparse_apply_kernel, dim3(nb), dim3(LOB_SPX_BLOCK), 0, e->stream, (const uint32_t*)e->spx_union, (i64)W, (const i64*)e->spx_block_off,
                            e->S.theta, e->S.theta_sync, (const f64*)e->spx_buf, e->S.theta_nz, e->S.nz_epoch, e->S.theta_nzx, e->S.theta_nzc, e->P.cshift,
-                           e->S.theta_nzd, e->S.nzd_terms, (i64)e->P.M);
+                           e->S.theta_nzd, e->S.nzd_terms, (i64)e->P.M, (i64)e->spx_count);
     }
     if (e->P.memo && !mid_step) launch_memo(e, e->last_par, 1);  // the current triples under the exchanged weights
     HIPCHK(hipGetLastError());
@@ -2088,6 +2137,14 @@ extern "C" int lob_debug_light(lob_engine* e, int64_t out[2]) {
     HIPCHK(hipStreamSynchronize(e->stream));
     out[0] = c[5];
     out[1] = d;
+    return LOB_OK;
+}
+
+// Diagnostics (not part of include/lob_engine.h): sparse exchanges without / with a host synchronisation, exchanges whose union outgrew
+// the fixed count (their surplus travelled one exchange later), the fixed count, the last union size known to the host.
+extern "C" int lob_debug_exchange(lob_engine* e, int64_t out[5]) {
+    if (!e || !out) return LOB_EINVAL;
+    out[0] = e->spx_nosync; out[1] = e->spx_synced; out[2] = e->spx_overflows; out[3] = e->spx_fixed; out[4] = e->spx_last_total;
     return LOB_OK;
 }
 

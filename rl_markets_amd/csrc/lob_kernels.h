@@ -2605,7 +2605,7 @@ __device__ inline i64 sparse_word_base(uint32_t u, const i64* block_off, i32* ld
 }
 #if LOB_IN_MAIN
 __global__ void __launch_bounds__(LOB_SPX_BLOCK) sparse_pack_kernel(const uint32_t* __restrict__ u_map, i64 words, const i64* __restrict__ block_off,
-                                                                    const f64* __restrict__ theta, const f64* __restrict__ sync, f64* buf) {
+                                                                    const f64* __restrict__ theta, const f64* __restrict__ sync, f64* buf, i64 cap) {
     __shared__ i32 lds[LOB_SPX_BLOCK / 64];
     const i64 w = (i64)blockIdx.x * LOB_SPX_BLOCK + threadIdx.x;
     uint32_t u = w < words ? u_map[w] : 0u;
@@ -2613,8 +2613,14 @@ __global__ void __launch_bounds__(LOB_SPX_BLOCK) sparse_pack_kernel(const uint32
     while (u) {
         const i64 f = (w << 5) + __builtin_ctz(u);
         u &= u - 1;
-        buf[p++] = theta[f] - sync[f];
+        if (p < cap) buf[p] = theta[f] - sync[f];   // (an entry beyond the exchanged count keeps its delta for the next exchange)
+        p++;
     }
+}
+// the exchanged vector has a FIXED length (agreed without asking the device): the entries behind the union's are zero
+__global__ void __launch_bounds__(256) sparse_tail_kernel(f64* buf, const i64* __restrict__ total, i64 cap) {
+    const i64 n = *total;
+    for (i64 i = n + (i64)blockIdx.x * 256 + threadIdx.x; i < cap; i += (i64)gridDim.x * 256) buf[i] = 0.0;
 }
 #endif
 // theta = theta_sync + sum(delta), theta_sync = theta for the weights of the union; the maps take the union's bits (a set bit
@@ -2622,7 +2628,7 @@ __global__ void __launch_bounds__(LOB_SPX_BLOCK) sparse_pack_kernel(const uint32
 #if LOB_IN_MAIN
 __global__ void __launch_bounds__(LOB_SPX_BLOCK) sparse_apply_kernel(const uint32_t* __restrict__ u_map, i64 words, const i64* __restrict__ block_off,
                                                                      f64* theta, f64* sync, const f64* __restrict__ buf, uint32_t* nz, i32* nz_epoch,
-                                                                     uint32_t* nzx, uint32_t* nzc, int cshift, uint32_t* nzd, const uint32_t* nzd_terms, i64 M) {
+                                                                     uint32_t* nzx, uint32_t* nzc, int cshift, uint32_t* nzd, const uint32_t* nzd_terms, i64 M, i64 cap) {
     __shared__ i32 lds[LOB_SPX_BLOCK / 64];
     const i64 w = (i64)blockIdx.x * LOB_SPX_BLOCK + threadIdx.x;
     if (w == 0) atomicAdd(nz_epoch, 1);  // verdicts saved before this exchange are stale
@@ -2633,9 +2639,12 @@ __global__ void __launch_bounds__(LOB_SPX_BLOCK) sparse_apply_kernel(const uint3
     while (u) {
         const i64 f = (w << 5) + __builtin_ctz(u);
         u &= u - 1;
-        const f64 t = sync[f] + buf[p++];
-        theta[f] = t;
-        sync[f] = t;
+        if (p < cap) {   // (beyond the exchanged count: theta and theta_sync stay as they are, the delta travels next time)
+            const f64 t = sync[f] + buf[p];
+            theta[f] = t;
+            sync[f] = t;
+        }
+        p++;
         nzm |= LOB_NZ_BIT(f);
     }
     if (u0) {
