@@ -291,6 +291,7 @@ def main():
         exchange = comm.exchange_stats()                  # HIP events on the engine stream around the exchange's phases (this rank)
         exchange["pinned_host_cpus"] = pinned_cpus
         exchange["ms_per_exchange"] = round(exchange["pack_ms"] + exchange["collectives_ms"] + exchange["apply_ms"], 4)
+        exchange["sparse_counts"] = eng.exchange_debug()   # (whole run: how many exchanges went without a host synchronisation)
         elapsed = comm.reduce([elapsed], MAX)[0]          # the slowest rank's clock
         steps_done, events_done = (int(v) for v in comm.reduce([steps_done, events_done], SUM))
 

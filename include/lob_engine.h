@@ -296,6 +296,14 @@ void lob_destroy(lob_engine* e);
  * step, and an agent step consumes at least one event). */
 int lob_load_events(lob_engine* e, const uint32_t* host_records, int32_t n_events);
 int lob_gen_events_device(lob_engine* e, const lob_gen_params* g);
+/* The NEXT episode's per-book streams, handed over WHILE the current episode runs -- the reference loads a fresh day before every
+ * episode (src/main.cpp:53-55: rs.sample() + env.LoadData per episode and thread): validation and the host-to-HBM copy run on a
+ * host thread and a HIP stream of their own into a second record buffer (another n_books x n_events records of HBM) and the call
+ * returns at once; the lob_reset that follows waits for the hand-over if it has to and makes the staged stream the current one.
+ * `host_records` must stay valid until that lob_reset (or lob_stage_wait) returns; n_events must equal the loaded stream's.
+ * lob_stage_wait: block until the hand-over is complete and return its status (LOB_EDATA etc. as lob_load_events would). */
+int lob_stage_events(lob_engine* e, const uint32_t* host_records, int32_t n_events);
+int lob_stage_wait(lob_engine* e);
 /* One recorded stream replayed by every book (BASELINE config 5: a converted LOBSTER day):
  * `host_records` holds n_total records of ONE book; book b plays the n_events records
  * starting at record phase[b] (0 <= phase[b], phase[b] + n_events <= n_total), i.e. it

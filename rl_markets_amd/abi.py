@@ -187,6 +187,8 @@ def load():
         "lob_delta_begin": (C.c_int, [vp, P(vp), P(C.c_int64)]),
         "lob_delta_begin_async": (C.c_int, [vp, P(vp), P(C.c_int64)]),
         "lob_delta_apply": (C.c_int, [vp]),
+        "lob_stage_events": (C.c_int, [vp, vp, C.c_int32]),
+        "lob_stage_wait": (C.c_int, [vp]),
         "lob_delta_sparse_supported": (C.c_int, [vp]),
         "lob_delta_sparse_maps": (C.c_int, [vp, C.c_int32, P(vp), P(vp), P(C.c_int64)]),
         "lob_delta_sparse_pack": (C.c_int, [vp, C.c_int32, P(vp), P(C.c_int64)]),

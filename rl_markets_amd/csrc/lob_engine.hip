@@ -153,6 +153,15 @@ struct lob_engine {
     long long spx_nosync = 0, spx_synced = 0, spx_overflows = 0;
     uint32_t* rnd_dev = nullptr;
     uint32_t* records_dev = nullptr;
+    // The NEXT episode's streams, handed over while the current episode runs (lob_stage_events): a second record buffer filled by
+    // a host thread through a stream of its own -- validation, pinned staging, DMA, repack, none of it on the engine's stream --
+    // and adopted by the lob_reset that follows.  The reference loads a fresh day before every episode (src/main.cpp:53-55).
+    uint32_t* records_next = nullptr;
+    hipStream_t stream_up = nullptr;
+    std::thread stage_thread;
+    bool stage_active = false;      // a hand-over has been started and not adopted / waited for yet
+    int stage_rc = LOB_OK;
+    std::string stage_err;
     i64* phase_dev = nullptr;  // replayed stream: first record of every book's window
     Track* track_dev = nullptr;
     i32* actions_dev = nullptr;
@@ -766,6 +775,9 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
 void lob_destroy(lob_engine* e) {
     if (!e) return;
     hipSetDevice(e->device);
+    if (e->stage_thread.joinable()) e->stage_thread.join();
+    if (e->stream_up) { hipStreamSynchronize(e->stream_up); hipStreamDestroy(e->stream_up); }
+    if (e->records_next) hipFree(e->records_next);
     if (e->stream2) hipStreamSynchronize(e->stream2);
     if (e->stream) hipStreamSynchronize(e->stream);
     drain_timers(e);
@@ -840,11 +852,14 @@ static int finalize_episode(lob_engine* e) {
     return LOB_OK;
 }
 
+static int stage_join(lob_engine* e);
 // n_rows: records to allocate (B * n_events for per-book streams, the stream length for a replayed one)
 static int set_records(lob_engine* e, int32_t n_events, size_t n_rows) {
     // (the TickStatistics counters of a book are 32-bit like the reference's ints, lob_state.h tick_ab / tick_pos / tick_both: one count
     // per agent step, at most one agent step per event, n_events < 2^31 -- a recorded day of millions of rows is fine)
     { int rc = finalize_episode(e); if (rc) return rc; }  // needs the old stream
+    if (e->stage_active) { (void)stage_join(e); e->stage_active = false; }   // (a staged stream is void once another one is loaded)
+    if (e->records_next) { hipFree(e->records_next); e->records_next = nullptr; }
     // the old stream is gone from here on, whatever happens below: no kernel may see a freed pointer
     e->have_events = false;
     e->was_reset = false;
@@ -936,7 +951,9 @@ struct CopyPool {
 // pieces, not another whole stream.  Without pinned memory (a locked-memory limit; LOB_UPLOAD_PINNED=0 forces it, for the tests)
 // the same pieces go from the caller's pageable memory directly: slower, and still two pieces of device memory, never a second
 // whole stream.
-static int upload_records(lob_engine* e, const uint32_t* host_records, size_t n_records) {
+static int upload_records(lob_engine* e, const uint32_t* host_records, size_t n_records, hipStream_t st = nullptr, uint32_t* dst = nullptr) {
+    if (!st) st = e->stream;
+    if (!dst) dst = e->records_dev;
     const size_t rec_bytes = (size_t)e->P.W * 4;
     const size_t bytes = n_records * rec_bytes;
     size_t piece_recs = std::max<size_t>(1, ((size_t)64 << 20) / rec_bytes);
@@ -944,12 +961,12 @@ static int upload_records(lob_engine* e, const uint32_t* host_records, size_t n_
     if (n_records <= 2 * piece_recs) {
         uint32_t* tmp = nullptr;
         if (hipMalloc((void**)&tmp, bytes) != hipSuccess) { lob_set_error("hipMalloc(upload buffer) failed"); return LOB_ENOMEM; }
-        hipError_t err = hipMemcpyAsync(tmp, host_records, bytes, hipMemcpyHostToDevice, e->stream);
+        hipError_t err = hipMemcpyAsync(tmp, host_records, bytes, hipMemcpyHostToDevice, st);
         if (err == hipSuccess) {
-            lobk_repack(e->stream, (const uint32_t*)tmp, e->P.D, e->P.T, n_records, e->records_dev);
+            lobk_repack(st, (const uint32_t*)tmp, e->P.D, e->P.T, n_records, dst);
             err = hipGetLastError();
         }
-        if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+        if (err == hipSuccess) err = hipStreamSynchronize(st);
         hipFree(tmp);
         if (err != hipSuccess) { lob_set_error(std::string("record upload: ") + hipGetErrorString(err)); return LOB_EHIP; }
         return LOB_OK;
@@ -994,21 +1011,21 @@ static int upload_records(lob_engine* e, const uint32_t* host_records, size_t n_
             const char* src = reinterpret_cast<const char*>(host_records) + r0 * rec_bytes;
             if (use_pinned) {
                 pool.copy(reinterpret_cast<char*>(pinned[i]), src, nb);
-                err = hipMemcpyAsync(tmp[i], pinned[i], nb, hipMemcpyHostToDevice, e->stream);
+                err = hipMemcpyAsync(tmp[i], pinned[i], nb, hipMemcpyHostToDevice, st);
             } else {
-                err = hipMemcpyAsync(tmp[i], src, nb, hipMemcpyHostToDevice, e->stream);   // (pageable: the runtime stages it, synchronously)
+                err = hipMemcpyAsync(tmp[i], src, nb, hipMemcpyHostToDevice, st);   // (pageable: the runtime stages it, synchronously)
             }
             if (err == hipSuccess) {
-                lobk_repack(e->stream, (const uint32_t*)tmp[i], e->P.D, e->P.T, nr, e->records_dev + r0 * (size_t)e->P.Wd);
+                lobk_repack(st, (const uint32_t*)tmp[i], e->P.D, e->P.T, nr, dst + r0 * (size_t)e->P.Wd);
                 err = hipGetLastError();
             }
-            if (err == hipSuccess) err = hipEventRecord(done[i], e->stream);
+            if (err == hipSuccess) err = hipEventRecord(done[i], st);
         }
     } catch (const std::exception& ex) {   // (nothing may cross the C ABI)
         lob_set_error(std::string("record upload: ") + ex.what());
         rc = LOB_ENOMEM;
     }
-    const hipError_t err2 = hipStreamSynchronize(e->stream);
+    const hipError_t err2 = hipStreamSynchronize(st);
     if (err == hipSuccess) err = err2;
     release();
     if (rc != LOB_OK) return rc;
@@ -1027,6 +1044,59 @@ int lob_load_events(lob_engine* e, const uint32_t* host_records, int32_t n_event
     rc = upload_records(e, host_records, (size_t)e->B * n_events);
     e->have_events = rc == LOB_OK;
     return rc;
+}
+
+static int stage_join(lob_engine* e) {
+    if (e->stage_thread.joinable()) e->stage_thread.join();
+    if (e->stage_rc != LOB_OK) lob_set_error(e->stage_err);
+    return e->stage_rc;
+}
+int lob_stage_events(lob_engine* e, const uint32_t* host_records, int32_t n_events) {
+    if (!e || !host_records) { lob_set_error("lob_stage_events: bad argument"); return LOB_EINVAL; }
+    if (!e->have_events || e->S.rec_phase || n_events != e->S.n_events) {
+        lob_set_error("lob_stage_events: needs a loaded per-book stream of the same length (lob_load_events first)");
+        return LOB_ESTATE;
+    }
+    if (e->stage_active) { lob_set_error("lob_stage_events: the stream staged before has not been adopted (lob_reset) or waited for"); return LOB_ESTATE; }
+    HIPCHK(hipSetDevice(e->device));
+    const size_t n_rows = (size_t)e->B * n_events;
+    if (!e->records_next) {
+        if (hipMalloc((void**)&e->records_next, n_rows * e->P.Wd * 4 + 256) != hipSuccess) { e->records_next = nullptr; lob_set_error("hipMalloc(second record buffer) failed"); return LOB_ENOMEM; }
+    }
+    if (!e->stream_up) HIPCHK(hipStreamCreateWithFlags(&e->stream_up, hipStreamNonBlocking));
+    e->stage_rc = LOB_OK;
+    e->stage_err.clear();
+    e->stage_active = true;
+    try {
+        e->stage_thread = std::thread([e, host_records, n_events, n_rows] {
+            int rc = hipSetDevice(e->device) == hipSuccess ? LOB_OK : LOB_EHIP;
+            if (rc == LOB_OK) rc = lob_validate_stream(host_records, e->P.D, e->P.T, e->B, n_events);
+            if (rc == LOB_OK) rc = upload_records(e, host_records, n_rows, e->stream_up, e->records_next);
+            e->stage_rc = rc;
+            if (rc != LOB_OK) e->stage_err = lob_last_error();   // (the error text is the failing thread's: handed to whoever waits)
+        });
+    } catch (const std::system_error&) {   // no thread to be had: the hand-over happens here and now
+        int rc = lob_validate_stream(host_records, e->P.D, e->P.T, e->B, n_events);
+        if (rc == LOB_OK) rc = upload_records(e, host_records, n_rows, e->stream_up, e->records_next);
+        e->stage_rc = rc;
+        if (rc != LOB_OK) e->stage_err = lob_last_error();
+    }
+    return LOB_OK;
+}
+int lob_stage_wait(lob_engine* e) {
+    if (!e) return LOB_EINVAL;
+    if (!e->stage_active) { lob_set_error("lob_stage_wait: nothing staged"); return LOB_ESTATE; }
+    return stage_join(e);
+}
+// (lob_reset) the staged stream becomes the current one: the buffers change places
+static int stage_adopt(lob_engine* e) {
+    if (!e->stage_active) return LOB_OK;
+    const int rc = stage_join(e);
+    e->stage_active = false;
+    if (rc != LOB_OK) return rc;
+    std::swap(e->records_dev, e->records_next);
+    e->S.records = e->records_dev;
+    return LOB_OK;
 }
 
 int lob_load_events_shared(lob_engine* e, const uint32_t* host_records, int64_t n_total, const int64_t* phase, int32_t n_events) {
@@ -1132,7 +1202,8 @@ int lob_reset(lob_engine* e) {
     if (!e) return LOB_EINVAL;
     if (!e->have_events) { lob_set_error("lob_reset: no event stream loaded"); return LOB_ESTATE; }
     HIPCHK(hipSetDevice(e->device));
-    { int rc = finalize_episode(e); if (rc) return rc; }
+    { int rc = finalize_episode(e); if (rc) return rc; }   // (the window sums of the episode that ends: on the stream it ran on)
+    { int rc = stage_adopt(e); if (rc) return rc; }        // a stream handed over meanwhile (lob_stage_events) is this episode's
     { int rc = registry_join(e); if (rc) return rc; }
     { int rc = sync_state(e); if (rc) return rc; }
     // the memo table starts empty every episode (reset_kernel voids every book's slot)

@@ -125,6 +125,16 @@ class Engine:
         assert ph.shape == (self.B,)
         self._check(self.lib.lob_load_events_shared(self.h, _ptr(rec), rec.shape[0], _ptr(ph), n_events))
 
+    def stage_events(self, records):
+        """lob_stage_events: the next episode's streams, handed over while this one runs; the next reset() adopts them."""
+        rec = np.ascontiguousarray(records, dtype=np.uint32)
+        assert rec.shape[0] == self.B
+        self._staged = rec          # (the caller's buffer must outlive the hand-over)
+        self._check(self.lib.lob_stage_events(self.h, _ptr(rec), rec.shape[1]))
+
+    def stage_wait(self):
+        self._check(self.lib.lob_stage_wait(self.h))
+
     def gen_events(self, gen):
         self._check(self.lib.lob_gen_events_device(self.h, C.byref(gen)))
 
@@ -331,6 +341,15 @@ class Engine:
 
     def delta_sparse_apply(self):
         self._check(self.lib.lob_delta_sparse_apply(self.h))
+
+    def exchange_debug(self):
+        """lob_debug_exchange (a diagnostic export): sparse exchanges without / with a host synchronisation, unions that outgrew the fixed count."""
+        c = np.zeros(5, np.int64)
+        fn = self.lib.lob_debug_exchange
+        fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_void_p]
+        self._check(fn(self.h, _ptr(c)))
+        return {"without_host_sync": int(c[0]), "with_host_sync": int(c[1]), "unions_beyond_the_fixed_count": int(c[2]), "fixed_count": int(c[3]),
+                "last_union": int(c[4])}
 
     def sync(self):
         self._check(self.lib.lob_sync(self.h))

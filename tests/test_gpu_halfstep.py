@@ -99,3 +99,47 @@ def test_the_piecewise_upload_paths_hand_over_the_same_stream(monkeypatch, pinne
     assert bytes(eng.get_books()) == want
     np.testing.assert_allclose(eng.theta(), th0, rtol=1e-9, atol=1e-12)
     eng.close()
+
+
+def test_the_next_episodes_stream_staged_while_this_one_runs(monkeypatch):
+    """lob_stage_events: the reference loads a fresh day before every episode (src/main.cpp:53-55); here the next episode's
+    streams are handed over WHILE the current episode steps -- a host thread, a second record buffer, a stream of its own -- and
+    the lob_reset that follows adopts them.  Books and weights must be those of an engine that loads the second stream the
+    ordinary way between the episodes (pieces of 1 000 records, so that the hand-over is still going on while the steps run)."""
+    monkeypatch.setenv("LOB_UPLOAD_PIECE_RECS", "1000")
+    p, rec_a, eng = _make(B=48)
+    g = engine.default_gen_params()
+    g.n_events = 300
+    g.seed = 777
+    rec_b = engine.gen_stream_host(g, p.depth, p.max_trades, 1000, 48)
+    ref = engine.Engine(p, 48)
+    ref.load_events(rec_a)
+    for e in (eng, ref):
+        e.reset()
+    eng.stage_events(rec_b)            # ... and the steps of the first episode go on
+    for e in (eng, ref):
+        e.td_step(40)
+        e.clear_inventory()
+        e.handle_terminal()
+    ref.load_events(rec_b)
+    for e in (eng, ref):
+        e.reset()                      # (eng: adopts the staged stream)
+        e.td_step(40)
+    assert bytes(eng.get_books()) == bytes(ref.get_books())
+    np.testing.assert_allclose(eng.theta(), ref.theta(), rtol=1e-9, atol=1e-12)
+    # a stream of another length, or a second hand-over before the first was adopted, is refused
+    eng.stage_events(rec_a)
+    with pytest.raises(engine.LobError):
+        eng.stage_events(rec_a)
+    eng.stage_wait()
+    eng.reset()
+    with pytest.raises(engine.LobError):
+        eng.stage_events(rec_a[:, :200])
+    # ... and a stream that fails validation reports it where the hand-over is waited for
+    bad = rec_b.copy()
+    bad[3, 10, 4] = 0                   # (a zero best-ask price)
+    eng.stage_events(bad)
+    with pytest.raises(engine.LobError):
+        eng.reset()
+    eng.close()
+    ref.close()
