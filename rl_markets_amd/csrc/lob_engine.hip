@@ -156,6 +156,7 @@ struct lob_engine {
     // The NEXT episode's streams, handed over while the current episode runs (lob_stage_events): a second record buffer filled by
     // a host thread through a stream of its own -- validation, pinned staging, DMA, repack, none of it on the engine's stream --
     // and adopted by the lob_reset that follows.  The reference loads a fresh day before every episode (src/main.cpp:53-55).
+    size_t records_bytes = 0, track_bytes = 0;   // sizes of records_dev / track_dev (set_records re-uses buffers of the right size)
     uint32_t* records_next = nullptr;
     hipStream_t stream_up = nullptr;
     std::thread stage_thread;
@@ -867,23 +868,33 @@ static int set_records(lob_engine* e, int32_t n_events, size_t n_rows) {
     e->S.track = nullptr;
     e->S.rec_phase = nullptr;
     e->S.n_events = 0;
-    if (e->records_dev) { hipFree(e->records_dev); e->records_dev = nullptr; }
     if (e->phase_dev) { hipFree(e->phase_dev); e->phase_dev = nullptr; }
-    if (e->track_dev) { hipFree(e->track_dev); e->track_dev = nullptr; }
-    size_t bytes = n_rows * e->P.Wd * 4 + 256;  // (tail pad: drec_levels reads whole 16-byte quads past a short level array)
-    hipError_t err = hipMalloc((void**)&e->records_dev, bytes);
-    if (err != hipSuccess) { e->records_dev = nullptr; lob_set_error("hipMalloc(records) failed"); return LOB_ENOMEM; }
+    const size_t bytes = n_rows * e->P.Wd * 4 + 256;  // (tail pad: drec_levels reads whole 16-byte quads past a short level array)
     // market track: resident (one entry per event) up to track_ring events per book, a ring of that many beyond
     e->chunked = n_events > e->track_ring;
     e->S.track_len = e->chunked ? e->track_ring : n_events;
     e->S.track_mask = e->chunked ? e->track_ring - 1 : 0x7fffffff;
-    err = hipMalloc((void**)&e->track_dev, (size_t)e->B * e->S.track_len * sizeof(Track));
-    if (err != hipSuccess) {
-        e->track_dev = nullptr;
-        hipFree(e->records_dev);
-        e->records_dev = nullptr;
-        lob_set_error("hipMalloc(track) failed");
-        return LOB_ENOMEM;
+    const size_t track_bytes = (size_t)e->B * e->S.track_len * sizeof(Track);
+    // (a stream of the size of the one before it -- a fresh day per episode -- moves into the buffers that are there: freeing and
+    // allocating 31 + 18 GB cost more than the copy of a whole stream, round 6)
+    hipError_t err = hipSuccess;
+    if (!e->records_dev || e->records_bytes != bytes) {
+        if (e->records_dev) { hipFree(e->records_dev); e->records_dev = nullptr; }
+        err = hipMalloc((void**)&e->records_dev, bytes);
+        if (err != hipSuccess) { e->records_dev = nullptr; e->records_bytes = 0; lob_set_error("hipMalloc(records) failed"); return LOB_ENOMEM; }
+        e->records_bytes = bytes;
+    }
+    if (!e->track_dev || e->track_bytes != track_bytes) {
+        if (e->track_dev) { hipFree(e->track_dev); e->track_dev = nullptr; }
+        err = hipMalloc((void**)&e->track_dev, track_bytes);
+        if (err != hipSuccess) {
+            e->track_dev = nullptr; e->track_bytes = 0;
+            hipFree(e->records_dev);
+            e->records_dev = nullptr; e->records_bytes = 0;
+            lob_set_error("hipMalloc(track) failed");
+            return LOB_ENOMEM;
+        }
+        e->track_bytes = track_bytes;
     }
     e->S.track = e->track_dev;
     e->S.records = e->records_dev;

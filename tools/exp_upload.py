@@ -35,3 +35,37 @@ for rep in range(3):
 rate = rec.nbytes / best
 full = 65536 * g.n_events * rec.shape[2] * 4
 print("65 536 books x %d events = %.1f GB of caller records: %.2f s at that rate" % (g.n_events, full / 1e9, full / rate))
+
+# ---- a fresh stream per episode: handed over between the episodes (lob_load_events) against staged while the episode runs (lob_stage_events)
+def episode(eng, chunk=32):
+    n = 0
+    while True:
+        eng.td_step(chunk)
+        n += chunk
+        if eng.counters()[2] == 0:
+            return n
+g2 = engine.default_gen_params()
+g2.n_events = g.n_events
+g2.seed = 4242
+rec2 = engine.gen_stream_host(g2, 10, 2, B, B)
+streams = [rec, rec2]
+for mode in ("between", "staged"):
+    eng.load_events(streams[0])
+    eng.reset()
+    eng.sync()
+    c0 = eng.counters()[0]
+    t0 = time.perf_counter()
+    for ep in range(4):
+        nxt = streams[(ep + 1) % 2]
+        if mode == "staged":
+            eng.stage_events(nxt)
+        episode(eng)
+        eng.clear_inventory()
+        eng.handle_terminal()
+        if mode == "between":
+            eng.load_events(nxt)
+        eng.reset()
+    eng.sync()
+    dt = time.perf_counter() - t0
+    steps = eng.counters()[0] - c0
+    print("fresh stream every episode, %s: 4 episodes, %d env-steps in %.3f s = %.1f M env-steps/s PCIe-inclusive" % (mode, steps, dt, steps / dt / 1e6))
