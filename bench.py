@@ -62,7 +62,7 @@ def algorithmic_bytes(kernel, depth, trades, n_vars, n_live, events_per_step):
 
 
 # timer name (lob_kernel_time_ms) -> kernel function(s) launched under it, as rocprofv3 names them
-TIMER_KERNELS = {"act_kernel": ("act_light_kernel", "act_fast_kernel", "act_kernel"), "env_kernel": ("env_step_kernel", "env_kernel"), "trace_kernel": ("trace_lane_kernel", "trace_fast_kernel"),
+TIMER_KERNELS = {"act_kernel": ("act_light_kernel", "act_fast_kernel", "act_kernel"), "env_kernel": ("env_step_kernel", "env_step16_kernel", "env_kernel"), "trace_kernel": ("trace_lane_kernel", "trace_fast_kernel"),
                  "trace_light_kernel": ("trace_light_kernel",),
                  "learn_kernel": ("learn_q_pair_kernel", "learn_q_lane_kernel", "learn_q_fast_kernel", "learn_kernel"), "act_rest_kernel": (), "learn_rest_kernel": ("learn_q_rest_kernel",),
                  "accumulate_kernel": ("trace_rest_kernel", "accumulate_block_kernel", "accumulate_kernel")}

@@ -1616,7 +1616,7 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                 if (rest_side_now) e->flow[1]++;
                 if (acc_blocked(e) && e->S.cb_dense) {
                     // sums by the slots' dense ids in a direct-indexed LDS array, one block per CU (accumulate_dense_kernel)
-                    dense_blocks = std::min(std::min(e->n_cus, LOB_ACD_MAX_BLOCKS), (e->B + 255) / 256);
+                    dense_blocks = std::min(std::min(e->n_cus, LOB_ACD_MAX_BLOCKS), (e->B + 127) / 128);   // (a block takes 128 books per pass)
                     const int bpb = ((e->B + dense_blocks - 1) / dense_blocks + 31) / 32 * 32;
                     dense_blocks = (e->B + bpb - 1) / bpb;
                     hipLaunchKernelGGL(accumulate_dense_kernel, dim3(dense_blocks), dim3(LOB_ACD_BLOCK), acd_lds_bytes(), e->stream, LOB_PS(e), par, e->step_id, bpb);

@@ -1,11 +1,11 @@
 set -u
-# Runs ON THE GPU BOX (through gpurun), end of round 5: the driver's command twice, the counter profiles of the same command (no
+# Runs ON THE GPU BOX (through gpurun), end of a round (R below): the driver's command twice, the counter profiles of the same command (no
 # sustained / dense legs under the profiler), kernel statistics + FETCH_SIZE / WRITE_SIZE of every other configuration the
-# documents quote (-> profiles/r05_<cfg>_*), the benches.  Outputs under gpurun_out/; tools/collect_r05.sh copies what is kept
+# documents quote (-> profiles/r05_<cfg>_*), the benches.  Outputs under gpurun_out/; tools/collect_round.sh copies what is kept
 # to profiles/.   usage: bash tools/final_validation.sh [quick]   (quick: no full test suite)
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/prof
-R=r05
+R=${ROUND:-r06}
 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_${R}_driver1.json 2>gpurun_out/bench_${R}_driver1.err
 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/bench_${R}_driver2.json 2>/dev/null
 # ---- the headline configuration: kernel statistics + six counter passes of the driver's command ----
@@ -33,6 +33,7 @@ python bench.py --gpus 1 --books 4096 --algo sarsa --steps 200 --warmup 20 --no-
 python bench.py --gpus 1 --replay 61200 --events 50000 --steps 200 --warmup 20 --no-cpu-baseline > gpurun_out/bench_${R}_c5.json 2>/dev/null
 python bench.py --gpus 1 --books 262144 --events 300 --steps 200 --warmup 20 --no-cpu-baseline --sustained 0 --dense 0 > gpurun_out/bench_${R}_262k.json 2>/dev/null
 LOB_FORCE_DIST=1 python bench.py --gpus 1 --steps 256 --warmup 64 --no-cpu-baseline > gpurun_out/bench_${R}_dist.json 2>/dev/null
+timeout 600 python tools/exp_upload.py 16384 > gpurun_out/exp_upload_${R}.txt 2>&1
 python bench.py --gpus 1 --epsilon 0.01 --steps 200 --warmup 20 --no-cpu-baseline --sustained 0 --dense 0 > gpurun_out/bench_${R}_eps01.json 2>/dev/null
 python - <<PY
 import json, glob
