@@ -624,10 +624,10 @@ def test_zz_update_paths_the_sweep_went_through():
     if not FLOWS:
         pytest.skip("the sweep did not run in this session")
     ql = [(v, f) for v, a, f in FLOWS if a == abi.ALGO_QLAMBDA]
-    in_place = [f for v, f in ql if v in ("pair", "pair_rest_split") and f["added_in_place"] > 0 and f["every_book"] == 0]
+    in_place = [f for v, f in ql if v in ("pair", "pair_rest_split", "pair_env64") and f["added_in_place"] > 0 and f["every_book"] == 0]
     whole = [f for v, f in ql if v == "pair_acc_pass" and f["every_book"] > 0]
     print("Q(lambda) cases with updates added in place: %d, with the accumulate pass over every book: %d" % (len(in_place), len(whole)))
     if os.environ.get("PYTEST_XDIST_WORKER"):
         pytest.skip("under pytest-xdist this process has seen only its share of the sweep")
     assert len(in_place) >= 6 and len(whole) >= 3
-    assert all(f["added_in_place"] == 0 for v, f in ql if v not in ("pair", "pair_rest_split", "lane"))
+    assert all(f["added_in_place"] == 0 for v, f in ql if v not in ("pair", "pair_rest_split", "pair_env64", "lane"))
