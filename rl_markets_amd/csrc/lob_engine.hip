@@ -70,6 +70,7 @@ struct lob_engine {
     bool dq_pair = true;        // double Q(lambda): learn_q_pair_kernel<DOUBLE_Q> (LOB_DQ_PAIR=0: a lane per book, learn_q_lane_kernel; A/B switch)
     int ts_lds = 0, ts_grid = 0; // (experiments: trace_lane_kernel<SARSA> with dynamic LDS / a persistent grid)
     bool no_hint = false;       // (experiment: learn_q_rest_kernel without its report to the host)
+    bool exp_learn_first = false;  // (experiment LOB_SARSA_LEARN_FIRST=1: DevParams::exp_learn_first)
     long long flow[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // lob_debug_flow: learner steps by the shape of their update / action selection (see there)
     bool acc_fuse = true;       // Q(lambda), the pair kernel + the lane-per-generation trace kernel: updates added to their slots there, accumulate_kernel over a list (LOB_ACC_FUSE=0: over every book; A/B switch)
     bool acc_batches_set = false;
@@ -405,6 +406,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     if (const char* g = getenv("LOB_REST_MERGE")) e->rest_merge = !(g[0] == '0');
     if (exps) {
         if (const char* g = getenv("LOB_TS_LDS")) e->ts_lds = atoi(g);
+        e->exp_learn_first = getenv("LOB_SARSA_LEARN_FIRST") != nullptr;
         if (const char* g = getenv("LOB_TS_GRID")) e->ts_grid = atoi(g);
         e->no_hint = getenv("LOB_NO_HINT") != nullptr;
     }
@@ -509,6 +511,7 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
         P.epi_epoch = 0;
     }
     P.seed = p->seed; P.book_id_offset = p->book_id_offset;
+    P.exp_learn_first = e->exp_learn_first ? 1 : 0;
 
     // ---- DevState ----
     DevState& S = e->S;
@@ -1507,20 +1510,27 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                     TimedLaunch t(e, "trace_light_kernel", st);
                     hipLaunchKernelGGL(trace_light_kernel, dim3((nb + LOB_LIGHT_BLOCK - 1) / LOB_LIGHT_BLOCK), dim3(LOB_LIGHT_BLOCK), 0, st, LOB_PS(e), lpar);
                 }
-                if (!fuse) {
-                    TimedLaunch t(e, "trace_kernel", st);
-                    if (tl) hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_QLAMBDA, 1>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, LOB_PS(e), rnd, par, lpar, sid);
-                    else if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_QLAMBDA, 0>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, LOB_PS(e), rnd, par, lpar, sid);
-                    else if (e->P.sarsa_lanes) {
-                        // a lane per generation; the wave-per-book kernel for the books it leaves on the list
-                        // (LOB_TS_GRID / LOB_TS_LDS, experiments: fewer, persistent blocks / dynamic LDS to throttle the occupancy -- halving
-                        // it costs 28 %, a persistent grid changes nothing: NOTES.md "Round 5")
-                        const int ts_full = (nb + LOB_TS_BLOCK / 32 - 1) / (LOB_TS_BLOCK / 32);
-                        hipLaunchKernelGGL(trace_lane_kernel<LOB_ALGO_SARSA>, dim3(e->ts_grid > 0 ? std::min(e->ts_grid, ts_full) : ts_full), dim3(LOB_TS_BLOCK), e->ts_lds, st, LOB_PS(e), lpar, sid, 0);
-                        hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_SARSA, 1>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, LOB_PS(e), rnd, par, lpar, sid);
+                auto launch_traces = [&]() {
+                    if (!fuse) {
+                        TimedLaunch t(e, "trace_kernel", st);
+                        if (tl) hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_QLAMBDA, 1>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, LOB_PS(e), rnd, par, lpar, sid);
+                        else if (e->P.algo == LOB_ALGO_QLAMBDA) hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_QLAMBDA, 0>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, LOB_PS(e), rnd, par, lpar, sid);
+                        else if (e->P.sarsa_lanes) {
+                            // a lane per generation; the wave-per-book kernel for the books it leaves on the list
+                            // (LOB_TS_GRID / LOB_TS_LDS, experiments: fewer, persistent blocks / dynamic LDS to throttle the occupancy -- halving
+                            // it costs 28 %, a persistent grid changes nothing: NOTES.md "Round 5")
+                            const int ts_full = (nb + LOB_TS_BLOCK / 32 - 1) / (LOB_TS_BLOCK / 32);
+                            hipLaunchKernelGGL(trace_lane_kernel<LOB_ALGO_SARSA>, dim3(e->ts_grid > 0 ? std::min(e->ts_grid, ts_full) : ts_full), dim3(LOB_TS_BLOCK), e->ts_lds, st, LOB_PS(e), lpar, sid, 0);
+                            hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_SARSA, 1>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, LOB_PS(e), rnd, par, lpar, sid);
+                        }
+                        else hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_SARSA, 0>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, LOB_PS(e), rnd, par, lpar, sid);
                     }
-                    else hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_SARSA, 0>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, LOB_PS(e), rnd, par, lpar, sid);
-                }
+                };
+                const bool learn_first = lobk_experiments() && e->P.exp_learn_first && e->P.algo == LOB_ALGO_SARSA;
+                // (SARSA(lambda)'s trace kernels run IN FRONT OF its learn kernels: they mark the new generation's tiles in the
+                // written-weights maps the learn kernels build the hit lists by -- lob_state.h above hl_rec.  The other order exists in
+                // -DLOB_EXPERIMENTS builds only (LOB_SARSA_LEARN_FIRST=1), for the test that shows it to fail.)
+                if (!learn_first) launch_traces();
                 {
                     TimedLaunch t(e, "learn_kernel", st);
                     if (lanes) {
@@ -1570,6 +1580,7 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                         rest_side_now = true;
                     }
                 }
+                if (learn_first) launch_traces();
                 if (e->P.sarsa_lanes && !e->reg_fork_late) { int rc = registry_fork(e, st, rnd, par); if (rc) return rc; }
                 if (fuse) {
                     TimedLaunch t(e, "trace_kernel", st);

@@ -561,7 +561,7 @@ __global__ void __launch_bounds__(LOB_TRACE_BLOCK, LOB_TRACE_OCC) trace_fast_ker
         if (lmatch && lid.w == 0 && lane == 0) S.mk_ident[(size_t)lslot * 4 + 3] = dup ? 2 : 1;  // (every wave that gets here writes the same value)
         if (LIST != 2 && lane == 0) {
             LHdr* hp = S.hdr + b;
-            hp->td = sel9(qs_last, h.action);  // Q(s, a), for the TD error
+            if (!LOB_TD_KEEP(P)) hp->td = sel9(qs_last, h.action);  // Q(s, a), for the TD error
             hp->rng_ctr = g.ctr;
         }
         cb_claim_finish(S, prev);
@@ -753,7 +753,7 @@ __global__ void __launch_bounds__(LOB_LIGHT_BLOCK) trace_light_kernel(LOB_PS_ARG
     S.tr_alive[(size_t)b * G + nh] = 0xffffffffu;
     hp->tr_head = nh;
     hp->tr_n = 1;
-    hp->td = sel9(qs_last, action);  // Q(s, a), for the TD error
+    if (!LOB_TD_KEEP(P)) hp->td = sel9(qs_last, action);  // Q(s, a), for the TD error
     hp->rng_ctr = g.ctr;
     if (P.combine) {
         *reinterpret_cast<int4*>(S.tr_sig + ((size_t)b * G + nh) * 4) = make_int4(q0, q1, q2, action);
@@ -933,7 +933,7 @@ __global__ void __launch_bounds__(LOB_TS_BLOCK, 5) trace_lane_kernel(LOB_PS_ARGS
             *reinterpret_cast<int4*>(S.tr_sig + ni * 4) = make_int4(q0, q1, q2, action);
             hp->tr_head = nh;
             hp->tr_n = n_old + 1;
-            if (!QL) hp->td = S.qs_last[(size_t)b * LOB_N_ACTIONS + action];  // Q(s, a), for the TD error
+            if (!QL && !LOB_TD_KEEP(P)) hp->td = S.qs_last[(size_t)b * LOB_N_ACTIONS + action];  // Q(s, a), for the TD error
             const u64 ch = cb_hash(q0, q1, q2, action, 0xffffffffu);
             const uint32_t home = (uint32_t)ch & (uint32_t)(S.cb_slots - 1);
             bool at_home = false;
@@ -1051,7 +1051,7 @@ __global__ void __launch_bounds__(LOB_FAST_BLOCK) learn_q_fast_kernel(LOB_PS_ARG
         for (int k = 0; k < NB; k++) {
             if (!go[k]) continue;
             Rng g{P.seed, P.book_id_offset + (u64)b[k], h[k].rng_ctr};
-            learn_delta_single<ALGO>(P, S.hdr + b[k], h[k], qs[k], h[k].td, g, lane);
+            learn_delta_single<ALGO>(P, S.hdr + b[k], h[k], qs[k], LOB_QSA(P, S, b[k], h[k], ALGO), g, lane);
         }
         hit_list_store<NB>(S, lane, hcnt, wr_b, hbuf);
         pf.mark(19);  // argmax / delta / header stores
@@ -1297,7 +1297,7 @@ __global__ void __launch_bounds__(LOB_QL_BLOCK) learn_q_lane_kernel(LOB_PS_ARGS,
         if (!h.stepped) { recp[0] = LOB_HL_NONE; continue; }
         Rng g{P.seed, P.book_id_offset + (u64)b, h.rng_ctr};
         // ---- UpdateTraces, first half: the decisions (QLearn::UpdateTraces, agent.cpp:272-280) ----
-        f64 q_sa = h.td;
+        f64 q_sa = LOB_QSA(P, S, b, h, ALGO);
         int amax = 0, lslot = -1, tq0 = 0, tq1 = 0, tq2 = 0;
         bool tlight = false;
         uint32_t tmarked = 0;
@@ -1571,7 +1571,7 @@ __global__ void __launch_bounds__(LOB_QP_BLOCK) learn_q_pair_kernel(const DevPar
         if (!second) {
             // ---- group-1 lane: the trace step's decisions, the group-1 walk, S0 + its additions, the trace step's stores ----
             Rng g{P.seed, P.book_id_offset + (u64)bb, h.rng_ctr};
-            f64 q_sa = h.td;
+            f64 q_sa = LOB_QSA(P, S, b, h, ALGO);
             int amax = 0, lslot = -1, tq0 = 0, tq1 = 0, tq2 = 0;
             bool tlight = false;
             uint32_t tmarked = 0;

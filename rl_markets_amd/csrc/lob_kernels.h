@@ -1286,7 +1286,7 @@ __device__ __forceinline__ void learn_q_book(const DevParams& P, const DevState&
         S.verdict_b[(size_t)b * 64 + lane] = (uint16_t)my_vd_b;
         learn_delta_double<true>(P, S, hp, h, b, qs_to, qb_to, h.td, g, lane, reinterpret_cast<u64*>(L.vals[w]));
     } else {
-        learn_delta_single<ALGO == LOB_ALGO_DOUBLE_Q ? LOB_ALGO_SARSA : ALGO>(P, hp, h, qs_to, h.td, g, lane);
+        learn_delta_single<ALGO == LOB_ALGO_DOUBLE_Q ? LOB_ALGO_SARSA : ALGO>(P, hp, h, qs_to, LOB_QSA(P, S, b, h, ALGO), g, lane);
     }
 }
 template <int ALGO>

@@ -471,6 +471,8 @@ struct DevParams {
     i32 epi_epoch;       // episodes begun (lob_reset): tags the memo slots the generations refer to (tr_mslot)
     i32 memo;            // group-0 memo + fast learner kernels on (shared theta, SARSA / Q(lambda), one book group; 0 with LOB_NO_MEMO=1)
     i32 cshift, cwords4; // coarse map: bit = weight index >> cshift; size in 16-byte units
+    i32 exp_learn_first; // (-DLOB_EXPERIMENTS builds, LOB_SARSA_LEARN_FIRST=1) SARSA(lambda)'s learn kernels IN FRONT OF its trace kernels: the order
+                         //   the written-weights maps forbid (lob_state.h above hl_rec) -- kept so that a test can show that it fails
     u64 seed, book_id_offset;
 };
 
@@ -493,6 +495,15 @@ __device__ __forceinline__ void cnt_add(const DevState& S, int idx, unsigned lon
 }
 #else   // (the device headers compiled as host code by tests/host_env: one "block")
 inline void cnt_add(const DevState& S, int idx, unsigned long long v) { S.counters.p[idx] += (i64)v; }
+#endif
+
+// Q(s, a) for SARSA's TD error: left in LHdr::td by the trace step -- or, in the experiment that runs the learn kernels first, from qs_last
+#ifdef LOB_EXPERIMENTS
+#define LOB_QSA(P, S, b, h, ALGO) (((ALGO) == LOB_ALGO_SARSA && (P).exp_learn_first) ? (S).qs_last[(size_t)(b) * LOB_N_ACTIONS + (h).action] : (h).td)
+#define LOB_TD_KEEP(P) ((P).exp_learn_first != 0)
+#else
+#define LOB_QSA(P, S, b, h, ALGO) ((h).td)
+#define LOB_TD_KEEP(P) false
 #endif
 
 #define LOB_ERR_BAD_ORDER_PRICE 1  /* Order ctor would throw (src/market/order.cpp:22-27) */

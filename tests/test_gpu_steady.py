@@ -469,6 +469,33 @@ def test_model_log_rows_in_the_merged_rest_flow(algo, monkeypatch):
     orc.close()
 
 
+def test_sarsa_learn_kernels_in_front_of_its_trace_kernels_must_fail(monkeypatch):
+    """The order SARSA(lambda)'s kernels may NOT have (rl_markets_amd/csrc/lob_state.h, above `hl_rec`): its trace step marks the
+    new generation's 32 tiles in the written-weights maps, and the learn kernel builds the next step's hit list by those maps --
+    a list built BEFORE the mark lacks every tile of s' that hashes onto a weight this very step's update is about to write, and
+    the next action selection then drops that addition.  Round 5 ran the trace kernels BESIDE the learn kernels, saw TD errors
+    off by 2e-4 in three books of 16 384 one step into the second episode, and did not find the reader.  A -DLOB_EXPERIMENTS
+    build keeps the forbidden order behind LOB_SARSA_LEARN_FIRST=1 (the learn kernels first, Q(s, a) taken from qs_last):
+    this test runs it against the oracle and REQUIRES a mismatch -- if it ever passes, the dependency documented there is gone
+    or the comparison has gone blind."""
+    from tests.test_gpu_parity import experiments_build
+    if not experiments_build():
+        pytest.skip("the forbidden order exists in -DLOB_EXPERIMENTS builds only (tools/exp_variants.sh)")
+    monkeypatch.setenv("LOB_SARSA_LEARN_FIRST", "1")
+    B = 16384
+    p, eng, orc = make(B, abi.ALGO_SARSA, n_events=260)
+    with pytest.raises(AssertionError):
+        for episode, n_steps in ((0, 40), (1, 12)):
+            eng.reset(); orc.reset()
+            for step in range(n_steps):
+                eng.td_step(1); orc.td_step(1)
+                compare_learner_step(eng, orc, "learn first, episode %d step %d" % (episode, step), exact=False, rtol=1e-9)
+            eng.clear_inventory(); orc.clear_inventory()
+            eng.handle_terminal(); orc.handle_terminal()
+    eng.close()
+    orc.close()
+
+
 def test_reset_then_weight_load_then_steps(monkeypatch):
     """lob_reset -> lob_theta_set -> lob_td_step: the weight load re-evaluates the memo records of the slots on the
     current list, which after a reset must be EMPTY -- slots of the episode before would be re-stamped as holding
