@@ -179,8 +179,8 @@ def test_traffic_table_is_what_the_committed_counter_passes_give(tmp_path):
     import json
     import subprocess
     import sys
-    for tag, name in (("r05", "pmc_traffic.json"), ("r05_sarsa", "pmc_traffic_sarsa.json"), ("r05_c2", "pmc_traffic_c2.json"),
-                      ("r05_double_q", "pmc_traffic_double_q.json"), ("r05_c5", "pmc_traffic_c5.json"), ("r05_eps01", "pmc_traffic_eps01.json")):
+    for tag, name in (("r06", "pmc_traffic.json"), ("r06_sarsa", "pmc_traffic_sarsa.json"), ("r06_c2", "pmc_traffic_c2.json"),
+                      ("r06_double_q", "pmc_traffic_double_q.json"), ("r06_c5", "pmc_traffic_c5.json"), ("r06_eps01", "pmc_traffic_eps01.json")):
         out = str(tmp_path / name)
         subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_traffic.py"), tag, out], stdout=subprocess.DEVNULL)
         assert json.load(open(out)) == json.load(open(os.path.join(ROOT, "profiles", name))), name
