@@ -223,3 +223,86 @@ def test_a_union_that_outgrows_the_fixed_count_loses_nothing(monkeypatch):
     np.testing.assert_array_equal(engs[0].theta(), engs[1].theta())
     for e in engs:
         e.close()
+
+
+def test_checkpoint_loaded_after_delta_init_is_not_scaled_by_world_size():
+    """lob_theta_set after lob_delta_init (ShardedLearner's constructor ran, then a checkpoint is
+    loaded on every rank): the loaded weights are the new common base.  Before the fix every rank
+    contributed (loaded - sync) and theta came out as sync + world * (loaded - sync)."""
+    engs, orcs = make_shards(abi.ALGO_SARSA)
+    for e in engs:
+        e.td_step(8)
+    host_allreduce(engs)
+    loaded = np.random.default_rng(5).standard_normal(engs[0].M) * 1e-3
+    for e in engs:
+        e.set_theta(loaded)
+    host_allreduce(engs)          # nobody stepped: the sum of the deltas must be zero
+    for e in engs:
+        np.testing.assert_array_equal(e.theta(), loaded)
+    for e in engs:
+        e.td_step(4)
+    host_allreduce(engs)
+    np.testing.assert_array_equal(engs[0].theta(), engs[1].theta())
+    assert np.abs(engs[0].theta() - loaded).max() < 1.0   # a few small TD updates on top of the checkpoint, not 2 x checkpoint
+    for e in engs:
+        e.close()
+
+
+def test_rccl_allreduce_in_place_on_the_engine_buffer(tmp_path):
+    """The product's exchange: lob_theta_allreduce = delta kernel -> RCCL all-reduce (f64, SUM) in place
+    on the engine's own buffer, on the engine's stream -> apply kernel.  One rank: the sum over ranks is
+    the rank's own delta, so the weights must come out bit-identical, and stay in step with the oracle."""
+    from rl_markets_amd.comm import MAX, SUM, RcclComm
+    comm = RcclComm(str(tmp_path / "rdzv"), 0, 1, 0)
+    assert not (tmp_path / "rdzv").exists()          # rank 0 removes the token once everybody has joined
+    engs, orcs = make_shards(abi.ALGO_QLAMBDA, total=16, world=1)
+    eng, orc = engs[0], orcs[0]
+    learner = ShardedLearner(EngineBackend(eng), comm, sync_every=8)
+    learner.run(40)
+    orc.td_step(40)
+    eng.sync()
+    assert learner.n_syncs == 5
+    np.testing.assert_allclose(eng.theta(), orc.theta(), rtol=1e-9, atol=1e-15)
+    before = eng.theta()
+    comm.sync_weights(EngineBackend(eng))
+    eng.sync()
+    np.testing.assert_array_equal(eng.theta(), before)
+    assert comm.reduce([1.5, -2.0], MAX) == [1.5, -2.0] and comm.reduce([3.0], SUM) == [3.0]
+    comm.barrier()
+    comm.close()
+    eng.close()
+
+
+def test_bench_multi_gpu_code_path_on_one_rank():
+    """bench.py with LOB_FORCE_DIST=1: the N > 1 code path (RCCL communicator, delta kernels, in-place
+    all-reduce every 64 steps, max/sum reductions of the timings over ranks) on a single rank."""
+    env = dict(os.environ, LOB_FORCE_DIST="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--books", "2048", "--steps", "130", "--warmup", "10",
+                          "--no-cpu-baseline"], capture_output=True, text=True, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    d = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["config"]["sync_every"] == 64 and d["value"] > 0
+    ks = d["roofline"]["all_kernels_avg_ms"]
+    assert "delta_begin_kernel" in ks and "delta_apply_kernel" in ks
+    assert "torch" not in out.stderr.lower()
+
+
+def test_lob_run_multi_gpu_path_on_one_rank(tmp_path):
+    """The C++ driver's --gpus path (fork per GPU, file rendezvous, Learner::_step exchanging through
+    lob_theta_allreduce, global live-book count deciding the end of the episode) with one rank."""
+    exe = os.path.join(ROOT, "rl_markets_amd", "host", "lob_run")
+    cfg = os.path.join(ROOT, "config", "engine.yaml")
+    th = [str(tmp_path / "a.bin"), str(tmp_path / "b.bin")]
+    outs = []
+    for force, path in (("1", th[0]), ("0", th[1])):
+        env = dict(os.environ, LOB_FORCE_DIST=force)
+        out = subprocess.run([exe, "-c", cfg, "-n", "64", "-e", "1", "--events", "400", "--sync-every", "16", "--theta", path],
+                             capture_output=True, text=True, env=env)
+        assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+        # (RCCL prints a version banner on stdout when the communicator comes up)
+        outs.append([l for l in out.stdout.splitlines() if l.startswith("episode,") or l[:1].isdigit()])
+    # same books, same weights: one rank's exchange is the identity (up to the float order of theta_sync + delta)
+    assert len(outs[0]) == 2 and outs[0] == outs[1]
+    a, b = np.fromfile(th[0]), np.fromfile(th[1])
+    np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-15)
+    assert np.count_nonzero(a) > 100
