@@ -2214,6 +2214,22 @@ __global__ void __launch_bounds__(256) memo_kernel(DevParams P, DevState S, cons
         f64 t[5], tb[5];
         const bool fill = (S.mk_tiles_ok[s] & 1) == 0;  // first time on a list: leave the tile indices for the trace kernel
         const bool two = S.mk_rec_b != nullptr;         // double Q: the same 288 tiles under theta_b
+        if (which == 0 && !fill) {
+            // theta_t of this step is theta_{t+1} of the step before: a triple that was on THAT step's list has its S0 under these very
+            // weights in the other record already (memo_kernel which 1, same version) -- 80 bytes copied instead of 288 gathers
+            // (most triples of a step: the books move among a few hundred of them)
+            const f64* r1 = S.mk_rec + ((size_t)S.mk_slots + s) * LOB_MK_REC;
+            if (reinterpret_cast<const u64*>(r1)[LOB_N_ACTIONS] == ver) {   // (wave-uniform)
+                f64* r0 = S.mk_rec + (size_t)s * LOB_MK_REC;
+                if (lane <= LOB_N_ACTIONS) reinterpret_cast<u64*>(r0)[lane] = reinterpret_cast<const u64*>(r1)[lane];
+                if (two) {
+                    const f64* b1 = S.mk_rec_b + ((size_t)S.mk_slots + s) * LOB_MK_REC;
+                    f64* b0 = S.mk_rec_b + (size_t)s * LOB_MK_REC;
+                    if (lane <= LOB_N_ACTIONS) reinterpret_cast<u64*>(b0)[lane] = reinterpret_cast<const u64*>(b1)[lane];
+                }
+                continue;
+            }
+        }
 #pragma unroll
         for (int k = 0; k < 5; k++) {
             const int a = (hi ? 5 : 0) + k;
