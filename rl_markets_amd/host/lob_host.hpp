@@ -261,6 +261,10 @@ public:
         invalidate();
     }
     void LoadSynthetic(const lob_gen_params& g) { check(lob_gen_events_device(e_, &g), "LoadData"); invalidate(); }
+    // the NEXT episode's day, handed over while this episode runs (src/main.cpp:53-55: rs.sample() + env.LoadData before every
+    // episode): returns at once, the Initialise() that follows adopts the stream; `records` must stay valid until then
+    void StageData(const uint32_t* records, int n_events) { check(lob_stage_events(e_, records, n_events), "StageData"); }
+    void StageWait() { check(lob_stage_wait(e_), "StageData"); }
 
     bool Initialise() {  // false = no data for at least one book (base.h:122)
         check(lob_reset(e_), "Initialise");
