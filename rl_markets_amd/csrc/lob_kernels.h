@@ -2460,14 +2460,24 @@ __global__ void td_stats_fold_kernel(DevState S, int n_blocks) {
 
 // The striped device counters (lob_state.h cnt_add) added up for the host: out[i] = sum over the stripes of counter i.
 #if LOB_IN_MAIN
-__global__ void __launch_bounds__(LOB_CNT_STRIPES) counters_fold_kernel(const i64* __restrict__ cnt, i64* out) {
+// ... and, in out[15] (no counter lives there), the books that are still live (done == 0): what Runner::RunEpisode's loop asks after
+// every chunk of steps -- counted here instead of copying every book's flag to the host
+__global__ void __launch_bounds__(LOB_CNT_STRIPES) counters_fold_kernel(const i64* __restrict__ cnt, i64* out, const i32* __restrict__ done, int B) {
     __shared__ i64 part[LOB_CNT_STRIPES][16];
+    __shared__ i32 live[LOB_CNT_STRIPES];
     for (int i = 0; i < 16; i++) part[threadIdx.x][i] = cnt[(size_t)threadIdx.x * LOB_CNT_STRIDE + i];
+    i32 n = 0;
+    for (int b = threadIdx.x; b < B; b += LOB_CNT_STRIPES) n += done[b] == 0;
+    live[threadIdx.x] = n;
     __syncthreads();
-    if (threadIdx.x < 16) {
+    if (threadIdx.x < 15) {
         i64 acc = 0;
         for (int st = 0; st < LOB_CNT_STRIPES; st++) acc += part[st][threadIdx.x];
         out[threadIdx.x] = acc;
+    } else if (threadIdx.x == 15) {
+        i64 acc = 0;
+        for (int st = 0; st < LOB_CNT_STRIPES; st++) acc += live[st];
+        out[15] = acc;
     }
 }
 __global__ void counters_zero_kernel(i64* cnt, int idx) { cnt[(size_t)threadIdx.x * LOB_CNT_STRIDE + idx] = 0; }
