@@ -138,6 +138,9 @@ __global__ void repack_kernel(const uint32_t* __restrict__ src, int D, int T, si
 template <int RB, int TM>
 // (the state BY VALUE here: read through its device-resident copy the kernel spills nothing to scratch -- 176 spilled scalar
 // registers -> 10, 180 bytes of scratch per lane -> 0 -- and takes the same 16.5-16.7 ms: round 6)
+#ifdef LOB_RESET_REGCAP  // probe only (tools/exp_background_prepass.py): 112 = 224 registers in all, a wave that fits beside env_step_kernel's
+__attribute__((amdgpu_num_vgpr(LOB_RESET_REGCAP)))
+#endif
 __global__ void __launch_bounds__(RB) reset_kernel(const DevParams* __restrict__ Pp, DevState S) {
     const DevParams& P = *Pp;
     __shared__ TickLds tick_lds;
