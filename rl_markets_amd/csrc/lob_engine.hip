@@ -2031,15 +2031,25 @@ int lob_delta_sparse_maps(lob_engine* e, int32_t world, uint32_t** dev_own, uint
         e->spx_world = world;
     }
     if (!e->spx_union) {
+        // the pinned word the union's size is handed over in, and its event.  A rank without them would ask for the exact count at
+        // every exchange while the others use the fixed one -- collectives of different lengths: it fails HERE instead, where a
+        // failing rank makes all of them fail together (see below)
+        if (!e->spx_total_host && hipHostMalloc((void**)&e->spx_total_host, sizeof(i64), hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError(); e->spx_total_host = nullptr;
+            lob_set_error("lob_delta_sparse_maps: no pinned memory for the exchange's size hand-over");
+            return LOB_ENOMEM;
+        }
+        if (!e->spx_ev && hipEventCreateWithFlags(&e->spx_ev, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError(); hipHostFree(e->spx_total_host); e->spx_total_host = nullptr;
+            lob_set_error("lob_delta_sparse_maps: no event for the exchange's size hand-over");
+            return LOB_ENOMEM;
+        }
         const int nb = (int)((W + LOB_SPX_BLOCK - 1) / LOB_SPX_BLOCK);
         int rc = dev_alloc(e, &e->spx_union, (size_t)W);
         if (rc == LOB_OK) rc = dev_alloc(e, &e->spx_block_cnt, (size_t)nb);
         if (rc == LOB_OK) rc = dev_alloc(e, &e->spx_block_off, (size_t)nb);
         if (rc == LOB_OK) rc = dev_alloc(e, &e->spx_total, 1);
         if (rc != LOB_OK) return rc;
-        // (without pinned memory for the size hand-over every exchange synchronises, as before)
-        if (hipHostMalloc((void**)&e->spx_total_host, sizeof(i64), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); e->spx_total_host = nullptr; }
-        if (e->spx_total_host && hipEventCreateWithFlags(&e->spx_ev, hipEventDisableTiming) != hipSuccess) { hipHostFree(e->spx_total_host); e->spx_total_host = nullptr; }
         // (the first fixed count: a 64th of the table, 4 096 .. 262 144 entries; LOB_SPX_COUNT: the tests' small one)
         e->spx_fixed = std::max<int64_t>(4096, std::min<int64_t>(1 << 18, e->P.M / 64));
         if (const char* g = getenv("LOB_SPX_COUNT")) { const long long v = atoll(g); if (v >= 64) e->spx_fixed = v; }
