@@ -63,7 +63,6 @@ struct lob_engine {
     hipStream_t stream = nullptr;   // main stream (all API calls)
     hipStream_t stream2 = nullptr;  // second book group of the step pipeline
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_stagger = nullptr;
-    hipEvent_t ev_reg_go = nullptr, ev_reg_done = nullptr;  // tile registry kernels on stream2 beside the learner kernels (lob_kernels.h registry_kernel)
     hipEvent_t ev_rest_go = nullptr, ev_rest_done = nullptr;  // learn_q_rest_kernel on stream2 beside the trace kernels
     bool rest_side = true;      // (LOB_REST_SIDE=0: on the main stream, as before; A/B switch)
     bool rest_merge = true;     // the fused Q(lambda) / double Q flow: trace_rest_kernel (LOB_REST_MERGE=0: learn_q_rest_kernel + trace_fast_kernel<., 2> + accumulate_kernel over its list; A/B switch)
@@ -98,8 +97,7 @@ struct lob_engine {
     int hint_now = 0;           // the hint this step goes by (run_steps)
     int force_general = -1;     // LOB_MOSTLY_GENERAL=0|1: the work-list act path never / always (tests); -1: by the hint
     int rest_recent = 0;        // steps left to keep the launch on the second stream after the last non-empty list seen
-    bool reg_pending = false;
-    bool reg_fork_late = false;
+    int reg_apar = 0;   // which of the two lists of newly ambiguous indices this step's registry blocks fill (trace_lane_kernel's launch) and its scan blocks read (apply_kernel's)
     int n_groups = 1;
     int env_lanes = 0;     // books per env_kernel wave: 0 = by batch size, or 16 / 32 / 64; 256 = env_compact_kernel (LOB_ENV_LANES, read by lob_create)
     int reset_lanes = 64;  // books per reset_kernel wave (LOB_RESET_LANES)
@@ -223,26 +221,6 @@ template <class T> int dev_alloc(lob_engine* e, T** p, size_t count) {
 
 template <class T> int dev_alloc(lob_engine* e, GP<T>* p, size_t count) { return dev_alloc(e, &p->p, count); }
 
-// The registry kernels of the previous learner step (stream2) must be done before anything else looks at what they write.
-static int registry_join(lob_engine* e) {
-    if (e->reg_pending) {
-        HIPCHK(hipStreamWaitEvent(e->stream, e->ev_reg_done, 0));
-        e->reg_pending = false;
-    }
-    return LOB_OK;
-}
-// The step's new memo slots enter the tile registry on the second stream, beside kernels that follow on the main one (never
-// beside the learn kernel: its one block per CU wants the CU's LDS to itself).  LOB_REG_FORK=late: after the update instead of
-// after the learn kernels.
-static int registry_fork(lob_engine* e, hipStream_t st, const uint32_t* rnd, int par) {
-    HIPCHK(hipEventRecord(e->ev_reg_go, st));
-    HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_reg_go, 0));
-    hipLaunchKernelGGL(registry_kernel, dim3(64), dim3(256), 0, e->stream2, LOB_PS(e), rnd, par);
-    hipLaunchKernelGGL(registry_scan_kernel, dim3(256), dim3(256), 0, e->stream2, e->S, par);
-    HIPCHK(hipEventRecord(e->ev_reg_done, e->stream2));
-    e->reg_pending = true;
-    return LOB_OK;
-}
 // The device copy of DevState follows the host's (rare: a stream loaded, the exchange's buffers allocated, model_log switched on).
 int sync_state(lob_engine* e) {
     DevState now = e->S;
@@ -389,8 +367,6 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     HIPCHK_E(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming | hipEventDisableSystemFence));
     HIPCHK_E(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming | hipEventDisableSystemFence));
     HIPCHK_E(hipEventCreateWithFlags(&e->ev_stagger, hipEventDisableTiming | hipEventDisableSystemFence));
-    HIPCHK_E(hipEventCreateWithFlags(&e->ev_reg_go, hipEventDisableTiming | hipEventDisableSystemFence));
-    HIPCHK_E(hipEventCreateWithFlags(&e->ev_reg_done, hipEventDisableTiming | hipEventDisableSystemFence));
     HIPCHK_E(hipEventCreateWithFlags(&e->ev_rest_go, hipEventDisableTiming | hipEventDisableSystemFence));
     HIPCHK_E(hipEventCreateWithFlags(&e->ev_rest_done, hipEventDisableTiming | hipEventDisableSystemFence));
     // Runtime switches.  Honoured by every build: the A/B switches of first-class paths that the parity tests force on or off at
@@ -441,7 +417,6 @@ int lob_create(const lob_params* p, int32_t n_books, int32_t device, lob_engine*
     if (const char* g = getenv("LOB_NO_TLIGHT")) e->t_light = !(g[0] == '1');
     if (const char* g = getenv("LOB_Q_PAIR")) e->q_pair = !(g[0] == '0');
     if (const char* g = getenv("LOB_NO_FUSE")) e->no_fuse = g[0] == '1';
-    if (const char* g = getenv("LOB_REG_FORK")) e->reg_fork_late = exps && g[0] == 'l';
     if (const char* g = getenv("LOB_ENV_STEP")) e->env_step = !(exps && g[0] == '0');
     if (const char* g = getenv("LOB_INLINE_GENERAL")) e->inline_general = !(exps && g[0] == '0');
     if (const char* g = getenv("LOB_RESET_LANES")) { int v = atoi(g); if (v == 64 || (exps && (v == 16 || v == 32))) e->reset_lanes = v; }
@@ -788,8 +763,6 @@ void lob_destroy(lob_engine* e) {
     if (e->ev_fork) hipEventDestroy(e->ev_fork);
     if (e->ev_join) hipEventDestroy(e->ev_join);
     if (e->ev_stagger) hipEventDestroy(e->ev_stagger);
-    if (e->ev_reg_go) hipEventDestroy(e->ev_reg_go);
-    if (e->ev_reg_done) hipEventDestroy(e->ev_reg_done);
     if (e->rest_hint) hipHostFree(e->rest_hint);
     for (int i = 0; i < LOB_HINT_RING; i++) if (e->hint_ev[i]) hipEventDestroy(e->hint_ev[i]);
     if (e->ev_rest_go) hipEventDestroy(e->ev_rest_go);
@@ -1218,7 +1191,6 @@ int lob_reset(lob_engine* e) {
     HIPCHK(hipSetDevice(e->device));
     { int rc = finalize_episode(e); if (rc) return rc; }   // (the window sums of the episode that ends: on the stream it ran on)
     { int rc = stage_adopt(e); if (rc) return rc; }        // a stream handed over meanwhile (lob_stage_events) is this episode's
-    { int rc = registry_join(e); if (rc) return rc; }
     { int rc = sync_state(e); if (rc) return rc; }
     // the memo table starts empty every episode (reset_kernel voids every book's slot)
     HIPCHK(hipMemsetAsync(e->S.mk_hash, 0xff, (size_t)e->S.mk_slots * 8, e->stream));
@@ -1249,6 +1221,7 @@ int lob_reset(lob_engine* e) {
         HIPCHK(hipMemsetAsync(e->S.ow_tab, 0xff, (size_t)e->S.ow_slots * 8, e->stream));
         HIPCHK(hipMemsetAsync(e->S.amb_bits, 0, ((size_t)e->P.M / 32 + 1) * 4, e->stream));
         HIPCHK(hipMemsetAsync(e->S.amb_new_n, 0, 2 * sizeof(i32), e->stream));
+        e->reg_apar = 0;
         HIPCHK(hipMemsetAsync(e->S.amb_flag, 0, sizeof(i32), e->stream));
         HIPCHK(hipMemsetAsync(e->S.mk_all_n, 0, sizeof(i32), e->stream));
         HIPCHK(hipMemsetAsync(e->S.tr_cbslot, 0xff, (size_t)e->B * e->P.trace_gens * 4, e->stream));  // (slots of books that stopped stepping may be gone)
@@ -1434,6 +1407,7 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
         bool rest_pending = false;
         bool acc_fused = false;  // (this step: see the learn kernel's launch)
         bool rest_merged = false;  // ... and then trace_rest_kernel instead of trace_fast_kernel<., 2> + accumulate_kernel over its list
+        bool registered = false;   // this step's trace_lane_kernel launch carries the tile registry's blocks (its apply_kernel launch then carries the scan's)
         bool rest_side_now = false;
         const bool dq = e->P.algo == LOB_ALGO_DOUBLE_Q;  // (fast && dq: every step without usable hit lists takes the general act kernel over the whole batch)
         const int lpar = first ? (e->list_par ^= 1) : e->list_par;
@@ -1492,10 +1466,8 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
             if (fast) launch_memo(e, par, mode == 0 ? 0 : 1);  // learner: S0 under theta_t for learn_kernel; backtester: for the next act
             // (... and, which 0, the step's cb_par / cb_dense_on into the state's device-resident copy; without a memo launch:)
             else if (mode == 0 && e->P.combine) hipLaunchKernelGGL(step_words_kernel, dim3(1), dim3(1), 0, st, e->S_dev, e->S.cb_par, e->S.cb_dense_on);
-            // (the previous learner step's registry kernels have had the update kernels of their own step, and this step's env and
-            // memo kernels, to finish beside: what they write is read from here on -- the dup flags by the light trace step, the
-            // rest by trace_lane_kernel)
-            if (mode == 0) { int rc = registry_join(e); if (rc) return rc; }
+            // (the tile registry's entries for the slots that were new in the step before -- the extra blocks of its trace_lane_kernel
+            // and apply_kernel launches -- are read from here on: the dup flags by the light trace step, the rest by trace_lane_kernel)
             if (mode == 0 && fast) {
                 const bool tl = (e->P.algo == LOB_ALGO_QLAMBDA || dq) && e->t_light;
                 // Q(s', .) + TD error: a lane per book once the batch gives every CU a full block of them, else a wave per book
@@ -1520,7 +1492,10 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                             // (LOB_TS_GRID / LOB_TS_LDS, experiments: fewer, persistent blocks / dynamic LDS to throttle the occupancy -- halving
                             // it costs 28 %, a persistent grid changes nothing: NOTES.md "Round 5")
                             const int ts_full = (nb + LOB_TS_BLOCK / 32 - 1) / (LOB_TS_BLOCK / 32);
-                            hipLaunchKernelGGL(trace_lane_kernel<LOB_ALGO_SARSA>, dim3(e->ts_grid > 0 ? std::min(e->ts_grid, ts_full) : ts_full), dim3(LOB_TS_BLOCK), e->ts_lds, st, LOB_PS(e), lpar, sid, 0);
+                            // (its first LOB_REG_BLOCKS blocks: the tile registry for the memo slots that are new on this step's list)
+                            registered = true;
+                            hipLaunchKernelGGL(trace_lane_kernel<LOB_ALGO_SARSA>, dim3((e->ts_grid > 0 ? std::min(e->ts_grid, ts_full) : ts_full) + LOB_REG_BLOCKS), dim3(LOB_TS_BLOCK), e->ts_lds, st,
+                                               LOB_PS(e), lpar, sid, 0, rnd, par, e->reg_apar, LOB_REG_BLOCKS);
                             hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_SARSA, 1>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, LOB_PS(e), rnd, par, lpar, sid);
                         }
                         else hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_SARSA, 0>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, LOB_PS(e), rnd, par, lpar, sid);
@@ -1581,13 +1556,16 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                     }
                 }
                 if (learn_first) launch_traces();
-                if (e->P.sarsa_lanes && !e->reg_fork_late) { int rc = registry_fork(e, st, rnd, par); if (rc) return rc; }
                 if (fuse) {
                     TimedLaunch t(e, "trace_kernel", st);
                     // the listed books (their traces survive the step): a lane per generation, then the wave-per-book kernel for
                     // those the lane kernel hands on
-                    if (e->P.sarsa_lanes)
-                        hipLaunchKernelGGL(trace_lane_kernel<LOB_ALGO_QLAMBDA>, dim3(std::min(4 * e->n_cus, (nb + LOB_TS_BLOCK / 32 - 1) / (LOB_TS_BLOCK / 32))), dim3(LOB_TS_BLOCK), 0, st, LOB_PS(e), lpar, sid, acc_fused ? (rest_merged ? 2 : 1) : 0);
+                    if (e->P.sarsa_lanes) {
+                        // (its first LOB_REG_BLOCKS blocks: the tile registry for the memo slots that are new on this step's list)
+                        registered = true;
+                        hipLaunchKernelGGL(trace_lane_kernel<LOB_ALGO_QLAMBDA>, dim3(std::min(4 * e->n_cus, (nb + LOB_TS_BLOCK / 32 - 1) / (LOB_TS_BLOCK / 32)) + LOB_REG_BLOCKS), dim3(LOB_TS_BLOCK), 0, st,
+                                           LOB_PS(e), lpar, sid, acc_fused ? (rest_merged ? 2 : 1) : 0, rnd, par, e->reg_apar, LOB_REG_BLOCKS);
+                    }
                     // (rest_merged: what the lane kernel hands on is served by trace_rest_kernel, in the place of accumulate_kernel below)
                     if (!rest_merged) hipLaunchKernelGGL((trace_fast_kernel<LOB_ALGO_QLAMBDA, 2>), dim3(gt), dim3(LOB_TRACE_BLOCK), trace_lds_bytes(), st, LOB_PS(e), rnd, par, lpar, sid);
                 }
@@ -1670,9 +1648,11 @@ static int run_steps(lob_engine* e, int32_t n_steps, int mode, int half = 0) {
                 TimedLaunch t(e, "apply_kernel");
                 const int blocks = e->S.cb_segs;
                 // (dense_blocks -1: no slot has ever been given a dense id -- apply_kernel does not look any up)
-                hipLaunchKernelGGL(apply_kernel, dim3(blocks), dim3(256), 0, e->stream, LOB_PS(e), rnd, par, e->step_id, e->dense_ever ? dense_blocks : -1);
+                // (+ the indices the step's registry blocks -- trace_lane_kernel's launch -- found ambiguous, marked in every registered slot)
+                hipLaunchKernelGGL(apply_kernel, dim3(blocks + (registered ? LOB_SCAN_BLOCKS : 0)), dim3(256), 0, e->stream, LOB_PS(e), rnd, par, e->step_id,
+                                   e->dense_ever ? dense_blocks : -1, e->reg_apar);
+                if (registered) e->reg_apar ^= 1;
             }
-            if (e->P.sarsa_lanes && e->reg_fork_late) { int rc = registry_fork(e, e->stream, rnd, par); if (rc) return rc; }
         } else if (mode == 0) {
             TimedLaunch t(e, "update_kernel");
             hipLaunchKernelGGL(update_kernel, dim3(grid_waves(e->B)), dim3(LOB_BLOCK), 0, e->stream, LOB_PS(e), par, e->step_id);
@@ -1932,7 +1912,6 @@ int lob_get_counters(lob_engine* e, int64_t out[4]) {
 int lob_get_path_stats(lob_engine* e, int64_t out[8]) {
     if (!e || !out) return LOB_EINVAL;
     HIPCHK(hipSetDevice(e->device));
-    { int rc = registry_join(e); if (rc) return rc; }
     i64 c[16];
     i32 n_all = 0, flag = 0, mk_n[2] = {0, 0};
     { int rc = read_counters(e, c); if (rc) return rc; }

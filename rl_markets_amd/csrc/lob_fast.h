@@ -784,11 +784,140 @@ __global__ void __launch_bounds__(LOB_LIGHT_BLOCK) trace_light_kernel(LOB_PS_ARG
 // wave-per-book kernel: SARSA on `tr_list` (trace_fast_kernel<SARSA, 1>), Q(lambda) on `tr_list2` (trace_fast_kernel<.., 2>).
 // Same stores as learn_traces for the books it takes.
 #define LOB_TS_BLOCK 256
+#define LOB_TS_BLOCK_WAVES (LOB_TS_BLOCK / 64)
+// Tile registry (lob_state.h ow_tab): the memo slots on this step's list whose tiles are not registered yet -- new triples, a few
+// per step, dozens in an episode's first steps -- enter their 288 tiles, learn which of them lie on an index another tile uses
+// (mk_amb) and whether two of their own coincide (mk_ident[3]).  One wave per slot.  Runs as the FIRST LOB_REG_BLOCKS blocks of
+// trace_lane_kernel's launch, beside the blocks that read what it writes: nothing of it is needed before the next step's trace
+// kernel (a slot new in step t is nobody's last_state before step t + 1; bits that appear early in mk_amb of older slots only
+// widen the set of tile pairs the lane kernel compares index by index, and equal indices are the ground truth; a slot counts
+// as registered -- mk_tiles_ok bit 1 -- behind a fence, last).  Until round 6 a kernel of its own on the engine's second
+// stream, whose fork and join were the main stream's only cross-stream operations: two gaps of 5-6 us per step between kernels
+// that otherwise follow each other within 0.0 us -- and 40-70 us long, a chain of round trips: a lane's five compare-and-swaps
+// one after the other, each followed by a load (now: all ten in flight at once, tile_register_ask), and 1 600 compares per lane
+// to find two equal tiles among the 288 (now: a 512-entry hash set per wave in LDS, filled while the swaps are under way).
+#define LOB_REG_BLOCKS 128   /* blocks of trace_lane_kernel's launch that run registry_block */
+#define LOB_SCAN_BLOCKS 256  /* blocks of apply_kernel's launch that run registry_scan_block (lob_kernels.h) */
+struct RegistryLds {
+    uint32_t rnd[2048 + 32];
+    uint32_t seen[LOB_TS_BLOCK_WAVES][512];
+};
+__device__ inline void registry_block(const DevParams& P, const DevState& S, const uint32_t* __restrict__ rnd_g, RegistryLds& L, int par, int apar, int blk, int nblk) {
+    // (a short chain of dependent look-ups -- count -> list entry -> registered? -> identity: the first entry is asked for with
+    // the count, as memo_kernel does, and an entry's identity with its flags)
+    const int wave0 = blk * LOB_TS_BLOCK_WAVES + (int)(threadIdx.x >> 6);
+    const int s_first = S.mk_list[(size_t)par * S.mk_slots + (wave0 < S.mk_slots ? wave0 : 0)];
+    int count = S.mk_count[par];
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(rnd_g);
+        uint4* dst = reinterpret_cast<uint4*>(L.rnd);
+        const uint4 r0 = src[threadIdx.x], r1 = src[threadIdx.x + 256];
+        dst[threadIdx.x] = r0; dst[threadIdx.x + 256] = r1;
+        if (threadIdx.x < 27) L.rnd[2048 + threadIdx.x] = rnd_g[2048 + threadIdx.x];
+    }
+    __syncthreads();
+    const uint32_t* rnd = L.rnd;
+    const int lane = threadIdx.x & 63, j = lane & 31;
+    const bool hi = lane >= 32;
+    const int wave = blk * LOB_TS_BLOCK_WAVES + (threadIdx.x >> 6), n_waves = nblk * LOB_TS_BLOCK_WAVES;
+    uint32_t* seen = L.seen[threadIdx.x >> 6];
+    const uint32_t M = (uint32_t)P.M;
+    if (count > S.mk_slots) count = S.mk_slots;
+    for (int i = wave; i < count; i += n_waves) {
+        const int s = i == wave ? s_first : S.mk_list[(size_t)par * S.mk_slots + i];
+        const int ok_bits = S.mk_tiles_ok[s];
+        const int4 id = *reinterpret_cast<const int4*>(S.mk_ident + (size_t)s * 4);
+        if (ok_bits & 2) continue;
+#pragma unroll
+        for (int x = 0; x < 8; x++) seen[x * 64 + lane] = 0xffffffffu;
+        uint32_t sum = 0;
+        {
+            int base = j;
+            sum = mod_add(sum, rnd[(tile_coord(id.x, base) + 449 * 0) & 2047], M); base += 2 * j;
+            sum = mod_add(sum, rnd[(tile_coord(id.y, base) + 449 * 1) & 2047], M); base += 2 * j;
+            sum = mod_add(sum, rnd[(tile_coord(id.z, base) + 449 * 2) & 2047], M);
+            sum = mod_add(sum, rnd[(j + 449 * 3) & 2047], M);
+        }
+        // a lane's five tiles (action (hi ? 5 : 0) + k of tiling j; lanes 32-63 have four): every first probe under way at once
+        i32 tl[5];
+        u64 first_old[5];
+        uint32_t first_word[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int a = (hi ? 5 : 0) + k;
+            const i32 tile = tile_index(sum, rnd[2048 + (a < LOB_N_ACTIONS ? a : 0)], M);
+            tl[k] = tile;
+            first_old[k] = 0; first_word[k] = 0;
+            if (a < LOB_N_ACTIONS) {
+                S.mk_tiles[((size_t)s * LOB_N_ACTIONS + a) * 32 + j] = tile;  // (memo_kernel writes the same values: registry_scan_block must find them)
+                tile_register_ask(S, s, a, j, tile, first_old[k], first_word[k]);
+            }
+        }
+        // do two of the triple's 288 tiles coincide?  (mk_ident[3]: the lane trace kernel takes only triples known to be free of
+        // that; the wave-per-book kernel would find out the first time it builds the set -- a step later, for every book that
+        // starts from this triple.)  Every tile goes into the wave's hash set; the second of two equal ones finds the first.
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local");
+        __builtin_amdgcn_wave_barrier();
+        bool dupl = false;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            if ((hi ? 5 : 0) + k >= LOB_N_ACTIONS) continue;
+            const uint32_t v = (uint32_t)tl[k];
+            uint32_t hh = (v * 2654435761u) >> 23;
+            for (int probe = 0; probe < 512; probe++) {
+                const uint32_t old = atomicCAS(&seen[hh], 0xffffffffu, v);
+                if (old == 0xffffffffu) break;
+                if (old == v) { dupl = true; break; }
+                hh = (hh + 1) & 511u;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local");
+        __builtin_amdgcn_wave_barrier();
+        bool reg_fail = false;
+        uint32_t my_amb = 0;  // bit k: this lane's tile of action (hi ? 5 : 0) + k lies on an ambiguous index
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int a = (hi ? 5 : 0) + k;
+            if (a < LOB_N_ACTIONS) {
+                const int r = tile_register_impl<true>(S, id, s, a, j, tl[k], apar, first_old[k], first_word[k]);
+                reg_fail |= r < 0;
+                if (r > 0) my_amb |= 1u << k;
+            }
+        }
+        const bool any_dup = __ballot(dupl) != 0;
+        const bool failed = __ballot(reg_fail) != 0;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const u64 mb = __ballot((my_amb >> k) & 1u);
+            if (lane == 0) {
+                S.mk_amb[(size_t)s * LOB_N_ACTIONS + k] = (uint32_t)mb;
+                if (k < 4) S.mk_amb[(size_t)s * LOB_N_ACTIONS + 5 + k] = (uint32_t)(mb >> 32);
+            }
+        }
+        if (lane == 0) {
+            S.mk_ident[(size_t)s * 4 + 3] = any_dup ? 2 : 1;
+            __threadfence();
+            if (!failed) {
+                const int pos = atomicAdd(S.mk_all_n, 1);
+                S.mk_all[pos] = s;  // (pos < mk_slots: a slot registers once per episode)
+                atomicOr(&S.mk_tiles_ok[s], 2);
+            }
+        }
+    }
+}
+
 // acc_fuse (Q(lambda)): every generation's update is added to its slot as soon as the slot is known (acc_generation); a book
 // the learn kernel handed back (its TD error is not known yet: acc_pend) or this kernel hands on goes on acc_list.
 template <int ALGO>
-__global__ void __launch_bounds__(LOB_TS_BLOCK, 5) trace_lane_kernel(LOB_PS_ARGS, int lpar, int sid, int acc_fuse) {
+__global__ void __launch_bounds__(LOB_TS_BLOCK, 5) trace_lane_kernel(LOB_PS_ARGS, int lpar, int sid, int acc_fuse, const uint32_t* __restrict__ rnd_g, int par, int apar,
+                                                                     int reg_blocks) {
     LOB_PS_REFS
+    if ((int)blockIdx.x < reg_blocks) {  // the launch's first blocks: the tile registry
+        __shared__ RegistryLds reg_lds;
+        registry_block(P, S, rnd_g, reg_lds, par, apar, (int)blockIdx.x, reg_blocks);
+        return;
+    }
+    const int bid = (int)blockIdx.x - reg_blocks, n_blocks = (int)gridDim.x - reg_blocks;
     constexpr bool QL = ALGO == LOB_ALGO_QLAMBDA;
     const int lane = threadIdx.x & 63, k = lane & 31, half = lane >> 5, grp = threadIdx.x >> 5;
     const int n_todo = QL ? S.tr_list_n[lpar] : S.B;
@@ -797,7 +926,7 @@ __global__ void __launch_bounds__(LOB_TS_BLOCK, 5) trace_lane_kernel(LOB_PS_ARGS
     const int lim = LOB_TILE_PLAIN_MIN;  // (below: tile_coord's wrap-around branch -- a NaN variable)
     const bool reg_ok = S.amb_flag[0] == 0;
 #pragma unroll 1
-    for (int t0 = blockIdx.x * (LOB_TS_BLOCK / 32); t0 < n_todo; t0 += gridDim.x * (LOB_TS_BLOCK / 32)) {
+    for (int t0 = bid * (LOB_TS_BLOCK / 32); t0 < n_todo; t0 += n_blocks * (LOB_TS_BLOCK / 32)) {
         const int t = t0 + grp;
         const bool in = t < n_todo;
         const int ent = QL ? S.tr_list[in ? t : 0] : t;

@@ -2040,6 +2040,38 @@ __global__ void __launch_bounds__(256) reduce_dense_kernel(DevState S, int dense
 }
 #endif
 
+// ... and the indices that launch found ambiguous for the first time are marked in every registered slot that holds them (the
+// slots registered since then know already: tile_register looks at the bitmap).  LOB_SCAN_BLOCKS extra blocks of apply_kernel's
+// launch, behind the launch that registered (trace_lane_kernel's: registry_block, lob_fast.h).
+#if LOB_IN_MAIN
+__device__ inline void registry_scan_block(const DevState& S, int par /* of the registry launch, not the step's */, int blk, int nblk) {
+    int n_new = S.amb_new_n[par];
+    if (n_new > S.amb_cap) n_new = S.amb_cap;
+    if (blk == 0 && threadIdx.x == 0) S.amb_new_n[par ^ 1] = 0;  // (consumed by the step before this one)
+    if (n_new == 0) return;
+    const int lane = threadIdx.x & 63, j = lane & 31;
+    const bool hi = lane >= 32;
+    const int wave = blk * 4 + (threadIdx.x >> 6), n_waves = nblk * 4;
+    const int n_all = S.mk_all_n[0];
+    const i32* nw = S.amb_new + (size_t)par * S.amb_cap;
+    for (int i = wave; i < n_all; i += n_waves) {
+        const int s = S.mk_all[i];
+        i32 tl[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int a = (hi ? 5 : 0) + k;
+            tl[k] = a < LOB_N_ACTIONS ? S.mk_tiles[((size_t)s * LOB_N_ACTIONS + a) * 32 + j] : -1;
+        }
+        for (int e = 0; e < n_new; e++) {
+            const i32 f = nw[e];  // (wave-uniform)
+#pragma unroll
+            for (int k = 0; k < 5; k++)
+                if (tl[k] == f) atomicOr(&S.mk_amb[(size_t)s * LOB_N_ACTIONS + (hi ? 5 : 0) + k], 1u << j);
+        }
+    }
+}
+#endif
+
 // apply_kernel: one wave per occupied slot (the step's list, lob_learn.h).  Touched this step: theta[tile] += the summed update
 // for the live tiles of the slot's generation -- the 32 indices follow from its identity (quantised triple + action; all 0 for
 // a constructor-zero State: learn_traces) --, maintain the written-weights map and the carry-over filter, hand the slot on to
@@ -2049,13 +2081,18 @@ __global__ void __launch_bounds__(256) reduce_dense_kernel(DevState S, int dense
 // LOB_ACD_GROUPS partial sums of cb_red at its id (lane x reads group x's; LOB_ACD_MARK = no block of the group had a term for
 // it), and counts as touched if any holds a term.  A slot that is freed hands its id back to the list it came from.  (< 0: no
 // slot has ever been given an id -- nothing is looked up.)
-__global__ void __launch_bounds__(256) apply_kernel(LOB_PS_ARGS, const uint32_t* __restrict__ rnd_g, int par, int sid, int dense_blocks) {
+__global__ void __launch_bounds__(256) apply_kernel(LOB_PS_ARGS, const uint32_t* __restrict__ rnd_g, int par, int sid, int dense_blocks, int apar) {
     LOB_PS_REFS
     __shared__ uint32_t rnd[2048 + 32];
     __shared__ int n_surv;
+    const int segs = S.cb_segs;
+    if ((int)blockIdx.x >= segs) {  // the launch's extra blocks: registry_scan_block above
+        registry_scan_block(S, apar, (int)blockIdx.x - segs, (int)gridDim.x - segs);
+        return;
+    }
     // one block per segment of the table: its list, its survivors -- no counter shared between blocks
-    const int seg = par * S.cb_segs + blockIdx.x, seg_next = (par ^ 1) * S.cb_segs + blockIdx.x, cap = S.cb_slots / S.cb_segs;
-    apply_deferred_generations(P, S, par, sid, (int)(blockIdx.x * 4 + (threadIdx.x >> 6)), (int)(gridDim.x * 4), (int)(threadIdx.x & 63));
+    const int seg = par * segs + blockIdx.x, seg_next = (par ^ 1) * segs + blockIdx.x, cap = S.cb_slots / segs;
+    apply_deferred_generations(P, S, par, sid, (int)(blockIdx.x * 4 + (threadIdx.x >> 6)), segs * 4, (int)(threadIdx.x & 63));
     const int count = S.cb_count[seg];
     if (count == 0) return;  // (block-uniform)
     {
@@ -2243,7 +2280,7 @@ __global__ void __launch_bounds__(256) memo_kernel(DevParams P, DevState S, cons
         }
         if (fill && lane == 0) {
             __threadfence();  // (read by a LATER kernel only; the flag just must not precede the tiles of another wave's view: one wave per slot)
-            atomicOr(&S.mk_tiles_ok[s], 1);  // (bit 1 belongs to registry_kernel, which may run beside this launch)
+            atomicOr(&S.mk_tiles_ok[s], 1);  // (bit 1 belongs to registry_block)
         }
 #pragma unroll
         for (int k = 0; k < 5; k++) {
@@ -2291,122 +2328,6 @@ __global__ void __launch_bounds__(256) memo_kernel(DevParams P, DevState S, cons
         }
     } else if (blockIdx.x == 0 && threadIdx.x == 0) {
         S.mk_markcount[0] = 0;
-    }
-}
-#endif
-
-// Tile registry (lob_state.h ow_tab; trace_lane_kernel): the memo slots on this step's list whose tiles are not registered yet --
-// new triples, a few dozen per step -- enter their 288 tiles, learn which of them lie on an index another tile uses (mk_amb) and
-// whether two of their own coincide (mk_ident[3]).  One wave per slot.  Runs on the engine's SECOND stream beside the step's
-// learner kernels: nothing of what it writes is needed before the next step's trace kernel (a slot new in step t is nobody's
-// last_state before step t + 1; bits that appear early in mk_amb of older slots only widen the set of tile pairs the lane
-// kernel compares index by index, and equal indices are the ground truth).
-#if LOB_IN_MAIN
-__global__ void __launch_bounds__(256) registry_kernel(LOB_PS_ARGS, const uint32_t* __restrict__ rnd_g, int par) {
-    LOB_PS_REFS
-    __shared__ uint32_t rnd[2048 + 32];
-    {
-        const uint4* src = reinterpret_cast<const uint4*>(rnd_g);
-        uint4* dst = reinterpret_cast<uint4*>(rnd);
-        const uint4 r0 = src[threadIdx.x], r1 = src[threadIdx.x + 256];
-        dst[threadIdx.x] = r0; dst[threadIdx.x + 256] = r1;
-        if (threadIdx.x < 27) rnd[2048 + threadIdx.x] = rnd_g[2048 + threadIdx.x];
-    }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, j = lane & 31;
-    const bool hi = lane >= 32;
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
-    const uint32_t M = (uint32_t)P.M;
-    int count = S.mk_count[par];
-    if (count > S.mk_slots) count = S.mk_slots;
-    for (int i = wave; i < count; i += n_waves) {
-        const int s = S.mk_list[(size_t)par * S.mk_slots + i];
-        if (S.mk_tiles_ok[s] & 2) continue;
-        const int4 id = *reinterpret_cast<const int4*>(S.mk_ident + (size_t)s * 4);
-        uint32_t sum = 0;
-        {
-            int base = j;
-            sum = mod_add(sum, rnd[(tile_coord(id.x, base) + 449 * 0) & 2047], M); base += 2 * j;
-            sum = mod_add(sum, rnd[(tile_coord(id.y, base) + 449 * 1) & 2047], M); base += 2 * j;
-            sum = mod_add(sum, rnd[(tile_coord(id.z, base) + 449 * 2) & 2047], M);
-            sum = mod_add(sum, rnd[(j + 449 * 3) & 2047], M);
-        }
-        bool reg_fail = false;
-        uint32_t my_amb = 0;  // bit k: this lane's tile of action (hi ? 5 : 0) + k lies on an ambiguous index
-        i32 tl[5];
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            const int a = (hi ? 5 : 0) + k;
-            const i32 tile = tile_index(sum, rnd[2048 + (a < LOB_N_ACTIONS ? a : 0)], M);
-            tl[k] = a < LOB_N_ACTIONS ? tile : -1 - lane;  // (the idle fifth slot of lanes 32-63: equal to nothing)
-            if (a < LOB_N_ACTIONS) {
-                S.mk_tiles[((size_t)s * LOB_N_ACTIONS + a) * 32 + j] = tile;  // (memo_kernel writes the same values: registry_scan_kernel must find them)
-                const int r = tile_register(S, id, s, a, j, tile, par);
-                reg_fail |= r < 0;
-                if (r > 0) my_amb |= 1u << k;
-            }
-        }
-        // do two of the triple's 288 tiles coincide?  (mk_ident[3]: the lane trace kernel takes only triples known to be free of
-        // that; the wave-per-book kernel would find out the first time it builds the set -- a step later, for every book that
-        // starts from this triple)
-        bool dupl = false;
-#pragma unroll
-        for (int k2 = 0; k2 < 5; k2++) {
-            for (int l = 0; l < 64; l++) {
-                const i32 t2 = __builtin_amdgcn_readlane(tl[k2], l);
-#pragma unroll
-                for (int k = 0; k < 5; k++) dupl |= tl[k] == t2 && !(k == k2 && l == lane);
-            }
-        }
-        const bool any_dup = __ballot(dupl) != 0;
-        const bool failed = __ballot(reg_fail) != 0;
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            const u64 mb = __ballot((my_amb >> k) & 1u);
-            if (lane == 0) {
-                S.mk_amb[(size_t)s * LOB_N_ACTIONS + k] = (uint32_t)mb;
-                if (k < 4) S.mk_amb[(size_t)s * LOB_N_ACTIONS + 5 + k] = (uint32_t)(mb >> 32);
-            }
-        }
-        if (lane == 0) {
-            S.mk_ident[(size_t)s * 4 + 3] = any_dup ? 2 : 1;
-            __threadfence();
-            if (!failed) {
-                const int pos = atomicAdd(S.mk_all_n, 1);
-                S.mk_all[pos] = s;  // (pos < mk_slots: a slot registers once per episode)
-                atomicOr(&S.mk_tiles_ok[s], 2);
-            }
-        }
-    }
-}
-#endif
-// ... and the indices that launch found ambiguous for the first time are marked in every registered slot that holds them (the
-// slots registered since then know already: tile_register looks at the bitmap).  Same stream, right after it.
-#if LOB_IN_MAIN
-__global__ void __launch_bounds__(256) registry_scan_kernel(DevState S, int par) {
-    int n_new = S.amb_new_n[par];
-    if (n_new > S.amb_cap) n_new = S.amb_cap;
-    if (blockIdx.x == 0 && threadIdx.x == 0) S.amb_new_n[par ^ 1] = 0;  // (consumed by the previous step's launch)
-    if (n_new == 0) return;
-    const int lane = threadIdx.x & 63, j = lane & 31;
-    const bool hi = lane >= 32;
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
-    const int n_all = S.mk_all_n[0];
-    const i32* nw = S.amb_new + (size_t)par * S.amb_cap;
-    for (int i = wave; i < n_all; i += n_waves) {
-        const int s = S.mk_all[i];
-        i32 tl[5];
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            const int a = (hi ? 5 : 0) + k;
-            tl[k] = a < LOB_N_ACTIONS ? S.mk_tiles[((size_t)s * LOB_N_ACTIONS + a) * 32 + j] : -1;
-        }
-        for (int e = 0; e < n_new; e++) {
-            const i32 f = nw[e];  // (wave-uniform)
-#pragma unroll
-            for (int k = 0; k < 5; k++)
-                if (tl[k] == f) atomicOr(&S.mk_amb[(size_t)s * LOB_N_ACTIONS + (hi ? 5 : 0) + k], 1u << j);
-        }
     }
 }
 #endif

@@ -64,7 +64,7 @@ __device__ inline i32 tile_index(uint32_t base_m, uint32_t term_m, uint32_t M) {
 // the same cell of tiling j when, for the three coordinates i, the cell numbers ((q_i - (1 + 2 i) j) >> 5) agree mod 64: the
 // hash reads the cell's coordinate & 2047 (tile_base_m), so two tiles of one tiling and one action whose cells agree that
 // far ARE one table term sum, one weight index.  Bit j of the result: same cell in tiling j.  (trace_lane_kernel: which tiles
-// of an old generation the new state re-sets or clears, without the indices; registry_kernel's tile_same_cell is the same
+// of an old generation the new state re-sets or clears, without the indices; the registry's tile_same_cell is the same
 // test through tile_coord, for any coordinate.)
 #define LOB_TILE_PLAIN_MIN ((int)0x80000400)
 __device__ inline uint32_t tile_same_cell_mask(int a0, int a1, int a2, int b0, int b1, int b2) {
@@ -90,15 +90,20 @@ __device__ inline bool tile_same_cell(const int4& x, const int4& y, int j) {
 // Tile registry (lob_state.h ow_tab): enter tile (slot s of triple `id`, action a, tiling j) with weight index `tile`.  Returns 1 if the index
 // is (now) known to be ambiguous, 0 if not, -1 if the table had no room (the slot then stays unregistered: the lane path
 // leaves every book that meets it to the wave-per-book kernel).
-__device__ inline int tile_register(const DevState& S, const int4& id, int s, int a, int j, i32 tile, int par) {
+// FIRST: the first probe's compare-and-swap and the index's word of the ambiguity bitmap have been asked for by the caller
+// (tile_register_ask: registry_block puts a lane's five tiles in flight at once instead of waiting for them one after the
+// other); `first_word` may be older than the swap -- an index that turns ambiguous between the two is on amb_new, and the scan
+// behind the registry marks it in every registered slot.
+template <bool FIRST>
+__device__ inline int tile_register_impl(const DevState& S, const int4& id, int s, int a, int j, i32 tile, int par, u64 first_old, uint32_t first_word) {
     const u64 want = ((u64)(uint32_t)tile << 32) | (u64)(uint32_t)(s * (LOB_N_ACTIONS * 32) + a * 32 + j);
     const uint32_t mask = (uint32_t)(S.ow_slots - 1);
     uint32_t h = ((uint32_t)tile * 2654435761u) & mask;
     const uint32_t bit = 1u << ((uint32_t)tile & 31);
     uint32_t* word = S.amb_bits + ((uint32_t)tile >> 5);
     for (int probe = 0; probe < 64; probe++) {
-        const u64 old = atomicCAS((unsigned long long*)&S.ow_tab[h], ~0ull, (unsigned long long)want);
-        if (old == ~0ull) return (*word & bit) ? 1 : 0;  // first tile on this index (the bit is clear unless the table lost an entry)
+        const u64 old = (FIRST && probe == 0) ? first_old : (u64)atomicCAS((unsigned long long*)&S.ow_tab[h], ~0ull, (unsigned long long)want);
+        if (old == ~0ull) return (((FIRST && probe == 0) ? first_word : *word) & bit) ? 1 : 0;  // first tile on this index (the bit is clear unless the table lost an entry)
         if ((uint32_t)(old >> 32) == (uint32_t)tile) {
             const uint32_t ref = (uint32_t)old;
             const int s2 = (int)(ref / (LOB_N_ACTIONS * 32)), r2 = (int)(ref % (LOB_N_ACTIONS * 32));
@@ -119,6 +124,15 @@ __device__ inline int tile_register(const DevState& S, const int4& id, int s, in
         h = (h + 1) & mask;
     }
     return -1;
+}
+__device__ inline int tile_register(const DevState& S, const int4& id, int s, int a, int j, i32 tile, int par) {
+    return tile_register_impl<false>(S, id, s, a, j, tile, par, 0ull, 0u);
+}
+__device__ inline void tile_register_ask(const DevState& S, int s, int a, int j, i32 tile, u64& first_old, uint32_t& first_word) {
+    const u64 want = ((u64)(uint32_t)tile << 32) | (u64)(uint32_t)(s * (LOB_N_ACTIONS * 32) + a * 32 + j);
+    const uint32_t h = ((uint32_t)tile * 2654435761u) & (uint32_t)(S.ow_slots - 1);
+    first_old = (u64)atomicCAS((unsigned long long*)&S.ow_tab[h], ~0ull, (unsigned long long)want);
+    first_word = S.amb_bits[(uint32_t)tile >> 5];
 }
 
 #endif

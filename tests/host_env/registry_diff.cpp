@@ -1,5 +1,5 @@
 // TEST INFRASTRUCTURE ONLY.  The tile registry's invariant (rl_markets_amd/csrc/lob_tiles.h tile_register, the engine's own
-// function compiled as host code through tests/host_env/shim; registry_kernel's per-slot loop and registry_scan_kernel are
+// function compiled as host code through tests/host_env/shim; registry_block's per-slot loop (lob_fast.h) and registry_scan_block (lob_kernels.h) are
 // restated serially here): after every step's registrations and scan,
 //     two registered tiles share a weight index and are NOT the same tile (tiling, action, cell)
 //         =>  both carry their bit in mk_amb,
@@ -69,7 +69,7 @@ int main(int argc, char** argv) {
         int done = 0, par = 0;
         for (int step = 0; step < n_steps; step++) {
             const int upto = step == n_steps - 1 ? n_slots : std::min(n_slots, done + ri(1, n_slots));
-            // ---- registry_kernel: a "wave" per new slot, its 288 tiles in (action, tiling) order of the lanes' loop ----
+            // ---- registry_block: a "wave" per new slot, its 288 tiles in (action, tiling) order of the lanes' loop ----
             for (; done < upto; done++) {
                 const int s = order[done];
                 uint32_t bits[9] = {0};
@@ -86,7 +86,7 @@ int main(int argc, char** argv) {
                 for (int a = 0; a < 9; a++) mk_amb[(size_t)s * 9 + a] = bits[a];
                 mk_all.push_back(s);
             }
-            // ---- registry_scan_kernel ----
+            // ---- registry_scan_block ----
             const int n_new = amb_new_n[par];
             amb_new_n[par ^ 1] = 0;
             for (int e = 0; e < n_new; e++) {

@@ -53,8 +53,8 @@ def test_same_cell_arithmetic_equals_tile_coord_and_implies_same_index(tmp_path)
 
 
 def test_tile_registry_flags_every_shared_index(tmp_path):
-    """The tile registry (lob_tiles.h tile_register -- the engine's own function --, registry_kernel's per-slot loop and
-    registry_scan_kernel restated serially in tests/host_env/registry_diff.cpp): whenever two registered tiles share a weight
+    """The tile registry (lob_tiles.h tile_register -- the engine's own function --, registry_block's per-slot loop and
+    registry_scan_block restated serially in tests/host_env/registry_diff.cpp): whenever two registered tiles share a weight
     index without being the same tile, both carry their bit in mk_amb -- after every step's registrations and scan, for random
     batches of memo slots in random order (cells that coincide, twins 2 048 apart, three and more tiles on one index, tables
     from 4 099 to 1 M weights) -- and no tile is flagged without reason.  That invariant is what allows trace_lane_kernel to

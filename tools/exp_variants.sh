@@ -8,7 +8,7 @@
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 CS=rl_markets_amd/csrc
 # (the library's translation units compiled in parallel and linked: __graft_entry__.build_engine; the kernel variants measured
-# and lost -- env_compact_kernel, the two-wave pre-pass, 32-lane env_step_kernel, two book groups, LOB_REG_FORK, LOB_ACC_REPS > 8,
+# and lost -- env_compact_kernel, the two-wave pre-pass, 32-lane env_step_kernel, two book groups, LOB_ACC_REPS > 8,
 # 16 / 32-lane reset kernels -- exist only with -DLOB_EXPERIMENTS:   tools/exp_variants.sh build "exp:-DLOB_EXPERIMENTS"
 # then LOB_ENGINE_LIB=$PWD/rl_markets_amd/csrc/_var/exp/liblob_engine.so python -m pytest tests -m gpu -k "books_per_wave or two_waves")
 build_one() {
