@@ -798,15 +798,30 @@ __global__ void __launch_bounds__(LOB_LIGHT_BLOCK) trace_light_kernel(LOB_PS_ARG
 // to find two equal tiles among the 288 (now: a 512-entry hash set per wave in LDS, filled while the swaps are under way).
 #define LOB_REG_BLOCKS 128   /* blocks of trace_lane_kernel's launch that run registry_block */
 #define LOB_SCAN_BLOCKS 256  /* blocks of apply_kernel's launch that run registry_scan_block (lob_kernels.h) */
+// (a wave's hash set of the tiles it has met: true if `v` was there already)
+__device__ __forceinline__ bool registry_seen(uint32_t* seen /* LDS, 512 entries, 0xffffffff = free */, uint32_t v) {
+    uint32_t hh = (v * 2654435761u) >> 23;
+    for (int probe = 0; probe < 512; probe++) {
+        const uint32_t old = atomicCAS(&seen[hh], 0xffffffffu, v);
+        if (old == 0xffffffffu) return false;
+        if (old == v) return true;
+        hh = (hh + 1) & 511u;
+    }
+    return false;
+}
 struct RegistryLds {
     uint32_t rnd[2048 + 32];
     uint32_t seen[LOB_TS_BLOCK_WAVES][512];
 };
-__device__ inline void registry_block(const DevParams& P, const DevState& S, const uint32_t* __restrict__ rnd_g, RegistryLds& L, int par, int apar, int blk, int nblk) {
+// (always inlined: as a called function -- shared by the kernel's two instantiations -- it gave the whole kernel a stack, 96
+// registers instead of 82, and itself generic pointers into LDS)
+__device__ __forceinline__ void registry_block(const DevParams& P, const DevState& S, const uint32_t* __restrict__ rnd_g, RegistryLds& L, int par, int apar, int blk, int nblk) {
     // (a short chain of dependent look-ups -- count -> list entry -> registered? -> identity: the first entry is asked for with
     // the count, as memo_kernel does, and an entry's identity with its flags)
     const int wave0 = blk * LOB_TS_BLOCK_WAVES + (int)(threadIdx.x >> 6);
     const int s_first = S.mk_list[(size_t)par * S.mk_slots + (wave0 < S.mk_slots ? wave0 : 0)];
+    const int wave1 = wave0 + nblk * LOB_TS_BLOCK_WAVES;   // (a step's list is longer than the launch has waves: the second entry too)
+    const int s_second = S.mk_list[(size_t)par * S.mk_slots + (wave1 < S.mk_slots ? wave1 : 0)];
     int count = S.mk_count[par];
     {
         const uint4* src = reinterpret_cast<const uint4*>(rnd_g);
@@ -824,7 +839,7 @@ __device__ inline void registry_block(const DevParams& P, const DevState& S, con
     const uint32_t M = (uint32_t)P.M;
     if (count > S.mk_slots) count = S.mk_slots;
     for (int i = wave; i < count; i += n_waves) {
-        const int s = i == wave ? s_first : S.mk_list[(size_t)par * S.mk_slots + i];
+        const int s = i == wave ? s_first : i == wave + n_waves ? s_second : S.mk_list[(size_t)par * S.mk_slots + i];
         const int ok_bits = S.mk_tiles_ok[s];
         const int4 id = *reinterpret_cast<const int4*>(S.mk_ident + (size_t)s * 4);
         if (ok_bits & 2) continue;
@@ -860,17 +875,8 @@ __device__ inline void registry_block(const DevParams& P, const DevState& S, con
         __builtin_amdgcn_wave_barrier();
         bool dupl = false;
 #pragma unroll
-        for (int k = 0; k < 5; k++) {
-            if ((hi ? 5 : 0) + k >= LOB_N_ACTIONS) continue;
-            const uint32_t v = (uint32_t)tl[k];
-            uint32_t hh = (v * 2654435761u) >> 23;
-            for (int probe = 0; probe < 512; probe++) {
-                const uint32_t old = atomicCAS(&seen[hh], 0xffffffffu, v);
-                if (old == 0xffffffffu) break;
-                if (old == v) { dupl = true; break; }
-                hh = (hh + 1) & 511u;
-            }
-        }
+        for (int k = 0; k < 5; k++)
+            if ((hi ? 5 : 0) + k < LOB_N_ACTIONS) dupl |= registry_seen(seen, (uint32_t)tl[k]);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local");
         __builtin_amdgcn_wave_barrier();
         bool reg_fail = false;
@@ -896,9 +902,11 @@ __device__ inline void registry_block(const DevParams& P, const DevState& S, con
         }
         if (lane == 0) {
             S.mk_ident[(size_t)s * 4 + 3] = any_dup ? 2 : 1;
+            // (its place on the list of registered slots is asked for in front of the fence: one round trip instead of two.  The
+            // list is read by the scan blocks of a later launch.)
+            const int pos = failed ? 0 : atomicAdd(S.mk_all_n, 1);
             __threadfence();
             if (!failed) {
-                const int pos = atomicAdd(S.mk_all_n, 1);
                 S.mk_all[pos] = s;  // (pos < mk_slots: a slot registers once per episode)
                 atomicOr(&S.mk_tiles_ok[s], 2);
             }

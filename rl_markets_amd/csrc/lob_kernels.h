@@ -2085,14 +2085,15 @@ __global__ void __launch_bounds__(256) apply_kernel(LOB_PS_ARGS, const uint32_t*
     LOB_PS_REFS
     __shared__ uint32_t rnd[2048 + 32];
     __shared__ int n_surv;
-    const int segs = S.cb_segs;
-    if ((int)blockIdx.x >= segs) {  // the launch's extra blocks: registry_scan_block above
-        registry_scan_block(S, apar, (int)blockIdx.x - segs, (int)gridDim.x - segs);
+    const int segs = S.cb_segs, scan_blocks = (int)gridDim.x - segs;
+    if ((int)blockIdx.x < scan_blocks) {  // the launch's FIRST blocks (they start with it, not behind its 2 048 others): registry_scan_block above
+        registry_scan_block(S, apar, (int)blockIdx.x, scan_blocks);
         return;
     }
     // one block per segment of the table: its list, its survivors -- no counter shared between blocks
-    const int seg = par * segs + blockIdx.x, seg_next = (par ^ 1) * segs + blockIdx.x, cap = S.cb_slots / segs;
-    apply_deferred_generations(P, S, par, sid, (int)(blockIdx.x * 4 + (threadIdx.x >> 6)), segs * 4, (int)(threadIdx.x & 63));
+    const int sblk = (int)blockIdx.x - scan_blocks;
+    const int seg = par * segs + sblk, seg_next = (par ^ 1) * segs + sblk, cap = S.cb_slots / segs;
+    apply_deferred_generations(P, S, par, sid, sblk * 4 + (int)(threadIdx.x >> 6), segs * 4, (int)(threadIdx.x & 63));
     const int count = S.cb_count[seg];
     if (count == 0) return;  // (block-uniform)
     {

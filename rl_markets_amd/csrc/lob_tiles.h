@@ -95,7 +95,7 @@ __device__ inline bool tile_same_cell(const int4& x, const int4& y, int j) {
 // other); `first_word` may be older than the swap -- an index that turns ambiguous between the two is on amb_new, and the scan
 // behind the registry marks it in every registered slot.
 template <bool FIRST>
-__device__ inline int tile_register_impl(const DevState& S, const int4& id, int s, int a, int j, i32 tile, int par, u64 first_old, uint32_t first_word) {
+__device__ __forceinline__ int tile_register_impl(const DevState& S, const int4& id, int s, int a, int j, i32 tile, int par, u64 first_old, uint32_t first_word) {
     const u64 want = ((u64)(uint32_t)tile << 32) | (u64)(uint32_t)(s * (LOB_N_ACTIONS * 32) + a * 32 + j);
     const uint32_t mask = (uint32_t)(S.ow_slots - 1);
     uint32_t h = ((uint32_t)tile * 2654435761u) & mask;
@@ -128,7 +128,7 @@ __device__ inline int tile_register_impl(const DevState& S, const int4& id, int 
 __device__ inline int tile_register(const DevState& S, const int4& id, int s, int a, int j, i32 tile, int par) {
     return tile_register_impl<false>(S, id, s, a, j, tile, par, 0ull, 0u);
 }
-__device__ inline void tile_register_ask(const DevState& S, int s, int a, int j, i32 tile, u64& first_old, uint32_t& first_word) {
+__device__ __forceinline__ void tile_register_ask(const DevState& S, int s, int a, int j, i32 tile, u64& first_old, uint32_t& first_word) {
     const u64 want = ((u64)(uint32_t)tile << 32) | (u64)(uint32_t)(s * (LOB_N_ACTIONS * 32) + a * 32 + j);
     const uint32_t h = ((uint32_t)tile * 2654435761u) & (uint32_t)(S.ow_slots - 1);
     first_old = (u64)atomicCAS((unsigned long long*)&S.ow_tab[h], ~0ull, (unsigned long long)want);
