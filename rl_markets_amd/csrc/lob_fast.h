@@ -1644,7 +1644,7 @@ template <int ALGO, int VT, bool TR>
 // the slot (in the sums of the vector the coin picked) are the group-2 lane's; the trace step is Watkins's over Q_a.
 __global__ void __launch_bounds__(LOB_QP_BLOCK) learn_q_pair_kernel(const DevParams* __restrict__ Pp, const DevState* __restrict__ Sp, const uint32_t* __restrict__ rnd_g, int lpar, u64 ver, int sid, int acc_fuse) {
     // parameters and state through their device-resident copies (3 KB of by-value arguments before: 145 spilled scalar registers
-    // -> 10, 170 -> 166 vector registers = three waves per SIMD instead of two; 0.0638 -> 0.0608 ms at 65 536 books, round 6)
+    // -> 10, 170 -> 166 vector registers; 0.0638 -> 0.0608 ms at 65 536 books, round 6.  Two blocks per CU either way: 61 KB of LDS each)
     const DevParams& P = *Pp;
     const DevState& S = *Sp;
     constexpr bool DQ = ALGO == LOB_ALGO_DOUBLE_Q;
